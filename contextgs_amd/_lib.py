@@ -1,0 +1,111 @@
+"""ctypes binding of libcgs_hip.so (include/cgs.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call
+fails, a RuntimeError is raised.  torch is used only for device memory and the
+current stream; every entry point receives raw device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgs_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+c_void_p, c_int, c_int32, c_int64, c_size_t, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+
+
+class RasterCfg(C.Structure):
+    """struct cgs_raster_cfg — mirrors GaussianRasterizationSettings
+    (reference: gaussian_renderer/__init__.py:179-192)."""
+    _fields_ = [
+        ("image_height", c_int32),
+        ("image_width", c_int32),
+        ("tanfovx", c_float),
+        ("tanfovy", c_float),
+        ("scale_modifier", c_float),
+        ("prefiltered", c_int32),
+        ("debug", c_int32),
+        ("viewmatrix", c_void_p),
+        ("projmatrix", c_void_p),
+        ("campos", c_void_p),
+        ("bg", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); the authoritative list of exported symbols.
+# tests/test_abi.py checks it against include/cgs.h.
+SIGNATURES = {
+    "cgs_version": (c_int, []),
+    "cgs_last_error": (C.c_char_p, []),
+    "cgs_filter": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_raster_geom_bytes": (c_size_t, [c_int64]),
+    "cgs_raster_bin_bytes": (c_size_t, [c_int64, c_int64]),
+    "cgs_raster_img_bytes": (c_size_t, [c_int32, c_int32]),
+    "cgs_raster_bwd_scratch_bytes": (c_size_t, [c_int64]),
+    "cgs_raster_preprocess": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p, C.POINTER(c_int64), c_void_p]),
+    "cgs_raster_render": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
+                                  c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_raster_backward": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
+    "cgs_raster_stats": (c_int, [C.POINTER(RasterCfg), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_scan_scratch_bytes": (c_size_t, [c_int64]),
+    "cgs_scan_exclusive_u32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_sort_scratch_bytes": (c_size_t, [c_int64]),
+    "cgs_sort_pairs_u32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                   c_void_p, c_size_t, c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libcgs_hip.so (once).  Raises if it is absent: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found. Build it with `python -m contextgs_amd.build` "
+                "(or __graft_entry__.build()); contextgs_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError => ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().cgs_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libcgs_hip takes dense row-major buffers"
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("contextgs_amd operators run on the HIP device only (tensor on %s); "
+                               "there is no CPU path" % t.device)

@@ -1,0 +1,264 @@
+// extern "C" entry points of libcgs_hip.so (see include/cgs.h) for the
+// rasterizer, plus error plumbing and workspace carving.
+#include <stdarg.h>
+#include <string.h>
+#include "cgs_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void cgs_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *cgs_last_error(void) { return g_err; }
+extern "C" int cgs_version(void) { return CGS_VERSION; }
+
+int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
+                                 size_t scratch_bytes, uint32_t *grand_total, hipStream_t stream);
+int cgs_launch_iota(int64_t n, uint32_t *out, hipStream_t stream);
+int cgs_launch_gather_tiles(int64_t P, const uint32_t *order, const uint32_t *tiles, uint32_t *out,
+                            hipStream_t stream);
+int cgs_launch_stats(const cgs_raster_cfg *cfg, CgsImg &im, int64_t *stats_out, hipStream_t stream);
+
+// ---- workspace carving ---------------------------------------------------------
+size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P) {
+    CgsCarver c(ws, bytes);
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    g->rec = c.take<float4>(3 * n);
+    g->depth_key = c.take<uint32_t>(n);
+    g->tiles = c.take<uint32_t>(n);
+    g->rect = c.take<uint2>(n);
+    g->order = c.take<uint32_t>(n);
+    g->offsets = c.take<uint32_t>(n);
+    g->sort_a = c.take<uint32_t>(n);
+    g->sort_b = c.take<uint32_t>(n);
+    g->sort_c = c.take<uint32_t>(n);
+    g->sort_d = c.take<uint32_t>(n);
+    g->total = c.take<uint32_t>(2);
+    size_t sb = cgs_sort_scratch_bytes((int64_t)n);
+    size_t sc = cgs_scan_scratch_bytes((int64_t)n);
+    g->scratch_bytes = sb > sc ? sb : sc;
+    g->scratch = c.take<char>(g->scratch_bytes);
+    return c.ok ? c.used() : 0;
+}
+
+size_t cgs_bin_carve(CgsBin *b, void *ws, size_t bytes, int64_t P, int64_t R) {
+    (void)P;
+    CgsCarver c(ws, bytes);
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    b->tile_key_a = c.take<uint32_t>(n);
+    b->tile_key_b = c.take<uint32_t>(n);
+    b->gid_a = c.take<uint32_t>(n);
+    b->gid_b = c.take<uint32_t>(n);
+    b->tile_key_c = c.take<uint32_t>(n);
+    b->gid_sorted = c.take<uint32_t>(n);
+    b->scratch_bytes = cgs_sort_scratch_bytes((int64_t)n);
+    b->scratch = c.take<char>(b->scratch_bytes);
+    return c.ok ? c.used() : 0;
+}
+
+size_t cgs_img_carve(CgsImg *im, void *ws, size_t bytes, int32_t H, int32_t W) {
+    CgsCarver c(ws, bytes);
+    const size_t tiles = (size_t)((W + CGS_TILE - 1) / CGS_TILE) * ((H + CGS_TILE - 1) / CGS_TILE);
+    const size_t hw = (size_t)H * W;
+    im->ranges = c.take<uint2>(tiles);
+    im->final_T = c.take<float>(hw);
+    im->n_contrib = c.take<uint32_t>(hw);
+    im->tile_last = c.take<uint32_t>(tiles);
+    return c.ok ? c.used() : 0;
+}
+
+extern "C" size_t cgs_raster_geom_bytes(int64_t P) {
+    CgsGeom g;
+    CgsCarver probe(nullptr, 0);
+    (void)probe;
+    return cgs_geom_carve(&g, nullptr, 0, P);
+}
+extern "C" size_t cgs_raster_bin_bytes(int64_t P, int64_t R) {
+    CgsBin b;
+    return cgs_bin_carve(&b, nullptr, 0, P, R);
+}
+extern "C" size_t cgs_raster_img_bytes(int32_t H, int32_t W) {
+    CgsImg im;
+    return cgs_img_carve(&im, nullptr, 0, H, W);
+}
+extern "C" size_t cgs_raster_bwd_scratch_bytes(int64_t P) {
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return cgs_align_up(2 * n * sizeof(float), 256) + cgs_align_up(3 * n * sizeof(float), 256);
+}
+
+static int check_cfg(const cgs_raster_cfg *cfg) {
+    if (!cfg) { cgs_set_error("cfg is NULL"); return CGS_ERR_ARG; }
+    if (cfg->image_height <= 0 || cfg->image_width <= 0) {
+        cgs_set_error("bad image size %dx%d", cfg->image_width, cfg->image_height);
+        return CGS_ERR_ARG;
+    }
+    if (cfg->image_height > 65535 * CGS_TILE / 16 * 16 || cfg->image_width > 65535 * 16) {
+        cgs_set_error("image too large for 16-bit tile coordinates");
+        return CGS_ERR_ARG;
+    }
+    if (!cfg->viewmatrix || !cfg->projmatrix) { cgs_set_error("matrices are NULL"); return CGS_ERR_ARG; }
+    return CGS_OK;
+}
+
+// ---- visible_filter ----------------------------------------------------------------
+extern "C" int cgs_filter(const cgs_raster_cfg *cfg, int64_t N, const float *means3D, const float *scales,
+                          const float *rotations, int32_t *radii, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (N < 0) { cgs_set_error("N < 0"); return CGS_ERR_ARG; }
+    if (N > 0 && (!means3D || !scales || !rotations || !radii)) {
+        cgs_set_error("cgs_filter: NULL input");
+        return CGS_ERR_ARG;
+    }
+    CgsGeom g;
+    memset(&g, 0, sizeof(g));
+    return cgs_launch_preprocess(cfg, N, means3D, nullptr, nullptr, scales, rotations, g, radii, true,
+                                 (hipStream_t)stream);
+}
+
+// ---- forward stage 1 -----------------------------------------------------------------
+extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+                                     const float *colors, const float *opacities, const float *scales,
+                                     const float *rotations, void *geom_ws, size_t geom_bytes, int32_t *radii,
+                                     int64_t *num_rendered_host, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (P < 0 || P >= (1ll << 31)) { cgs_set_error("P out of range"); return CGS_ERR_ARG; }
+    if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
+    *num_rendered_host = 0;
+    if (P == 0) return CGS_OK;
+    if (!means3D || !colors || !opacities || !scales || !rotations || !radii || !geom_ws) {
+        cgs_set_error("cgs_raster_preprocess: NULL input");
+        return CGS_ERR_ARG;
+    }
+    CgsGeom g;
+    if (!cgs_geom_carve(&g, geom_ws, geom_bytes, P)) {
+        cgs_set_error("geometry workspace too small: %zu < %zu", geom_bytes, cgs_raster_geom_bytes(P));
+        return CGS_ERR_WORKSPACE;
+    }
+    if ((rc = cgs_launch_preprocess(cfg, P, means3D, colors, opacities, scales, rotations, g, radii, false,
+                                    stream)))
+        return rc;
+    // depth order (stable: ties keep ascending Gaussian id)
+    if ((rc = cgs_launch_iota(P, g.sort_c, stream))) return rc;
+    if ((rc = cgs_sort_pairs_u32(g.depth_key, g.sort_c, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
+                                 g.scratch, g.scratch_bytes, stream)))
+        return rc;
+    if ((rc = cgs_launch_gather_tiles(P, g.order, g.tiles, g.sort_a, stream))) return rc;
+    if ((rc = cgs_scan_exclusive_u32_total(g.sort_a, g.offsets, P, g.scratch, g.scratch_bytes, g.total, stream)))
+        return rc;
+    static thread_local uint32_t *pinned = nullptr;
+    if (!pinned) CGS_CHECK_HIP(hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
+    CGS_CHECK_HIP(hipMemcpyAsync(pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CGS_CHECK_HIP(hipStreamSynchronize(stream));
+    *num_rendered_host = (int64_t)pinned[0];
+    return CGS_OK;
+}
+
+// ---- forward stage 2 -----------------------------------------------------------------
+static int tile_bits(const cgs_raster_cfg *cfg) {
+    const uint32_t nt = (uint32_t)(cgs_tiles_x(cfg) * cgs_tiles_y(cfg));
+    int bits = 0;
+    while ((1u << bits) < nt) ++bits;
+    return bits;
+}
+
+extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws,
+                                 size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
+                                 size_t img_bytes, float *out_color, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!cfg->bg || !out_color || !img_ws) { cgs_set_error("cgs_raster_render: NULL input"); return CGS_ERR_ARG; }
+    CgsGeom g;
+    CgsBin b;
+    CgsImg im;
+    memset(&g, 0, sizeof(g));
+    memset(&b, 0, sizeof(b));
+    if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width)) {
+        cgs_set_error("image workspace too small");
+        return CGS_ERR_WORKSPACE;
+    }
+    if (P > 0 && (!geom_ws || !cgs_geom_carve(&g, geom_ws, geom_bytes, P))) {
+        cgs_set_error("geometry workspace missing or too small");
+        return CGS_ERR_WORKSPACE;
+    }
+    if (R > 0) {
+        if (!bin_ws || !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R)) {
+            cgs_set_error("binning workspace too small: %zu < %zu", bin_bytes, cgs_raster_bin_bytes(P, R));
+            return CGS_ERR_WORKSPACE;
+        }
+        if ((rc = cgs_launch_emit_pairs(cfg, P, g, b, stream))) return rc;
+        if ((rc = cgs_sort_pairs_u32(b.tile_key_a, b.gid_a, b.tile_key_c, b.gid_sorted, b.tile_key_b, b.gid_b, R,
+                                     0, tile_bits(cfg), b.scratch, b.scratch_bytes, stream)))
+            return rc;
+    }
+    if ((rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
+    return cgs_launch_blend_fwd(cfg, g, b, im, out_color, stream);
+}
+
+// ---- backward -----------------------------------------------------------------------------
+extern "C" int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P, int64_t R, const float *means3D,
+                                   const float *colors, const float *opacities, const float *scales,
+                                   const float *rotations, const int32_t *radii, void *geom_ws,
+                                   size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
+                                   size_t img_bytes, const float *dL_dout, float *dL_dmeans3D,
+                                   float *dL_dmeans2D, float *dL_dcolors, float *dL_dopacities,
+                                   float *dL_dscales, float *dL_drotations, void *scratch,
+                                   size_t scratch_bytes, void *stream_) {
+    (void)colors;
+    (void)opacities;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (P == 0) return CGS_OK;
+    if (!dL_dout || !dL_dmeans3D || !dL_dmeans2D || !dL_dcolors || !dL_dopacities || !dL_dscales ||
+        !dL_drotations || !scratch || !radii) {
+        cgs_set_error("cgs_raster_backward: NULL input");
+        return CGS_ERR_ARG;
+    }
+    if (scratch_bytes < cgs_raster_bwd_scratch_bytes(P)) {
+        cgs_set_error("backward scratch too small");
+        return CGS_ERR_WORKSPACE;
+    }
+    CgsGeom g;
+    CgsBin b;
+    CgsImg im;
+    memset(&b, 0, sizeof(b));
+    if (!geom_ws || !img_ws || !cgs_geom_carve(&g, geom_ws, geom_bytes, P) ||
+        !cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width)) {
+        cgs_set_error("workspace too small");
+        return CGS_ERR_WORKSPACE;
+    }
+    float *d_mean_px = (float *)scratch;
+    float *d_conic = (float *)((char *)scratch + cgs_align_up(2 * (size_t)P * sizeof(float), 256));
+    CGS_CHECK_HIP(hipMemsetAsync(scratch, 0, cgs_raster_bwd_scratch_bytes(P), stream));
+    if (R > 0) {
+        if (!bin_ws || !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R)) {
+            cgs_set_error("binning workspace missing or too small");
+            return CGS_ERR_WORKSPACE;
+        }
+        if ((rc = cgs_launch_blend_bwd(cfg, g, b, im, dL_dout, d_mean_px, d_conic, dL_dopacities, dL_dcolors,
+                                       stream)))
+            return rc;
+    }
+    return cgs_launch_preprocess_bwd(cfg, P, means3D, scales, rotations, radii, d_mean_px, d_conic, dL_dmeans3D,
+                                     dL_dmeans2D, dL_dscales, dL_drotations, stream);
+}
+
+extern "C" int cgs_raster_stats(const cgs_raster_cfg *cfg, void *img_ws, size_t img_bytes, int64_t *stats_out,
+                                void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    CgsImg im;
+    if (!img_ws || !stats_out || !cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width)) {
+        cgs_set_error("image workspace missing or too small");
+        return CGS_ERR_WORKSPACE;
+    }
+    return cgs_launch_stats(cfg, im, stats_out, (hipStream_t)stream);
+}

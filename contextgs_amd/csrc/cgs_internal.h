@@ -1,0 +1,116 @@
+// Internal helpers shared by the HIP translation units of libcgs_hip.so.
+// gfx950 only: wave = 64 lanes, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/cgs.h"
+
+#define CGS_TILE 16          // tile edge in pixels (reference: 16x16 tiles)
+#define CGS_WAVE 64
+
+void cgs_set_error(const char *fmt, ...);
+
+#define CGS_CHECK_HIP(expr)                                                   \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess) {                                              \
+            cgs_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,       \
+                          hipGetErrorString(e__));                            \
+            return CGS_ERR_HIP;                                               \
+        }                                                                     \
+    } while (0)
+
+// After a launch: always pick up launch-configuration errors; in debug mode
+// also synchronise so that the failing kernel is the one reported.
+#define CGS_CHECK_LAUNCH(stream, debug)                                       \
+    do {                                                                      \
+        CGS_CHECK_HIP(hipGetLastError());                                     \
+        if (debug) CGS_CHECK_HIP(hipStreamSynchronize(stream));               \
+    } while (0)
+
+static inline size_t cgs_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-owned workspace.
+struct CgsCarver {
+    char *base;
+    size_t off;
+    size_t cap;
+    bool ok;
+    CgsCarver(void *p, size_t n) : base((char *)p), off(0), cap(n), ok(true) {}
+    template <typename T> T *take(size_t count) {
+        off = cgs_align_up(off, 256);
+        size_t bytes = count * sizeof(T);
+        T *r = (T *)(base ? base + off : nullptr);
+        off += bytes;
+        if (base && off > cap) ok = false;
+        return r;
+    }
+    size_t used() const { return cgs_align_up(off, 256); }
+};
+
+// ---- geometry workspace layout (per-Gaussian state of one view) ----------
+// rec: 3 x float4 per Gaussian, AoS so that one gather touches one 48-byte
+// span:  r0 = (px, py, A, B)   A,B,C = conic pre-scaled for exp2:
+//        r1 = (C, opacity, red, green)   power2 = A dx^2 + C dy^2 + B dx dy
+//        r2 = (blue, rcut2, conic_a_raw?, unused) -- see raster_preprocess.hip
+struct CgsGeom {
+    float4 *rec;            // [3P]
+    uint32_t *depth_key;    // [P] float bits of view depth (positive => order-preserving)
+    uint32_t *tiles;        // [P] tiles touched (0 => culled)
+    uint2 *rect;            // [P] packed tile rect: .x = x0 | y0<<16, .y = x1 | y1<<16 (exclusive max)
+    uint32_t *order;        // [P] Gaussian ids in ascending (depth, id) order
+    uint32_t *offsets;      // [P] exclusive scan of tiles[order[i]]
+    uint32_t *sort_a;       // [P] ping-pong scratch (keys)
+    uint32_t *sort_b;       // [P]
+    uint32_t *sort_c;       // [P] (vals)
+    uint32_t *sort_d;       // [P]
+    uint32_t *total;        // [2] device: num_rendered
+    void *scratch;          // scan/sort scratch
+    size_t scratch_bytes;
+};
+
+struct CgsBin {
+    uint32_t *tile_key_a;   // [R]
+    uint32_t *tile_key_b;   // [R]
+    uint32_t *gid_a;        // [R]
+    uint32_t *gid_b;        // [R]
+    uint32_t *tile_key_c;   // [R] sorted keys
+    uint32_t *gid_sorted;   // [R] final per-tile lists (depth order inside each tile)
+    void *scratch;
+    size_t scratch_bytes;
+};
+
+struct CgsImg {
+    uint2 *ranges;          // [tiles] (start, end) into gid_sorted
+    float *final_T;         // [H*W]
+    uint32_t *n_contrib;    // [H*W] 1-based position (within the tile list) of the last contributor
+    uint32_t *tile_last;    // [tiles] max over the tile's pixels of n_contrib
+};
+
+size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P);
+size_t cgs_bin_carve(CgsBin *b, void *ws, size_t bytes, int64_t P, int64_t R);
+size_t cgs_img_carve(CgsImg *im, void *ws, size_t bytes, int32_t H, int32_t W);
+
+// internal launchers (raster_*.hip)
+int cgs_launch_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+                          const float *colors, const float *opacities, const float *scales,
+                          const float *rotations, CgsGeom &g, int32_t *radii, bool filter_only,
+                          hipStream_t stream);
+int cgs_launch_emit_pairs(const cgs_raster_cfg *cfg, int64_t P, CgsGeom &g, CgsBin &b,
+                          hipStream_t stream);
+int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &im,
+                      hipStream_t stream);
+int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,
+                         float *out_color, hipStream_t stream);
+int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,
+                         const float *dL_dout, float *dL_dmean2D_px, float *dL_dconic,
+                         float *dL_dopacity, float *dL_dcolors, hipStream_t stream);
+int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+                              const float *scales, const float *rotations,
+                              const int32_t *radii, const float *dL_dmean2D_px,
+                              const float *dL_dconic, float *dL_dmeans3D, float *dL_dmeans2D,
+                              float *dL_dscales, float *dL_drotations, hipStream_t stream);
+
+static inline int cgs_tiles_x(const cgs_raster_cfg *c) { return (c->image_width + CGS_TILE - 1) / CGS_TILE; }
+static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height + CGS_TILE - 1) / CGS_TILE; }

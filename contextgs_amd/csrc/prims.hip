@@ -1,0 +1,292 @@
+// Device-wide primitives for the binning stage: exclusive scan (R3 in
+// SURVEY §2.1) and a stable LSD radix sort of (u32 key, u32 value) pairs
+// (R5).  Written for wave64: ranks inside a wave come from 64-bit ballots,
+// cross-wave composition goes through LDS, nothing uses 32-lane idioms.
+#include "cgs_internal.h"
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+#define SORT_THREADS 256
+#define SORT_ITEMS 16
+#define SORT_TILE (SORT_THREADS * SORT_ITEMS)
+#define SORT_WAVES (SORT_THREADS / CGS_WAVE)
+#define RADIX_BITS 8
+#define RADIX 256
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (256 threads); returns the
+// exclusive prefix, *total gets the block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total,
+                                                         uint32_t *lds_wave /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) lds_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        uint32_t s = lds_wave[w];
+        if (w < wave) wbase += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return wbase + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in,
+                                                                   uint32_t *__restrict__ sums,
+                                                                   int64_t n) {
+    __shared__ uint32_t lds_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) acc += in[idx];
+    }
+    uint32_t tot;
+    block_exclusive_scan(acc, &tot, lds_wave);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// Scans one tile per block.  block_offsets == nullptr => single-tile call.
+__global__ void __launch_bounds__(SCAN_THREADS)
+    scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                      const uint32_t *__restrict__ block_offsets, int64_t n,
+                      uint32_t *__restrict__ grand_total) {
+    __shared__ uint32_t lds_wave[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + i;
+        v[i] = idx < n ? in[idx] : 0u;
+        acc += v[i];
+    }
+    uint32_t tot;
+    uint32_t excl = block_exclusive_scan(acc, &tot, lds_wave);
+    uint32_t run = excl + (block_offsets ? block_offsets[blockIdx.x] : 0u);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        int64_t idx = base + i;
+        if (idx < n) out[idx] = run;
+        run += v[i];
+    }
+    if (grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1)
+        *grand_total = run;
+}
+
+static int64_t scan_blocks(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+extern "C" size_t cgs_scan_scratch_bytes(int64_t n) {
+    size_t bytes = 0;
+    int64_t m = scan_blocks(n);
+    while (m > 1) {
+        bytes += cgs_align_up((size_t)m * sizeof(uint32_t), 256);
+        m = scan_blocks(m);
+    }
+    return bytes + 256;
+}
+
+// Recursive helper: exclusive scan of `in` into `out`, optional grand total.
+static int scan_rec(const uint32_t *in, uint32_t *out, int64_t n, char *scratch, size_t scratch_bytes,
+                    uint32_t *grand_total, hipStream_t stream) {
+    if (n <= 0) return CGS_OK;
+    int64_t nb = scan_blocks(n);
+    if (nb == 1) {
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, in, out,
+                           (const uint32_t *)nullptr, n, grand_total);
+        CGS_CHECK_HIP(hipGetLastError());
+        return CGS_OK;
+    }
+    size_t need = cgs_align_up((size_t)nb * sizeof(uint32_t), 256);
+    if (need > scratch_bytes) {
+        cgs_set_error("scan: scratch too small (%zu < %zu)", scratch_bytes, need);
+        return CGS_ERR_WORKSPACE;
+    }
+    uint32_t *sums = (uint32_t *)scratch;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, sums, n);
+    CGS_CHECK_HIP(hipGetLastError());
+    int rc = scan_rec(sums, sums, nb, scratch + need, scratch_bytes - need, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out,
+                       (const uint32_t *)sums, n, grand_total);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
+                                 size_t scratch_bytes, uint32_t *grand_total, hipStream_t stream) {
+    return scan_rec(in, out, n, (char *)scratch, scratch_bytes, grand_total, stream);
+}
+
+extern "C" int cgs_scan_exclusive_u32(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
+                                      size_t scratch_bytes, void *stream) {
+    if (n < 0) { cgs_set_error("scan: negative n"); return CGS_ERR_ARG; }
+    return scan_rec(in, out, n, (char *)scratch, scratch_bytes, nullptr, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------
+// Radix sort
+// ----------------------------------------------------------------------------
+// Tile layout shared by the histogram and scatter kernels: block b owns items
+// [b*SORT_TILE, (b+1)*SORT_TILE); inside it wave w owns a contiguous quarter
+// and walks it in rounds of 64 so that (wave, round, lane) is ascending input
+// order — that is what makes the per-digit ranks stable.
+
+__global__ void __launch_bounds__(SORT_THREADS)
+    radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist /*[RADIX][nblocks]*/,
+                      int64_t n, int shift, uint32_t digit_mask) {
+    __shared__ uint32_t h[RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & digit_mask], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+    radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                         uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                         const uint32_t *__restrict__ hist_scanned, int64_t n, int shift,
+                         uint32_t digit_mask) {
+    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];   // running per-wave digit counts -> bases
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (SORT_TILE / SORT_WAVES);
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    volatile uint32_t *my = wcnt[wave];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t idx = wbase + (int64_t)r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[idx] : 0u;
+        const uint32_t d = (key[r] >> shift) & digit_mask;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t old = 0;
+        if (valid) {
+            const int leader = __builtin_ctzll(peers);
+            if (lane == leader) {
+                old = my[d];
+                my[d] = old + (uint32_t)__builtin_popcountll(peers);
+            }
+            old = __shfl(old, leader, 64);
+            rank[r] = old + (uint32_t)__builtin_popcountll(peers & lt_mask);
+        } else {
+            rank[r] = 0;
+        }
+    }
+    __syncthreads();
+    {
+        // thread t owns digit t: turn per-wave counts into absolute bases.
+        const int d = threadIdx.x;
+        uint32_t run = hist_scanned[(int64_t)d * gridDim.x + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            uint32_t c = wcnt[w][d];
+            wcnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t idx = wbase + (int64_t)r * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[r] >> shift) & digit_mask;
+            const uint32_t pos = wcnt[wave][d] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
+}
+
+static int64_t sort_blocks(int64_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+
+extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
+    int64_t nb = sort_blocks(n > 0 ? n : 1);
+    size_t hist = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
+    return hist + cgs_scan_scratch_bytes((int64_t)RADIX * nb) + 256;
+}
+
+extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n,
+                                  int bit_lo, int bit_hi, void *scratch, size_t scratch_bytes,
+                                  void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || bit_lo < 0 || bit_hi > 32 || bit_hi < bit_lo) {
+        cgs_set_error("sort: bad arguments");
+        return CGS_ERR_ARG;
+    }
+    if (n >= (1ll << 32)) { cgs_set_error("sort: n must fit in uint32"); return CGS_ERR_ARG; }
+    const int bits = bit_hi - bit_lo;
+    const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+    if (n == 0) return CGS_OK;
+    if (passes == 0) {
+        if (keys_out != keys_in)
+            CGS_CHECK_HIP(hipMemcpyAsync(keys_out, keys_in, n * 4, hipMemcpyDeviceToDevice, stream));
+        if (vals_out != vals_in)
+            CGS_CHECK_HIP(hipMemcpyAsync(vals_out, vals_in, n * 4, hipMemcpyDeviceToDevice, stream));
+        return CGS_OK;
+    }
+    const int64_t nb = sort_blocks(n);
+    const size_t hist_bytes = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
+    if (scratch_bytes < cgs_sort_scratch_bytes(n)) {
+        cgs_set_error("sort: scratch too small (%zu < %zu)", scratch_bytes, cgs_sort_scratch_bytes(n));
+        return CGS_ERR_WORKSPACE;
+    }
+    uint32_t *hist = (uint32_t *)scratch;
+    char *scan_scratch = (char *)scratch + hist_bytes;
+    const size_t scan_scratch_bytes = scratch_bytes - hist_bytes;
+
+    // Choose the ping-pong start so that the last pass lands in *_out.
+    const uint32_t *src_k = keys_in, *src_v = vals_in;
+    uint32_t *dst_k = (passes & 1) ? keys_out : keys_tmp;
+    uint32_t *dst_v = (passes & 1) ? vals_out : vals_tmp;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = bit_lo + p * RADIX_BITS;
+        const int nb_bits = (bit_hi - shift) < RADIX_BITS ? (bit_hi - shift) : RADIX_BITS;
+        const uint32_t mask = (1u << nb_bits) - 1u;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k, hist,
+                           n, shift, mask);
+        CGS_CHECK_HIP(hipGetLastError());
+        int rc = scan_rec(hist, hist, (int64_t)RADIX * nb, scan_scratch, scan_scratch_bytes, nullptr, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k,
+                           src_v, dst_k, dst_v, (const uint32_t *)hist, n, shift, mask);
+        CGS_CHECK_HIP(hipGetLastError());
+        src_k = dst_k;
+        src_v = dst_v;
+        dst_k = (dst_k == keys_out) ? keys_tmp : keys_out;
+        dst_v = (dst_v == vals_out) ? vals_tmp : vals_out;
+    }
+    return CGS_OK;
+}

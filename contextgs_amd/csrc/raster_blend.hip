@@ -1,0 +1,342 @@
+// Tile alpha-blend forward (R7) and backward (R8, blend half) for gfx950.
+//
+// Mapping: one 256-thread workgroup per 16x16 tile; each of its 4 waves owns
+// one 8x8 pixel quadrant (lane -> (lane&7, lane>>3)), so a whole wave
+// terminates as soon as its 64 pixels are saturated and so that a Gaussian
+// whose alpha>=1/255 footprint misses the quadrant is never evaluated by that
+// wave.  Per batch of 256 list entries every thread gathers one 48-byte
+// record into LDS and classifies it against the 4 quadrants; a 64-bit ballot
+// per (source wave, quadrant) turns that into scalar bit masks, and each wave
+// then walks only its own set bits with s_ff1 — no per-entry divergent test.
+// All lanes read the same LDS record (broadcast ds_read_b128 x3).
+//
+// Semantics: SURVEY.md Appendix A (the CUDA source is not in the mount).
+#include "cgs_internal.h"
+
+#define BLEND_THREADS 256
+#define ALPHA_MIN (1.0f / 255.0f)
+#define T_EPS 0.0001f
+#define INV_LOG2E 0.6931471805599453f
+
+struct BlendEval {
+    float dx, dy, g, alpha;
+    bool hit;
+};
+
+// One (pixel, Gaussian) evaluation; shared verbatim by forward and backward so
+// both passes take bit-identical skip decisions.
+__device__ __forceinline__ BlendEval blend_eval(const float4 r0, const float4 r1, float pxf, float pyf) {
+    BlendEval e;
+    e.dx = r0.x - pxf;
+    e.dy = r0.y - pyf;
+    const float p2 = fmaf(r0.z * e.dx, e.dx, fmaf(r1.x * e.dy, e.dy, (r0.w * e.dx) * e.dy));
+    e.g = __builtin_amdgcn_exp2f(p2);
+    e.alpha = fminf(0.99f, r1.y * e.g);
+    e.hit = (p2 <= 0.f) && (e.alpha >= ALPHA_MIN);
+    return e;
+}
+
+__device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float hx, float hy, int tile_px0,
+                                                  int tile_py0) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = (float)(tile_px0 + (q & 1) * 8), y0 = (float)(tile_py0 + (q >> 1) * 8);
+        const bool ov = (gx - hx <= x0 + 7.f) && (gx + hx >= x0) && (gy - hy <= y0 + 7.f) && (gy + hy >= y0);
+        m |= (ov ? 1u : 0u) << q;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(BLEND_THREADS)
+    blend_fwd_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                     const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                     const float *__restrict__ bg, float *__restrict__ out_color,
+                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                     uint32_t *__restrict__ tile_last) {
+    __shared__ float4 srec[BLEND_THREADS * 3];
+    __shared__ uint64_t qmask[4][4];   // [quadrant][source wave]
+    __shared__ uint32_t wave_last[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tx * CGS_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * CGS_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t start = range.x; start < range.y; start += BLEND_THREADS) {
+        if (__syncthreads_count(done) == BLEND_THREADS) break;
+        const uint32_t i = start + tid;
+        uint32_t m4 = 0;
+        if (i < range.y) {
+            const uint32_t g = gid_sorted[i];
+            const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+            srec[tid * 3] = r0;
+            srec[tid * 3 + 1] = r1;
+            srec[tid * 3 + 2] = r2;
+            m4 = quadrant_mask(r0.x, r0.y, r2.y, r2.z, tx * CGS_TILE, ty * CGS_TILE);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t b = __ballot((m4 >> q) & 1u);
+            if (lane == 0) qmask[q][wave] = b;
+        }
+        __syncthreads();
+        const uint32_t base_pos = start - range.x;
+        if (!__all(done)) {
+            for (int s = 0; s < 4; ++s) {
+                uint64_t m = uniform_u64(qmask[wave][s]);
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int e = s * 64 + j;
+                    const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
+                    const float blue = srec[e * 3 + 2].x;
+                    const BlendEval ev = blend_eval(r0, r1, pxf, pyf);
+                    if (!done && ev.hit) {
+                        const float test_T = T * (1.f - ev.alpha);
+                        if (test_T < T_EPS) {
+                            done = true;
+                        } else {
+                            const float w = ev.alpha * T;
+                            cr = fmaf(r1.z, w, cr);
+                            cg = fmaf(r1.w, w, cg);
+                            cb = fmaf(blue, w, cb);
+                            T = test_T;
+                            last = base_pos + (uint32_t)e + 1u;
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t pix = (size_t)py * W + px;
+        const size_t hw = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, bg[0], cr);
+        out_color[hw + pix] = fmaf(T, bg[1], cg);
+        out_color[2 * hw + pix] = fmaf(T, bg[2], cb);
+    }
+    // deepest contributor of the tile: where the backward walk starts, and R_eff.
+    uint32_t wl = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+    if (lane == 0) wave_last[wave] = wl;
+    __syncthreads();
+    if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+}
+
+int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
+                         hipStream_t stream) {
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
+                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, out_color, im.final_T,
+                       im.n_contrib, im.tile_last);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Backward
+// ---------------------------------------------------------------------------
+// Full-wave sum on the DPP network (no LDS crossbar): after the 6 steps lane 63
+// holds the total of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+#define NGRAD 9   // Mx, My, Sa, Sb, Sc, dop, dr, dg, db
+
+__global__ void __launch_bounds__(BLEND_THREADS)
+    blend_bwd_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                     const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                     const float *__restrict__ bg, const float *__restrict__ final_T,
+                     const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ tile_last,
+                     const float *__restrict__ dL_dout, float *__restrict__ dL_dmean2D_px,
+                     float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
+                     float *__restrict__ dL_dcolors) {
+    __shared__ float4 srec[BLEND_THREADS * 3];
+    __shared__ uint32_t sgid[BLEND_THREADS];
+    __shared__ float sacc[BLEND_THREADS][NGRAD];
+    __shared__ uint64_t qmask[4][4];
+
+    const int tile = blockIdx.x;
+    const uint32_t tlast = tile_last[tile];
+    if (tlast == 0) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tx * CGS_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * CGS_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t my_last = inside ? n_contrib[pix] : 0u;
+    float T = T_final;
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (inside) { gr = dL_dout[pix]; gg = dL_dout[hw + pix]; gb = dL_dout[2 * hw + pix]; }
+    const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
+    float ar = 0.f, ag = 0.f, ab = 0.f;         // accum_rec
+    float lr = 0.f, lg = 0.f, lb = 0.f, last_alpha = 0.f;
+
+    const int nbatch = (int)((tlast + BLEND_THREADS - 1) / BLEND_THREADS);
+    for (int bi = nbatch - 1; bi >= 0; --bi) {
+        const uint32_t base_pos = (uint32_t)bi * BLEND_THREADS;     // 0-based position of entry 0
+        const uint32_t pos = base_pos + tid;
+        uint32_t m4 = 0;
+        __syncthreads();   // previous batch fully flushed before LDS is reused
+        if (pos < tlast) {
+            const uint32_t g = gid_sorted[range.x + pos];
+            const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+            srec[tid * 3] = r0;
+            srec[tid * 3 + 1] = r1;
+            srec[tid * 3 + 2] = r2;
+            sgid[tid] = g;
+            m4 = quadrant_mask(r0.x, r0.y, r2.y, r2.z, tx * CGS_TILE, ty * CGS_TILE);
+        }
+#pragma unroll
+        for (int k = 0; k < NGRAD; ++k) sacc[tid][k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t b = __ballot((m4 >> q) & 1u);
+            if (lane == 0) qmask[q][wave] = b;
+        }
+        __syncthreads();
+
+        for (int s = 3; s >= 0; --s) {
+            uint64_t m = uniform_u64(qmask[wave][s]);
+            while (m) {
+                const int j = 63 - __builtin_clzll(m);
+                m &= ~(1ull << j);
+                const int e = s * 64 + j;
+                const uint32_t position = base_pos + (uint32_t)e + 1u;   // 1-based
+                const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
+                const float blue = srec[e * 3 + 2].x;
+                const BlendEval ev = blend_eval(r0, r1, pxf, pyf);
+                const bool act = (position <= my_last) && ev.hit;
+                if (__ballot(act) == 0ull) continue;
+                float v[NGRAD];
+#pragma unroll
+                for (int k = 0; k < NGRAD; ++k) v[k] = 0.f;
+                if (act) {
+                    const float om = 1.f - ev.alpha;
+                    T = T / om;
+                    const float w = ev.alpha * T;
+                    ar = fmaf(last_alpha, lr, (1.f - last_alpha) * ar);
+                    ag = fmaf(last_alpha, lg, (1.f - last_alpha) * ag);
+                    ab = fmaf(last_alpha, lb, (1.f - last_alpha) * ab);
+                    lr = r1.z; lg = r1.w; lb = blue;
+                    float dL_dalpha = (lr - ar) * gr + (lg - ag) * gg + (lb - ab) * gb;
+                    dL_dalpha *= T;
+                    last_alpha = ev.alpha;
+                    dL_dalpha += (-T_final / om) * bg_dot;
+                    const float dL_dG = r1.y * dL_dalpha;
+                    const float gG = dL_dG * ev.g;
+                    v[0] = gG * fmaf(2.f * r0.z, ev.dx, r0.w * ev.dy);   // d power2 / d gx
+                    v[1] = gG * fmaf(2.f * r1.x, ev.dy, r0.w * ev.dx);   // d power2 / d gy
+                    v[2] = gG * ev.dx * ev.dx;
+                    v[3] = gG * ev.dx * ev.dy;
+                    v[4] = gG * ev.dy * ev.dy;
+                    v[5] = ev.g * dL_dalpha;
+                    v[6] = w * gr;
+                    v[7] = w * gg;
+                    v[8] = w * gb;
+                }
+#pragma unroll
+                for (int k = 0; k < NGRAD; ++k) v[k] = wave_sum_to_lane63(v[k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < NGRAD; ++k) atomicAdd(&sacc[e][k], v[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (pos < tlast) {
+            const uint32_t g = sgid[tid];
+            const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
+                        a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],
+                        a8 = sacc[tid][8];
+            if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f || a6 != 0.f ||
+                a7 != 0.f || a8 != 0.f) {
+                // power = power2 / log2(e); conic = (-2A, -B, -2C) / log2(e)
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g], a0 * INV_LOG2E);
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g + 1], a1 * INV_LOG2E);
+                atomicAdd(&dL_dconic[3 * (size_t)g], -0.5f * a2);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 1], -a3);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 2], -0.5f * a4);
+                atomicAdd(&dL_dopacity[g], a5);
+                atomicAdd(&dL_dcolors[3 * (size_t)g], a6);
+                atomicAdd(&dL_dcolors[3 * (size_t)g + 1], a7);
+                atomicAdd(&dL_dcolors[3 * (size_t)g + 2], a8);
+            }
+        }
+    }
+}
+
+int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
+                         float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                         hipStream_t stream) {
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
+                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg,
+                       (const float *)im.final_T, (const uint32_t *)im.n_contrib,
+                       (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity,
+                       dL_dcolors);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
+// R_eff / non-empty tile statistics for the roofline accounting.
+__global__ void __launch_bounds__(256) raster_stats_kernel(int ntiles, const uint32_t *__restrict__ tile_last,
+                                                           unsigned long long *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = 0, nz = 0;
+    if (i < ntiles) { v = tile_last[i]; nz = v ? 1ull : 0ull; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        v += __shfl_xor(v, d, 64);
+        nz += __shfl_xor(nz, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], nz); }
+}
+
+int cgs_launch_stats(const cgs_raster_cfg *cfg, CgsImg &im, int64_t *stats_out, hipStream_t stream) {
+    const int nt = cgs_tiles_x(cfg) * cgs_tiles_y(cfg);
+    CGS_CHECK_HIP(hipMemsetAsync(stats_out, 0, 2 * sizeof(int64_t), stream));
+    hipLaunchKernelGGL(raster_stats_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, nt,
+                       (const uint32_t *)im.tile_last, (unsigned long long *)stats_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

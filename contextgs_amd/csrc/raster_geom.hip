@@ -1,0 +1,206 @@
+// Per-Gaussian stages of the tile rasterizer (R1/R2/R4/R6 of SURVEY §2.1):
+// preprocess (project, cov3D -> conic, radius, tile rect), pair emission in
+// depth order, tile ranges.  One lane per Gaussian, all arrays streamed once,
+// coalesced; the camera matrices are wave-uniform and live in SGPRs.
+//
+// The reference's CUDA rasterizer is not in the mount; semantics follow the
+// public 3DGS algorithm as recorded in SURVEY.md Appendix A and the call-site
+// contract gaussian_renderer/__init__.py:179-205,250-285.
+#include "cgs_internal.h"
+#include "raster_math.h"
+
+#define PRE_THREADS 256
+
+template <bool FILTER_ONLY>
+__global__ void __launch_bounds__(PRE_THREADS)
+    preprocess_kernel(int64_t P, int W, int H, float tanfovx, float tanfovy, float scale_modifier,
+                      const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
+                      const float *__restrict__ means3D, const float *__restrict__ colors,
+                      const float *__restrict__ opacities, const float *__restrict__ scales,
+                      const float *__restrict__ rotations, float4 *__restrict__ rec,
+                      uint32_t *__restrict__ depth_key, uint32_t *__restrict__ tiles,
+                      uint2 *__restrict__ rect, int32_t *__restrict__ radii) {
+    const int64_t i = (int64_t)blockIdx.x * PRE_THREADS + threadIdx.x;
+    if (i >= P) return;
+
+    float V[16], Pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = viewmatrix[k]; Pm[k] = projmatrix[k]; }
+
+    const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    const float3 s = make_float3(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]);
+    const float4 q = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
+                                 rotations[4 * i + 3]);
+
+    CgsProj pr;
+    const bool ok = cgs_project<float>(p, s, q, V, Pm, W, H, tanfovx, tanfovy, scale_modifier, pr);
+
+    int32_t radius = 0;
+    uint32_t ntiles = 0;
+    uint2 packed = make_uint2(0u, 0u);
+    uint32_t dkey = 0xFFFFFFFFu;
+    if (ok) {
+        const int gx = (W + CGS_TILE - 1) / CGS_TILE, gy = (H + CGS_TILE - 1) / CGS_TILE;
+        // reference tile rect: centre +- 3 sigma radius
+        const float r = pr.radius;
+        int x0 = min(gx, max(0, (int)((pr.px - r) / (float)CGS_TILE)));
+        int y0 = min(gy, max(0, (int)((pr.py - r) / (float)CGS_TILE)));
+        int x1 = min(gx, max(0, (int)((pr.px + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
+        int y1 = min(gy, max(0, (int)((pr.py + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
+        if ((x1 - x0) * (y1 - y0) > 0) {
+            radius = (int32_t)r;
+            if (!FILTER_ONLY) {
+                const float op = opacities[i];
+                // Output-invariant tightening: alpha >= 1/255 needs
+                // 0.5 d^T conic d <= tau = ln(255 op); that ellipse's bounding box has
+                // half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).  Pixels outside
+                // it are skipped by the blend loop anyway, so tiles (and 8x8 quadrants)
+                // outside it never need to see this Gaussian.
+                float hx = -1.f, hy = -1.f;
+                const float t255 = 255.f * op;
+                if (t255 >= 1.f) {
+                    const float tau2 = 2.f * logf(t255);
+                    hx = sqrtf(tau2 * pr.cov_a) * 1.002f + 0.02f;
+                    hy = sqrtf(tau2 * pr.cov_c) * 1.002f + 0.02f;
+                    // pixels are at integer coordinates; first/last pixel inside the box
+                    const float fx0 = ceilf(pr.px - hx), fx1 = floorf(pr.px + hx);
+                    const float fy0 = ceilf(pr.py - hy), fy1 = floorf(pr.py + hy);
+                    if (fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) &&
+                        fy0 <= (float)(H - 1)) {
+                        const int tx0 = max(0, (int)fx0) / CGS_TILE;
+                        const int ty0 = max(0, (int)fy0) / CGS_TILE;
+                        const int tx1 = min(W - 1, (int)fx1) / CGS_TILE + 1;
+                        const int ty1 = min(H - 1, (int)fy1) / CGS_TILE + 1;
+                        x0 = max(x0, tx0); y0 = max(y0, ty0);
+                        x1 = min(x1, tx1); y1 = min(y1, ty1);
+                    } else {
+                        x1 = x0; y1 = y0;
+                    }
+                } else {
+                    x1 = x0; y1 = y0;
+                }
+                if (x1 > x0 && y1 > y0) {
+                    ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                    packed = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+                    dkey = __float_as_uint(pr.depth);
+                }
+                const float k = 1.4426950408889634f;  // log2(e): blend uses exp2
+                rec[3 * i + 0] = make_float4(pr.px, pr.py, -0.5f * k * pr.con_a, -k * pr.con_b);
+                rec[3 * i + 1] = make_float4(-0.5f * k * pr.con_c, op, colors[3 * i], colors[3 * i + 1]);
+                rec[3 * i + 2] = make_float4(colors[3 * i + 2], hx, hy, 0.f);
+            }
+        }
+    }
+    radii[i] = radius;
+    if (!FILTER_ONLY) {
+        tiles[i] = ntiles;
+        rect[i] = packed;
+        depth_key[i] = dkey;
+    }
+}
+
+int cgs_launch_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D, const float *colors,
+                          const float *opacities, const float *scales, const float *rotations, CgsGeom &g,
+                          int32_t *radii, bool filter_only, hipStream_t stream) {
+    if (P == 0) return CGS_OK;
+    const unsigned nb = (unsigned)((P + PRE_THREADS - 1) / PRE_THREADS);
+    if (filter_only) {
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3(nb), dim3(PRE_THREADS), 0, stream, P,
+                           cfg->image_width, cfg->image_height, cfg->tanfovx, cfg->tanfovy,
+                           cfg->scale_modifier, cfg->viewmatrix, cfg->projmatrix, means3D,
+                           (const float *)nullptr, (const float *)nullptr, scales, rotations,
+                           (float4 *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint2 *)nullptr, radii);
+    } else {
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3(nb), dim3(PRE_THREADS), 0, stream, P,
+                           cfg->image_width, cfg->image_height, cfg->tanfovx, cfg->tanfovy,
+                           cfg->scale_modifier, cfg->viewmatrix, cfg->projmatrix, means3D, colors, opacities,
+                           scales, rotations, g.rec, g.depth_key, g.tiles, g.rect, radii);
+    }
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
+// ---- offsets: tiles[] gathered into depth order (input of the scan) --------
+__global__ void __launch_bounds__(256) gather_tiles_kernel(int64_t P, const uint32_t *__restrict__ order,
+                                                           const uint32_t *__restrict__ tiles,
+                                                           uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < P) out[i] = tiles[order[i]];
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(int64_t n, uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+int cgs_launch_iota(int64_t n, uint32_t *out, hipStream_t stream) {
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+int cgs_launch_gather_tiles(int64_t P, const uint32_t *order, const uint32_t *tiles, uint32_t *out,
+                            hipStream_t stream) {
+    if (P == 0) return CGS_OK;
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P, order,
+                       tiles, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ---- pair emission (R4): walk Gaussians in depth order, write (tile, id) ---
+__global__ void __launch_bounds__(256)
+    emit_pairs_kernel(int64_t P, int tiles_x, const uint32_t *__restrict__ order,
+                      const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ tiles,
+                      const uint2 *__restrict__ rect, uint32_t *__restrict__ tile_key,
+                      uint32_t *__restrict__ gid) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t g = order[i];
+    if (tiles[g] == 0) return;
+    const uint2 rc = rect[g];
+    const int x0 = rc.x & 0xFFFF, y0 = rc.x >> 16, x1 = rc.y & 0xFFFF, y1 = rc.y >> 16;
+    uint32_t off = offsets[i];
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            tile_key[off] = (uint32_t)(y * tiles_x + x);
+            gid[off] = g;
+            ++off;
+        }
+}
+
+int cgs_launch_emit_pairs(const cgs_raster_cfg *cfg, int64_t P, CgsGeom &g, CgsBin &b, hipStream_t stream) {
+    if (P == 0) return CGS_OK;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P,
+                       cgs_tiles_x(cfg), g.order, g.offsets, g.tiles, g.rect, b.tile_key_a, b.gid_a);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
+// ---- tile ranges (R6) -------------------------------------------------------
+__global__ void __launch_bounds__(256) ranges_kernel(int64_t R, const uint32_t *__restrict__ tile_key,
+                                                     uint2 *__restrict__ ranges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t t = tile_key[i];
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t prev = tile_key[i - 1];
+        if (prev != t) {
+            ranges[prev].y = (uint32_t)i;
+            ranges[t].x = (uint32_t)i;
+        }
+    }
+    if (i == R - 1) ranges[t].y = (uint32_t)R;
+}
+
+int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &im, hipStream_t stream) {
+    const size_t nt = (size_t)cgs_tiles_x(cfg) * cgs_tiles_y(cfg);
+    CGS_CHECK_HIP(hipMemsetAsync(im.ranges, 0, nt * sizeof(uint2), stream));
+    if (R == 0) return CGS_OK;
+    hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R,
+                       (const uint32_t *)b.tile_key_c, im.ranges);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}

@@ -1,0 +1,180 @@
+"""Drop-in for the reference's `diff_gaussian_rasterization` package.
+
+Same Python surface as the Scaffold-GS fork the reference imports
+(gaussian_renderer/__init__.py:20): `GaussianRasterizationSettings`,
+`GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp,
+opacities, scales, rotations, cov3D_precomp) -> (color[3,H,W], radii int32[P])`
+and `.visible_filter(means3D, scales, rotations, cov3D_precomp) -> radii`.
+All arithmetic runs in libcgs_hip.so (hand-written gfx950 kernels) through the
+C-ABI of include/cgs.h; there is no CPU implementation here.
+
+Only the argument combination the reference uses is implemented
+(shs=None, colors_precomp given, scales+rotations given, cov3D_precomp=None;
+gaussian_renderer/__init__.py:197-205, 280-285); the others raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Cfg:
+    """Owns the ctypes struct plus the device tensors it points at."""
+
+    def __init__(self, rs: GaussianRasterizationSettings):
+        self.view = _f32c(rs.viewmatrix)
+        self.proj = _f32c(rs.projmatrix)
+        self.bg = _f32c(rs.bg)
+        self.campos = _f32c(rs.campos) if rs.campos is not None else None
+        _lib.require_device(self.view, self.proj, self.bg)
+        self.c = _lib.RasterCfg(
+            image_height=int(rs.image_height), image_width=int(rs.image_width),
+            tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+            scale_modifier=float(rs.scale_modifier), prefiltered=int(bool(rs.prefiltered)),
+            debug=int(bool(rs.debug)),
+            viewmatrix=_lib.ptr(self.view), projmatrix=_lib.ptr(self.proj),
+            campos=_lib.ptr(self.campos), bg=_lib.ptr(self.bg))
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, raster_settings):
+        L = _lib.lib()
+        _lib.require_device(means3D, colors, opacities, scales, rotations)
+        means3D_c, colors_c = _f32c(means3D), _f32c(colors)
+        opac_c, scales_c, rots_c = _f32c(opacities), _f32c(scales), _f32c(rotations)
+        P = means3D_c.shape[0]
+        dev = means3D_c.device
+        cfg = _Cfg(raster_settings)
+        H, W = cfg.c.image_height, cfg.c.image_width
+        stream = _lib.current_stream()
+
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        geom = _workspace(L.cgs_raster_geom_bytes(P), dev)
+        img = _workspace(L.cgs_raster_img_bytes(H, W), dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        R = C.c_int64(0)
+        _lib.check(L.cgs_raster_preprocess(cfg.ref, P, _lib.ptr(means3D_c), _lib.ptr(colors_c), _lib.ptr(opac_c),
+                                           _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
+                                           _lib.ptr(radii), C.byref(R), stream), "cgs_raster_preprocess")
+        num_rendered = int(R.value)
+        binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
+        _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
+                                       binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
+                   "cgs_raster_render")
+        ctx.cfg = cfg
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii):
+        L = _lib.lib()
+        means3D, colors, opac, scales, rots, radii, geom, binws, img = ctx.saved_tensors
+        cfg = ctx.cfg
+        P = means3D.shape[0]
+        dev = means3D.device
+        g = _f32c(grad_color)
+        d_means3D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+        d_means2D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+        d_colors = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+        d_opac = torch.zeros_like(opac)
+        d_scales = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+        d_rots = torch.zeros(P, 4, dtype=torch.float32, device=dev)
+        scratch = _workspace(L.cgs_raster_bwd_scratch_bytes(P), dev)
+        _lib.check(L.cgs_raster_backward(
+            cfg.ref, P, ctx.num_rendered, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(scales),
+            _lib.ptr(rots), _lib.ptr(radii), _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
+            _lib.ptr(img), img.numel(), _lib.ptr(g), _lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_colors),
+            _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rots), _lib.ptr(scratch), scratch.numel(),
+            _lib.current_stream()), "cgs_raster_backward")
+        return d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rots, None
+
+
+def rasterize_gaussians(means3D, means2D, colors_precomp, opacities, scales, rotations, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, colors_precomp, opacities, scales, rotations, raster_settings)
+
+
+def raster_stats(raster_settings: GaussianRasterizationSettings, img_ws: torch.Tensor) -> torch.Tensor:
+    """[R_eff, non-empty tiles] of the last render that used `img_ws` (int64[2], device)."""
+    L = _lib.lib()
+    cfg = _Cfg(raster_settings)
+    out = torch.zeros(2, dtype=torch.int64, device=img_ws.device)
+    _lib.check(L.cgs_raster_stats(cfg.ref, _lib.ptr(img_ws), img_ws.numel(), _lib.ptr(out), _lib.current_stream()),
+               "cgs_raster_stats")
+    return out
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Near-plane frustum test (the only cull the rasterizer applies)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            ones = torch.ones_like(positions[:, :1])
+            z = (torch.cat([positions, ones], dim=1) @ rs.viewmatrix)[:, 2]
+            return z > 0.2
+
+    def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError("visible_filter: only the scales+rotations form is on the hot path "
+                                      "(gaussian_renderer/__init__.py:280-285)")
+        L = _lib.lib()
+        _lib.require_device(means3D, scales, rotations)
+        with torch.no_grad():
+            m, s, r = _f32c(means3D), _f32c(scales), _f32c(rotations)
+            N = m.shape[0]
+            cfg = _Cfg(self.raster_settings)
+            radii = torch.zeros(N, dtype=torch.int32, device=m.device)
+            _lib.check(L.cgs_filter(cfg.ref, N, _lib.ptr(m), _lib.ptr(s), _lib.ptr(r), _lib.ptr(radii),
+                                    _lib.current_stream()), "cgs_filter")
+        return radii
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if shs is not None or colors_precomp is None:
+            raise NotImplementedError("ContextGS renders with precomputed colours (shs=None, "
+                                      "gaussian_renderer/__init__.py:200-201)")
+        if cov3D_precomp is not None or scales is None or rotations is None:
+            raise NotImplementedError("ContextGS passes scales+rotations (cov3D_precomp=None, "
+                                      "gaussian_renderer/__init__.py:203-205)")
+        return rasterize_gaussians(means3D, means2D, colors_precomp, opacities, scales, rotations,
+                                   self.raster_settings)

@@ -1,0 +1,157 @@
+/*
+ * cgs.h — C-ABI of libcgs_hip.so, the MI355X (gfx950) hot-path library of
+ * contextgs_amd.
+ *
+ * Every entry point takes raw DEVICE pointers (unless the name says host),
+ * sizes, and the hipStream_t (as void*) the work must be enqueued on.  The
+ * caller owns every buffer; the library never allocates or frees device
+ * memory and never synchronises the device, except for the single 4-byte
+ * read-back of `num_rendered` in cgs_raster_preprocess (the reference
+ * rasterizer has the same one).  Every function returns 0 on success and a
+ * non-zero code otherwise; cgs_last_error() gives the thread-local message.
+ *
+ * What each group replaces in the reference (wyf0912/ContextGS, paths
+ * relative to the reference checkout):
+ *
+ *   cgs_filter                 GaussianRasterizer.visible_filter
+ *                              (call site gaussian_renderer/__init__.py:280-285;
+ *                              the CUDA extension itself is NOT in the mount)
+ *   cgs_raster_*               GaussianRasterizer.__call__ forward + autograd
+ *                              backward (call sites
+ *                              gaussian_renderer/__init__.py:179-205, train.py:211)
+ *   cgs_expand_*               generate_neural_gaussians' elementwise chain
+ *                              (gaussian_renderer/__init__.py:106-145)
+ *   cgs_entropy_gaussian_*     utils/entropy_models.py:30-50,141-156
+ *   cgs_ste_multistep,
+ *   cgs_quantize_anchor        utils/encodings.py:203-231
+ *   cgs_level_*                utils/multi_level.py:3-31,
+ *                              scene/gaussian_model.py:1751-1765
+ *   cgs_ac_*                   torchac.encode_float_cdf / decode_float_cdf as
+ *                              called from utils/encodings.py:108,138,157,178
+ *   cgs_gaussian_codec_*       encoder_gaussian / decoder_gaussian
+ *                              (utils/encodings.py:83-144) without the
+ *                              [n_sym, L] float table
+ */
+#ifndef CGS_H
+#define CGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGS_VERSION 100 /* 0.1.0 */
+
+#define CGS_OK 0
+#define CGS_ERR_ARG 1
+#define CGS_ERR_HIP 2
+#define CGS_ERR_WORKSPACE 3
+#define CGS_ERR_BOUNDS 4
+
+int cgs_version(void);
+const char *cgs_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* Rasterizer                                                          */
+/* ------------------------------------------------------------------ */
+
+/* Mirrors GaussianRasterizationSettings (the 12 keyword fields built at
+ * gaussian_renderer/__init__.py:179-192).  Matrices are the tensors the
+ * reference passes: ROW-vector convention, p_view = [x y z 1] @ viewmatrix,
+ * row-major 4x4 fp32 on the device.  sh_degree / campos are accepted for
+ * API parity; colours are always precomputed on this path (shs=None). */
+typedef struct cgs_raster_cfg {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;              /* !=0: synchronise + check after each kernel */
+    const float *viewmatrix;    /* device, 16 floats */
+    const float *projmatrix;    /* device, 16 floats */
+    const float *campos;        /* device, 3 floats (unused: colours precomputed) */
+    const float *bg;            /* device, 3 floats */
+} cgs_raster_cfg;
+
+/* visible_filter: preprocess-only; radii[i] > 0 iff anchor i survives the
+ * near cull and touches at least one tile.  scales [N,3], rotations [N,4]
+ * (r,x,y,z; used as given, not renormalised). */
+int cgs_filter(const cgs_raster_cfg *cfg, int64_t N, const float *means3D,
+               const float *scales, const float *rotations, int32_t *radii,
+               void *stream);
+
+/* Workspace sizes in bytes (host-side helpers, no device work). */
+size_t cgs_raster_geom_bytes(int64_t P);
+size_t cgs_raster_bin_bytes(int64_t P, int64_t num_rendered);
+size_t cgs_raster_img_bytes(int32_t height, int32_t width);
+
+/* Forward, stage 1: per-Gaussian preprocess, depth sort, offsets scan.
+ * Writes radii[P] and the geometry workspace; returns the number of
+ * tile/Gaussian pairs in *num_rendered_host (stream is synchronised once for
+ * this 8-byte read-back). */
+int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P,
+                          const float *means3D, const float *colors,
+                          const float *opacities, const float *scales,
+                          const float *rotations, void *geom_ws,
+                          size_t geom_bytes, int32_t *radii,
+                          int64_t *num_rendered_host, void *stream);
+
+/* Forward, stage 2: pair emission, per-tile stable sort, ranges, alpha blend.
+ * out_color is [3, H, W]. */
+int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P,
+                      int64_t num_rendered, void *geom_ws, size_t geom_bytes,
+                      void *bin_ws, size_t bin_bytes, void *img_ws,
+                      size_t img_bytes, float *out_color, void *stream);
+
+/* Backward of the two stages above.  dL_dout is [3,H,W].  All gradient
+ * buffers must be zero-initialised by the caller (the blend pass
+ * accumulates).  dL_dmeans2D is [P,3] (x,y in the NDC-scaled convention the
+ * densification threshold assumes; z = 0), the others match their inputs. */
+int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P,
+                        int64_t num_rendered, const float *means3D,
+                        const float *colors, const float *opacities,
+                        const float *scales, const float *rotations,
+                        const int32_t *radii, void *geom_ws, size_t geom_bytes,
+                        void *bin_ws, size_t bin_bytes, void *img_ws,
+                        size_t img_bytes, const float *dL_dout,
+                        float *dL_dmeans3D, float *dL_dmeans2D,
+                        float *dL_dcolors, float *dL_dopacities,
+                        float *dL_dscales, float *dL_drotations,
+                        void *scratch, size_t scratch_bytes, void *stream);
+size_t cgs_raster_bwd_scratch_bytes(int64_t P);
+
+/* Statistics of the last render held in img_ws (device reads; async):
+ * stats_out[0] = R_eff = sum over tiles of the deepest contributor position
+ * (pairs the blend pass had to read), stats_out[1] = number of non-empty
+ * tiles. int64 x 2 on the device. */
+int cgs_raster_stats(const cgs_raster_cfg *cfg, void *img_ws, size_t img_bytes,
+                     int64_t *stats_out, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Generic device primitives used by the path (exposed for tests)      */
+/* ------------------------------------------------------------------ */
+
+/* Exclusive prefix sum of uint32, n elements; scratch from
+ * cgs_scan_scratch_bytes(n). in == out allowed. */
+size_t cgs_scan_scratch_bytes(int64_t n);
+int cgs_scan_exclusive_u32(const uint32_t *in, uint32_t *out, int64_t n,
+                           void *scratch, size_t scratch_bytes, void *stream);
+
+/* Stable LSD radix sort of (key,value) uint32 pairs on key bits
+ * [bit_lo, bit_hi).  Result lands in keys_out/vals_out; keys_tmp/vals_tmp
+ * are ping-pong buffers of the same size. scratch from
+ * cgs_sort_scratch_bytes(n). */
+size_t cgs_sort_scratch_bytes(int64_t n);
+int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in,
+                       uint32_t *keys_out, uint32_t *vals_out,
+                       uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n,
+                       int bit_lo, int bit_hi, void *scratch,
+                       size_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGS_H */
