@@ -61,6 +61,21 @@ SIGNATURES = {
     "cgs_sort_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_sort_pairs_u32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                    c_void_p, c_size_t, c_void_p]),
+    "cgs_quantize_anchor": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "cgs_ste_multistep": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "cgs_entropy_gaussian_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int,
+                                         c_void_p, c_void_p]),
+    "cgs_entropy_gaussian_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_prof_enable": (c_int, [c_int]),
+    "cgs_prof_count": (c_int, []),
+    "cgs_prof_name": (C.c_char_p, [c_int]),
+    "cgs_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64)]),
+    "cgs_expand_scratch_bytes": (c_size_t, [c_int64, c_int]),
+    "cgs_expand_count": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_size_t, C.POINTER(c_int64), c_void_p]),
+    "cgs_expand_write": (c_int, [c_int64, c_int] + [c_void_p] * 14),
+    "cgs_expand_backward": (c_int, [c_int64, c_int] + [c_void_p] * 21),
 }
 
 

@@ -145,13 +145,20 @@ extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const
                                     stream)))
         return rc;
     // depth order (stable: ties keep ascending Gaussian id)
-    if ((rc = cgs_launch_iota(P, g.sort_c, stream))) return rc;
-    if ((rc = cgs_sort_pairs_u32(g.depth_key, g.sort_c, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
-                                 g.scratch, g.scratch_bytes, stream)))
-        return rc;
-    if ((rc = cgs_launch_gather_tiles(P, g.order, g.tiles, g.sort_a, stream))) return rc;
-    if ((rc = cgs_scan_exclusive_u32_total(g.sort_a, g.offsets, P, g.scratch, g.scratch_bytes, g.total, stream)))
-        return rc;
+    {
+        CgsProfScope prof(CGS_PROF_DEPTH_SORT, stream);
+        if ((rc = cgs_launch_iota(P, g.sort_c, stream))) return rc;
+        if ((rc = cgs_sort_pairs_u32(g.depth_key, g.sort_c, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
+                                     g.scratch, g.scratch_bytes, stream)))
+            return rc;
+    }
+    {
+        CgsProfScope prof(CGS_PROF_OFFSETS_SCAN, stream);
+        if ((rc = cgs_launch_gather_tiles(P, g.order, g.tiles, g.sort_a, stream))) return rc;
+        if ((rc = cgs_scan_exclusive_u32_total(g.sort_a, g.offsets, P, g.scratch, g.scratch_bytes, g.total,
+                                               stream)))
+            return rc;
+    }
     static thread_local uint32_t *pinned = nullptr;
     if (!pinned) CGS_CHECK_HIP(hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
     CGS_CHECK_HIP(hipMemcpyAsync(pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -194,9 +201,12 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
             return CGS_ERR_WORKSPACE;
         }
         if ((rc = cgs_launch_emit_pairs(cfg, P, g, b, stream))) return rc;
-        if ((rc = cgs_sort_pairs_u32(b.tile_key_a, b.gid_a, b.tile_key_c, b.gid_sorted, b.tile_key_b, b.gid_b, R,
-                                     0, tile_bits(cfg), b.scratch, b.scratch_bytes, stream)))
-            return rc;
+        {
+            CgsProfScope prof(CGS_PROF_TILE_SORT, stream);
+            if ((rc = cgs_sort_pairs_u32(b.tile_key_a, b.gid_a, b.tile_key_c, b.gid_sorted, b.tile_key_b, b.gid_b,
+                                         R, 0, tile_bits(cfg), b.scratch, b.scratch_bytes, stream)))
+                return rc;
+        }
     }
     if ((rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
     return cgs_launch_blend_fwd(cfg, g, b, im, out_color, stream);

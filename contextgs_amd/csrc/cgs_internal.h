@@ -31,6 +31,23 @@ void cgs_set_error(const char *fmt, ...);
 
 static inline size_t cgs_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional per-kernel timing (bench.py's roofline leg) -------------------
+// HIP events recorded on the launch stream around a kernel (or a short fixed
+// sequence of kernels); off by default, zero cost when off.
+enum CgsProfId {
+    CGS_PROF_FILTER = 0, CGS_PROF_PREPROCESS, CGS_PROF_DEPTH_SORT, CGS_PROF_OFFSETS_SCAN, CGS_PROF_EMIT_PAIRS,
+    CGS_PROF_TILE_SORT, CGS_PROF_RANGES, CGS_PROF_BLEND_FWD, CGS_PROF_BLEND_BWD, CGS_PROF_PREPROCESS_BWD,
+    CGS_PROF_EXPAND_FWD, CGS_PROF_EXPAND_BWD, CGS_PROF_RATE_FWD, CGS_PROF_RATE_BWD, CGS_PROF_COUNT
+};
+extern int g_cgs_prof_on;
+void cgs_prof_begin(int id, hipStream_t stream);
+void cgs_prof_end(int id, hipStream_t stream);
+struct CgsProfScope {
+    int id; hipStream_t s;
+    CgsProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { if (g_cgs_prof_on) cgs_prof_begin(id, s); }
+    ~CgsProfScope() { if (g_cgs_prof_on) cgs_prof_end(id, s); }
+};
+
 // Bump allocator over a caller-owned workspace.
 struct CgsCarver {
     char *base;

@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(BLEND_THREADS)
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    CgsProfScope prof(CGS_PROF_BLEND_FWD, stream);
     hipLaunchKernelGGL(blend_fwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
                        (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, out_color, im.final_T,
@@ -308,6 +309,7 @@ int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
                          float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
                        (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg,

@@ -147,6 +147,7 @@ int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float 
                               const float *dL_dconic, float *dL_dmeans3D, float *dL_dmeans2D,
                               float *dL_dscales, float *dL_drotations, hipStream_t stream) {
     if (P == 0) return CGS_OK;
+    CgsProfScope prof(CGS_PROF_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((unsigned)((P + PB_THREADS - 1) / PB_THREADS)),
                        dim3(PB_THREADS), 0, stream, P, cfg->image_width, cfg->image_height, cfg->tanfovx,
                        cfg->tanfovy, cfg->scale_modifier, cfg->viewmatrix, cfg->projmatrix, means3D, scales,

@@ -104,6 +104,7 @@ int cgs_launch_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *mea
                           int32_t *radii, bool filter_only, hipStream_t stream) {
     if (P == 0) return CGS_OK;
     const unsigned nb = (unsigned)((P + PRE_THREADS - 1) / PRE_THREADS);
+    CgsProfScope prof(filter_only ? CGS_PROF_FILTER : CGS_PROF_PREPROCESS, stream);
     if (filter_only) {
         hipLaunchKernelGGL(preprocess_kernel<true>, dim3(nb), dim3(PRE_THREADS), 0, stream, P,
                            cfg->image_width, cfg->image_height, cfg->tanfovx, cfg->tanfovy,
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256)
 
 int cgs_launch_emit_pairs(const cgs_raster_cfg *cfg, int64_t P, CgsGeom &g, CgsBin &b, hipStream_t stream) {
     if (P == 0) return CGS_OK;
+    CgsProfScope prof(CGS_PROF_EMIT_PAIRS, stream);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P,
                        cgs_tiles_x(cfg), g.order, g.offsets, g.tiles, g.rect, b.tile_key_a, b.gid_a);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
@@ -199,6 +201,7 @@ int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &i
     const size_t nt = (size_t)cgs_tiles_x(cfg) * cgs_tiles_y(cfg);
     CGS_CHECK_HIP(hipMemsetAsync(im.ranges, 0, nt * sizeof(uint2), stream));
     if (R == 0) return CGS_OK;
+    CgsProfScope prof(CGS_PROF_RANGES, stream);
     hipLaunchKernelGGL(ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, R,
                        (const uint32_t *)b.tile_key_c, im.ranges);
     CGS_CHECK_LAUNCH(stream, cfg->debug);

@@ -1,0 +1,196 @@
+"""Hyper-prior codec: a factorised-density `EntropyBottleneck(channels)`.
+
+Replaces the six methods of compressai's EntropyBottleneck the reference uses
+(scene/gaussian_model.py:135 ctor, :223/:913 update, :1040 quantize "symbols" +
+_get_medians, :1088 compress, :1331 decompress, :1556 forward(x, training)).
+compressai is NOT in the mount and unpinned (parity
+unpinned); this restates the published factorised prior (Ballé et al. 2018,
+the same maths as utils/entropy_models.py:103-138 `Entropy_factorized`, which
+IS in the mount) and codes the symbols with our own range-ANS
+(contextgs_amd.codec), so hyper.b streams are self-consistent (encode ->
+decode bit-exact) but not byte-compatible with compressai's.
+
+Layout: inputs are [N, C] (N anchors, C = feat_dim // hyper_divisor = 12
+channels); every channel owns an independent 1 -> 3 -> 3 -> 3 -> 3 -> 1
+cumulative-logit network.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _LowerBound(torch.autograd.Function):
+    """max(x, bound) whose gradient also passes where it moves x towards the bound's
+    feasible side (the usual likelihood lower bound)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x)
+        ctx.bound = bound
+        return torch.clamp(x, min=bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        pass_through = (x >= ctx.bound) | (g < 0)
+        return g * pass_through.to(g.dtype), None
+
+
+class EntropyBottleneck(nn.Module):
+    def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10.0,
+                 filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9, entropy_coder_precision: int = 16):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.likelihood_bound = float(likelihood_bound)
+        self.precision = int(entropy_coder_precision)
+
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1.0 / (len(self.filters) + 1))
+        self.matrices = nn.ParameterList()
+        self.biases = nn.ParameterList()
+        self.factors = nn.ParameterList()
+        for i in range(len(self.filters) + 1):
+            init = math.log(math.expm1(1.0 / scale / f[i + 1]))
+            self.matrices.append(nn.Parameter(torch.full((channels, f[i + 1], f[i]), init)))
+            self.biases.append(nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.factors.append(nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        # support: never trained in ContextGS (no aux loss anywhere) -> stays (-10, 0, 10)
+        self.quantiles = nn.Parameter(torch.tensor([-self.init_scale, 0.0, self.init_scale]).repeat(channels, 1, 1))
+        self.register_buffer("_offset", torch.zeros(0, dtype=torch.int32))
+        self.register_buffer("_quantized_cdf", torch.zeros(0, 0, dtype=torch.int32))
+        self.register_buffer("_cdf_length", torch.zeros(0, dtype=torch.int32))
+
+    # ---- density ---------------------------------------------------------------
+    def _logits_cumulative(self, x: torch.Tensor, stop_gradient: bool = False) -> torch.Tensor:
+        """x: [C, 1, M] -> cumulative logits [C, 1, M]."""
+        logits = x
+        for i in range(len(self.filters) + 1):
+            m, b = self.matrices[i], self.biases[i]
+            if stop_gradient:
+                m, b = m.detach(), b.detach()
+            logits = torch.matmul(F.softplus(m), logits) + b
+            if i < len(self.filters):
+                a = self.factors[i].detach() if stop_gradient else self.factors[i]
+                logits = logits + torch.tanh(a) * torch.tanh(logits)
+        return logits
+
+    def _likelihood(self, x: torch.Tensor, stop_gradient: bool = False) -> torch.Tensor:
+        lower = self._logits_cumulative(x - 0.5, stop_gradient)
+        upper = self._logits_cumulative(x + 0.5, stop_gradient)
+        sign = -torch.sign(lower + upper).detach()
+        return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+
+    def _get_medians(self) -> torch.Tensor:
+        return self.quantiles[:, :, 1:2].detach()     # [C,1,1]
+
+    # ---- quantisation ------------------------------------------------------------
+    def quantize(self, inputs: torch.Tensor, mode: str, means: torch.Tensor | None = None) -> torch.Tensor:
+        if mode == "noise":
+            return inputs + torch.empty_like(inputs).uniform_(-0.5, 0.5)
+        out = inputs if means is None else inputs - means
+        out = torch.round(out)
+        if mode == "dequantize":
+            return out if means is None else out + means
+        if mode == "symbols":
+            return out.int()
+        raise ValueError(f"unknown quantisation mode {mode!r}")
+
+    def forward(self, x: torch.Tensor, training: bool | None = None):
+        """x [N, C] -> (x_hat [N, C], likelihood [N, C])."""
+        if training is None:
+            training = self.training
+        assert x.dim() == 2 and x.shape[1] == self.channels, "expects [N, C]"
+        v = x.t().reshape(self.channels, 1, -1)                      # [C,1,N]
+        out = self.quantize(v, "noise" if training else "dequantize", self._get_medians())
+        lik = _LowerBound.apply(self._likelihood(out), self.likelihood_bound)
+        back = lambda t: t.reshape(self.channels, -1).t()
+        return back(out), back(lik)
+
+    # ---- tables --------------------------------------------------------------------
+    @torch.no_grad()
+    def update(self, force: bool = False) -> bool:
+        """(Re)build the per-channel quantised CDF tables used by compress/decompress."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        med = self.quantiles[:, 0, 1]
+        minima = torch.clamp(torch.ceil(med - self.quantiles[:, 0, 0]), min=0).int()
+        maxima = torch.clamp(torch.ceil(self.quantiles[:, 0, 2] - med), min=0).int()
+        self._offset = (-minima).int()
+        pmf_start = med - minima
+        pmf_length = maxima + minima + 1
+        max_len = int(pmf_length.max().item())
+        samples = torch.arange(max_len, device=med.device, dtype=med.dtype)[None, None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative(samples - 0.5, True)
+        upper = self._logits_cumulative(samples + 0.5, True)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        cdf = torch.zeros(self.channels, max_len + 2, dtype=torch.int32)
+        pmf_c, tail_c, len_c = pmf.double().cpu().numpy(), tail.double().cpu().numpy(), pmf_length.cpu().numpy()
+        for c in range(self.channels):
+            probs = np.concatenate([pmf_c[c, : len_c[c]], tail_c[c]])
+            q = pmf_to_quantized_cdf(probs, self.precision)
+            cdf[c, : q.size] = torch.from_numpy(q.astype(np.int32))
+        self._quantized_cdf = cdf.to(med.device)
+        self._cdf_length = (pmf_length + 2).int()
+        return True
+
+    # ---- coding (host rANS via libcgs, see codec.py) -----------------------------------
+    @torch.no_grad()
+    def compress(self, x: torch.Tensor) -> list[bytes]:
+        """x [1, C, n] (the reference's rearrange 'b c -> 1 c b', gaussian_model.py:1088) -> [bytes]."""
+        from . import codec
+        assert x.dim() == 3 and x.shape[0] == 1 and x.shape[1] == self.channels
+        if self._offset.numel() == 0:
+            self.update()
+        sym = self.quantize(x[0], "symbols", self._get_medians()[:, 0])           # [C, n] int32
+        return [codec.rans_encode_channels(sym.cpu().numpy(), self._quantized_cdf.cpu().numpy(),
+                                           self._cdf_length.cpu().numpy(), self._offset.cpu().numpy(),
+                                           self.precision)]
+
+    @torch.no_grad()
+    def decompress(self, strings: list[bytes], size) -> torch.Tensor:
+        """inverse of compress: -> [1, C, n] dequantised."""
+        from . import codec
+        n = int(size[0]) if isinstance(size, (tuple, list, torch.Size)) else int(size)
+        if self._offset.numel() == 0:
+            self.update()
+        sym = codec.rans_decode_channels(strings[0], self.channels, n, self._quantized_cdf.cpu().numpy(),
+                                         self._cdf_length.cpu().numpy(), self._offset.cpu().numpy(), self.precision)
+        dev = self.quantiles.device
+        out = torch.from_numpy(sym).to(dev).to(self.quantiles.dtype) + self._get_medians()[:, 0]
+        return out.unsqueeze(0)
+
+
+def pmf_to_quantized_cdf(pmf: np.ndarray, precision: int = 16) -> np.ndarray:
+    """Probabilities -> strictly increasing integer CDF with total 2**precision
+    (every symbol keeps frequency >= 1; the excess is taken from the symbols that lose
+    the least relative mass).  Deterministic pure-integer steal loop."""
+    total = 1 << precision
+    freq = np.maximum(1, np.round(np.asarray(pmf, dtype=np.float64) / max(pmf.sum(), 1e-300) * total)).astype(np.int64)
+    diff = int(freq.sum() - total)
+    while diff != 0:
+        if diff > 0:      # remove from the largest entries first
+            i = int(np.argmax(freq))
+            take = min(diff, int(freq[i]) - 1)
+            if take <= 0:
+                raise ValueError("cannot normalise pmf")
+            freq[i] -= take
+            diff -= take
+        else:
+            i = int(np.argmax(freq))
+            freq[i] += -diff
+            diff = 0
+    cdf = np.zeros(freq.size + 1, dtype=np.int64)
+    np.cumsum(freq, out=cdf[1:])
+    assert cdf[-1] == total and (np.diff(cdf) > 0).all()
+    return cdf

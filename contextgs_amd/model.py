@@ -1,0 +1,157 @@
+"""Hot-path half of the reference's `GaussianModel` (scene/gaussian_model.py).
+
+Carries exactly the state tensors, accessors and MLP definitions the
+render-and-compress path reads (SURVEY §8a rows a6/a7 and the state-tensor
+table): same attribute and property names, same shapes, same activations, so
+`render()` / `multi_scale_generating()` / the codec accept either this class
+or the reference's own GaussianModel.  Optimiser, densification, ply I/O stay
+in the reference (out of scope).
+
+Cited lines are scene/gaussian_model.py unless stated otherwise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .encodings import Quantize_anchor
+from .entropy_bottleneck import EntropyBottleneck
+from .entropy_models import Entropy_gaussian
+
+
+class GaussianModel(nn.Module):
+    def __init__(self, feat_dim: int = 50, n_offsets: int = 10, voxel_size: float = 0.01, level_num: int = 3,
+                 hyper_divisor: int = 4, target_ratio: float = 0.2, adaptQ_per_channel: bool = False,
+                 disable_hyper: bool = False, decoded_version: bool = False, device="cuda"):
+        super().__init__()
+        self.feat_dim, self.n_offsets, self.voxel_size = feat_dim, n_offsets, voxel_size
+        self.level_num, self.hyper_divisor, self.target_ratio = level_num, hyper_divisor, target_ratio
+        self.adaptQ_per_channel, self.disable_hyper = adaptQ_per_channel, disable_hyper
+        self.decoded_version = decoded_version
+        self.level_scale = None
+        self.use_feat_bank = False
+        dev = torch.device(device)
+        self.x_bound_min = torch.zeros(1, 3, device=dev)           # :93-94
+        self.x_bound_max = torch.ones(1, 3, device=dev)
+        H = feat_dim // hyper_divisor
+
+        e = torch.empty(0, device=dev)
+        self._anchor = e; self._offset = e; self._mask = e; self._anchor_feat = e
+        self._hyper_latent = e; self._scaling = e; self._rotation = e; self._opacity = e
+
+        self.latent_codec = EntropyBottleneck(channels=H).to(dev)    # :135
+        D = feat_dim
+        self.mlp_opacity = nn.Sequential(nn.Linear(D + 4, D), nn.ReLU(True), nn.Linear(D, n_offsets), nn.Tanh()).to(dev)      # :153-158
+        self.mlp_cov = nn.Sequential(nn.Linear(D + 4, D), nn.ReLU(True), nn.Linear(D, 7 * n_offsets)).to(dev)                  # :161-166
+        self.mlp_color = nn.Sequential(nn.Linear(D + 4, D), nn.ReLU(True), nn.Linear(D, 3 * n_offsets), nn.Sigmoid()).to(dev)  # :169-174
+        self.mlp_grid = nn.ModuleList()                                                                                         # :177-188
+        out_dim = (D + 6 + 3 * n_offsets) * 2 + 3
+        ctx_dim = D + 6 + 3
+        for i in range(level_num):
+            in_dim = H + 3 if i == level_num - 1 else ctx_dim + H
+            self.mlp_grid.append(nn.Sequential(nn.Linear(in_dim, 2 * D), nn.ReLU(True), nn.Linear(2 * D, out_dim)).to(dev))
+        self.entropy_gaussian = Entropy_gaussian(Q=1)                 # :190
+        self.rotation_activation = torch.nn.functional.normalize      # :58
+        # caches (SURVEY §8a "caching opportunity"): see context_model.divide_levels_cached
+        self._level_cache = None
+
+    # ---- train / eval switches (:200-220) ------------------------------------
+    def eval(self):
+        for m in (self.mlp_opacity, self.mlp_cov, self.mlp_color, self.latent_codec, self.mlp_grid):
+            m.eval()
+        return self
+
+    def train(self, mode: bool = True):
+        for m in (self.mlp_opacity, self.mlp_cov, self.mlp_color, self.latent_codec, self.mlp_grid):
+            m.train(mode)
+        return self
+
+    # ---- accessors (:288-345) --------------------------------------------------
+    @property
+    def get_scaling(self):
+        if self.decoded_version:
+            return self._scaling
+        return 1.0 * torch.exp(self._scaling)
+
+    @property
+    def get_mask(self):
+        if self.decoded_version:
+            return self._mask
+        s = torch.sigmoid(self._mask)
+        return ((s > 0.01).float() - s).detach() + s
+
+    @property
+    def get_mask_anchor(self):
+        with torch.no_grad():
+            if self.decoded_version:
+                return torch.sum(self._mask, dim=1)[:, 0] > 0
+            s = torch.sigmoid(self._mask)
+            m = ((s > 0.01).float() - s).detach() + s
+            return torch.sum(m, dim=1)[:, 0] > 0
+
+    @property
+    def get_opacity_mlp(self): return self.mlp_opacity
+    @property
+    def get_cov_mlp(self): return self.mlp_cov
+    @property
+    def get_color_mlp(self): return self.mlp_color
+    @property
+    def get_grid_mlp(self): return self.mlp_grid
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_anchor(self):
+        if self.decoded_version:
+            return self._anchor
+        anchor, _q = Quantize_anchor.apply(self._anchor, self.x_bound_min, self.x_bound_max)
+        return anchor
+
+    @torch.no_grad()
+    def update_anchor_bound(self):                                  # :351-361
+        lo = torch.min(self._anchor, dim=0, keepdim=True)[0].detach()
+        hi = torch.max(self._anchor, dim=0, keepdim=True)[0].detach()
+        self.x_bound_min = torch.where(lo < 0, lo * 1.2, lo * 0.8)
+        self.x_bound_max = torch.where(hi > 0, hi * 1.2, hi * 0.8)
+        self._level_cache = None
+
+    def get_mlp_size(self, digit: int = 32):                        # :193-198
+        n = sum(p.numel() for name, p in self.named_parameters() if "mlp" in name and "deform" not in name)
+        return n * digit, n * digit / 8 / 1024 / 1024
+
+    # ---- state -------------------------------------------------------------------
+    def set_state(self, anchor, offset, mask, feat, hyper, scaling, rotation=None, requires_grad=True):
+        """Install the per-anchor parameters (shapes of :399-423)."""
+        dev = self.x_bound_min.device
+        P = lambda t, g=True: nn.Parameter(torch.as_tensor(t, dtype=torch.float32, device=dev).contiguous(),
+                                           requires_grad=requires_grad and g)
+        N = anchor.shape[0]
+        self._anchor = P(anchor)
+        self._offset = P(offset)
+        self._mask = P(mask)
+        self._anchor_feat = P(feat)
+        self._hyper_latent = P(hyper)
+        self._scaling = P(scaling)
+        if rotation is None:
+            rotation = torch.zeros(N, 4)
+            rotation[:, 0] = 1
+        self._rotation = P(rotation, False)
+        self._opacity = P(torch.zeros(N, 1), False)
+        self._level_cache = None
+        return self
+
+    # the codec / rate-report methods live in codec_driver.py and are bound here so the
+    # reference's call sites (train.py:301-314, test.py:168-177) work unchanged.
+    def estimate_final_bits(self):
+        from .codec_driver import estimate_final_bits
+        return estimate_final_bits(self)
+
+    def conduct_encoding(self, pre_path_name):
+        from .codec_driver import conduct_encoding
+        return conduct_encoding(self, pre_path_name)
+
+    def conduct_decoding(self, pre_path_name):
+        from .codec_driver import conduct_decoding
+        return conduct_decoding(self, pre_path_name)

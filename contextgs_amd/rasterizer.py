@@ -66,6 +66,9 @@ class _Cfg:
         return C.byref(self.c)
 
 
+last_call: dict = {}   # sizes / image workspace of the most recent forward (bench.py's byte accounting)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -98,6 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                    "cgs_raster_render")
         ctx.cfg = cfg
         ctx.num_rendered = num_rendered
+        last_call.update(P=P, num_rendered=num_rendered, img_ws=img)
         ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii)
         return color, radii

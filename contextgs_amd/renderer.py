@@ -1,0 +1,223 @@
+"""Drop-in for the reference's `gaussian_renderer/__init__.py`:
+`prefilter_voxel`, `generate_neural_gaussians`, `render` with the same
+signatures, phase switches and return values (cited lines are that file).
+
+What runs where: the visibility filter and the whole rasterizer are HIP
+kernels (rasterizer.py); the anchor->Gaussian elementwise/compaction chain is
+the fused HIP expansion (expand.hip) behind `_ExpandGaussians`; the three tiny
+anchor MLPs go through rocBLAS via torch (north_star), with their first layers
+batched into one [N,54]x[54,150] GEMM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .context_model import multi_scale_generating
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+Q_FEAT, Q_SCALING, Q_OFFSETS = 1, 0.001, 0.2      # :40-42
+
+
+def _c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+class _ExpandGaussians(torch.autograd.Function):
+    """(anchor, grid_scaling, offsets, masks, mlp outputs) -> compacted Gaussians (:112-145)."""
+
+    @staticmethod
+    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, K):
+        L = _lib.lib()
+        _lib.require_device(anchor, gscaling, offsets, masks, op_raw, color_in, cov_in)
+        anchor, gscaling, offsets = _c(anchor), _c(gscaling), _c(offsets)
+        masks, op_raw, color_in, cov_in = _c(masks), _c(op_raw), _c(color_in), _c(cov_in)
+        n = anchor.shape[0]
+        dev = anchor.device
+        stream = _lib.current_stream()
+        slots = n * K
+        neural_opacity = torch.empty(slots, 1, dtype=torch.float32, device=dev)
+        mask_out = torch.empty(slots, dtype=torch.bool, device=dev)
+        flags = torch.empty(slots, dtype=torch.int32, device=dev)
+        pos = torch.empty(slots, dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.cgs_expand_scratch_bytes(n, K), dtype=torch.uint8, device=dev)
+        cnt = C.c_int64(0)
+        _lib.check(L.cgs_expand_count(n, K, _lib.ptr(op_raw), _lib.ptr(masks), _lib.ptr(neural_opacity),
+                                      _lib.ptr(mask_out), _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(scratch),
+                                      scratch.numel(), C.byref(cnt), stream), "cgs_expand_count")
+        P = int(cnt.value)
+        xyz = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        color = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        opacity = torch.empty(P, 1, dtype=torch.float32, device=dev)
+        scaling = torch.empty(P, 3, dtype=torch.float32, device=dev)
+        rot = torch.empty(P, 4, dtype=torch.float32, device=dev)
+        _lib.check(L.cgs_expand_write(n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(anchor), _lib.ptr(gscaling),
+                                      _lib.ptr(offsets), _lib.ptr(neural_opacity), _lib.ptr(color_in),
+                                      _lib.ptr(cov_in), _lib.ptr(xyz), _lib.ptr(color), _lib.ptr(opacity),
+                                      _lib.ptr(scaling), _lib.ptr(rot), stream), "cgs_expand_write")
+        ctx.K = K
+        ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in)
+        ctx.mark_non_differentiable(mask_out)
+        return xyz, color, opacity, scaling, rot, neural_opacity, mask_out
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_no, _g_mask):
+        L = _lib.lib()
+        flags, pos, gscaling, offsets, op_raw, masks, cov_in = ctx.saved_tensors
+        K = ctx.K
+        n = gscaling.shape[0]
+        dev = gscaling.device
+        P = int(g_xyz.shape[0]) if g_xyz is not None else 0
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        g_xyz = _c(g_xyz) if g_xyz is not None else z(P, 3)
+        g_color = _c(g_color) if g_color is not None else z(P, 3)
+        g_opacity = _c(g_opacity) if g_opacity is not None else z(P, 1)
+        g_scaling = _c(g_scaling) if g_scaling is not None else z(P, 3)
+        g_rot = _c(g_rot) if g_rot is not None else z(P, 4)
+        g_no = _c(g_no) if g_no is not None else None
+        e = lambda t: torch.empty_like(t)
+        d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        d_gs, d_off, d_op, d_mask = e(gscaling), e(offsets), e(op_raw), e(masks)
+        d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
+        d_cov = e(cov_in)
+        _lib.check(L.cgs_expand_backward(
+            n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(gscaling), _lib.ptr(offsets), _lib.ptr(op_raw),
+            _lib.ptr(masks), _lib.ptr(cov_in), _lib.ptr(g_xyz), _lib.ptr(g_color), _lib.ptr(g_opacity),
+            _lib.ptr(g_scaling), _lib.ptr(g_rot), _lib.ptr(g_no), _lib.ptr(d_anchor), _lib.ptr(d_gs),
+            _lib.ptr(d_off), _lib.ptr(d_op), _lib.ptr(d_mask), _lib.ptr(d_color), _lib.ptr(d_cov),
+            _lib.current_stream()), "cgs_expand_backward")
+        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None
+
+
+def _anchor_mlps(pc, x):
+    """mlp_opacity / mlp_color / mlp_cov on the shared [N,54] input (:112,122,126).
+    The three first layers are one GEMM; outputs are identical dot products."""
+    mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    D = mo[0].out_features
+    W1 = torch.cat([mo[0].weight, mc[0].weight, mv[0].weight], dim=0)
+    b1 = torch.cat([mo[0].bias, mc[0].bias, mv[0].bias], dim=0)
+    h = F.relu(F.linear(x, W1, b1))
+    op_raw = torch.tanh(F.linear(h[:, :D], mo[2].weight, mo[2].bias))
+    color = torch.sigmoid(F.linear(h[:, D:2 * D], mc[2].weight, mc[2].bias))
+    cov = F.linear(h[:, 2 * D:], mv[2].weight, mv[2].bias)
+    return op_raw, color, cov
+
+
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0):   # :25-150
+    time_sub = 0
+    if visible_mask is None:
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+
+    bit_per_param = bit_per_anchor_param = bit_per_feat_param = None
+    bit_per_scaling_param = bit_per_offsets_param = bpp_per_level = None
+
+    full_anchor = pc.get_anchor
+    anchor = full_anchor[visible_mask]
+    feat = pc._anchor_feat[visible_mask]
+    grid_offsets = pc._offset[visible_mask]
+    grid_scaling = pc.get_scaling[visible_mask]
+    binary_grid_masks = pc.get_mask[visible_mask]
+
+    if is_training:
+        if 3000 < step <= 10000:                                                        # :54-58
+            feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q_FEAT
+            grid_scaling = grid_scaling + torch.empty_like(grid_scaling).uniform_(-0.5, 0.5) * Q_SCALING
+            grid_offsets = grid_offsets + torch.empty_like(grid_offsets).uniform_(-0.5, 0.5) * Q_OFFSETS
+        if step == 10000:                                                               # :60-61
+            pc.update_anchor_bound()
+        if step > 10000:                                                                # :63-81
+            mask_anchor_bool = pc.get_mask_anchor.to(torch.bool)
+            binary_all = pc.get_mask
+            (feat, grid_scaling, grid_offsets, bit_per_param, bit_per_feat_param, bit_per_scaling_param,
+             bit_per_offsets_param, bpp_per_level) = multi_scale_generating(
+                pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
+                mask_anchor_bool, predict_bpp=True, training=True)
+            anchor = pc.get_anchor[visible_mask]
+            feat = feat[visible_mask]
+            grid_offsets = grid_offsets[visible_mask]
+            grid_scaling = grid_scaling[visible_mask]
+            binary_grid_masks = binary_all[visible_mask]
+    elif not pc.decoded_version:                                                        # :83-101
+        mask_anchor_bool = pc.get_mask_anchor.to(torch.bool)
+        binary_all = pc.get_mask
+        feat, grid_scaling, grid_offsets = multi_scale_generating(
+            pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
+            mask_anchor_bool, predict_bpp=False, training=False)
+        anchor = pc.get_anchor[visible_mask]
+        feat = feat[visible_mask]
+        grid_offsets = grid_offsets[visible_mask]
+        grid_scaling = grid_scaling[visible_mask]
+        binary_grid_masks = binary_all[visible_mask]
+
+    ob_view = anchor - viewpoint_camera.camera_center                                   # :106-110
+    ob_dist = ob_view.norm(dim=1, keepdim=True)
+    ob_view = ob_view / ob_dist
+    cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
+
+    op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                          # :112-127
+    K = pc.n_offsets
+    xyz, color, opacity, scaling, rot, neural_opacity, mask = _ExpandGaussians.apply(
+        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K)
+
+    if is_training:                                                                      # :147-150
+        return (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, 16, bit_per_feat_param,
+                bit_per_scaling_param, bit_per_offsets_param, bpp_per_level)
+    return xyz, color, opacity, scaling, rot, time_sub
+
+
+def _raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=1, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_mask=None, retain_grad=False,
+           step=0):                                                                      # :155-229
+    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    is_training = pc.get_color_mlp.training
+    if is_training:
+        (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, bit_per_anchor_param,
+         bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level) = \
+            generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=True, step=step)
+    else:
+        xyz, color, opacity, scaling, rot, time_sub = generate_neural_gaussians(
+            viewpoint_camera, pc, visible_mask, is_training=False, step=step)
+
+    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+
+    rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier))
+    rendered_image, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=color,
+                                       opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    if is_training:
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii, "selection_mask": mask, "neural_opacity": neural_opacity, "scaling": scaling,
+                "bit_per_param": bit_per_param, "bit_per_anchor_param": bit_per_anchor_param,
+                "bit_per_feat_param": bit_per_feat_param, "bit_per_scaling_param": bit_per_scaling_param,
+                "bit_per_offsets_param": bit_per_offsets_param, "bpp_per_level": bpp_per_level}
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "time_sub": time_sub}
+
+
+def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):   # :232-287
+    """Anchor-level frustum/size cull: bool[N]."""
+    rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier))
+    means3D = pc.get_anchor
+    scales = pc.get_scaling
+    rotations = pc.get_rotation
+    with torch.no_grad():
+        radii_pure = rasterizer.visible_filter(means3D=means3D, scales=scales[:, :3],
+                                               rotations=rotations[[0], :].repeat(means3D.shape[0], 1),
+                                               cov3D_precomp=None)
+    return radii_pure > 0

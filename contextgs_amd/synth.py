@@ -102,3 +102,62 @@ def random_gaussians(P, seed=0, extent=1.0, scale_lo=0.005, scale_hi=0.05, dtype
     opac = rng.uniform(0.02, 0.95, size=(P, 1))
     f = lambda a: np.ascontiguousarray(a.astype(dtype))
     return dict(means3D=f(xyz), scales=f(scales), rotations=f(q), colors=f(colors), opacities=f(opac))
+
+
+def synthetic_anchors(N, voxel_size, seed=0):
+    """Exactly N distinct voxel-snapped anchors: a noisy unit-sphere shell plus 20 % uniform
+    in [-1,1]^3 (SURVEY §8d generator)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((0, 3), dtype=np.float64)
+    factor = 1.3
+    while out.shape[0] < N:
+        m = int(N * factor) + 16
+        n_shell = int(m * 0.8)
+        d = rng.normal(size=(n_shell, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        shell = d * (1.0 + 0.05 * rng.normal(size=(n_shell, 1)))
+        uni = rng.uniform(-1, 1, size=(m - n_shell, 3))
+        pts = np.concatenate([shell, uni], axis=0)
+        keys = np.unique(np.round(pts / voxel_size).astype(np.int64), axis=0)
+        rng.shuffle(keys)
+        out = keys[:N] * voxel_size
+        factor *= 1.5
+    return out.astype(np.float32)
+
+
+def make_scene(N, seed=0, voxel_size=None, feat_dim=50, n_offsets=10, device="cuda", requires_grad=True):
+    """Seeded synthetic ContextGS model with N anchors: returns a
+    contextgs_amd.model.GaussianModel with random-init MLPs (there is no network for
+    checkpoints) and trained-looking per-anchor state."""
+    import torch
+    from .model import GaussianModel
+
+    if voxel_size is None:
+        voxel_size = 0.01 if N <= 500_000 else 0.001
+    rng = np.random.default_rng(seed)
+    anchors = synthetic_anchors(N, voxel_size, seed)
+    K, D = n_offsets, feat_dim
+    base = rng.uniform(0.5, 2.0, size=(N, 6)) * voxel_size
+    base[:, 3:] *= 3.0
+    scaling = np.log(base)
+    offset = np.clip(rng.normal(0, 0.5, size=(N, K, 3)), -2, 2)
+    mask = np.where(rng.random((N, K, 1)) < 0.7, 4.0, -6.0)
+    feat = np.round(rng.normal(0, 3.0, size=(N, D)))
+    hyper = rng.normal(0, 2.0, size=(N, D // 4))
+
+    torch.manual_seed(seed)
+    pc = GaussianModel(feat_dim=D, n_offsets=K, voxel_size=voxel_size, device=device)
+    with torch.no_grad():
+        pc.mlp_opacity[2].bias.add_(0.5)          # ~60 % of the unmasked offsets survive opacity > 0
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    pc.set_state(f32(anchors), f32(offset), f32(mask), f32(feat), f32(hyper), f32(scaling),
+                 requires_grad=requires_grad)
+    pc.update_anchor_bound()
+    return pc
+
+
+class SynthPipe:
+    """PipelineParams stand-in (arguments/__init__.py): the fields render() reads."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False

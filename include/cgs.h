@@ -151,6 +151,85 @@ int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in,
                        int bit_lo, int bit_hi, void *scratch,
                        size_t scratch_bytes, void *stream);
 
+/* ------------------------------------------------------------------ */
+/* Per-kernel timing (used by bench.py's roofline leg)                  */
+/* ------------------------------------------------------------------ */
+/* When enabled, every hot kernel launch is bracketed by HIP events on its own
+ * launch stream.  cgs_prof_enable resets the counters; cgs_prof_read waits for
+ * the pending events of kernel `id` and returns total milliseconds and launch
+ * count since the last reset.  Off by default; zero cost when off. */
+int cgs_prof_enable(int on);
+int cgs_prof_count(void);
+const char *cgs_prof_name(int id);
+int cgs_prof_read(int id, double *total_ms, int64_t *launches);
+
+/* ------------------------------------------------------------------ */
+/* Quantisers and rate model (utils/encodings.py, utils/entropy_models.py) */
+/* ------------------------------------------------------------------ */
+
+/* Quantize_anchor.forward (utils/encodings.py:219-227): anchors [N,3],
+ * min_v/max_v [3] on the device; writes anchors_q [N,3] and the integer-valued
+ * quantized [N,3].  round_digits = anchor_round_digits (16). */
+int cgs_quantize_anchor(const float *anchors, const float *min_v,
+                        const float *max_v, int64_t N, int round_digits,
+                        float *anchors_q, float *quantized, void *stream);
+
+/* STE_multistep.forward (utils/encodings.py:205-213): out = round(clamp(x)/Q)*Q.
+ * x has n elements; element i uses Q[i / q_div] (q_div = row length for one Q
+ * per row, 1 for elementwise Q). */
+int cgs_ste_multistep(const float *x, const float *Q, int64_t n, int64_t q_div,
+                      int use_clamp, float *out, void *stream);
+
+/* Entropy_gaussian.forward (utils/entropy_models.py:34-50): bits =
+ * -log2(max(|Phi(x+Q/2) - Phi(x-Q/2)|, 1e-6)) with the +-15000 Q clamp about
+ * *x_mean (a device scalar).  Backward reproduces autograd through the
+ * reference's graph including Low_bound.backward (:149-156), fused, without
+ * the reference's host round trip. g_Q is elementwise; the caller reduces it
+ * over the broadcast dimension. */
+int cgs_entropy_gaussian_fwd(const float *x, const float *mean,
+                             const float *scale, const float *Q, int64_t n,
+                             int64_t q_div, const float *x_mean, int use_clamp,
+                             float *bits, void *stream);
+int cgs_entropy_gaussian_bwd(const float *x, const float *mean,
+                             const float *scale, const float *Q, int64_t n,
+                             int64_t q_div, const float *x_mean, int use_clamp,
+                             const float *g_bits, float *g_x, float *g_mean,
+                             float *g_scale, float *g_Q, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Anchor -> Gaussian expansion (gaussian_renderer/__init__.py:112-145)   */
+/* ------------------------------------------------------------------ */
+/* Slots are (anchor n, offset k), i = n*K + k.  op_raw [n,K] is mlp_opacity's
+ * output, mask [n,K] the binary offset mask, color_in [n,3K], cov_in [n,7K]
+ * the raw mlp_color / mlp_cov outputs, gscaling [n,6], offsets [n,K,3].
+ * cgs_expand_count writes neural_opacity [n*K], mask_out (bool bytes), the
+ * survivor flags and their compacted rows (pos), and returns the survivor
+ * count on the host; cgs_expand_write fills the compacted outputs
+ * xyz/color/scaling [P,3], opacity [P], rot [P,4]; cgs_expand_backward
+ * returns gradients for every differentiable input (all fully written). */
+size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K);
+int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw,
+                     const float *mask, float *neural_opacity,
+                     uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
+                     void *scratch, size_t scratch_bytes, int64_t *count_host,
+                     void *stream);
+int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags,
+                     const uint32_t *pos, const float *anchor,
+                     const float *gscaling, const float *offsets,
+                     const float *neural_opacity, const float *color_in,
+                     const float *cov_in, float *xyz, float *color,
+                     float *opacity, float *scaling, float *rot, void *stream);
+int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
+                        const uint32_t *pos, const float *gscaling,
+                        const float *offsets, const float *op_raw,
+                        const float *mask, const float *cov_in,
+                        const float *g_xyz, const float *g_color,
+                        const float *g_opacity, const float *g_scaling,
+                        const float *g_rot, const float *g_neural_opacity,
+                        float *d_anchor, float *d_gscaling, float *d_offsets,
+                        float *d_op_raw, float *d_mask, float *d_color_in,
+                        float *d_cov_in, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,85 @@
+"""Seeded inputs shared by tools/make_goldens.py (which runs the REFERENCE on them in
+the authoring container) and the parity tests (which run the oracle / HIP path on
+them).  Everything comes from numpy's PCG64 so that both sides regenerate identical
+arrays from (N, seed); only the reference's OUTPUTS are stored under tests/golden/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+D, K, H = 50, 10, 12          # feat_dim, n_offsets, hyper dim (arguments/__init__.py:50-51, hyper_divisor=4)
+LEVELS = 3
+
+
+def _linear(rng, fan_in, fan_out):
+    b = 1.0 / np.sqrt(fan_in)
+    return (rng.uniform(-b, b, size=(fan_out, fan_in)).astype(np.float32),
+            rng.uniform(-b, b, size=(fan_out,)).astype(np.float32))
+
+
+def mlp_weights(seed):
+    """State dicts (numpy) for mlp_opacity / mlp_cov / mlp_color / mlp_grid[0..2] with the
+    shapes of scene/gaussian_model.py:153-188, and the latent_codec parameters."""
+    rng = np.random.default_rng(seed + 1000)
+    w = {}
+    for name, out in (("mlp_opacity", K), ("mlp_cov", 7 * K), ("mlp_color", 3 * K)):
+        w[f"{name}.0.weight"], w[f"{name}.0.bias"] = _linear(rng, D + 4, D)
+        w[f"{name}.2.weight"], w[f"{name}.2.bias"] = _linear(rng, D, out)
+    w["mlp_opacity.2.bias"] = w["mlp_opacity.2.bias"] + np.float32(0.3)
+    out_dim = (D + 6 + 3 * K) * 2 + 3
+    for i in range(LEVELS):
+        in_dim = H + 3 if i == LEVELS - 1 else (D + 6 + 3) + H
+        w[f"mlp_grid.{i}.0.weight"], w[f"mlp_grid.{i}.0.bias"] = _linear(rng, in_dim, 2 * D)
+        w[f"mlp_grid.{i}.2.weight"], w[f"mlp_grid.{i}.2.bias"] = _linear(rng, 2 * D, out_dim)
+    # factorised prior (filters 3,3,3,3): perturbed around the standard init so that likelihoods vary
+    f = (1, 3, 3, 3, 3, 1)
+    scale = 10.0 ** (1.0 / 5)
+    for i in range(5):
+        init = np.log(np.expm1(1.0 / scale / f[i + 1]))
+        w[f"latent_codec.matrices.{i}"] = (init + 0.1 * rng.normal(size=(H, f[i + 1], f[i]))).astype(np.float32)
+        w[f"latent_codec.biases.{i}"] = rng.uniform(-0.5, 0.5, size=(H, f[i + 1], 1)).astype(np.float32)
+        if i < 4:
+            w[f"latent_codec.factors.{i}"] = (0.2 * rng.normal(size=(H, f[i + 1], 1))).astype(np.float32)
+    w["latent_codec.quantiles"] = np.tile(np.array([-10.0, 0.0, 10.0], dtype=np.float32), (H, 1, 1))
+    return w
+
+
+def anchor_state(N, seed, voxel_size=0.01):
+    """Per-anchor parameters (shapes of scene/gaussian_model.py:399-423)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(size=(4 * N, 3))
+    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * (0.3 + 0.7 * rng.random((4 * N, 1)))
+    keys = np.unique(np.round(pts / voxel_size).astype(np.int64), axis=0)
+    rng.shuffle(keys)
+    assert keys.shape[0] >= N
+    anchor = (keys[:N] * voxel_size).astype(np.float32)
+    base = rng.uniform(0.5, 2.0, size=(N, 6)) * voxel_size
+    base[:, 3:] *= 3.0
+    st = {
+        "anchor": anchor,
+        "offset": np.clip(rng.normal(0, 0.5, size=(N, K, 3)), -2, 2).astype(np.float32),
+        "mask": np.where(rng.random((N, K, 1)) < 0.7, 4.0, -6.0).astype(np.float32),
+        "feat": np.round(rng.normal(0, 3.0, size=(N, D))).astype(np.float32) + rng.uniform(-0.3, 0.3, size=(N, D)).astype(np.float32),
+        "hyper": rng.normal(0, 2.0, size=(N, H)).astype(np.float32),
+        "scaling": np.log(base).astype(np.float32),
+    }
+    # a few fully-masked anchors so that get_mask_anchor is not all-true (Q4 path)
+    st["mask"][:: 17] = -6.0
+    return st
+
+
+def camera_center(seed):
+    rng = np.random.default_rng(seed + 77)
+    c = rng.normal(size=3)
+    return (c / np.linalg.norm(c) * 3.0).astype(np.float32)
+
+
+def elementwise_inputs(n, seed):
+    rng = np.random.default_rng(seed + 5)
+    x = (np.round(rng.normal(0, 3, size=(n, D))) * 1.0 + rng.uniform(-0.4, 0.4, size=(n, D))).astype(np.float32)
+    mean = rng.normal(0, 2, size=(n, D)).astype(np.float32)
+    scale = np.exp(rng.normal(0, 1, size=(n, D))).astype(np.float32)
+    scale[0, :5] = 1e-12                         # exercises the 1e-9 clamp
+    Q = (1.0 * (1 + np.tanh(rng.normal(0, 0.5, size=(n, 1))))).clip(1e-9).astype(np.float32)
+    x[1, :3] = 9e4                               # exercises the +-15000 Q clamp
+    return x, mean, scale, Q
