@@ -67,6 +67,23 @@ SIGNATURES = {
                                          c_void_p, c_void_p]),
     "cgs_entropy_gaussian_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_ac_max_bytes": (c_size_t, [c_int64]),
+    "cgs_cdf_float_to_u16_host": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "cgs_ac_encode_table_host": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_size_t, C.POINTER(c_size_t)]),
+    "cgs_ac_decode_table_host": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_ac_encode_const_host": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_size_t, C.POINTER(c_size_t)]),
+    "cgs_ac_decode_const_host": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_gaussian_stream_minmax": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "cgs_gaussian_ac_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_gaussian_ac_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_gaussian_cdf_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "cgs_rans_max_bytes": (c_size_t, [c_int64]),
+    "cgs_rans_encode_host": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_size_t, C.POINTER(c_size_t)]),
+    "cgs_rans_decode_host": (c_int, [c_void_p, c_size_t, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p]),
     "cgs_prof_enable": (c_int, [c_int]),
     "cgs_prof_count": (c_int, []),
     "cgs_prof_name": (C.c_char_p, [c_int]),

@@ -1,0 +1,258 @@
+"""Entropy-coding front end over libcgs_hip.so's codec
+entry points (csrc/codec.hip):
+
+  * `encode_float_cdf` / `decode_float_cdf`        — the `torchac` API the reference
+    imports (utils/encodings.py:6), host arithmetic coder on uint16 CDFs;
+  * `encoder_gaussian` / `decoder_gaussian`         — utils/encodings.py:83-144, same
+    signatures and return values, but the per-symbol integer CDF is evaluated inside
+    the device coder (no [n_sym, L] float table, no PCIe round trip);
+  * `gaussian_encode_streams` / `gaussian_decode_streams` — the batched form the
+    container driver uses: every 1000-anchor chunk stream of a level/attribute is coded
+    concurrently, one lane per stream;
+  * `encoder` / `decoder`                           — Bernoulli mask stream, :147-180;
+  * `rans_encode_channels` / `rans_decode_channels` — hyper-prior symbols.
+
+There is no CPU fallback for the Gaussian codec: tensors must live on the HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- torchac-compatible host coder ---------------------------------------------------------
+def _cdf_to_u16(cdf_float: torch.Tensor) -> np.ndarray:
+    L = _lib.lib()
+    cdf = np.ascontiguousarray(cdf_float.detach().cpu().numpy(), dtype=np.float32)
+    Lp = cdf.shape[-1]
+    flat = cdf.reshape(-1, Lp)
+    out = np.empty(flat.shape, dtype=np.uint16)
+    _lib.check(L.cgs_cdf_float_to_u16_host(_np_ptr(flat), flat.shape[0], Lp, _np_ptr(out)), "cgs_cdf_float_to_u16_host")
+    return out
+
+
+def encode_float_cdf(cdf_float, sym, needs_normalization=True, check_input_bounds=False) -> bytes:
+    """torchac.encode_float_cdf: cdf_float [..., Lp] in [0,1], sym int16 [...] in [0, Lp-2]."""
+    L = _lib.lib()
+    if not needs_normalization:
+        raise NotImplementedError("only the normalising conversion the reference uses is implemented")
+    if check_input_bounds:
+        if cdf_float.min() < 0:
+            raise ValueError(f"cdf_float.min() == {cdf_float.min()}, should be >=0.!")
+        if cdf_float.max() > 1:
+            raise ValueError(f"cdf_float.max() == {cdf_float.max()}, should be <=1.!")
+        if sym.max() >= cdf_float.shape[-1] - 1:
+            raise ValueError("symbol out of range for the given CDF")
+    cdf = _cdf_to_u16(cdf_float)
+    s = np.ascontiguousarray(sym.detach().cpu().numpy().reshape(-1), dtype=np.int16)
+    assert s.shape[0] == cdf.shape[0], "one CDF row per symbol"
+    cap = L.cgs_ac_max_bytes(s.shape[0])
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _lib.check(L.cgs_ac_encode_table_host(_np_ptr(cdf), cdf.shape[1], _np_ptr(s), s.shape[0], _np_ptr(out), cap,
+                                          C.byref(n)), "cgs_ac_encode_table_host")
+    return out[: n.value].tobytes()
+
+
+def decode_float_cdf(cdf_float, byte_stream: bytes, needs_normalization=True) -> torch.Tensor:
+    """torchac.decode_float_cdf -> int16 symbols shaped like cdf_float[..., 0]."""
+    L = _lib.lib()
+    cdf = _cdf_to_u16(cdf_float)
+    buf = np.frombuffer(byte_stream, dtype=np.uint8)
+    out = np.empty(cdf.shape[0], dtype=np.int16)
+    _lib.check(L.cgs_ac_decode_table_host(_np_ptr(cdf), cdf.shape[1], cdf.shape[0], _np_ptr(buf) if buf.size else None,
+                                          buf.size, _np_ptr(out)), "cgs_ac_decode_table_host")
+    return torch.from_numpy(out).reshape(cdf_float.shape[:-1])
+
+
+# ---- Bernoulli mask stream (utils/encodings.py:147-180) ---------------------------------------
+def _bernoulli_row(p: float) -> np.ndarray:
+    row = np.array([[0.0, 1.0 - p, 1.0]], dtype=np.float32)
+    out = np.empty((1, 3), dtype=np.uint16)
+    _lib.check(_lib.lib().cgs_cdf_float_to_u16_host(_np_ptr(row), 1, 3, _np_ptr(out)), "cgs_cdf_float_to_u16_host")
+    return out[0]
+
+
+def encoder(x, p, file_name):
+    """x in {-1,+1}, p = P(+1) per element (the reference passes one global value).  Returns bit length."""
+    L = _lib.lib()
+    assert file_name[-2:] == ".b"
+    p = p.detach().reshape(-1)
+    p0 = float(p[0].item()) if p.numel() else 0.5
+    row = _bernoulli_row(np.float32(p0))
+    sym = torch.floor((x.detach().reshape(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+    cap = L.cgs_ac_max_bytes(sym.shape[0])
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    _lib.check(L.cgs_ac_encode_const_host(_np_ptr(row), 3, _np_ptr(sym), sym.shape[0], _np_ptr(out), cap, C.byref(n)),
+               "cgs_ac_encode_const_host")
+    with open(file_name, "wb") as f:
+        f.write(out[: n.value].tobytes())
+    return n.value * 8
+
+
+def decoder(p, file_name):
+    L = _lib.lib()
+    assert file_name[-2:] == ".b"
+    dvc = p.device
+    pf = p.detach().reshape(-1)
+    row = _bernoulli_row(np.float32(float(pf[0].item()) if pf.numel() else 0.5))
+    with open(file_name, "rb") as f:
+        buf = np.frombuffer(f.read(), dtype=np.uint8)
+    out = np.empty(pf.numel(), dtype=np.int16)
+    _lib.check(L.cgs_ac_decode_const_host(_np_ptr(row), 3, out.shape[0], _np_ptr(buf) if buf.size else None, buf.size,
+                                          _np_ptr(out)), "cgs_ac_decode_const_host")
+    return (torch.from_numpy(out).to(torch.float32) * 2 - 1).to(dvc)
+
+
+# ---- batched device Gaussian codec ---------------------------------------------------------------
+def _f(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def gaussian_encode_streams(x, mean, scale, Q, stream_off, q_div=1):
+    """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
+    (device or host).  Returns (list of S byte strings, min int32[S] host, max int32[S] host)."""
+    L = _lib.lib()
+    _lib.require_device(x, mean, scale, Q)
+    x, mean, scale, Q = _f(x).reshape(-1), _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
+    dev = x.device
+    off = torch.as_tensor(stream_off, dtype=torch.int64)
+    S = int(off.numel()) - 1
+    if S <= 0:
+        return [], np.zeros(0, np.int32), np.zeros(0, np.int32)
+    off_h = off.cpu()
+    off_d = off_h.to(dev)
+    stream = _lib.current_stream()
+    mn = torch.empty(S, dtype=torch.int32, device=dev)
+    mx = torch.empty(S, dtype=torch.int32, device=dev)
+    _lib.check(L.cgs_gaussian_stream_minmax(_lib.ptr(x), _lib.ptr(Q), q_div, _lib.ptr(off_d), S, _lib.ptr(mn),
+                                            _lib.ptr(mx), stream), "cgs_gaussian_stream_minmax")
+    lens_sym = (off_h[1:] - off_h[:-1])
+    caps = (lens_sym * 2 + 16 + 7) // 8 * 8
+    out_off_h = torch.zeros(S + 1, dtype=torch.int64)
+    out_off_h[1:] = torch.cumsum(caps, 0)
+    out = torch.empty(int(out_off_h[-1]), dtype=torch.uint8, device=dev)
+    out_off = out_off_h.to(dev)
+    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.cgs_gaussian_ac_encode(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div,
+                                        _lib.ptr(off_d), S, _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(out), _lib.ptr(out_off),
+                                        _lib.ptr(out_len), _lib.ptr(status), stream), "cgs_gaussian_ac_encode")
+    st = int(status.item())
+    if st != 0:
+        raise RuntimeError("gaussian codec: " + ("symbol outside [min,max] / grid wider than 2^16" if st == 1
+                                                 else "stream overflowed its buffer"))
+    lens = out_len.cpu().numpy()
+    buf = out.cpu().numpy()
+    starts = out_off_h.numpy()
+    streams = [buf[starts[s]: starts[s] + lens[s]].tobytes() for s in range(S)]
+    return streams, mn.cpu().numpy(), mx.cpu().numpy()
+
+
+def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q_div=1):
+    """Inverse of gaussian_encode_streams -> flat float32 [n] device tensor of dequantised values."""
+    L = _lib.lib()
+    _lib.require_device(mean, scale, Q)
+    mean, scale, Q = _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
+    dev = mean.device
+    off_h = torch.as_tensor(stream_off, dtype=torch.int64).cpu()
+    S = int(off_h.numel()) - 1
+    x_out = torch.empty(mean.numel(), dtype=torch.float32, device=dev)
+    if S <= 0:
+        return x_out
+    assert len(streams) == S
+    in_off_h = np.zeros(S + 1, dtype=np.int64)
+    in_off_h[1:] = np.cumsum([len(b) for b in streams])
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    in_d = torch.from_numpy(blob.copy() if blob.size else np.zeros(1, np.uint8)).to(dev)
+    in_off = torch.from_numpy(in_off_h).to(dev)
+    mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
+    mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
+    off_d = off_h.to(dev)
+    _lib.check(L.cgs_gaussian_ac_decode(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
+                                        _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
+                                        _lib.current_stream()), "cgs_gaussian_ac_decode")
+    return x_out
+
+
+def gaussian_cdf_table(mean, scale, Q, min_v, max_v, q_div=1):
+    """uint16 [n, max-min+2] integer CDF table of one stream (test hook)."""
+    L = _lib.lib()
+    mean, scale, Q = _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
+    n, Lp = mean.numel(), int(max_v) - int(min_v) + 2
+    table = torch.empty(n, Lp, dtype=torch.int16, device=mean.device)
+    _lib.check(L.cgs_gaussian_cdf_table(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, n, int(min_v), int(max_v),
+                                        _lib.ptr(table), _lib.current_stream()), "cgs_gaussian_cdf_table")
+    return table.cpu().numpy().view(np.uint16)
+
+
+# ---- the reference's single-stream signatures (utils/encodings.py:83-144) -----------------------------
+def encoder_gaussian(x, mean, scale, Q, file_name=None):
+    if file_name is not None:
+        assert file_name.endswith(".b")
+    if not isinstance(Q, torch.Tensor):
+        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
+    assert x.shape == mean.shape == scale.shape == Q.shape
+    n = x.numel()
+    streams, mn, mx = gaussian_encode_streams(x, mean, scale, Q, [0, n])
+    byte_stream = streams[0]
+    if file_name is not None:
+        with open(file_name, "wb") as f:
+            f.write(byte_stream)
+    dev = x.device
+    return (byte_stream, len(byte_stream) * 8, torch.tensor(float(mn[0]), device=dev), torch.tensor(float(mx[0]), device=dev))
+
+
+def decoder_gaussian(mean, scale, Q, file_name=None, min_value=-100, max_value=100, bstream=None):
+    if file_name is not None:
+        assert file_name.endswith(".b")
+        with open(file_name, "rb") as f:
+            bstream = f.read()
+    else:
+        assert bstream is not None
+    if not isinstance(Q, torch.Tensor):
+        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
+    assert mean.shape == scale.shape == Q.shape
+    mn = int(min_value.item()) if isinstance(min_value, torch.Tensor) else int(min_value)
+    mx = int(max_value.item()) if isinstance(max_value, torch.Tensor) else int(max_value)
+    return gaussian_decode_streams(mean, scale, Q, [0, mean.numel()], [mn], [mx], [bstream]).reshape(mean.shape)
+
+
+# ---- hyper-prior rANS ------------------------------------------------------------------------------------
+def rans_encode_channels(symbols: np.ndarray, cdf: np.ndarray, cdf_len: np.ndarray, offset: np.ndarray,
+                         precision: int = 16) -> bytes:
+    """symbols int32 [C, n]; cdf int32 [C, max_len]; returns one byte string."""
+    L = _lib.lib()
+    sym = np.ascontiguousarray(symbols, dtype=np.int32)
+    cdf = np.ascontiguousarray(cdf, dtype=np.int32)
+    cl = np.ascontiguousarray(cdf_len, dtype=np.int32)
+    of = np.ascontiguousarray(offset, dtype=np.int32)
+    Cn, n = sym.shape
+    cap = L.cgs_rans_max_bytes(Cn * n)
+    out = np.empty(cap, dtype=np.uint8)
+    ln = C.c_size_t(0)
+    _lib.check(L.cgs_rans_encode_host(_np_ptr(sym), Cn, n, _np_ptr(cdf), cdf.shape[1], _np_ptr(cl), _np_ptr(of),
+                                      precision, _np_ptr(out), cap, C.byref(ln)), "cgs_rans_encode_host")
+    return out[: ln.value].tobytes()
+
+
+def rans_decode_channels(data: bytes, channels: int, n: int, cdf: np.ndarray, cdf_len: np.ndarray, offset: np.ndarray,
+                         precision: int = 16) -> np.ndarray:
+    L = _lib.lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    cdf = np.ascontiguousarray(cdf, dtype=np.int32)
+    cl = np.ascontiguousarray(cdf_len, dtype=np.int32)
+    of = np.ascontiguousarray(offset, dtype=np.int32)
+    out = np.empty((channels, n), dtype=np.int32)
+    _lib.check(L.cgs_rans_decode_host(_np_ptr(buf), buf.size, channels, n, _np_ptr(cdf), cdf.shape[1], _np_ptr(cl),
+                                      _np_ptr(of), precision, _np_ptr(out)), "cgs_rans_decode_host")
+    return out

@@ -1,0 +1,305 @@
+"""Bitstream container: `conduct_encoding`, `conduct_decoding`, `estimate_final_bits`,
+`save/load_mlp_checkpoints` (scene/gaussian_model.py:912-951,
+980-1004, 1007-1295, 1299-1539 — cited lines are that file).
+
+Same container as the reference — anchor.npy (uint16 [N_valid,3]), hyper.b,
+feat{l}.b / scaling{l}.b / offsets{l}.b (1000-anchor chunk streams concatenated,
+byte lengths in meta), masks.b, meta.b (a torch.save'd 14-item list, :1277), mlp.pt —
+and the same level / chunk / mask order.  What differs is how a level is coded: instead
+of a Python loop of ~3 N/1000 serial torchac calls, each shipping a [50 000, L] float
+table over PCIe (:1192-1232), all chunk streams of a level+attribute are coded by ONE
+device launch, one lane per stream (codec.gaussian_encode_streams).
+
+Deliberate deviation: the reference's decoder raises IndexError when fewer
+than 10 000 anchors are valid (:1322-1331); this one decodes any size.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import codec
+from .context_model import (extract_context_feat, find_divide_scale, level_plan, multi_scale_generating,
+                            split_prediction)
+from .encodings import Q_anchor, Quantize_anchor, STE_multistep, decoder, encoder
+
+bit2MB_scale = 8 * 1024 * 1024
+MAX_BATCH = 1_000                                              # :1071
+
+
+def save_mlp_checkpoints(pc, path):                            # :912-936
+    pc.latent_codec.update()
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save({"opacity_mlp": pc.mlp_opacity.state_dict(), "cov_mlp": pc.mlp_cov.state_dict(),
+                "color_mlp": pc.mlp_color.state_dict(), "latent_codec": pc.latent_codec.state_dict(),
+                "grid_mlp": pc.mlp_grid.state_dict(), "bound": [pc.x_bound_min, pc.x_bound_max],
+                "level_scale": pc.level_scale}, path)
+
+
+def load_mlp_checkpoints(pc, path):                            # :939-950
+    ck = torch.load(path, weights_only=False)
+    pc.mlp_opacity.load_state_dict(ck["opacity_mlp"])
+    pc.mlp_cov.load_state_dict(ck["cov_mlp"])
+    pc.mlp_color.load_state_dict(ck["color_mlp"])
+    pc.latent_codec.update()
+    pc.latent_codec.load_state_dict(ck["latent_codec"], strict=False)
+    pc.mlp_grid.load_state_dict(ck["grid_mlp"])
+    pc.x_bound_min, pc.x_bound_max = ck["bound"]
+    pc.level_scale = ck["level_scale"]
+
+
+@torch.no_grad()
+def estimate_final_bits(pc):                                   # :980-1004
+    m = pc.get_mask_anchor
+    sums = multi_scale_generating(pc, pc.get_anchor[m], pc._hyper_latent[m], pc._anchor_feat[m], pc._offset[m],
+                                  pc.get_scaling[m], binary_grid_masks=pc.get_mask[m], predict_bpp=True,
+                                  return_sum_bits=True)
+    a, h, f, s, o, mk = sums
+    mlp = pc.get_mlp_size()[0]
+    r = lambda v: round(v / bit2MB_scale, 4)
+    return (f"\nEstimated sizes in MB: anchor {r(a)}, feat {r(f)}, scaling {r(s)}, offsets {r(o)}, hyper {r(h)}, "
+            f"masks {r(mk)}, MLPs {r(mlp)}, Total {r(a + f + s + o + h + mk + mlp)}")
+
+
+def _chunk_rows(n):
+    edges = list(range(0, n, MAX_BATCH)) + [n]
+    return edges if n > 0 else [0]
+
+
+def _predict(pc, level, feat_in):
+    (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
+        split_prediction(pc, pc.get_grid_mlp[level](feat_in))
+    c = lambda t: torch.clamp(t, min=1e-9).contiguous()
+    return (mean_feat.contiguous(), c(scale_feat), mean_scaling.contiguous(), c(scale_scaling),
+            mean_offsets.contiguous(), c(scale_offsets), Qf.reshape(-1).contiguous(), Qs.reshape(-1).contiguous(),
+            Qo.reshape(-1).contiguous())
+
+
+@torch.no_grad()
+def conduct_encoding(pc, pre_path_name):                       # :1007-1295
+    torch.cuda.synchronize(); t1 = time.time()
+    print("Start encoding ...")
+    t_codec = 0.0
+    os.makedirs(pre_path_name, exist_ok=True)
+    pc.latent_codec.update(force=True)
+    K, D = pc.n_offsets, pc.feat_dim
+
+    mask_anchor = pc.get_mask_anchor
+    _anchor, quantized_anchor = Quantize_anchor.apply(pc._anchor[mask_anchor], pc.x_bound_min, pc.x_bound_max)
+    _feat = pc._anchor_feat[mask_anchor]
+    _grid_offsets = pc._offset[mask_anchor]
+    _scaling = pc.get_scaling[mask_anchor]
+    _mask = pc.get_mask[mask_anchor]
+    _hyper_latent = pc._hyper_latent[mask_anchor]
+    # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
+    hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
+    if pc.level_scale is None:
+        pc.level_scale = find_divide_scale(pc, _anchor, pc.target_ratio, pc.level_num)
+    plan, inverse_indices_list, mapping_list = level_plan(pc, _anchor, None)
+
+    feat_after_Q = torch.zeros_like(_feat)
+    grid_scaling_after_Q = torch.zeros_like(_scaling)
+    already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
+
+    # hyper: 10 000-anchor rANS chunks (:1082-1098)
+    N_anchor = _anchor.shape[0]
+    hyper_bytes, bit_hyper_list = [], []
+    for s0 in range(0, N_anchor, MAX_BATCH * 10):
+        b = pc.latent_codec.compress(_hyper_latent[s0:s0 + MAX_BATCH * 10].t().unsqueeze(0))[0]
+        hyper_bytes.append(b)
+        bit_hyper_list.append(len(b) * 8)
+    np.save(os.path.join(pre_path_name, "anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))   # :1100-1101
+    with open(os.path.join(pre_path_name, "hyper.b"), "wb") as f:
+        f.write(b"".join(hyper_bytes))
+
+    bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    min_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    max_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    N_levels_list = []
+    content_pre_gathered = None
+
+    for (level, to_code, orig, hybrid_anchor) in plan:                                   # :1112
+        n_l = int(orig.shape[0])
+        N_levels_list.append(n_l)
+        if content_pre_gathered is None:
+            feat_in = torch.cat([hybrid_anchor, hyper_feat[orig].float()], dim=1)
+        else:
+            feat_in = torch.cat([content_pre_gathered, hyper_feat[orig].float()], dim=1)
+        (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
+            _predict(pc, level, feat_in)
+        rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
+
+        feat_q = STE_multistep.apply(_feat[orig], Qf.unsqueeze(1))
+        scal_q = STE_multistep.apply(_scaling[orig], Qs.unsqueeze(1))
+        off_q = STE_multistep.apply(_grid_offsets[orig].reshape(n_l, 3 * K), Qo.unsqueeze(1))
+        m30 = _mask[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)              # :1222-1223
+        cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=m30.device)
+        cnt[1:] = torch.cumsum(m30.sum(1), 0)
+        off_edges = cnt[rows.to(cnt.device)].cpu()
+        mflat = m30.reshape(-1)
+        Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
+
+        torch.cuda.synchronize(); t0 = time.time()
+        s_feat, mn_f, mx_f = codec.gaussian_encode_streams(feat_q, mean_feat, scale_feat, Qf, rows * D, q_div=D)
+        s_scal, mn_s, mx_s = codec.gaussian_encode_streams(scal_q, mean_scaling, scale_scaling, Qs, rows * 6, q_div=6)
+        s_off, mn_o, mx_o = codec.gaussian_encode_streams(off_q.reshape(-1)[mflat], mean_offsets.reshape(-1)[mflat],
+                                                          scale_offsets.reshape(-1)[mflat], Qo30[mflat], off_edges)
+        torch.cuda.synchronize(); t_codec += time.time() - t0
+
+        for name, streams, mn, mx in (("feat", s_feat, mn_f, mx_f), ("scaling", s_scal, mn_s, mx_s),
+                                      ("offsets", s_off, mn_o, mx_o)):
+            with open(os.path.join(pre_path_name, f"{name}{level}.b"), "wb") as f:      # :1235-1238
+                f.write(b"".join(streams))
+            bit_d[name][level] = [len(b) * 8 for b in streams]
+            min_d[name][level] = [int(v) for v in mn]
+            max_d[name][level] = [int(v) for v in mx]
+
+        feat_after_Q[orig] = feat_q                                                      # :1240-1242
+        grid_scaling_after_Q[orig] = scal_q
+        already_coded[orig] = True
+        if level != 0:
+            content_pre_gathered = extract_context_feat(_anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
+                                                        inverse_indices_list, mapping_list, level)
+
+    bit_anchor = _anchor.numel() * 16
+    bit_hyper = sum(bit_hyper_list)
+    bit_feat = sum(sum(v) for v in bit_d["feat"].values())
+    bit_scaling = sum(sum(v) for v in bit_d["scaling"].values())
+    bit_offsets = sum(sum(v) for v in bit_d["offsets"].values())
+
+    prob_masks = (_mask.sum() / _mask.numel()).item()                                     # :1265-1269
+    p = torch.full_like(_mask, prob_masks, dtype=torch.float32)
+    bit_masks = encoder((_mask * 2 - 1).view(-1), p.view(-1), file_name=os.path.join(pre_path_name, "masks.b"))
+
+    torch.cuda.synchronize(); t2 = time.time()
+    print("encoding time:", t2 - t1)
+    print("codec time:", t_codec)
+
+    meta_path = os.path.join(pre_path_name, "meta.b")                                     # :1276-1277
+    torch.save([pc._anchor.shape[0], MAX_BATCH, min_d["feat"], max_d["feat"], min_d["scaling"], max_d["scaling"],
+                min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
+                bit_d["offsets"], N_levels_list], meta_path)
+    save_mlp_checkpoints(pc, os.path.join(pre_path_name, "mlp.pt"))
+    bit_meta = os.path.getsize(meta_path) * 8
+    mlp = pc.get_mlp_size()[0]
+    r = lambda v: round(v / bit2MB_scale, 4)
+    return (f"\nEncoded sizes in MB: meta {r(bit_meta)}, hyper {r(bit_hyper)}, anchor {r(bit_anchor)}, "
+            f"feat {r(bit_feat)}, scaling {r(bit_scaling)}, offsets {r(bit_offsets)}, masks {r(bit_masks)}, "
+            f"MLPs {r(mlp)}, Total {r(bit_meta + bit_hyper + bit_anchor + bit_feat + bit_scaling + bit_offsets + bit_masks + mlp)}, "
+            f"EncTime {round(t2 - t1, 4)}")
+
+
+@torch.no_grad()
+def conduct_decoding(pc, pre_path_name):                       # :1299-1539
+    torch.cuda.synchronize(); t1 = time.time()
+    print("Start decoding ...")
+    (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
+     bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(
+        os.path.join(pre_path_name, "meta.b"), weights_only=False)
+    load_mlp_checkpoints(pc, os.path.join(pre_path_name, "mlp.pt"))
+    pc.latent_codec.update(force=True)
+    dev = pc.x_bound_min.device
+    K, D, H = pc.n_offsets, pc.feat_dim, pc.feat_dim // pc.hyper_divisor
+    N_levels_list = list(reversed(N_levels_list))
+    N_valid = sum(N_levels_list)
+
+    with open(os.path.join(pre_path_name, "hyper.b"), "rb") as f:
+        hyper_stream = f.read()
+    pos, parts = 0, []
+    for s, s0 in enumerate(range(0, N_valid, max_batch * 10)):                           # :1326-1336 (any N_valid, Q2)
+        n = min(max_batch * 10, N_valid - s0)
+        nb = bit_hyper_list[s] // 8
+        parts.append(pc.latent_codec.decompress([hyper_stream[pos:pos + nb]], [n])[0].t())
+        pos += nb
+    hyper_decoded = torch.cat(parts, dim=0) if parts else torch.zeros(0, H, device=dev)
+
+    q = torch.from_numpy(np.load(os.path.join(pre_path_name, "anchor.npy")).astype(np.int32)).to(dev)   # :1340-1342
+    interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
+    anchor_decoded = q * interval + pc.x_bound_min
+
+    if pc.level_scale is None:
+        pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
+    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
+
+    p = torch.full((N_valid, K, 1), float(prob_masks), dtype=torch.float32, device=dev)   # :1348-1353
+    masks_decoded = (decoder(p.view(-1), os.path.join(pre_path_name, "masks.b")) + 1) / 2
+    masks_decoded = masks_decoded.view(-1, K, 1)
+
+    feat_after_Q = torch.zeros(N_valid, D, device=dev)
+    grid_scaling_after_Q = torch.zeros(N_valid, 6, device=dev)
+    grid_offset_after_Q = torch.zeros(N_valid, K, 3, device=dev)
+    already_coded = torch.zeros(N_valid, dtype=torch.bool, device=dev)
+    content_pre_gathered = None
+
+    def split_stream(blob, bit_list):
+        out, pos_ = [], 0
+        for b in bit_list:
+            out.append(blob[pos_:pos_ + b // 8])
+            pos_ += b // 8
+        assert pos_ == len(blob)                                                          # :1479-1481
+        return out
+
+    for (level, to_code, orig, hybrid_anchor) in plan:
+        n_l = int(orig.shape[0])
+        assert n_l == N_levels_list[level]
+        blobs = {}
+        for name in ("feat", "scaling", "offsets"):
+            with open(os.path.join(pre_path_name, f"{name}{level}.b"), "rb") as f:
+                blobs[name] = f.read()
+        if content_pre_gathered is None:
+            feat_in = torch.cat([anchor_decoded[orig], hyper_decoded[orig].float()], dim=1)
+        else:
+            feat_in = torch.cat([content_pre_gathered, hyper_decoded[orig]], dim=1)
+        (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
+            _predict(pc, level, feat_in)
+        rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
+        feat_dec = codec.gaussian_decode_streams(mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
+                                                 split_stream(blobs["feat"], bit_feat_d[level]), q_div=D).view(n_l, D)
+        scal_dec = codec.gaussian_decode_streams(mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level],
+                                                 max_scaling_d[level], split_stream(blobs["scaling"], bit_scaling_d[level]),
+                                                 q_div=6).view(n_l, 6)
+        m30 = masks_decoded[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)
+        cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=dev)
+        cnt[1:] = torch.cumsum(m30.sum(1), 0)
+        off_edges = cnt[rows.to(dev)].cpu()
+        mflat = m30.reshape(-1)
+        Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
+        off_vals = codec.gaussian_decode_streams(mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat],
+                                                 Qo30[mflat], off_edges, min_offsets_d[level], max_offsets_d[level],
+                                                 split_stream(blobs["offsets"], bit_offsets_d[level]))
+        off_dec = torch.zeros(n_l * 3 * K, device=dev)
+        off_dec[mflat] = off_vals
+
+        feat_after_Q[orig] = feat_dec
+        grid_scaling_after_Q[orig] = scal_dec
+        grid_offset_after_Q[orig] = off_dec.view(n_l, K, 3)
+        if level != 0:
+            already_coded[orig] = True
+            content_pre_gathered = extract_context_feat(anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
+                                                        inverse_indices_list, mapping_list, level)
+    torch.cuda.synchronize(); t2 = time.time()
+    print("decoding time:", t2 - t1)
+
+    z = lambda *s: torch.zeros(*s, device=dev)                                            # :1503-1533
+    _hyper, _anchor, _feat = z(N_full, H), z(N_full, 3), z(N_full, D)
+    _offset, _scaling, _mask = z(N_full, K, 3), z(N_full, 6), z(N_full, K, 1)
+    _anchor[:N_valid] = anchor_decoded
+    _hyper[:N_valid] = hyper_decoded
+    _feat[:N_valid] = feat_after_Q
+    _offset[:N_valid] = grid_offset_after_Q
+    _scaling[:N_valid] = grid_scaling_after_Q
+    _mask[:N_valid] = masks_decoded
+    pc._hyper_latent = nn.Parameter(_hyper)
+    pc._anchor_feat = nn.Parameter(_feat)
+    pc._offset = nn.Parameter(_offset)
+    pc.decoded_version = True
+    pc._anchor = nn.Parameter(_anchor)
+    pc._scaling = nn.Parameter(_scaling)
+    pc._mask = nn.Parameter(_mask)
+    if hasattr(pc, "_level_cache"):
+        pc._level_cache = None
+    return f"\nDecTime {round(t2 - t1, 4)}"

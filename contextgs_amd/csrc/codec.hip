@@ -1,0 +1,535 @@
+// Entropy coding for the bitstream container.
+//
+// 1. A 32-bit binary arithmetic coder over 16-bit integer CDFs: the algorithm of
+//    the `torchac` wheel the reference calls (utils/encodings.py:108,138,157,178;
+//    NOT in the mount, unpinned — restated from its public description, SURVEY
+//    Appendix B): low/high registers, underflow ("pending") bits, MSB-first bit
+//    packing, the top symbol's upper bound fixed at 2^16, one trailing
+//    disambiguation bit.  The core is a __host__ __device__ template used by
+//      * the table-driven host coder (torchac drop-in; Bernoulli mask stream), and
+//      * the batched GPU Gaussian codec below.
+// 2. The Gaussian codec of encoder_gaussian / decoder_gaussian
+//    (utils/encodings.py:83-144) WITHOUT the [n_sym, L] float table: one lane per
+//    1000-anchor chunk stream; the lane evaluates the integer CDF of exactly the
+//    entries it needs (2 per symbol when encoding, ~log2(L) when decoding) with the
+//    same device erff on both sides, so encode -> decode is bit-exact by
+//    construction and nothing crosses PCIe but the bitstream.  All chunk streams of
+//    a level/attribute run concurrently.
+// 3. A range-ANS coder for the hyper-prior symbols (EntropyBottleneck.compress /
+//    decompress; compressai is NOT in the mount): per-channel frequency tables,
+//    escape symbol + Elias-gamma style bypass for out-of-support values.
+#include <vector>
+#include "cgs_internal.h"
+
+#define AC_PRECISION 16
+#define AC_TOP 0x10000u
+
+// ---------------------------------------------------------------------------------
+// bit I/O
+// ---------------------------------------------------------------------------------
+struct BitWriter {
+    uint8_t *p;
+    uint8_t *end;
+    uint32_t cache;
+    int count;
+    bool overflow;
+    __host__ __device__ void init(uint8_t *buf, size_t cap) { p = buf; end = buf + cap; cache = 0; count = 0; overflow = false; }
+    __host__ __device__ void put(int bit) {
+        cache = (cache << 1) | (uint32_t)bit;
+        if (++count == 8) {
+            if (p < end) *p++ = (uint8_t)cache; else overflow = true;
+            count = 0;
+            cache = 0;
+        }
+    }
+    __host__ __device__ void put_with_pending(int bit, uint64_t &pending) {
+        put(bit);
+        while (pending > 0) { put(!bit); --pending; }
+    }
+    __host__ __device__ void flush() { while (count != 0) put(0); }
+};
+
+struct BitReader {
+    const uint8_t *buf;
+    uint64_t nbits;
+    uint64_t pos;
+    __host__ __device__ void init(const uint8_t *b, size_t len) { buf = b; nbits = (uint64_t)len * 8; pos = 0; }
+    // shifts one bit into value, MSB first (zeros past the end of the stream)
+    __host__ __device__ void get(uint32_t &value) {
+        uint32_t bit = 0;
+        if (pos < nbits) bit = ((uint32_t)buf[pos >> 3] >> (7u - (uint32_t)(pos & 7u))) & 1u;
+        ++pos;
+        value = (value << 1) | bit;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// arithmetic coder core
+// ---------------------------------------------------------------------------------
+struct AcEncoder {
+    uint32_t low, high;
+    uint64_t pending;
+    BitWriter out;
+    __host__ __device__ void init(uint8_t *buf, size_t cap) { low = 0; high = 0xFFFFFFFFu; pending = 0; out.init(buf, cap); }
+    __host__ __device__ void encode(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        for (;;) {
+            if (high < 0x80000000u) {
+                out.put_with_pending(0, pending);
+                low <<= 1; high = (high << 1) | 1u;
+            } else if (low >= 0x80000000u) {
+                out.put_with_pending(1, pending);
+                low <<= 1; high = (high << 1) | 1u;
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                ++pending;
+                low = (low << 1) & 0x7FFFFFFFu;
+                high = (high << 1) | 0x80000001u;
+            } else {
+                break;
+            }
+        }
+    }
+    __host__ __device__ size_t finish(uint8_t *base) {
+        ++pending;
+        out.put_with_pending(low < 0x40000000u ? 0 : 1, pending);
+        out.flush();
+        return (size_t)(out.p - base);
+    }
+};
+
+struct AcDecoder {
+    uint32_t low, high, value;
+    BitReader in;
+    __host__ __device__ void init(const uint8_t *buf, size_t len) {
+        low = 0; high = 0xFFFFFFFFu; value = 0;
+        in.init(buf, len);
+        for (int i = 0; i < 32; ++i) in.get(value);
+    }
+    __host__ __device__ uint32_t target() const {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        return (uint32_t)((((uint64_t)value - (uint64_t)low + 1) * (uint64_t)AC_TOP - 1) / span) & 0xFFFFu;
+    }
+    __host__ __device__ void consume(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        for (;;) {
+            if (low >= 0x80000000u || high < 0x80000000u) {
+                low <<= 1; high = (high << 1) | 1u;
+                in.get(value);
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                low = (low << 1) & 0x7FFFFFFFu;
+                high = (high << 1) | 0x80000001u;
+                value -= 0x40000000u;
+                in.get(value);
+            } else {
+                break;
+            }
+        }
+    }
+};
+
+// Largest m in [0, max_sym] with cdf(m) <= target (cdf strictly increasing).
+template <typename CdfFn>
+__host__ __device__ inline int ac_search(CdfFn cdf, uint32_t target, int max_sym) {
+    int left = 0, right = max_sym + 1;
+    while (left + 1 < right) {
+        const int m = (left + right) >> 1;
+        const uint32_t v = cdf(m);
+        if (v < target) left = m;
+        else if (v > target) right = m;
+        else return m;
+    }
+    return left;
+}
+
+// ---------------------------------------------------------------------------------
+// host, table driven (torchac drop-in)
+// ---------------------------------------------------------------------------------
+extern "C" size_t cgs_ac_max_bytes(int64_t n_sym) { return (size_t)(n_sym > 0 ? n_sym : 0) * 2 + 16; }
+
+// cdf_float [n_sym, Lp] -> uint16 [n_sym, Lp]: round(c * (2^16 - (Lp-1))) + j, wrapped to 16 bits
+// (the published conversion; strictly increasing for any non-decreasing input row).
+extern "C" int cgs_cdf_float_to_u16_host(const float *cdf, int64_t n_sym, int Lp, uint16_t *out) {
+    if (!cdf || !out || Lp < 2 || n_sym < 0) { cgs_set_error("cdf_float_to_u16: bad args"); return CGS_ERR_ARG; }
+    const float scale = (float)(65536 - (Lp - 1));
+    for (int64_t i = 0; i < n_sym; ++i)
+        for (int j = 0; j < Lp; ++j) {
+            const float v = nearbyintf(cdf[i * Lp + j] * scale);
+            out[i * Lp + j] = (uint16_t)((int32_t)v + j);
+        }
+    return CGS_OK;
+}
+
+extern "C" int cgs_ac_encode_table_host(const uint16_t *cdf, int Lp, const int16_t *sym, int64_t n_sym,
+                                        uint8_t *out, size_t out_cap, size_t *out_len) {
+    if (!cdf || !sym || !out || !out_len || Lp < 2 || n_sym < 0) { cgs_set_error("ac_encode_table: bad args"); return CGS_ERR_ARG; }
+    AcEncoder enc;
+    enc.init(out, out_cap);
+    const int max_sym = Lp - 2;
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const int s = sym[i];
+        if (s < 0 || s > max_sym) { cgs_set_error("ac_encode_table: symbol %d out of [0,%d] at %lld", s, max_sym, (long long)i); return CGS_ERR_BOUNDS; }
+        const uint16_t *row = cdf + i * Lp;
+        enc.encode(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
+    }
+    *out_len = enc.finish(out);
+    if (enc.out.overflow) { cgs_set_error("ac_encode_table: output buffer too small"); return CGS_ERR_WORKSPACE; }
+    return CGS_OK;
+}
+
+extern "C" int cgs_ac_decode_table_host(const uint16_t *cdf, int Lp, int64_t n_sym, const uint8_t *in, size_t in_len,
+                                        int16_t *sym_out) {
+    if (!cdf || !sym_out || (!in && in_len) || Lp < 2 || n_sym < 0) { cgs_set_error("ac_decode_table: bad args"); return CGS_ERR_ARG; }
+    AcDecoder dec;
+    dec.init(in, in_len);
+    const int max_sym = Lp - 2;
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const uint16_t *row = cdf + i * Lp;
+        const int s = ac_search([&](int m) { return (uint32_t)row[m]; }, dec.target(), max_sym);
+        sym_out[i] = (int16_t)s;
+        if (i == n_sym - 1) break;
+        dec.consume(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
+    }
+    return CGS_OK;
+}
+
+// Constant-CDF stream (the Bernoulli mask stream, utils/encodings.py:147-180): every symbol
+// shares one row, so no [n,3] table is materialised.
+extern "C" int cgs_ac_encode_const_host(const uint16_t *row, int Lp, const int16_t *sym, int64_t n_sym, uint8_t *out,
+                                        size_t out_cap, size_t *out_len) {
+    if (!row || !sym || !out || !out_len || Lp < 2) { cgs_set_error("ac_encode_const: bad args"); return CGS_ERR_ARG; }
+    AcEncoder enc;
+    enc.init(out, out_cap);
+    const int max_sym = Lp - 2;
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const int s = sym[i];
+        if (s < 0 || s > max_sym) { cgs_set_error("ac_encode_const: symbol out of range"); return CGS_ERR_BOUNDS; }
+        enc.encode(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
+    }
+    *out_len = enc.finish(out);
+    if (enc.out.overflow) { cgs_set_error("ac_encode_const: output buffer too small"); return CGS_ERR_WORKSPACE; }
+    return CGS_OK;
+}
+
+extern "C" int cgs_ac_decode_const_host(const uint16_t *row, int Lp, int64_t n_sym, const uint8_t *in, size_t in_len,
+                                        int16_t *sym_out) {
+    if (!row || !sym_out || Lp < 2) { cgs_set_error("ac_decode_const: bad args"); return CGS_ERR_ARG; }
+    AcDecoder dec;
+    dec.init(in, in_len);
+    const int max_sym = Lp - 2;
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const int s = ac_search([&](int m) { return (uint32_t)row[m]; }, dec.target(), max_sym);
+        sym_out[i] = (int16_t)s;
+        if (i == n_sym - 1) break;
+        dec.consume(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
+    }
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// GPU Gaussian codec
+// ---------------------------------------------------------------------------------
+#define SQRT2F 1.4142135623730951f
+
+// Integer CDF entry j of a symbol with (mean, scale, Q) over the grid [min_v .. max_v + 1]:
+// the reference's table entry lower[i, j] = Normal(mean, scale).cdf((min_v + j - 0.5) * Q)
+// (utils/encodings.py:91-97) pushed through the float -> int16 conversion above.
+__device__ __forceinline__ uint32_t gaussian_cdf_int(int j, int min_v, float norm, float mean, float inv_scale,
+                                                     float q) {
+    const float sample = ((float)(min_v + j) - 0.5f) * q;
+    const float z = (sample - mean) * inv_scale / SQRT2F;
+    const float c = 0.5f * (1.f + erff(z));
+    return (uint32_t)((int32_t)rintf(c * norm) + j) & 0xFFFFu;
+}
+
+// per-stream min/max of round(x/Q)
+__global__ void __launch_bounds__(256)
+    stream_minmax_kernel(const float *__restrict__ x, const float *__restrict__ Q, int64_t q_div,
+                         const int64_t *__restrict__ stream_off, int n_streams, int32_t *__restrict__ min_out,
+                         int32_t *__restrict__ max_out) {
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    const int64_t b = stream_off[s], e = stream_off[s + 1];
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+        const int v = (int)rintf(x[i] / Q[i / q_div]);
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    __shared__ int slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
+        hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+        if (e <= b) { lo = 0; hi = 0; }
+        min_out[s] = lo;
+        max_out[s] = hi;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+    gaussian_encode_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                           const float *__restrict__ scale, const float *__restrict__ Q, int64_t q_div,
+                           const int64_t *__restrict__ stream_off, int n_streams,
+                           const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
+                           uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
+                           uint32_t *__restrict__ out_len, int32_t *__restrict__ status) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    const int64_t b = stream_off[s], e = stream_off[s + 1];
+    uint8_t *base = out + out_off[s];
+    AcEncoder enc;
+    enc.init(base, (size_t)(out_off[s + 1] - out_off[s]));
+    const int lo = min_v[s];
+    const int Lp = max_v[s] - lo + 2;
+    const int max_sym = Lp - 2;
+    const float norm = (float)(65536 - (Lp - 1));
+    bool bad = Lp > 65536;
+    for (int64_t i = b; i < e && !bad; ++i) {
+        const float q = Q[i / q_div];
+        const int sym = (int)rintf(x[i] / q) - lo;
+        if (sym < 0 || sym > max_sym) { bad = true; break; }
+        const float inv = 1.f / scale[i];
+        const float m = mean[i];
+        const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+        const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+        enc.encode(c_low, c_high);
+    }
+    out_len[s] = (uint32_t)enc.finish(base);
+    if (bad) atomicMax(status, 1);
+    if (enc.out.overflow) atomicMax(status, 2);
+}
+
+__global__ void __launch_bounds__(64)
+    gaussian_decode_kernel(const float *__restrict__ mean, const float *__restrict__ scale,
+                           const float *__restrict__ Q, int64_t q_div, const int64_t *__restrict__ stream_off,
+                           int n_streams, const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
+                           const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off,
+                           float *__restrict__ x_out) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    const int64_t b = stream_off[s], e = stream_off[s + 1];
+    AcDecoder dec;
+    dec.init(in + in_off[s], (size_t)(in_off[s + 1] - in_off[s]));
+    const int lo = min_v[s];
+    const int Lp = max_v[s] - lo + 2;
+    const int max_sym = Lp - 2;
+    const float norm = (float)(65536 - (Lp - 1));
+    for (int64_t i = b; i < e; ++i) {
+        const float q = Q[i / q_div];
+        const float inv = 1.f / scale[i];
+        const float m = mean[i];
+        const int sym = ac_search([&](int j) { return gaussian_cdf_int(j, lo, norm, m, inv, q); }, dec.target(), max_sym);
+        x_out[i] = (float)(sym + lo) * q;
+        if (i == e - 1) break;
+        const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+        const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+        dec.consume(c_low, c_high);
+    }
+}
+
+// test hook: the full integer table of one stream, [n, Lp] uint16 (what the reference ships over PCIe as floats)
+__global__ void __launch_bounds__(256)
+    gaussian_table_kernel(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q,
+                          int64_t q_div, int64_t n, int min_v, int Lp, uint16_t *__restrict__ table) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * Lp) return;
+    const int64_t i = idx / Lp;
+    const int j = (int)(idx % Lp);
+    table[idx] = (uint16_t)gaussian_cdf_int(j, min_v, (float)(65536 - (Lp - 1)), mean[i], 1.f / scale[i], Q[i / q_div]);
+}
+
+// test hook: the decoder core on the device over an explicit table (one lane)
+__global__ void ac_decode_table_kernel(const uint16_t *__restrict__ cdf, int Lp, int64_t n,
+                                       const uint8_t *__restrict__ in, int64_t in_len, int16_t *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    AcDecoder dec;
+    dec.init(in, (size_t)in_len);
+    const int max_sym = Lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t *row = cdf + i * Lp;
+        const int s = ac_search([&](int m) { return (uint32_t)row[m]; }, dec.target(), max_sym);
+        out[i] = (int16_t)s;
+        if (i == n - 1) break;
+        dec.consume(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
+    }
+}
+
+extern "C" int cgs_ac_decode_table_device(const uint16_t *cdf, int Lp, int64_t n, const uint8_t *in, int64_t in_len,
+                                          int16_t *sym_out, void *stream) {
+    if (n <= 0) return CGS_OK;
+    hipLaunchKernelGGL(ac_decode_table_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cdf, Lp, n, in, in_len, sym_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_gaussian_stream_minmax(const float *x, const float *Q, int64_t q_div, const int64_t *stream_off,
+                                          int n_streams, int32_t *min_out, int32_t *max_out, void *stream) {
+    if (n_streams < 0 || q_div < 1) { cgs_set_error("stream_minmax: bad args"); return CGS_ERR_ARG; }
+    if (n_streams == 0) return CGS_OK;
+    hipLaunchKernelGGL(stream_minmax_kernel, dim3(n_streams), dim3(256), 0, (hipStream_t)stream, x, Q, q_div, stream_off,
+                       n_streams, min_out, max_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_gaussian_ac_encode(const float *x, const float *mean, const float *scale, const float *Q,
+                                      int64_t q_div, const int64_t *stream_off, int n_streams, const int32_t *min_v,
+                                      const int32_t *max_v, uint8_t *out, const int64_t *out_off, uint32_t *out_len,
+                                      int32_t *status, void *stream) {
+    if (n_streams < 0 || q_div < 1) { cgs_set_error("gaussian_ac_encode: bad args"); return CGS_ERR_ARG; }
+    if (n_streams == 0) return CGS_OK;
+    hipLaunchKernelGGL(gaussian_encode_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, mean,
+                       scale, Q, q_div, stream_off, n_streams, min_v, max_v, out, out_off, out_len, status);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_gaussian_ac_decode(const float *mean, const float *scale, const float *Q, int64_t q_div,
+                                      const int64_t *stream_off, int n_streams, const int32_t *min_v,
+                                      const int32_t *max_v, const uint8_t *in, const int64_t *in_off, float *x_out,
+                                      void *stream) {
+    if (n_streams < 0 || q_div < 1) { cgs_set_error("gaussian_ac_decode: bad args"); return CGS_ERR_ARG; }
+    if (n_streams == 0) return CGS_OK;
+    hipLaunchKernelGGL(gaussian_decode_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean,
+                       scale, Q, q_div, stream_off, n_streams, min_v, max_v, in, in_off, x_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_gaussian_cdf_table(const float *mean, const float *scale, const float *Q, int64_t q_div, int64_t n,
+                                      int min_v, int max_v, uint16_t *table, void *stream) {
+    const int Lp = max_v - min_v + 2;
+    if (n < 0 || Lp < 2 || q_div < 1) { cgs_set_error("gaussian_cdf_table: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    const int64_t tot = n * Lp;
+    hipLaunchKernelGGL(gaussian_table_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       mean, scale, Q, q_div, n, min_v, Lp, table);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// range-ANS for the hyper-prior symbols (host)
+// ---------------------------------------------------------------------------------
+// 32-bit state, 16-bit renormalisation words, frequency precision `prec` (16).
+// Symbols are coded in REVERSE so that the decoder reads them forward.  Channel c's
+// table cdf[c] has cdf_len[c] entries; index value = symbol - offset[c]; the last
+// table slot (cdf_len-2) is the escape: out-of-support values are sent as escape
+// followed by (sign, Elias-gamma(magnitude)) in 1-bit uniform rANS steps.
+#define RANS_L (1u << 16)
+
+struct RansEnc {
+    uint32_t x;
+    std::vector<uint16_t> words;   // emitted in reverse order
+    RansEnc() : x(RANS_L) {}
+    void put(uint32_t start, uint32_t freq, int prec) {
+        const uint32_t x_max = ((RANS_L >> prec) << 16) * freq;
+        while (x >= x_max) { words.push_back((uint16_t)(x & 0xFFFFu)); x >>= 16; }
+        x = ((x / freq) << prec) + (x % freq) + start;
+    }
+    void put_bits(uint32_t v, int nbits) { for (int i = 0; i < nbits; ++i) put((v >> i) & 1u, 1, 1); }   // LSB first pushed => MSB first popped? see decoder
+};
+
+struct RansDec {
+    uint32_t x;
+    const uint16_t *p, *end;
+    void init(const uint8_t *buf, size_t len) {
+        p = (const uint16_t *)(buf + 4);
+        end = (const uint16_t *)(buf + (len & ~(size_t)1));
+        x = (uint32_t)buf[0] | ((uint32_t)buf[1] << 8) | ((uint32_t)buf[2] << 16) | ((uint32_t)buf[3] << 24);
+    }
+    uint32_t peek(int prec) const { return x & ((1u << prec) - 1u); }
+    void advance(uint32_t start, uint32_t freq, int prec) {
+        x = freq * (x >> prec) + (x & ((1u << prec) - 1u)) - start;
+        while (x < RANS_L && p < end) { x = (x << 16) | *p++; }
+    }
+    uint32_t get_bit() { const uint32_t b = peek(1); advance(b, 1, 1); return b; }
+};
+
+// Escape payload: sign bit, then n = bit-length of m (unary: n-1 zeros then a one), then the n-1 low bits of m,
+// where m = out-of-support distance + 1 >= 1.
+static void esc_bits(int value, int max_value, std::vector<int> &bits) {
+    uint32_t m;
+    int sign;
+    if (value < 0) { sign = 1; m = (uint32_t)(-value); } else { sign = 0; m = (uint32_t)(value - max_value + 1); }
+    bits.push_back(sign);
+    int n = 0;
+    while ((m >> n) > 1) ++n;            // n = floor(log2 m)
+    for (int i = 0; i < n; ++i) bits.push_back(0);
+    bits.push_back(1);
+    for (int i = n - 1; i >= 0; --i) bits.push_back((m >> i) & 1);
+}
+
+extern "C" size_t cgs_rans_max_bytes(int64_t n_sym) { return (size_t)(n_sym > 0 ? n_sym : 0) * 12 + 64; }
+
+// symbols int32 [C, n] (channel-major), cdf int32 [C, max_len], cdf_len [C], offset [C]
+extern "C" int cgs_rans_encode_host(const int32_t *symbols, int C_, int64_t n, const int32_t *cdf, int max_len,
+                                    const int32_t *cdf_len, const int32_t *offset, int prec, uint8_t *out,
+                                    size_t out_cap, size_t *out_len) {
+    if (!symbols || !cdf || !cdf_len || !offset || !out || !out_len || prec < 8 || prec > 16) {
+        cgs_set_error("rans_encode: bad args");
+        return CGS_ERR_ARG;
+    }
+    RansEnc enc;
+    std::vector<int> bits;
+    // coding order (decoder's view): for i in 0..n-1, for c in 0..C-1  -> encode in reverse
+    for (int64_t i = n - 1; i >= 0; --i)
+        for (int c = C_ - 1; c >= 0; --c) {
+            const int32_t *tab = cdf + (size_t)c * max_len;
+            const int max_value = cdf_len[c] - 2;          // escape slot
+            int value = symbols[(size_t)c * n + i] - offset[c];
+            bool esc = false;
+            int raw = value;
+            if (value < 0 || value >= max_value) { esc = true; value = max_value; }
+            if (esc) {
+                bits.clear();
+                esc_bits(raw, max_value, bits);
+                for (int k = (int)bits.size() - 1; k >= 0; --k) enc.put((uint32_t)bits[k], 1, 1);
+            }
+            enc.put((uint32_t)tab[value], (uint32_t)(tab[value + 1] - tab[value]), prec);
+        }
+    const size_t need = 4 + enc.words.size() * 2;
+    if (need > out_cap) { cgs_set_error("rans_encode: output buffer too small"); return CGS_ERR_WORKSPACE; }
+    out[0] = (uint8_t)enc.x; out[1] = (uint8_t)(enc.x >> 8); out[2] = (uint8_t)(enc.x >> 16); out[3] = (uint8_t)(enc.x >> 24);
+    uint8_t *p = out + 4;
+    for (size_t k = enc.words.size(); k-- > 0;) { *p++ = (uint8_t)enc.words[k]; *p++ = (uint8_t)(enc.words[k] >> 8); }
+    *out_len = need;
+    return CGS_OK;
+}
+
+extern "C" int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C_, int64_t n, const int32_t *cdf, int max_len,
+                                    const int32_t *cdf_len, const int32_t *offset, int prec, int32_t *symbols) {
+    if (!in || in_len < 4 || !cdf || !cdf_len || !offset || !symbols) { cgs_set_error("rans_decode: bad args"); return CGS_ERR_ARG; }
+    RansDec dec;
+    dec.init(in, in_len);
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < C_; ++c) {
+            const int32_t *tab = cdf + (size_t)c * max_len;
+            const int max_value = cdf_len[c] - 2;
+            const uint32_t t = dec.peek(prec);
+            int lo = 0, hi = max_value + 1;                // largest v with tab[v] <= t
+            while (lo + 1 < hi) { const int m = (lo + hi) >> 1; if ((uint32_t)tab[m] <= t) lo = m; else hi = m; }
+            int value = lo;
+            dec.advance((uint32_t)tab[value], (uint32_t)(tab[value + 1] - tab[value]), prec);
+            if (value == max_value) {
+                const int sign = (int)dec.get_bit();
+                int nz = 0;
+                while (dec.get_bit() == 0) { if (++nz > 31) { cgs_set_error("rans_decode: corrupt escape"); return CGS_ERR_BOUNDS; } }
+                uint32_t m = 1;
+                for (int k = 0; k < nz; ++k) m = (m << 1) | dec.get_bit();
+                value = sign ? -(int)m : (int)m + max_value - 1;
+            }
+            symbols[(size_t)c * n + i] = value + offset[c];
+        }
+    return CGS_OK;
+}

@@ -197,6 +197,78 @@ int cgs_entropy_gaussian_bwd(const float *x, const float *mean,
                              float *g_scale, float *g_Q, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* Entropy coding (torchac / compressai call sites of the reference)     */
+/* ------------------------------------------------------------------ */
+/* --- table-driven arithmetic coder on the HOST (torchac drop-in:
+ * torchac.encode_float_cdf / decode_float_cdf, utils/encodings.py:108,138,
+ * 157,178).  cdf is uint16 [n_sym, Lp] (cgs_cdf_float_to_u16_host applies the
+ * published float->int conversion), sym int16 in [0, Lp-2].  All pointers
+ * are HOST pointers. */
+size_t cgs_ac_max_bytes(int64_t n_sym);
+int cgs_cdf_float_to_u16_host(const float *cdf, int64_t n_sym, int Lp,
+                              uint16_t *out);
+int cgs_ac_encode_table_host(const uint16_t *cdf, int Lp, const int16_t *sym,
+                             int64_t n_sym, uint8_t *out, size_t out_cap,
+                             size_t *out_len);
+int cgs_ac_decode_table_host(const uint16_t *cdf, int Lp, int64_t n_sym,
+                             const uint8_t *in, size_t in_len,
+                             int16_t *sym_out);
+/* one CDF row shared by every symbol (the Bernoulli mask stream,
+ * utils/encodings.py:147-180) */
+int cgs_ac_encode_const_host(const uint16_t *row, int Lp, const int16_t *sym,
+                             int64_t n_sym, uint8_t *out, size_t out_cap,
+                             size_t *out_len);
+int cgs_ac_decode_const_host(const uint16_t *row, int Lp, int64_t n_sym,
+                             const uint8_t *in, size_t in_len,
+                             int16_t *sym_out);
+
+/* --- batched Gaussian codec on the DEVICE (encoder_gaussian /
+ * decoder_gaussian, utils/encodings.py:83-144, for all 1000-anchor chunk
+ * streams of a level/attribute at once).  x/mean/scale are flat [n_total]
+ * device arrays; element i uses Q[i / q_div]; stream s covers
+ * [stream_off[s], stream_off[s+1]) (int64, device).  min_v/max_v [n_streams]
+ * hold round(x/Q) extrema per stream (cgs_gaussian_stream_minmax fills them).
+ * Encode writes stream s at out + out_off[s] (capacity out_off[s+1]-out_off[s],
+ * use cgs_ac_max_bytes) and its byte length to out_len[s]; *status (device
+ * int32, zeroed by the caller) becomes non-zero on a range/overflow error.
+ * Decode is the exact inverse: x_out[i] = (sym + min) * Q. */
+int cgs_gaussian_stream_minmax(const float *x, const float *Q, int64_t q_div,
+                               const int64_t *stream_off, int n_streams,
+                               int32_t *min_out, int32_t *max_out,
+                               void *stream);
+int cgs_gaussian_ac_encode(const float *x, const float *mean,
+                           const float *scale, const float *Q, int64_t q_div,
+                           const int64_t *stream_off, int n_streams,
+                           const int32_t *min_v, const int32_t *max_v,
+                           uint8_t *out, const int64_t *out_off,
+                           uint32_t *out_len, int32_t *status, void *stream);
+int cgs_gaussian_ac_decode(const float *mean, const float *scale,
+                           const float *Q, int64_t q_div,
+                           const int64_t *stream_off, int n_streams,
+                           const int32_t *min_v, const int32_t *max_v,
+                           const uint8_t *in, const int64_t *in_off,
+                           float *x_out, void *stream);
+/* test hook: the integer CDF table [n, max_v-min_v+2] of one stream */
+int cgs_gaussian_cdf_table(const float *mean, const float *scale,
+                           const float *Q, int64_t q_div, int64_t n, int min_v,
+                           int max_v, uint16_t *table, void *stream);
+
+/* --- range-ANS for the hyper-prior symbols on the HOST
+ * (EntropyBottleneck.compress / decompress, scene/gaussian_model.py:1088,
+ * 1331).  symbols int32 [C, n] channel-major; cdf int32 [C, max_len] with
+ * cdf_len[c] valid entries (last slot = escape), offset[c] = -minima. */
+size_t cgs_rans_max_bytes(int64_t n_sym);
+int cgs_rans_encode_host(const int32_t *symbols, int C, int64_t n,
+                         const int32_t *cdf, int max_len,
+                         const int32_t *cdf_len, const int32_t *offset,
+                         int prec, uint8_t *out, size_t out_cap,
+                         size_t *out_len);
+int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C, int64_t n,
+                         const int32_t *cdf, int max_len,
+                         const int32_t *cdf_len, const int32_t *offset,
+                         int prec, int32_t *symbols);
+
+/* ------------------------------------------------------------------ */
 /* Anchor -> Gaussian expansion (gaussian_renderer/__init__.py:112-145)   */
 /* ------------------------------------------------------------------ */
 /* Slots are (anchor n, offset k), i = n*K + k.  op_raw [n,K] is mlp_opacity's
