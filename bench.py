@@ -62,15 +62,8 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, dist_on):
         loss = loss + 0.001 * pkg["bit_per_param"]          # lambda * rate term (train.py:206-209)
     loss.backward()
     if dist_on:
-        import torch.distributed as dist
-        grads = flat_grads(params)
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)                                 # RCCL over xGMI: one bucket per step
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
+        from contextgs_amd.dist import allreduce_gradients
+        allreduce_gradients(params, average=True)             # RCCL over xGMI: one flat bucket per step
     return pkg
 
 

@@ -1,0 +1,66 @@
+"""Drop-in glue: make the reference checkout (wyf0912/ContextGS) run on contextgs_amd.
+
+Two levels:
+  * put this directory on PYTHONPATH -> the shim packages `diff_gaussian_rasterization`,
+    `torchac`, `compressai` replace the reference's absent native wheels;
+  * call `install()` -> additionally rebind the reference's own Python hot-path functions
+    to the accelerated ones.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def install(patch_reference_python: bool = True) -> list[str]:
+    """Register the shims and (optionally) rebind the reference's hot-path functions.
+    Returns the list of names that were patched."""
+    if HERE not in sys.path:
+        sys.path.insert(0, HERE)
+    for name in ("diff_gaussian_rasterization", "torchac", "compressai", "compressai.entropy_models",
+                 "compressai.latent_codecs"):
+        importlib.import_module(name)
+    patched = []
+    if not patch_reference_python:
+        return patched
+    from .. import codec_driver, context_model, encodings, entropy_models, multi_level, renderer
+
+    def rebind(modname, src, names):
+        try:
+            mod = importlib.import_module(modname)
+        except Exception:
+            return                      # reference module not importable in this process: nothing to patch
+        for n in names:
+            if hasattr(src, n):
+                setattr(mod, n, getattr(src, n))
+                patched.append(f"{modname}.{n}")
+
+    rebind("utils.entropy_models", entropy_models,
+           ["Entropy_gaussian", "Entropy_gaussian_clamp", "Entropy_bernoulli", "Entropy_factorized", "Low_bound", "UniverseQuant"])
+    rebind("utils.encodings", encodings,
+           ["STE_binary", "STE_multistep", "Quantize_anchor", "encoder", "decoder", "encoder_gaussian", "decoder_gaussian",
+            "get_binary_vxl_size"])
+    rebind("utils.multi_level", multi_level, ["torch_unique_with_indices"])
+    ctx_names = ["multi_scale_generating", "extract_context_feat", "find_divide_scale", "divide_levels", "mapping_to_orign",
+                 "index_of_level_L_in_orign"]
+    rebind("scene.gaussian_model", context_model, ctx_names)
+    rebind("scene.gaussian_model", encodings, ["STE_binary", "STE_multistep", "Quantize_anchor", "encoder", "decoder",
+                                               "encoder_gaussian", "decoder_gaussian", "get_binary_vxl_size"])
+    rebind("scene.gaussian_model", entropy_models, ["Entropy_gaussian", "Entropy_bernoulli", "Entropy_factorized"])
+    rebind("scene.gaussian_model", multi_level, ["torch_unique_with_indices"])
+    try:
+        gm = importlib.import_module("scene.gaussian_model")
+        gm.GaussianModel.conduct_encoding = lambda self, p: codec_driver.conduct_encoding(self, p)
+        gm.GaussianModel.conduct_decoding = lambda self, p: codec_driver.conduct_decoding(self, p)
+        gm.GaussianModel.estimate_final_bits = lambda self: codec_driver.estimate_final_bits(self)
+        patched += ["scene.gaussian_model.GaussianModel.conduct_encoding", "scene.gaussian_model.GaussianModel.conduct_decoding",
+                    "scene.gaussian_model.GaussianModel.estimate_final_bits"]
+    except Exception:
+        pass
+    rebind("gaussian_renderer", renderer, ["render", "prefilter_voxel", "generate_neural_gaussians"])
+    rebind("gaussian_renderer", context_model, ["multi_scale_generating"])
+    rebind("train", renderer, ["render", "prefilter_voxel"])
+    return patched

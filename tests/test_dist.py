@@ -1,0 +1,74 @@
+"""Multi-process (gloo, world_size=2, CPU) coverage of the data-parallel helpers."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        torch.manual_seed(0)                                  # identical replicas
+        lin = torch.nn.Linear(4, 3)
+        extra = torch.nn.Parameter(torch.zeros(5))            # gets a gradient on rank 1 only
+        frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+        params = list(lin.parameters()) + [extra, frozen]
+        # each rank "renders" a different view
+        views = [cd.view_for(step, 8) for step in range(4)]
+        x = torch.full((2, 4), float(rank + 1))
+        loss = lin(x).sum()
+        if rank == 1:
+            loss = loss + (extra * torch.arange(5.0)).sum()
+        loss.backward()
+        n = cd.allreduce_gradients(params, average=True)
+        stats = [torch.full((3, 1), float(rank + 1)), torch.tensor([rank], dtype=torch.int32)]
+        cd.allreduce_stats(stats)
+        p2 = torch.nn.Parameter(torch.full((3,), float(rank)))
+        cd.broadcast_parameters([p2], src=1)
+        chunks = cd.shard([bytes([i]) for i in range(7)])
+        merged = cd.gather_bytes(chunks, dst=0)
+        q.put((rank, views, n, lin.weight.grad.clone(), extra.grad.clone(), stats[0].clone(), int(stats[1]),
+               p2.data.clone(), merged))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gradient_sync_and_sharding():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # views: step s -> ranks take views 2s and 2s+1
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
+    assert res[0][2] == res[1][2] == 4 * 3 + 3 + 5
+    # d/dW of sum(W x + b) over 2 rows of constant x = 2 * x ; averaged over x=1 and x=2 -> 3
+    for r in (0, 1):
+        assert torch.allclose(res[r][3], torch.full((3, 4), 3.0))
+        assert torch.allclose(res[r][4], torch.arange(5.0) / 2)        # only rank 1 had it; average over 2
+        assert torch.equal(res[r][5], torch.full((3, 1), 3.0)) and res[r][6] == 1
+        assert torch.equal(res[r][7], torch.full((3,), 1.0))
+    assert res[0][8] == [bytes([i]) for i in range(7)] and res[1][8] is None

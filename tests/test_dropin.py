@@ -1,0 +1,51 @@
+"""The drop-in layer: shim packages carry the reference's import names, and — in the authoring
+container only, where /root/reference exists — the reference's own GaussianModel / render code
+imports and constructs on top of them."""
+import importlib
+import os
+import sys
+
+import pytest
+
+
+def test_shims_expose_reference_import_names():
+    import contextgs_amd.dropin as dropin
+    dropin.install(patch_reference_python=False)
+    dgr = importlib.import_module("diff_gaussian_rasterization")
+    assert hasattr(dgr, "GaussianRasterizationSettings") and hasattr(dgr, "GaussianRasterizer")
+    fields = dgr.GaussianRasterizationSettings._fields
+    assert fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                      "projmatrix", "sh_degree", "campos", "prefiltered", "debug")      # gaussian_renderer/__init__.py:179-192
+    ta = importlib.import_module("torchac")
+    assert callable(ta.encode_float_cdf) and callable(ta.decode_float_cdf)
+    em = importlib.import_module("compressai.entropy_models")
+    eb = em.EntropyBottleneck(channels=12)
+    for m in ("forward", "quantize", "compress", "decompress", "update", "_get_medians"):
+        assert hasattr(eb, m)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scene"), reason="reference checkout only exists in the authoring container")
+def test_reference_python_imports_on_top_of_the_shims():
+    import types
+    import contextgs_amd.dropin as dropin
+    for name in ("plyfile", "simple_knn", "simple_knn._C", "torch_scatter", "colorama"):        # not on the hot path
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = None
+    sys.modules["torch_scatter"].scatter_max = None
+    sys.modules["colorama"].Fore = sys.modules["colorama"].Style = types.SimpleNamespace(YELLOW="", RESET_ALL="")
+    sys.modules["colorama"].init = lambda *a, **k: None
+    sys.path.insert(0, "/root/reference")
+    try:
+        dropin.install(patch_reference_python=False)
+        gm = importlib.import_module("scene.gaussian_model")
+        patched = dropin.install()
+        assert "scene.gaussian_model.multi_scale_generating" in patched
+        from contextgs_amd import context_model
+        assert gm.multi_scale_generating is context_model.multi_scale_generating
+        assert gm.EntropyBottleneck.__module__ == "contextgs_amd.entropy_bottleneck"
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k.split(".")[0] in ("scene", "utils", "gaussian_renderer", "arguments")]:
+            del sys.modules[k]
