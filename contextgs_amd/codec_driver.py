@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import codec
-from .context_model import (extract_context_feat, find_divide_scale, level_plan, multi_scale_generating,
+from .context_model import (extract_context_feat, find_divide_scale, grid_mlp, level_plan, multi_scale_generating,
                             split_prediction)
 from .encodings import Q_anchor, Quantize_anchor, STE_multistep, decoder, encoder
 
@@ -72,7 +72,7 @@ def _chunk_rows(n):
 
 def _predict(pc, level, feat_in):
     (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
-        split_prediction(pc, pc.get_grid_mlp[level](feat_in))
+        split_prediction(pc, grid_mlp(pc, level, feat_in))
     c = lambda t: torch.clamp(t, min=1e-9).contiguous()
     return (mean_feat.contiguous(), c(scale_feat), mean_scaling.contiguous(), c(scale_scaling),
             mean_offsets.contiguous(), c(scale_offsets), Qf.reshape(-1).contiguous(), Qs.reshape(-1).contiguous(),

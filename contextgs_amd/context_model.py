@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import torch
 
+from . import mlp as _mlp
 from .encodings import STE_multistep, get_binary_vxl_size
 from .multi_level import torch_unique_with_indices
 
@@ -120,6 +121,12 @@ def level_plan(pc, anchor, mask_anchor_bool):
     return plan, inverse_indices_list, mapping_list
 
 
+def grid_mlp(pc, level, feat_in):
+    """mlp_grid[level](feat_in) (:1600) on the fused fp32-MFMA kernels when the shape has an instance."""
+    seq = pc.get_grid_mlp[level]
+    return _mlp.mlp2(feat_in, seq) if _mlp.supported(seq) else seq(feat_in)
+
+
 def split_prediction(pc, predicted):                                    # :1603-1608
     D, K = pc.feat_dim, pc.n_offsets
     (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, qf, qs, qo) = torch.split(
@@ -168,7 +175,7 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
             else:
                 feat_in = torch.cat([content_pre_gathered, hyper_feat[orig]], dim=1)
             (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,
-             Q_offsets) = split_prediction(pc, pc.get_grid_mlp[i](feat_in))
+             Q_offsets) = split_prediction(pc, grid_mlp(pc, i, feat_in))
 
             if training:                                                               # :1610-1616
                 hybrid_feat = hybrid_feat + torch.empty_like(hybrid_feat).uniform_(-0.5, 0.5) * Q_feat

@@ -1,0 +1,82 @@
+"""`mlp2(x, seq)`: the nn.Sequential(Linear, ReLU, Linear [, Tanh | Sigmoid]) modules of the
+hot path (scene/gaussian_model.py:153-188) evaluated by libcgs_hip.so's fused fp32-MFMA
+kernels (csrc/mlp.hip) — forward, input gradient and weight/bias gradients — instead of
+4-6 rocBLAS/elementwise launches each way.  Falls back to nothing: shapes without a kernel
+instance raise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ACT = {None: 0, nn.Tanh: 1, nn.Sigmoid: 2}
+_SUPPORTED = {(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0), (71, 100, 175, 0), (15, 100, 175, 0)}
+
+
+def _describe(seq: nn.Sequential):
+    l1, l2 = seq[0], seq[2]
+    act = _ACT[type(seq[3])] if len(seq) > 3 else 0
+    return l1, l2, act
+
+
+def supported(seq: nn.Sequential) -> bool:
+    try:
+        l1, l2, act = _describe(seq)
+    except Exception:
+        return False
+    return (l1.in_features, l1.out_features, l2.out_features, act) in _SUPPORTED
+
+
+class _MLP2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, act):
+        L = _lib.lib()
+        _lib.require_device(x, W1, W2)
+        x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+        W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
+        n, in_f = x.shape
+        hid, out = W1c.shape[0], W2c.shape[0]
+        need_grad = any(ctx.needs_input_grad[:5])
+        y = torch.empty(n, out, dtype=torch.float32, device=x.device)
+        h = torch.empty(n, hid, dtype=torch.float32, device=x.device) if need_grad else None
+        _lib.check(L.cgs_mlp2_forward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1c), _lib.ptr(b1c), _lib.ptr(W2c),
+                                      _lib.ptr(b2c), _lib.ptr(y), out, _lib.ptr(h), n, _lib.current_stream()),
+                   "cgs_mlp2_forward")
+        if need_grad:
+            ctx.save_for_backward(x, W1c, W2c, y, h)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, W1, W2, y, h = ctx.saved_tensors
+        act = ctx.act
+        n, in_f = x.shape
+        hid, out = W1.shape[0], W2.shape[0]
+        dev = x.device
+        dy = dy.contiguous() if dy.dtype == torch.float32 else dy.float().contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(n, in_f, dtype=torch.float32, device=dev) if need_dx else None
+        dz1 = torch.empty(n, hid, dtype=torch.float32, device=dev)
+        dz2 = torch.empty(n, out, dtype=torch.float32, device=dev) if act != 0 else None
+        dW1 = torch.zeros_like(W1)
+        db1 = torch.zeros(hid, dtype=torch.float32, device=dev)
+        dW2 = torch.zeros_like(W2)
+        db2 = torch.zeros(out, dtype=torch.float32, device=dev)
+        _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(W2), _lib.ptr(y),
+                                       _lib.ptr(dy), out, _lib.ptr(h), _lib.ptr(dx), in_f, 0, _lib.ptr(dz1), _lib.ptr(dz2),
+                                       _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n,
+                                       _lib.current_stream()), "cgs_mlp2_backward")
+        return dx, dW1, db1, dW2, db2, None
+
+
+def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
+    """seq(x) for a supported Sequential(Linear, ReLU, Linear[, act])."""
+    l1, l2, act = _describe(seq)
+    key = (l1.in_features, l1.out_features, l2.out_features, act)
+    if key not in _SUPPORTED:
+        raise NotImplementedError(f"no fused MLP kernel for {key}; instantiate it in csrc/mlp.hip")
+    return _MLP2.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, act)

@@ -16,7 +16,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, mlp
 from .context_model import multi_scale_generating
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
@@ -97,6 +97,10 @@ def _anchor_mlps(pc, x):
     """mlp_opacity / mlp_color / mlp_cov on the shared [N,54] input (:112,122,126).
     The three first layers are one GEMM; outputs are identical dot products."""
     mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    if mlp.supported(mo) and mlp.supported(mc) and mlp.supported(mv):
+        # one fused fp32-MFMA launch per MLP forward, three backward (csrc/mlp.hip): rocprof showed the
+        # rocBLAS + elementwise + bias-reduction version of these skinny MLPs dominating the step
+        return mlp.mlp2(x, mo), mlp.mlp2(x, mc), mlp.mlp2(x, mv)
     D = mo[0].out_features
     W1 = torch.cat([mo[0].weight, mc[0].weight, mv[0].weight], dim=0)
     b1 = torch.cat([mo[0].bias, mc[0].bias, mv[0].bias], dim=0)

@@ -197,6 +197,32 @@ int cgs_entropy_gaussian_bwd(const float *x, const float *mean,
                              float *g_scale, float *g_Q, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* Fused 2-layer MLPs on the fp32 matrix cores                            */
+/* ------------------------------------------------------------------ */
+/* Y = act(W2 relu(W1 x + b1) + b2) for the nn.Sequential(Linear, ReLU, Linear
+ * [, Tanh | Sigmoid]) modules of the path: mlp_opacity / mlp_color / mlp_cov
+ * (scene/gaussian_model.py:153-174, 54 -> 50 -> {10 tanh, 30 sigmoid, 70}) and
+ * mlp_grid[l] (:177-188, {71, 15} -> 100 -> 175).  act: 0 none, 1 tanh,
+ * 2 sigmoid.  Weights in nn.Linear layout (W1 [hid,in], W2 [out,hid]).
+ * X [n, ldx], Y [n, ldy]; H [n, hid] receives relu(.) for the backward (NULL
+ * for inference).  Only the (in, hid, out, act) combinations above are
+ * instantiated; others return CGS_ERR_ARG. */
+int cgs_mlp2_forward(int in, int hid, int out, int act, const float *X,
+                     int64_t ldx, const float *W1, const float *b1,
+                     const float *W2, const float *b2, float *Y, int64_t ldy,
+                     float *H, int64_t n, void *stream);
+/* Backward: dX [n, lddx] (NULL to skip; accumulate_dx != 0 adds into it), dZ1
+ * [n, hid] and dZ2 [n, out] are scratch outputs (dZ2 may be NULL when act == 0).
+ * dW1/db1/dW2/db2 are ACCUMULATED into (fp32 atomics): zero or pre-load them. */
+int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
+                      int64_t ldx, const float *W1, const float *W2,
+                      const float *Y, const float *dY, int64_t ldy,
+                      const float *H, float *dX, int64_t lddx,
+                      int accumulate_dx, float *dZ1, float *dZ2, float *dW1,
+                      float *db1, float *dW2, float *db2, int64_t n,
+                      void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Entropy coding (torchac / compressai call sites of the reference)     */
 /* ------------------------------------------------------------------ */
 /* --- table-driven arithmetic coder on the HOST (torchac drop-in:

@@ -1,0 +1,58 @@
+"""Fused fp32-MFMA 2-layer MLP kernels (csrc/mlp.hip) vs a plain PyTorch fp32 reference of
+the same nn.Sequential (the one floating-point op here whose oracle is torch itself).
+v_mfma_f32_16x16x4_f32 is exact fp32 (an fmaf chain), so only the summation order differs:
+tolerance 2e-5 relative to the tensor's max for activations, 2e-4 for the weight gradients
+(sums over all rows)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [(54, 50, 10, nn.Tanh), (54, 50, 30, nn.Sigmoid), (54, 50, 70, None), (71, 100, 175, None), (15, 100, 175, None)]
+
+
+def _seq(i, h, o, act):
+    layers = [nn.Linear(i, h), nn.ReLU(True), nn.Linear(h, o)]
+    if act is not None:
+        layers.append(act())
+    return nn.Sequential(*layers).cuda()
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 40001])
+def test_forward_backward_match_torch(cfg, n):
+    from contextgs_amd import mlp
+    i, h, o, act = cfg
+    torch.manual_seed(n + i + o)
+    seq = _seq(i, h, o, act)
+    assert mlp.supported(seq)
+    x = torch.randn(n, i, device="cuda", requires_grad=True)
+    w = torch.randn(n, o, device="cuda")
+    y = mlp.mlp2(x, seq)
+    (y * w).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in seq.parameters()]
+    x.grad = None
+    seq.zero_grad()
+    y_ref = seq(x)
+    (y_ref * w).sum().backward()
+    ref = [x.grad] + [p.grad for p in seq.parameters()]
+    assert (y - y_ref).abs().max() <= 2e-5 * max(1.0, float(y_ref.abs().max()))
+    for a, b, name in zip(got, ref, ["dx", "dW1", "db1", "dW2", "db2"]):
+        tol = (2e-5 if name == "dx" else 2e-4) * max(1e-6, float(b.abs().max()))
+        assert (a - b).abs().max() <= tol, (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_empty_no_grad_and_unsupported_shape():
+    from contextgs_amd import mlp
+    seq = _seq(71, 100, 175, None)
+    y = mlp.mlp2(torch.zeros(0, 71, device="cuda"), seq)
+    assert y.shape == (0, 175)
+    with torch.no_grad():
+        x = torch.randn(100, 71, device="cuda")
+        assert torch.allclose(mlp.mlp2(x, seq), seq(x), atol=2e-5)
+    odd = _seq(33, 20, 7, None)
+    assert not mlp.supported(odd)
+    with pytest.raises(NotImplementedError):
+        mlp.mlp2(torch.randn(4, 33, device="cuda"), odd)
