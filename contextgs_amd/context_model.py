@@ -137,24 +137,41 @@ def split_prediction(pc, predicted):                                    # :1603-
     return mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling, Q_offsets
 
 
+class _GatherUnique(torch.autograd.Function):
+    """x[idx] for UNIQUE row indices: the backward is a plain row scatter into zeros (index_copy_) instead of
+    torch's index_put_(accumulate=True), which sorts the indices first (rocprof: ~44 ms of merge-sort +
+    indexing_backward kernels per 14 steps at 1 M anchors)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_copy_(0, idx, g.contiguous())
+        return out, None
+
+
+def gather_unique(x, idx):
+    return _GatherUnique.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
+
+
 def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
                            mask_anchor_bool=None, training=False, predict_bpp=False, return_sum_bits=False):   # :1541-1707
     K = pc.n_offsets
     n = anchor.shape[0]
     dev = anchor.device
     content_pre_gathered = None
-    to_code_list = []
+    levels = []          # per coded level: everything the rate model needs, in the level's own row order
 
     feat_after_Q = torch.zeros_like(feat)
     grid_scaling_after_Q = torch.zeros_like(grid_scaling)
     grid_offsets_after_Q = torch.zeros_like(grid_offsets)
     already_coded = torch.zeros(n, dtype=torch.bool, device=dev)
-    if predict_bpp:
-        z = torch.zeros_like
-        off2 = grid_offsets.reshape(-1, 3 * K)
-        mean_feat_all, scale_feat_all, Q_feat_all = z(feat), z(feat), z(feat[:, [0]])
-        mean_scaling_all, scale_scaling_all, Q_scaling_all = z(grid_scaling), z(grid_scaling), z(grid_scaling[:, [0]])
-        mean_offsets_all, scale_offsets_all, Q_offsets_all = z(off2), z(off2), z(off2[:, [0]])
 
     hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)           # :1556
     if pc.disable_hyper:
@@ -166,14 +183,15 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
 
     for (i, to_code, orig, hybrid_anchor) in plan:
         if int(orig.shape[0]) > 0:
-            hybrid_feat = feat[orig]
-            hybrid_grid_scaling = grid_scaling[orig]
-            hybrid_grid_offsets = grid_offsets[orig]
-            to_code_list.append(orig)
+            # rows of a level are distinct anchors -> sort-free gathers (reference: feat[mapping][to_code], :1569-1585)
+            hybrid_feat = gather_unique(feat, orig)
+            hybrid_grid_scaling = gather_unique(grid_scaling, orig)
+            hybrid_grid_offsets = gather_unique(grid_offsets, orig)
+            hyper_l = gather_unique(hyper_feat, orig)
             if content_pre_gathered is None:                                           # :1596-1600
-                feat_in = torch.cat([hybrid_anchor, hyper_feat[orig].float()], dim=1)
+                feat_in = torch.cat([hybrid_anchor, hyper_l.float()], dim=1)
             else:
-                feat_in = torch.cat([content_pre_gathered, hyper_feat[orig]], dim=1)
+                feat_in = torch.cat([content_pre_gathered, hyper_l], dim=1)
             (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,
              Q_offsets) = split_prediction(pc, grid_mlp(pc, i, feat_in))
 
@@ -189,11 +207,13 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
                 hybrid_grid_offsets = STE_multistep.apply(hybrid_grid_offsets, qo).detach()
             hybrid_grid_offsets = hybrid_grid_offsets.reshape(-1, 3 * K)
 
-            if predict_bpp:                                                            # :1629-1641
-                mean_feat_all[orig] = mean_feat; scale_feat_all[orig] = scale_feat; Q_feat_all[orig] = Q_feat
-                mean_scaling_all[orig] = mean_scaling; scale_scaling_all[orig] = scale_scaling; Q_scaling_all[orig] = Q_scaling
-                mean_offsets_all[orig] = mean_offsets; scale_offsets_all[orig] = scale_offsets; Q_offsets_all[orig] = Q_offsets
-
+            if predict_bpp:
+                # The reference scatters these nine tensors into N-sized buffers (:1629-1641) and gathers the
+                # 15 % rate subset back out (:1666-1669); the subset of a level is gathered from the level's own
+                # rows instead — same elements, no N-sized round trip.
+                levels.append(dict(orig=orig, feat=hybrid_feat, scaling=hybrid_grid_scaling, offsets=hybrid_grid_offsets,
+                                   mf=mean_feat, sf=scale_feat, qf=Q_feat, ms=mean_scaling, ss=scale_scaling, qs=Q_scaling,
+                                   mo=mean_offsets, so=scale_offsets, qo=Q_offsets))
             feat_after_Q[orig] = hybrid_feat                                           # :1644-1647
             grid_scaling_after_Q[orig] = hybrid_grid_scaling
             grid_offsets_after_Q[orig] = hybrid_grid_offsets.view(-1, K, 3)
@@ -213,46 +233,48 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
         mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach()
     else:
         mask_anchor_rate = 1
-    sel = torch.nonzero(choose_mask)[:, 0]
-    bit_hyper = -torch.log2(likelihood_hyper[sel])
+    bit_hyper = -torch.log2(likelihood_hyper[torch.nonzero(choose_mask)[:, 0]])
     eg = pc.entropy_gaussian
-    bit_feat = eg(feat_after_Q[sel], mean_feat_all[sel], scale_feat_all[sel], Q_feat_all[sel], pc._anchor_feat.mean())
-    bit_scaling = eg(grid_scaling_after_Q[sel], mean_scaling_all[sel], scale_scaling_all[sel], Q_scaling_all[sel],
-                     pc.get_scaling.mean())
-    bit_offsets = eg(grid_offsets_after_Q[sel].view(-1, 3 * K), mean_offsets_all[sel], scale_offsets_all[sel],
-                     Q_offsets_all[sel], pc._offset.mean())
-    bit_offsets = bit_offsets * binary_grid_masks[sel].repeat(1, 1, 3).view(-1, 3 * K)
+    xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
+    masks30 = binary_grid_masks.repeat(1, 1, 3).view(-1, 3 * K)
+    zero = torch.zeros((), device=dev)
+    s_feat, s_scaling, s_offsets = zero, zero, zero
+    n_feat = n_scaling = n_offsets = 0
+    level_bpp_sums, level_rows = [], []
+    for L in levels:
+        loc = torch.nonzero(choose_mask[L["orig"]])[:, 0]
+        rows = L["orig"][loc]
+        g = lambda t: gather_unique(t, loc)
+        bf = eg(g(L["feat"]), g(L["mf"]), g(L["sf"]), g(L["qf"]), xm_feat)
+        bs = eg(g(L["scaling"]), g(L["ms"]), g(L["ss"]), g(L["qs"]), xm_scaling)
+        bo = eg(g(L["offsets"]), g(L["mo"]), g(L["so"]), g(L["qo"]), xm_offsets) * masks30[rows]
+        s_feat, s_scaling, s_offsets = s_feat + bf.sum(), s_scaling + bs.sum(), s_offsets + bo.sum()
+        n_feat, n_scaling, n_offsets = n_feat + bf.numel(), n_scaling + bs.numel(), n_offsets + bo.numel()
+        level_rows.append(int(loc.shape[0]))
+        level_bpp_sums.append((bf.detach().sum() + bs.detach().sum() + bo.detach().sum()))
 
     if return_sum_bits:                                                                # :1672-1685
         bit_anchor = bit_hyper.shape[0] * 3 * 16
         bit_masks_sum = get_binary_vxl_size(binary_grid_masks)[1].item()
-        return (bit_anchor, torch.sum(bit_hyper).item(), torch.sum(bit_feat).item(), torch.sum(bit_scaling).item(),
-                torch.sum(bit_offsets).item(), bit_masks_sum)
+        return (bit_anchor, torch.sum(bit_hyper).item(), s_feat.item(), s_scaling.item(), s_offsets.item(), bit_masks_sum)
 
-    s_feat, s_scaling, s_offsets, s_hyper = torch.sum(bit_feat), torch.sum(bit_scaling), torch.sum(bit_offsets), torch.sum(bit_hyper)
-    bit_per_hyper_param = s_hyper / bit_hyper.numel() * mask_anchor_rate
-    bit_per_feat_param = s_feat / bit_feat.numel() * mask_anchor_rate
-    bit_per_scaling_param = s_scaling / bit_scaling.numel() * mask_anchor_rate
-    bit_per_offsets_param = s_offsets / bit_offsets.numel() * mask_anchor_rate
-    bit_per_param = (s_feat + s_scaling + s_offsets + s_hyper) / \
-                    (bit_feat.numel() + bit_scaling.numel() + bit_offsets.numel()) * mask_anchor_rate
+    s_hyper = torch.sum(bit_hyper)
+    bit_per_hyper_param = s_hyper / max(1, bit_hyper.numel()) * mask_anchor_rate
+    bit_per_feat_param = s_feat / max(1, n_feat) * mask_anchor_rate
+    bit_per_scaling_param = s_scaling / max(1, n_scaling) * mask_anchor_rate
+    bit_per_offsets_param = s_offsets / max(1, n_offsets) * mask_anchor_rate
+    bit_per_param = (s_feat + s_scaling + s_offsets + s_hyper) / max(1, n_feat + n_scaling + n_offsets) * mask_anchor_rate
 
-    # per-level bpp (:1697-1705); one host read for the whole report instead of one .item() per level
+    # per-level bpp (:1697-1705); ONE host read for the whole report instead of one .item() per level
     with torch.no_grad():
-        bpp_sum_map = bit_offsets.sum(dim=1) + bit_scaling.sum(dim=1) + bit_feat.sum(dim=1)
         feat_dim = pc.feat_dim + 6 + 3 * K
-        level_of = torch.full((n,), -1, dtype=torch.long, device=dev)
-        for li, index in enumerate(to_code_list):
-            level_of[index] = li
-        lv = level_of[sel]
         stats = [1 - (mask_anchor_bool.float().mean() if mask_anchor_bool is not None else torch.ones((), device=dev)),
-                 bit_per_hyper_param.detach() if torch.is_tensor(bit_per_hyper_param) else torch.tensor(float(bit_per_hyper_param), device=dev)]
-        for li in range(len(to_code_list)):
-            stats.append(bpp_sum_map[lv == li].mean() / feat_dim)
-        host = torch.stack([s.reshape(()).float() for s in stats]).cpu().tolist()
+                 bit_per_hyper_param.detach()]
+        stats += [s / max(1, r) / feat_dim for s, r in zip(level_bpp_sums, level_rows)]
+        host = torch.stack([t.reshape(()).float() for t in stats]).cpu().tolist()
     each_level_bpp = [host[0], host[1]]
-    for li, index in enumerate(to_code_list):
-        each_level_bpp.append([index.shape[0] / n, host[2 + li]])
+    for li, L in enumerate(levels):
+        each_level_bpp.append([L["orig"].shape[0] / n, host[2 + li]])
 
     return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q, bit_per_param, bit_per_feat_param,
             bit_per_scaling_param, bit_per_offsets_param, each_level_bpp)

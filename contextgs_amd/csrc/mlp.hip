@@ -267,56 +267,66 @@ __global__ void __launch_bounds__(WAVES * 64)
 
 // ------------------------------------------------------------------------------------------
 // dW[a][b] += sum_rows P[row][a] * Q[row][b];  db[a] += sum_rows P[row][a]
-// wave w owns A tiles u = w + WAVES*j (j < UPW) and all NB B tiles.
-template <int NB, int UPW, int WAVES>
+// The NA x NB output tiles are dealt round-robin to the WAVES waves of a workgroup (tile id =
+// wave + WAVES*j), so every wave has MFMA work whatever the aspect ratio; the row loop is
+// unrolled UNR deep so that 2*TPW*UNR fragment loads are in flight per wave (the operands
+// come straight from HBM/L2 in fragment order: 4 rows x 64 B per instruction, and the 8
+// waves of a workgroup re-touch each other's lines in L1).
+template <int TPW, int WAVES, int UNR>
 __global__ void __launch_bounds__(WAVES * 64)
     wgrad_kernel(const float *__restrict__ P, int64_t ldp, int DA, const float *__restrict__ Q, int64_t ldq, int DB,
                  float *__restrict__ dW, float *__restrict__ db, int64_t n, int64_t rows_per_block) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int NA = (DA + 15) / 16, NB = (DB + 15) / 16, T = NA * NB;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = min(n, r_begin + rows_per_block);
-    f32x4 acc[UPW][NB], accb[UPW];
-    int ua[UPW];
+    f32x4 acc[TPW], accb[TPW];
+    int acol[TPW], bcol[TPW];
+    bool live[TPW], bias[TPW];
 #pragma unroll
-    for (int j = 0; j < UPW; ++j) {
-        ua[j] = 16 * (wave + WAVES * j) + c;
+    for (int j = 0; j < TPW; ++j) {
+        const int id = wave + WAVES * j;
+        live[j] = id < T;
+        const int u = live[j] ? id / NB : 0, t = live[j] ? id % NB : 0;
+        acol[j] = 16 * u + c;
+        bcol[j] = 16 * t + c;
+        bias[j] = live[j] && t == 0 && db != nullptr;
+        live[j] = live[j] && true;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NB; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (16 * wave >= DA) return;     // this wave owns no A tile at all
-    for (int64_t row0 = r_begin; row0 < r_end; row0 += 4) {
-        const int64_t row = row0 + g;
-        const bool valid = row < r_end;
-        float a[UPW];
+    for (int64_t row0 = r_begin; row0 < r_end; row0 += 4 * UNR) {
+        float a[UNR][TPW], b[UNR][TPW], one[UNR];
 #pragma unroll
-        for (int j = 0; j < UPW; ++j) a[j] = (valid && ua[j] < DA) ? P[row * ldp + ua[j]] : 0.f;
+        for (int q = 0; q < UNR; ++q) {
+            const int64_t row = row0 + 4 * q + g;
+            const bool valid = row < r_end;
+            one[q] = valid ? 1.f : 0.f;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int bcol = 16 * t + c;
-            const float b = (valid && bcol < DB) ? Q[row * ldq + bcol] : 0.f;
-#pragma unroll
-            for (int j = 0; j < UPW; ++j) acc[j][t] = mfma4(a[j], b, acc[j][t]);
+            for (int j = 0; j < TPW; ++j) {
+                a[q][j] = (valid && live[j] && acol[j] < DA) ? P[row * ldp + acol[j]] : 0.f;
+                b[q][j] = (valid && live[j] && bcol[j] < DB) ? Q[row * ldq + bcol[j]] : 0.f;
+            }
         }
-        if (db) {
 #pragma unroll
-            for (int j = 0; j < UPW; ++j) accb[j] = mfma4(a[j], valid ? 1.f : 0.f, accb[j]);
-        }
+        for (int q = 0; q < UNR; ++q)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                acc[j] = mfma4(a[q][j], b[q][j], acc[j]);
+                if (bias[j]) accb[j] = mfma4(a[q][j], one[q], accb[j]);
+            }
     }
     // D layout: reg r of lane l <-> (a = 16u + 4g + r, b = 16t + c)
 #pragma unroll
-    for (int j = 0; j < UPW; ++j) {
-        const int u16 = 16 * (wave + WAVES * j);
+    for (int j = 0; j < TPW; ++j) {
+        if (!live[j]) continue;
+        const int u16 = acol[j] - c, b_ = bcol[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int arow = u16 + 4 * g + r;
             if (arow >= DA) continue;
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                const int bcol = 16 * t + c;
-                if (bcol < DB) atomicAdd(&dW[(int64_t)arow * DB + bcol], acc[j][t][r]);
-            }
-            if (db && c == 0) atomicAdd(&db[arow], accb[j][r]);
+            if (b_ < DB) atomicAdd(&dW[(int64_t)arow * DB + b_], acc[j][r]);
+            if (bias[j] && c == 0) atomicAdd(&db[arow], accb[j][r]);
         }
     }
 }
@@ -363,24 +373,29 @@ static int launch_wgrad(const float *P, int64_t ldp, int DA, const float *Q, int
                         int64_t n, hipStream_t s) {
     constexpr int WAVES = 8;
     if (n <= 0) return CGS_OK;
-    const int na = (DA + 15) / 16, nb = (DB + 15) / 16;
-    const int upw = (na + WAVES - 1) / WAVES;
-    int64_t blocks = (n + 2047) / 2048;
-    const int64_t cap = 2 * (int64_t)num_cus();
+    const int T = ((DA + 15) / 16) * ((DB + 15) / 16);
+    const int tpw = (T + WAVES - 1) / WAVES;
+    int64_t blocks = (n + 1023) / 1024;
+    const int64_t cap = 4 * (int64_t)num_cus();
     if (blocks > cap) blocks = cap;
     int64_t rpb = (n + blocks - 1) / blocks;
-    rpb = (rpb + 3) / 4 * 4;
+    rpb = (rpb + 15) / 16 * 16;
     blocks = (n + rpb - 1) / rpb;
-#define WG(NB_, UPW_)                                                                                                   \
-    hipLaunchKernelGGL((wgrad_kernel<NB_, UPW_, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, P, ldp, DA, Q, ldq, \
+#define WG(TPW_, UNR_)                                                                                                  \
+    hipLaunchKernelGGL((wgrad_kernel<TPW_, WAVES, UNR_>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, s, P, ldp, DA, Q, ldq, \
                        DB, dW, db, n, rpb)
-    if (upw > 2 || nb > 7) { cgs_set_error("wgrad: unsupported dims %d x %d", DA, DB); return CGS_ERR_ARG; }
-    if (upw == 1) {
-        switch (nb) { case 1: WG(1, 1); break; case 2: WG(2, 1); break; case 3: WG(3, 1); break; case 4: WG(4, 1); break;
-                      case 5: WG(5, 1); break; case 6: WG(6, 1); break; default: WG(7, 1); break; }
-    } else {
-        switch (nb) { case 1: WG(1, 2); break; case 2: WG(2, 2); break; case 3: WG(3, 2); break; case 4: WG(4, 2); break;
-                      case 5: WG(5, 2); break; case 6: WG(6, 2); break; default: WG(7, 2); break; }
+    switch (tpw) {
+        case 1: WG(1, 4); break;
+        case 2: WG(2, 4); break;
+        case 3: WG(3, 4); break;
+        case 4: WG(4, 4); break;
+        case 5: WG(5, 2); break;
+        case 6: WG(6, 2); break;
+        case 7: WG(7, 2); break;
+        case 8: WG(8, 2); break;
+        case 9: WG(9, 2); break;
+        case 10: WG(10, 2); break;
+        default: cgs_set_error("wgrad: unsupported dims %d x %d", DA, DB); return CGS_ERR_ARG;
     }
 #undef WG
     CGS_CHECK_HIP(hipGetLastError());

@@ -41,6 +41,36 @@ class _LowerBound(torch.autograd.Function):
         return g * pass_through.to(g.dtype), None
 
 
+class _FusedLikelihood(torch.autograd.Function):
+    """likelihood[N,C] of already-quantised values under the factorised prior (csrc/eb.hip)."""
+
+    @staticmethod
+    def forward(ctx, v, packed):
+        from . import _lib
+        L = _lib.lib()
+        v = v.contiguous()
+        packed = packed.contiguous()
+        n, C = v.shape
+        lik = torch.empty_like(v)
+        _lib.check(L.cgs_eb_likelihood_fwd(_lib.ptr(v), _lib.ptr(packed), n, C, _lib.ptr(lik), _lib.current_stream()),
+                   "cgs_eb_likelihood_fwd")
+        ctx.save_for_backward(v, packed)
+        return lik
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        L = _lib.lib()
+        v, packed = ctx.saved_tensors
+        n, C = v.shape
+        g = g.contiguous()
+        g_v = torch.empty_like(v)
+        g_p = torch.zeros_like(packed)
+        _lib.check(L.cgs_eb_likelihood_bwd(_lib.ptr(v), _lib.ptr(packed), _lib.ptr(g), n, C, _lib.ptr(g_v), _lib.ptr(g_p),
+                                           _lib.current_stream()), "cgs_eb_likelihood_bwd")
+        return g_v, g_p
+
+
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10.0,
                  filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9, entropy_coder_precision: int = 16):
@@ -109,11 +139,28 @@ class EntropyBottleneck(nn.Module):
         if training is None:
             training = self.training
         assert x.dim() == 2 and x.shape[1] == self.channels, "expects [N, C]"
+        if x.is_cuda and self.filters == (3, 3, 3, 3):
+            # fused HIP path (csrc/eb.hip): quantisation stays a 2-op torch prologue (keeps torch's RNG stream),
+            # the 1-3-3-3-3-1 density network forward/backward is one kernel each
+            med = self._get_medians()[:, 0, 0]                        # [C]
+            out = x + torch.empty_like(x).uniform_(-0.5, 0.5) if training else torch.round(x - med) + med
+            return out, _FusedLikelihood.apply(out, self._packed_params())
         v = x.t().reshape(self.channels, 1, -1)                      # [C,1,N]
         out = self.quantize(v, "noise" if training else "dequantize", self._get_medians())
         lik = _LowerBound.apply(self._likelihood(out), self.likelihood_bound)
         back = lambda t: t.reshape(self.channels, -1).t()
         return back(out), back(lik)
+
+    def _packed_params(self) -> torch.Tensor:
+        """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat)."""
+        C = self.channels
+        parts = []
+        for i in range(5):
+            parts.append(self.matrices[i].reshape(C, -1))
+            parts.append(self.biases[i].reshape(C, -1))
+            if i < 4:
+                parts.append(self.factors[i].reshape(C, -1))
+        return torch.cat(parts, dim=1).contiguous()
 
     # ---- tables --------------------------------------------------------------------
     @torch.no_grad()

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, mlp
-from .context_model import multi_scale_generating
+from .context_model import gather_unique, multi_scale_generating
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 Q_FEAT, Q_SCALING, Q_OFFSETS = 1, 0.001, 0.2      # :40-42
@@ -119,12 +119,16 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     bit_per_param = bit_per_anchor_param = bit_per_feat_param = None
     bit_per_scaling_param = bit_per_offsets_param = bpp_per_level = None
 
+    # visible rows are distinct anchors: gather by index with a sort-free scatter backward (the reference's
+    # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
+    vis_idx = torch.nonzero(visible_mask)[:, 0]
+    sel = lambda t: gather_unique(t, vis_idx)
     full_anchor = pc.get_anchor
-    anchor = full_anchor[visible_mask]
-    feat = pc._anchor_feat[visible_mask]
-    grid_offsets = pc._offset[visible_mask]
-    grid_scaling = pc.get_scaling[visible_mask]
-    binary_grid_masks = pc.get_mask[visible_mask]
+    anchor = sel(full_anchor)
+    feat = sel(pc._anchor_feat)
+    grid_offsets = sel(pc._offset)
+    grid_scaling = sel(pc.get_scaling)
+    binary_grid_masks = sel(pc.get_mask)
 
     if is_training:
         if 3000 < step <= 10000:                                                        # :54-58
@@ -140,22 +144,22 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
              bit_per_offsets_param, bpp_per_level) = multi_scale_generating(
                 pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
                 mask_anchor_bool, predict_bpp=True, training=True)
-            anchor = pc.get_anchor[visible_mask]
-            feat = feat[visible_mask]
-            grid_offsets = grid_offsets[visible_mask]
-            grid_scaling = grid_scaling[visible_mask]
-            binary_grid_masks = binary_all[visible_mask]
+            anchor = sel(pc.get_anchor)
+            feat = sel(feat)
+            grid_offsets = sel(grid_offsets)
+            grid_scaling = sel(grid_scaling)
+            binary_grid_masks = sel(binary_all)
     elif not pc.decoded_version:                                                        # :83-101
         mask_anchor_bool = pc.get_mask_anchor.to(torch.bool)
         binary_all = pc.get_mask
         feat, grid_scaling, grid_offsets = multi_scale_generating(
             pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
             mask_anchor_bool, predict_bpp=False, training=False)
-        anchor = pc.get_anchor[visible_mask]
-        feat = feat[visible_mask]
-        grid_offsets = grid_offsets[visible_mask]
-        grid_scaling = grid_scaling[visible_mask]
-        binary_grid_masks = binary_all[visible_mask]
+        anchor = sel(pc.get_anchor)
+        feat = sel(feat)
+        grid_offsets = sel(grid_offsets)
+        grid_scaling = sel(grid_scaling)
+        binary_grid_masks = sel(binary_all)
 
     ob_view = anchor - viewpoint_camera.camera_center                                   # :106-110
     ob_dist = ob_view.norm(dim=1, keepdim=True)

@@ -222,6 +222,19 @@ int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       float *db1, float *dW2, float *db2, int64_t n,
                       void *stream);
 
+/* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
+ * scene/gaussian_model.py:1556; compressai is not in the mount, the density is
+ * the one of utils/entropy_models.py:103-138 with filters (3,3,3,3)).  v, lik,
+ * g_lik, g_v are [n, C] row-major; raw / g_raw are [C, 58] packed raw
+ * parameters per channel: M0 3, B0 3, F0 3, then (M 9, B 3, F 3) x 3, M4 3, B4 1
+ * (matrices pass through softplus, factors through tanh inside the kernel).
+ * lik = max(|sigmoid(s u) - sigmoid(s l)|, 1e-9). g_raw is ACCUMULATED into. */
+int cgs_eb_likelihood_fwd(const float *v, const float *raw, int64_t n, int C,
+                          float *lik, void *stream);
+int cgs_eb_likelihood_bwd(const float *v, const float *raw, const float *g_lik,
+                          int64_t n, int C, float *g_v, float *g_raw,
+                          void *stream);
+
 /* ------------------------------------------------------------------ */
 /* Entropy coding (torchac / compressai call sites of the reference)     */
 /* ------------------------------------------------------------------ */
