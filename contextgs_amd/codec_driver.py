@@ -126,7 +126,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         n_l = int(orig.shape[0])
         N_levels_list.append(n_l)
         if content_pre_gathered is None:
-            feat_in = torch.cat([hybrid_anchor, hyper_feat[orig].float()], dim=1)
+            feat_in = torch.cat([_anchor[orig], hyper_feat[orig].float()], dim=1)
         else:
             feat_in = torch.cat([content_pre_gathered, hyper_feat[orig].float()], dim=1)
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \

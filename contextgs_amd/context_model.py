@@ -101,7 +101,33 @@ def extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, alr
 def level_plan(pc, anchor, mask_anchor_bool):
     """Index bookkeeping of the level loop (:1559-1593), shared by the rate model, the
     encoder and the decoder.  Returns per level (from L-1 down to 0) the original-space
-    indices to code and the level anchors of those rows."""
+    indices to code and the level anchors of those rows.
+
+    The division depends only on (anchor, mask, voxel_size, level_scale); anchors are frozen
+    after densification (position lr = 0, arguments/__init__.py:86-87) and the anchor mask
+    changes rarely, so the plan of the previous call is reused when both tensors compare equal
+    (two elementwise compares + one host read instead of two device sorts and ~40 index
+    kernels; SURVEY §8a "caching opportunity")."""
+    key = (float(pc.voxel_size), tuple(float(v) for v in pc.level_scale), int(pc.level_num),
+           tuple(anchor.shape), mask_anchor_bool is None)
+    cache = getattr(pc, "_level_cache", None)
+    if cache is not None and cache["key"] == key:
+        same = (anchor == cache["anchor"]).all()
+        if mask_anchor_bool is not None:
+            same = same & (mask_anchor_bool == cache["mask"]).all()
+        if bool(same):
+            return cache["plan"], cache["inverse"], cache["mapping"]
+    plan, inverse_indices_list, mapping_list = _level_plan_uncached(pc, anchor, mask_anchor_bool)
+    try:
+        pc._level_cache = dict(key=key, anchor=anchor.detach().clone(),
+                               mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
+                               inverse=inverse_indices_list, mapping=mapping_list)
+    except Exception:
+        pass
+    return plan, inverse_indices_list, mapping_list
+
+
+def _level_plan_uncached(pc, anchor, mask_anchor_bool):
     hybrid_anchor_list, inverse_indices_list, mapping_list, _ = divide_levels(pc, anchor, mask_anchor_bool)
     n = anchor.shape[0]
     dev = anchor.device
@@ -117,8 +143,16 @@ def level_plan(pc, anchor, mask_anchor_bool):
             orig = mapping_to_orign(mapping_list, i, to_code)
         else:
             orig = torch.arange(n, device=dev)[to_code]
-        plan.append((i, to_code, orig, hybrid_anchor_list[i][to_code]))
+        plan.append((i, to_code, orig, None))     # level anchors are re-gathered from the live tensor: level_anchors()
     return plan, inverse_indices_list, mapping_list
+
+
+def level_anchors(anchor, mask_anchor_bool, level, orig):
+    """hybrid_anchor_list[level][to_code] of the reference (:1594): the rows `orig` of the anchors the level
+    was built from (masked anchors are zeroed from level 1 up, :1758-1759)."""
+    if level >= 1 and mask_anchor_bool is not None:
+        anchor = anchor * mask_anchor_bool.unsqueeze(1)
+    return anchor[orig]
 
 
 def grid_mlp(pc, level, feat_in):
@@ -181,7 +215,7 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
         pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
     plan, inverse_indices_list, mapping_list = level_plan(pc, anchor, mask_anchor_bool)
 
-    for (i, to_code, orig, hybrid_anchor) in plan:
+    for (i, to_code, orig, _unused) in plan:
         if int(orig.shape[0]) > 0:
             # rows of a level are distinct anchors -> sort-free gathers (reference: feat[mapping][to_code], :1569-1585)
             hybrid_feat = gather_unique(feat, orig)
@@ -189,7 +223,7 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
             hybrid_grid_offsets = gather_unique(grid_offsets, orig)
             hyper_l = gather_unique(hyper_feat, orig)
             if content_pre_gathered is None:                                           # :1596-1600
-                feat_in = torch.cat([hybrid_anchor, hyper_l.float()], dim=1)
+                feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyper_l.float()], dim=1)
             else:
                 feat_in = torch.cat([content_pre_gathered, hyper_l], dim=1)
             (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,

@@ -58,8 +58,12 @@ __global__ void __launch_bounds__(EX_THREADS)
 }
 
 #define EX_MAX_K 32
+#define EX_APB 32          // anchors per workgroup in the backward
 
-__global__ void __launch_bounds__(EX_THREADS)
+// One thread per slot (coalesced reads/writes of every per-slot array); the nine per-anchor sums
+// (d_anchor 3, d_gscaling 6) are reduced over the anchor's K slots with LDS float atomics.
+// Workgroup = EX_APB anchors x K slots.
+__global__ void __launch_bounds__(EX_APB * EX_MAX_K)
     expand_bwd_kernel(int64_t n_anchor, int K, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
                       const float *__restrict__ gscaling, const float *__restrict__ offsets,
                       const float *__restrict__ op_raw, const float *__restrict__ mask,
@@ -70,14 +74,21 @@ __global__ void __launch_bounds__(EX_THREADS)
                       float *__restrict__ d_anchor, float *__restrict__ d_gscaling, float *__restrict__ d_offsets,
                       float *__restrict__ d_op_raw, float *__restrict__ d_mask, float *__restrict__ d_color_in,
                       float *__restrict__ d_cov_in) {
-    const int64_t n = (int64_t)blockIdx.x * EX_THREADS + threadIdx.x;
-    if (n >= n_anchor) return;
-    float gs[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) gs[c] = gscaling[6 * n + c];
-    float da[3] = {0.f, 0.f, 0.f}, dgs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {
-        const int64_t i = n * K + k;
+    __shared__ float acc[EX_APB][9];
+    __shared__ float sgs[EX_APB][6];
+    const int tid = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * EX_APB;
+    for (int t = tid; t < EX_APB * 9; t += blockDim.x) acc[t / 9][t % 9] = 0.f;
+    for (int t = tid; t < EX_APB * 6; t += blockDim.x) {
+        const int64_t n = a0 + t / 6;
+        sgs[t / 6][t % 6] = n < n_anchor ? gscaling[6 * n + t % 6] : 0.f;
+    }
+    __syncthreads();
+    const int la = tid / K;                 // local anchor
+    const int64_t n = a0 + la;
+    const int64_t i = n * K + (tid - la * K);
+    if (la < EX_APB && n < n_anchor) {
+        const float *gs = sgs[la];
         float g_no = g_neural_opacity ? g_neural_opacity[i] : 0.f;
         float dcol[3] = {0.f, 0.f, 0.f}, doff[3] = {0.f, 0.f, 0.f}, dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (flags[i]) {
@@ -88,13 +99,13 @@ __global__ void __launch_bounds__(EX_THREADS)
             for (int c = 0; c < 3; ++c) {
                 dcol[c] = g_color[3 * j + c];
                 const float gx = g_xyz[3 * j + c];
-                da[c] += gx;
                 doff[c] = gx * gs[c];
-                dgs[c] += gx * offsets[3 * i + c];
                 const float sig = 1.f / (1.f + __expf(-sr[c]));
                 const float gsc = g_scaling[3 * j + c];
-                dgs[3 + c] += gsc * sig;
                 dsr[c] = gsc * gs[3 + c] * sig * (1.f - sig);
+                atomicAdd(&acc[la][c], gx);
+                atomicAdd(&acc[la][3 + c], gx * offsets[3 * i + c]);
+                atomicAdd(&acc[la][6 + c], gsc * sig);
             }
             const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
             const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
@@ -121,10 +132,15 @@ __global__ void __launch_bounds__(EX_THREADS)
 #pragma unroll
         for (int c = 0; c < 7; ++c) d_cov_in[7 * i + c] = dsr[c];
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) d_anchor[3 * n + c] = da[c];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) d_gscaling[6 * n + c] = dgs[c];
+    __syncthreads();
+    for (int t = tid; t < EX_APB * 9; t += blockDim.x) {
+        const int64_t nn = a0 + t / 9;
+        const int c = t % 9;
+        if (nn < n_anchor) {
+            if (c < 3) d_anchor[3 * nn + c] = acc[t / 9][c];
+            else d_gscaling[6 * nn + (c - 3)] = acc[t / 9][c];
+        }
+    }
 }
 
 int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
@@ -192,8 +208,8 @@ extern "C" int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flag
     if (n_anchor < 0 || K < 1 || K > EX_MAX_K) { cgs_set_error("expand_backward: bad args"); return CGS_ERR_ARG; }
     if (n_anchor == 0) return CGS_OK;
     CgsProfScope prof(CGS_PROF_EXPAND_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((n_anchor + EX_THREADS - 1) / EX_THREADS)),
-                       dim3(EX_THREADS), 0, (hipStream_t)stream, n_anchor, K, flags, pos, gscaling, offsets, op_raw,
+    hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((n_anchor + EX_APB - 1) / EX_APB)),
+                       dim3(EX_APB * K), 0, (hipStream_t)stream, n_anchor, K, flags, pos, gscaling, offsets, op_raw,
                        mask, cov_in, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_neural_opacity, d_anchor,
                        d_gscaling, d_offsets, d_op_raw, d_mask, d_color_in, d_cov_in);
     CGS_CHECK_HIP(hipGetLastError());

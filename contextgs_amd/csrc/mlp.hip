@@ -375,8 +375,10 @@ static int launch_wgrad(const float *P, int64_t ldp, int DA, const float *Q, int
     if (n <= 0) return CGS_OK;
     const int T = ((DA + 15) / 16) * ((DB + 15) / 16);
     const int tpw = (T + WAVES - 1) / WAVES;
+    // few, long-running workgroups: every workgroup ends with DA*DB same-address atomics, so their number
+    // (not the row count) sets the L2 atomic traffic
     int64_t blocks = (n + 1023) / 1024;
-    const int64_t cap = 4 * (int64_t)num_cus();
+    const int64_t cap = (int64_t)num_cus();
     if (blocks > cap) blocks = cap;
     int64_t rpb = (n + blocks - 1) / blocks;
     rpb = (rpb + 15) / 16 * 16;

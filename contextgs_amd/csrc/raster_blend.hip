@@ -11,6 +11,7 @@
 // All lanes read the same LDS record (broadcast ds_read_b128 x3).
 //
 // Semantics: SURVEY.md Appendix A (the CUDA source is not in the mount).
+#include <stdlib.h>
 #include "cgs_internal.h"
 
 #define BLEND_THREADS 256
@@ -175,8 +176,14 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 #define NGRAD 9   // Mx, My, Sa, Sb, Sc, dop, dr, dg, db
 
+template <int ABLATE>
 __global__ void __launch_bounds__(BLEND_THREADS)
     blend_bwd_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
@@ -274,16 +281,44 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                     v[7] = w * gg;
                     v[8] = w * gb;
                 }
+                if (ABLATE < 3) {
+                    // Transposing reduction: instead of 9 independent 6-step wave sums (54 DPP adds) and 9 LDS
+                    // atomics from one lane, two butterfly stages fold the 8 values v0..v7 onto the lanes of
+                    // each quad (lane l ends up owning value 4j + (l&3)), two row rotations finish the sum over
+                    // the 16-lane row, and the four rows add their partials with ONE ds_add_f32 (4-way same-
+                    // address conflicts only).  26 VALU + 1 LDS instruction per (wave, Gaussian).
+                    const bool b0 = lane & 1, b1 = lane & 2;
+                    float a4[4], b2[2];
 #pragma unroll
-                for (int k = 0; k < NGRAD; ++k) v[k] = wave_sum_to_lane63(v[k]);
-                if (lane == 63) {
+                    for (int j = 0; j < 4; ++j) {
+                        const float keep = b0 ? v[2 * j + 1] : v[2 * j], send = b0 ? v[2 * j] : v[2 * j + 1];
+                        a4[j] = keep + dpp_move<0xB1>(send);          // quad_perm [1,0,3,2]
+                    }
 #pragma unroll
-                    for (int k = 0; k < NGRAD; ++k) atomicAdd(&sacc[e][k], v[k]);
+                    for (int j = 0; j < 2; ++j) {
+                        const float keep = b1 ? a4[2 * j + 1] : a4[2 * j], send = b1 ? a4[2 * j] : a4[2 * j + 1];
+                        b2[j] = keep + dpp_move<0x4E>(send);          // quad_perm [2,3,0,1]
+                    }
+                    float c8 = v[8];
+                    c8 += dpp_move<0xB1>(c8);
+                    c8 += dpp_move<0x4E>(c8);
+                    b2[0] += dpp_move<0x124>(b2[0]); b2[0] += dpp_move<0x128>(b2[0]);   // row_ror:4, row_ror:8
+                    b2[1] += dpp_move<0x124>(b2[1]); b2[1] += dpp_move<0x128>(b2[1]);
+                    c8 += dpp_move<0x124>(c8); c8 += dpp_move<0x128>(c8);
+                    const int sub = lane & 15;
+                    if (ABLATE < 2) {
+                        if (sub < NGRAD) atomicAdd(&sacc[e][sub], sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8));
+                    } else {
+                        asm volatile("" ::"v"(b2[0]), "v"(b2[1]), "v"(c8));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NGRAD; ++k) asm volatile("" ::"v"(v[k]));
                 }
             }
         }
         __syncthreads();
-        if (pos < tlast) {
+        if (pos < tlast && ABLATE < 1) {
             const uint32_t g = sgid[tid];
             const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
                         a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],
@@ -310,12 +345,16 @@ int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
-                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
-                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg,
-                       (const float *)im.final_T, (const uint32_t *)im.n_contrib,
-                       (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity,
-                       dL_dcolors);
+    static int ablate = -1;     // CGS_BWD_ABLATE=1..3: timing experiments only (wrong results)
+    if (ablate < 0) { const char *e = getenv("CGS_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }
+#define BWD_LAUNCH(A)                                                                                               \
+    hipLaunchKernelGGL(blend_bwd_kernel<A>, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,             \
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,                          \
+                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, (const float *)im.final_T,   \
+                       (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px,      \
+                       dL_dconic, dL_dopacity, dL_dcolors)
+    switch (ablate) { case 1: BWD_LAUNCH(1); break; case 2: BWD_LAUNCH(2); break; case 3: BWD_LAUNCH(3); break; default: BWD_LAUNCH(0); }
+#undef BWD_LAUNCH
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 }
