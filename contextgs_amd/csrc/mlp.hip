@@ -332,6 +332,9 @@ __global__ void __launch_bounds__(WAVES * 64)
 }
 
 // ------------------------------------------------------------------------------------------
+int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
+                      int64_t n, int num_cus, hipStream_t s);
+
 static int num_cus() {
     static int cus = 0;
     if (!cus) {
@@ -457,6 +460,6 @@ extern "C" int cgs_mlp2_backward(int in, int hid, int out, int act, const float 
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
     const float *P2 = (act == ACT_NONE || !dZ2) ? dY : dZ2;
     const int64_t ldp2 = (act == ACT_NONE || !dZ2) ? ldy : out;
-    if ((rc = launch_wgrad(P2, ldp2, out, H, hid, hid, dW2, db2, n, stream))) return rc;
-    return launch_wgrad(dZ1, hid, hid, X, ldx, in, dW1, db1, n, stream);
+    if ((rc = cgs_launch_wgrad2(P2, ldp2, out, H, hid, hid, dW2, db2, n, num_cus(), stream))) return rc;
+    return cgs_launch_wgrad2(dZ1, hid, hid, X, ldx, in, dW1, db1, n, num_cus(), stream);
 }

@@ -1,0 +1,33 @@
+# HBM traffic of the dominant kernels via PMC counters, collected in their OWN passes (no trace flags), as
+# MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots).
+set -x
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-raster-only --no-codec --step-semantics 1000"
+rm -rf /tmp/pmc_r /tmp/pmc_w
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -o r -- $CMD > gpurun_out/pmc_r.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- $CMD > gpurun_out/pmc_w.log 2>&1
+python - <<'PY'
+import csv, glob, collections
+out = []
+for tag, d in (("FETCH_SIZE", "/tmp/pmc_r"), ("WRITE_SIZE", "/tmp/pmc_w")):
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != tag:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+    out.append((tag, agg))
+with open("gpurun_out/pmc_hbm_summary.txt", "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per-dispatch averages in KiB-units as reported\n")
+    f.write("# NOTE (MI355X_MICROARCH.md): on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x\n")
+    for tag, agg in out:
+        f.write(f"\n[{tag}]\n")
+        for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+            f.write(f"{n:6d} dispatches  avg {tot/n:14.1f}  total {tot:16.1f}  {k[:90]}\n")
+print(open("gpurun_out/pmc_hbm_summary.txt").read())
+PY
