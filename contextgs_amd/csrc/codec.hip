@@ -27,45 +27,85 @@
 // ---------------------------------------------------------------------------------
 // bit I/O
 // ---------------------------------------------------------------------------------
+__host__ __device__ inline int clz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v ? __clz((int)v) : 32;
+#else
+    return v ? __builtin_clz(v) : 32;
+#endif
+}
+
 struct BitWriter {
     uint8_t *p;
     uint8_t *end;
-    uint32_t cache;
-    int count;
+    uint64_t acc;     // pending output bits (< 8 between calls), MSB first
+    int nacc;
     bool overflow;
-    __host__ __device__ void init(uint8_t *buf, size_t cap) { p = buf; end = buf + cap; cache = 0; count = 0; overflow = false; }
-    __host__ __device__ void put(int bit) {
-        cache = (cache << 1) | (uint32_t)bit;
-        if (++count == 8) {
-            if (p < end) *p++ = (uint8_t)cache; else overflow = true;
-            count = 0;
-            cache = 0;
+    bool writer;      // wave-cooperative coders keep the state in every lane but let only one lane store
+    __host__ __device__ void init(uint8_t *buf, size_t cap) { p = buf; end = buf + cap; acc = 0; nacc = 0; overflow = false; writer = true; }
+    // append the low n bits of v (n <= 32), MSB first
+    __host__ __device__ void put_bits(uint32_t v, int n) {
+        acc = (acc << n) | (uint64_t)v;
+        nacc += n;
+        while (nacc >= 8) {
+            const uint8_t byte = (uint8_t)(acc >> (nacc - 8));
+            if (p < end) { if (writer) *p = byte; ++p; } else overflow = true;
+            nacc -= 8;
         }
+        acc &= 0xFFu;             // only the < 8 leftover bits matter
     }
     __host__ __device__ void put_with_pending(int bit, uint64_t &pending) {
-        put(bit);
-        while (pending > 0) { put(!bit); --pending; }
+        put_bits((uint32_t)bit, 1);
+        while (pending > 0) {
+            const int n = pending > 31 ? 31 : (int)pending;
+            put_bits(bit ? 0u : ((1u << n) - 1u), n);
+            pending -= (uint64_t)n;
+        }
     }
-    __host__ __device__ void flush() { while (count != 0) put(0); }
+    __host__ __device__ void flush() { if (nacc > 0) put_bits(0u, 8 - nacc); }
 };
 
 struct BitReader {
     const uint8_t *buf;
-    uint64_t nbits;
-    uint64_t pos;
-    __host__ __device__ void init(const uint8_t *b, size_t len) { buf = b; nbits = (uint64_t)len * 8; pos = 0; }
-    // shifts one bit into value, MSB first (zeros past the end of the stream)
-    __host__ __device__ void get(uint32_t &value) {
-        uint32_t bit = 0;
-        if (pos < nbits) bit = ((uint32_t)buf[pos >> 3] >> (7u - (uint32_t)(pos & 7u))) & 1u;
-        ++pos;
-        value = (value << 1) | bit;
+    uint64_t len;
+    uint64_t pos;     // bit position
+    __host__ __device__ void init(const uint8_t *b, size_t n) { buf = b; len = (uint64_t)n; pos = 0; }
+    // next n bits (1..32), MSB first; zeros past the end of the stream
+    __host__ __device__ uint32_t get_bits(int n) {
+        const uint64_t idx = pos >> 3;
+        uint64_t w = 0;
+        for (int t = 0; t < 5; ++t) w = (w << 8) | (idx + t < len ? (uint64_t)buf[idx + t] : 0ull);
+        const int shift = 40 - (int)(pos & 7u) - n;
+        pos += (uint64_t)n;
+        return (uint32_t)((w >> shift) & ((1ull << n) - 1ull));
     }
 };
 
 // ---------------------------------------------------------------------------------
 // arithmetic coder core
 // ---------------------------------------------------------------------------------
+// Renormalisation is done in bulk: the published bit-at-a-time loop always runs as (equal leading
+// bits)* (underflow steps)*, so k = clz(low ^ high) settled bits are emitted at once (the first one
+// followed by the pending run) and u = min(leading ones of low<<1, leading zeros of high<<1)
+// underflow steps are applied at once.  Bit-for-bit the same stream as the per-bit loop
+// (tests/test_codec.py pins it against the pure-Python bit-list oracle).
+struct AcRenorm { int k, u; };
+
+__host__ __device__ inline AcRenorm ac_renorm(uint32_t &low, uint32_t &high) {
+    AcRenorm r;
+    r.k = clz32(low ^ high);
+    if (r.k >= 32) { low = 0; high = 0xFFFFFFFFu; r.u = 0; return r; }
+    if (r.k > 0) { low <<= r.k; high = (high << r.k) | ((1u << r.k) - 1u); }
+    const uint32_t hs = high << 1;
+    const int ones = clz32(~(low << 1)), zeros = hs ? clz32(hs) : 31;
+    r.u = ones < zeros ? ones : zeros;
+    if (r.u > 0) {
+        low = (low << r.u) & 0x7FFFFFFFu;
+        high = (high << r.u) | 0x80000000u | ((1u << r.u) - 1u);
+    }
+    return r;
+}
+
 struct AcEncoder {
     uint32_t low, high;
     uint64_t pending;
@@ -75,21 +115,14 @@ struct AcEncoder {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
         low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
-        for (;;) {
-            if (high < 0x80000000u) {
-                out.put_with_pending(0, pending);
-                low <<= 1; high = (high << 1) | 1u;
-            } else if (low >= 0x80000000u) {
-                out.put_with_pending(1, pending);
-                low <<= 1; high = (high << 1) | 1u;
-            } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                ++pending;
-                low = (low << 1) & 0x7FFFFFFFu;
-                high = (high << 1) | 0x80000001u;
-            } else {
-                break;
-            }
+        const uint32_t settled = low;            // its top k bits are the bits to emit
+        const AcRenorm r = ac_renorm(low, high);
+        if (r.k > 0) {
+            const uint32_t bits = r.k >= 32 ? settled : (settled >> (32 - r.k));
+            out.put_with_pending((int)((bits >> (r.k - 1)) & 1u), pending);
+            if (r.k > 1) out.put_bits(bits & ((1u << (r.k - 1)) - 1u), r.k - 1);
         }
+        pending += (uint64_t)r.u;
     }
     __host__ __device__ size_t finish(uint8_t *base) {
         ++pending;
@@ -103,9 +136,9 @@ struct AcDecoder {
     uint32_t low, high, value;
     BitReader in;
     __host__ __device__ void init(const uint8_t *buf, size_t len) {
-        low = 0; high = 0xFFFFFFFFu; value = 0;
+        low = 0; high = 0xFFFFFFFFu;
         in.init(buf, len);
-        for (int i = 0; i < 32; ++i) in.get(value);
+        value = in.get_bits(32);
     }
     __host__ __device__ uint32_t target() const {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
@@ -115,19 +148,11 @@ struct AcDecoder {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
         low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
-        for (;;) {
-            if (low >= 0x80000000u || high < 0x80000000u) {
-                low <<= 1; high = (high << 1) | 1u;
-                in.get(value);
-            } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                low = (low << 1) & 0x7FFFFFFFu;
-                high = (high << 1) | 0x80000001u;
-                value -= 0x40000000u;
-                in.get(value);
-            } else {
-                break;
-            }
-        }
+        const AcRenorm r = ac_renorm(low, high);
+        if (r.k >= 32) { value = in.get_bits(32); }
+        else if (r.k > 0) { value = (value << r.k) | in.get_bits(r.k); }
+        // u underflow steps: each is value = ((value - 2^30) << 1) | bit  ==  ((value << u) ^ 2^31) | bits
+        if (r.u > 0) value = ((value << r.u) ^ 0x80000000u) | in.get_bits(r.u);
     }
 };
 
@@ -276,6 +301,18 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+__device__ __forceinline__ float bcast_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+__device__ __forceinline__ uint32_t bcast_u(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
+}
+
+// ONE WAVE PER STREAM.  The 64 lanes evaluate the integer CDF entries of 64 consecutive symbols in
+// parallel (coalesced loads of x / mean / scale, 2 erff per lane), then the range coder — whose state is
+// wave-uniform — consumes them one by one via v_readlane; only lane 0 writes bytes.  All chunk streams of a
+// level/attribute run concurrently, one wave each, instead of one serial LANE each (which left 63/64 of
+// every wave and most of the chip idle: 190 ms per launch at 1 M anchors).
 __global__ void __launch_bounds__(64)
     gaussian_encode_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                            const float *__restrict__ scale, const float *__restrict__ Q, int64_t q_div,
@@ -283,39 +320,58 @@ __global__ void __launch_bounds__(64)
                            const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
                            uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
                            uint32_t *__restrict__ out_len, int32_t *__restrict__ status) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
     if (s >= n_streams) return;
     const int64_t b = stream_off[s], e = stream_off[s + 1];
     uint8_t *base = out + out_off[s];
     AcEncoder enc;
     enc.init(base, (size_t)(out_off[s + 1] - out_off[s]));
+    enc.out.writer = (lane == 0);
     const int lo = min_v[s];
     const int Lp = max_v[s] - lo + 2;
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
     bool bad = Lp > 65536;
-    for (int64_t i = b; i < e && !bad; ++i) {
-        const float q = Q[i / q_div];
-        const int sym = (int)rintf(x[i] / q) - lo;
-        if (sym < 0 || sym > max_sym) { bad = true; break; }
-        const float inv = 1.f / scale[i];
-        const float m = mean[i];
-        const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
-        const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
-        enc.encode(c_low, c_high);
+    for (int64_t i0 = b; i0 < e && !bad; i0 += 64) {
+        const int64_t i = i0 + lane;
+        uint32_t c_low = 0, c_high = 1;
+        bool my_bad = false;
+        if (i < e) {
+            const float q = Q[i / q_div];
+            const int sym = (int)rintf(x[i] / q) - lo;
+            if (sym < 0 || sym > max_sym) {
+                my_bad = true;
+            } else {
+                const float inv = 1.f / scale[i];
+                const float m = mean[i];
+                c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+                c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+            }
+        }
+        if (__ballot(my_bad) != 0ull) { bad = true; break; }
+        const int cnt = (int)min((int64_t)64, e - i0);
+        for (int j = 0; j < cnt; ++j) enc.encode(bcast_u(c_low, j), bcast_u(c_high, j));
     }
-    out_len[s] = (uint32_t)enc.finish(base);
-    if (bad) atomicMax(status, 1);
-    if (enc.out.overflow) atomicMax(status, 2);
+    const uint32_t len = (uint32_t)enc.finish(base);
+    if (lane == 0) {
+        out_len[s] = len;
+        if (bad) atomicMax(status, 1);
+        if (enc.out.overflow) atomicMax(status, 2);
+    }
 }
 
+// Decoder, same mapping: per symbol the 64 lanes evaluate 64 consecutive CDF entries at once and a ballot
+// replaces the binary search (one erff of latency instead of log2(L) dependent ones); distribution
+// parameters are fetched 64 symbols at a time, coalesced, and broadcast with v_readlane.
 __global__ void __launch_bounds__(64)
     gaussian_decode_kernel(const float *__restrict__ mean, const float *__restrict__ scale,
                            const float *__restrict__ Q, int64_t q_div, const int64_t *__restrict__ stream_off,
                            int n_streams, const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
                            const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off,
                            float *__restrict__ x_out) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
     if (s >= n_streams) return;
     const int64_t b = stream_off[s], e = stream_off[s + 1];
     AcDecoder dec;
@@ -324,16 +380,33 @@ __global__ void __launch_bounds__(64)
     const int Lp = max_v[s] - lo + 2;
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
-    for (int64_t i = b; i < e; ++i) {
-        const float q = Q[i / q_div];
-        const float inv = 1.f / scale[i];
-        const float m = mean[i];
-        const int sym = ac_search([&](int j) { return gaussian_cdf_int(j, lo, norm, m, inv, q); }, dec.target(), max_sym);
-        x_out[i] = (float)(sym + lo) * q;
-        if (i == e - 1) break;
-        const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
-        const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
-        dec.consume(c_low, c_high);
+    for (int64_t i0 = b; i0 < e; i0 += 64) {
+        const int64_t i = i0 + lane;
+        float q_l = 1.f, m_l = 0.f, inv_l = 1.f;
+        if (i < e) {
+            q_l = Q[i / q_div];
+            m_l = mean[i];
+            inv_l = 1.f / scale[i];
+        }
+        float x_l = 0.f;
+        const int cnt = (int)min((int64_t)64, e - i0);
+        for (int j = 0; j < cnt; ++j) {
+            const float q = bcast_f(q_l, j), m = bcast_f(m_l, j), inv = bcast_f(inv_l, j);
+            const uint32_t target = dec.target();
+            int sym = 0;
+            for (int cb = 0;; cb += 64) {
+                const int cand = cb + lane;
+                const bool le = cand <= max_sym && gaussian_cdf_int(cand, lo, norm, m, inv, q) <= target;
+                const int n_le = __builtin_popcountll(__ballot(le));     // the CDF is strictly increasing: a prefix
+                if (n_le < 64 || cb + 64 > max_sym) { sym = max(0, cb + n_le - 1); break; }
+            }
+            if (lane == j) x_l = (float)(sym + lo) * q;
+            if (i0 + j == e - 1) break;
+            const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+            const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+            dec.consume(c_low, c_high);
+        }
+        if (i < e) x_out[i] = x_l;
     }
 }
 
@@ -388,7 +461,7 @@ extern "C" int cgs_gaussian_ac_encode(const float *x, const float *mean, const f
                                       int32_t *status, void *stream) {
     if (n_streams < 0 || q_div < 1) { cgs_set_error("gaussian_ac_encode: bad args"); return CGS_ERR_ARG; }
     if (n_streams == 0) return CGS_OK;
-    hipLaunchKernelGGL(gaussian_encode_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, mean,
+    hipLaunchKernelGGL(gaussian_encode_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, x, mean,
                        scale, Q, q_div, stream_off, n_streams, min_v, max_v, out, out_off, out_len, status);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
@@ -400,7 +473,7 @@ extern "C" int cgs_gaussian_ac_decode(const float *mean, const float *scale, con
                                       void *stream) {
     if (n_streams < 0 || q_div < 1) { cgs_set_error("gaussian_ac_decode: bad args"); return CGS_ERR_ARG; }
     if (n_streams == 0) return CGS_OK;
-    hipLaunchKernelGGL(gaussian_decode_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean,
+    hipLaunchKernelGGL(gaussian_decode_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, mean,
                        scale, Q, q_div, stream_off, n_streams, min_v, max_v, in, in_off, x_out);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
