@@ -8,8 +8,17 @@ Same level semantics including the reference's quirks (level-1
 context rows are paired in lexicographic-voxel order vs ascending original
 index; Q4: the training variant zeroes masked anchors before level 1; Q5:
 fp32 left-to-right voxel key).  Quantisation and rate run in the fused HIP
-kernels of elementwise.hip (encodings.STE_multistep, entropy_models);
-grid MLPs go through rocBLAS (north_star).
+kernels of elementwise.hip (encodings.STE_multistep, entropy_models), the grid
+MLPs in the fused fp32-MFMA kernels of mlp.hip.
+
+Data layout of the fast path: the rows each level codes are disjoint and
+together cover every anchor, so the per-anchor tensors are gathered ONCE into
+"coding order" (level L-1 rows, then L-2, ..., then level 0) and every level
+works on a contiguous slice; context rows are gathered from the already-coded
+prefix; the N-ordered outputs the reference returns are one inverse gather at
+the end (or none: the renderer composes it with its visibility gather).  The
+reference instead scatters into / gathers from N-sized buffers at every level
+(:1569-1647), ~30 full-size passes per call.
 
 Cited lines are scene/gaussian_model.py unless stated otherwise.
 """
@@ -84,16 +93,21 @@ def divide_levels(pc, anchor, mask_anchor_bool=None):                   # :1751-
     return hybrid_anchor_list, inverse_indices_list, mapping_list, hybrid_anchor
 
 
-def extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, already_coded, inverse_indices_list,
-                         mapping_list, i):                              # :1711-1724
-    n = anchor_after_Q.shape[0]
+def _context_index(n, already_coded, inverse_indices_list, mapping_list, i):
+    """Original-space indices of the context rows extract_context_feat(i) gathers (:1713-1721)."""
+    dev = already_coded.device
     if i > 1:
-        to_be_gathered_mask = torch.zeros(n, dtype=torch.bool, device=anchor_after_Q.device)
+        to_be_gathered_mask = torch.zeros(n, dtype=torch.bool, device=dev)
         to_be_gathered_mask[mapping_to_orign(mapping_list, i - 1)] = True
     else:
-        to_be_gathered_mask = torch.ones(n, dtype=torch.bool, device=anchor_after_Q.device)
+        to_be_gathered_mask = torch.ones(n, dtype=torch.bool, device=dev)
     to_be_gathered_mask = to_be_gathered_mask & (~already_coded)
-    idx = index_of_level_L_in_orign(mapping_list, inverse_indices_list, torch.nonzero(to_be_gathered_mask)[:, 0], i)
+    return index_of_level_L_in_orign(mapping_list, inverse_indices_list, torch.nonzero(to_be_gathered_mask)[:, 0], i)
+
+
+def extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, already_coded, inverse_indices_list,
+                         mapping_list, i):                              # :1711-1724
+    idx = _context_index(anchor_after_Q.shape[0], already_coded, inverse_indices_list, mapping_list, i)
     # gather three row blocks instead of materialising the [N,59] concat (:1712) every level
     return torch.cat([anchor_after_Q[idx], feat_after_Q[idx], grid_scaling_after_Q[idx]], dim=1)
 
@@ -101,13 +115,18 @@ def extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, alr
 def level_plan(pc, anchor, mask_anchor_bool):
     """Index bookkeeping of the level loop (:1559-1593), shared by the rate model, the
     encoder and the decoder.  Returns per level (from L-1 down to 0) the original-space
-    indices to code and the level anchors of those rows.
+    indices to code.
 
     The division depends only on (anchor, mask, voxel_size, level_scale); anchors are frozen
     after densification (position lr = 0, arguments/__init__.py:86-87) and the anchor mask
     changes rarely, so the plan of the previous call is reused when both tensors compare equal
     (two elementwise compares + one host read instead of two device sorts and ~40 index
     kernels; SURVEY §8a "caching opportunity")."""
+    c = _cached_plan(pc, anchor, mask_anchor_bool)
+    return c["plan"], c["inverse"], c["mapping"]
+
+
+def _cached_plan(pc, anchor, mask_anchor_bool):
     key = (float(pc.voxel_size), tuple(float(v) for v in pc.level_scale), int(pc.level_num),
            tuple(anchor.shape), mask_anchor_bool is None)
     cache = getattr(pc, "_level_cache", None)
@@ -116,29 +135,46 @@ def level_plan(pc, anchor, mask_anchor_bool):
         if mask_anchor_bool is not None:
             same = same & (mask_anchor_bool == cache["mask"]).all()
         if bool(same):
-            return cache["plan"], cache["inverse"], cache["mapping"]
+            return cache
     plan, inverse_indices_list, mapping_list = _level_plan_uncached(pc, anchor, mask_anchor_bool)
+    n = anchor.shape[0]
+    dev = anchor.device
+    # coding order: perm = [rows of level L-1, rows of level L-2, ..., rows of level 0]
+    origs = [p[2] for p in plan]
+    perm = torch.cat(origs) if origs else torch.zeros(0, dtype=torch.long, device=dev)
+    inv_perm = torch.zeros(n, dtype=torch.long, device=dev)
+    inv_perm[perm] = torch.arange(perm.shape[0], device=dev)
+    sizes = [int(o.shape[0]) for o in origs]
+    # context rows (original space, and as positions in coding order) that the level coded AFTER level i needs
+    already = torch.zeros(n, dtype=torch.bool, device=dev)
+    ctx_idx, ctx_pos = {}, {}
+    for (i, _tc, orig, _a) in plan:
+        already[orig] = True
+        if i != 0:
+            idx = _context_index(n, already, inverse_indices_list, mapping_list, i)
+            ctx_idx[i] = idx
+            ctx_pos[i] = inv_perm[idx]
+    cache = dict(key=key, anchor=anchor.detach().clone(),
+                 mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
+                 inverse=inverse_indices_list, mapping=mapping_list, perm=perm, inv_perm=inv_perm, sizes=sizes,
+                 ctx_idx=ctx_idx, ctx_pos=ctx_pos, covers_all=bool(perm.shape[0] == n))
     try:
-        pc._level_cache = dict(key=key, anchor=anchor.detach().clone(),
-                               mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
-                               inverse=inverse_indices_list, mapping=mapping_list)
+        pc._level_cache = cache
     except Exception:
         pass
-    return plan, inverse_indices_list, mapping_list
+    return cache
 
 
 def _level_plan_uncached(pc, anchor, mask_anchor_bool):
-    hybrid_anchor_list, inverse_indices_list, mapping_list, _ = divide_levels(pc, anchor, mask_anchor_bool)
+    _hl, inverse_indices_list, mapping_list, _ = divide_levels(pc, anchor, mask_anchor_bool)
     n = anchor.shape[0]
     dev = anchor.device
     plan = []
     for i in reversed(range(pc.level_num)):
         n_level = n if i == 0 else mapping_list[i - 1].shape[0]
+        to_code = torch.ones(n_level, dtype=torch.bool, device=dev)
         if i != pc.level_num - 1:
-            to_code = torch.ones(n_level, dtype=torch.bool, device=dev)
             to_code[mapping_list[i]] = False
-        else:
-            to_code = torch.ones(n_level, dtype=torch.bool, device=dev)
         if i != 0:
             orig = mapping_to_orign(mapping_list, i, to_code)
         else:
@@ -194,72 +230,74 @@ def gather_unique(x, idx):
     return _GatherUnique.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
 
 
-def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
-                           mask_anchor_bool=None, training=False, predict_bpp=False, return_sum_bits=False):   # :1541-1707
+def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
+                               keep_stats):
+    """The level loop of multi_scale_generating (:1556-1652) in coding order.
+
+    Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
+    likelihood_hyper [N-ordered], levels) where `levels` holds, per coded level, the slices the rate model
+    needs (only when keep_stats)."""
     K = pc.n_offsets
-    n = anchor.shape[0]
-    dev = anchor.device
-    content_pre_gathered = None
-    levels = []          # per coded level: everything the rate model needs, in the level's own row order
-
-    feat_after_Q = torch.zeros_like(feat)
-    grid_scaling_after_Q = torch.zeros_like(grid_scaling)
-    grid_offsets_after_Q = torch.zeros_like(grid_offsets)
-    already_coded = torch.zeros(n, dtype=torch.bool, device=dev)
-
     hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)           # :1556
     if pc.disable_hyper:
         hyper_feat = hyper_feat * 0
     if pc.level_scale is None:                                                         # :1559
         sel = anchor[mask_anchor_bool] if mask_anchor_bool is not None else anchor
         pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
-    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor, mask_anchor_bool)
+    c = _cached_plan(pc, anchor, mask_anchor_bool)
+    perm, sizes = c["perm"], c["sizes"]
 
-    for (i, to_code, orig, _unused) in plan:
-        if int(orig.shape[0]) > 0:
-            # rows of a level are distinct anchors -> sort-free gathers (reference: feat[mapping][to_code], :1569-1585)
-            hybrid_feat = gather_unique(feat, orig)
-            hybrid_grid_scaling = gather_unique(grid_scaling, orig)
-            hybrid_grid_offsets = gather_unique(grid_offsets, orig)
-            hyper_l = gather_unique(hyper_feat, orig)
+    # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
+    feat_l = torch.split(gather_unique(feat, perm), sizes)
+    scal_l = torch.split(gather_unique(grid_scaling, perm), sizes)
+    off_l = torch.split(gather_unique(grid_offsets, perm), sizes)
+    hyp_l = torch.split(gather_unique(hyper_feat, perm), sizes)
+
+    feat_q, scal_q, off_q, levels = [], [], [], []
+    content_pre_gathered = None
+    for j, (i, _tc, orig, _a) in enumerate(c["plan"]):
+        n_l = sizes[j]
+        if n_l > 0:
             if content_pre_gathered is None:                                           # :1596-1600
-                feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyper_l.float()], dim=1)
+                feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
             else:
-                feat_in = torch.cat([content_pre_gathered, hyper_l], dim=1)
+                feat_in = torch.cat([content_pre_gathered, hyp_l[j]], dim=1)
             (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,
              Q_offsets) = split_prediction(pc, grid_mlp(pc, i, feat_in))
-
+            hf, hs, ho = feat_l[j], scal_l[j], off_l[j]
+            qo = Q_offsets.view(n_l, K, -1) if pc.adaptQ_per_channel else Q_offsets.unsqueeze(1)
             if training:                                                               # :1610-1616
-                hybrid_feat = hybrid_feat + torch.empty_like(hybrid_feat).uniform_(-0.5, 0.5) * Q_feat
-                hybrid_grid_scaling = hybrid_grid_scaling + torch.empty_like(hybrid_grid_scaling).uniform_(-0.5, 0.5) * Q_scaling
-                qo = Q_offsets.view(hybrid_feat.shape[0], K, -1) if pc.adaptQ_per_channel else Q_offsets.unsqueeze(1)
-                hybrid_grid_offsets = hybrid_grid_offsets + torch.empty_like(hybrid_grid_offsets).uniform_(-0.5, 0.5) * qo
+                hf = hf + torch.empty_like(hf).uniform_(-0.5, 0.5) * Q_feat
+                hs = hs + torch.empty_like(hs).uniform_(-0.5, 0.5) * Q_scaling
+                ho = ho + torch.empty_like(ho).uniform_(-0.5, 0.5) * qo
             else:                                                                      # :1617-1625
-                hybrid_feat = STE_multistep.apply(hybrid_feat, Q_feat).detach()
-                hybrid_grid_scaling = STE_multistep.apply(hybrid_grid_scaling, Q_scaling).detach()
-                qo = Q_offsets.view(hybrid_feat.shape[0], K, -1) if pc.adaptQ_per_channel else Q_offsets.unsqueeze(1)
-                hybrid_grid_offsets = STE_multistep.apply(hybrid_grid_offsets, qo).detach()
-            hybrid_grid_offsets = hybrid_grid_offsets.reshape(-1, 3 * K)
+                hf = STE_multistep.apply(hf, Q_feat).detach()
+                hs = STE_multistep.apply(hs, Q_scaling).detach()
+                ho = STE_multistep.apply(ho, qo).detach()
+            ho = ho.reshape(-1, 3 * K)
+            if keep_stats:
+                levels.append(dict(level=i, orig=orig, feat=hf, scaling=hs, offsets=ho, mf=mean_feat, sf=scale_feat,
+                                   qf=Q_feat, ms=mean_scaling, ss=scale_scaling, qs=Q_scaling, mo=mean_offsets,
+                                   so=scale_offsets, qo=Q_offsets))
+        else:
+            hf, hs, ho = feat_l[j], scal_l[j], off_l[j].reshape(-1, 3 * K)
+        feat_q.append(hf)
+        scal_q.append(hs)
+        off_q.append(ho)
+        if i != 0:                                                                     # :1650-1651 / 1711-1724
+            idx, pos = c["ctx_idx"][i], c["ctx_pos"][i]
+            base_f = feat_q[0] if len(feat_q) == 1 else torch.cat(feat_q, dim=0)       # coded prefix (<= 20 % of N)
+            base_s = scal_q[0] if len(scal_q) == 1 else torch.cat(scal_q, dim=0)
+            content_pre_gathered = torch.cat([anchor[idx], base_f[pos], base_s[pos]], dim=1)
+    cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    return c, cat(feat_q), cat(scal_q), cat(off_q).view(-1, K, 3), likelihood_hyper, levels
 
-            if predict_bpp:
-                # The reference scatters these nine tensors into N-sized buffers (:1629-1641) and gathers the
-                # 15 % rate subset back out (:1666-1669); the subset of a level is gathered from the level's own
-                # rows instead — same elements, no N-sized round trip.
-                levels.append(dict(orig=orig, feat=hybrid_feat, scaling=hybrid_grid_scaling, offsets=hybrid_grid_offsets,
-                                   mf=mean_feat, sf=scale_feat, qf=Q_feat, ms=mean_scaling, ss=scale_scaling, qs=Q_scaling,
-                                   mo=mean_offsets, so=scale_offsets, qo=Q_offsets))
-            feat_after_Q[orig] = hybrid_feat                                           # :1644-1647
-            grid_scaling_after_Q[orig] = hybrid_grid_scaling
-            grid_offsets_after_Q[orig] = hybrid_grid_offsets.view(-1, K, 3)
-            already_coded[orig] = True
-        if i != 0:                                                                     # :1650-1651
-            content_pre_gathered = extract_context_feat(anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
-                                                        inverse_indices_list, mapping_list, i)
 
-    if not predict_bpp:
-        return feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q
-
-    # ---- rate (:1657-1707) ----------------------------------------------------------------
+def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, return_sum_bits):
+    """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows."""
+    K = pc.n_offsets
+    n = anchor.shape[0]
+    dev = anchor.device
     thresh = 1 if return_sum_bits else 0.15
     choose_mask = torch.rand_like(anchor[:, 0]) <= thresh
     if mask_anchor_bool is not None:
@@ -309,6 +347,42 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
     each_level_bpp = [host[0], host[1]]
     for li, L in enumerate(levels):
         each_level_bpp.append([L["orig"].shape[0] / n, host[2 + li]])
+    return bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, each_level_bpp
 
-    return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q, bit_per_param, bit_per_feat_param,
-            bit_per_scaling_param, bit_per_offsets_param, each_level_bpp)
+
+def _unpermute(c, t):
+    """coding order -> anchor order; anchors no level codes (none in practice: level 0 takes every leftover)
+    read as zeros like the reference's zero-initialised buffers (:1547-1549)."""
+    if c["covers_all"]:
+        return gather_unique(t, c["inv_perm"])
+    out = torch.zeros((c["inv_perm"].shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return out.index_copy(0, c["perm"], t)
+
+
+def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
+                           mask_anchor_bool=None, training=False, predict_bpp=False, return_sum_bits=False):   # :1541-1707
+    c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
+        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp)
+    if predict_bpp and return_sum_bits:
+        return rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, True)
+    feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q = (_unpermute(c, t) for t in (feat_p, scal_p, off_p))
+    if not predict_bpp:
+        return feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q
+    rates = rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False)
+    return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q) + tuple(rates)
+
+
+def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
+                                   mask_anchor_bool, vis_idx, training, predict_bpp):
+    """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
+    two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]]."""
+    c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
+        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp)
+    if c["covers_all"]:
+        pos = c["inv_perm"][vis_idx]
+        outs = tuple(gather_unique(t, pos) for t in (feat_p, scal_p, off_p))
+    else:
+        outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
+    if not predict_bpp:
+        return outs
+    return outs + tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False))

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, mlp
-from .context_model import gather_unique, multi_scale_generating
+from .context_model import gather_unique, multi_scale_generating, multi_scale_generating_visible
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 Q_FEAT, Q_SCALING, Q_OFFSETS = 1, 0.001, 0.2      # :40-42
@@ -123,42 +123,29 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
     vis_idx = torch.nonzero(visible_mask)[:, 0]
     sel = lambda t: gather_unique(t, vis_idx)
-    full_anchor = pc.get_anchor
+    full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
+    use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
     anchor = sel(full_anchor)
-    feat = sel(pc._anchor_feat)
-    grid_offsets = sel(pc._offset)
-    grid_scaling = sel(pc.get_scaling)
-    binary_grid_masks = sel(pc.get_mask)
-
-    if is_training:
-        if 3000 < step <= 10000:                                                        # :54-58
+    if not use_context:
+        feat = sel(pc._anchor_feat)
+        grid_offsets = sel(pc._offset)
+        grid_scaling = sel(pc.get_scaling)
+        binary_grid_masks = sel(pc.get_mask)
+        if is_training and 3000 < step <= 10000:                                        # :54-58
             feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q_FEAT
             grid_scaling = grid_scaling + torch.empty_like(grid_scaling).uniform_(-0.5, 0.5) * Q_SCALING
             grid_offsets = grid_offsets + torch.empty_like(grid_offsets).uniform_(-0.5, 0.5) * Q_OFFSETS
-        if step == 10000:                                                               # :60-61
-            pc.update_anchor_bound()
-        if step > 10000:                                                                # :63-81
-            mask_anchor_bool = pc.get_mask_anchor.to(torch.bool)
-            binary_all = pc.get_mask
-            (feat, grid_scaling, grid_offsets, bit_per_param, bit_per_feat_param, bit_per_scaling_param,
-             bit_per_offsets_param, bpp_per_level) = multi_scale_generating(
-                pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
-                mask_anchor_bool, predict_bpp=True, training=True)
-            anchor = sel(pc.get_anchor)
-            feat = sel(feat)
-            grid_offsets = sel(grid_offsets)
-            grid_scaling = sel(grid_scaling)
-            binary_grid_masks = sel(binary_all)
-    elif not pc.decoded_version:                                                        # :83-101
+    if is_training and step == 10000:                                                   # :60-61
+        pc.update_anchor_bound()
+    if use_context:                                                                     # :63-81 (train) / :83-101 (eval)
         mask_anchor_bool = pc.get_mask_anchor.to(torch.bool)
         binary_all = pc.get_mask
-        feat, grid_scaling, grid_offsets = multi_scale_generating(
-            pc, pc.get_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling, binary_all,
-            mask_anchor_bool, predict_bpp=False, training=False)
-        anchor = sel(pc.get_anchor)
-        feat = sel(feat)
-        grid_offsets = sel(grid_offsets)
-        grid_scaling = sel(grid_scaling)
+        res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
+                                             pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
+                                             training=is_training, predict_bpp=is_training)
+        feat, grid_scaling, grid_offsets = res[:3]
+        if is_training:
+            bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
         binary_grid_masks = sel(binary_all)
 
     ob_view = anchor - viewpoint_camera.camera_center                                   # :106-110

@@ -10,6 +10,7 @@ from collections import defaultdict
 
 
 def main(d, out, top=45):
+    top = int(top)
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     rows = []
     if stats:
@@ -40,4 +41,4 @@ def main(d, out, top=45):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
