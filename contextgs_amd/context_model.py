@@ -188,7 +188,7 @@ def level_anchors(anchor, mask_anchor_bool, level, orig):
     was built from (masked anchors are zeroed from level 1 up, :1758-1759)."""
     if level >= 1 and mask_anchor_bool is not None:
         anchor = anchor * mask_anchor_bool.unsqueeze(1)
-    return anchor[orig]
+    return gather_unique(anchor, orig)
 
 
 def grid_mlp(pc, level, feat_in):
@@ -228,6 +228,28 @@ class _GatherUnique(torch.autograd.Function):
 
 def gather_unique(x, idx):
     return _GatherUnique.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
+
+
+class _GatherRows(torch.autograd.Function):
+    """x[idx] for arbitrary (repeating) row indices with an atomic scatter-add backward (index_add_) instead of
+    torch's sort-based index_put_(accumulate=True)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_add_(0, idx, g.contiguous())
+        return out, None
+
+
+def gather_rows(x, idx):
+    return _GatherRows.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
 
 
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
@@ -288,7 +310,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             idx, pos = c["ctx_idx"][i], c["ctx_pos"][i]
             base_f = feat_q[0] if len(feat_q) == 1 else torch.cat(feat_q, dim=0)       # coded prefix (<= 20 % of N)
             base_s = scal_q[0] if len(scal_q) == 1 else torch.cat(scal_q, dim=0)
-            content_pre_gathered = torch.cat([anchor[idx], base_f[pos], base_s[pos]], dim=1)
+            content_pre_gathered = torch.cat([gather_rows(anchor, idx), gather_rows(base_f, pos), gather_rows(base_s, pos)], dim=1)
     cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     return c, cat(feat_q), cat(scal_q), cat(off_q).view(-1, K, 3), likelihood_hyper, levels
 
@@ -305,7 +327,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach()
     else:
         mask_anchor_rate = 1
-    bit_hyper = -torch.log2(likelihood_hyper[torch.nonzero(choose_mask)[:, 0]])
+    bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
     eg = pc.entropy_gaussian
     xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
     masks30 = binary_grid_masks.repeat(1, 1, 3).view(-1, 3 * K)
@@ -319,7 +341,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         g = lambda t: gather_unique(t, loc)
         bf = eg(g(L["feat"]), g(L["mf"]), g(L["sf"]), g(L["qf"]), xm_feat)
         bs = eg(g(L["scaling"]), g(L["ms"]), g(L["ss"]), g(L["qs"]), xm_scaling)
-        bo = eg(g(L["offsets"]), g(L["mo"]), g(L["so"]), g(L["qo"]), xm_offsets) * masks30[rows]
+        bo = eg(g(L["offsets"]), g(L["mo"]), g(L["so"]), g(L["qo"]), xm_offsets) * gather_unique(masks30, rows)
         s_feat, s_scaling, s_offsets = s_feat + bf.sum(), s_scaling + bs.sum(), s_offsets + bo.sum()
         n_feat, n_scaling, n_offsets = n_feat + bf.numel(), n_scaling + bs.numel(), n_offsets + bo.numel()
         level_rows.append(int(loc.shape[0]))
