@@ -1,0 +1,374 @@
+// The three anchor MLPs of generate_neural_gaussians (gaussian_renderer/__init__.py:112,122,126:
+// mlp_opacity 54->50->10 tanh, mlp_color 54->50->30 sigmoid, mlp_cov 54->50->70) share their
+// input row, so they run as ONE fused fp32-MFMA launch forward and one backward: the X
+// fragments are loaded once, the three hidden activations land in one [n,150] buffer (which
+// makes the three first-layer weight gradients a single [150 x 54] contraction), and the three
+// dX contributions are summed in the accumulator registers.  Same transposed-chaining design
+// as mlp.hip (weights = A operand from LDS, activations = B operand in registers).
+#include "cgs_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int m3_pad16mod32(int x) { int s = 16; while (s < x) s += 32; return s; }
+constexpr int m3_pad4mod8(int x) { int s = 4; while (s < x) s += 8; return s; }
+
+#define M3_IN 54
+#define M3_HID 50
+#define M3_KS1 14            // ceil(54/4)
+#define M3_NT1 4             // ceil(50/16)
+#define M3_HP 64
+#define M3_NTX 4             // ceil(54/16)
+#define M3_HCAT 150
+
+struct M3Head {
+    const float *W1, *b1, *W2, *b2;
+    float *Y;            // forward output [n, OUT] (backward: saved forward output, read-only use)
+    const float *dY;     // backward input  [n, OUT]
+    float *dZ2;          // backward scratch [n, OUT] (only for heads with an activation)
+};
+
+__device__ __forceinline__ f32x4 m3_mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int ACT>
+__device__ __forceinline__ float m3_act(float z) {
+    if (ACT == 1) return tanhf(z);
+    if (ACT == 2) return 1.f / (1.f + __expf(-z));
+    return z;
+}
+template <int ACT>
+__device__ __forceinline__ float m3_act_grad(float y) {
+    if (ACT == 1) return 1.f - y * y;
+    if (ACT == 2) return y * (1.f - y);
+    return 1.f;
+}
+
+// ---- LDS images ------------------------------------------------------------------------------
+template <int OUT>
+struct M3FwdLds {
+    static constexpr int NT2 = (OUT + 15) / 16, OP = NT2 * 16;
+    static constexpr int S1 = m3_pad16mod32(M3_HP), S2 = m3_pad4mod8(OP);
+    static constexpr int FLOATS = M3_KS1 * 4 * S1 + M3_HP * S2 + M3_HP + OP;
+};
+
+template <int OUT>
+__device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int tid, int nthr) {
+    using L = M3FwdLds<OUT>;
+    float *W1s = lds, *W2s = W1s + M3_KS1 * 4 * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
+    for (int i = tid; i < M3_KS1 * 4 * L::S1; i += nthr) {
+        const int k = i / L::S1, j = i % L::S1;
+        W1s[i] = (k < M3_IN && j < M3_HID) ? h.W1[j * M3_IN + k] : 0.f;
+    }
+    for (int i = tid; i < M3_HP * L::S2; i += nthr) {
+        const int hh = i / L::S2, o = i % L::S2;
+        W2s[i] = (hh < M3_HID && o < OUT) ? h.W2[o * M3_HID + hh] : 0.f;
+    }
+    for (int i = tid; i < M3_HP; i += nthr) b1s[i] = i < M3_HID ? h.b1[i] : 0.f;
+    for (int i = tid; i < L::OP; i += nthr) b2s[i] = i < OUT ? h.b2[i] : 0.f;
+}
+
+template <int OUT, int ACT, int RT>
+__device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const float (&xb)[RT][M3_KS1],
+                                            const bool (&valid)[RT], int64_t row0, int g, int c,
+                                            float *__restrict__ Hcat) {
+    using L = M3FwdLds<OUT>;
+    const float *W1s = lds, *W2s = W1s + M3_KS1 * 4 * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
+    f32x4 acc1[M3_NT1][RT];
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < M3_KS1; ++s)
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) {
+            const float a = W1s[(4 * s + g) * L::S1 + 16 * t + c];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = m3_mfma(a, xb[rt][s], acc1[t][rt]);
+        }
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = row0 + rt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = 16 * t + 4 * g + r;
+                const float v = fmaxf(acc1[t][rt][r] + b1s[hh], 0.f);
+                acc1[t][rt][r] = v;
+                if (Hcat && valid[rt] && hh < M3_HID) Hcat[row * M3_HCAT + M3_HID * head + hh] = v;
+            }
+        }
+    f32x4 acc2[L::NT2][RT];
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * t + r >= M3_HID) continue;
+#pragma unroll
+            for (int u = 0; u < L::NT2; ++u) {
+                const float a = W2s[(16 * t + 4 * g + r) * L::S2 + 16 * u + c];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = m3_mfma(a, acc1[t][rt][r], acc2[u][rt]);
+            }
+        }
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = row0 + rt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * u + 4 * g + r;
+                if (valid[rt] && o < OUT) h.Y[row * OUT + o] = m3_act<ACT>(acc2[u][rt][r] + b2s[o]);
+            }
+        }
+}
+
+template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+    mlp3_fwd_kernel(const float *__restrict__ X, int64_t ldx, M3Head h0, M3Head h1, M3Head h2,
+                    float *__restrict__ Hcat, int64_t n) {
+    __shared__ float lds[M3FwdLds<O0>::FLOATS + M3FwdLds<O1>::FLOATS + M3FwdLds<O2>::FLOATS];
+    float *l0 = lds, *l1 = l0 + M3FwdLds<O0>::FLOATS, *l2 = l1 + M3FwdLds<O1>::FLOATS;
+    const int tid = threadIdx.x, nthr = WAVES * 64;
+    m3_stage_fwd<O0>(l0, h0, tid, nthr);
+    m3_stage_fwd<O1>(l1, h1, tid, nthr);
+    m3_stage_fwd<O2>(l2, h2, tid, nthr);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t row0 = tile * 16 * RT;
+        float xb[RT][M3_KS1];
+        bool valid[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = row0 + rt * 16 + c;
+            valid[rt] = row < n;
+            const float *xr = X + row * ldx;
+#pragma unroll
+            for (int s = 0; s < M3_KS1; ++s) {
+                const int k = 4 * s + g;
+                xb[rt][s] = (valid[rt] && k < M3_IN) ? xr[k] : 0.f;
+            }
+        }
+        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
+        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
+        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat);
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+template <int OUT>
+struct M3BwdLds {
+    static constexpr int KS2 = (OUT + 3) / 4;
+    static constexpr int SA = m3_pad16mod32(M3_HP), SB = m3_pad4mod8(M3_NTX * 16);
+    static constexpr int FLOATS = KS2 * 4 * SA + M3_HP * SB;
+};
+
+template <int OUT>
+__device__ __forceinline__ void m3_stage_bwd(float *lds, const M3Head &h, int tid, int nthr) {
+    using L = M3BwdLds<OUT>;
+    float *W2n = lds, *W1n = W2n + L::KS2 * 4 * L::SA;
+    for (int i = tid; i < L::KS2 * 4 * L::SA; i += nthr) {
+        const int o = i / L::SA, hh = i % L::SA;
+        W2n[i] = (o < OUT && hh < M3_HID) ? h.W2[o * M3_HID + hh] : 0.f;
+    }
+    for (int i = tid; i < M3_HP * L::SB; i += nthr) {
+        const int hh = i / L::SB, k = i % L::SB;
+        W1n[i] = (hh < M3_HID && k < M3_IN) ? h.W1[hh * M3_IN + k] : 0.f;
+    }
+}
+
+template <int OUT, int ACT, int RT>
+__device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, int head, const bool (&valid)[RT],
+                                            int64_t row0, int g, int c, const float *__restrict__ Hcat,
+                                            float *__restrict__ dZ1cat, f32x4 (&adx)[M3_NTX][RT]) {
+    using L = M3BwdLds<OUT>;
+    const float *W2n = lds, *W1n = W2n + L::KS2 * 4 * L::SA;
+    f32x4 adh[M3_NT1][RT];
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) adh[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < L::KS2; ++s) {
+        float b[RT];
+        const int o = 4 * s + g;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = row0 + rt * 16 + c;
+            float v = 0.f;
+            if (valid[rt] && o < OUT) {
+                v = h.dY[row * OUT + o];
+                if (ACT != 0) {
+                    v *= m3_act_grad<ACT>(h.Y[row * OUT + o]);
+                    h.dZ2[row * OUT + o] = v;
+                }
+            }
+            b[rt] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) {
+            const float a = W2n[(4 * s + g) * L::SA + 16 * t + c];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) adh[t][rt] = m3_mfma(a, b[rt], adh[t][rt]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = row0 + rt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hh = 16 * t + 4 * g + r;
+                float d = 0.f;
+                if (valid[rt] && hh < M3_HID) {
+                    const int64_t at = row * M3_HCAT + M3_HID * head + hh;
+                    d = Hcat[at] > 0.f ? adh[t][rt][r] : 0.f;
+                    dZ1cat[at] = d;
+                }
+                adh[t][rt][r] = d;
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * t + r >= M3_HID) continue;
+#pragma unroll
+            for (int v = 0; v < M3_NTX; ++v) {
+                const float a = W1n[(16 * t + 4 * g + r) * L::SB + 16 * v + c];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) adx[v][rt] = m3_mfma(a, adh[t][rt][r], adx[v][rt]);
+            }
+        }
+}
+
+template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+    mlp3_bwd_kernel(M3Head h0, M3Head h1, M3Head h2, const float *__restrict__ Hcat, float *__restrict__ dZ1cat,
+                    float *__restrict__ dX, int64_t lddx, int64_t n) {
+    __shared__ float lds[M3BwdLds<O0>::FLOATS + M3BwdLds<O1>::FLOATS + M3BwdLds<O2>::FLOATS];
+    float *l0 = lds, *l1 = l0 + M3BwdLds<O0>::FLOATS, *l2 = l1 + M3BwdLds<O1>::FLOATS;
+    const int tid = threadIdx.x, nthr = WAVES * 64;
+    m3_stage_bwd<O0>(l0, h0, tid, nthr);
+    m3_stage_bwd<O1>(l1, h1, tid, nthr);
+    m3_stage_bwd<O2>(l2, h2, tid, nthr);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t row0 = tile * 16 * RT;
+        bool valid[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) valid[rt] = row0 + rt * 16 + c < n;
+        f32x4 adx[M3_NTX][RT];
+#pragma unroll
+        for (int v = 0; v < M3_NTX; ++v)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) adx[v][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m3_head_bwd<O0, A0, RT>(l0, h0, 0, valid, row0, g, c, Hcat, dZ1cat, adx);
+        m3_head_bwd<O1, A1, RT>(l1, h1, 1, valid, row0, g, c, Hcat, dZ1cat, adx);
+        m3_head_bwd<O2, A2, RT>(l2, h2, 2, valid, row0, g, c, Hcat, dZ1cat, adx);
+        if (dX) {
+#pragma unroll
+            for (int v = 0; v < M3_NTX; ++v)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int64_t row = row0 + rt * 16 + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 16 * v + 4 * g + r;
+                        if (valid[rt] && k < M3_IN) dX[row * lddx + k] = adx[v][rt][r];
+                    }
+                }
+        }
+    }
+}
+
+int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
+                      int64_t n, int num_cus, hipStream_t s);
+
+static int m3_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// X [n, ldx]; W1* [50,54], b1* [50], W2* [OUT,50], b2* [OUT]; outputs Y_op [n,10] (tanh), Y_color [n,30] (sigmoid),
+// Y_cov [n,70]; Hcat [n,150] = relu hidden of the three MLPs (NULL for inference).
+extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float *const *W1, const float *const *b1,
+                                       const float *const *W2, const float *const *b2, float *Y_op, float *Y_color,
+                                       float *Y_cov, float *Hcat, int64_t n, void *stream) {
+    if (n < 0) { cgs_set_error("anchor_mlp3_forward: n < 0"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!X || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) { cgs_set_error("anchor_mlp3_forward: NULL"); return CGS_ERR_ARG; }
+    constexpr int RT = 2, WAVES = 8;
+    M3Head h[3];
+    float *ys[3] = {Y_op, Y_color, Y_cov};
+    for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
+    const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
+    const int64_t want = (tiles + WAVES - 1) / WAVES;
+    const int grid = (int)(want < m3_cus() ? want : m3_cus());
+    CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                       X, ldx, h[0], h[1], h[2], Hcat, n);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// dY_* are the gradients of the three outputs; Y_op / Y_color the saved forward outputs (activation derivatives).
+// Scratch: dZ1cat [n,150], dZ2_op [n,10], dZ2_color [n,30].  dX [n, lddx] may be NULL.  Weight / bias gradients are
+// ACCUMULATED (atomics): dW1cat [150,54], db1cat [150], dW2[i] [OUT_i,50], db2[i] [OUT_i].
+extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2,
+                                        const float *Y_op, const float *Y_color, const float *dY_op,
+                                        const float *dY_color, const float *dY_cov, const float *Hcat, float *dX,
+                                        int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color, float *dW1cat,
+                                        float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) { cgs_set_error("anchor_mlp3_backward: n < 0"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!X || !W1 || !W2 || !Y_op || !Y_color || !dY_op || !dY_color || !dY_cov || !Hcat || !dZ1cat || !dZ2_op ||
+        !dZ2_color || !dW1cat || !db1cat || !dW2 || !db2) {
+        cgs_set_error("anchor_mlp3_backward: NULL");
+        return CGS_ERR_ARG;
+    }
+    constexpr int RT = 2, WAVES = 8;
+    M3Head h[3];
+    h[0] = M3Head{W1[0], nullptr, W2[0], nullptr, const_cast<float *>(Y_op), dY_op, dZ2_op};
+    h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};
+    h[2] = M3Head{W1[2], nullptr, W2[2], nullptr, nullptr, dY_cov, nullptr};
+    const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
+    const int64_t want = (tiles + WAVES - 1) / WAVES;
+    const int grid = (int)(want < m3_cus() ? want : m3_cus());
+    {
+        CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
+        hipLaunchKernelGGL((mlp3_bwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, stream, h[0],
+                           h[1], h[2], Hcat, dZ1cat, dX, lddx, n);
+        CGS_CHECK_HIP(hipGetLastError());
+    }
+    CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+    int rc;
+    // three first layers at once: [150 x 54]
+    if ((rc = cgs_launch_wgrad2(dZ1cat, M3_HCAT, M3_HCAT, X, ldx, M3_IN, dW1cat, db1cat, n, m3_cus(), stream))) return rc;
+    const float *P[3] = {dZ2_op, dZ2_color, dY_cov};
+    const int outs[3] = {10, 30, 70};
+    for (int i = 0; i < 3; ++i)
+        if ((rc = cgs_launch_wgrad2(P[i], outs[i], outs[i], Hcat + M3_HID * i, M3_HCAT, M3_HID, dW2[i], db2[i], n, m3_cus(),
+                                    stream)))
+            return rc;
+    return CGS_OK;
+}

@@ -80,3 +80,81 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
     if key not in _SUPPORTED:
         raise NotImplementedError(f"no fused MLP kernel for {key}; instantiate it in csrc/mlp.hip")
     return _MLP2.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, act)
+
+
+# ---- the three anchor MLPs in one launch (csrc/mlp3.hip) ---------------------------------------------
+import ctypes as _C
+
+
+def _ptr_array(tensors):
+    return (_C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def anchor_mlp3_supported(mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential) -> bool:
+    try:
+        keys = [(s[0].in_features, s[0].out_features, s[2].out_features, _describe(s)[2]) for s in (mo, mc, mv)]
+    except Exception:
+        return False
+    return keys == [(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0)]
+
+
+class _AnchorMLP3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *params):
+        # params: (W1, b1, W2, b2) x (opacity, color, cov)
+        L = _lib.lib()
+        _lib.require_device(x)
+        x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+        p = [t.detach().contiguous() for t in params]
+        W1, b1, W2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
+        n = x.shape[0]
+        dev = x.device
+        need_grad = any(ctx.needs_input_grad)
+        y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
+        y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
+        y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
+        hcat = torch.empty(n, 150, dtype=torch.float32, device=dev) if need_grad else None
+        _lib.check(L.cgs_anchor_mlp3_forward(_lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(b1), _ptr_array(W2),
+                                             _ptr_array(b2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov),
+                                             _lib.ptr(hcat), n, _lib.current_stream()), "cgs_anchor_mlp3_forward")
+        if need_grad:
+            ctx.save_for_backward(x, y_op, y_color, hcat, *W1, *W2)
+        return y_op, y_color, y_cov
+
+    @staticmethod
+    def backward(ctx, g_op, g_color, g_cov):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, y_op, y_color, hcat = saved[:4]
+        W1, W2 = list(saved[4:7]), list(saved[7:10])
+        n = x.shape[0]
+        dev = x.device
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else (
+            t.contiguous() if t.dtype == torch.float32 else t.float().contiguous())
+        g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(n, x.shape[1], dtype=torch.float32, device=dev) if need_dx else None
+        dz1 = torch.empty(n, 150, dtype=torch.float32, device=dev)
+        dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
+        dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
+        dW1cat = torch.zeros(150, 54, dtype=torch.float32, device=dev)
+        db1cat = torch.zeros(150, dtype=torch.float32, device=dev)
+        dW2 = [torch.zeros_like(w) for w in W2]
+        db2 = [torch.zeros(w.shape[0], dtype=torch.float32, device=dev) for w in W2]
+        _lib.check(L.cgs_anchor_mlp3_backward(
+            _lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(g_op),
+            _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(dx), x.shape[1], _lib.ptr(dz1), _lib.ptr(dz2_op),
+            _lib.ptr(dz2_color), _lib.ptr(dW1cat), _lib.ptr(db1cat), _ptr_array(dW2), _ptr_array(db2), n,
+            _lib.current_stream()), "cgs_anchor_mlp3_backward")
+        grads = [dx]
+        for i in range(3):
+            grads += [dW1cat[50 * i:50 * (i + 1)], db1cat[50 * i:50 * (i + 1)], dW2[i], db2[i]]
+        return tuple(grads)
+
+
+def anchor_mlp3(x, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):
+    """(mlp_opacity(x), mlp_color(x), mlp_cov(x)) in one fused launch each way."""
+    params = []
+    for s in (mo, mc, mv):
+        params += [s[0].weight, s[0].bias, s[2].weight, s[2].bias]
+    return _AnchorMLP3.apply(x, *params)

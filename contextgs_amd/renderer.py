@@ -97,6 +97,9 @@ def _anchor_mlps(pc, x):
     """mlp_opacity / mlp_color / mlp_cov on the shared [N,54] input (:112,122,126).
     The three first layers are one GEMM; outputs are identical dot products."""
     mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    if mlp.anchor_mlp3_supported(mo, mc, mv):
+        # the three MLPs share x: one fused launch forward, one backward (csrc/mlp3.hip)
+        return mlp.anchor_mlp3(x, mo, mc, mv)
     if mlp.supported(mo) and mlp.supported(mc) and mlp.supported(mv):
         # one fused fp32-MFMA launch per MLP forward, three backward (csrc/mlp.hip): rocprof showed the
         # rocBLAS + elementwise + bias-reduction version of these skinny MLPs dominating the step

@@ -222,6 +222,29 @@ int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       float *db1, float *dW2, float *db2, int64_t n,
                       void *stream);
 
+/* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
+ * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on
+ * their shared input in ONE launch each way.  W1/b1/W2/b2 (and dW2/db2) are
+ * HOST arrays of three device pointers in the order (opacity, color, cov).
+ * Hcat [n,150] holds the three ReLU hidden layers side by side; dZ1cat [n,150],
+ * dZ2_op [n,10], dZ2_color [n,30] are backward scratch.  dW1cat [150,54] /
+ * db1cat [150] stack the three first-layer gradients; all weight / bias
+ * gradients are ACCUMULATED into. */
+int cgs_anchor_mlp3_forward(const float *X, int64_t ldx,
+                            const float *const *W1, const float *const *b1,
+                            const float *const *W2, const float *const *b2,
+                            float *Y_op, float *Y_color, float *Y_cov,
+                            float *Hcat, int64_t n, void *stream);
+int cgs_anchor_mlp3_backward(const float *X, int64_t ldx,
+                             const float *const *W1, const float *const *W2,
+                             const float *Y_op, const float *Y_color,
+                             const float *dY_op, const float *dY_color,
+                             const float *dY_cov, const float *Hcat, float *dX,
+                             int64_t lddx, float *dZ1cat, float *dZ2_op,
+                             float *dZ2_color, float *dW1cat, float *db1cat,
+                             float *const *dW2, float *const *db2, int64_t n,
+                             void *stream);
+
 /* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
  * scene/gaussian_model.py:1556; compressai is not in the mount, the density is
  * the one of utils/entropy_models.py:103-138 with filters (3,3,3,3)).  v, lik,

@@ -56,3 +56,28 @@ def test_empty_no_grad_and_unsupported_shape():
     assert not mlp.supported(odd)
     with pytest.raises(NotImplementedError):
         mlp.mlp2(torch.randn(4, 33, device="cuda"), odd)
+
+
+@pytest.mark.parametrize("n", [1, 33, 5000, 100003])
+def test_anchor_mlp3_matches_three_torch_mlps(n):
+    from contextgs_amd import mlp
+    torch.manual_seed(n)
+    mo, mc, mv = _seq(54, 50, 10, nn.Tanh), _seq(54, 50, 30, nn.Sigmoid), _seq(54, 50, 70, None)
+    assert mlp.anchor_mlp3_supported(mo, mc, mv)
+    x = torch.randn(n, 54, device="cuda", requires_grad=True)
+    ws = [torch.randn(n, o, device="cuda") for o in (10, 30, 70)]
+    ys = mlp.anchor_mlp3(x, mo, mc, mv)
+    sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+    params = [p for s in (mo, mc, mv) for p in s.parameters()]
+    got = [x.grad.clone()] + [p.grad.clone() for p in params]
+    x.grad = None
+    for s in (mo, mc, mv):
+        s.zero_grad()
+    refs = [s(x) for s in (mo, mc, mv)]
+    sum((y * w).sum() for y, w in zip(refs, ws)).backward()
+    ref = [x.grad] + [p.grad for p in params]
+    for y, r in zip(ys, refs):
+        assert (y - r).abs().max() <= 2e-5 * max(1.0, float(r.detach().abs().max()))
+    for i, (a, b) in enumerate(zip(got, ref)):
+        tol = (2e-5 if i == 0 else 2e-4) * max(1e-6, float(b.abs().max()))
+        assert (a - b).abs().max() <= tol, (i, float((a - b).abs().max()), float(b.abs().max()))
