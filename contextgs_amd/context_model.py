@@ -253,7 +253,7 @@ def gather_rows(x, idx):
 
 
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
-                               keep_stats):
+                               keep_stats, choose_mask=None):
     """The level loop of multi_scale_generating (:1556-1652) in coding order.
 
     Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
@@ -284,8 +284,27 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
             else:
                 feat_in = torch.cat([content_pre_gathered, hyp_l[j]], dim=1)
-            (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,
-             Q_offsets) = split_prediction(pc, grid_mlp(pc, i, feat_in))
+            # Only the three step-size outputs of mlp_grid are needed for EVERY row (they scale the noise /
+            # the rounding); the 172 mean/scale outputs are consumed by the rate model alone, i.e. by the
+            # `choose_mask` rows (15 % in training, :1658-1669; none at all when predict_bpp is off).  The
+            # reference evaluates all 175 outputs for all rows and throws 85-100 % of them away; here the
+            # second layer runs with its 3 step-size rows on every anchor and with all rows on the chosen
+            # anchors only (identical values: the same fp32 fma chains).
+            loc = None
+            if keep_stats and choose_mask is not None:
+                loc = torch.nonzero(choose_mask[orig])[:, 0]
+            subset_mode = _mlp.supported(pc.get_grid_mlp[i]) and (not keep_stats or loc is not None)
+            if subset_mode:
+                seq = pc.get_grid_mlp[i]
+                D_ = pc.feat_dim
+                n_stat = 2 * (D_ + 6 + 3 * K)
+                qadj = _mlp.mlp2_weights(feat_in, seq[0].weight, seq[0].bias, seq[2].weight[n_stat:], seq[2].bias[n_stat:])
+                Q_feat = (Q_FEAT0 * (1 + torch.tanh(qadj[:, 0:1]))).clamp(1e-9)
+                Q_scaling = (Q_SCALING0 * (1 + torch.tanh(qadj[:, 1:2]))).clamp(1e-9)
+                Q_offsets = (Q_OFFSETS0 * (1 + torch.tanh(qadj[:, 2:3]))).clamp(1e-9)
+            else:
+                (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Q_feat, Q_scaling,
+                 Q_offsets) = split_prediction(pc, grid_mlp(pc, i, feat_in))
             hf, hs, ho = feat_l[j], scal_l[j], off_l[j]
             qo = Q_offsets.view(n_l, K, -1) if pc.adaptQ_per_channel else Q_offsets.unsqueeze(1)
             if training:                                                               # :1610-1616
@@ -297,10 +316,17 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 hs = STE_multistep.apply(hs, Q_scaling).detach()
                 ho = STE_multistep.apply(ho, qo).detach()
             ho = ho.reshape(-1, 3 * K)
-            if keep_stats:
-                levels.append(dict(level=i, orig=orig, feat=hf, scaling=hs, offsets=ho, mf=mean_feat, sf=scale_feat,
-                                   qf=Q_feat, ms=mean_scaling, ss=scale_scaling, qs=Q_scaling, mo=mean_offsets,
-                                   so=scale_offsets, qo=Q_offsets))
+            if keep_stats and subset_mode:
+                g = lambda t: gather_unique(t, loc)
+                (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, _qf, _qs, _qo) = \
+                    split_prediction(pc, grid_mlp(pc, i, g(feat_in)))
+                levels.append(dict(level=i, orig=orig, rows=orig[loc], n_level=n_l, selected=True, feat=g(hf), scaling=g(hs),
+                                   offsets=g(ho), mf=mean_feat, sf=scale_feat, qf=g(Q_feat), ms=mean_scaling,
+                                   ss=scale_scaling, qs=g(Q_scaling), mo=mean_offsets, so=scale_offsets, qo=g(Q_offsets)))
+            elif keep_stats:
+                levels.append(dict(level=i, orig=orig, n_level=n_l, selected=False, feat=hf, scaling=hs, offsets=ho,
+                                   mf=mean_feat, sf=scale_feat, qf=Q_feat, ms=mean_scaling, ss=scale_scaling,
+                                   qs=Q_scaling, mo=mean_offsets, so=scale_offsets, qo=Q_offsets))
         else:
             hf, hs, ho = feat_l[j], scal_l[j], off_l[j].reshape(-1, 3 * K)
         feat_q.append(hf)
@@ -315,18 +341,24 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     return c, cat(feat_q), cat(scal_q), cat(off_q).view(-1, K, 3), likelihood_hyper, levels
 
 
-def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, return_sum_bits):
-    """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows."""
-    K = pc.n_offsets
-    n = anchor.shape[0]
-    dev = anchor.device
+def draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits):
+    """:1658-1661 — the anchors whose bits enter the rate estimate."""
     thresh = 1 if return_sum_bits else 0.15
     choose_mask = torch.rand_like(anchor[:, 0]) <= thresh
     if mask_anchor_bool is not None:
         choose_mask = choose_mask & mask_anchor_bool
-        mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach()
-    else:
-        mask_anchor_rate = 1
+    return choose_mask
+
+
+def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, return_sum_bits,
+               choose_mask=None):
+    """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows."""
+    K = pc.n_offsets
+    n = anchor.shape[0]
+    dev = anchor.device
+    if choose_mask is None:
+        choose_mask = draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits)
+    mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach() if mask_anchor_bool is not None else 1
     bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
     eg = pc.entropy_gaussian
     xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
@@ -336,15 +368,19 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     n_feat = n_scaling = n_offsets = 0
     level_bpp_sums, level_rows = [], []
     for L in levels:
-        loc = torch.nonzero(choose_mask[L["orig"]])[:, 0]
-        rows = L["orig"][loc]
-        g = lambda t: gather_unique(t, loc)
+        if L["selected"]:                       # the level already holds the chosen rows only
+            rows = L["rows"]
+            g = lambda t: t
+        else:
+            loc = torch.nonzero(choose_mask[L["orig"]])[:, 0]
+            rows = L["orig"][loc]
+            g = lambda t, loc=loc: gather_unique(t, loc)
         bf = eg(g(L["feat"]), g(L["mf"]), g(L["sf"]), g(L["qf"]), xm_feat)
         bs = eg(g(L["scaling"]), g(L["ms"]), g(L["ss"]), g(L["qs"]), xm_scaling)
         bo = eg(g(L["offsets"]), g(L["mo"]), g(L["so"]), g(L["qo"]), xm_offsets) * gather_unique(masks30, rows)
         s_feat, s_scaling, s_offsets = s_feat + bf.sum(), s_scaling + bs.sum(), s_offsets + bo.sum()
         n_feat, n_scaling, n_offsets = n_feat + bf.numel(), n_scaling + bs.numel(), n_offsets + bo.numel()
-        level_rows.append(int(loc.shape[0]))
+        level_rows.append(int(rows.shape[0]))
         level_bpp_sums.append((bf.detach().sum() + bs.detach().sum() + bo.detach().sum()))
 
     if return_sum_bits:                                                                # :1672-1685
@@ -368,7 +404,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         host = torch.stack([t.reshape(()).float() for t in stats]).cpu().tolist()
     each_level_bpp = [host[0], host[1]]
     for li, L in enumerate(levels):
-        each_level_bpp.append([L["orig"].shape[0] / n, host[2 + li]])
+        each_level_bpp.append([L["n_level"] / n, host[2 + li]])
     return bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, each_level_bpp
 
 
@@ -383,14 +419,18 @@ def _unpermute(c, t):
 
 def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
                            mask_anchor_bool=None, training=False, predict_bpp=False, return_sum_bits=False):   # :1541-1707
+    # The rate subset is drawn BEFORE the level loop (the reference draws it after, :1659) so that the loop can
+    # skip the mean/scale outputs of unchosen anchors; same distribution, different position in the RNG stream.
+    choose_mask = draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits) if predict_bpp else None
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
-        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp)
+        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
+        choose_mask=choose_mask)
     if predict_bpp and return_sum_bits:
-        return rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, True)
+        return rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, True, choose_mask)
     feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q = (_unpermute(c, t) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:
         return feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q
-    rates = rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False)
+    rates = rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False, choose_mask)
     return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q) + tuple(rates)
 
 
@@ -398,8 +438,10 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
                                    mask_anchor_bool, vis_idx, training, predict_bpp):
     """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
     two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]]."""
+    choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False) if predict_bpp else None
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
-        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp)
+        pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
+        choose_mask=choose_mask)
     if c["covers_all"]:
         pos = c["inv_perm"][vis_idx]
         outs = tuple(gather_unique(t, pos) for t in (feat_p, scal_p, off_p))
@@ -407,4 +449,5 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
         outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:
         return outs
-    return outs + tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False))
+    return outs + tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False,
+                                   choose_mask))

@@ -412,7 +412,9 @@ static int launch_wgrad(const float *P, int64_t ldp, int DA, const float *Q, int
     X_(54, 50, 30, ACT_SIGMOID)   \
     X_(54, 50, 70, ACT_NONE)      \
     X_(71, 100, 175, ACT_NONE)    \
-    X_(15, 100, 175, ACT_NONE)
+    X_(15, 100, 175, ACT_NONE)    \
+    X_(71, 100, 3, ACT_NONE)      \
+    X_(15, 100, 3, ACT_NONE)
 
 // Y = act(W2 relu(W1 x + b1) + b2); H [n,HID] receives relu(.) (may be NULL for inference).
 extern "C" int cgs_mlp2_forward(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,

@@ -316,7 +316,7 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
     if (n < 0) { cgs_set_error("anchor_mlp3_forward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) { cgs_set_error("anchor_mlp3_forward: NULL"); return CGS_ERR_ARG; }
-    constexpr int RT = 2, WAVES = 8;
+    constexpr int RT = 1, WAVES = 16;
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
@@ -346,7 +346,7 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
         cgs_set_error("anchor_mlp3_backward: NULL");
         return CGS_ERR_ARG;
     }
-    constexpr int RT = 2, WAVES = 8;
+    constexpr int RT = 1, WAVES = 16;
     M3Head h[3];
     h[0] = M3Head{W1[0], nullptr, W2[0], nullptr, const_cast<float *>(Y_op), dY_op, dZ2_op};
     h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};

@@ -12,7 +12,8 @@ import torch.nn as nn
 from . import _lib
 
 _ACT = {None: 0, nn.Tanh: 1, nn.Sigmoid: 2}
-_SUPPORTED = {(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0), (71, 100, 175, 0), (15, 100, 175, 0)}
+_SUPPORTED = {(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0), (71, 100, 175, 0), (15, 100, 175, 0), (71, 100, 3, 0),
+              (15, 100, 3, 0)}
 
 
 def _describe(seq: nn.Sequential):
@@ -71,6 +72,14 @@ class _MLP2(torch.autograd.Function):
                                        _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n,
                                        _lib.current_stream()), "cgs_mlp2_backward")
         return dx, dW1, db1, dW2, db2, None
+
+
+def mlp2_weights(x: torch.Tensor, W1, b1, W2, b2, act: int = 0) -> torch.Tensor:
+    """Same kernels on explicit weight tensors (e.g. a row slice of the second layer)."""
+    key = (W1.shape[1], W1.shape[0], W2.shape[0], act)
+    if key not in _SUPPORTED:
+        raise NotImplementedError(f"no fused MLP kernel for {key}; instantiate it in csrc/mlp.hip")
+    return _MLP2.apply(x, W1, b1, W2, b2, act)
 
 
 def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
