@@ -71,12 +71,13 @@ SIGNATURES = {
                                  c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "cgs_mlp2_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p, c_void_p, c_int64, c_void_p]),
+                                  c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_mlp_wgrad_scratch_bytes": (c_size_t, []),
     "cgs_anchor_mlp3_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_void_p]),
     "cgs_anchor_mlp3_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_eb_likelihood_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_eb_likelihood_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_ac_max_bytes": (c_size_t, [c_int64]),

@@ -132,3 +132,8 @@ int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float 
 
 static inline int cgs_tiles_x(const cgs_raster_cfg *c) { return (c->image_width + CGS_TILE - 1) / CGS_TILE; }
 static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height + CGS_TILE - 1) / CGS_TILE; }
+
+// mlp_wgrad.hip
+int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
+                      int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s);
+size_t cgs_wgrad_scratch_bytes_for(int num_cus);

@@ -4,20 +4,17 @@
 // fragments are loaded once, the three hidden activations land in one [n,150] buffer (which
 // makes the three first-layer weight gradients a single [150 x 54] contraction), and the three
 // dX contributions are summed in the accumulator registers.  Same transposed-chaining design
-// as mlp.hip (weights = A operand from LDS, activations = B operand in registers).
+// as mlp.hip (weights = A operand from LDS, activations = B operand in registers, one 16-byte
+// access per lane for every activation read/write — mlp_frag.h).
 #include "cgs_internal.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int m3_pad16mod32(int x) { int s = 16; while (s < x) s += 32; return s; }
-constexpr int m3_pad4mod8(int x) { int s = 4; while (s < x) s += 8; return s; }
+#include "mlp_frag.h"
 
 #define M3_IN 54
 #define M3_HID 50
-#define M3_KS1 14            // ceil(54/4)
+#define M3_NTI 4             // ceil(54/16)
+#define M3_XP 64
 #define M3_NT1 4             // ceil(50/16)
 #define M3_HP 64
-#define M3_NTX 4             // ceil(54/16)
 #define M3_HCAT 150
 
 struct M3Head {
@@ -27,36 +24,19 @@ struct M3Head {
     float *dZ2;          // backward scratch [n, OUT] (only for heads with an activation)
 };
 
-__device__ __forceinline__ f32x4 m3_mfma(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-template <int ACT>
-__device__ __forceinline__ float m3_act(float z) {
-    if (ACT == 1) return tanhf(z);
-    if (ACT == 2) return 1.f / (1.f + __expf(-z));
-    return z;
-}
-template <int ACT>
-__device__ __forceinline__ float m3_act_grad(float y) {
-    if (ACT == 1) return 1.f - y * y;
-    if (ACT == 2) return y * (1.f - y);
-    return 1.f;
-}
-
 // ---- LDS images ------------------------------------------------------------------------------
 template <int OUT>
 struct M3FwdLds {
     static constexpr int NT2 = (OUT + 15) / 16, OP = NT2 * 16;
-    static constexpr int S1 = m3_pad16mod32(M3_HP), S2 = m3_pad4mod8(OP);
-    static constexpr int FLOATS = M3_KS1 * 4 * S1 + M3_HP * S2 + M3_HP + OP;
+    static constexpr int S1 = frag_pad4mod8(M3_HP), S2 = frag_pad4mod8(OP);
+    static constexpr int FLOATS = M3_XP * S1 + M3_HP * S2 + M3_HP + OP;
 };
 
 template <int OUT>
 __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int tid, int nthr) {
     using L = M3FwdLds<OUT>;
-    float *W1s = lds, *W2s = W1s + M3_KS1 * 4 * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
-    for (int i = tid; i < M3_KS1 * 4 * L::S1; i += nthr) {
+    float *W1s = lds, *W2s = W1s + M3_XP * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
+    for (int i = tid; i < M3_XP * L::S1; i += nthr) {
         const int k = i / L::S1, j = i % L::S1;
         W1s[i] = (k < M3_IN && j < M3_HID) ? h.W1[j * M3_IN + k] : 0.f;
     }
@@ -69,23 +49,27 @@ __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int ti
 }
 
 template <int OUT, int ACT, int RT>
-__device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const float (&xb)[RT][M3_KS1],
+__device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const f32x4 (&xb)[RT][M3_NTI],
                                             const bool (&valid)[RT], int64_t row0, int g, int c,
                                             float *__restrict__ Hcat) {
     using L = M3FwdLds<OUT>;
-    const float *W1s = lds, *W2s = W1s + M3_KS1 * 4 * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
+    const float *W1s = lds, *W2s = W1s + M3_XP * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
     f32x4 acc1[M3_NT1][RT];
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < M3_KS1; ++s)
+    for (int q = 0; q < M3_NTI; ++q)
 #pragma unroll
-        for (int t = 0; t < M3_NT1; ++t) {
-            const float a = W1s[(4 * s + g) * L::S1 + 16 * t + c];
+        for (int j = 0; j < 4; ++j) {
+            if (16 * q + j >= M3_IN) continue;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = m3_mfma(a, xb[rt][s], acc1[t][rt]);
+            for (int t = 0; t < M3_NT1; ++t) {
+                const float a = W1s[(16 * q + 4 * g + j) * L::S1 + 16 * t + c];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = frag_mfma(a, xb[rt][q][j], acc1[t][rt]);
+            }
         }
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
@@ -93,12 +77,8 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hh = 16 * t + 4 * g + r;
-                const float v = fmaxf(acc1[t][rt][r] + b1s[hh], 0.f);
-                acc1[t][rt][r] = v;
-                if (Hcat && valid[rt] && hh < M3_HID) Hcat[row * M3_HCAT + M3_HID * head + hh] = v;
-            }
+            for (int r = 0; r < 4; ++r) acc1[t][rt][r] = fmaxf(acc1[t][rt][r] + b1s[16 * t + 4 * g + r], 0.f);
+            if (Hcat) frag_store4<M3_HID>(Hcat + row * M3_HCAT + M3_HID * head, t, g, valid[rt], acc1[t][rt]);
         }
     f32x4 acc2[L::NT2][RT];
 #pragma unroll
@@ -114,7 +94,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             for (int u = 0; u < L::NT2; ++u) {
                 const float a = W2s[(16 * t + 4 * g + r) * L::S2 + 16 * u + c];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = m3_mfma(a, acc1[t][rt][r], acc2[u][rt]);
+                for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = frag_mfma(a, acc1[t][rt][r], acc2[u][rt]);
             }
         }
 #pragma unroll
@@ -122,11 +102,10 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
+            f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * u + 4 * g + r;
-                if (valid[rt] && o < OUT) h.Y[row * OUT + o] = m3_act<ACT>(acc2[u][rt][r] + b2s[o]);
-            }
+            for (int r = 0; r < 4; ++r) y[r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
+            frag_store4<OUT>(h.Y + row * OUT, u, g, valid[rt], y);
         }
 }
 
@@ -145,18 +124,15 @@ __global__ void __launch_bounds__(WAVES * 64)
     const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
         const int64_t row0 = tile * 16 * RT;
-        float xb[RT][M3_KS1];
+        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
+        f32x4 xb[RT][M3_NTI];
         bool valid[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
             valid[rt] = row < n;
-            const float *xr = X + row * ldx;
 #pragma unroll
-            for (int s = 0; s < M3_KS1; ++s) {
-                const int k = 4 * s + g;
-                xb[rt][s] = (valid[rt] && k < M3_IN) ? xr[k] : 0.f;
-            }
+            for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
         }
         m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
         m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
@@ -167,16 +143,16 @@ __global__ void __launch_bounds__(WAVES * 64)
 // ---- backward ------------------------------------------------------------------------------------
 template <int OUT>
 struct M3BwdLds {
-    static constexpr int KS2 = (OUT + 3) / 4;
-    static constexpr int SA = m3_pad16mod32(M3_HP), SB = m3_pad4mod8(M3_NTX * 16);
-    static constexpr int FLOATS = KS2 * 4 * SA + M3_HP * SB;
+    static constexpr int NT2 = (OUT + 15) / 16, OP = NT2 * 16;
+    static constexpr int SA = frag_pad4mod8(M3_HP), SB = frag_pad4mod8(M3_XP);
+    static constexpr int FLOATS = OP * SA + M3_HP * SB;
 };
 
 template <int OUT>
 __device__ __forceinline__ void m3_stage_bwd(float *lds, const M3Head &h, int tid, int nthr) {
     using L = M3BwdLds<OUT>;
-    float *W2n = lds, *W1n = W2n + L::KS2 * 4 * L::SA;
-    for (int i = tid; i < L::KS2 * 4 * L::SA; i += nthr) {
+    float *W2n = lds, *W1n = W2n + L::OP * L::SA;
+    for (int i = tid; i < L::OP * L::SA; i += nthr) {
         const int o = i / L::SA, hh = i % L::SA;
         W2n[i] = (o < OUT && hh < M3_HID) ? h.W2[o * M3_HID + hh] : 0.f;
     }
@@ -189,54 +165,48 @@ __device__ __forceinline__ void m3_stage_bwd(float *lds, const M3Head &h, int ti
 template <int OUT, int ACT, int RT>
 __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, int head, const bool (&valid)[RT],
                                             int64_t row0, int g, int c, const float *__restrict__ Hcat,
-                                            float *__restrict__ dZ1cat, f32x4 (&adx)[M3_NTX][RT]) {
+                                            float *__restrict__ dZ1cat, f32x4 (&adx)[M3_NTI][RT]) {
     using L = M3BwdLds<OUT>;
-    const float *W2n = lds, *W1n = W2n + L::KS2 * 4 * L::SA;
+    const float *W2n = lds, *W1n = W2n + L::OP * L::SA;
     f32x4 adh[M3_NT1][RT];
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) adh[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < L::KS2; ++s) {
-        float b[RT];
-        const int o = 4 * s + g;
+    for (int u = 0; u < L::NT2; ++u) {
+        f32x4 b[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
-            float v = 0.f;
-            if (valid[rt] && o < OUT) {
-                v = h.dY[row * OUT + o];
-                if (ACT != 0) {
-                    v *= m3_act_grad<ACT>(h.Y[row * OUT + o]);
-                    h.dZ2[row * OUT + o] = v;
-                }
+            b[rt] = frag_load4<OUT>(h.dY + row * OUT, u, g, valid[rt]);
+            if (ACT != FRAG_ACT_NONE) {
+                const f32x4 y = frag_load4<OUT>(h.Y + row * OUT, u, g, valid[rt]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[rt][r] *= frag_act_grad<ACT>(y[r]);
+                frag_store4<OUT>(h.dZ2 + row * OUT, u, g, valid[rt], b[rt]);
             }
-            b[rt] = v;
         }
 #pragma unroll
-        for (int t = 0; t < M3_NT1; ++t) {
-            const float a = W2n[(4 * s + g) * L::SA + 16 * t + c];
+        for (int j = 0; j < 4; ++j) {
+            if (16 * u + j >= OUT) continue;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) adh[t][rt] = m3_mfma(a, b[rt], adh[t][rt]);
+            for (int t = 0; t < M3_NT1; ++t) {
+                const float a = W2n[(16 * u + 4 * g + j) * L::SA + 16 * t + c];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) adh[t][rt] = frag_mfma(a, b[rt][j], adh[t][rt]);
+            }
         }
     }
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int64_t row = row0 + rt * 16 + c;
+            const int64_t at = (row0 + rt * 16 + c) * M3_HCAT + M3_HID * head;
+            const f32x4 hv = frag_load4<M3_HID>(Hcat + at, t, g, valid[rt]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hh = 16 * t + 4 * g + r;
-                float d = 0.f;
-                if (valid[rt] && hh < M3_HID) {
-                    const int64_t at = row * M3_HCAT + M3_HID * head + hh;
-                    d = Hcat[at] > 0.f ? adh[t][rt][r] : 0.f;
-                    dZ1cat[at] = d;
-                }
-                adh[t][rt][r] = d;
-            }
+            for (int r = 0; r < 4; ++r) adh[t][rt][r] = hv[r] > 0.f ? adh[t][rt][r] : 0.f;
+            frag_store4<M3_HID>(dZ1cat + at, t, g, valid[rt], adh[t][rt]);
         }
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
@@ -244,10 +214,10 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
         for (int r = 0; r < 4; ++r) {
             if (16 * t + r >= M3_HID) continue;
 #pragma unroll
-            for (int v = 0; v < M3_NTX; ++v) {
+            for (int v = 0; v < M3_NTI; ++v) {
                 const float a = W1n[(16 * t + 4 * g + r) * L::SB + 16 * v + c];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) adx[v][rt] = m3_mfma(a, adh[t][rt][r], adx[v][rt]);
+                for (int rt = 0; rt < RT; ++rt) adx[v][rt] = frag_mfma(a, adh[t][rt][r], adx[v][rt]);
             }
         }
 }
@@ -267,12 +237,13 @@ __global__ void __launch_bounds__(WAVES * 64)
     const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
         const int64_t row0 = tile * 16 * RT;
+        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
         bool valid[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) valid[rt] = row0 + rt * 16 + c < n;
-        f32x4 adx[M3_NTX][RT];
+        f32x4 adx[M3_NTI][RT];
 #pragma unroll
-        for (int v = 0; v < M3_NTX; ++v)
+        for (int v = 0; v < M3_NTI; ++v)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) adx[v][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         m3_head_bwd<O0, A0, RT>(l0, h0, 0, valid, row0, g, c, Hcat, dZ1cat, adx);
@@ -280,22 +251,14 @@ __global__ void __launch_bounds__(WAVES * 64)
         m3_head_bwd<O2, A2, RT>(l2, h2, 2, valid, row0, g, c, Hcat, dZ1cat, adx);
         if (dX) {
 #pragma unroll
-            for (int v = 0; v < M3_NTX; ++v)
+            for (int v = 0; v < M3_NTI; ++v)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int64_t row = row0 + rt * 16 + c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k = 16 * v + 4 * g + r;
-                        if (valid[rt] && k < M3_IN) dX[row * lddx + k] = adx[v][rt][r];
-                    }
-                }
+                for (int rt = 0; rt < RT; ++rt)
+                    frag_store4<M3_IN>(dX + (row0 + rt * 16 + c) * lddx, v, g, valid[rt], adx[v][rt]);
         }
     }
 }
 
-int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
-                      int64_t n, int num_cus, hipStream_t s);
 
 static int m3_cus() {
     static int cus = 0;
@@ -316,7 +279,7 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
     if (n < 0) { cgs_set_error("anchor_mlp3_forward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) { cgs_set_error("anchor_mlp3_forward: NULL"); return CGS_ERR_ARG; }
-    constexpr int RT = 1, WAVES = 16;
+    constexpr int RT = 2, WAVES = 8;
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
@@ -337,7 +300,8 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
                                         const float *Y_op, const float *Y_color, const float *dY_op,
                                         const float *dY_color, const float *dY_cov, const float *Hcat, float *dX,
                                         int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color, float *dW1cat,
-                                        float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *stream_) {
+                                        float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
+                                        size_t scratch_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("anchor_mlp3_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
@@ -346,7 +310,7 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
         cgs_set_error("anchor_mlp3_backward: NULL");
         return CGS_ERR_ARG;
     }
-    constexpr int RT = 1, WAVES = 16;
+    constexpr int RT = 2, WAVES = 8;
     M3Head h[3];
     h[0] = M3Head{W1[0], nullptr, W2[0], nullptr, const_cast<float *>(Y_op), dY_op, dZ2_op};
     h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};
@@ -363,12 +327,12 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
     int rc;
     // three first layers at once: [150 x 54]
-    if ((rc = cgs_launch_wgrad2(dZ1cat, M3_HCAT, M3_HCAT, X, ldx, M3_IN, dW1cat, db1cat, n, m3_cus(), stream))) return rc;
+    if ((rc = cgs_launch_wgrad2(dZ1cat, M3_HCAT, M3_HCAT, X, ldx, M3_IN, dW1cat, db1cat, n, m3_cus(), scratch, scratch_bytes, stream))) return rc;
     const float *P[3] = {dZ2_op, dZ2_color, dY_cov};
     const int outs[3] = {10, 30, 70};
     for (int i = 0; i < 3; ++i)
         if ((rc = cgs_launch_wgrad2(P[i], outs[i], outs[i], Hcat + M3_HID * i, M3_HCAT, M3_HID, dW2[i], db2[i], n, m3_cus(),
-                                    stream)))
+                                    scratch, scratch_bytes, stream)))
             return rc;
     return CGS_OK;
 }

@@ -2,134 +2,254 @@
 // db[a] += sum_rows P[row][a]   (P = dZ [n, DA], Q = layer input [n, DB], both row-major in HBM).
 //
 // fp32 MFMA 16x16x4 with the ROW index as the contraction dimension: one instruction consumes 4
-// rows; both operand fragments are 4 rows x 64 B straight from memory (lane l reads
-// row0 + (l>>4), column 16*tile + (l&15)), no LDS.
+// rows (lane (g, c) supplies row 4q + g).  The output-tile indices m and n are free to permute,
+// so a wave works on a 64-feature GROUP of P against a 64-feature group of Q as 4 x 4 tiles in
+// which tile j's index c stands for feature 64*group + 4c + j: one 16-byte load per lane (a wave
+// instruction = 4 rows x 256 contiguous bytes) feeds four tiles, i.e. 2 loads per 16 MFMAs.
+// The next 4*UNR rows are prefetched into a second register set while the current ones are in
+// the matrix pipe.  (History: v1 scattered tiles over waves, 2 dword loads per MFMA, L1-bound;
+// v2 register-blocked UA x UB tiles with dword loads and no prefetch ran latency-bound at
+// ~4x its HBM time — profiles/r01_rocprof_bench_1m_v1_mfma_mlp.txt.)
 //
-// Register blocking: the 8 waves of a workgroup form a WA x WB grid over the NA x NB output
-// tiles; a wave owns UA x UB tiles and loads UA + UB fragments per 4-row step for UA*UB MFMAs
-// (the first version gave each wave scattered tiles: 2 loads per MFMA, L1-bandwidth bound — see
-// profiles/r01_rocprof_bench_1m_v1_mfma_mlp.txt).  Rows are split over workgroups; each ends with
-// one fp32 atomic per owned output element.
+// The 8 waves of a workgroup take (group pair, row sub-range); rows are split over workgroups;
+// each wave ends with one fp32 atomic per owned output element.  The bias gradient is a plain
+// per-lane running sum of the P fragments, reduced over g at the end.
 #include "cgs_internal.h"
+#include "mlp_frag.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int UA, int UB, int UNR>
-__global__ void __launch_bounds__(512)
-    wgrad2_kernel(const float *__restrict__ P, int64_t ldp, int DA, const float *__restrict__ Q, int64_t ldq, int DB,
-                  float *__restrict__ dW, float *__restrict__ db, int64_t n, int64_t rows_per_block, int WA, int WB) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int wa = wave / WB, wb = wave % WB;
-    const int NA = (DA + 15) / 16, NB = (DB + 15) / 16;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r_end = min(n, r_begin + rows_per_block);
-    int acol[UA], bcol[UB];
-    bool alive[UA], blive[UB];
+// One operand stream of a workgroup: a raw buffer descriptor over rows [r_begin, r_end) that ends exactly at the
+// last valid element, so rows past the range (tail iterations, the prefetch) and the overhang of the last row read
+// as 0 from the hardware bounds check — no branches around the loads, which is what lets the prefetch overlap.
+struct WgStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int ld4;            // row stride in bytes
+    int col4;           // this lane's first column, in bytes
+    bool m[4];          // column col0 + j < dim  (a 16-byte access that crosses the row end picks up the next row)
+    bool partial;       // wave-uniform: this 64-feature group crosses the row end
+};
+
+__device__ __forceinline__ WgStream wg_stream(const float *base, int64_t ld, int dim, int group, int c, int64_t r_begin,
+                                              int64_t r_end) {
+    WgStream st;
+    const float *p = base + r_begin * ld;
+    const int64_t rows = r_end - r_begin;
+    const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ld + dim) * 4) : 0u;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+    st.ld4 = (int)ld * 4;
+    const int col0 = 64 * group + 4 * c;
+    st.col4 = col0 * 4;
 #pragma unroll
-    for (int j = 0; j < UA; ++j) {
-        const int u = wa + WA * j;
-        alive[j] = u < NA && (16 * u + c) < DA;
-        acol[j] = 16 * u + c;
+    for (int j = 0; j < 4; ++j) st.m[j] = col0 + j < dim;
+    st.partial = 64 * group + 63 >= dim;
+    return st;
+}
+
+__device__ __forceinline__ f32x4 wg_load4(const WgStream &st, int rel_row) {
+    const i32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, rel_row * st.ld4 + st.col4, 0, 0);
+    return __builtin_bit_cast(f32x4, raw);
+}
+
+// applied at consume time: a use next to the load would put the wait there and defeat the prefetch
+__device__ __forceinline__ f32x4 wg_mask(const WgStream &st, f32x4 v) {
+    if (st.partial) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = st.m[j] ? v[j] : 0.f;
     }
+    return v;
+}
+
+template <int UNR>
+struct WgFrag {
+    f32x4 a[UNR], b[UNR];
+};
+
+template <int UNR>
+__device__ __forceinline__ void wg_fetch(WgFrag<UNR> &f, const WgStream &sa, const WgStream &sb, int rel_row0, int g) {
 #pragma unroll
-    for (int k = 0; k < UB; ++k) {
-        const int t = wb + WB * k;
-        blive[k] = t < NB && (16 * t + c) < DB;
-        bcol[k] = 16 * t + c;
-    }
-    if (wa >= NA || wb >= NB) return;
-    const bool do_bias = db != nullptr && wb == 0;
-    f32x4 acc[UA][UB], accb[UA];
-#pragma unroll
-    for (int j = 0; j < UA; ++j) {
-        accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < UB; ++k) acc[j][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    for (int64_t row0 = r_begin; row0 < r_end; row0 += 4 * UNR) {
-        float a[UNR][UA], b[UNR][UB], one[UNR];
-#pragma unroll
-        for (int q = 0; q < UNR; ++q) {
-            const int64_t row = row0 + 4 * q + g;
-            const bool valid = row < r_end;
-            one[q] = valid ? 1.f : 0.f;
-#pragma unroll
-            for (int j = 0; j < UA; ++j) a[q][j] = (valid && alive[j]) ? P[row * ldp + acol[j]] : 0.f;
-#pragma unroll
-            for (int k = 0; k < UB; ++k) b[q][k] = (valid && blive[k]) ? Q[row * ldq + bcol[k]] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < UNR; ++q)
-#pragma unroll
-            for (int j = 0; j < UA; ++j) {
-#pragma unroll
-                for (int k = 0; k < UB; ++k)
-                    acc[j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[q][k], acc[j][k], 0, 0, 0);
-                if (do_bias) accb[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], one[q], accb[j], 0, 0, 0);
-            }
-    }
-    // D layout: reg r of lane l <-> (a = 16u + 4g + r, b = 16t + c)
-#pragma unroll
-    for (int j = 0; j < UA; ++j) {
-        const int u = wa + WA * j;
-        if (u >= NA) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int arow = 16 * u + 4 * g + r;
-            if (arow >= DA) continue;
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const int t = wb + WB * k;
-                if (t < NB && bcol[k] < DB) atomicAdd(&dW[(int64_t)arow * DB + bcol[k]], acc[j][k][r]);
-            }
-            if (do_bias && c == 0) atomicAdd(&db[arow], accb[j][r]);
-        }
+    for (int q = 0; q < UNR; ++q) {
+        f.a[q] = wg_load4(sa, rel_row0 + 4 * q + g);
+        f.b[q] = wg_load4(sb, rel_row0 + 4 * q + g);
     }
 }
 
-int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
-                      int64_t n, int num_cus, hipStream_t s) {
-    if (n <= 0) return CGS_OK;
-    const int NA = (DA + 15) / 16, NB = (DB + 15) / 16;
-    // wave grid WA x WB = 8: as square as the tile grid allows
-    int WA = 0, WB = 0, UA = 0, UB = 0;
-    double best = 1e30;
-    for (int wa = 1; wa <= 8; wa *= 2) {
-        const int wb = 8 / wa;
-        const int ua = (NA + wa - 1) / wa, ub = (NB + wb - 1) / wb;
-        if (ua > 4 || ub > 4) continue;
-        const int active = (wa < NA ? wa : NA) * (wb < NB ? wb : NB);
-        // loads per MFMA, penalised by idle waves
-        const double cost = (double)(ua + ub) / (ua * ub) * 8.0 / active;
-        if (cost < best) { best = cost; WA = wa; WB = wb; UA = ua; UB = ub; }
+template <int UNR>
+__device__ __forceinline__ void wg_consume(const WgFrag<UNR> &f, const WgStream &sa, const WgStream &sb,
+                                           f32x4 (&acc)[4][4], f32x4 &bsum) {
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+        const f32x4 a = wg_mask(sa, f.a[q]), b = wg_mask(sb, f.b[q]);
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = frag_mfma(a[ja], b[jb], acc[ja][jb]);
+        bsum += a;
     }
-    if (!WA) { cgs_set_error("wgrad: tile grid %dx%d too large", NA, NB); return CGS_ERR_ARG; }
-    int64_t blocks = (n + 1023) / 1024;
-    const int64_t cap = 2 * (int64_t)num_cus;
+}
+
+// no IR-level motion of the loads (memory clobber) and no machine-scheduler motion (sched_barrier) across
+#define WG_FENCE()                        \
+    do {                                  \
+        asm volatile("" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+#define WG_MAX_E (175 * 100 + 175)   // largest dW + db image (mlp_grid second layer)
+
+// partial == NULL: every wave adds its tiles to dW/db with global fp32 atomics.
+// partial != NULL: the waves of a workgroup combine in an LDS image of [dW | db] (ds_add_f32), the
+// workgroup stores it to partial[blockIdx.x][E] and wgrad_reduce_kernel sums the images — no global
+// atomics (same-line atomics from the 8 XCDs' L2s were the dominant cost of the atomic variant) and a
+// run-to-run deterministic summation order.
+template <int UNR>
+__global__ void __launch_bounds__(512)
+    wgrad4_kernel(const float *__restrict__ P, int64_t ldp, int DA, const float *__restrict__ Q, int64_t ldq, int DB,
+                  float *__restrict__ dW, float *__restrict__ db, int64_t n, int64_t rows_per_block, int GB,
+                  int npairs, int nsub, float *__restrict__ partial) {
+    __shared__ float img[WG_MAX_E];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar loop control
+    const int pair = wave % npairs, sub = wave / npairs;
+    const bool active = sub < nsub;
+    const int E = DA * DB + DA;
+    if (partial) {
+        for (int i = tid; i < E; i += 512) img[i] = 0.f;
+        __syncthreads();
+    }
+    const int ga = pair / GB, gb = pair % GB;
+    const int acol0 = 64 * ga + 4 * c, bcol0 = 64 * gb + 4 * c;
+    if (active) {
+        const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r_end = min(n, r_begin + rows_per_block);
+        f32x4 acc[4][4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end);
+        const WgStream sb = wg_stream(Q, ldq, DB, gb, c, r_begin, r_end);
+        const int rows = (int)(r_end - r_begin), stride = nsub * 4 * UNR;
+        int row0 = sub * 4 * UNR;
+        WgFrag<UNR> f0, f1;
+        wg_fetch<UNR>(f0, sa, sb, row0, g);
+        // Straight-line double-buffered body (no mid-loop exit: rows past the range load as zeros, so a surplus
+        // half-iteration is harmless) with fences, or the prefetch gets sunk next to its first use.
+        for (; row0 < rows; row0 += 2 * stride) {
+            wg_fetch<UNR>(f1, sa, sb, row0 + stride, g);
+            WG_FENCE();
+            wg_consume<UNR>(f0, sa, sb, acc, bsum);
+            WG_FENCE();
+            wg_fetch<UNR>(f0, sa, sb, row0 + 2 * stride, g);
+            WG_FENCE();
+            wg_consume<UNR>(f1, sa, sb, acc, bsum);
+            WG_FENCE();
+        }
+        float *const outW = partial ? img : dW;
+        float *const outb = partial ? img + DA * DB : db;
+        // D layout of tile (ja, jb): reg r of lane (g, c) <-> a = 64 ga + 4 (4g + r) + ja, b = 64 gb + 4c + jb
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 64 * ga + 4 * (4 * g + r) + ja;
+                if (a >= DA) continue;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int b = bcol0 + jb;
+                    if (b < DB) atomicAdd(&outW[a * DB + b], acc[ja][jb][r]);
+                }
+            }
+        if (gb == 0 && (partial || db != nullptr)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = bsum[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g == 0 && acol0 + j < DA) atomicAdd(&outb[acol0 + j], v);
+            }
+        }
+    }
+    if (partial) {
+        __syncthreads();
+        float *dst = partial + (int64_t)blockIdx.x * E;
+        for (int i = tid; i < E; i += 512) dst[i] = img[i];
+    }
+}
+
+// dW[e] += sum_b partial[b][e]  (e < DA*DB), db[e - DA*DB] += ... ; 64 elements x 4 block-chunks per workgroup
+__global__ void __launch_bounds__(256)
+    wgrad_reduce_kernel(const float *__restrict__ partial, int blocks, int E, int DADB, float *__restrict__ dW,
+                        float *__restrict__ db) {
+    __shared__ float s[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < E) {
+        int b = ty;
+        for (; b + 12 < blocks; b += 16) {
+            a0 += partial[(int64_t)b * E + e];
+            a1 += partial[(int64_t)(b + 4) * E + e];
+            a2 += partial[(int64_t)(b + 8) * E + e];
+            a3 += partial[(int64_t)(b + 12) * E + e];
+        }
+        for (; b < blocks; b += 4) a0 += partial[(int64_t)b * E + e];
+    }
+    s[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && e < E) {
+        const float t = (s[0][tx] + s[1][tx]) + (s[2][tx] + s[3][tx]);
+        if (e < DADB) dW[e] += t;
+        else if (db) db[e - DADB] += t;
+    }
+}
+
+static int wgrad_blocks_per_cu() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("CGS_WGRAD_BLOCKS_PER_CU");
+        v = e ? atoi(e) : 1;
+        if (v < 1) v = 1;
+        if (v > 2) v = 2;
+    }
+    return v;
+}
+
+size_t cgs_wgrad_scratch_bytes_for(int num_cus) { return (size_t)2 * num_cus * WG_MAX_E * sizeof(float); }
+
+// scratch (>= cgs_mlp_wgrad_scratch_bytes()) selects the atomics-free two-pass path; NULL the atomic one.
+int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
+                      int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s) {
+    if (n <= 0) return CGS_OK;
+    static const int UNR = getenv("CGS_WGRAD_UNR") ? atoi(getenv("CGS_WGRAD_UNR")) : 2;
+    const int GA = (DA + 63) / 64, GB = (DB + 63) / 64, npairs = GA * GB;
+    const int E = DA * DB + DA;
+    if (npairs > 8 || E > WG_MAX_E) { cgs_set_error("wgrad: %d x %d not supported", DA, DB); return CGS_ERR_ARG; }
+    const int nsub = 8 / npairs;
+    int64_t blocks = (n + 255) / 256;
+    int64_t cap = (int64_t)(scratch ? wgrad_blocks_per_cu() : 1) * num_cus;
+    if (scratch) {
+        const int64_t fit = (int64_t)(scratch_bytes / ((size_t)E * sizeof(float)));
+        if (fit < 1) { cgs_set_error("wgrad: scratch too small"); return CGS_ERR_ARG; }
+        if (cap > fit) cap = fit;
+    }
     if (blocks > cap) blocks = cap;
     int64_t rpb = (n + blocks - 1) / blocks;
-    rpb = (rpb + 15) / 16 * 16;
+    const int64_t quantum = (int64_t)nsub * 4 * UNR;
+    rpb = (rpb + quantum - 1) / quantum * quantum;
     blocks = (n + rpb - 1) / rpb;
-#define WG(UA_, UB_, UNR_)                                                                                          \
-    hipLaunchKernelGGL((wgrad2_kernel<UA_, UB_, UNR_>), dim3((unsigned)blocks), dim3(512), 0, s, P, ldp, DA, Q, ldq, DB, dW, \
-                       db, n, rpb, WA, WB)
-#define ROW(UA_)                                                     \
-    switch (UB) {                                                    \
-        case 1: WG(UA_, 1, 4); break;                                \
-        case 2: WG(UA_, 2, 4); break;                                \
-        case 3: WG(UA_, 3, 2); break;                                \
-        case 4: WG(UA_, 4, 2); break;                                \
-        default: cgs_set_error("wgrad: tile grid %dx%d too large", NA, NB); return CGS_ERR_ARG; \
-    }
-    switch (UA) {
-        case 1: ROW(1); break;
-        case 2: ROW(2); break;
-        case 3: ROW(3); break;
-        case 4: ROW(4); break;
-        default: cgs_set_error("wgrad: tile grid %dx%d too large", NA, NB); return CGS_ERR_ARG;
-    }
-#undef ROW
-#undef WG
+#define WG_LAUNCH(U)                                                                                                  \
+    hipLaunchKernelGGL((wgrad4_kernel<U>), dim3((unsigned)blocks), dim3(512), 0, s, P, ldp, DA, Q, ldq, DB, dW, db, n, rpb, \
+                       GB, npairs, nsub, (float *)scratch)
+    if (UNR == 4) WG_LAUNCH(4);
+    else if (UNR == 1) WG_LAUNCH(1);
+    else WG_LAUNCH(2);
+#undef WG_LAUNCH
     CGS_CHECK_HIP(hipGetLastError());
+    if (scratch) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, (const float *)scratch,
+                           (int)blocks, E, DA * DB, dW, db);
+        CGS_CHECK_HIP(hipGetLastError());
+    }
     return CGS_OK;
 }

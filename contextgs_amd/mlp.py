@@ -12,6 +12,12 @@ import torch.nn as nn
 from . import _lib
 
 _ACT = {None: 0, nn.Tanh: 1, nn.Sigmoid: 2}
+def _wgrad_workspace(dev) -> torch.Tensor:
+    """Device scratch for the two-pass (atomics-free, deterministic) weight-gradient reduction; taken from the
+    caching allocator per call so that it is stream-safe."""
+    return torch.empty(int(_lib.lib().cgs_mlp_wgrad_scratch_bytes()), dtype=torch.uint8, device=dev)
+
+
 _SUPPORTED = {(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0), (71, 100, 175, 0), (15, 100, 175, 0), (71, 100, 3, 0),
               (15, 100, 3, 0)}
 
@@ -67,10 +73,11 @@ class _MLP2(torch.autograd.Function):
         db1 = torch.zeros(hid, dtype=torch.float32, device=dev)
         dW2 = torch.zeros_like(W2)
         db2 = torch.zeros(out, dtype=torch.float32, device=dev)
+        ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(W2), _lib.ptr(y),
                                        _lib.ptr(dy), out, _lib.ptr(h), _lib.ptr(dx), in_f, 0, _lib.ptr(dz1), _lib.ptr(dz2),
                                        _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n,
-                                       _lib.current_stream()), "cgs_mlp2_backward")
+                                       _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_mlp2_backward")
         return dx, dW1, db1, dW2, db2, None
 
 
@@ -150,11 +157,12 @@ class _AnchorMLP3(torch.autograd.Function):
         db1cat = torch.zeros(150, dtype=torch.float32, device=dev)
         dW2 = [torch.zeros_like(w) for w in W2]
         db2 = [torch.zeros(w.shape[0], dtype=torch.float32, device=dev) for w in W2]
+        ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward(
             _lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(g_op),
             _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(dx), x.shape[1], _lib.ptr(dz1), _lib.ptr(dz2_op),
             _lib.ptr(dz2_color), _lib.ptr(dW1cat), _lib.ptr(db1cat), _ptr_array(dW2), _ptr_array(db2), n,
-            _lib.current_stream()), "cgs_anchor_mlp3_backward")
+            _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward")
         grads = [dx]
         for i in range(3):
             grads += [dW1cat[50 * i:50 * (i + 1)], db1cat[50 * i:50 * (i + 1)], dW2[i], db2[i]]

@@ -213,14 +213,18 @@ int cgs_mlp2_forward(int in, int hid, int out, int act, const float *X,
                      float *H, int64_t n, void *stream);
 /* Backward: dX [n, lddx] (NULL to skip; accumulate_dx != 0 adds into it), dZ1
  * [n, hid] and dZ2 [n, out] are scratch outputs (dZ2 may be NULL when act == 0).
- * dW1/db1/dW2/db2 are ACCUMULATED into (fp32 atomics): zero or pre-load them. */
+ * dW1/db1/dW2/db2 are ACCUMULATED into: zero or pre-load them.  scratch (device,
+ * >= cgs_mlp_wgrad_scratch_bytes()) holds per-workgroup partial weight gradients
+ * that a second kernel sums (deterministic, no global atomics); with scratch ==
+ * NULL the partials are combined with fp32 atomics instead. */
+size_t cgs_mlp_wgrad_scratch_bytes(void);
 int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       int64_t ldx, const float *W1, const float *W2,
                       const float *Y, const float *dY, int64_t ldy,
                       const float *H, float *dX, int64_t lddx,
                       int accumulate_dx, float *dZ1, float *dZ2, float *dW1,
                       float *db1, float *dW2, float *db2, int64_t n,
-                      void *stream);
+                      void *scratch, size_t scratch_bytes, void *stream);
 
 /* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
  * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on
@@ -229,7 +233,7 @@ int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
  * Hcat [n,150] holds the three ReLU hidden layers side by side; dZ1cat [n,150],
  * dZ2_op [n,10], dZ2_color [n,30] are backward scratch.  dW1cat [150,54] /
  * db1cat [150] stack the three first-layer gradients; all weight / bias
- * gradients are ACCUMULATED into. */
+ * gradients are ACCUMULATED into (scratch as for cgs_mlp2_backward). */
 int cgs_anchor_mlp3_forward(const float *X, int64_t ldx,
                             const float *const *W1, const float *const *b1,
                             const float *const *W2, const float *const *b2,
@@ -243,7 +247,7 @@ int cgs_anchor_mlp3_backward(const float *X, int64_t ldx,
                              int64_t lddx, float *dZ1cat, float *dZ2_op,
                              float *dZ2_color, float *dW1cat, float *db1cat,
                              float *const *dW2, float *const *db2, int64_t n,
-                             void *stream);
+                             void *scratch, size_t scratch_bytes, void *stream);
 
 /* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
  * scene/gaussian_model.py:1556; compressai is not in the mount, the density is
