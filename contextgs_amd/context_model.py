@@ -26,11 +26,14 @@ from __future__ import annotations
 
 import torch
 
+from . import ctx_ops as _ctx
+from . import encodings as _enc
 from . import mlp as _mlp
 from .encodings import STE_multistep, get_binary_vxl_size
 from .multi_level import torch_unique_with_indices
 
 Q_FEAT0, Q_SCALING0, Q_OFFSETS0 = 1, 0.001, 0.2      # :1564-1566
+FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip it to compare with the torch composition)
 
 
 def mapping_to_orign(mapping_list, L, mask=None):                       # :1768-1787
@@ -276,29 +279,56 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     hyp_l = torch.split(gather_unique(hyper_feat, perm), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
-    content_pre_gathered = None
+    ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
+    # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
+    fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
     for j, (i, _tc, orig, _a) in enumerate(c["plan"]):
         n_l = sizes[j]
         if n_l > 0:
-            if content_pre_gathered is None:                                           # :1596-1600
-                feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
+            loc = None
+            if keep_stats and choose_mask is not None:
+                loc = torch.nonzero(choose_mask[orig])[:, 0]
+            subset_mode = _mlp.supported(pc.get_grid_mlp[i]) and (not keep_stats or loc is not None)
+            use_fused = fused and subset_mode
+            if ctx_src is None:                                                        # :1596-1600
+                if use_fused:
+                    a_src = anchor * mask_anchor_bool.unsqueeze(1) if (i >= 1 and mask_anchor_bool is not None) else anchor
+                    feat_in = _ctx.rowcat([(a_src, orig, True), (hyp_l[j], None, True)])
+                else:
+                    feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
             else:
-                feat_in = torch.cat([content_pre_gathered, hyp_l[j]], dim=1)
+                idx, pos, base_f, base_s = ctx_src
+                if use_fused:
+                    feat_in = _ctx.rowcat([(anchor, idx, False), (base_f, pos, False), (base_s, pos, False),
+                                           (hyp_l[j], None, True)])
+                else:
+                    feat_in = torch.cat([gather_rows(anchor, idx), gather_rows(base_f, pos), gather_rows(base_s, pos),
+                                         hyp_l[j]], dim=1)
             # Only the three step-size outputs of mlp_grid are needed for EVERY row (they scale the noise /
             # the rounding); the 172 mean/scale outputs are consumed by the rate model alone, i.e. by the
             # `choose_mask` rows (15 % in training, :1658-1669; none at all when predict_bpp is off).  The
             # reference evaluates all 175 outputs for all rows and throws 85-100 % of them away; here the
             # second layer runs with its 3 step-size rows on every anchor and with all rows on the chosen
             # anchors only (identical values: the same fp32 fma chains).
-            loc = None
-            if keep_stats and choose_mask is not None:
-                loc = torch.nonzero(choose_mask[orig])[:, 0]
-            subset_mode = _mlp.supported(pc.get_grid_mlp[i]) and (not keep_stats or loc is not None)
             if subset_mode:
                 seq = pc.get_grid_mlp[i]
                 D_ = pc.feat_dim
                 n_stat = 2 * (D_ + 6 + 3 * K)
                 qadj = _mlp.mlp2_weights(feat_in, seq[0].weight, seq[0].bias, seq[2].weight[n_stat:], seq[2].bias[n_stat:])
+            if use_fused:
+                # step sizes + noise (:1603-1616) in one launch; the rate of the chosen rows is one more (rate_model)
+                hf, hs, ho, Q_all = _ctx.noise_quant(feat_l[j], scal_l[j], off_l[j].reshape(n_l, 3 * K), qadj,
+                                                     (Q_FEAT0, Q_SCALING0, Q_OFFSETS0))
+                if keep_stats:
+                    levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
+                                       yo=ho, Q=Q_all, pred=grid_mlp(pc, i, gather_unique(feat_in, loc))))
+                feat_q.append(hf)
+                scal_q.append(hs)
+                off_q.append(ho)
+                if i != 0:
+                    ctx_src = _next_context(c, i, feat_q, scal_q)
+                continue
+            if subset_mode:
                 Q_feat = (Q_FEAT0 * (1 + torch.tanh(qadj[:, 0:1]))).clamp(1e-9)
                 Q_scaling = (Q_SCALING0 * (1 + torch.tanh(qadj[:, 1:2]))).clamp(1e-9)
                 Q_offsets = (Q_OFFSETS0 * (1 + torch.tanh(qadj[:, 2:3]))).clamp(1e-9)
@@ -332,13 +362,18 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         feat_q.append(hf)
         scal_q.append(hs)
         off_q.append(ho)
-        if i != 0:                                                                     # :1650-1651 / 1711-1724
-            idx, pos = c["ctx_idx"][i], c["ctx_pos"][i]
-            base_f = feat_q[0] if len(feat_q) == 1 else torch.cat(feat_q, dim=0)       # coded prefix (<= 20 % of N)
-            base_s = scal_q[0] if len(scal_q) == 1 else torch.cat(scal_q, dim=0)
-            content_pre_gathered = torch.cat([gather_rows(anchor, idx), gather_rows(base_f, pos), gather_rows(base_s, pos)], dim=1)
+        if i != 0:
+            ctx_src = _next_context(c, i, feat_q, scal_q)
     cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     return c, cat(feat_q), cat(scal_q), cat(off_q).view(-1, K, 3), likelihood_hyper, levels
+
+
+def _next_context(c, i, feat_q, scal_q):
+    """:1650-1651 / 1711-1724 — what the level coded after level i reads of the already coded anchors: their
+    original rows (for the anchor position) and their positions in the coded prefix (<= 20 % of N)."""
+    base_f = feat_q[0] if len(feat_q) == 1 else torch.cat(feat_q, dim=0)
+    base_s = scal_q[0] if len(scal_q) == 1 else torch.cat(scal_q, dim=0)
+    return c["ctx_idx"][i], c["ctx_pos"][i], base_f, base_s
 
 
 def draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits):
@@ -367,7 +402,19 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     s_feat, s_scaling, s_offsets = zero, zero, zero
     n_feat = n_scaling = n_offsets = 0
     level_bpp_sums, level_rows = [], []
+    x_means = None
     for L in levels:
+        if L.get("fused"):                      # one launch: gathers of the chosen rows + the three rate terms + sums
+            if x_means is None:
+                x_means = torch.stack([xm_feat, xm_scaling, xm_offsets]).detach()
+            n_sub = int(L["loc"].shape[0])
+            sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"],
+                                   binary_grid_masks.reshape(n, K), L["rows"], x_means, _enc.use_clamp, K)
+            s_feat, s_scaling, s_offsets = s_feat + sums[0], s_scaling + sums[1], s_offsets + sums[2]
+            n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
+            level_rows.append(n_sub)
+            level_bpp_sums.append(sums.detach().sum())
+            continue
         if L["selected"]:                       # the level already holds the chosen rows only
             rows = L["rows"]
             g = lambda t: t

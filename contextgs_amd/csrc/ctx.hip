@@ -1,0 +1,343 @@
+// Fused element-wise stages of the per-level context model (scene/gaussian_model.py:1556-1707), training path.
+// The level loop of the reference is ~120 small torch kernels per level and direction (gathers, cats, uniform_,
+// tanh/clamp chains, masked sums); rocprof of the 1 M-anchor step shows them as ~8 ms of 5-25 us launches
+// (profiles/r01_rocprof_bench_1m_v1_mfma_mlp.txt).  Three HBM-bound kernels per direction replace them:
+//
+//   rowcat        out[r] = [src0[idx0[r]] | src1[idx1[r]] | ...]        the MLP input of a level (:1594-1600,
+//                                                                       :1650-1651, :1711-1724)
+//   noise_quant   Q = clamp(Q0 (1 + tanh(q)), 1e-9); y = x + U(-.5,.5) Q  (:1603-1616) for feat/scaling/offsets
+//   level_rate    sum of the discretised-Gaussian bits of the chosen rows (:1658-1669 + utils/entropy_models.py:30-50)
+//
+// All three are pure streaming kernels: their roofline is HBM bytes (rows x widths x 4 B).
+#include "cgs_internal.h"
+#include "rate_math.h"
+
+// ------------------------------------------------------------------------------------------------------------
+#define RC_MAX_SRC 4
+struct RowcatArgs {
+    const float *src[RC_MAX_SRC];
+    float *dsrc[RC_MAX_SRC];
+    const int64_t *idx[RC_MAX_SRC];
+    int width[RC_MAX_SRC], ld[RC_MAX_SRC], mode[RC_MAX_SRC], begin[RC_MAX_SRC];
+    int nsrc, W;
+};
+
+__global__ void __launch_bounds__(256) rowcat_fwd_kernel(RowcatArgs a, int64_t n, float *__restrict__ out) {
+    const int64_t total = n * a.W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.W;
+        const int c = (int)(i - r * a.W);
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < RC_MAX_SRC; ++k)
+            if (k < a.nsrc && c >= a.begin[k]) s = k;
+        const int64_t row = a.idx[s] ? a.idx[s][r] : r;
+        out[i] = a.src[s][row * a.ld[s] + (c - a.begin[s])];
+    }
+}
+
+// mode 0: no gradient; 1: store (rows of this source are distinct, or identity); 2: atomic add (rows repeat)
+__global__ void __launch_bounds__(256) rowcat_bwd_kernel(RowcatArgs a, int64_t n, const float *__restrict__ dout) {
+    const int64_t total = n * a.W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.W;
+        const int c = (int)(i - r * a.W);
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < RC_MAX_SRC; ++k)
+            if (k < a.nsrc && c >= a.begin[k]) s = k;
+        if (a.mode[s] == 0) continue;
+        const int64_t row = a.idx[s] ? a.idx[s][r] : r;
+        float *p = a.dsrc[s] + row * a.ld[s] + (c - a.begin[s]);
+        if (a.mode[s] == 1) *p = dout[i];
+        else atomicAdd(p, dout[i]);
+    }
+}
+
+static int rowcat_fill(RowcatArgs &a, int nsrc, const void *const *data, const int64_t *const *idx, const int *width,
+                       const int *ld, const int *mode, bool bwd) {
+    if (nsrc < 1 || nsrc > RC_MAX_SRC || !data || !width || !ld) { cgs_set_error("rowcat: bad source list"); return CGS_ERR_ARG; }
+    a.nsrc = nsrc;
+    int W = 0;
+    for (int s = 0; s < RC_MAX_SRC; ++s) {
+        const bool on = s < nsrc;
+        a.src[s] = on && !bwd ? (const float *)data[s] : nullptr;
+        a.dsrc[s] = on && bwd ? (float *)data[s] : nullptr;
+        a.idx[s] = on && idx ? idx[s] : nullptr;
+        a.width[s] = on ? width[s] : 0;
+        a.ld[s] = on ? ld[s] : 0;
+        a.mode[s] = on && mode ? mode[s] : 0;
+        a.begin[s] = W;
+        if (on) {
+            if (width[s] < 1 || ld[s] < width[s]) { cgs_set_error("rowcat: bad width/ld of source %d", s); return CGS_ERR_ARG; }
+            if (!data[s] && (!bwd || (mode && mode[s]))) { cgs_set_error("rowcat: NULL source %d", s); return CGS_ERR_ARG; }
+            W += width[s];
+        }
+    }
+    a.W = W;
+    return CGS_OK;
+}
+
+static unsigned stream_grid(int64_t total, int per_block) {
+    int64_t b = (total + per_block - 1) / per_block;
+    const int64_t cap = 256 * 16;
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *const *idx, const int *width,
+                              const int *ld, int64_t n, float *out, void *stream) {
+    if (n < 0) { cgs_set_error("rowcat_fwd: n < 0"); return CGS_ERR_ARG; }
+    RowcatArgs a;
+    int rc = rowcat_fill(a, nsrc, data, idx, width, ld, nullptr, false);
+    if (rc) return rc;
+    if (n == 0) return CGS_OK;
+    if (!out) { cgs_set_error("rowcat_fwd: NULL out"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(rowcat_fwd_kernel, dim3(stream_grid(n * a.W, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, n, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const *idx, const int *width, const int *ld,
+                              const int *mode, int64_t n, const float *dout, void *stream) {
+    if (n < 0 || !mode) { cgs_set_error("rowcat_bwd: bad args"); return CGS_ERR_ARG; }
+    RowcatArgs a;
+    int rc = rowcat_fill(a, nsrc, (const void *const *)ddata, idx, width, ld, mode, true);
+    if (rc) return rc;
+    if (n == 0) return CGS_OK;
+    if (!dout) { cgs_set_error("rowcat_bwd: NULL dout"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(rowcat_bwd_kernel, dim3(stream_grid(n * a.W, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, n, dout);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Counter-based noise: u(seed, tensor, element) in [-0.5, 0.5), regenerated (not stored) by the backward.
+__device__ __forceinline__ float ctx_noise(uint64_t seed, uint32_t tensor, uint64_t elem) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (elem * 4 + tensor + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+__device__ __forceinline__ float ctx_step(float q0, float qadj) { return fmaxf(q0 * (1.f + tanhf(qadj)), 1e-9f); }
+
+// 16 lanes per row: a wave instruction touches 4 rows x 64 contiguous bytes of each tensor
+__global__ void __launch_bounds__(256)
+    noise_quant_fwd_kernel(const float *__restrict__ xf, const float *__restrict__ xs, const float *__restrict__ xo,
+                           const float *__restrict__ qadj, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
+                           float q0s, float q0o, float *__restrict__ yf, float *__restrict__ ys,
+                           float *__restrict__ yo, float *__restrict__ Q) {
+    const int l = threadIdx.x & 15;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
+        const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
+                    qo = ctx_step(q0o, qadj[r * 3 + 2]);
+        if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);
+        for (int c = l; c < D; c += 16) yf[r * D + c] = xf[r * D + c] + ctx_noise(seed, 0, (uint64_t)r * D + c) * qf;
+        for (int c = l; c < S; c += 16) ys[r * S + c] = xs[r * S + c] + ctx_noise(seed, 1, (uint64_t)r * S + c) * qs;
+        for (int c = l; c < O; c += 16) yo[r * O + c] = xo[r * O + c] + ctx_noise(seed, 2, (uint64_t)r * O + c) * qo;
+    }
+}
+
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// d_x = d_y (identity, done by the caller);  d_qadj[r,k] = (sum_c d_y[r,c] u[r,c] + dQ_ext[r,k]) * dQ/dqadj
+__global__ void __launch_bounds__(256)
+    noise_quant_bwd_kernel(const float *__restrict__ dyf, const float *__restrict__ dys, const float *__restrict__ dyo,
+                           const float *__restrict__ dQ_ext, const float *__restrict__ qadj, int64_t n, int D, int S,
+                           int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ dqadj) {
+    const int l = threadIdx.x & 15;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
+        float af = 0.f, as = 0.f, ao = 0.f;
+        if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise(seed, 0, (uint64_t)r * D + c);
+        if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise(seed, 1, (uint64_t)r * S + c);
+        if (dyo) for (int c = l; c < O; c += 16) ao += dyo[r * O + c] * ctx_noise(seed, 2, (uint64_t)r * O + c);
+        af = sum16(af);
+        as = sum16(as);
+        ao = sum16(ao);
+        if (l < 3) {
+            const float q0 = l == 0 ? q0f : (l == 1 ? q0s : q0o);
+            float g = l == 0 ? af : (l == 1 ? as : ao);
+            if (dQ_ext) g += dQ_ext[r * 3 + l];
+            const float t = tanhf(qadj[r * 3 + l]);
+            dqadj[r * 3 + l] = (q0 * (1.f + t) >= 1e-9f) ? g * q0 * (1.f - t * t) : 0.f;
+        }
+    }
+}
+
+extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo, const float *qadj, int64_t n,
+                                   int D, int S, int O, uint64_t seed, float q0f, float q0s, float q0o, float *yf,
+                                   float *ys, float *yo, float *Q, void *stream) {
+    if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_fwd: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!xf || !xs || !xo || !qadj || !yf || !ys || !yo || !Q) { cgs_set_error("noise_quant_fwd: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(noise_quant_fwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
+                       xo, qadj, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
+                                   const float *qadj, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
+                                   float q0s, float q0o, float *dqadj, void *stream) {
+    if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_bwd: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!qadj || !dqadj) { cgs_set_error("noise_quant_bwd: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(noise_quant_bwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dyf,
+                       dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// One wave per chosen row s (level row r = loc[s], anchor row grows[s]); element e of the row's D + 6 + 3K values:
+//   e <  D        feat     x = yf[r,e]        mean = pred[s, e]             scale = pred[s, D + e]          q = Q[r,0]
+//   e <  D + 6    scaling  x = ys[r,e-D]      mean = pred[s, 2D + .]        scale = pred[s, 2D + 6 + .]     q = Q[r,1]
+//   else          offsets  x = yo[r,.]        mean = pred[s, 2D + 12 + .]   scale = pred[s, 2D + 12 + 3K + .] q = Q[r,2]
+//                 weighted by masks[grows[s], ./3]   (binary_grid_masks.repeat(1,1,3), :1664)
+struct RateElem { float x, mean, scale, q, w, xm; int kind, mcol, scol; int64_t xoff; };
+
+__device__ __forceinline__ RateElem rate_elem(int e, int64_t s, int64_t r, int64_t grow, int D, int K, int64_t ldp,
+                                              const float *__restrict__ yf, const float *__restrict__ ys,
+                                              const float *__restrict__ yo, const float *__restrict__ Q,
+                                              const float *__restrict__ pred, const float *__restrict__ masks,
+                                              const float *__restrict__ x_means) {
+    RateElem t;
+    const int O = 3 * K;
+    const float *xsrc;
+    int c;
+    if (e < D) { t.kind = 0; c = e; xsrc = yf; t.xoff = r * D + c; t.mcol = c; t.scol = D + c; }
+    else if (e < D + 6) { t.kind = 1; c = e - D; xsrc = ys; t.xoff = r * 6 + c; t.mcol = 2 * D + c; t.scol = 2 * D + 6 + c; }
+    else { t.kind = 2; c = e - D - 6; xsrc = yo; t.xoff = r * O + c; t.mcol = 2 * D + 12 + c; t.scol = 2 * D + 12 + O + c; }
+    t.x = xsrc[t.xoff];
+    t.mean = pred[s * ldp + t.mcol];
+    t.scale = pred[s * ldp + t.scol];
+    t.q = Q[r * 3 + t.kind];
+    t.w = (t.kind == 2 && masks) ? masks[grow * K + c / 3] : 1.f;
+    t.xm = x_means ? x_means[t.kind] : 0.f;
+    return t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+    level_rate_fwd_kernel(const float *__restrict__ yf, const float *__restrict__ ys, const float *__restrict__ yo,
+                          const float *__restrict__ Q, const int64_t *__restrict__ loc, const float *__restrict__ pred,
+                          const float *__restrict__ masks, const int64_t *__restrict__ grows,
+                          const float *__restrict__ x_means, int use_clamp, int64_t n_sub, int D, int K,
+                          int64_t ldp, float *__restrict__ sums) {
+    __shared__ float part[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = D + 6 + 3 * K;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
+        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : 0;
+        for (int e = lane; e < E; e += 64) {
+            const RateElem t = rate_elem(e, s, r, grow, D, K, ldp, yf, ys, yo, Q, pred, masks, x_means);
+            const float b = rate_bits(rate_terms(t.x, t.mean, t.scale, t.q, t.xm, use_clamp)) * t.w;
+            acc[0] += t.kind == 0 ? b : 0.f;
+            acc[1] += t.kind == 1 ? b : 0.f;
+            acc[2] += t.kind == 2 ? b : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&sums[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                                       (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// d_pred [n_sub, P] is fully written; d_yf/d_ys/d_yo rows loc[s] are written (other rows: caller zero-fills);
+// dQ [n_l, 3] rows loc[s] are written.
+__global__ void __launch_bounds__(256)
+    level_rate_bwd_kernel(const float *__restrict__ yf, const float *__restrict__ ys, const float *__restrict__ yo,
+                          const float *__restrict__ Q, const int64_t *__restrict__ loc, const float *__restrict__ pred,
+                          const float *__restrict__ masks, const int64_t *__restrict__ grows,
+                          const float *__restrict__ x_means, int use_clamp, int64_t n_sub, int D, int K,
+                          int64_t ldp, const float *__restrict__ g_sums, float *__restrict__ d_pred, float *__restrict__ d_yf,
+                          float *__restrict__ d_ys, float *__restrict__ d_yo, float *__restrict__ dQ) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = D + 6 + 3 * K, P = 2 * E;
+    const float g0 = g_sums[0], g1 = g_sums[1], g2 = g_sums[2];
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
+        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : 0;
+        float gq[3] = {0.f, 0.f, 0.f};
+        if (lane < ldp - P) d_pred[s * ldp + P + lane] = 0.f;   // outputs beyond the mean/scale block (the step sizes)
+        for (int e = lane; e < E; e += 64) {
+            const RateElem t = rate_elem(e, s, r, grow, D, K, ldp, yf, ys, yo, Q, pred, masks, x_means);
+            const RateTerms rt = rate_terms(t.x, t.mean, t.scale, t.q, t.xm, use_clamp);
+            const float gb = (t.kind == 0 ? g0 : (t.kind == 1 ? g1 : g2)) * t.w;
+            const RateGrads g = rate_grads(rt, t.scale, gb);
+            d_pred[s * ldp + t.mcol] = g.gm;
+            d_pred[s * ldp + t.scol] = g.gs;
+            float *dx = t.kind == 0 ? d_yf : (t.kind == 1 ? d_ys : d_yo);
+            dx[t.xoff] = g.gx;
+            gq[0] += t.kind == 0 ? g.gq : 0.f;
+            gq[1] += t.kind == 1 ? g.gq : 0.f;
+            gq[2] += t.kind == 2 ? g.gq : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = wave_sum(gq[k]);
+            if (lane == 0) dQ[r * 3 + k] = v;
+        }
+    }
+}
+
+static int level_rate_check(const float *yf, const float *ys, const float *yo, const float *Q, const float *pred,
+                            int64_t n_sub, int D, int K, int64_t ldpred, const char *what) {
+    if (n_sub < 0 || D < 1 || K < 1 || ldpred < 2 * (D + 6 + 3 * K) || ldpred > 2 * (D + 6 + 3 * K) + 64) { cgs_set_error("%s: bad args", what); return CGS_ERR_ARG; }
+    if (n_sub > 0 && (!yf || !ys || !yo || !Q || !pred)) { cgs_set_error("%s: NULL", what); return CGS_ERR_ARG; }
+    return CGS_OK;
+}
+
+extern "C" int cgs_level_rate_fwd(const float *yf, const float *ys, const float *yo, const float *Q, const int64_t *loc,
+                                  const float *pred, const float *masks, const int64_t *grows, const float *x_means,
+                                  int use_clamp, int64_t n_sub, int D, int K, int64_t ldpred, float *sums,
+                                  void *stream) {
+    int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_fwd");
+    if (rc) return rc;
+    if (n_sub == 0) return CGS_OK;
+    if (!sums || (use_clamp && !x_means) || (masks && !grows)) { cgs_set_error("level_rate_fwd: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_RATE_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(level_rate_fwd_kernel, dim3(stream_grid(n_sub, 4 * 4)), dim3(256), 0, (hipStream_t)stream, yf, ys, yo,
+                       Q, loc, pred, masks, grows, use_clamp ? x_means : nullptr, use_clamp, n_sub, D, K, ldpred, sums);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo, const float *Q, const int64_t *loc,
+                                  const float *pred, const float *masks, const int64_t *grows, const float *x_means,
+                                  int use_clamp, int64_t n_sub, int D, int K, int64_t ldpred, const float *g_sums,
+                                  float *d_pred, float *d_yf, float *d_ys, float *d_yo, float *dQ, void *stream) {
+    int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_bwd");
+    if (rc) return rc;
+    if (n_sub == 0) return CGS_OK;
+    if (!g_sums || !d_pred || !d_yf || !d_ys || !d_yo || !dQ || (use_clamp && !x_means) || (masks && !grows)) {
+        cgs_set_error("level_rate_bwd: NULL");
+        return CGS_ERR_ARG;
+    }
+    CgsProfScope prof(CGS_PROF_RATE_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(level_rate_bwd_kernel, dim3(stream_grid(n_sub, 4 * 4)), dim3(256), 0, (hipStream_t)stream, yf, ys, yo,
+                       Q, loc, pred, masks, grows, use_clamp ? x_means : nullptr, use_clamp, n_sub, D, K, ldpred, g_sums, d_pred,
+                       d_yf, d_ys, d_yo, dQ);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

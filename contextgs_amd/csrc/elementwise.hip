@@ -80,33 +80,7 @@ extern "C" int cgs_ste_multistep(const float *x, const float *Q, int64_t n, int6
     return CGS_OK;
 }
 
-#define INV_SQRT2 0.70710678118654752440f
-#define SQRT2 1.4142135623730951f
-#define INV_SQRT_PI 0.56418958354775628695f
-#define LIK_BOUND 1e-6f
-
-struct RateTerms { float xc, s, inv, zu, zl, diff; bool in_range; };
-
-__device__ __forceinline__ RateTerms rate_terms(float x, float mean, float scale, float q, float x_mean,
-                                                int use_clamp) {
-    RateTerms t;
-    t.in_range = true;
-    t.xc = x;
-    if (use_clamp) {
-        const float lo = x_mean - 15000.f * q, hi = x_mean + 15000.f * q;
-        t.in_range = (x >= lo) && (x <= hi);
-        t.xc = fminf(fmaxf(x, lo), hi);
-    }
-    t.s = fmaxf(scale, 1e-9f);
-    t.inv = 1.f / t.s;
-    // Normal(mean, s).cdf(v) = 0.5 * (1 + erf((v - mean) * (1/s) / sqrt(2)))
-    t.zu = ((t.xc + 0.5f * q) - mean) * t.inv / SQRT2;
-    t.zl = ((t.xc - 0.5f * q) - mean) * t.inv / SQRT2;
-    const float upper = 0.5f * (1.f + erff(t.zu));
-    const float lower = 0.5f * (1.f + erff(t.zl));
-    t.diff = upper - lower;
-    return t;
-}
+#include "rate_math.h"
 
 __global__ void __launch_bounds__(EW_THREADS)
     entropy_gaussian_fwd_kernel(int64_t n, const float *__restrict__ x, const float *__restrict__ mean,
@@ -115,7 +89,7 @@ __global__ void __launch_bounds__(EW_THREADS)
     const int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= n) return;
     const RateTerms t = rate_terms(x[i], mean[i], scale[i], Q[i / q_div], use_clamp ? x_mean[0] : 0.f, use_clamp);
-    bits[i] = -log2f(fmaxf(fabsf(t.diff), LIK_BOUND));
+    bits[i] = rate_bits(t);
 }
 
 __global__ void __launch_bounds__(EW_THREADS)
@@ -128,26 +102,11 @@ __global__ void __launch_bounds__(EW_THREADS)
     if (i >= n) return;
     const float sc = scale[i];
     const RateTerms t = rate_terms(x[i], mean[i], sc, Q[i / q_div], use_clamp ? x_mean[0] : 0.f, use_clamp);
-    const float lik = fabsf(t.diff);
-    float gx = 0.f, gm = 0.f, gs = 0.f, gq = 0.f;
-    // Low_bound.backward zeroes the gradient wherever the raw likelihood is below the bound
-    if (lik >= LIK_BOUND) {
-        const float g_lik = g_bits[i] * (-1.4426950408889634f / lik);
-        const float sgn = t.diff > 0.f ? 1.f : (t.diff < 0.f ? -1.f : 0.f);
-        const float g_diff = g_lik * sgn;
-        const float g_zu = g_diff * INV_SQRT_PI * __expf(-t.zu * t.zu);
-        const float g_zl = -g_diff * INV_SQRT_PI * __expf(-t.zl * t.zl);
-        const float k = t.inv * INV_SQRT2;
-        const float g_xc = (g_zu + g_zl) * k;
-        gx = t.in_range ? g_xc : 0.f;
-        gm = -g_xc;
-        gq = 0.5f * (g_zu - g_zl) * k;
-        gs = (sc >= 1e-9f) ? -(g_zu * t.zu + g_zl * t.zl) * t.inv : 0.f;
-    }
-    g_x[i] = gx;
-    g_mean[i] = gm;
-    g_scale[i] = gs;
-    g_Q[i] = gq;
+    const RateGrads g = rate_grads(t, sc, g_bits[i]);
+    g_x[i] = g.gx;
+    g_mean[i] = g.gm;
+    g_scale[i] = g.gs;
+    g_Q[i] = g.gq;
 }
 
 extern "C" int cgs_entropy_gaussian_fwd(const float *x, const float *mean, const float *scale, const float *Q,

@@ -1,0 +1,162 @@
+"""Fused element-wise stages of the per-level context model (training path), include/cgs.h
+`cgs_rowcat_*`, `cgs_noise_quant_*`, `cgs_level_rate_*` (csrc/ctx.hip).
+
+Reference: scene/gaussian_model.py:1556-1707 (multi_scale_generating).  Each op is an
+autograd.Function whose forward and backward are ONE HIP launch each; the torch composition
+they replace stays in context_model.py as the eval / unsupported-shape path and as the
+parity reference of tests/test_ctx_ops_gpu.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+
+import torch
+
+from . import _lib
+
+_f32 = torch.float32
+
+
+def _c(t):
+    t = t if t.dtype == _f32 else t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptrs(ts):
+    return (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _ints(v):
+    return (C.c_int * len(v))(*v)
+
+
+class _RowCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, *srcs):
+        # spec[s] = (idx LongTensor | None, distinct: bool)
+        srcs = [_c(s) for s in srcs]
+        _lib.require_device(*srcs)
+        idxs = [sp[0] for sp in spec]
+        n = next((i.shape[0] for i in idxs if i is not None), srcs[0].shape[0])
+        for s, i in zip(srcs, idxs):
+            if i is None and s.shape[0] != n:
+                raise ValueError("rowcat: an un-indexed source must have one row per output row")
+        widths = [int(s.shape[1]) for s in srcs]
+        out = torch.empty(n, sum(widths), dtype=_f32, device=srcs[0].device)
+        if n > 0:
+            _lib.check(_lib.lib().cgs_rowcat_fwd(len(srcs), _ptrs(srcs), _ptrs(idxs), _ints(widths), _ints(widths), n,
+                                                 _lib.ptr(out), _lib.current_stream()), "cgs_rowcat_fwd")
+        ctx.spec, ctx.widths, ctx.n = spec, widths, n
+        ctx.rows = [int(s.shape[0]) for s in srcs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        grads, modes = [], []
+        for k, ((idx, distinct), w, rows) in enumerate(zip(ctx.spec, ctx.widths, ctx.rows)):
+            if not ctx.needs_input_grad[1 + k]:
+                grads.append(None)
+                modes.append(0)
+            elif idx is None:
+                grads.append(torch.empty(rows, w, dtype=_f32, device=g.device))      # every row written
+                modes.append(1)
+            else:
+                grads.append(torch.zeros(rows, w, dtype=_f32, device=g.device))
+                modes.append(1 if distinct else 2)
+        if any(modes) and ctx.n > 0:
+            _lib.check(_lib.lib().cgs_rowcat_bwd(len(grads), _ptrs(grads), _ptrs([sp[0] for sp in ctx.spec]),
+                                                 _ints(ctx.widths), _ints(ctx.widths), _ints(modes), ctx.n,
+                                                 _lib.ptr(g), _lib.current_stream()), "cgs_rowcat_bwd")
+        return (None, *grads)
+
+
+def rowcat(parts):
+    """cat([src[idx] for (src, idx, distinct) in parts], dim=1) in one launch; idx None = all rows in order;
+    distinct says the rows of idx do not repeat (plain scatter backward instead of atomics)."""
+    spec = tuple((idx, bool(distinct)) for (_s, idx, distinct) in parts)
+    return _RowCat.apply(spec, *[s for (s, _i, _d) in parts])
+
+
+_seed_counter = itertools.count(1)
+
+
+def next_seed() -> int:
+    """A fresh 64-bit stream id per call, derived from torch's seed without a device sync."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+
+
+class _NoiseQuant(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xf, xs, xo, qadj, seed, q0):
+        xf, xs, xo, qadj = _c(xf), _c(xs), _c(xo), _c(qadj)
+        _lib.require_device(xf, xs, xo, qadj)
+        n = xf.shape[0]
+        yf, ys, yo = torch.empty_like(xf), torch.empty_like(xs), torch.empty_like(xo)
+        Q = torch.empty(n, 3, dtype=_f32, device=xf.device)
+        _lib.check(_lib.lib().cgs_noise_quant_fwd(
+            _lib.ptr(xf), _lib.ptr(xs), _lib.ptr(xo), _lib.ptr(qadj), n, xf.shape[1], xs.shape[1], xo.shape[1], seed,
+            q0[0], q0[1], q0[2], _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.current_stream()),
+            "cgs_noise_quant_fwd")
+        ctx.save_for_backward(qadj)
+        ctx.dims, ctx.seed, ctx.q0 = (n, xf.shape[1], xs.shape[1], xo.shape[1]), seed, q0
+        return yf, ys, yo, Q
+
+    @staticmethod
+    def backward(ctx, gf, gs, go, gQ):
+        (qadj,) = ctx.saved_tensors
+        n, D, S, O = ctx.dims
+        gf, gs, go, gQ = (None if t is None else _c(t) for t in (gf, gs, go, gQ))
+        dq = None
+        if ctx.needs_input_grad[3]:
+            dq = torch.empty(n, 3, dtype=_f32, device=qadj.device)
+            _lib.check(_lib.lib().cgs_noise_quant_bwd(
+                _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), _lib.ptr(qadj), n, D, S, O, ctx.seed, ctx.q0[0],
+                ctx.q0[1], ctx.q0[2], _lib.ptr(dq), _lib.current_stream()), "cgs_noise_quant_bwd")
+        return gf, gs, go, dq, None, None
+
+
+def noise_quant(xf, xs, xo, qadj, q0, seed=None):
+    """(xf + u Qf, xs + u Qs, xo + u Qo, Q[n,3]) with Q = clamp(q0 (1 + tanh(qadj)), 1e-9), u ~ U[-0.5, 0.5)."""
+    return _NoiseQuant.apply(xf, xs, xo, qadj, next_seed() if seed is None else int(seed),
+                             tuple(float(v) for v in q0))
+
+
+class _LevelRate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):
+        yf, ys, yo, Q, pred = _c(yf), _c(ys), _c(yo), _c(Q), _c(pred)
+        _lib.require_device(yf, pred)
+        n_sub, D = pred.shape[0], yf.shape[1]
+        sums = torch.zeros(3, dtype=_f32, device=yf.device)
+        masks = None if masks is None else _c(masks)
+        x_means = None if x_means is None else _c(x_means)
+        _lib.check(_lib.lib().cgs_level_rate_fwd(
+            _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred), _lib.ptr(masks),
+            _lib.ptr(grows), _lib.ptr(x_means), int(use_clamp), n_sub, D, K, pred.shape[1], _lib.ptr(sums),
+            _lib.current_stream()), "cgs_level_rate_fwd")
+        ctx.save_for_backward(yf, ys, yo, Q, pred, loc, masks, grows, x_means)
+        ctx.cfg = (int(use_clamp), n_sub, D, K)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        yf, ys, yo, Q, pred, loc, masks, grows, x_means = ctx.saved_tensors
+        use_clamp, n_sub, D, K = ctx.cfg
+        n_l = yf.shape[0]
+        # one zero fill for the four row-scattered gradients
+        flat = torch.zeros(n_l * (D + 6 + 3 * K + 3), dtype=_f32, device=yf.device)
+        d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_l * D, n_l * 6, n_l * 3 * K, n_l * 3])
+        d_yf, d_ys, d_yo, dQ = d_yf.view(n_l, D), d_ys.view(n_l, 6), d_yo.view(n_l, 3 * K), dQ.view(n_l, 3)
+        d_pred = torch.empty_like(pred)
+        _lib.check(_lib.lib().cgs_level_rate_bwd(
+            _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred), _lib.ptr(masks),
+            _lib.ptr(grows), _lib.ptr(x_means), use_clamp, n_sub, D, K, pred.shape[1], _lib.ptr(_c(g)), _lib.ptr(d_pred),
+            _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.current_stream()), "cgs_level_rate_bwd")
+        return d_yf, d_ys, d_yo, dQ, d_pred, None, None, None, None, None, None
+
+
+def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):
+    """[bits_feat, bits_scaling, bits_offsets (mask-weighted)] summed over the chosen rows `loc` of a level."""
+    return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K))

@@ -226,6 +226,59 @@ int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       float *db1, float *dW2, float *db2, int64_t n,
                       void *scratch, size_t scratch_bytes, void *stream);
 
+/* ---- fused element-wise stages of the per-level context model (training path) ----
+ * Reference: scene/gaussian_model.py:1556-1707 (multi_scale_generating).
+ *
+ * cgs_rowcat_fwd: out[r] = [src_0[idx_0[r]] | src_1[idx_1[r]] | ...] — the input row of
+ * mlp_grid[level] (:1594-1600: level anchor + hyper prior; :1650-1651 / :1711-1724: parent
+ * anchor, parent feat, parent scaling + hyper prior).  data/idx/width/ld are HOST arrays
+ * of nsrc (<= 4) entries; idx[s] == NULL means row r of source s; out is [n, sum(width)].
+ * cgs_rowcat_bwd scatters dout back: mode[s] 0 = no gradient, 1 = store (distinct rows;
+ * rows never referenced must be pre-zeroed by the caller), 2 = atomic add (repeating rows;
+ * pre-zeroed by the caller). */
+int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *const *idx,
+                   const int *width, const int *ld, int64_t n, float *out,
+                   void *stream);
+int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const *idx,
+                   const int *width, const int *ld, const int *mode, int64_t n,
+                   const float *dout, void *stream);
+/* Adaptive step sizes + training noise (:1603-1616):
+ *   Q[r,k] = max(q0_k * (1 + tanh(qadj[r,k])), 1e-9),  k = feat, scaling, offsets
+ *   yf = xf + u * Q[r,0], ys = xs + u * Q[r,1], yo = xo + u * Q[r,2],  u ~ U[-0.5, 0.5)
+ * xf [n,D], xs [n,S], xo [n,O], qadj/Q [n,3].  u is a counter-based hash of (seed, tensor,
+ * element) that the backward regenerates; the reference draws it with torch's Philox
+ * uniform_, so streams differ while the distribution is the same.  The backward returns
+ * d_qadj only (d_x == d_y): dy* may be NULL (no gradient), dQ_ext [n,3] is the gradient
+ * that reaches Q from elsewhere (the rate term), may be NULL. */
+int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo,
+                        const float *qadj, int64_t n, int D, int S, int O,
+                        uint64_t seed, float q0f, float q0s, float q0o, float *yf,
+                        float *ys, float *yo, float *Q, void *stream);
+int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
+                        const float *dQ_ext, const float *qadj, int64_t n, int D,
+                        int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
+                        float *dqadj, void *stream);
+/* Bits of the chosen rows of one level (:1658-1669 with utils/entropy_models.py:30-50):
+ * for s < n_sub, r = loc[s] (row inside the level; NULL = s):
+ *   sums[0] += bits(yf[r], mean_f, scale_f, Q[r,0])      sums[1] += bits(ys[r], ..., Q[r,1])
+ *   sums[2] += bits(yo[r], ..., Q[r,2]) * masks[grows[s], k]   (masks [N,K], may be NULL)
+ * pred [n_sub, ldpred >= 2(D+6+3K)] = [mean_f D | scale_f D | mean_s 6 | scale_s 6 | mean_o 3K |
+ * scale_o 3K] (the first 2(D+6+3K) outputs of mlp_grid).  x_means [3] are the clamp
+ * centres when use_clamp != 0.  sums [3] is ACCUMULATED into.  The backward takes
+ * g_sums [3] (device) and writes d_pred (all of it), rows loc[s] of d_yf/d_ys/d_yo and
+ * of dQ [n_level,3] (the caller zero-fills the other rows). */
+int cgs_level_rate_fwd(const float *yf, const float *ys, const float *yo,
+                       const float *Q, const int64_t *loc, const float *pred,
+                       const float *masks, const int64_t *grows,
+                       const float *x_means, int use_clamp, int64_t n_sub, int D,
+                       int K, int64_t ldpred, float *sums, void *stream);
+int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
+                       const float *Q, const int64_t *loc, const float *pred,
+                       const float *masks, const int64_t *grows,
+                       const float *x_means, int use_clamp, int64_t n_sub, int D,
+                       int K, int64_t ldpred, const float *g_sums, float *d_pred, float *d_yf,
+                       float *d_ys, float *d_yo, float *dQ, void *stream);
+
 /* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
  * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on
  * their shared input in ONE launch each way.  W1/b1/W2/b2 (and dW2/db2) are
