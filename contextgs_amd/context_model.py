@@ -229,7 +229,17 @@ class _GatherUnique(torch.autograd.Function):
         return out, None
 
 
+def _rowcat_ok(x):
+    # torch's index_select is the faster row gather (tools/gather_micro.py) EXCEPT for rows that are a multiple of
+    # 16 bytes, where it switches to a vectorized_gather kernel that runs ~6x slower on gfx950 (214 vs 33 us for
+    # 1 M rows of 12 floats): those go through the one-source rowcat kernel.
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] > 0 and x[0].numel() > 0
+            and (x[0].numel() * 4) % 16 == 0)
+
+
 def gather_unique(x, idx):
+    if _rowcat_ok(x):                # one-source rowcat: row gather forward, plain row scatter backward (HIP)
+        return _ctx.rowcat([(x.reshape(x.shape[0], -1), idx, True)]).view((idx.shape[0],) + tuple(x.shape[1:]))
     return _GatherUnique.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
 
 
@@ -252,6 +262,8 @@ class _GatherRows(torch.autograd.Function):
 
 
 def gather_rows(x, idx):
+    if _rowcat_ok(x):
+        return _ctx.rowcat([(x.reshape(x.shape[0], -1), idx, False)]).view((idx.shape[0],) + tuple(x.shape[1:]))
     return _GatherRows.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
 
 

@@ -12,6 +12,13 @@ import torch.nn as nn
 from . import _lib
 
 _ACT = {None: 0, nn.Tanh: 1, nn.Sigmoid: 2}
+def _zeros_views(dev, *shapes):
+    """Zero-initialised tensors of the given shapes carved from ONE buffer (one fill launch)."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    return [t.view(s) for t, s in zip(torch.split(flat, sizes), shapes)]
+
+
 def _wgrad_workspace(dev) -> torch.Tensor:
     """Device scratch for the two-pass (atomics-free, deterministic) weight-gradient reduction; taken from the
     caching allocator per call so that it is stream-safe."""
@@ -69,10 +76,7 @@ class _MLP2(torch.autograd.Function):
         dx = torch.empty(n, in_f, dtype=torch.float32, device=dev) if need_dx else None
         dz1 = torch.empty(n, hid, dtype=torch.float32, device=dev)
         dz2 = torch.empty(n, out, dtype=torch.float32, device=dev) if act != 0 else None
-        dW1 = torch.zeros_like(W1)
-        db1 = torch.zeros(hid, dtype=torch.float32, device=dev)
-        dW2 = torch.zeros_like(W2)
-        db2 = torch.zeros(out, dtype=torch.float32, device=dev)
+        dW1, db1, dW2, db2 = _zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))   # one fill for the four
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(W2), _lib.ptr(y),
                                        _lib.ptr(dy), out, _lib.ptr(h), _lib.ptr(dx), in_f, 0, _lib.ptr(dz1), _lib.ptr(dz2),
@@ -153,10 +157,8 @@ class _AnchorMLP3(torch.autograd.Function):
         dz1 = torch.empty(n, 150, dtype=torch.float32, device=dev)
         dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
-        dW1cat = torch.zeros(150, 54, dtype=torch.float32, device=dev)
-        db1cat = torch.zeros(150, dtype=torch.float32, device=dev)
-        dW2 = [torch.zeros_like(w) for w in W2]
-        db2 = [torch.zeros(w.shape[0], dtype=torch.float32, device=dev) for w in W2]
+        views = _zeros_views(dev, (150, 54), (150,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward(
             _lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(g_op),

@@ -114,12 +114,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = means3D.shape[0]
         dev = means3D.device
         g = _f32c(grad_color)
-        d_means3D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
-        d_means2D = torch.zeros(P, 3, dtype=torch.float32, device=dev)
-        d_colors = torch.zeros(P, 3, dtype=torch.float32, device=dev)
-        d_opac = torch.zeros_like(opac)
-        d_scales = torch.zeros(P, 3, dtype=torch.float32, device=dev)
-        d_rots = torch.zeros(P, 4, dtype=torch.float32, device=dev)
+        # one zero fill for the six gradient arrays (they are atomically accumulated into)
+        flat = torch.zeros(P * (3 + 3 + 3 + 1 + 3 + 4), dtype=torch.float32, device=dev)
+        parts = torch.split(flat, [3 * P, 3 * P, 3 * P, P, 3 * P, 4 * P])
+        d_means3D, d_means2D, d_colors = parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(P, 3)
+        d_opac, d_scales, d_rots = parts[3].view(opac.shape), parts[4].view(P, 3), parts[5].view(P, 4)
         scratch = _workspace(L.cgs_raster_bwd_scratch_bytes(P), dev)
         _lib.check(L.cgs_raster_backward(
             cfg.ref, P, ctx.num_rendered, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(scales),
