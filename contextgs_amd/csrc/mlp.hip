@@ -56,18 +56,26 @@ __global__ void __launch_bounds__(WAVES * 64)
 
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // X of the next tile is fetched while this tile is in the matrix pipe (double-buffered in registers)
+    f32x4 xb[RT][NTI], xn[RT][NTI];
+    bool valid[RT], validn[RT];
+    const int64_t tile0 = (int64_t)blockIdx.x * WAVES + wave, tstride = (int64_t)gridDim.x * WAVES;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t row = tile0 * 16 * RT + rt * 16 + c;
+        valid[rt] = tile0 < ntiles && row < n;
+#pragma unroll
+        for (int q = 0; q < NTI; ++q) xb[rt][q] = frag_load4<IN>(X + row * ldx, q, g, valid[rt]);
+    }
+    for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16 * RT;
         asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
-        f32x4 xb[RT][NTI];
-        bool valid[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int64_t row = row0 + rt * 16 + c;
-            valid[rt] = row < n;
-            const float *xr = X + row * ldx;
+            const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c;
+            validn[rt] = row < n;
 #pragma unroll
-            for (int q = 0; q < NTI; ++q) xb[rt][q] = frag_load4<IN>(xr, q, g, valid[rt]);
+            for (int q = 0; q < NTI; ++q) xn[rt][q] = frag_load4<IN>(X + row * ldx, q, g, validn[rt]);
         }
         f32x4 acc1[NT1][RT];
 #pragma unroll
@@ -123,6 +131,12 @@ __global__ void __launch_bounds__(WAVES * 64)
                 for (int r = 0; r < 4; ++r) y[r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
                 frag_store4<OUT>(Y + row * ldy, u, g, valid[rt], y);
             }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            valid[rt] = validn[rt];
+#pragma unroll
+            for (int q = 0; q < NTI; ++q) xb[rt][q] = xn[rt][q];
+        }
     }
 }
 
@@ -163,28 +177,44 @@ __global__ void __launch_bounds__(WAVES * 64)
         for (int t = 0; t < NT1; ++t)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) adh[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Loads run ahead of their use (the scheduler does not move them across the exec-masked blocks by itself):
+        // the saved activations, needed last, are issued first; the dY (and Y) fragments LA tiles ahead of the MFMAs.
+        f32x4 hv[NT1][RT];
 #pragma unroll
-        for (int u = 0; u < NT2; ++u) {
-            f32x4 b[RT];
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                hv[t][rt] = frag_load4<HID>(Hsave + (row0 + rt * 16 + c) * HID, t, g, valid[rt]);
+        constexpr int LA = NT2 < 3 ? NT2 : 3;
+        f32x4 b[NT2][RT], yv[NT2][RT];
+#pragma unroll
+        for (int u = 0; u < NT2 + LA; ++u) {
+            if (u < NT2) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int64_t row = row0 + rt * 16 + c;
+                    b[u][rt] = frag_load4<OUT>(dY + row * ldy, u, g, valid[rt]);
+                    if (ACT != ACT_NONE) yv[u][rt] = frag_load4<OUT>(Y + row * ldy, u, g, valid[rt]);
+                }
+            }
+            const int w = u - LA;      // the tile consumed this round
+            if (w < 0) continue;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int64_t row = row0 + rt * 16 + c;
-                b[rt] = frag_load4<OUT>(dY + row * ldy, u, g, valid[rt]);
                 if (ACT != ACT_NONE) {
-                    const f32x4 y = frag_load4<OUT>(Y + row * ldy, u, g, valid[rt]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) b[rt][r] *= frag_act_grad<ACT>(y[r]);
+                    for (int r = 0; r < 4; ++r) b[w][rt][r] *= frag_act_grad<ACT>(yv[w][rt][r]);
                 }
-                if (dZ2) frag_store4<OUT>(dZ2 + row * OUT, u, g, valid[rt], b[rt]);
+                if (dZ2) frag_store4<OUT>(dZ2 + (row0 + rt * 16 + c) * OUT, w, g, valid[rt], b[w][rt]);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (16 * u + j >= OUT) continue;
+                if (16 * w + j >= OUT) continue;
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) {
-                    const float a = W2n[(16 * u + 4 * g + j) * SA + 16 * t + c];
+                    const float a = W2n[(16 * w + 4 * g + j) * SA + 16 * t + c];
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) adh[t][rt] = frag_mfma(a, b[rt][j], adh[t][rt]);
+                    for (int rt = 0; rt < RT; ++rt) adh[t][rt] = frag_mfma(a, b[w][rt][j], adh[t][rt]);
                 }
             }
         }
@@ -193,11 +223,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         for (int t = 0; t < NT1; ++t)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int64_t row = row0 + rt * 16 + c;
-                const f32x4 h = frag_load4<HID>(Hsave + row * HID, t, g, valid[rt]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) adh[t][rt][r] = h[r] > 0.f ? adh[t][rt][r] : 0.f;
-                frag_store4<HID>(dZ1 + row * HID, t, g, valid[rt], adh[t][rt]);
+                for (int r = 0; r < 4; ++r) adh[t][rt][r] = hv[t][rt][r] > 0.f ? adh[t][rt][r] : 0.f;
+                frag_store4<HID>(dZ1 + (row0 + rt * 16 + c) * HID, t, g, valid[rt], adh[t][rt]);
             }
         if (dX) {
             f32x4 adx[NTX][RT];

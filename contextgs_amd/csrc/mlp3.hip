@@ -122,21 +122,36 @@ __global__ void __launch_bounds__(WAVES * 64)
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int64_t ntiles = (n + 16 * RT - 1) / (16 * RT);
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // X of the next tile is fetched while this tile is in the matrix pipe (double-buffered in registers)
+    f32x4 xb[RT][M3_NTI], xn[RT][M3_NTI];
+    bool valid[RT], validn[RT];
+    const int64_t tile0 = (int64_t)blockIdx.x * WAVES + wave, tstride = (int64_t)gridDim.x * WAVES;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t row = tile0 * 16 * RT + rt * 16 + c;
+        valid[rt] = tile0 < ntiles && row < n;
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
+    }
+    for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16 * RT;
         asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
-        f32x4 xb[RT][M3_NTI];
-        bool valid[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int64_t row = row0 + rt * 16 + c;
-            valid[rt] = row < n;
+            const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c;
+            validn[rt] = row < n;
 #pragma unroll
-            for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
+            for (int q = 0; q < M3_NTI; ++q) xn[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, validn[rt]);
         }
         m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
         m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
         m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            valid[rt] = validn[rt];
+#pragma unroll
+            for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = xn[rt][q];
+        }
     }
 }
 
@@ -173,20 +188,34 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) adh[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Every load of the head is issued before its first store: the head pointers may alias as far as the compiler
+    // knows, so a store in between would pin the later loads behind it (and their latency in front of the MFMAs).
+    f32x4 b[L::NT2][RT], yv[L::NT2][RT], hv[M3_NT1][RT];
 #pragma unroll
-    for (int u = 0; u < L::NT2; ++u) {
-        f32x4 b[RT];
+    for (int u = 0; u < L::NT2; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
-            b[rt] = frag_load4<OUT>(h.dY + row * OUT, u, g, valid[rt]);
-            if (ACT != FRAG_ACT_NONE) {
-                const f32x4 y = frag_load4<OUT>(h.Y + row * OUT, u, g, valid[rt]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[rt][r] *= frag_act_grad<ACT>(y[r]);
-                frag_store4<OUT>(h.dZ2 + row * OUT, u, g, valid[rt], b[rt]);
-            }
+            b[u][rt] = frag_load4<OUT>(h.dY + row * OUT, u, g, valid[rt]);
+            if (ACT != FRAG_ACT_NONE) yv[u][rt] = frag_load4<OUT>(h.Y + row * OUT, u, g, valid[rt]);
         }
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            hv[t][rt] = frag_load4<M3_HID>(Hcat + (row0 + rt * 16 + c) * M3_HCAT + M3_HID * head, t, g, valid[rt]);
+    if (ACT != FRAG_ACT_NONE) {
+#pragma unroll
+        for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[u][rt][r] *= frag_act_grad<ACT>(yv[u][rt][r]);
+                frag_store4<OUT>(h.dZ2 + (row0 + rt * 16 + c) * OUT, u, g, valid[rt], b[u][rt]);
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (16 * u + j >= OUT) continue;
@@ -194,18 +223,16 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
             for (int t = 0; t < M3_NT1; ++t) {
                 const float a = W2n[(16 * u + 4 * g + j) * L::SA + 16 * t + c];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) adh[t][rt] = frag_mfma(a, b[rt][j], adh[t][rt]);
+                for (int rt = 0; rt < RT; ++rt) adh[t][rt] = frag_mfma(a, b[u][rt][j], adh[t][rt]);
             }
         }
-    }
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t at = (row0 + rt * 16 + c) * M3_HCAT + M3_HID * head;
-            const f32x4 hv = frag_load4<M3_HID>(Hcat + at, t, g, valid[rt]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) adh[t][rt][r] = hv[r] > 0.f ? adh[t][rt][r] : 0.f;
+            for (int r = 0; r < 4; ++r) adh[t][rt][r] = hv[t][rt][r] > 0.f ? adh[t][rt][r] : 0.f;
             frag_store4<M3_HID>(dZ1cat + at, t, g, valid[rt], adh[t][rt]);
         }
 #pragma unroll
