@@ -203,9 +203,12 @@ def main():
         mlp_flops = 0.0
         if args.step_semantics > 10000:
             lv = pkg_full["bpp_per_level"][2:] if pkg_full is not None else []
-            dims = [(15, 100, 175)] + [(71, 100, 175)] * max(0, len(lv) - 1)
-            for (i_, h_, o_), (ratio, _bpp) in zip(dims, lv):
-                mlp_flops += 2.0 * ratio * N * (i_ * h_ + h_ * o_)
+            # per level: the 3 step-size outputs on every row of the level, all 175 outputs on the rate subset
+            # (15 % of the rows in expectation, scene/gaussian_model.py:1658-1661)
+            dims = [(15, 100)] + [(71, 100)] * max(0, len(lv) - 1)
+            for (i_, h_), (ratio, _bpp) in zip(dims, lv):
+                mlp_flops += 2.0 * ratio * N * (i_ * h_ + h_ * 3)
+                mlp_flops += 2.0 * 0.15 * ratio * N * (i_ * h_ + h_ * 175)
         for o_ in (10, 30, 70):
             mlp_flops += 2.0 * n_vis * (54 * 50 + 50 * o_)
         traffic = {}
