@@ -216,17 +216,34 @@ class _GatherUnique(torch.autograd.Function):
     indexing_backward kernels per 14 steps at 1 M anchors)."""
 
     @staticmethod
-    def forward(ctx, x, idx):
+    def forward(ctx, x, idx, complete=False):
         ctx.save_for_backward(idx)
         ctx.shape = x.shape
+        ctx.complete = complete and idx.shape[0] == x.shape[0]
         return x.index_select(0, idx)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        # `complete`: idx is a permutation of all rows, every row is written, no zero fill needed
+        out = (torch.empty if ctx.complete else torch.zeros)(ctx.shape, dtype=g.dtype, device=g.device)
         out.index_copy_(0, idx, g.contiguous())
-        return out, None
+        return out, None, None
+
+
+class _JoinRows(torch.autograd.Function):
+    """The row slices `parts` (consecutive, covering `whole`) were written in place by the fused kernels:
+    return `whole` as their concatenation without copying; the backward hands each part a view of the gradient."""
+
+    @staticmethod
+    def forward(ctx, whole, *parts):
+        ctx.sizes = [int(p.shape[0]) for p in parts]
+        assert sum(ctx.sizes) == whole.shape[0]
+        return whole.view_as(whole)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *torch.split(g, ctx.sizes))
 
 
 def _rowcat_ok(x):
@@ -237,10 +254,11 @@ def _rowcat_ok(x):
             and (x[0].numel() * 4) % 16 == 0)
 
 
-def gather_unique(x, idx):
+def gather_unique(x, idx, complete=False):
+    """x[idx] for distinct rows idx; complete = idx is a permutation of ALL rows of x."""
     if _rowcat_ok(x):                # one-source rowcat: row gather forward, plain row scatter backward (HIP)
         return _ctx.rowcat([(x.reshape(x.shape[0], -1), idx, True)]).view((idx.shape[0],) + tuple(x.shape[1:]))
-    return _GatherUnique.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
+    return _GatherUnique.apply(x, idx, complete) if x.requires_grad else x.index_select(0, idx)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -285,15 +303,22 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     perm, sizes = c["perm"], c["sizes"]
 
     # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
-    feat_l = torch.split(gather_unique(feat, perm), sizes)
-    scal_l = torch.split(gather_unique(grid_scaling, perm), sizes)
-    off_l = torch.split(gather_unique(grid_offsets, perm), sizes)
-    hyp_l = torch.split(gather_unique(hyper_feat, perm), sizes)
+    full = c["covers_all"]
+    feat_l = torch.split(gather_unique(feat, perm, full), sizes)
+    scal_l = torch.split(gather_unique(grid_scaling, perm, full), sizes)
+    off_l = torch.split(gather_unique(grid_offsets, perm, full), sizes)
+    hyp_l = torch.split(gather_unique(hyper_feat, perm, full), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
     # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
     fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
+    # the fused levels write their outputs side by side into these (coding order), so no cat is needed at the end
+    n_tot, row_off, joined = int(perm.shape[0]), 0, fused
+    if fused:
+        big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=anchor.device)
+        big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=anchor.device)
+        big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=anchor.device)
     for j, (i, _tc, orig, _a) in enumerate(c["plan"]):
         n_l = sizes[j]
         if n_l > 0:
@@ -329,8 +354,11 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 qadj = _mlp.mlp2_weights(feat_in, seq[0].weight, seq[0].bias, seq[2].weight[n_stat:], seq[2].bias[n_stat:])
             if use_fused:
                 # step sizes + noise (:1603-1616) in one launch; the rate of the chosen rows is one more (rate_model)
+                sl = slice(row_off, row_off + n_l)
                 hf, hs, ho, Q_all = _ctx.noise_quant(feat_l[j], scal_l[j], off_l[j].reshape(n_l, 3 * K), qadj,
-                                                     (Q_FEAT0, Q_SCALING0, Q_OFFSETS0))
+                                                     (Q_FEAT0, Q_SCALING0, Q_OFFSETS0),
+                                                     outs=(big_f[sl], big_s[sl], big_o[sl]) if joined else None)
+                row_off += n_l
                 if keep_stats:
                     levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
                                        yo=ho, Q=Q_all, pred=grid_mlp(pc, i, gather_unique(feat_in, loc))))
@@ -338,8 +366,9 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 scal_q.append(hs)
                 off_q.append(ho)
                 if i != 0:
-                    ctx_src = _next_context(c, i, feat_q, scal_q)
+                    ctx_src = _next_context(c, i, feat_q, scal_q, (big_f, big_s, row_off) if joined else None)
                 continue
+            joined = False
             if subset_mode:
                 Q_feat = (Q_FEAT0 * (1 + torch.tanh(qadj[:, 0:1]))).clamp(1e-9)
                 Q_scaling = (Q_SCALING0 * (1 + torch.tanh(qadj[:, 1:2]))).clamp(1e-9)
@@ -371,20 +400,29 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                                    qs=Q_scaling, mo=mean_offsets, so=scale_offsets, qo=Q_offsets))
         else:
             hf, hs, ho = feat_l[j], scal_l[j], off_l[j].reshape(-1, 3 * K)
+            joined = joined and n_l == 0
         feat_q.append(hf)
         scal_q.append(hs)
         off_q.append(ho)
         if i != 0:
             ctx_src = _next_context(c, i, feat_q, scal_q)
+    if joined and row_off == n_tot:
+        return (c, _JoinRows.apply(big_f, *feat_q), _JoinRows.apply(big_s, *scal_q),
+                _JoinRows.apply(big_o, *off_q).view(-1, K, 3), likelihood_hyper, levels)
     cat = lambda parts: parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     return c, cat(feat_q), cat(scal_q), cat(off_q).view(-1, K, 3), likelihood_hyper, levels
 
 
-def _next_context(c, i, feat_q, scal_q):
+def _next_context(c, i, feat_q, scal_q, joined=None):
     """:1650-1651 / 1711-1724 — what the level coded after level i reads of the already coded anchors: their
     original rows (for the anchor position) and their positions in the coded prefix (<= 20 % of N)."""
-    base_f = feat_q[0] if len(feat_q) == 1 else torch.cat(feat_q, dim=0)
-    base_s = scal_q[0] if len(scal_q) == 1 else torch.cat(scal_q, dim=0)
+    if len(feat_q) == 1:
+        base_f, base_s = feat_q[0], scal_q[0]
+    elif joined is not None:            # the prefix already lies contiguously in the level output buffers
+        big_f, big_s, rows = joined
+        base_f, base_s = _JoinRows.apply(big_f[:rows], *feat_q), _JoinRows.apply(big_s[:rows], *scal_q)
+    else:
+        base_f, base_s = torch.cat(feat_q, dim=0), torch.cat(scal_q, dim=0)
     return c["ctx_idx"][i], c["ctx_pos"][i], base_f, base_s
 
 

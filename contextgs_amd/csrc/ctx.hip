@@ -205,7 +205,7 @@ extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const flo
 //   e <  D + 6    scaling  x = ys[r,e-D]      mean = pred[s, 2D + .]        scale = pred[s, 2D + 6 + .]     q = Q[r,1]
 //   else          offsets  x = yo[r,.]        mean = pred[s, 2D + 12 + .]   scale = pred[s, 2D + 12 + 3K + .] q = Q[r,2]
 //                 weighted by masks[grows[s], ./3]   (binary_grid_masks.repeat(1,1,3), :1664)
-struct RateElem { float x, mean, scale, q, w, xm; int kind, mcol, scol; int64_t xoff; };
+struct RateElem { float x, mean, scale, q, w, xm; int kind, mcol, scol; int64_t xoff, moff; };
 
 __device__ __forceinline__ RateElem rate_elem(int e, int64_t s, int64_t r, int64_t grow, int D, int K, int64_t ldp,
                                               const float *__restrict__ yf, const float *__restrict__ ys,
@@ -223,7 +223,8 @@ __device__ __forceinline__ RateElem rate_elem(int e, int64_t s, int64_t r, int64
     t.mean = pred[s * ldp + t.mcol];
     t.scale = pred[s * ldp + t.scol];
     t.q = Q[r * 3 + t.kind];
-    t.w = (t.kind == 2 && masks) ? masks[grow * K + c / 3] : 1.f;
+    t.moff = grow * K + c / 3;
+    t.w = (t.kind == 2 && masks) ? masks[t.moff] : 1.f;
     t.xm = x_means ? x_means[t.kind] : 0.f;
     return t;
 }
@@ -272,7 +273,8 @@ __global__ void __launch_bounds__(256)
                           const float *__restrict__ masks, const int64_t *__restrict__ grows,
                           const float *__restrict__ x_means, int use_clamp, int64_t n_sub, int D, int K,
                           int64_t ldp, const float *__restrict__ g_sums, float *__restrict__ d_pred, float *__restrict__ d_yf,
-                          float *__restrict__ d_ys, float *__restrict__ d_yo, float *__restrict__ dQ) {
+                          float *__restrict__ d_ys, float *__restrict__ d_yo, float *__restrict__ dQ,
+                          float *__restrict__ d_masks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = D + 6 + 3 * K, P = 2 * E;
     const float g0 = g_sums[0], g1 = g_sums[1], g2 = g_sums[2];
@@ -289,6 +291,8 @@ __global__ void __launch_bounds__(256)
             d_pred[s * ldp + t.scol] = g.gs;
             float *dx = t.kind == 0 ? d_yf : (t.kind == 1 ? d_ys : d_yo);
             dx[t.xoff] = g.gx;
+            // the offsets' bits are weighted by the (straight-through) binary mask: d bits*w / d w = bits (:1664)
+            if (d_masks && t.kind == 2) atomicAdd(&d_masks[t.moff], g2 * rate_bits(rt));
             gq[0] += t.kind == 0 ? g.gq : 0.f;
             gq[1] += t.kind == 1 ? g.gq : 0.f;
             gq[2] += t.kind == 2 ? g.gq : 0.f;
@@ -326,7 +330,8 @@ extern "C" int cgs_level_rate_fwd(const float *yf, const float *ys, const float 
 extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo, const float *Q, const int64_t *loc,
                                   const float *pred, const float *masks, const int64_t *grows, const float *x_means,
                                   int use_clamp, int64_t n_sub, int D, int K, int64_t ldpred, const float *g_sums,
-                                  float *d_pred, float *d_yf, float *d_ys, float *d_yo, float *dQ, void *stream) {
+                                  float *d_pred, float *d_yf, float *d_ys, float *d_yo, float *dQ, float *d_masks,
+                                  void *stream) {
     int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_bwd");
     if (rc) return rc;
     if (n_sub == 0) return CGS_OK;
@@ -337,7 +342,7 @@ extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float 
     CgsProfScope prof(CGS_PROF_RATE_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(level_rate_bwd_kernel, dim3(stream_grid(n_sub, 4 * 4)), dim3(256), 0, (hipStream_t)stream, yf, ys, yo,
                        Q, loc, pred, masks, grows, use_clamp ? x_means : nullptr, use_clamp, n_sub, D, K, ldpred, g_sums, d_pred,
-                       d_yf, d_ys, d_yo, dQ);
+                       d_yf, d_ys, d_yo, dQ, masks ? d_masks : nullptr);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

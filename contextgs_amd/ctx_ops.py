@@ -89,11 +89,16 @@ def next_seed() -> int:
 
 class _NoiseQuant(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xf, xs, xo, qadj, seed, q0):
+    def forward(ctx, xf, xs, xo, qadj, seed, q0, outs):
         xf, xs, xo, qadj = _c(xf), _c(xs), _c(xo), _c(qadj)
         _lib.require_device(xf, xs, xo, qadj)
         n = xf.shape[0]
-        yf, ys, yo = torch.empty_like(xf), torch.empty_like(xs), torch.empty_like(xo)
+        if outs is None:
+            yf, ys, yo = torch.empty_like(xf), torch.empty_like(xs), torch.empty_like(xo)
+        else:           # row slices of caller-owned buffers (the level outputs land side by side: no cat afterwards)
+            yf, ys, yo = outs
+            assert yf.shape == xf.shape and ys.shape == xs.shape and yo.shape == xo.shape
+            assert yf.is_contiguous() and ys.is_contiguous() and yo.is_contiguous()
         Q = torch.empty(n, 3, dtype=_f32, device=xf.device)
         _lib.check(_lib.lib().cgs_noise_quant_fwd(
             _lib.ptr(xf), _lib.ptr(xs), _lib.ptr(xo), _lib.ptr(qadj), n, xf.shape[1], xs.shape[1], xo.shape[1], seed,
@@ -114,13 +119,14 @@ class _NoiseQuant(torch.autograd.Function):
             _lib.check(_lib.lib().cgs_noise_quant_bwd(
                 _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), _lib.ptr(qadj), n, D, S, O, ctx.seed, ctx.q0[0],
                 ctx.q0[1], ctx.q0[2], _lib.ptr(dq), _lib.current_stream()), "cgs_noise_quant_bwd")
-        return gf, gs, go, dq, None, None
+        return gf, gs, go, dq, None, None, None
 
 
-def noise_quant(xf, xs, xo, qadj, q0, seed=None):
-    """(xf + u Qf, xs + u Qs, xo + u Qo, Q[n,3]) with Q = clamp(q0 (1 + tanh(qadj)), 1e-9), u ~ U[-0.5, 0.5)."""
+def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None):
+    """(xf + u Qf, xs + u Qs, xo + u Qo, Q[n,3]) with Q = clamp(q0 (1 + tanh(qadj)), 1e-9), u ~ U[-0.5, 0.5).
+    outs = (yf, ys, yo) optionally names the (contiguous) tensors to write the three results into."""
     return _NoiseQuant.apply(xf, xs, xo, qadj, next_seed() if seed is None else int(seed),
-                             tuple(float(v) for v in q0))
+                             tuple(float(v) for v in q0), outs)
 
 
 class _LevelRate(torch.autograd.Function):
@@ -150,11 +156,13 @@ class _LevelRate(torch.autograd.Function):
         d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_l * D, n_l * 6, n_l * 3 * K, n_l * 3])
         d_yf, d_ys, d_yo, dQ = d_yf.view(n_l, D), d_ys.view(n_l, 6), d_yo.view(n_l, 3 * K), dQ.view(n_l, 3)
         d_pred = torch.empty_like(pred)
+        d_masks = torch.zeros_like(masks) if (masks is not None and ctx.needs_input_grad[6]) else None
         _lib.check(_lib.lib().cgs_level_rate_bwd(
             _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred), _lib.ptr(masks),
             _lib.ptr(grows), _lib.ptr(x_means), use_clamp, n_sub, D, K, pred.shape[1], _lib.ptr(_c(g)), _lib.ptr(d_pred),
-            _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.current_stream()), "cgs_level_rate_bwd")
-        return d_yf, d_ys, d_yo, dQ, d_pred, None, None, None, None, None, None
+            _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.ptr(d_masks), _lib.current_stream()),
+            "cgs_level_rate_bwd")
+        return d_yf, d_ys, d_yo, dQ, d_pred, None, d_masks, None, None, None, None
 
 
 def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):

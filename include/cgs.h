@@ -266,7 +266,8 @@ int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
  * scale_o 3K] (the first 2(D+6+3K) outputs of mlp_grid).  x_means [3] are the clamp
  * centres when use_clamp != 0.  sums [3] is ACCUMULATED into.  The backward takes
  * g_sums [3] (device) and writes d_pred (all of it), rows loc[s] of d_yf/d_ys/d_yo and
- * of dQ [n_level,3] (the caller zero-fills the other rows). */
+ * of dQ [n_level,3] (the caller zero-fills the other rows); d_masks [N,K] (may be NULL,
+ * pre-zeroed) receives the gradient of the mask weights (+= g_sums[2] * bits). */
 int cgs_level_rate_fwd(const float *yf, const float *ys, const float *yo,
                        const float *Q, const int64_t *loc, const float *pred,
                        const float *masks, const int64_t *grows,
@@ -277,7 +278,8 @@ int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
                        const float *masks, const int64_t *grows,
                        const float *x_means, int use_clamp, int64_t n_sub, int D,
                        int K, int64_t ldpred, const float *g_sums, float *d_pred, float *d_yf,
-                       float *d_ys, float *d_yo, float *dQ, void *stream);
+                       float *d_ys, float *d_yo, float *dQ, float *d_masks,
+                       void *stream);
 
 /* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
  * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on

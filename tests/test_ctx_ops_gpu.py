@@ -108,7 +108,7 @@ def test_level_rate(n_l, frac, clamp):
         pred[:, 2 * D + 6:2 * D + 12] = pred[:, 2 * D + 6:2 * D + 12].abs() * 0.01 + 1e-3
         pred[:, 2 * D + 12 + 3 * K:2 * E] = pred[:, 2 * D + 12 + 3 * K:2 * E].abs() + 0.1
     pred.requires_grad_()
-    masks = (torch.rand(N, K, device=_dev(), generator=g) < 0.6).float()
+    masks = (torch.rand(N, K, device=_dev(), generator=g) < 0.6).float().requires_grad_()
     grows = torch.randint(0, N, (n_sub,), device=_dev(), generator=g)
     x_means = torch.tensor([0.1, 0.0, -0.05], device=_dev())
     old = encodings.use_clamp
@@ -123,8 +123,8 @@ def test_level_rate(n_l, frac, clamp):
         ref = torch.stack([bf.sum(), bs.sum(), bo.sum()])
         torch.testing.assert_close(sums, ref, rtol=2e-5, atol=1e-3)
         w = torch.tensor([1.0, 0.5, 2.0], device=_dev())
-        got = torch.autograd.grad((sums * w).sum(), [yf, ys, yo, Q, pred], allow_unused=True)
-        exp = torch.autograd.grad((ref * w).sum(), [yf, ys, yo, Q, pred], allow_unused=True)
+        got = torch.autograd.grad((sums * w).sum(), [yf, ys, yo, Q, pred, masks], allow_unused=True)
+        exp = torch.autograd.grad((ref * w).sum(), [yf, ys, yo, Q, pred, masks], allow_unused=True)
         for a, b in zip(got, exp):
             if b is None:
                 assert a is None or not a.abs().any()
