@@ -30,6 +30,7 @@ from . import ctx_ops as _ctx
 from . import encodings as _enc
 from . import mlp as _mlp
 from .encodings import STE_multistep, get_binary_vxl_size
+from .entropy_bottleneck import EntropyBottleneck as _EntropyBottleneck
 from .multi_level import torch_unique_with_indices
 
 Q_FEAT0, Q_SCALING0, Q_OFFSETS0 = 1, 0.001, 0.2      # :1564-1566
@@ -293,7 +294,13 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     likelihood_hyper [N-ordered], levels) where `levels` holds, per coded level, the slices the rate model
     needs (only when keep_stats)."""
     K = pc.n_offsets
-    hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)           # :1556
+    # :1556.  Only the rate subset's hyper likelihood is ever read (:1662): ask the bottleneck for those rows only
+    # (likelihood_hyper is then [n_chosen, C], in nonzero(choose_mask) order; rate_model recognises it by its length)
+    if (FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda
+            and isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3)):
+        hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training, rows=torch.nonzero(choose_mask)[:, 0])
+    else:
+        hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)
     if pc.disable_hyper:
         hyper_feat = hyper_feat * 0
     if pc.level_scale is None:                                                         # :1559
@@ -444,7 +451,10 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     if choose_mask is None:
         choose_mask = draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits)
     mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach() if mask_anchor_bool is not None else 1
-    bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
+    if likelihood_hyper.shape[0] != n:          # already restricted to the chosen rows (context_model_coding_order)
+        bit_hyper = -torch.log2(likelihood_hyper)
+    else:
+        bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
     eg = pc.entropy_gaussian
     xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
     masks30 = binary_grid_masks.repeat(1, 1, 3).view(-1, 3 * K)

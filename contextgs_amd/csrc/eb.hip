@@ -112,12 +112,11 @@ __device__ __forceinline__ float eb_eval_bwd(const float p[EB_P], const EbTrace 
 __global__ void __launch_bounds__(256)
     eb_likelihood_fwd_kernel(const float *__restrict__ v, const float *__restrict__ raw, int64_t n, int C,
                              float *__restrict__ lik) {
-    const int lane = threadIdx.x & 63;
-    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int c = (int)(gw % C);
-    const int64_t w_in_c = gw / C, waves_per_c = nw / C;
-    if (w_in_c >= waves_per_c) return;
+    // the 4 waves of a workgroup share ONE channel (blockIdx % C): the backward can then combine their parameter
+    // gradients in LDS and issue one set of 58 atomics per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (int)(blockIdx.x % C);
+    const int64_t w_in_c = (int64_t)(blockIdx.x / C) * 4 + wave, waves_per_c = (int64_t)(gridDim.x / C) * 4;
     float p[EB_P];
     eb_load_params(raw, c, p);
     for (int64_t row = w_in_c * 64 + lane; row < n; row += waves_per_c * 64) {
@@ -148,12 +147,11 @@ __device__ __forceinline__ float eb_wave_sum63(float v) {
 __global__ void __launch_bounds__(256)
     eb_likelihood_bwd_kernel(const float *__restrict__ v, const float *__restrict__ raw, const float *__restrict__ g_lik,
                              int64_t n, int C, float *__restrict__ g_v, float *__restrict__ g_raw) {
-    const int lane = threadIdx.x & 63;
-    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int c = (int)(gw % C);
-    const int64_t w_in_c = gw / C, waves_per_c = nw / C;
-    if (w_in_c >= waves_per_c) return;
+    // the 4 waves of a workgroup share ONE channel (blockIdx % C): the backward can then combine their parameter
+    // gradients in LDS and issue one set of 58 atomics per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (int)(blockIdx.x % C);
+    const int64_t w_in_c = (int64_t)(blockIdx.x / C) * 4 + wave, waves_per_c = (int64_t)(gridDim.x / C) * 4;
     float p[EB_P], gp[EB_P];
     eb_load_params(raw, c, p);
 #pragma unroll
@@ -176,30 +174,39 @@ __global__ void __launch_bounds__(256)
         dx += eb_eval_bwd(p, tl, g_lo, gp);
         g_v[row * C + c] = dx;
     }
-    // wave reduction of the parameter gradients, then chain through softplus / tanh of the raw parameters
+    // wave reduction of the parameter gradients, workgroup reduction in LDS, then the chain rule through
+    // softplus / tanh of the raw parameters and one atomic per parameter and workgroup
+    __shared__ float part[4][EB_P];
 #pragma unroll
     for (int i = 0; i < EB_P; ++i) {
         const float tot = eb_wave_sum63(gp[i]);
-        if (lane == 63) {
-            const float rv = raw[c * EB_P + i];
-            const bool is_f = (i >= OFF_F0 && i < OFF_F0 + 3) || (i >= OFF_F(1) && i < OFF_F(1) + 3) ||
-                              (i >= OFF_F(2) && i < OFF_F(2) + 3) || (i >= OFF_F(3) && i < OFF_F(3) + 3);
-            const bool is_b = (i >= OFF_B0 && i < OFF_B0 + 3) || (i >= OFF_B(1) && i < OFF_B(1) + 3) ||
-                              (i >= OFF_B(2) && i < OFF_B(2) + 3) || (i >= OFF_B(3) && i < OFF_B(3) + 3) || i == OFF_B4;
-            const float chain = is_b ? 1.f : (is_f ? (1.f - p[i] * p[i]) : sigmoidf(rv));
-            atomicAdd(&g_raw[c * EB_P + i], tot * chain);
-        }
+        if (lane == 63) part[wave][i] = tot;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < EB_P) {
+        const float tot = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+        const float rv = raw[c * EB_P + i];
+        const bool is_f = (i >= OFF_F0 && i < OFF_F0 + 3) || (i >= OFF_F(1) && i < OFF_F(1) + 3) ||
+                          (i >= OFF_F(2) && i < OFF_F(2) + 3) || (i >= OFF_F(3) && i < OFF_F(3) + 3);
+        const bool is_b = (i >= OFF_B0 && i < OFF_B0 + 3) || (i >= OFF_B(1) && i < OFF_B(1) + 3) ||
+                          (i >= OFF_B(2) && i < OFF_B(2) + 3) || (i >= OFF_B(3) && i < OFF_B(3) + 3) || i == OFF_B4;
+        const float pv = is_b ? rv : (is_f ? tanhf(rv) : softplusf(rv));
+        const float chain = is_b ? 1.f : (is_f ? (1.f - pv * pv) : sigmoidf(rv));
+        atomicAdd(&g_raw[c * EB_P + i], tot * chain);
     }
 }
 
-static int eb_grid(int64_t n, int C) {
-    // waves = multiple of C; enough to fill the chip, no more than one wave per 64 rows per channel
-    int64_t per_c = (n + 63) / 64;
-    const int64_t cap = (256 * 8 * 4) / C;        // 8 blocks of 4 waves per CU
+static int eb_grid(int64_t n, int C, int blocks_per_cu) {
+    // workgroups = multiple of C (4 waves of one channel each), no more than one wave per 64 rows and channel;
+    // the backward (2 waves / SIMD by its registers) takes two per CU, which also keeps its per-workgroup
+    // parameter-gradient atomics few
+    int64_t per_c = (n + 255) / 256;
+    int64_t cap = (256 * blocks_per_cu) / C;
+    if (cap < 1) cap = 1;
     if (per_c > cap) per_c = cap;
     if (per_c < 1) per_c = 1;
-    const int64_t waves = per_c * C;
-    return (int)((waves + 3) / 4);
+    return (int)(per_c * C);
 }
 
 // v, lik, g_lik, g_v: [n, C] row-major; raw, g_raw: [C, 58] packed raw parameters (see layout above)
@@ -207,8 +214,7 @@ extern "C" int cgs_eb_likelihood_fwd(const float *v, const float *raw, int64_t n
     if (n < 0 || C < 1) { cgs_set_error("eb_likelihood_fwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!v || !raw || !lik) { cgs_set_error("eb_likelihood_fwd: NULL"); return CGS_ERR_ARG; }
-    const int grid = eb_grid(n, C);
-    // the kernels assume (#waves % C == 0): round the wave count down inside the kernel (extra waves return)
+    const int grid = eb_grid(n, C, 8);
     hipLaunchKernelGGL(eb_likelihood_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, raw, n, C, lik);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
@@ -219,7 +225,7 @@ extern "C" int cgs_eb_likelihood_bwd(const float *v, const float *raw, const flo
     if (n < 0 || C < 1) { cgs_set_error("eb_likelihood_bwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!v || !raw || !g_lik || !g_v || !g_raw) { cgs_set_error("eb_likelihood_bwd: NULL"); return CGS_ERR_ARG; }
-    const int grid = eb_grid(n, C);
+    const int grid = eb_grid(n, C, 2);
     hipLaunchKernelGGL(eb_likelihood_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, raw, g_lik, n, C, g_v,
                        g_raw);
     CGS_CHECK_HIP(hipGetLastError());

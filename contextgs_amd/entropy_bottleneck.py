@@ -71,6 +71,27 @@ class _FusedLikelihood(torch.autograd.Function):
         return g_v, g_p
 
 
+class _RowsOf(torch.autograd.Function):
+    """x[rows] for distinct rows; backward = row scatter into zeros (no sort, unlike index_put_ accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        ctx.save_for_backward(rows)
+        ctx.shape = x.shape
+        return x.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        out.index_copy_(0, rows, g.contiguous())
+        return out, None
+
+
+def _rows_of(x, rows):
+    return _RowsOf.apply(x, rows)
+
+
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10.0,
                  filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9, entropy_coder_precision: int = 16):
@@ -134,8 +155,12 @@ class EntropyBottleneck(nn.Module):
             return out.int()
         raise ValueError(f"unknown quantisation mode {mode!r}")
 
-    def forward(self, x: torch.Tensor, training: bool | None = None):
-        """x [N, C] -> (x_hat [N, C], likelihood [N, C])."""
+    def forward(self, x: torch.Tensor, training: bool | None = None, rows: torch.Tensor | None = None):
+        """x [N, C] -> (x_hat [N, C], likelihood [N, C]).
+
+        rows (extension; distinct row indices): evaluate the likelihood of those rows only and return it as
+        [len(rows), C].  The training step consumes the likelihood of the ~15 % anchors of its rate subset
+        (scene/gaussian_model.py:1658-1662) and discards the rest, which is 85 % of this module's work."""
         if training is None:
             training = self.training
         assert x.dim() == 2 and x.shape[1] == self.channels, "expects [N, C]"
@@ -144,7 +169,10 @@ class EntropyBottleneck(nn.Module):
             # the 1-3-3-3-3-1 density network forward/backward is one kernel each
             med = self._get_medians()[:, 0, 0]                        # [C]
             out = x + torch.empty_like(x).uniform_(-0.5, 0.5) if training else torch.round(x - med) + med
-            return out, _FusedLikelihood.apply(out, self._packed_params())
+            sub = out if rows is None else out.index_select(0, rows) if not out.requires_grad else _rows_of(out, rows)
+            return out, _FusedLikelihood.apply(sub, self._packed_params())
+        if rows is not None:
+            raise NotImplementedError("rows= is only implemented for the fused device path")
         v = x.t().reshape(self.channels, 1, -1)                      # [C,1,N]
         out = self.quantize(v, "noise" if training else "dequantize", self._get_medians())
         lik = _LowerBound.apply(self._likelihood(out), self.likelihood_bound)
