@@ -169,6 +169,48 @@ def _cached_plan(pc, anchor, mask_anchor_bool):
     return cache
 
 
+def _plan_key(pc, anchor, mask_anchor_bool):
+    return (float(pc.voxel_size), tuple(float(v) for v in pc.level_scale), int(pc.level_num),
+            tuple(anchor.shape), mask_anchor_bool is None)
+
+
+def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask):
+    """(_cached_plan(...), per-level row lists of the rate subset, all chosen rows) with ONE host read.
+
+    The cache check ("are anchor and mask what the plan was built from?") and the sizes of the per-level
+    subsets (nonzero needs them to size its output) are device results the host has to wait for; each wait
+    drains the launch queue, so they are fetched together: the plan is used speculatively, the per-level counts
+    come from one cumulative sum over choose_mask in coding order, and nonzero_static(size=known) needs no
+    further read.  Per level this equals nonzero(choose_mask[orig]) (:1658-1669 restricted to the level)."""
+    cache = getattr(pc, "_level_cache", None)
+    if (choose_mask is None or cache is None or cache["key"] != _plan_key(pc, anchor, mask_anchor_bool)
+            or not cache["covers_all"] or not hasattr(torch, "nonzero_static")):
+        c = _cached_plan(pc, anchor, mask_anchor_bool)
+        return c, None, None
+    same = (anchor == cache["anchor"]).all()
+    if mask_anchor_bool is not None:
+        same = same & (mask_anchor_bool == cache["mask"]).all()
+    perm, sizes = cache["perm"], cache["sizes"]
+    if "bounds" not in cache:
+        b = [0]
+        for s in sizes:
+            b.append(b[-1] + s)
+        cache["bounds"] = torch.tensor(b, dtype=torch.long, device=perm.device)
+    cm_p = choose_mask.index_select(0, perm)
+    csum = torch.cat([torch.zeros(1, dtype=torch.long, device=perm.device), cm_p.cumsum(0)])
+    host = torch.cat([same.reshape(1).long(), csum.index_select(0, cache["bounds"])]).tolist()   # the one sync
+    if not host[0]:
+        c = _cached_plan(pc, anchor, mask_anchor_bool)       # rebuilds (rare: anchors / anchor mask changed)
+        return c, None, None
+    cum = host[1:]
+    nz = torch.nonzero_static(cm_p, size=cum[-1])[:, 0]
+    locs, off = [], 0
+    for j, n_l in enumerate(sizes):
+        locs.append(nz[cum[j]:cum[j + 1]] - off)
+        off += n_l
+    return cache, locs, perm.index_select(0, nz)
+
+
 def _level_plan_uncached(pc, anchor, mask_anchor_bool):
     _hl, inverse_indices_list, mapping_list, _ = divide_levels(pc, anchor, mask_anchor_bool)
     n = anchor.shape[0]
@@ -294,20 +336,23 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     likelihood_hyper [N-ordered], levels) where `levels` holds, per coded level, the slices the rate model
     needs (only when keep_stats)."""
     K = pc.n_offsets
+    if pc.level_scale is None:                                                         # :1559
+        sel = anchor[mask_anchor_bool] if mask_anchor_bool is not None else anchor
+        pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
+    # level plan (cached) + the rate subset's rows per level, with one host read for both
+    c, locs, chosen_rows = _plan_and_chosen(pc, anchor, mask_anchor_bool,
+                                            choose_mask if (keep_stats and anchor.is_cuda) else None)
+    perm, sizes = c["perm"], c["sizes"]
     # :1556.  Only the rate subset's hyper likelihood is ever read (:1662): ask the bottleneck for those rows only
-    # (likelihood_hyper is then [n_chosen, C], in nonzero(choose_mask) order; rate_model recognises it by its length)
+    # (likelihood_hyper is then [n_chosen, C] in `chosen_rows` order; rate_model recognises it by its length)
     if (FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda
             and isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3)):
-        hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training, rows=torch.nonzero(choose_mask)[:, 0])
+        rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(choose_mask)[:, 0]
+        hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training, rows=rows_h)
     else:
         hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)
     if pc.disable_hyper:
         hyper_feat = hyper_feat * 0
-    if pc.level_scale is None:                                                         # :1559
-        sel = anchor[mask_anchor_bool] if mask_anchor_bool is not None else anchor
-        pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
-    c = _cached_plan(pc, anchor, mask_anchor_bool)
-    perm, sizes = c["perm"], c["sizes"]
 
     # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
     full = c["covers_all"]
@@ -331,7 +376,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         if n_l > 0:
             loc = None
             if keep_stats and choose_mask is not None:
-                loc = torch.nonzero(choose_mask[orig])[:, 0]
+                loc = locs[j] if locs is not None else torch.nonzero(choose_mask[orig])[:, 0]
             subset_mode = _mlp.supported(pc.get_grid_mlp[i]) and (not keep_stats or loc is not None)
             use_fused = fused and subset_mode
             if ctx_src is None:                                                        # :1596-1600
