@@ -586,17 +586,34 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
     return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q) + tuple(rates)
 
 
+class LazyRows:
+    """src[idx] (distinct rows) not yet materialised."""
+
+    def __init__(self, src, idx):
+        self.src, self.idx = src, idx
+
+    def materialize(self):
+        return gather_unique(self.src, self.idx)
+
+    def cat_with(self, *others):
+        """cat([src[idx], *others], dim=1) as one rowcat launch."""
+        return _ctx.rowcat([(self.src, self.idx, True)] + [(o, None, True) for o in others])
+
+
 def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
-                                   mask_anchor_bool, vis_idx, training, predict_bpp):
+                                   mask_anchor_bool, vis_idx, training, predict_bpp, defer_feat=False):
     """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
-    two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]]."""
+    two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]].  defer_feat: return the
+    feature rows as a LazyRows (source + row index) so that the caller can fuse the gather into its own kernel."""
     choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False) if predict_bpp else None
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
         choose_mask=choose_mask)
     if c["covers_all"]:
         pos = c["inv_perm"][vis_idx]
-        outs = tuple(gather_unique(t, pos) for t in (feat_p, scal_p, off_p))
+        lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32
+        outs = ((LazyRows(feat_p, pos) if lazy else gather_unique(feat_p, pos)),
+                gather_unique(scal_p, pos), gather_unique(off_p, pos))
     else:
         outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:

@@ -4,9 +4,10 @@ signatures, phase switches and return values (cited lines are that file).
 
 What runs where: the visibility filter and the whole rasterizer are HIP
 kernels (rasterizer.py); the anchor->Gaussian elementwise/compaction chain is
-the fused HIP expansion (expand.hip) behind `_ExpandGaussians`; the three tiny
-anchor MLPs go through rocBLAS via torch (north_star), with their first layers
-batched into one [N,54]x[54,150] GEMM.
+the fused HIP expansion (expand.hip) behind `_ExpandGaussians`; the three
+anchor MLPs share their input and run as one fused fp32-MFMA launch each way
+(mlp3.hip; rocprof showed the rocBLAS + element-wise version dominating the
+step); the context model of the training / eval phases is context_model.py.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, mlp
-from .context_model import gather_unique, multi_scale_generating, multi_scale_generating_visible
+from .context_model import LazyRows, gather_unique, multi_scale_generating, multi_scale_generating_visible
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 Q_FEAT, Q_SCALING, Q_OFFSETS = 1, 0.001, 0.2      # :40-42
@@ -145,7 +146,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         binary_all = pc.get_mask
         res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
                                              pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
-                                             training=is_training, predict_bpp=is_training)
+                                             training=is_training, predict_bpp=is_training, defer_feat=True)
         feat, grid_scaling, grid_offsets = res[:3]
         if is_training:
             bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
@@ -154,7 +155,12 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     ob_view = anchor - viewpoint_camera.camera_center                                   # :106-110
     ob_dist = ob_view.norm(dim=1, keepdim=True)
     ob_view = ob_view / ob_dist
-    cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
+    if isinstance(feat, LazyRows):
+        # the visibility gather of the context model's output and this concatenation are one launch (and one
+        # scatter on the way back) instead of a gather + a cat
+        cat_local_view = feat.cat_with(ob_view, ob_dist)
+    else:
+        cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
 
     op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                          # :112-127
     K = pc.n_offsets
