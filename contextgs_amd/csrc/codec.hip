@@ -81,6 +81,34 @@ struct BitReader {
     }
 };
 
+// Device decoder input: the wave keeps a 256-byte window of the stream in one register (lane l = big-endian dword
+// l of the window) and the wave-uniform bit cursor picks its bits with two v_readlane — no memory access on the
+// per-symbol path (the byte-wise reader above costs one or two dependent global-load latencies per symbol).
+struct WaveBitReader {
+    const uint8_t *buf;
+    uint64_t len, pos, base;     // bytes, bit cursor, byte offset of the window
+    uint32_t win;
+    __device__ void fill(uint64_t b) {
+        base = b;
+        const uint64_t o = b + 4ull * (threadIdx.x & 63);
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w = (w << 8) | (o + t < len ? (uint32_t)buf[o + t] : 0u);
+        win = w;
+    }
+    __device__ void init(const uint8_t *b, size_t n) { buf = b; len = (uint64_t)n; pos = 0; fill(0); }
+    __device__ uint32_t get_bits(int n) {
+        const uint64_t idx = pos >> 3;
+        if (idx - base > 247) fill(idx & ~3ull);                 // needs dwords d and d + 1 inside the window
+        const int d = __builtin_amdgcn_readfirstlane((int)((idx - base) >> 2));
+        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, d) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, d + 1);
+        const int off = (int)((idx - base) & 3) * 8 + (int)(pos & 7u);
+        pos += (uint64_t)n;
+        return (uint32_t)((v << off) >> (64 - n));
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // arithmetic coder core
 // ---------------------------------------------------------------------------------
@@ -132,17 +160,24 @@ struct AcEncoder {
     }
 };
 
-struct AcDecoder {
+template <class Reader>
+struct AcDecoderT {
     uint32_t low, high, value;
-    BitReader in;
+    Reader in;
     __host__ __device__ void init(const uint8_t *buf, size_t len) {
         low = 0; high = 0xFFFFFFFFu;
         in.init(buf, len);
         value = in.get_bits(32);
     }
     __host__ __device__ uint32_t target() const {
+        // floor(num / span) with num < 2^49, span <= 2^32: one fp64 division (exact operands, quotient < 2^17)
+        // plus an integer fix-up instead of the ~150-instruction 64-bit integer division
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        return (uint32_t)((((uint64_t)value - (uint64_t)low + 1) * (uint64_t)AC_TOP - 1) / span) & 0xFFFFu;
+        const uint64_t num = ((uint64_t)value - (uint64_t)low + 1) * (uint64_t)AC_TOP - 1;
+        uint64_t q = (uint64_t)((double)num / (double)span);
+        while (q * span > num) --q;
+        while ((q + 1) * span <= num) ++q;
+        return (uint32_t)q & 0xFFFFu;
     }
     __host__ __device__ void consume(uint32_t c_low, uint32_t c_high) {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
@@ -155,6 +190,8 @@ struct AcDecoder {
         if (r.u > 0) value = ((value << r.u) ^ 0x80000000u) | in.get_bits(r.u);
     }
 };
+
+typedef AcDecoderT<BitReader> AcDecoder;
 
 // Largest m in [0, max_sym] with cdf(m) <= target (cdf strictly increasing).
 template <typename CdfFn>
@@ -374,7 +411,7 @@ __global__ void __launch_bounds__(64)
     const int lane = threadIdx.x;
     if (s >= n_streams) return;
     const int64_t b = stream_off[s], e = stream_off[s + 1];
-    AcDecoder dec;
+    AcDecoderT<WaveBitReader> dec;
     dec.init(in + in_off[s], (size_t)(in_off[s + 1] - in_off[s]));
     const int lo = min_v[s];
     const int Lp = max_v[s] - lo + 2;
@@ -393,17 +430,40 @@ __global__ void __launch_bounds__(64)
         for (int j = 0; j < cnt; ++j) {
             const float q = bcast_f(q_l, j), m = bcast_f(m_l, j), inv = bcast_f(inv_l, j);
             const uint32_t target = dec.target();
+            // sym = largest candidate with cdf[cand] <= target (the CDF is strictly increasing, so the lanes that
+            // pass form a prefix).  The 64-candidate window starts around the Gaussian's mean, where the mass is:
+            // wide grids (scaling: Q = 1e-3, thousands of symbols) otherwise cost max_sym/64 erff rounds per symbol.
             int sym = 0;
-            for (int cb = 0;; cb += 64) {
+            int cb = (int)rintf(m / q) - lo - 32;
+            cb = max(0, min(cb, max_sym - 63));
+            uint32_t cdf_l = 0;
+            for (;;) {
                 const int cand = cb + lane;
-                const bool le = cand <= max_sym && gaussian_cdf_int(cand, lo, norm, m, inv, q) <= target;
-                const int n_le = __builtin_popcountll(__ballot(le));     // the CDF is strictly increasing: a prefix
-                if (n_le < 64 || cb + 64 > max_sym) { sym = max(0, cb + n_le - 1); break; }
+                cdf_l = gaussian_cdf_int(cand, lo, norm, m, inv, q);
+                const bool le = cand <= max_sym && cdf_l <= target;
+                const int n_le = __builtin_popcountll(__ballot(le));
+                if (n_le == 0) {
+                    if (cb == 0) { sym = 0; break; }
+                    cb = max(0, cb - 64);                 // everything in the window is above the target
+                } else if (n_le == 64 && cb + 64 <= max_sym) {
+                    cb += 63;                             // keep the last passing candidate in the next window
+                } else {
+                    sym = cb + n_le - 1;
+                    break;
+                }
             }
             if (lane == j) x_l = (float)(sym + lo) * q;
             if (i0 + j == e - 1) break;
-            const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
-            const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+            // the symbol's two CDF entries were just evaluated by lanes sym - cb and sym + 1 - cb of the window
+            const int rel = __builtin_amdgcn_readfirstlane(sym - cb);
+            uint32_t c_low, c_high;
+            if (rel >= 0 && rel < 63) {
+                c_low = bcast_u(cdf_l, rel);
+                c_high = sym == max_sym ? AC_TOP : bcast_u(cdf_l, rel + 1);
+            } else {
+                c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+                c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+            }
             dec.consume(c_low, c_high);
         }
         if (i < e) x_out[i] = x_l;
