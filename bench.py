@@ -290,6 +290,7 @@ def codec_bench(pc):
         was = pc.get_color_mlp.training
         pc.eval()
         n_valid = int(pc.get_mask_anchor.sum())
+        pc.conduct_encoding(d)                      # untimed warm-up (first-touch allocations, CDF tables of the prior)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pc.conduct_encoding(d)
         torch.cuda.synchronize(); t1 = time.perf_counter()

@@ -412,8 +412,13 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                                                      outs=(big_f[sl], big_s[sl], big_o[sl]) if joined else None)
                 row_off += n_l
                 if keep_stats:
+                    # chosen_rows lists the chosen anchors level by level: this level's are [lo, lo + len(loc))
+                    span = None
+                    if chosen_rows is not None:
+                        lo_ = sum(int(l_.shape[0]) for l_ in locs[:j])
+                        span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
                     levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
-                                       yo=ho, Q=Q_all, pred=grid_mlp(pc, i, gather_unique(feat_in, loc))))
+                                       yo=ho, Q=Q_all, pred=grid_mlp(pc, i, gather_unique(feat_in, loc)), chosen=span))
                 feat_q.append(hf)
                 scal_q.append(hs)
                 off_q.append(ho)
@@ -507,14 +512,22 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     s_feat, s_scaling, s_offsets = zero, zero, zero
     n_feat = n_scaling = n_offsets = 0
     level_bpp_sums, level_rows = [], []
-    x_means = None
+    x_means = masks_chosen = None
     for L in levels:
         if L.get("fused"):                      # one launch: gathers of the chosen rows + the three rate terms + sums
             if x_means is None:
                 x_means = torch.stack([xm_feat, xm_scaling, xm_offsets]).detach()
             n_sub = int(L["loc"].shape[0])
-            sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"],
-                                   binary_grid_masks.reshape(n, K), L["rows"], x_means, _enc.use_clamp, K)
+            if L.get("chosen") is not None:
+                # the mask rows of ALL levels' chosen anchors in one gather (one scatter + one zero fill on the way
+                # back instead of an [N,K] gradient buffer and an accumulation per level)
+                if masks_chosen is None:
+                    masks_chosen = gather_unique(binary_grid_masks.reshape(n, K), L["chosen"][0])
+                m_rows, g_rows = masks_chosen[L["chosen"][1]:L["chosen"][2]], None
+            else:
+                m_rows, g_rows = binary_grid_masks.reshape(n, K), L["rows"]
+            sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"], m_rows, g_rows, x_means,
+                                   _enc.use_clamp, K)
             s_feat, s_scaling, s_offsets = s_feat + sums[0], s_scaling + sums[1], s_offsets + sums[2]
             n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
             level_rows.append(n_sub)

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256)
     const int E = D + 6 + 3 * K;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
-        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : 0;
+        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : s;
         for (int e = lane; e < E; e += 64) {
             const RateElem t = rate_elem(e, s, r, grow, D, K, ldp, yf, ys, yo, Q, pred, masks, x_means);
             const float b = rate_bits(rate_terms(t.x, t.mean, t.scale, t.q, t.xm, use_clamp)) * t.w;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256)
     const int E = D + 6 + 3 * K, P = 2 * E;
     const float g0 = g_sums[0], g1 = g_sums[1], g2 = g_sums[2];
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
-        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : 0;
+        const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : s;
         float gq[3] = {0.f, 0.f, 0.f};
         if (lane < ldp - P) d_pred[s * ldp + P + lane] = 0.f;   // outputs beyond the mean/scale block (the step sizes)
         for (int e = lane; e < E; e += 64) {
@@ -319,7 +319,7 @@ extern "C" int cgs_level_rate_fwd(const float *yf, const float *ys, const float 
     int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_fwd");
     if (rc) return rc;
     if (n_sub == 0) return CGS_OK;
-    if (!sums || (use_clamp && !x_means) || (masks && !grows)) { cgs_set_error("level_rate_fwd: NULL"); return CGS_ERR_ARG; }
+    if (!sums || (use_clamp && !x_means)) { cgs_set_error("level_rate_fwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_RATE_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(level_rate_fwd_kernel, dim3(stream_grid(n_sub, 4 * 4)), dim3(256), 0, (hipStream_t)stream, yf, ys, yo,
                        Q, loc, pred, masks, grows, use_clamp ? x_means : nullptr, use_clamp, n_sub, D, K, ldpred, sums);
@@ -335,7 +335,7 @@ extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float 
     int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_bwd");
     if (rc) return rc;
     if (n_sub == 0) return CGS_OK;
-    if (!g_sums || !d_pred || !d_yf || !d_ys || !d_yo || !dQ || (use_clamp && !x_means) || (masks && !grows)) {
+    if (!g_sums || !d_pred || !d_yf || !d_ys || !d_yo || !dQ || (use_clamp && !x_means)) {
         cgs_set_error("level_rate_bwd: NULL");
         return CGS_ERR_ARG;
     }

@@ -261,7 +261,8 @@ int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
 /* Bits of the chosen rows of one level (:1658-1669 with utils/entropy_models.py:30-50):
  * for s < n_sub, r = loc[s] (row inside the level; NULL = s):
  *   sums[0] += bits(yf[r], mean_f, scale_f, Q[r,0])      sums[1] += bits(ys[r], ..., Q[r,1])
- *   sums[2] += bits(yo[r], ..., Q[r,2]) * masks[grows[s], k]   (masks [N,K], may be NULL)
+ *   sums[2] += bits(yo[r], ..., Q[r,2]) * masks[grows[s], k]   (masks [N,K], may be NULL;
+ *                                                               grows == NULL: row s of masks)
  * pred [n_sub, ldpred >= 2(D+6+3K)] = [mean_f D | scale_f D | mean_s 6 | scale_s 6 | mean_o 3K |
  * scale_o 3K] (the first 2(D+6+3K) outputs of mlp_grid).  x_means [3] are the clamp
  * centres when use_clamp != 0.  sums [3] is ACCUMULATED into.  The backward takes
