@@ -566,11 +566,35 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         stats = [1 - (mask_anchor_bool.float().mean() if mask_anchor_bool is not None else torch.ones((), device=dev)),
                  bit_per_hyper_param.detach()]
         stats += [s / max(1, r) / feat_dim for s, r in zip(level_bpp_sums, level_rows)]
-        host = torch.stack([t.reshape(()).float() for t in stats]).cpu().tolist()
-    each_level_bpp = [host[0], host[1]]
-    for li, L in enumerate(levels):
-        each_level_bpp.append([L["n_level"] / n, host[2 + li]])
+        dev_stats = torch.stack([t.reshape(()).float() for t in stats])
+    each_level_bpp = LevelBppReport(dev_stats, [L["n_level"] / n for L in levels])
     return bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, each_level_bpp
+
+
+class LevelBppReport(list):
+    """`each_level_bpp` of the reference (:1697-1705): [masked-anchor ratio, hyper bpp, [level ratio, level bpp]...].
+
+    The reference fills it with `.item()` reads in the middle of the training step; the numbers are only logged,
+    so here the device values stay on the device until the list is first looked at (indexing, iteration, len,
+    printing) — one D2H read then, none (and no drained launch queue) for the iterations that do not log."""
+
+    def __init__(self, dev_stats, level_ratios):
+        super().__init__()
+        self._dev, self._ratios = dev_stats, level_ratios
+
+    def _fill(self):
+        if self._dev is not None:
+            host = self._dev.cpu().tolist()
+            self._dev = None
+            super().extend([host[0], host[1]] + [[r, host[2 + i]] for i, r in enumerate(self._ratios)])
+        return self
+
+    def __getitem__(self, k): return list.__getitem__(self._fill(), k)
+    def __iter__(self): return list.__iter__(self._fill())
+    def __len__(self): return list.__len__(self._fill())
+    def __repr__(self): return list.__repr__(self._fill())
+    def __eq__(self, other): return list.__eq__(self._fill(), other)
+    __hash__ = None
 
 
 def _unpermute(c, t):
