@@ -151,17 +151,24 @@ def _cached_plan(pc, anchor, mask_anchor_bool):
     sizes = [int(o.shape[0]) for o in origs]
     # context rows (original space, and as positions in coding order) that the level coded AFTER level i needs
     already = torch.zeros(n, dtype=torch.bool, device=dev)
-    ctx_idx, ctx_pos = {}, {}
+    ctx_idx, ctx_pos, ctx_csr = {}, {}, {}
+    coded = 0
     for (i, _tc, orig, _a) in plan:
         already[orig] = True
+        coded += int(orig.shape[0])
         if i != 0:
             idx = _context_index(n, already, inverse_indices_list, mapping_list, i)
             ctx_idx[i] = idx
             ctx_pos[i] = inv_perm[idx]
+            # children of every coded row (CSR), for the atomics-free backward of the context gather
+            order = torch.argsort(ctx_pos[i], stable=True)
+            counts = torch.bincount(ctx_pos[i], minlength=coded)
+            offs = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), counts.cumsum(0)])
+            ctx_csr[i] = (offs, order, perm[:coded].contiguous())
     cache = dict(key=key, anchor=anchor.detach().clone(),
                  mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
                  inverse=inverse_indices_list, mapping=mapping_list, perm=perm, inv_perm=inv_perm, sizes=sizes,
-                 ctx_idx=ctx_idx, ctx_pos=ctx_pos, covers_all=bool(perm.shape[0] == n))
+                 ctx_idx=ctx_idx, ctx_pos=ctx_pos, ctx_csr=ctx_csr, covers_all=bool(perm.shape[0] == n))
     try:
         pc._level_cache = cache
     except Exception:
@@ -386,10 +393,9 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 else:
                     feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
             else:
-                idx, pos, base_f, base_s = ctx_src
+                idx, pos, base_f, base_s, csr = ctx_src
                 if use_fused:
-                    feat_in = _ctx.rowcat([(anchor, idx, False), (base_f, pos, False), (base_s, pos, False),
-                                           (hyp_l[j], None, True)])
+                    feat_in = _ctx.ctx_assemble(anchor, base_f, base_s, hyp_l[j], idx, pos, csr)
                 else:
                     feat_in = torch.cat([gather_rows(anchor, idx), gather_rows(base_f, pos), gather_rows(base_s, pos),
                                          hyp_l[j]], dim=1)
@@ -480,7 +486,7 @@ def _next_context(c, i, feat_q, scal_q, joined=None):
         base_f, base_s = _JoinRows.apply(big_f[:rows], *feat_q), _JoinRows.apply(big_s[:rows], *scal_q)
     else:
         base_f, base_s = torch.cat(feat_q, dim=0), torch.cat(scal_q, dim=0)
-    return c["ctx_idx"][i], c["ctx_pos"][i], base_f, base_s
+    return c["ctx_idx"][i], c["ctx_pos"][i], base_f, base_s, c["ctx_csr"][i]
 
 
 def draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits):

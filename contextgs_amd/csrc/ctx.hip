@@ -346,3 +346,53 @@ extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float 
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward of the context gather (the parent rows read by the children of the next level) WITHOUT atomics: the
+// children of every parent are known from the level plan (CSR: offs[p] .. offs[p+1] into `order`), so one wave
+// per parent sums its children's gradient rows (lane = column, each child row is one coalesced read) and writes
+// the parent's gradient once.  Deterministic, no zero fill for d_f / d_s, and ~4x faster than the 47 M fp32
+// atomics of the scatter-add version at 800 k children.
+// dout [n_children, ldo]: columns [0, wa) -> d_anchor[parent_row[p]], [wa, wa+DF) -> d_f[p], [wa+DF, wa+DF+DS) -> d_s[p]
+__global__ void __launch_bounds__(256)
+    ctx_gather_bwd_kernel(const float *__restrict__ dout, int64_t ldo, int64_t n_parents,
+                          const int64_t *__restrict__ offs, const int64_t *__restrict__ order,
+                          const int64_t *__restrict__ parent_row, float *__restrict__ d_anchor,
+                          float *__restrict__ d_f, float *__restrict__ d_s, int wa, int DF, int DS) {
+    const int lane = threadIdx.x & 63;
+    const int W = wa + DF + DS;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_parents; p += (int64_t)gridDim.x * 4) {
+        const int64_t b = offs[p], e = offs[p + 1];
+        float acc0 = 0.f, acc1 = 0.f;                     // columns lane and lane + 64
+        for (int64_t k = b; k < e; ++k) {
+            const float *row = dout + order[k] * ldo;
+            if (lane < W) acc0 += row[lane];
+            if (lane + 64 < W) acc1 += row[lane + 64];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            const float v = h ? acc1 : acc0;
+            if (c >= W) continue;
+            if (c < wa) { if (d_anchor && e > b) d_anchor[parent_row[p] * wa + c] = v; }
+            else if (c < wa + DF) { if (d_f) d_f[p * DF + (c - wa)] = v; }
+            else if (d_s) d_s[p * DS + (c - wa - DF)] = v;
+        }
+    }
+}
+
+extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
+                                  const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
+                                  float *d_s, int wa, int DF, int DS, void *stream) {
+    if (n_parents < 0 || wa < 0 || DF < 0 || DS < 0 || wa + DF + DS < 1 || wa + DF + DS > 128 || ldo < wa + DF + DS) {
+        cgs_set_error("ctx_gather_bwd: bad args");
+        return CGS_ERR_ARG;
+    }
+    if (n_parents == 0) return CGS_OK;
+    if (!dout || !offs || !order || (d_anchor && !parent_row)) { cgs_set_error("ctx_gather_bwd: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(ctx_gather_bwd_kernel, dim3(stream_grid(n_parents, 4 * 8)), dim3(256), 0, (hipStream_t)stream, dout,
+                       ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -168,3 +168,53 @@ class _LevelRate(torch.autograd.Function):
 def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):
     """[bits_feat, bits_scaling, bits_offsets (mask-weighted)] summed over the chosen rows `loc` of a level."""
     return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K))
+
+
+class _CtxAssemble(torch.autograd.Function):
+    """[anchor[idx] | base_f[pos] | base_s[pos] | own] with the atomics-free CSR backward (cgs_ctx_gather_bwd)."""
+
+    @staticmethod
+    def forward(ctx, anchor, base_f, base_s, own, idx, pos, csr):
+        anchor, base_f, base_s, own = _c(anchor), _c(base_f), _c(base_s), _c(own)
+        _lib.require_device(anchor, base_f, base_s, own)
+        n = idx.shape[0]
+        srcs, idxs = [anchor, base_f, base_s, own], [idx, pos, pos, None]
+        widths = [int(s.shape[1]) for s in srcs]
+        out = torch.empty(n, sum(widths), dtype=_f32, device=anchor.device)
+        if n > 0:
+            _lib.check(_lib.lib().cgs_rowcat_fwd(4, _ptrs(srcs), _ptrs(idxs), _ints(widths), _ints(widths), n,
+                                                 _lib.ptr(out), _lib.current_stream()), "cgs_rowcat_fwd")
+        ctx.csr, ctx.widths, ctx.n = csr, widths, n
+        ctx.rows = (anchor.shape[0], base_f.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        offs, order, prow = ctx.csr
+        wa, DF, DS, WO = ctx.widths
+        n_anchor, n_par = ctx.rows
+        need = ctx.needs_input_grad
+        dev = g.device
+        d_anchor = torch.zeros(n_anchor, wa, dtype=_f32, device=dev) if need[0] else None
+        d_f = torch.empty(n_par, DF, dtype=_f32, device=dev) if need[1] else None
+        d_s = torch.empty(n_par, DS, dtype=_f32, device=dev) if need[2] else None
+        d_own = None
+        if ctx.n > 0:
+            if d_anchor is not None or d_f is not None or d_s is not None:
+                _lib.check(_lib.lib().cgs_ctx_gather_bwd(_lib.ptr(g), g.shape[1], n_par, _lib.ptr(offs), _lib.ptr(order),
+                                                         _lib.ptr(prow), _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s),
+                                                         wa, DF, DS, _lib.current_stream()), "cgs_ctx_gather_bwd")
+            if need[3]:
+                d_own = g[:, wa + DF + DS:].contiguous()
+        else:
+            d_f = None if d_f is None else d_f.zero_()
+            d_s = None if d_s is None else d_s.zero_()
+            d_own = torch.zeros(0, WO, dtype=_f32, device=dev) if need[3] else None
+        return d_anchor, d_f, d_s, d_own, None, None, None
+
+
+def ctx_assemble(anchor, base_f, base_s, own, idx, pos, csr):
+    """The MLP input rows of a level: parent anchor / coded feature / coded scaling rows + the level's own hyper
+    rows.  csr = (offs[n_parents+1], order[n_children], parent_row[n_parents]) lists every parent's children."""
+    return _CtxAssemble.apply(anchor, base_f, base_s, own, idx, pos, csr)

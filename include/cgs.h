@@ -242,6 +242,16 @@ int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *const *idx,
 int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const *idx,
                    const int *width, const int *ld, const int *mode, int64_t n,
                    const float *dout, void *stream);
+/* Atomics-free backward of a context assembly whose first three sources are gathered parent rows
+ * (anchor position [N,wa] by original row, coded features [n_parents,DF] and scaling [n_parents,DS]
+ * by position in the coded prefix): the children of parent p are order[offs[p] .. offs[p+1])
+ * (CSR from the level plan); their dout rows [n_children, ldo] are summed per parent.  d_f / d_s
+ * are fully written; d_anchor [N,wa] (pre-zeroed) gets row parent_row[p] for parents with children.
+ * Any of d_anchor / d_f / d_s may be NULL. */
+int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
+                       const int64_t *offs, const int64_t *order,
+                       const int64_t *parent_row, float *d_anchor, float *d_f,
+                       float *d_s, int wa, int DF, int DS, void *stream);
 /* Adaptive step sizes + training noise (:1603-1616):
  *   Q[r,k] = max(q0_k * (1 + tanh(qadj[r,k])), 1e-9),  k = feat, scaling, offsets
  *   yf = xf + u * Q[r,0], ys = xs + u * Q[r,1], yo = xo + u * Q[r,2],  u ~ U[-0.5, 0.5)

@@ -132,3 +132,30 @@ def test_level_rate(n_l, frac, clamp):
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
     finally:
         encodings.use_clamp = old
+
+
+@pytest.mark.parametrize("n_par,n_child", [(1, 1), (500, 2000), (20000, 81234)])
+def test_ctx_assemble_csr_backward_equals_scatter_add(n_par, n_child):
+    """cgs_ctx_gather_bwd (per-parent sums over the plan's child lists) == the atomic scatter-add backward."""
+    from contextgs_amd.ctx_ops import ctx_assemble, rowcat
+    g = torch.Generator(device="cuda").manual_seed(n_child)
+    N = n_par * 3 + 7
+    anchor = torch.randn(N, 3, device=_dev(), generator=g, requires_grad=True)
+    base_f = torch.randn(n_par, 50, device=_dev(), generator=g, requires_grad=True)
+    base_s = torch.randn(n_par, 6, device=_dev(), generator=g, requires_grad=True)
+    own = torch.randn(n_child, 12, device=_dev(), generator=g, requires_grad=True)
+    prow = torch.randperm(N, device=_dev(), generator=g)[:n_par]                 # original row of every coded parent
+    pos = torch.randint(0, n_par, (n_child,), device=_dev(), generator=g)
+    if n_par > 10:
+        pos[pos == 3] = 4                                                        # a parent without children
+    idx = prow[pos]
+    order = torch.argsort(pos, stable=True)
+    offs = torch.cat([torch.zeros(1, dtype=torch.long, device=_dev()), torch.bincount(pos, minlength=n_par).cumsum(0)])
+    out = ctx_assemble(anchor, base_f, base_s, own, idx, pos, (offs, order, prow))
+    ref = rowcat([(anchor, idx, False), (base_f, pos, False), (base_s, pos, False), (own, None, True)])
+    assert torch.equal(out, ref)
+    w = torch.randn_like(out)
+    got = torch.autograd.grad((out * w).sum(), [anchor, base_f, base_s, own])
+    exp = torch.autograd.grad((ref * w).sum(), [anchor, base_f, base_s, own])
+    for a, b in zip(got, exp):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
