@@ -34,6 +34,8 @@ from .entropy_bottleneck import EntropyBottleneck as _EntropyBottleneck
 from .multi_level import torch_unique_with_indices
 
 Q_FEAT0, Q_SCALING0, Q_OFFSETS0 = 1, 0.001, 0.2      # :1564-1566
+import os as _os
+LAZY_MODE = int(_os.environ.get("CGS_LAZY_MODE", "2"))   # tuning knob: 0 gather all, 1 defer feat, 2 defer feat+scaling+offsets
 FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip it to compare with the torch composition)
 
 
@@ -654,9 +656,13 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
         choose_mask=choose_mask)
     if c["covers_all"]:
         pos = c["inv_perm"][vis_idx]
-        lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32
-        outs = ((LazyRows(feat_p, pos) if lazy else gather_unique(feat_p, pos)),
-                gather_unique(scal_p, pos), gather_unique(off_p, pos))
+        lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32 and LAZY_MODE > 0
+        if lazy and LAZY_MODE == 1:
+            outs = (LazyRows(feat_p, pos), gather_unique(scal_p, pos), gather_unique(off_p, pos))
+        elif lazy:      # the consumers (MLP-input assembly, expansion kernels) gather the rows themselves
+            outs = (LazyRows(feat_p, pos), LazyRows(scal_p, pos), LazyRows(off_p, pos))
+        else:
+            outs = tuple(gather_unique(t, pos) for t in (feat_p, scal_p, off_p))
     else:
         outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:

@@ -35,18 +35,23 @@ __global__ void __launch_bounds__(EX_THREADS)
                         const float *__restrict__ gscaling, const float *__restrict__ offsets,
                         const float *__restrict__ neural_opacity, const float *__restrict__ color_in,
                         const float *__restrict__ cov_in, float *__restrict__ xyz, float *__restrict__ color,
-                        float *__restrict__ opacity, float *__restrict__ scaling, float *__restrict__ rot) {
+                        float *__restrict__ opacity, float *__restrict__ scaling, float *__restrict__ rot,
+                        const int64_t *__restrict__ src_row) {
     const int64_t i = (int64_t)blockIdx.x * EX_THREADS + threadIdx.x;
     if (i >= n_slots || !flags[i]) return;
     const int64_t n = i / K;
     const size_t j = pos[i];
-    const float *gs = gscaling + 6 * n;
+    // src_row: gscaling / offsets live in a larger array (the context model's coding-order output) and anchor n
+    // reads its row src_row[n] — the visibility gather fused into this kernel
+    const int64_t sn = src_row ? src_row[n] : n;
+    const int64_t si = sn * K + (i - n * K);
+    const float *gs = gscaling + 6 * sn;
     const float *sr = cov_in + 7 * i;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         color[3 * j + c] = color_in[3 * i + c];
         scaling[3 * j + c] = gs[3 + c] * (1.f / (1.f + __expf(-sr[c])));
-        xyz[3 * j + c] = anchor[3 * n + c] + offsets[3 * i + c] * gs[c];
+        xyz[3 * j + c] = anchor[3 * n + c] + offsets[3 * si + c] * gs[c];
     }
     opacity[j] = neural_opacity[i];
     const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
                       const float *__restrict__ g_neural_opacity /* may be null */,
                       float *__restrict__ d_anchor, float *__restrict__ d_gscaling, float *__restrict__ d_offsets,
                       float *__restrict__ d_op_raw, float *__restrict__ d_mask, float *__restrict__ d_color_in,
-                      float *__restrict__ d_cov_in) {
+                      float *__restrict__ d_cov_in, const int64_t *__restrict__ src_row) {
     __shared__ float acc[EX_APB][9];
     __shared__ float sgs[EX_APB][6];
     const int tid = threadIdx.x;
@@ -81,7 +86,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
     for (int t = tid; t < EX_APB * 9; t += blockDim.x) acc[t / 9][t % 9] = 0.f;
     for (int t = tid; t < EX_APB * 6; t += blockDim.x) {
         const int64_t n = a0 + t / 6;
-        sgs[t / 6][t % 6] = n < n_anchor ? gscaling[6 * n + t % 6] : 0.f;
+        sgs[t / 6][t % 6] = n < n_anchor ? gscaling[6 * (src_row ? src_row[n] : n) + t % 6] : 0.f;
     }
     __syncthreads();
     const int la = tid / K;                 // local anchor
@@ -89,6 +94,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
     const int64_t i = n * K + (tid - la * K);
     if (la < EX_APB && n < n_anchor) {
         const float *gs = sgs[la];
+        const int64_t si = src_row ? src_row[n] * K + (tid - la * K) : i;
         float g_no = g_neural_opacity ? g_neural_opacity[i] : 0.f;
         float dcol[3] = {0.f, 0.f, 0.f}, doff[3] = {0.f, 0.f, 0.f}, dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (flags[i]) {
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
                 const float gsc = g_scaling[3 * j + c];
                 dsr[c] = gsc * gs[3 + c] * sig * (1.f - sig);
                 atomicAdd(&acc[la][c], gx);
-                atomicAdd(&acc[la][3 + c], gx * offsets[3 * i + c]);
+                atomicAdd(&acc[la][3 + c], gx * offsets[3 * si + c]);
                 atomicAdd(&acc[la][6 + c], gsc * sig);
             }
             const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             d_color_in[3 * i + c] = dcol[c];
-            d_offsets[3 * i + c] = doff[c];
+            d_offsets[3 * si + c] = doff[c];
         }
 #pragma unroll
         for (int c = 0; c < 7; ++c) d_cov_in[7 * i + c] = dsr[c];
@@ -138,7 +144,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
         const int c = t % 9;
         if (nn < n_anchor) {
             if (c < 3) d_anchor[3 * nn + c] = acc[t / 9][c];
-            else d_gscaling[6 * nn + (c - 3)] = acc[t / 9][c];
+            else d_gscaling[6 * (src_row ? src_row[nn] : nn) + (c - 3)] = acc[t / 9][c];
         }
     }
 }
@@ -186,14 +192,15 @@ extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, co
 extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags, const uint32_t *pos,
                                 const float *anchor, const float *gscaling, const float *offsets,
                                 const float *neural_opacity, const float *color_in, const float *cov_in, float *xyz,
-                                float *color, float *opacity, float *scaling, float *rot, void *stream) {
+                                float *color, float *opacity, float *scaling, float *rot, const int64_t *src_row,
+                                void *stream) {
     const int64_t n = n_anchor * K;
     if (n_anchor < 0 || K < 1 || K > EX_MAX_K) { cgs_set_error("expand_write: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     CgsProfScope prof(CGS_PROF_EXPAND_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(expand_write_kernel, dim3((unsigned)((n + EX_THREADS - 1) / EX_THREADS)), dim3(EX_THREADS), 0,
                        (hipStream_t)stream, n, K, flags, pos, anchor, gscaling, offsets, neural_opacity, color_in,
-                       cov_in, xyz, color, opacity, scaling, rot);
+                       cov_in, xyz, color, opacity, scaling, rot, src_row);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -204,14 +211,14 @@ extern "C" int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flag
                                    const float *g_opacity, const float *g_scaling, const float *g_rot,
                                    const float *g_neural_opacity, float *d_anchor, float *d_gscaling,
                                    float *d_offsets, float *d_op_raw, float *d_mask, float *d_color_in,
-                                   float *d_cov_in, void *stream) {
+                                   float *d_cov_in, const int64_t *src_row, void *stream) {
     if (n_anchor < 0 || K < 1 || K > EX_MAX_K) { cgs_set_error("expand_backward: bad args"); return CGS_ERR_ARG; }
     if (n_anchor == 0) return CGS_OK;
     CgsProfScope prof(CGS_PROF_EXPAND_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((n_anchor + EX_APB - 1) / EX_APB)),
                        dim3(EX_APB * K), 0, (hipStream_t)stream, n_anchor, K, flags, pos, gscaling, offsets, op_raw,
                        mask, cov_in, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_neural_opacity, d_anchor,
-                       d_gscaling, d_offsets, d_op_raw, d_mask, d_color_in, d_cov_in);
+                       d_gscaling, d_offsets, d_op_raw, d_mask, d_color_in, d_cov_in, src_row);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -32,7 +32,9 @@ class _ExpandGaussians(torch.autograd.Function):
     """(anchor, grid_scaling, offsets, masks, mlp outputs) -> compacted Gaussians (:112-145)."""
 
     @staticmethod
-    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, K):
+    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, K, src_row=None):
+        # src_row: gscaling / offsets are the context model's full coding-order outputs and visible anchor n uses
+        # their row src_row[n] (the visibility gather is done by the kernel)
         L = _lib.lib()
         _lib.require_device(anchor, gscaling, offsets, masks, op_raw, color_in, cov_in)
         anchor, gscaling, offsets = _c(anchor), _c(gscaling), _c(offsets)
@@ -59,8 +61,10 @@ class _ExpandGaussians(torch.autograd.Function):
         _lib.check(L.cgs_expand_write(n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(anchor), _lib.ptr(gscaling),
                                       _lib.ptr(offsets), _lib.ptr(neural_opacity), _lib.ptr(color_in),
                                       _lib.ptr(cov_in), _lib.ptr(xyz), _lib.ptr(color), _lib.ptr(opacity),
-                                      _lib.ptr(scaling), _lib.ptr(rot), stream), "cgs_expand_write")
+                                      _lib.ptr(scaling), _lib.ptr(rot), _lib.ptr(src_row), stream), "cgs_expand_write")
         ctx.K = K
+        ctx.n = n
+        ctx.src_row = src_row
         ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in)
         ctx.mark_non_differentiable(mask_out)
         return xyz, color, opacity, scaling, rot, neural_opacity, mask_out
@@ -70,7 +74,8 @@ class _ExpandGaussians(torch.autograd.Function):
         L = _lib.lib()
         flags, pos, gscaling, offsets, op_raw, masks, cov_in = ctx.saved_tensors
         K = ctx.K
-        n = gscaling.shape[0]
+        n = ctx.n
+        src_row = ctx.src_row
         dev = gscaling.device
         P = int(g_xyz.shape[0]) if g_xyz is not None else 0
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
@@ -82,7 +87,12 @@ class _ExpandGaussians(torch.autograd.Function):
         g_no = _c(g_no) if g_no is not None else None
         e = lambda t: torch.empty_like(t)
         d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        d_gs, d_off, d_op, d_mask = e(gscaling), e(offsets), e(op_raw), e(masks)
+        d_op, d_mask = e(op_raw), e(masks)
+        if src_row is None:
+            d_gs, d_off = e(gscaling), e(offsets)
+        else:       # rows of the larger arrays that no visible anchor reads get a zero gradient (one fill for both)
+            flat = torch.zeros(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
+            d_gs, d_off = flat[:gscaling.numel()].view_as(gscaling), flat[gscaling.numel():].view_as(offsets)
         d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
         d_cov = e(cov_in)
         _lib.check(L.cgs_expand_backward(
@@ -90,8 +100,8 @@ class _ExpandGaussians(torch.autograd.Function):
             _lib.ptr(masks), _lib.ptr(cov_in), _lib.ptr(g_xyz), _lib.ptr(g_color), _lib.ptr(g_opacity),
             _lib.ptr(g_scaling), _lib.ptr(g_rot), _lib.ptr(g_no), _lib.ptr(d_anchor), _lib.ptr(d_gs),
             _lib.ptr(d_off), _lib.ptr(d_op), _lib.ptr(d_mask), _lib.ptr(d_color), _lib.ptr(d_cov),
-            _lib.current_stream()), "cgs_expand_backward")
-        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None
+            _lib.ptr(src_row), _lib.current_stream()), "cgs_expand_backward")
+        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None
 
 
 def _anchor_mlps(pc, x):
@@ -164,8 +174,15 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
 
     op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                          # :112-127
     K = pc.n_offsets
+    src_row = None
+    if isinstance(grid_scaling, LazyRows) and isinstance(grid_offsets, LazyRows) and grid_scaling.idx is grid_offsets.idx:
+        # the expansion kernels read the context model's coding-order outputs through the row index themselves
+        src_row, grid_scaling, grid_offsets = grid_scaling.idx, grid_scaling.src, grid_offsets.src
+    else:
+        grid_scaling = grid_scaling.materialize() if isinstance(grid_scaling, LazyRows) else grid_scaling
+        grid_offsets = grid_offsets.materialize() if isinstance(grid_offsets, LazyRows) else grid_offsets
     xyz, color, opacity, scaling, rot, neural_opacity, mask = _ExpandGaussians.apply(
-        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K)
+        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K, src_row)
 
     if is_training:                                                                      # :147-150
         return (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, 16, bit_per_feat_param,

@@ -410,7 +410,11 @@ int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C, int64_t n,
  * survivor flags and their compacted rows (pos), and returns the survivor
  * count on the host; cgs_expand_write fills the compacted outputs
  * xyz/color/scaling [P,3], opacity [P], rot [P,4]; cgs_expand_backward
- * returns gradients for every differentiable input (all fully written). */
+ * returns gradients for every differentiable input (all fully written).
+ * src_row (may be NULL): anchor n reads gscaling / offsets row src_row[n] of a larger
+ * array (the context model's coding-order output: the visibility gather is fused into
+ * the kernel); d_gscaling / d_offsets then have that array's shape, rows src_row[n]
+ * are written and the caller pre-zeroes the rest. */
 size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K);
 int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw,
                      const float *mask, float *neural_opacity,
@@ -422,7 +426,8 @@ int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags,
                      const float *gscaling, const float *offsets,
                      const float *neural_opacity, const float *color_in,
                      const float *cov_in, float *xyz, float *color,
-                     float *opacity, float *scaling, float *rot, void *stream);
+                     float *opacity, float *scaling, float *rot,
+                     const int64_t *src_row, void *stream);
 int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         const uint32_t *pos, const float *gscaling,
                         const float *offsets, const float *op_raw,
@@ -432,7 +437,7 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         const float *g_rot, const float *g_neural_opacity,
                         float *d_anchor, float *d_gscaling, float *d_offsets,
                         float *d_op_raw, float *d_mask, float *d_color_in,
-                        float *d_cov_in, void *stream);
+                        float *d_cov_in, const int64_t *src_row, void *stream);
 
 #ifdef __cplusplus
 }
