@@ -137,3 +137,6 @@ static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height
 int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
                       int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s);
 size_t cgs_wgrad_scratch_bytes_for(int num_cus);
+struct CgsWgProduct { const float *P; int64_t ldp; int DA; const float *Q; int64_t ldq; int DB; float *dW; float *db; };
+int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int num_cus, void *scratch,
+                           size_t scratch_bytes, hipStream_t s);

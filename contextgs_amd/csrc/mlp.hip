@@ -353,8 +353,8 @@ extern "C" int cgs_mlp2_backward(int in, int hid, int out, int act, const float 
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
     const float *P2 = (act == ACT_NONE || !dZ2) ? dY : dZ2;
     const int64_t ldp2 = (act == ACT_NONE || !dZ2) ? ldy : out;
-    if ((rc = cgs_launch_wgrad2(P2, ldp2, out, H, hid, hid, dW2, db2, n, num_cus(), scratch, scratch_bytes, stream))) return rc;
-    return cgs_launch_wgrad2(dZ1, hid, hid, X, ldx, in, dW1, db1, n, num_cus(), scratch, scratch_bytes, stream);
+    const CgsWgProduct prods[2] = {{P2, ldp2, out, H, hid, hid, dW2, db2}, {dZ1, hid, hid, X, ldx, in, dW1, db1}};
+    return cgs_launch_wgrad_multi(prods, 2, n, num_cus(), scratch, scratch_bytes, stream);
 }
 
 // Workspace for the atomics-free weight-gradient reduction of cgs_mlp2_backward / cgs_anchor_mlp3_backward.

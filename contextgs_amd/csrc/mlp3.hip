@@ -352,14 +352,12 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
         CGS_CHECK_HIP(hipGetLastError());
     }
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
-    int rc;
-    // three first layers at once: [150 x 54]
-    if ((rc = cgs_launch_wgrad2(dZ1cat, M3_HCAT, M3_HCAT, X, ldx, M3_IN, dW1cat, db1cat, n, m3_cus(), scratch, scratch_bytes, stream))) return rc;
-    const float *P[3] = {dZ2_op, dZ2_color, dY_cov};
-    const int outs[3] = {10, 30, 70};
-    for (int i = 0; i < 3; ++i)
-        if ((rc = cgs_launch_wgrad2(P[i], outs[i], outs[i], Hcat + M3_HID * i, M3_HCAT, M3_HID, dW2[i], db2[i], n, m3_cus(),
-                                    scratch, scratch_bytes, stream)))
-            return rc;
-    return CGS_OK;
+    // the three first layers as one [150 x 54] product and the three second layers, all in ONE launch over the
+    // same rows (7 wave tasks): an Hcat / dZ1cat row is pulled from HBM once
+    const CgsWgProduct prods[4] = {
+        {dZ1cat, M3_HCAT, M3_HCAT, X, ldx, M3_IN, dW1cat, db1cat},
+        {dZ2_op, 10, 10, Hcat, M3_HCAT, M3_HID, dW2[0], db2[0]},
+        {dZ2_color, 30, 30, Hcat + M3_HID, M3_HCAT, M3_HID, dW2[1], db2[1]},
+        {dY_cov, 70, 70, Hcat + 2 * M3_HID, M3_HCAT, M3_HID, dW2[2], db2[2]}};
+    return cgs_launch_wgrad_multi(prods, 4, n, m3_cus(), scratch, scratch_bytes, stream);
 }

@@ -215,7 +215,7 @@ static int wgrad_blocks_per_cu() {
     return v;
 }
 
-size_t cgs_wgrad_scratch_bytes_for(int num_cus) { return (size_t)2 * num_cus * WG_MAX_E * sizeof(float); }
+size_t cgs_wgrad_scratch_bytes_for(int num_cus) { return (size_t)2 * num_cus * 25000 * sizeof(float); }
 
 // scratch (>= cgs_mlp_wgrad_scratch_bytes()) selects the atomics-free two-pass path; NULL the atomic one.
 int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
@@ -251,5 +251,191 @@ int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64
                            (int)blocks, E, DA * DB, dW, db);
         CGS_CHECK_HIP(hipGetLastError());
     }
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Several weight-gradient products of ONE backward pass (the two layers of an MLP; the first layer and the three
+// second layers of the anchor MLPs) over the same rows in ONE launch: every (64-feature group of P) x (64-feature
+// group of Q) pair of every product is a task for one wave, all waves of a workgroup walk the same row range, so a
+// row's cache lines (e.g. the three 200-byte slices of an Hcat row) are pulled from HBM once, and 2-4 launches +
+// reductions become one of each.  Same inner loop and LDS-image / two-pass reduction as wgrad4_kernel.
+#define WGM_MAX_TASKS 16
+#define WGM_MAX_PROD 4
+#define WGM_MAX_E 25000      // floats of LDS image: 175x100+175 + 100x71+100 (both layers of mlp_grid) = 24875
+struct WgmTask {
+    const float *P, *Q;
+    int ldp, ldq, DA, DB, ga, gb, img_off;
+};
+struct WgmArgs {
+    WgmTask t[WGM_MAX_TASKS];
+    int ntask, nsub, E;
+};
+struct WgmProducts {
+    float *dW[WGM_MAX_PROD], *db[WGM_MAX_PROD];
+    int off[WGM_MAX_PROD + 1], dadb[WGM_MAX_PROD];
+    int nprod;
+};
+
+template <int UNR>
+__global__ void __launch_bounds__(1024)
+    wgrad_multi_kernel(WgmArgs a, int64_t n, int64_t rows_per_block, float *__restrict__ partial) {
+    __shared__ float img[WGM_MAX_E];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < a.E; i += 1024) img[i] = 0.f;
+    __syncthreads();
+    const int ti = wave % a.ntask, sub = wave / a.ntask;
+    if (sub < a.nsub) {
+        // scalar copies of the task (dynamic indexing of the by-value argument struct)
+        const float *P = nullptr, *Q = nullptr;
+        int ldp = 0, ldq = 0, DA = 0, DB = 0, ga = 0, gb = 0, img_off = 0;
+#pragma unroll
+        for (int k = 0; k < WGM_MAX_TASKS; ++k)
+            if (k == ti) {
+                P = a.t[k].P; Q = a.t[k].Q; ldp = a.t[k].ldp; ldq = a.t[k].ldq; DA = a.t[k].DA; DB = a.t[k].DB;
+                ga = a.t[k].ga; gb = a.t[k].gb; img_off = a.t[k].img_off;
+            }
+        const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r_end = min(n, r_begin + rows_per_block);
+        f32x4 acc[4][4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end);
+        const WgStream sb = wg_stream(Q, ldq, DB, gb, c, r_begin, r_end);
+        const int rows = (int)(r_end - r_begin), stride = a.nsub * 4 * UNR;
+        int row0 = sub * 4 * UNR;
+        WgFrag<UNR> f0, f1;
+        wg_fetch<UNR>(f0, sa, sb, row0, g);
+        for (; row0 < rows; row0 += 2 * stride) {
+            wg_fetch<UNR>(f1, sa, sb, row0 + stride, g);
+            WG_FENCE();
+            wg_consume<UNR>(f0, sa, sb, acc, bsum);
+            WG_FENCE();
+            wg_fetch<UNR>(f0, sa, sb, row0 + 2 * stride, g);
+            WG_FENCE();
+            wg_consume<UNR>(f1, sa, sb, acc, bsum);
+            WG_FENCE();
+        }
+        float *const outW = img + img_off;
+        float *const outb = outW + DA * DB;
+        const int acol0 = 64 * ga + 4 * c, bcol0 = 64 * gb + 4 * c;
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ar = 64 * ga + 4 * (4 * g + r) + ja;
+                if (ar >= DA) continue;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int b = bcol0 + jb;
+                    if (b < DB) atomicAdd(&outW[ar * DB + b], acc[ja][jb][r]);
+                }
+            }
+        if (gb == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = bsum[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g == 0 && acol0 + j < DA) atomicAdd(&outb[acol0 + j], v);
+            }
+        }
+    }
+    __syncthreads();
+    float *dst = partial + (int64_t)blockIdx.x * a.E;
+    for (int i = tid; i < a.E; i += 1024) dst[i] = img[i];
+}
+
+__global__ void __launch_bounds__(256)
+    wgrad_multi_reduce_kernel(const float *__restrict__ partial, int blocks, int E, WgmProducts pr) {
+    __shared__ float s[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < E) {
+        int b = ty;
+        for (; b + 12 < blocks; b += 16) {
+            a0 += partial[(int64_t)b * E + e];
+            a1 += partial[(int64_t)(b + 4) * E + e];
+            a2 += partial[(int64_t)(b + 8) * E + e];
+            a3 += partial[(int64_t)(b + 12) * E + e];
+        }
+        for (; b < blocks; b += 4) a0 += partial[(int64_t)b * E + e];
+    }
+    s[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && e < E) {
+        const float t = (s[0][tx] + s[1][tx]) + (s[2][tx] + s[3][tx]);
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < WGM_MAX_PROD; ++q)
+            if (q < pr.nprod && e >= pr.off[q]) k = q;
+        float *dW = nullptr, *db = nullptr;
+        int off = 0, dadb = 0;
+#pragma unroll
+        for (int q = 0; q < WGM_MAX_PROD; ++q)
+            if (q == k) { dW = pr.dW[q]; db = pr.db[q]; off = pr.off[q]; dadb = pr.dadb[q]; }
+        const int le = e - off;
+        if (le < dadb) dW[le] += t;
+        else if (db) db[le - dadb] += t;
+    }
+}
+
+// prods: nprod (<= 4) products over the same n rows.  Returns CGS_ERR_WORKSPACE-free: falls back to one launch per
+// product (cgs_launch_wgrad2) when the combination does not fit one workgroup (tasks > 16, LDS image, no scratch).
+int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int num_cus, void *scratch,
+                           size_t scratch_bytes, hipStream_t s) {
+    if (n <= 0 || nprod <= 0) return CGS_OK;
+    static const bool disabled = getenv("CGS_WGRAD_NO_MULTI") != nullptr;
+    WgmArgs a;
+    WgmProducts pr;
+    int ntask = 0, E = 0;
+    bool fits = scratch != nullptr && nprod <= WGM_MAX_PROD && !disabled;
+    for (int k = 0; k < nprod && fits; ++k) {
+        const CgsWgProduct &p = prods[k];
+        const int GA = (p.DA + 63) / 64, GB = (p.DB + 63) / 64;
+        pr.dW[k] = p.dW; pr.db[k] = p.db; pr.off[k] = E; pr.dadb[k] = p.DA * p.DB;
+        for (int ga = 0; ga < GA && fits; ++ga)
+            for (int gb = 0; gb < GB; ++gb) {
+                if (ntask >= WGM_MAX_TASKS) { fits = false; break; }
+                a.t[ntask++] = WgmTask{p.P, p.Q, (int)p.ldp, (int)p.ldq, p.DA, p.DB, ga, gb, E};
+            }
+        E += p.DA * p.DB + p.DA;
+    }
+    if (fits && E > WGM_MAX_E) fits = false;
+    if (fits && (size_t)E * sizeof(float) > scratch_bytes) fits = false;
+    if (!fits) {
+        for (int k = 0; k < nprod; ++k) {
+            const CgsWgProduct &p = prods[k];
+            int rc = cgs_launch_wgrad2(p.P, p.ldp, p.DA, p.Q, p.ldq, p.DB, p.dW, p.db, n, num_cus, scratch, scratch_bytes, s);
+            if (rc) return rc;
+        }
+        return CGS_OK;
+    }
+    for (int k = ntask; k < WGM_MAX_TASKS; ++k) a.t[k] = WgmTask{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = nprod; k < WGM_MAX_PROD; ++k) { pr.dW[k] = nullptr; pr.db[k] = nullptr; pr.off[k] = E; pr.dadb[k] = 0; }
+    pr.off[WGM_MAX_PROD] = E;
+    pr.nprod = nprod;
+    constexpr int UNR = 2;
+    a.ntask = ntask;
+    a.nsub = 16 / ntask;
+    a.E = E;
+    int64_t blocks = (n + 255) / 256;
+    int64_t cap = num_cus;
+    const int64_t fit_blocks = (int64_t)(scratch_bytes / ((size_t)E * sizeof(float)));
+    if (cap > fit_blocks) cap = fit_blocks;
+    if (blocks > cap) blocks = cap;
+    int64_t rpb = (n + blocks - 1) / blocks;
+    const int64_t quantum = (int64_t)a.nsub * 4 * UNR;
+    rpb = (rpb + quantum - 1) / quantum * quantum;
+    blocks = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL((wgrad_multi_kernel<UNR>), dim3((unsigned)blocks), dim3(1024), 0, s, a, n, rpb, (float *)scratch);
+    CGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, (const float *)scratch,
+                       (int)blocks, E, pr);
+    CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
