@@ -137,6 +137,11 @@ static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height
 int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
                       int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s);
 size_t cgs_wgrad_scratch_bytes_for(int num_cus);
+// mlp_small.hip: -1 = no instance
+int cgs_launch_mlp2_bwd_recompute(int in, int hid, int out, const float *X, int64_t ldx, const float *W1,
+                                  const float *b1, const float *W2, const float *dY, int64_t ldy, float *dX,
+                                  int64_t lddx, int acc, float *dZ1, float *dW2, float *db2, int64_t n, int num_cus,
+                                  void *scratch, size_t scratch_bytes, hipStream_t s);
 struct CgsWgProduct { const float *P; int64_t ldp; int DA; const float *Q; int64_t ldq; int DB; float *dW; float *db; };
 int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int num_cus, void *scratch,
                            size_t scratch_bytes, hipStream_t s);

@@ -325,18 +325,32 @@ extern "C" int cgs_mlp2_forward(int in, int hid, int out, int act, const float *
 // dX [n,lddx] (NULL to skip; accumulate_dx adds into it), dZ1 [n,hid], dZ2 [n,out] (may be NULL when act == none:
 // then dZ2 == dY).  Weight/bias gradients are ACCUMULATED (atomics) into dW1/db1/dW2/db2: zero or pre-load them.
 extern "C" int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,
-                                 const float *W2, const float *Y, const float *dY, int64_t ldy, const float *H,
+                                 const float *b1, const float *W2, const float *Y, const float *dY, int64_t ldy, const float *H,
                                  float *dX, int64_t lddx, int accumulate_dx, float *dZ1, float *dZ2, float *dW1,
                                  float *db1, float *dW2, float *db2, int64_t n, void *scratch,
                                  size_t scratch_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("mlp2_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
-    if (!X || !W1 || !W2 || !dY || !H || !dZ1 || !dW1 || !db1 || !dW2 || !db2 || (act != ACT_NONE && (!Y || !dZ2))) {
+    if (!X || !W1 || !W2 || !dY || !dZ1 || !dW1 || !db1 || !dW2 || !db2 || (act != ACT_NONE && (!Y || !dZ2))) {
         cgs_set_error("mlp2_backward: NULL");
         return CGS_ERR_ARG;
     }
     int rc = CGS_ERR_ARG;
+    if (!H) {
+        // no saved hidden layer: recompute it (instances for the tiny-output shapes only, csrc/mlp_small.hip)
+        if (act != ACT_NONE || !b1 || !scratch) { cgs_set_error("mlp2_backward: H == NULL needs act 0, b1 and scratch"); return CGS_ERR_ARG; }
+        {
+            CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
+            rc = cgs_launch_mlp2_bwd_recompute(in, hid, out, X, ldx, W1, b1, W2, dY, ldy, dX, lddx, accumulate_dx, dZ1, dW2,
+                                               db2, n, num_cus(), scratch, scratch_bytes, stream);
+        }
+        if (rc == -1) { cgs_set_error("mlp2_backward: no recompute instance for %d -> %d -> %d", in, hid, out); return CGS_ERR_ARG; }
+        if (rc) return rc;
+        CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+        const CgsWgProduct prod = {dZ1, hid, hid, X, ldx, in, dW1, db1};
+        return cgs_launch_wgrad_multi(&prod, 1, n, num_cus(), scratch, scratch_bytes, stream);
+    }
     {
         CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
         bool found = false;

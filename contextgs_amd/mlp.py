@@ -6,12 +6,18 @@ instance raise.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib
 
 _ACT = {None: 0, nn.Tanh: 1, nn.Sigmoid: 2}
+_RECOMPUTE = {(71, 100, 3, 0), (15, 100, 3, 0)}
+RECOMPUTE_HIDDEN = os.environ.get("CGS_MLP_RECOMPUTE", "1") != "0"      # tuning / A-B knob
+
+
 def _zeros_views(dev, *shapes):
     """Zero-initialised tensors of the given shapes carved from ONE buffer (one fill launch)."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
@@ -54,13 +60,15 @@ class _MLP2(torch.autograd.Function):
         hid, out = W1c.shape[0], W2c.shape[0]
         need_grad = any(ctx.needs_input_grad[:5])
         y = torch.empty(n, out, dtype=torch.float32, device=x.device)
-        h = torch.empty(n, hid, dtype=torch.float32, device=x.device) if need_grad else None
+        # tiny-output shapes: the hidden layer is recomputed by the backward instead of stored (csrc/mlp_small.hip)
+        recompute = RECOMPUTE_HIDDEN and (in_f, hid, out, act) in _RECOMPUTE
+        h = torch.empty(n, hid, dtype=torch.float32, device=x.device) if (need_grad and not recompute) else None
         _lib.check(L.cgs_mlp2_forward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1c), _lib.ptr(b1c), _lib.ptr(W2c),
                                       _lib.ptr(b2c), _lib.ptr(y), out, _lib.ptr(h), n, _lib.current_stream()),
                    "cgs_mlp2_forward")
         if need_grad:
-            ctx.save_for_backward(x, W1c, W2c, y, h)
-        ctx.act = act
+            ctx.save_for_backward(x, W1c, W2c, y, h if h is not None else b1c)
+        ctx.act, ctx.recompute = act, recompute
         return y
 
     @staticmethod
@@ -68,6 +76,9 @@ class _MLP2(torch.autograd.Function):
         L = _lib.lib()
         x, W1, W2, y, h = ctx.saved_tensors
         act = ctx.act
+        b1 = None
+        if ctx.recompute:
+            b1, h = h, None
         n, in_f = x.shape
         hid, out = W1.shape[0], W2.shape[0]
         dev = x.device
@@ -78,7 +89,7 @@ class _MLP2(torch.autograd.Function):
         dz2 = torch.empty(n, out, dtype=torch.float32, device=dev) if act != 0 else None
         dW1, db1, dW2, db2 = _zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))   # one fill for the four
         ws = _wgrad_workspace(dev)
-        _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(W2), _lib.ptr(y),
+        _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(y),
                                        _lib.ptr(dy), out, _lib.ptr(h), _lib.ptr(dx), in_f, 0, _lib.ptr(dz1), _lib.ptr(dz2),
                                        _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n,
                                        _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_mlp2_backward")

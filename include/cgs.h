@@ -216,10 +216,14 @@ int cgs_mlp2_forward(int in, int hid, int out, int act, const float *X,
  * dW1/db1/dW2/db2 are ACCUMULATED into: zero or pre-load them.  scratch (device,
  * >= cgs_mlp_wgrad_scratch_bytes()) holds per-workgroup partial weight gradients
  * that a second kernel sums (deterministic, no global atomics); with scratch ==
- * NULL the partials are combined with fp32 atomics instead. */
+ * NULL the partials are combined with fp32 atomics instead.
+ * H == NULL (forward called with H == NULL; instances for {71,15} -> 100 -> 3, act 0): the
+ * hidden layer is recomputed from X, W1, b1 instead of being stored and re-read, and the
+ * second layer's weight gradient is accumulated inside the same kernel; needs scratch.
+ * b1 is only read in that mode. */
 size_t cgs_mlp_wgrad_scratch_bytes(void);
 int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
-                      int64_t ldx, const float *W1, const float *W2,
+                      int64_t ldx, const float *W1, const float *b1, const float *W2,
                       const float *Y, const float *dY, int64_t ldy,
                       const float *H, float *dX, int64_t lddx,
                       int accumulate_dx, float *dZ1, float *dZ2, float *dW1,

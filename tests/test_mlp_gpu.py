@@ -10,7 +10,8 @@ import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = [(54, 50, 10, nn.Tanh), (54, 50, 30, nn.Sigmoid), (54, 50, 70, None), (71, 100, 175, None), (15, 100, 175, None)]
+CONFIGS = [(54, 50, 10, nn.Tanh), (54, 50, 30, nn.Sigmoid), (54, 50, 70, None), (71, 100, 175, None), (15, 100, 175, None),
+           (71, 100, 3, None), (15, 100, 3, None)]
 
 
 def _seq(i, h, o, act):
@@ -41,6 +42,31 @@ def test_forward_backward_match_torch(cfg, n):
     assert (y - y_ref).abs().max() <= 2e-5 * max(1.0, float(y_ref.abs().max()))
     for a, b, name in zip(got, ref, ["dx", "dW1", "db1", "dW2", "db2"]):
         tol = (2e-5 if name == "dx" else 2e-4) * max(1e-6, float(b.abs().max()))
+        assert (a - b).abs().max() <= tol, (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(71, 100, 3, None), (15, 100, 3, None)])
+@pytest.mark.parametrize("n", [1, 17, 5000, 70001])
+def test_tiny_output_backward_with_and_without_saved_hidden_layer(cfg, n, monkeypatch):
+    """{71,15} -> 100 -> 3: the default backward recomputes the hidden layer (csrc/mlp_small.hip); with the knob
+    off it reads the stored one (csrc/mlp.hip).  Same forward bits, gradients equal up to summation order."""
+    from contextgs_amd import mlp
+    i, h, o, act = cfg
+    torch.manual_seed(n)
+    seq = _seq(i, h, o, act)
+    x = torch.randn(n, i, device="cuda", requires_grad=True)
+    w = torch.randn(n, o, device="cuda")
+    outs = []
+    for rc in (True, False):
+        monkeypatch.setattr(mlp, "RECOMPUTE_HIDDEN", rc)
+        x.grad = None
+        seq.zero_grad()
+        y = mlp.mlp2(x, seq)
+        (y * w).sum().backward()
+        outs.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in seq.parameters()])
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b, name in zip(outs[0][1:], outs[1][1:], ["dx", "dW1", "db1", "dW2", "db2"]):
+        tol = (1e-6 if name == "dx" else 2e-4) * max(1e-6, float(b.abs().max()))
         assert (a - b).abs().max() <= tol, (name, float((a - b).abs().max()), float(b.abs().max()))
 
 
