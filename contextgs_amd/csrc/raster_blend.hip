@@ -259,7 +259,8 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                 for (int k = 0; k < NGRAD; ++k) v[k] = 0.f;
                 if (act) {
                     const float om = 1.f - ev.alpha;
-                    T = T / om;
+                    const float inv_om = 1.f / om;      // one IEEE division shared by the two quotients below
+                    T = T * inv_om;
                     const float w = ev.alpha * T;
                     ar = fmaf(last_alpha, lr, (1.f - last_alpha) * ar);
                     ag = fmaf(last_alpha, lg, (1.f - last_alpha) * ag);
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                     float dL_dalpha = (lr - ar) * gr + (lg - ag) * gg + (lb - ab) * gb;
                     dL_dalpha *= T;
                     last_alpha = ev.alpha;
-                    dL_dalpha += (-T_final / om) * bg_dot;
+                    dL_dalpha += (-T_final * inv_om) * bg_dot;
                     const float dL_dG = r1.y * dL_dalpha;
                     const float gG = dL_dG * ev.g;
                     v[0] = gG * fmaf(2.f * r0.z, ev.dx, r0.w * ev.dy);   // d power2 / d gx
