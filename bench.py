@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--no-image-loss", action="store_true")
     return ap.parse_args()
 
 
@@ -51,17 +52,24 @@ def flat_grads(params):
     return [p.grad for p in params if p.grad is not None]
 
 
-def one_step(pc, cam, pipe, bg, w, step_sem, params, dist_on):
-    """prefilter -> render -> backward (-> all-reduce). Returns the render dict."""
+def one_step(pc, cam, pipe, bg, w, step_sem, params, dist_on, gt=None):
+    """prefilter -> render -> backward (-> all-reduce). Returns the render dict.  gt: use the training image loss
+    of train.py:199-209 (L1 + SSIM + scaling / rate / mask regularisers) instead of the fixed linear loss."""
     import torch
     from contextgs_amd.renderer import prefilter_voxel, render
     for p in params:
         p.grad = None
     vis = prefilter_voxel(cam, pc, pipe, bg)
     pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=False, step=step_sem)
-    loss = (pkg["render"] * w).sum()
-    if pkg["bit_per_param"] is not None:
-        loss = loss + 0.001 * pkg["bit_per_param"]          # lambda * rate term (train.py:206-209)
+    if gt is None:
+        loss = (pkg["render"] * w).sum()
+        if pkg["bit_per_param"] is not None:
+            loss = loss + 0.001 * pkg["bit_per_param"]          # lambda * rate term (train.py:206-209)
+    else:
+        from contextgs_amd.loss_utils import training_image_loss
+        loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * pkg["scaling"].prod(dim=1).mean()
+        if pkg["bit_per_param"] is not None:
+            loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
     loss.backward()
     if dist_on:
         from contextgs_amd.dist import allreduce_gradients
@@ -164,6 +172,15 @@ def main():
             raster(i)
         dt_r = timed(raster, args.steps, dist_on)
         value_raster = views / dt_r
+    # the same step with the training image loss of train.py:199-209 (fused L1 + SSIM) instead
+    # of the metric's fixed linear loss
+    value_img_loss = None
+    if not args.no_image_loss:
+        gt_img = torch.rand(3, H, W, device="cuda", generator=g)
+        with_loss = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, dist_on, gt=gt_img)
+        for i in range(max(1, args.warmup // 2)):
+            with_loss(i)
+        value_img_loss = views / timed(with_loss, args.steps, dist_on)
 
     # ---- workload statistics of one view (rank 0) for the algorithmic-byte accounting ----
     result = None
@@ -264,6 +281,7 @@ def main():
                        "anchors": N, "image": [W, H], "views_per_step": world, "visible_anchors": n_vis,
                        "gaussians_per_view": P, "tile_pairs_per_view": R, "R_eff": R_eff, "parallelism": f"dp{world}"},
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
+            "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
             "roofline": roofline, "blend_roofline": blend, "kernels": kernels,
             "hip_kernel_ms_per_step": round(lib_ms, 3),
             "cpu_baseline": cpu,

@@ -111,6 +111,9 @@ SIGNATURES = {
     "cgs_prof_count": (c_int, []),
     "cgs_prof_name": (C.c_char_p, [c_int]),
     "cgs_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64)]),
+    "cgs_l1_ssim_partials": (c_size_t, [c_int, c_int, c_int]),
+    "cgs_l1_ssim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "cgs_l1_ssim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cgs_expand_scratch_bytes": (c_size_t, [c_int64, c_int]),
     "cgs_expand_count": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, C.POINTER(c_int64), c_void_p]),

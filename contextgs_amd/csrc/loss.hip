@@ -1,0 +1,183 @@
+// Image loss of the training iteration (train.py:199-204): L1 + (1 - SSIM) with the 11x11, sigma 1.5 Gaussian
+// window, zero padding and per-channel convolution of utils/loss_utils.py:17-63 — SURVEY section 8(f) rank 2:
+// it sits immediately after the rasterizer in every iteration and is ~20 full-image passes in the reference
+// (5 grouped conv2d + their backward + element-wise maps).
+//
+// One forward and one backward kernel.  A workgroup owns a 16x16 pixel tile of one channel: the 26x26 input patch
+// (halo 5) goes to LDS once, the five moment images (x, y, x^2, y^2, xy) are filtered separably (rows into LDS,
+// columns from LDS), SSIM and its three partial-derivative maps are formed in registers.  The backward filters
+// the three derivative maps the same way (the window is symmetric, so the transposed convolution is the same
+// filter) and combines them with the pixel values.  HBM traffic: forward 8 + 12 B / pixel / channel (two reads,
+// three map writes), backward 20 + 4 B.
+#include "cgs_internal.h"
+
+#define SS_T 16
+#define SS_R 5
+#define SS_P (SS_T + 2 * SS_R)     // 26
+#define SS_K 11
+
+struct SsimWin { float w[SS_K]; };
+
+// gaussian(11, 1.5) as utils/loss_utils.py:23-25 computes it: exp in double, stored fp32, normalised in fp32
+static SsimWin ssim_window() {
+    SsimWin g;
+    float s = 0.f;
+    for (int x = 0; x < SS_K; ++x) {
+        g.w[x] = (float)exp(-(double)((x - SS_K / 2) * (x - SS_K / 2)) / (2.0 * 1.5 * 1.5));
+        s += g.w[x];
+    }
+    for (int x = 0; x < SS_K; ++x) g.w[x] /= s;
+    return g;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void __launch_bounds__(256)
+    l1_ssim_fwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, int H, int W, SsimWin win,
+                       float *__restrict__ maps /* [3][C][H][W] or null */, float *__restrict__ partials) {
+    __shared__ float sx[SS_P][SS_P + 1], sy[SS_P][SS_P + 1];
+    __shared__ float hq[5][SS_P][SS_T + 1];
+    __shared__ float red[4];
+    const int c = blockIdx.z, C = gridDim.z;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const size_t plane = (size_t)H * W;
+    const float *xi = img + c * plane, *yi = gt + c * plane;
+    for (int i = tid; i < SS_P * SS_P; i += 256) {
+        const int py = i / SS_P, px = i - py * SS_P;
+        const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        sx[py][px] = in ? xi[(size_t)gy * W + gx] : 0.f;
+        sy[py][px] = in ? yi[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < SS_P * SS_T; i += 256) {
+        const int r = i >> 4, col = i & 15;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SS_K; ++k) {
+            const float x = sx[r][col + k], y = sy[r][col + k], w = win.w[k];
+            a0 += w * x; a1 += w * y; a2 += w * (x * x); a3 += w * (y * y); a4 += w * (x * y);
+        }
+        hq[0][r][col] = a0; hq[1][r][col] = a1; hq[2][r][col] = a2; hq[3][r][col] = a3; hq[4][r][col] = a4;
+    }
+    __syncthreads();
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SS_K; ++k) {
+        const float w = win.w[k];
+        mu1 += w * hq[0][ly + k][lx]; mu2 += w * hq[1][ly + k][lx];
+        e11 += w * hq[2][ly + k][lx]; e22 += w * hq[3][ly + k][lx]; e12 += w * hq[4][ly + k][lx];
+    }
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool inside = gx < W && gy < H;
+    float m = 0.f, l1 = 0.f;
+    if (inside) {
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float a1 = 2.f * mu12 + C1, a2 = 2.f * s12 + C2, b1 = mu1_sq + mu2_sq + C1, b2 = s1 + s2 + C2;
+        m = (a1 * a2) / (b1 * b2);
+        l1 = fabsf(sx[ly + SS_R][lx + SS_R] - sy[ly + SS_R][lx + SS_R]);
+        if (maps) {
+            const float inv = 1.f / (b1 * b2);
+            const float dm_ds1 = -(a1 * a2) * inv / b2;            // = dm / d sigma1_sq
+            const float dm_ds12 = 2.f * a1 * inv;
+            const float dm_dmu1 = (2.f * mu2 * a2 * b1 - 2.f * mu1 * a1 * a2) * inv / b1
+                                  - 2.f * mu1 * dm_ds1 - mu2 * dm_ds12;      // through sigma1_sq and sigma12 too
+            const size_t o = (size_t)c * plane + (size_t)gy * W + gx, cs = (size_t)C * plane;
+            maps[o] = dm_dmu1;
+            maps[cs + o] = dm_ds1;
+            maps[2 * cs + o] = dm_ds12;
+        }
+    }
+    const float sl = block_sum_256(l1, red);
+    __syncthreads();
+    const float sm = block_sum_256(m, red);
+    if (tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[2 * b] = sl;
+        partials[2 * b + 1] = sm;
+    }
+}
+
+// dimg = g[0] / n * sign(img - gt) + g[1] / n * (conv(A) + 2 img conv(B) + gt conv(Cc)),  n = C H W
+__global__ void __launch_bounds__(256)
+    l1_ssim_bwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ maps,
+                       const float *__restrict__ g, int H, int W, SsimWin win, float *__restrict__ dimg) {
+    __shared__ float sm[3][SS_P][SS_P + 1];
+    __shared__ float hq[3][SS_P][SS_T + 1];
+    const int c = blockIdx.z, C = gridDim.z;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const size_t plane = (size_t)H * W, cs = (size_t)C * plane;
+    for (int i = tid; i < SS_P * SS_P; i += 256) {
+        const int py = i / SS_P, px = i - py * SS_P;
+        const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = (size_t)c * plane + (size_t)gy * W + gx;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sm[q][py][px] = in ? maps[q * cs + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < SS_P * SS_T; i += 256) {
+        const int r = i >> 4, col = i & 15;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SS_K; ++k) {
+            const float w = win.w[k];
+            a0 += w * sm[0][r][col + k]; a1 += w * sm[1][r][col + k]; a2 += w * sm[2][r][col + k];
+        }
+        hq[0][r][col] = a0; hq[1][r][col] = a1; hq[2][r][col] = a2;
+    }
+    __syncthreads();
+    float cA = 0.f, cB = 0.f, cC = 0.f;
+#pragma unroll
+    for (int k = 0; k < SS_K; ++k) {
+        const float w = win.w[k];
+        cA += w * hq[0][ly + k][lx]; cB += w * hq[1][ly + k][lx]; cC += w * hq[2][ly + k][lx];
+    }
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx < W && gy < H) {
+        const size_t o = (size_t)c * plane + (size_t)gy * W + gx;
+        const float x = img[o], y = gt[o];
+        const float inv_n = 1.f / ((float)C * (float)H * (float)W);
+        const float d = x - y;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        dimg[o] = g[0] * inv_n * sgn + g[1] * inv_n * (cA + 2.f * x * cB + y * cC);
+    }
+}
+
+extern "C" size_t cgs_l1_ssim_partials(int C, int H, int W) {
+    return (size_t)C * ((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T);
+}
+
+extern "C" int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, int W, float *maps, float *partials,
+                               void *stream) {
+    if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_fwd: bad shape"); return CGS_ERR_ARG; }
+    if (!img || !gt || !partials) { cgs_set_error("l1_ssim_fwd: NULL"); return CGS_ERR_ARG; }
+    static const SsimWin win = ssim_window();
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    CgsProfScope prof(CGS_PROF_LOSS_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, H, W, win, maps, partials);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *maps, const float *g, int C, int H,
+                               int W, float *dimg, void *stream) {
+    if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_bwd: bad shape"); return CGS_ERR_ARG; }
+    if (!img || !gt || !maps || !g || !dimg) { cgs_set_error("l1_ssim_bwd: NULL"); return CGS_ERR_ARG; }
+    static const SsimWin win = ssim_window();
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g, H, W, win, dimg);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

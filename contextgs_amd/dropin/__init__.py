@@ -26,7 +26,7 @@ def install(patch_reference_python: bool = True) -> list[str]:
     patched = []
     if not patch_reference_python:
         return patched
-    from .. import codec_driver, context_model, encodings, entropy_models, multi_level, renderer
+    from .. import codec_driver, context_model, encodings, entropy_models, loss_utils, multi_level, renderer
 
     def rebind(modname, src, names):
         try:
@@ -63,4 +63,7 @@ def install(patch_reference_python: bool = True) -> list[str]:
     rebind("gaussian_renderer", renderer, ["render", "prefilter_voxel", "generate_neural_gaussians"])
     rebind("gaussian_renderer", context_model, ["multi_scale_generating"])
     rebind("train", renderer, ["render", "prefilter_voxel"])
+    # image loss: train.py does `from utils.loss_utils import l1_loss, ssim` (train.py:37)
+    rebind("utils.loss_utils", loss_utils, ["l1_loss", "ssim"])
+    rebind("train", loss_utils, ["l1_loss", "ssim"])
     return patched

@@ -1,0 +1,73 @@
+"""Drop-in for the reference's utils/loss_utils.py (`l1_loss`, `l2_loss`, `ssim`) — SURVEY section 8(f) rank 2.
+
+`ssim` (11x11 Gaussian window, sigma 1.5, zero padding, per channel, mean; utils/loss_utils.py:33-63) and
+`l1_loss` run as ONE fused HIP launch forward and one backward (csrc/loss.hip, `cgs_l1_ssim_{fwd,bwd}`) instead
+of five grouped conv2d + ~15 element-wise passes each way.  `l1_ssim(image, gt)` returns both means from a
+single launch; `ssim` / `l1_loss` keep the reference's signatures.  Device tensors only: there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class _L1Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt):
+        _lib.require_device(img, gt)
+        x = img if (img.dtype == torch.float32 and img.is_contiguous()) else img.float().contiguous()
+        y = gt if (gt.dtype == torch.float32 and gt.is_contiguous()) else gt.float().contiguous()
+        if x.shape != y.shape or x.dim() != 3:
+            raise ValueError("l1_ssim expects two [C,H,W] images of the same shape")
+        C, H, W = x.shape
+        L = _lib.lib()
+        need = ctx.needs_input_grad[0]
+        maps = torch.empty(3, C, H, W, dtype=torch.float32, device=x.device) if need else None
+        partials = torch.empty(int(L.cgs_l1_ssim_partials(C, H, W)), 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.cgs_l1_ssim_fwd(_lib.ptr(x), _lib.ptr(y), C, H, W, _lib.ptr(maps), _lib.ptr(partials),
+                                     _lib.current_stream()), "cgs_l1_ssim_fwd")
+        sums = partials.sum(dim=0) / float(C * H * W)
+        if need:
+            ctx.save_for_backward(x, y, maps)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        x, y, maps = ctx.saved_tensors
+        C, H, W = x.shape
+        z = torch.zeros((), dtype=torch.float32, device=x.device)
+        g = torch.stack([z if g_l1 is None else g_l1.float().reshape(()), z if g_ssim is None else g_ssim.float().reshape(())])
+        dimg = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_l1_ssim_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(maps), _lib.ptr(g), C, H, W,
+                                              _lib.ptr(dimg), _lib.current_stream()), "cgs_l1_ssim_bwd")
+        return dimg, None
+
+
+def l1_ssim(image: torch.Tensor, gt: torch.Tensor):
+    """(mean |image - gt|, mean SSIM) of two [C,H,W] images from one fused launch."""
+    if image.dim() == 4 and image.shape[0] == 1:
+        image, gt = image[0], gt[0]
+    return _L1Ssim.apply(image, gt)
+
+
+def l1_loss(network_output, gt):                                    # utils/loss_utils.py:17-18
+    if network_output.is_cuda and network_output.dim() == 3 and network_output.shape == gt.shape:
+        return l1_ssim(network_output, gt)[0]
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):                                    # :20-21
+    return ((network_output - gt) ** 2).mean()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):            # :33-63
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("the fused SSIM implements the training configuration: window 11, mean")
+    return l1_ssim(img1, img2)[1]
+
+
+def training_image_loss(image, gt, lambda_dssim: float = 0.2):
+    """(1 - lambda) L1 + lambda (1 - SSIM) of train.py:199-204, both terms from the same launch."""
+    l1, s = l1_ssim(image, gt)
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s), l1, s

@@ -443,6 +443,21 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         float *d_op_raw, float *d_mask, float *d_color_in,
                         float *d_cov_in, const int64_t *src_row, void *stream);
 
+/* ---- image loss of the training iteration ----
+ * train.py:199-204 with utils/loss_utils.py:17-63: L1 = mean|img - gt| and SSIM (11x11 Gaussian
+ * window, sigma 1.5, zero padding, per channel) of two [C,H,W] fp32 images, fused.
+ * cgs_l1_ssim_fwd writes per-workgroup partial sums: partials [cgs_l1_ssim_partials(C,H,W), 2] =
+ * (sum |img - gt|, sum ssim_map) — the caller adds them up and divides by C*H*W — and, for the
+ * backward, the three partial-derivative maps [3,C,H,W] (maps may be NULL for evaluation).
+ * cgs_l1_ssim_bwd: dimg = g[0] * dL1/dimg + g[1] * dSSIM/dimg with g [2] on the device (the
+ * upstream gradients of the two MEANS; no host read). */
+size_t cgs_l1_ssim_partials(int C, int H, int W);
+int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, int W,
+                    float *maps, float *partials, void *stream);
+int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *maps,
+                    const float *g, int C, int H, int W, float *dimg,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif
