@@ -1,0 +1,159 @@
+"""Densification statistics and anchor growing — SURVEY section 8(f) rank 1; drop-ins for
+`GaussianModel.training_statis` (scene/gaussian_model.py:696-713) and `GaussianModel.anchor_growing`
+(:762-855) of the reference.  `adjust_anchor` (:857-910) stays the reference's: it is bookkeeping around these two.
+
+* training_statis: one HIP pass over the visible slots (`cgs_densify_stats`, csrc/densify.hip) instead of ~15
+  launches with three boolean-mask index_puts over all N*K offsets.
+* anchor_growing: same candidate selection, voxel rounding, per-voxel feature max and new-anchor attributes; the
+  de-duplication of candidate voxels against the existing anchors — an O(candidates x N) all-pairs compare in 4096-row
+  chunks in the reference (:793-802) — is a sorted-key membership test (`voxels_already_present`).  The absent
+  `torch_scatter.scatter_max` is `scatter_reduce(amax)`.
+Device tensors only.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from .encodings import Quantize_anchor
+
+
+@torch.no_grad()
+def training_statis(pc, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
+    K = int(pc.n_offsets)
+    _lib.require_device(opacity, pc.opacity_accum)
+    vis_idx = torch.nonzero(anchor_visible_mask)[:, 0]
+    n_vis = int(vis_idx.shape[0])
+    op = opacity.detach().reshape(-1)
+    op = op if (op.dtype == torch.float32 and op.is_contiguous()) else op.float().contiguous()
+    if op.numel() != n_vis * K:
+        raise ValueError("training_statis: opacity must hold n_visible * n_offsets values")
+    sel = offset_selection_mask.reshape(-1).to(torch.uint8).contiguous()
+    sel_pos = (torch.cumsum(sel, 0, dtype=torch.int64) - sel).contiguous()
+    uf = update_filter.reshape(-1).to(torch.uint8).contiguous()
+    grad = viewspace_point_tensor.grad
+    grad = grad if (grad.dtype == torch.float32 and grad.is_contiguous()) else grad.float().contiguous()
+    if grad.dim() != 2 or grad.shape[1] != 3 or grad.shape[0] != uf.shape[0]:
+        raise ValueError("training_statis: viewspace_point_tensor.grad must be [P,3] with P = len(update_filter)")
+    for t in (pc.opacity_accum, pc.anchor_demon, pc.offset_gradient_accum, pc.offset_denom):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("training_statis: accumulators must be contiguous fp32")
+    _lib.check(_lib.lib().cgs_densify_stats(n_vis, K, _lib.ptr(vis_idx), _lib.ptr(op), _lib.ptr(sel), _lib.ptr(sel_pos),
+                                            _lib.ptr(uf), _lib.ptr(grad), _lib.ptr(pc.opacity_accum), _lib.ptr(pc.anchor_demon),
+                                            _lib.ptr(pc.offset_gradient_accum), _lib.ptr(pc.offset_denom),
+                                            _lib.current_stream()), "cgs_densify_stats")
+
+
+def _voxel_keys(v: torch.Tensor) -> torch.Tensor:
+    """int32 [n,3] voxel coordinates -> one int64 key each (21 bits per axis)."""
+    v = v.to(torch.int64) + (1 << 20)
+    return (v[:, 0] << 42) | (v[:, 1] << 21) | v[:, 2]
+
+
+def voxels_already_present(candidates: torch.Tensor, grid_coords: torch.Tensor) -> torch.Tensor:
+    """bool[M]: candidate voxel m equals some row of grid_coords ([N,3] int) — :793-802 without the M x N compare."""
+    if candidates.numel() == 0:
+        return torch.zeros(0, dtype=torch.bool, device=candidates.device)
+    lim = 1 << 20
+    both = max(int(candidates.abs().max()), int(grid_coords.abs().max()) if grid_coords.numel() else 0)
+    if both >= lim:
+        raise ValueError("voxel coordinates exceed the 21-bit key range")
+    return torch.isin(_voxel_keys(candidates), _voxel_keys(grid_coords))
+
+
+def _group_max(src: torch.Tensor, inverse: torch.Tensor, n_groups: int) -> torch.Tensor:
+    """torch_scatter.scatter_max(src, inverse[:,None].expand_as(src), dim=0)[0]"""
+    out = torch.zeros(n_groups, src.shape[1], dtype=src.dtype, device=src.device)
+    return out.scatter_reduce_(0, inverse.unsqueeze(1).expand(-1, src.shape[1]), src, reduce="amax", include_self=False)
+
+
+def _grow_round(i, anchor_q, offset, scale3, feat, hyper, cand_mask, voxel_size, K, init_factor, hier):
+    """One depth of anchor_growing given the CURRENT model tensors; returns the new-anchor dict or None."""
+    dev = anchor_q.device
+    all_xyz = anchor_q.unsqueeze(1) + offset * scale3.unsqueeze(1)
+    size_factor = init_factor // (hier ** i)
+    cur_size = voxel_size * size_factor
+    grid_coords = torch.round(anchor_q / cur_size).int()
+    selected_xyz = all_xyz.view(-1, 3)[cand_mask]
+    selected_grid = torch.round(selected_xyz / cur_size).int()
+    uniq, inverse = torch.unique(selected_grid, return_inverse=True, dim=0)
+    keep = ~voxels_already_present(uniq, grid_coords)
+    cand_anchor = uniq[keep] * cur_size
+    M = int(cand_anchor.shape[0])
+    if M == 0:
+        return None
+    new_scaling = torch.log(torch.ones(M, 6, dtype=torch.float32, device=dev) * cur_size)
+    new_rotation = torch.zeros(M, 4, dtype=torch.float32, device=dev)
+    new_rotation[:, 0] = 1.0
+    new_opacities = torch.full((M, 1), math.log(0.1 / 0.9), dtype=torch.float32, device=dev)     # inverse_sigmoid(0.1)
+    rep = lambda t: t.unsqueeze(1).expand(-1, K, -1).reshape(-1, t.shape[1])[cand_mask]
+    new_feat = _group_max(rep(feat), inverse, uniq.shape[0])[keep]
+    new_hyper = _group_max(rep(hyper), inverse, uniq.shape[0])[keep]
+    return {"anchor": cand_anchor.float(), "scaling": new_scaling, "rotation": new_rotation, "anchor_feat": new_feat,
+            "hyper_latent": new_hyper, "offset": torch.zeros(M, K, 3, dtype=torch.float32, device=dev),
+            "mask": torch.ones(M, K, 1, dtype=torch.float32, device=dev), "opacity": new_opacities, "depth": i}
+
+
+def _candidates(i, grads, threshold, offset_mask, hier, rand):
+    cand = (grads >= threshold * ((hier // 2) ** i)) & offset_mask
+    return cand & (rand > (0.5 ** (i + 1)))
+
+
+@torch.no_grad()
+def growing_rounds(anchor, offset, scaling, feat, hyper, x_bound_min, x_bound_max, grads, threshold, offset_mask, voxel_size,
+                   K, update_depth=3, init_factor=100, hier=4, rand_fn=None):
+    """Functional form of anchor_growing (:762-855): the per-round new-anchor dicts, the model tensors being
+    extended between rounds exactly as cat_tensors_to_optimizer would."""
+    _lib.require_device(anchor, grads)
+    rand_fn = rand_fn or (lambda i, like: torch.rand_like(like))
+    init_length = anchor.shape[0] * K
+    rounds = []
+    for i in range(update_depth):
+        cand = _candidates(i, grads, threshold, offset_mask, hier, rand_fn(i, grads))
+        length_inc = anchor.shape[0] * K - init_length
+        if length_inc == 0:
+            if i > 0:
+                continue                                    # :774-777 (rounds i > 0 only run once something was added)
+        else:
+            cand = torch.cat([cand, torch.zeros(length_inc, dtype=torch.bool, device=cand.device)])
+        anchor_q = Quantize_anchor.apply(anchor, x_bound_min, x_bound_max)[0]
+        d = _grow_round(i, anchor_q, offset, torch.exp(scaling[:, :3]), feat, hyper, cand, voxel_size, K, init_factor, hier)
+        if d is None:
+            continue
+        rounds.append(d)
+        anchor = torch.cat([anchor, d["anchor"]])
+        offset = torch.cat([offset, d["offset"]])
+        scaling = torch.cat([scaling, d["scaling"]])
+        feat = torch.cat([feat, d["anchor_feat"]])
+        hyper = torch.cat([hyper, d["hyper_latent"]])
+    return rounds
+
+
+@torch.no_grad()
+def anchor_growing(pc, grads, threshold, offset_mask):
+    """Drop-in for GaussianModel.anchor_growing (:762-855): mutates `pc` through its own cat_tensors_to_optimizer."""
+    K = int(pc.n_offsets)
+    init_length = pc.get_anchor.shape[0] * K
+    for i in range(pc.update_depth):
+        cand = _candidates(i, grads, threshold, offset_mask, pc.update_hierachy_factor, torch.rand_like(grads))
+        length_inc = pc.get_anchor.shape[0] * K - init_length
+        if length_inc == 0:
+            if i > 0:
+                continue
+        else:
+            cand = torch.cat([cand, torch.zeros(length_inc, dtype=torch.bool, device=cand.device)])
+        d = _grow_round(i, pc.get_anchor, pc._offset, pc.get_scaling[:, :3], pc._anchor_feat, pc._hyper_latent, cand,
+                        pc.voxel_size, K, pc.update_init_factor, pc.update_hierachy_factor)
+        if d is None:
+            continue
+        d.pop("depth")
+        M = d["anchor"].shape[0]
+        z = torch.zeros(M, 1, dtype=torch.float32, device=grads.device)
+        pc.anchor_demon = torch.cat([pc.anchor_demon, z], dim=0)
+        pc.opacity_accum = torch.cat([pc.opacity_accum, z.clone()], dim=0)
+        t = pc.cat_tensors_to_optimizer(d)
+        pc._anchor, pc._scaling, pc._rotation = t["anchor"], t["scaling"], t["rotation"]
+        pc._anchor_feat, pc._hyper_latent, pc._offset = t["anchor_feat"], t["hyper_latent"], t["offset"]
+        pc._mask, pc._opacity = t["mask"], t["opacity"]

@@ -21,12 +21,12 @@ def install(patch_reference_python: bool = True) -> list[str]:
     if HERE not in sys.path:
         sys.path.insert(0, HERE)
     for name in ("diff_gaussian_rasterization", "torchac", "compressai", "compressai.entropy_models",
-                 "compressai.latent_codecs"):
+                 "compressai.latent_codecs", "torch_scatter"):
         importlib.import_module(name)
     patched = []
     if not patch_reference_python:
         return patched
-    from .. import codec_driver, context_model, encodings, entropy_models, loss_utils, multi_level, renderer
+    from .. import codec_driver, context_model, densify, encodings, entropy_models, loss_utils, multi_level, renderer
 
     def rebind(modname, src, names):
         try:
@@ -58,6 +58,10 @@ def install(patch_reference_python: bool = True) -> list[str]:
         gm.GaussianModel.estimate_final_bits = lambda self: codec_driver.estimate_final_bits(self)
         patched += ["scene.gaussian_model.GaussianModel.conduct_encoding", "scene.gaussian_model.GaussianModel.conduct_decoding",
                     "scene.gaussian_model.GaussianModel.estimate_final_bits"]
+        # densification: statistics kernel + sort-based voxel de-duplication
+        gm.GaussianModel.training_statis = lambda self, *a, **k: densify.training_statis(self, *a, **k)
+        gm.GaussianModel.anchor_growing = lambda self, *a, **k: densify.anchor_growing(self, *a, **k)
+        patched += ["scene.gaussian_model.GaussianModel.training_statis", "scene.gaussian_model.GaussianModel.anchor_growing"]
     except Exception:
         pass
     rebind("gaussian_renderer", renderer, ["render", "prefilter_voxel", "generate_neural_gaussians"])

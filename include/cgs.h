@@ -443,6 +443,20 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         float *d_op_raw, float *d_mask, float *d_color_in,
                         float *d_cov_in, const int64_t *src_row, void *stream);
 
+/* ---- densification statistics ----
+ * scene/gaussian_model.py:696-713 (training_statis) in one pass over the n_vis*K slots of the visible
+ * anchors vis_idx [n_vis] (ascending anchor rows): opacity_accum[a] += sum_k max(opacity[.,k], 0),
+ * anchor_demon[a] += 1, and for every selected slot (sel != 0; sel_pos = its rank among the selected
+ * = its Gaussian index) whose Gaussian passed update_filter: offset_gradient_accum[a*K+k] +=
+ * ||grad[j, :2]||, offset_denom[a*K+k] += 1.  grad is [P,3] (viewspace_points.grad).  Accumulators are
+ * the model's [N,1] / [N*K,1] fp32 buffers, updated in place. */
+int cgs_densify_stats(int64_t n_vis, int K, const int64_t *vis_idx,
+                      const float *opacity, const uint8_t *sel,
+                      const int64_t *sel_pos, const uint8_t *update_filter,
+                      const float *grad, float *opacity_accum, float *anchor_demon,
+                      float *offset_gradient_accum, float *offset_denom,
+                      void *stream);
+
 /* ---- image loss of the training iteration ----
  * train.py:199-204 with utils/loss_utils.py:17-63: L1 = mean|img - gt| and SSIM (11x11 Gaussian
  * window, sigma 1.5, zero padding, per channel) of two [C,H,W] fp32 images, fused.
