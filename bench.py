@@ -264,12 +264,16 @@ def main():
                       "pmc_hbm_bytes": traffic.get(n_)} for n_ in ("blend_fwd", "blend_bwd") if n_ in kernels}
         lib_ms = sum(k["total_ms"] for k in kernels.values()) / max(1, args.steps)
 
+        # stdout carries exactly ONE line (the JSON below): the codec driver's progress prints (they mirror the
+        # reference's) and anything the baseline prints go to stderr
+        import contextlib
         codec = None
-        if not args.no_codec:
-            codec = codec_bench(pc)
         cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
+        with contextlib.redirect_stdout(sys.stderr):
+            if not args.no_codec:
+                codec = codec_bench(pc)
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
 
         result = {
             "metric": "views/sec fwd+bwd @1920x1080, 1M anchors", "value": round(value, 3), "unit": "views/s",
