@@ -170,7 +170,9 @@ def _cached_plan(pc, anchor, mask_anchor_bool):
     cache = dict(key=key, anchor=anchor.detach().clone(),
                  mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
                  inverse=inverse_indices_list, mapping=mapping_list, perm=perm, inv_perm=inv_perm, sizes=sizes,
-                 ctx_idx=ctx_idx, ctx_pos=ctx_pos, ctx_csr=ctx_csr, covers_all=bool(perm.shape[0] == n))
+                 ctx_idx=ctx_idx, ctx_pos=ctx_pos, ctx_csr=ctx_csr, covers_all=bool(perm.shape[0] == n),
+                 # anchors already stored in coding order (layout.reorder_anchors_to_coding_order): no permutation gathers
+                 identity=bool(perm.shape[0] == n and n > 0 and bool((perm == torch.arange(n, device=dev)).all())))
     try:
         pc._level_cache = cache
     except Exception:
@@ -205,7 +207,7 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask):
         for s in sizes:
             b.append(b[-1] + s)
         cache["bounds"] = torch.tensor(b, dtype=torch.long, device=perm.device)
-    cm_p = choose_mask.index_select(0, perm)
+    cm_p = choose_mask if cache.get("identity") else choose_mask.index_select(0, perm)
     csum = torch.cat([torch.zeros(1, dtype=torch.long, device=perm.device), cm_p.cumsum(0)])
     host = torch.cat([same.reshape(1).long(), csum.index_select(0, cache["bounds"])]).tolist()   # the one sync
     if not host[0]:
@@ -217,7 +219,7 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask):
     for j, n_l in enumerate(sizes):
         locs.append(nz[cum[j]:cum[j + 1]] - off)
         off += n_l
-    return cache, locs, perm.index_select(0, nz)
+    return cache, locs, (nz if cache.get("identity") else perm.index_select(0, nz))
 
 
 def _level_plan_uncached(pc, anchor, mask_anchor_bool):
@@ -365,10 +367,14 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
 
     # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
     full = c["covers_all"]
-    feat_l = torch.split(gather_unique(feat, perm, full), sizes)
-    scal_l = torch.split(gather_unique(grid_scaling, perm, full), sizes)
-    off_l = torch.split(gather_unique(grid_offsets, perm, full), sizes)
-    hyp_l = torch.split(gather_unique(hyper_feat, perm, full), sizes)
+    if c.get("identity"):       # parameters are stored in coding order: the level slices are views, nothing moves
+        in_order = lambda t: t
+    else:
+        in_order = lambda t: gather_unique(t, perm, full)
+    feat_l = torch.split(in_order(feat), sizes)
+    scal_l = torch.split(in_order(grid_scaling), sizes)
+    off_l = torch.split(in_order(grid_offsets), sizes)
+    hyp_l = torch.split(in_order(hyper_feat), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
