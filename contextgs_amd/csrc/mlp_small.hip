@@ -143,20 +143,21 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
 }
 
+// one wave per output element: the lanes stride over the workgroup partials (a handful of loads deep instead of a
+// serial walk over ~256 partials by two half-empty workgroups)
 __global__ void __launch_bounds__(256)
     mlp_small_reduce_kernel(const float *__restrict__ partial, int blocks, int E, int DADB, float *__restrict__ dW,
                             float *__restrict__ db) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= E) return;
-    float a0 = 0.f, a1 = 0.f;
-    int b = 0;
-    for (; b + 1 < blocks; b += 2) {
-        a0 += partial[(int64_t)b * E + e];
-        a1 += partial[(int64_t)(b + 1) * E + e];
+    float a = 0.f;
+    for (int b = lane; b < blocks; b += 64) a += partial[(int64_t)b * E + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+    if (lane == 0) {
+        if (e < DADB) dW[e] += a;
+        else db[e - DADB] += a;
     }
-    if (b < blocks) a0 += partial[(int64_t)b * E + e];
-    if (e < DADB) dW[e] += a0 + a1;
-    else db[e - DADB] += a0 + a1;
 }
 
 template <int IN, int HID, int OUT>
@@ -171,7 +172,7 @@ static int launch_rc(const float *X, int64_t ldx, const float *W1, const float *
     hipLaunchKernelGGL((mlp2_bwd_rc_kernel<IN, HID, OUT, WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), 0, s, X, ldx, W1, b1,
                        W2, dY, ldy, dX, lddx, acc, dZ1, n, (float *)scratch);
     CGS_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mlp_small_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, s, (const float *)scratch, (int)grid, E,
+    hipLaunchKernelGGL(mlp_small_reduce_kernel, dim3((E + 3) / 4), dim3(256), 0, s, (const float *)scratch, (int)grid, E,
                        OUT * HID, dW2, db2);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
