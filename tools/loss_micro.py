@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from contextgs_amd.loss_utils import training_image_loss
-from oracle.loss_ref import window   # the 11 taps only (test infrastructure: this is a measurement tool)
+from math import exp
 gt = torch.rand(3, 1080, 1920, device="cuda")
 img = (gt + 0.1 * torch.randn_like(gt)).clamp(0, 1).requires_grad_()
-w1 = torch.tensor(window(), device="cuda"); w2 = (w1[:, None] * w1[None, :]).expand(3, 1, 11, 11).contiguous()
+w1 = torch.tensor([exp(-(x - 5) ** 2 / 4.5) for x in range(11)], device="cuda"); w1 = w1 / w1.sum(); w2 = (w1[:, None] * w1[None, :]).expand(3, 1, 11, 11).contiguous()
 def ref():
     conv = lambda t: F.conv2d(t, w2, padding=5, groups=3)
     mu1, mu2 = conv(img), conv(gt)
