@@ -56,22 +56,26 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
         return 0
     dev = params[0].device
     sizes = [p.numel() for p in params]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    # one bucket, as few passes over it as possible: no zero fill (only gradient-less parameters are zeroed), the
+    # average is part of the collective where the backend has it (RCCL: ReduceOp.AVG), and the reduced bucket
+    # BECOMES the gradients (views) instead of being copied back
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
     off = 0
     for p, n in zip(params, sizes):
         if p.grad is not None:
-            flat[off:off + n] = p.grad.reshape(-1)
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+        else:
+            flat[off:off + n].zero_()
         off += n
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if average:
-        flat /= w
+    if average and dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= w
     off = 0
     for p, n in zip(params, sizes):
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        p.grad = flat[off:off + n].view_as(p)
         off += n
     return int(flat.numel())
 
