@@ -527,6 +527,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     n_feat = n_scaling = n_offsets = 0
     level_bpp_sums, level_rows = [], []
     x_means = masks_chosen = None
+    fused_sums = []
     for L in levels:
         if L.get("fused"):                      # one launch: gathers of the chosen rows + the three rate terms + sums
             if x_means is None:
@@ -542,10 +543,9 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
                 m_rows, g_rows = binary_grid_masks.reshape(n, K), L["rows"]
             sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"], m_rows, g_rows, x_means,
                                    _enc.use_clamp, K)
-            s_feat, s_scaling, s_offsets = s_feat + sums[0], s_scaling + sums[1], s_offsets + sums[2]
+            fused_sums.append(sums)
             n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
             level_rows.append(n_sub)
-            level_bpp_sums.append(sums.detach().sum())
             continue
         if L["selected"]:                       # the level already holds the chosen rows only
             rows = L["rows"]
@@ -561,6 +561,27 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         n_feat, n_scaling, n_offsets = n_feat + bf.numel(), n_scaling + bs.numel(), n_offsets + bo.numel()
         level_rows.append(int(rows.shape[0]))
         level_bpp_sums.append((bf.detach().sum() + bs.detach().sum() + bo.detach().sum()))
+
+    if fused_sums and len(fused_sums) == len(levels) and not return_sum_bits:
+        # all levels came from the fused rate kernel: the scalar bookkeeping below as a handful of [3]-vector ops
+        # (the element-by-element version is ~60 one-element launches per step, forward and backward)
+        S = torch.stack(fused_sums)                               # [levels, 3] = (feat, scaling, offsets) bits
+        tot = S.sum(dim=0) * mask_anchor_rate
+        s_hyper = torch.sum(bit_hyper) * mask_anchor_rate
+        bit_per_feat_param = tot[0] / max(1, n_feat)
+        bit_per_scaling_param = tot[1] / max(1, n_scaling)
+        bit_per_offsets_param = tot[2] / max(1, n_offsets)
+        bit_per_param = (tot.sum() + s_hyper) / max(1, n_feat + n_scaling + n_offsets)
+        with torch.no_grad():
+            raw = torch.cat([(1 - mask_anchor_bool.float().mean()).reshape(1) if mask_anchor_bool is not None
+                             else torch.zeros(1, device=dev), s_hyper.detach().reshape(1), S.detach().sum(dim=1)])
+        feat_dim = pc.feat_dim + 6 + 3 * K
+        divisors = [1.0, float(max(1, bit_hyper.numel()))] + [float(max(1, r) * feat_dim) for r in level_rows]
+        each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
+        return bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, each_level_bpp
+    for sums in fused_sums:                     # mixed fused / unfused levels: element-wise bookkeeping
+        s_feat, s_scaling, s_offsets = s_feat + sums[0], s_scaling + sums[1], s_offsets + sums[2]
+        level_bpp_sums.append(sums.detach().sum())
 
     if return_sum_bits:                                                                # :1672-1685
         bit_anchor = bit_hyper.shape[0] * 3 * 16
@@ -592,13 +613,15 @@ class LevelBppReport(list):
     so here the device values stay on the device until the list is first looked at (indexing, iteration, len,
     printing) — one D2H read then, none (and no drained launch queue) for the iterations that do not log."""
 
-    def __init__(self, dev_stats, level_ratios):
+    def __init__(self, dev_stats, level_ratios, divisors=None):
         super().__init__()
-        self._dev, self._ratios = dev_stats, level_ratios
+        self._dev, self._ratios, self._div = dev_stats, level_ratios, divisors
 
     def _fill(self):
         if self._dev is not None:
             host = self._dev.cpu().tolist()
+            if self._div is not None:           # normalisations that only the report needs are done on the host
+                host = [v / d for v, d in zip(host, self._div)]
             self._dev = None
             super().extend([host[0], host[1]] + [[r, host[2 + i]] for i, r in enumerate(self._ratios)])
         return self
