@@ -270,14 +270,17 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                     dL_dalpha *= T;
                     last_alpha = ev.alpha;
                     dL_dalpha += (-T_final * inv_om) * bg_dot;
-                    const float dL_dG = r1.y * dL_dalpha;
-                    const float gG = dL_dG * ev.g;
-                    v[0] = gG * fmaf(2.f * r0.z, ev.dx, r0.w * ev.dy);   // d power2 / d gx
-                    v[1] = gG * fmaf(2.f * r1.x, ev.dy, r0.w * ev.dx);   // d power2 / d gy
-                    v[2] = gG * ev.dx * ev.dx;
-                    v[3] = gG * ev.dx * ev.dy;
-                    v[4] = gG * ev.dy * ev.dy;
-                    v[5] = ev.g * dL_dalpha;
+                    // dL/dG = opacity * dL/dalpha and d power2 / d (gx, gy) = (2A dx + B dy, 2C dy + B dx) have
+                    // per-GAUSSIAN coefficients: the pixels sum g dL/dalpha times 1, dx, dy, dx^2, dx dy, dy^2 and
+                    // the opacity factor and the 2x2 map are applied once at the flush
+                    const float gG = ev.g * dL_dalpha;
+                    const float gx = gG * ev.dx, gy = gG * ev.dy;
+                    v[0] = gx;
+                    v[1] = gy;
+                    v[2] = gx * ev.dx;
+                    v[3] = gx * ev.dy;
+                    v[4] = gy * ev.dy;
+                    v[5] = gG;
                     v[6] = w * gr;
                     v[7] = w * gg;
                     v[8] = w * gb;
@@ -326,12 +329,15 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                         a8 = sacc[tid][8];
             if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f || a6 != 0.f ||
                 a7 != 0.f || a8 != 0.f) {
-                // power = power2 / log2(e); conic = (-2A, -B, -2C) / log2(e)
-                atomicAdd(&dL_dmean2D_px[2 * (size_t)g], a0 * INV_LOG2E);
-                atomicAdd(&dL_dmean2D_px[2 * (size_t)g + 1], a1 * INV_LOG2E);
-                atomicAdd(&dL_dconic[3 * (size_t)g], -0.5f * a2);
-                atomicAdd(&dL_dconic[3 * (size_t)g + 1], -a3);
-                atomicAdd(&dL_dconic[3 * (size_t)g + 2], -0.5f * a4);
+                // power = power2 / log2(e); conic = (-2A, -B, -2C) / log2(e); (a0, a1) = sum gG (dx, dy) -> the mean
+                // gradient through the Gaussian's own (pre-scaled) conic A, B, C = rec.z, rec.w, rec'.x
+                const float4 q0 = srec[tid * 3], q1 = srec[tid * 3 + 1];
+                const float cC = q1.x, op = q1.y;                 // a0..a4 carry dL/dalpha * g: times the opacity = dL/dG
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g], op * fmaf(2.f * q0.z, a0, q0.w * a1) * INV_LOG2E);
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g + 1], op * fmaf(2.f * cC, a1, q0.w * a0) * INV_LOG2E);
+                atomicAdd(&dL_dconic[3 * (size_t)g], -0.5f * op * a2);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 1], -op * a3);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 2], -0.5f * op * a4);
                 atomicAdd(&dL_dopacity[g], a5);
                 atomicAdd(&dL_dcolors[3 * (size_t)g], a6);
                 atomicAdd(&dL_dcolors[3 * (size_t)g + 1], a7);
