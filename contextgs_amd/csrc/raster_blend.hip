@@ -215,8 +215,12 @@ __global__ void __launch_bounds__(BLEND_THREADS)
     float gr = 0.f, gg = 0.f, gb = 0.f;
     if (inside) { gr = dL_dout[pix]; gg = dL_dout[hw + pix]; gb = dL_dout[2 * hw + pix]; }
     const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
-    float ar = 0.f, ag = 0.f, ab = 0.f;         // accum_rec
-    float lr = 0.f, lg = 0.f, lb = 0.f, last_alpha = 0.f;
+    const float neg_bg_T = -T_final * bg_dot;     // background term of dL/dalpha, per pixel constant
+    // The published backward keeps accum_rec[3] (colour accumulated behind the current Gaussian) and the last
+    // colour; only their dot products with the pixel's dL/dout enter dL/dalpha, so the recurrence is carried as ONE
+    // scalar: acc_dot' = last_alpha * last_cdot + (1 - last_alpha) * acc_dot  (7 -> 3 instructions, and the three
+    // colour differences fold into one subtraction)
+    float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;
 
     const int nbatch = (int)((tlast + BLEND_THREADS - 1) / BLEND_THREADS);
     for (int bi = nbatch - 1; bi >= 0; --bi) {
@@ -262,14 +266,11 @@ __global__ void __launch_bounds__(BLEND_THREADS)
                     const float inv_om = 1.f / om;      // one IEEE division shared by the two quotients below
                     T = T * inv_om;
                     const float w = ev.alpha * T;
-                    ar = fmaf(last_alpha, lr, (1.f - last_alpha) * ar);
-                    ag = fmaf(last_alpha, lg, (1.f - last_alpha) * ag);
-                    ab = fmaf(last_alpha, lb, (1.f - last_alpha) * ab);
-                    lr = r1.z; lg = r1.w; lb = blue;
-                    float dL_dalpha = (lr - ar) * gr + (lg - ag) * gg + (lb - ab) * gb;
-                    dL_dalpha *= T;
+                    acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);
+                    last_cdot = fmaf(r1.z, gr, fmaf(r1.w, gg, blue * gb));
+                    float dL_dalpha = (last_cdot - acc_dot) * T;
                     last_alpha = ev.alpha;
-                    dL_dalpha += (-T_final * inv_om) * bg_dot;
+                    dL_dalpha = fmaf(neg_bg_T, inv_om, dL_dalpha);
                     // dL/dG = opacity * dL/dalpha and d power2 / d (gx, gy) = (2A dx + B dy, 2C dy + B dx) have
                     // per-GAUSSIAN coefficients: the pixels sum g dL/dalpha times 1, dx, dy, dx^2, dx dy, dy^2 and
                     // the opacity factor and the 2x2 map are applied once at the flush
