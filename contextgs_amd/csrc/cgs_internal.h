@@ -119,6 +119,12 @@ int cgs_launch_emit_pairs(const cgs_raster_cfg *cfg, int64_t P, CgsGeom &g, CgsB
                           hipStream_t stream);
 int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &im,
                       hipStream_t stream);
+// raster_blend_rows.hip: row-mapped variants (four 4x4 blocks per wave), selected by cgs_blend_rows_enabled()
+int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
+                              hipStream_t stream);
+int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
+                              float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                              hipStream_t stream);
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,
                          float *out_color, hipStream_t stream);
 int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,

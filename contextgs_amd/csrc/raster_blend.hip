@@ -144,10 +144,19 @@ __global__ void __launch_bounds__(BLEND_THREADS)
     if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
 }
 
+// CGS_BLEND_ROWS=0 selects the quadrant-mapped kernels of this file, anything else (default) the row-mapped ones of
+// raster_blend_rows.hip (A/B knob; both give the same image and gradients)
+static bool blend_rows_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("CGS_BLEND_ROWS"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_FWD, stream);
+    if (blend_rows_enabled()) return cgs_launch_blend_fwd_rows(cfg, g, b, im, out_color, stream);
     hipLaunchKernelGGL(blend_fwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
                        (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, out_color, im.final_T,
@@ -353,6 +362,8 @@ int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
+    if (blend_rows_enabled() && !getenv("CGS_BWD_ABLATE"))
+        return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
     static int ablate = -1;     // CGS_BWD_ABLATE=1..3: timing experiments only (wrong results)
     if (ablate < 0) { const char *e = getenv("CGS_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }
 #define BWD_LAUNCH(A)                                                                                               \

@@ -1,0 +1,327 @@
+// Tile alpha-blend forward / backward, ROW-MAPPED variant: the four 16-lane DPP rows of a wave own one 4x4 pixel
+// block each (together the wave's 8x8 quadrant) and walk their OWN Gaussian lists, so one wave iteration processes
+// up to four different Gaussians.
+//
+// Why: the blend kernels are VALU-issue bound (~95 wave instructions per (quadrant, Gaussian)
+// visit, all 64 lanes issue them however few pixels contribute).  In the dense-anchor scenes of the headline
+// benchmark a Gaussian's alpha >= 1/255 footprint overlaps on average only 2.1 of the four 4x4 blocks of a quadrant
+// it touches (tools/blend_occupancy.py: 11.9 M quadrant visits per 1080p view, 7.6 M row-mapped iterations), so
+// letting the rows advance independently removes a third of the iterations.  Everything the reduction needs already
+// happens inside a 16-lane row (two quad butterflies + two row rotations), and each row adds into the LDS
+// accumulator of ITS Gaussian (fewer same-address conflicts than four rows adding into one).
+//
+// Same arithmetic per (pixel, Gaussian) as raster_blend.hip (blend_eval is identical), same list order per pixel, so
+// results are bit-identical to the quadrant-mapped kernels for the forward and equal up to the summation order of
+// the per-Gaussian partial sums for the backward.
+#include <stdlib.h>
+#include "cgs_internal.h"
+
+#define RB_THREADS 256
+#define RB_ALPHA_MIN (1.0f / 255.0f)
+#define RB_T_EPS 0.0001f
+#define RB_INV_LOG2E 0.6931471805599453f
+#define RB_NGRAD 9
+
+namespace {
+
+struct RbEval { float dx, dy, g, alpha; bool hit; };
+
+__device__ __forceinline__ RbEval rb_eval(const float4 r0, const float4 r1, float pxf, float pyf) {
+    RbEval e;
+    e.dx = r0.x - pxf;
+    e.dy = r0.y - pyf;
+    const float p2 = fmaf(r0.z * e.dx, e.dx, fmaf(r1.x * e.dy, e.dy, (r0.w * e.dx) * e.dy));
+    e.g = __builtin_amdgcn_exp2f(p2);
+    e.alpha = fminf(0.99f, r1.y * e.g);
+    e.hit = (p2 <= 0.f) && (e.alpha >= RB_ALPHA_MIN);
+    return e;
+}
+
+// 16-bit mask of the 4x4-pixel blocks (row-major 4x4 grid of the 16x16 tile) the bounding box overlaps
+__device__ __forceinline__ uint32_t rb_block_mask(float gx, float gy, float hx, float hy, int tile_px0, int tile_py0) {
+    uint32_t xm = 0, ym = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = (float)(tile_px0 + 4 * k), y0 = (float)(tile_py0 + 4 * k);
+        xm |= ((gx - hx <= x0 + 3.f) && (gx + hx >= x0)) ? (1u << k) : 0u;
+        ym |= ((gy - hy <= y0 + 3.f) && (gy + hy >= y0)) ? (1u << k) : 0u;
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m |= ((ym >> k) & 1u) ? (xm << (4 * k)) : 0u;
+    return m;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float rb_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+struct RbLane {
+    int px, py, blk;
+};
+
+// lane -> pixel: wave = quadrant, row (lane >> 4) = 4x4 block of the quadrant, lane & 15 = pixel of the block
+__device__ __forceinline__ RbLane rb_lane(int tx, int ty, int wave, int lane) {
+    const int row = lane >> 4, i = lane & 15;
+    const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1);
+    RbLane l;
+    l.px = tx * CGS_TILE + bx * 4 + (i & 3);
+    l.py = ty * CGS_TILE + by * 4 + (i >> 2);
+    l.blk = by * 4 + bx;
+    return l;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(RB_THREADS)
+    blend_fwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                          const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                          const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ final_T,
+                          uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ tile_last) {
+    __shared__ float4 srec[RB_THREADS * 3];
+    __shared__ uint64_t bmask[16][4];     // [block][source wave]
+    __shared__ uint32_t wave_last[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RbLane L = rb_lane(tx, ty, wave, lane);
+    const bool inside = L.px < W && L.py < H;
+    const float pxf = (float)L.px, pyf = (float)L.py;
+    const uint2 range = ranges[tile];
+
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t start = range.x; start < range.y; start += RB_THREADS) {
+        if (__syncthreads_count(done) == RB_THREADS) break;
+        const uint32_t i = start + tid;
+        uint32_t m16 = 0;
+        if (i < range.y) {
+            const uint32_t g = gid_sorted[i];
+            const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+            srec[tid * 3] = r0;
+            srec[tid * 3 + 1] = r1;
+            srec[tid * 3 + 2] = r2;
+            m16 = rb_block_mask(r0.x, r0.y, r2.y, r2.z, tx * CGS_TILE, ty * CGS_TILE);
+        }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint64_t bal = __ballot((m16 >> b) & 1u);
+            if (lane == 0) bmask[b][wave] = bal;
+        }
+        __syncthreads();
+        const uint32_t base_pos = start - range.x;
+        if (!__all(done)) {
+            for (int s = 0; s < 4; ++s) {
+                uint64_t m = done ? 0ull : bmask[L.blk][s];
+                while (__ballot(m != 0ull) != 0ull) {
+                    const bool has = m != 0ull;
+                    const int j = has ? __builtin_ctzll(m) : 0;
+                    m &= m - 1ull;                                   // 0 stays 0
+                    const int e = s * 64 + j;
+                    const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
+                    const float blue = srec[e * 3 + 2].x;
+                    const RbEval ev = rb_eval(r0, r1, pxf, pyf);
+                    if (has && !done && ev.hit) {
+                        const float test_T = T * (1.f - ev.alpha);
+                        if (test_T < RB_T_EPS) {
+                            done = true;
+                        } else {
+                            const float w = ev.alpha * T;
+                            cr = fmaf(r1.z, w, cr);
+                            cg = fmaf(r1.w, w, cg);
+                            cb = fmaf(blue, w, cb);
+                            T = test_T;
+                            last = base_pos + (uint32_t)e + 1u;
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t pix = (size_t)L.py * W + L.px;
+        const size_t hw = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = fmaf(T, bg[0], cr);
+        out_color[hw + pix] = fmaf(T, bg[1], cg);
+        out_color[2 * hw + pix] = fmaf(T, bg[2], cb);
+    }
+    uint32_t wl = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+    if (lane == 0) wave_last[wave] = wl;
+    __syncthreads();
+    if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
+}
+
+__global__ void __launch_bounds__(RB_THREADS)
+    blend_bwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                          const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                          const float *__restrict__ bg, const float *__restrict__ final_T,
+                          const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ tile_last,
+                          const float *__restrict__ dL_dout, float *__restrict__ dL_dmean2D_px,
+                          float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
+                          float *__restrict__ dL_dcolors) {
+    __shared__ float4 srec[RB_THREADS * 3];
+    __shared__ uint32_t sgid[RB_THREADS];
+    __shared__ float sacc[RB_THREADS][RB_NGRAD];
+    __shared__ uint64_t bmask[16][4];
+
+    const int tile = blockIdx.x;
+    const uint32_t tlast = tile_last[tile];
+    if (tlast == 0) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RbLane L = rb_lane(tx, ty, wave, lane);
+    const bool inside = L.px < W && L.py < H;
+    const float pxf = (float)L.px, pyf = (float)L.py;
+    const uint2 range = ranges[tile];
+    const size_t pix = (size_t)L.py * W + L.px, hw = (size_t)H * W;
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t my_last = inside ? n_contrib[pix] : 0u;
+    float T = T_final;
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (inside) { gr = dL_dout[pix]; gg = dL_dout[hw + pix]; gb = dL_dout[2 * hw + pix]; }
+    const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
+    const float neg_bg_T = -T_final * bg_dot;
+    float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;       // scalar colour recurrence (see raster_blend.hip)
+
+    const int nbatch = (int)((tlast + RB_THREADS - 1) / RB_THREADS);
+    for (int bi = nbatch - 1; bi >= 0; --bi) {
+        const uint32_t base_pos = (uint32_t)bi * RB_THREADS;
+        const uint32_t pos = base_pos + tid;
+        uint32_t m16 = 0;
+        __syncthreads();   // previous batch fully flushed before LDS is reused
+        if (pos < tlast) {
+            const uint32_t g = gid_sorted[range.x + pos];
+            const float4 r0 = rec[3 * (size_t)g], r1 = rec[3 * (size_t)g + 1], r2 = rec[3 * (size_t)g + 2];
+            srec[tid * 3] = r0;
+            srec[tid * 3 + 1] = r1;
+            srec[tid * 3 + 2] = r2;
+            sgid[tid] = g;
+            m16 = rb_block_mask(r0.x, r0.y, r2.y, r2.z, tx * CGS_TILE, ty * CGS_TILE);
+        }
+#pragma unroll
+        for (int k = 0; k < RB_NGRAD; ++k) sacc[tid][k] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint64_t bal = __ballot((m16 >> b) & 1u);
+            if (lane == 0) bmask[b][wave] = bal;
+        }
+        __syncthreads();
+
+        for (int s = 3; s >= 0; --s) {
+            uint64_t m = bmask[L.blk][s];
+            while (__ballot(m != 0ull) != 0ull) {
+                const bool has = m != 0ull;
+                const int j = has ? 63 - __builtin_clzll(m) : 0;
+                m = has ? (m & ~(1ull << j)) : 0ull;
+                const int e = s * 64 + j;
+                const uint32_t position = base_pos + (uint32_t)e + 1u;   // 1-based
+                const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
+                const float blue = srec[e * 3 + 2].x;
+                const RbEval ev = rb_eval(r0, r1, pxf, pyf);
+                const bool act = has && (position <= my_last) && ev.hit;
+                if (__ballot(act) == 0ull) continue;
+                float v[RB_NGRAD];
+#pragma unroll
+                for (int k = 0; k < RB_NGRAD; ++k) v[k] = 0.f;
+                if (act) {
+                    const float om = 1.f - ev.alpha;
+                    const float inv_om = 1.f / om;
+                    T = T * inv_om;
+                    const float w = ev.alpha * T;
+                    acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);
+                    last_cdot = fmaf(r1.z, gr, fmaf(r1.w, gg, blue * gb));
+                    float dL_dalpha = (last_cdot - acc_dot) * T;
+                    last_alpha = ev.alpha;
+                    dL_dalpha = fmaf(neg_bg_T, inv_om, dL_dalpha);
+                    const float gG = ev.g * dL_dalpha;
+                    const float gx = gG * ev.dx, gy = gG * ev.dy;
+                    v[0] = gx;
+                    v[1] = gy;
+                    v[2] = gx * ev.dx;
+                    v[3] = gx * ev.dy;
+                    v[4] = gy * ev.dy;
+                    v[5] = gG;
+                    v[6] = w * gr;
+                    v[7] = w * gg;
+                    v[8] = w * gb;
+                }
+                // transposing reduction inside each 16-lane row (identical to raster_blend.hip); every row then adds
+                // into the accumulator of ITS OWN Gaussian
+                const bool b0 = lane & 1, b1 = lane & 2;
+                float a4[4], b2[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float keep = b0 ? v[2 * q + 1] : v[2 * q], send = b0 ? v[2 * q] : v[2 * q + 1];
+                    a4[q] = keep + rb_dpp<0xB1>(send);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float keep = b1 ? a4[2 * q + 1] : a4[2 * q], send = b1 ? a4[2 * q] : a4[2 * q + 1];
+                    b2[q] = keep + rb_dpp<0x4E>(send);
+                }
+                float c8 = v[8];
+                c8 += rb_dpp<0xB1>(c8);
+                c8 += rb_dpp<0x4E>(c8);
+                b2[0] += rb_dpp<0x124>(b2[0]); b2[0] += rb_dpp<0x128>(b2[0]);
+                b2[1] += rb_dpp<0x124>(b2[1]); b2[1] += rb_dpp<0x128>(b2[1]);
+                c8 += rb_dpp<0x124>(c8); c8 += rb_dpp<0x128>(c8);
+                const int sub = lane & 15;
+                if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8));
+            }
+        }
+        __syncthreads();
+        if (pos < tlast) {
+            const uint32_t g = sgid[tid];
+            const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
+                        a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],
+                        a8 = sacc[tid][8];
+            if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f || a6 != 0.f ||
+                a7 != 0.f || a8 != 0.f) {
+                const float4 q0 = srec[tid * 3], q1 = srec[tid * 3 + 1];
+                const float cC = q1.x, op = q1.y;
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g], op * fmaf(2.f * q0.z, a0, q0.w * a1) * RB_INV_LOG2E);
+                atomicAdd(&dL_dmean2D_px[2 * (size_t)g + 1], op * fmaf(2.f * cC, a1, q0.w * a0) * RB_INV_LOG2E);
+                atomicAdd(&dL_dconic[3 * (size_t)g], -0.5f * op * a2);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 1], -op * a3);
+                atomicAdd(&dL_dconic[3 * (size_t)g + 2], -0.5f * op * a4);
+                atomicAdd(&dL_dopacity[g], a5);
+                atomicAdd(&dL_dcolors[3 * (size_t)g], a6);
+                atomicAdd(&dL_dcolors[3 * (size_t)g + 1], a7);
+                atomicAdd(&dL_dcolors[3 * (size_t)g + 2], a8);
+            }
+        }
+    }
+}
+
+int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
+                              hipStream_t stream) {
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_fwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
+                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
+                       (const float4 *)g.rec, cfg->bg, out_color, im.final_T, im.n_contrib, im.tile_last);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
+int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
+                              float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
+                              hipStream_t stream) {
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
+                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
+                       (const float4 *)g.rec, cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib,
+                       (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}

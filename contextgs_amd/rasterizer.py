@@ -101,7 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                    "cgs_raster_render")
         ctx.cfg = cfg
         ctx.num_rendered = num_rendered
-        last_call.update(P=P, num_rendered=num_rendered, img_ws=img)
+        last_call.update(P=P, num_rendered=num_rendered, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
         ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii)
         return color, radii

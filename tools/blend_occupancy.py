@@ -1,0 +1,26 @@
+"""Wave-iteration count of the blend kernels: current mapping (8x8 quadrant per wave, one Gaussian per iteration)
+vs four 4x4 blocks per wave walking their own lists (csrc/raster_debug.hip)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from contextgs_amd import _lib
+from contextgs_amd.rasterizer import last_call
+from contextgs_amd.renderer import prefilter_voxel, render
+from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+pc = make_scene(N, seed=0); pc.train()
+pipe = SynthPipe(); bg = torch.zeros(3, device="cuda")
+cam = orbit_cameras(8, 1920, 1080)[0].to_torch("cuda")
+vis = prefilter_voxel(cam, pc, pipe, bg)
+pkg = render(cam, pc, pipe, bg, visible_mask=vis, step=1000)
+L = C.CDLL(_lib.LIB_PATH)
+out = torch.zeros(3, dtype=torch.int64, device="cuda")
+f = L.cgs_debug_blend_occupancy
+f.restype = C.c_int
+f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+lc = last_call
+rc = f(C.addressof(lc["cfg"].c), lc["P"], lc["num_rendered"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
+       lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out.data_ptr(), None)
+torch.cuda.synchronize()
+q, b, v = out.tolist()
+print(f"rc={rc} P={lc['P']} R={lc['num_rendered']}: quadrant iterations {q}, block-mapped iterations {b} ({q / max(1, b):.2f}x fewer), 4x4 block visits {v} ({v / max(1, q):.2f} per quadrant visit)")
