@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     __shared__ float4 srec[RB_THREADS * 3];
     __shared__ uint32_t sgid[RB_THREADS];
     __shared__ float sacc[RB_THREADS][RB_NGRAD];
-    __shared__ uint64_t bmask[16][4];
+    __shared__ uint32_t bmask[16][8];     // [block][32-entry segment]: 32-bit masks keep the per-lane bit walk cheap
 
     const int tile = blockIdx.x;
     const uint32_t tlast = tile_last[tile];
@@ -214,17 +214,17 @@ __global__ void __launch_bounds__(RB_THREADS)
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const uint64_t bal = __ballot((m16 >> b) & 1u);
-            if (lane == 0) bmask[b][wave] = bal;
+            if (lane == 0) { bmask[b][2 * wave] = (uint32_t)bal; bmask[b][2 * wave + 1] = (uint32_t)(bal >> 32); }
         }
         __syncthreads();
 
-        for (int s = 3; s >= 0; --s) {
-            uint64_t m = bmask[L.blk][s];
-            while (__ballot(m != 0ull) != 0ull) {
-                const bool has = m != 0ull;
-                const int j = has ? 63 - __builtin_clzll(m) : 0;
-                m = has ? (m & ~(1ull << j)) : 0ull;
-                const int e = s * 64 + j;
+        for (int s = 7; s >= 0; --s) {
+            uint32_t m = bmask[L.blk][s];
+            while (__ballot(m != 0u) != 0ull) {
+                const bool has = m != 0u;
+                const int j = 31 - __builtin_clz(m | 1u);            // m == 0: j = 0, has = false
+                m &= ~(1u << j);
+                const int e = s * 32 + j;
                 const uint32_t position = base_pos + (uint32_t)e + 1u;   // 1-based
                 const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
                 const float blue = srec[e * 3 + 2].x;
