@@ -15,7 +15,7 @@ for f in glob.glob("/tmp/pmc_sq/**/*counter_collection.csv", recursive=True):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_WAVE_CYCLES":
             cnt[k] += 1
-want = ["blend_bwd_kernel", "blend_fwd_kernel", "mlp3_bwd_kernel", "mlp3_fwd_kernel", "wgrad_multi_kernel", "mlp2_bwd_kernel",
+want = ["blend_bwd_rows_kernel", "blend_fwd_rows_kernel", "blend_bwd_kernel", "blend_fwd_kernel", "mlp3_bwd_kernel", "mlp3_fwd_kernel", "wgrad_multi_kernel", "mlp2_bwd_kernel",
         "expand_bwd_kernel", "preprocess_kernel", "radix_scatter_kernel", "noise_quant_fwd_kernel", "rowcat_fwd_kernel"]
 with open("gpurun_out/pmc_sq_summary.txt", "w") as f:
     f.write("# rocprofv3 --pmc SQ_* (one pass), sums over the dispatches of a kernel; fractions of SQ_WAVE_CYCLES\n")
