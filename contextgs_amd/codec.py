@@ -81,35 +81,64 @@ def _bernoulli_row(p: float) -> np.ndarray:
     return out[0]
 
 
-def encoder(x, p, file_name):
-    """x in {-1,+1}, p = P(+1) per element (the reference passes one global value).  Returns bit length."""
+_POOL = None
+
+
+def host_pool():
+    """Host threads for the format's serial streams (mask stream, hyper rANS strings): the coders are C calls
+    through ctypes, which release the GIL, so independent streams run concurrently with each other and with the
+    device launches of the level loop."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(32, os.cpu_count() or 2)), thread_name_prefix="cgs-codec")
+    return _POOL
+
+
+def bernoulli_encode_host(sym: np.ndarray, p0: float) -> bytes:
+    """sym int16 [n] in {0,1}, P(1) = p0 -> the single arithmetic-coded stream of utils/encodings.py:147-163."""
     L = _lib.lib()
-    assert file_name[-2:] == ".b"
-    p = p.detach().reshape(-1)
-    p0 = float(p[0].item()) if p.numel() else 0.5
     row = _bernoulli_row(np.float32(p0))
-    sym = torch.floor((x.detach().reshape(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+    sym = np.ascontiguousarray(sym, dtype=np.int16)
     cap = L.cgs_ac_max_bytes(sym.shape[0])
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_size_t(0)
     _lib.check(L.cgs_ac_encode_const_host(_np_ptr(row), 3, _np_ptr(sym), sym.shape[0], _np_ptr(out), cap, C.byref(n)),
                "cgs_ac_encode_const_host")
+    return out[: n.value].tobytes()
+
+
+def bernoulli_decode_host(data, n: int, p0: float) -> np.ndarray:
+    """inverse of bernoulli_encode_host -> int16 [n] in {0,1} (utils/encodings.py:166-180)."""
+    L = _lib.lib()
+    row = _bernoulli_row(np.float32(p0))
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    out = np.empty(int(n), dtype=np.int16)
+    _lib.check(L.cgs_ac_decode_const_host(_np_ptr(row), 3, out.shape[0], _np_ptr(buf) if buf.size else None, buf.size,
+                                          _np_ptr(out)), "cgs_ac_decode_const_host")
+    return out
+
+
+def encoder(x, p, file_name):
+    """x in {-1,+1}, p = P(+1) per element (the reference passes one global value).  Returns bit length."""
+    assert file_name[-2:] == ".b"
+    p = p.detach().reshape(-1)
+    p0 = float(p[0].item()) if p.numel() else 0.5
+    sym = torch.floor((x.detach().reshape(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+    data = bernoulli_encode_host(sym, p0)
     with open(file_name, "wb") as f:
-        f.write(out[: n.value].tobytes())
-    return n.value * 8
+        f.write(data)
+    return len(data) * 8
 
 
 def decoder(p, file_name):
-    L = _lib.lib()
     assert file_name[-2:] == ".b"
     dvc = p.device
     pf = p.detach().reshape(-1)
-    row = _bernoulli_row(np.float32(float(pf[0].item()) if pf.numel() else 0.5))
     with open(file_name, "rb") as f:
-        buf = np.frombuffer(f.read(), dtype=np.uint8)
-    out = np.empty(pf.numel(), dtype=np.int16)
-    _lib.check(L.cgs_ac_decode_const_host(_np_ptr(row), 3, out.shape[0], _np_ptr(buf) if buf.size else None, buf.size,
-                                          _np_ptr(out)), "cgs_ac_decode_const_host")
+        data = f.read()
+    out = bernoulli_decode_host(data, pf.numel(), float(pf[0].item()) if pf.numel() else 0.5)
     return (torch.from_numpy(out).to(torch.float32) * 2 - 1).to(dvc)
 
 
@@ -118,9 +147,11 @@ def _f(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
-def gaussian_encode_streams(x, mean, scale, Q, stream_off, q_div=1):
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
-    (device or host).  Returns (list of S byte strings, min int32[S] host, max int32[S] host)."""
+    (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
+    blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
+    b"".join(chunk strings) file), lens int64[S], min/max int32[S] (host)."""
     L = _lib.lib()
     _lib.require_device(x, mean, scale, Q)
     x, mean, scale, Q = _f(x).reshape(-1), _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
@@ -128,38 +159,84 @@ def gaussian_encode_streams(x, mean, scale, Q, stream_off, q_div=1):
     off = torch.as_tensor(stream_off, dtype=torch.int64)
     S = int(off.numel()) - 1
     if S <= 0:
-        return [], np.zeros(0, np.int32), np.zeros(0, np.int32)
+        return np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32)
     off_h = off.cpu()
     off_d = off_h.to(dev)
     stream = _lib.current_stream()
-    mn = torch.empty(S, dtype=torch.int32, device=dev)
-    mx = torch.empty(S, dtype=torch.int32, device=dev)
+    mnmx = torch.empty(2, S, dtype=torch.int32, device=dev)
+    mn, mx = mnmx[0], mnmx[1]
     _lib.check(L.cgs_gaussian_stream_minmax(_lib.ptr(x), _lib.ptr(Q), q_div, _lib.ptr(off_d), S, _lib.ptr(mn),
                                             _lib.ptr(mx), stream), "cgs_gaussian_stream_minmax")
     lens_sym = (off_h[1:] - off_h[:-1])
     caps = (lens_sym * 2 + 16 + 7) // 8 * 8
     out_off_h = torch.zeros(S + 1, dtype=torch.int64)
     out_off_h[1:] = torch.cumsum(caps, 0)
-    out = torch.empty(int(out_off_h[-1]), dtype=torch.uint8, device=dev)
+    out = torch.empty(int(out_off_h[-1]) + 16, dtype=torch.uint8, device=dev)
     out_off = out_off_h.to(dev)
-    out_len = torch.zeros(S, dtype=torch.int32, device=dev)
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    # [status, len_0 .. len_{S-1}] in one buffer: ONE device->host read decides everything below
+    st_len = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    status, out_len = st_len[:1], st_len[1:]
     _lib.check(L.cgs_gaussian_ac_encode(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div,
                                         _lib.ptr(off_d), S, _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(out), _lib.ptr(out_off),
                                         _lib.ptr(out_len), _lib.ptr(status), stream), "cgs_gaussian_ac_encode")
-    st = int(status.item())
+    dst_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(out_len, 0, out=dst_off[1:])
+    st_len_h = st_len.cpu().numpy()
+    st = int(st_len_h[0])
     if st != 0:
         raise RuntimeError("gaussian codec: " + ("symbol outside [min,max] / grid wider than 2^16" if st == 1
                                                  else "stream overflowed its buffer"))
-    lens = out_len.cpu().numpy()
-    buf = out.cpu().numpy()
-    starts = out_off_h.numpy()
-    streams = [buf[starts[s]: starts[s] + lens[s]].tobytes() for s in range(S)]
-    return streams, mn.cpu().numpy(), mx.cpu().numpy()
+    lens = st_len_h[1:].astype(np.int64)
+    packed = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device=dev)
+    _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
+                                     _lib.ptr(packed), stream), "cgs_streams_compact")
+    blob = packed.cpu().numpy()[: int(lens.sum())]
+    mnmx_h = mnmx.cpu().numpy()
+    return blob, lens, mnmx_h[0], mnmx_h[1]
 
 
-def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q_div=1):
-    """Inverse of gaussian_encode_streams -> flat float32 [n] device tensor of dequantised values."""
+def gaussian_encode_streams(x, mean, scale, Q, stream_off, q_div=1):
+    """gaussian_encode_packed with the streams as S separate byte strings:
+    (list of S byte strings, min int32[S] host, max int32[S] host)."""
+    blob, lens, mn, mx = gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div)
+    ends = np.cumsum(lens)
+    return [blob[e - n: e].tobytes() for e, n in zip(ends, lens)], mn, mx
+
+
+def _expand_q(Q, q_div):
+    Q = _f(Q).reshape(-1)
+    return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
+
+
+def gaussian_encode_groups(groups):
+    """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
+    All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
+    lasts as long as its longest stream however many streams it holds."""
+    groups = [g for g in groups]
+    if not groups:
+        return []
+    xs, ms, ss, qs, edges, counts, base = [], [], [], [], [torch.zeros(1, dtype=torch.int64)], [], 0
+    for (x, mean, scale, Q, off, q_div) in groups:
+        off = torch.as_tensor(off, dtype=torch.int64).cpu()
+        xs.append(_f(x).reshape(-1)); ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1))
+        qs.append(_expand_q(Q, q_div))
+        assert xs[-1].numel() == qs[-1].numel() == int(off[-1]) if off.numel() else True
+        edges.append(off[1:] + base)
+        counts.append(max(int(off.numel()) - 1, 0))
+        base += int(xs[-1].numel())
+    blob, lens, mn, mx = gaussian_encode_packed(torch.cat(xs), torch.cat(ms), torch.cat(ss), torch.cat(qs),
+                                                torch.cat(edges), 1)
+    out, s0, b0 = [], 0, 0
+    for c in counts:
+        nb = int(lens[s0:s0 + c].sum())
+        out.append((blob[b0:b0 + nb], lens[s0:s0 + c], mn[s0:s0 + c], mx[s0:s0 + c]))
+        s0 += c; b0 += nb
+    return out
+
+
+def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div=1):
+    """Inverse of gaussian_encode_packed -> flat float32 [n] device tensor of dequantised values.
+    blob: bytes / uint8 ndarray with the S streams back to back; lens: their byte lengths."""
     L = _lib.lib()
     _lib.require_device(mean, scale, Q)
     mean, scale, Q = _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
@@ -169,11 +246,15 @@ def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q
     x_out = torch.empty(mean.numel(), dtype=torch.float32, device=dev)
     if S <= 0:
         return x_out
-    assert len(streams) == S
+    lens = np.asarray(lens, dtype=np.int64)
+    assert lens.shape[0] == S
     in_off_h = np.zeros(S + 1, dtype=np.int64)
-    in_off_h[1:] = np.cumsum([len(b) for b in streams])
-    blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
-    in_d = torch.from_numpy(blob.copy() if blob.size else np.zeros(1, np.uint8)).to(dev)
+    np.cumsum(lens, out=in_off_h[1:])
+    buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+    assert buf.size == int(in_off_h[-1]), "stream lengths do not add up to the blob"
+    in_d = torch.empty(buf.size + 16, dtype=torch.uint8, device=dev)
+    if buf.size:
+        in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf)))
     in_off = torch.from_numpy(in_off_h).to(dev)
     mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
     mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
@@ -182,6 +263,32 @@ def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q
                                         _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
                                         _lib.current_stream()), "cgs_gaussian_ac_decode")
     return x_out
+
+
+def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q_div=1):
+    """gaussian_decode_packed on S separate byte strings."""
+    return gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, b"".join(streams),
+                                  [len(b) for b in streams], q_div)
+
+
+def gaussian_decode_groups(groups):
+    """groups = [(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div), ...] -> [flat float32 values, ...];
+    one coder launch for all streams of all groups."""
+    if not groups:
+        return []
+    ms, ss, qs, edges, mns, mxs, blobs, lns, sizes, base = [], [], [], [torch.zeros(1, dtype=torch.int64)], [], [], [], [], [], 0
+    for (mean, scale, Q, off, mn, mx, blob, lens, q_div) in groups:
+        off = torch.as_tensor(off, dtype=torch.int64).cpu()
+        ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1)); qs.append(_expand_q(Q, q_div))
+        edges.append(off[1:] + base)
+        mns.append(np.asarray(mn, dtype=np.int32).reshape(-1)); mxs.append(np.asarray(mx, dtype=np.int32).reshape(-1))
+        blobs.append(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        lns.append(np.asarray(lens, dtype=np.int64).reshape(-1))
+        sizes.append(int(ms[-1].numel()))
+        base += sizes[-1]
+    flat = gaussian_decode_packed(torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges), np.concatenate(mns),
+                                  np.concatenate(mxs), np.concatenate(blobs), np.concatenate(lns), 1)
+    return list(torch.split(flat, sizes))
 
 
 def gaussian_cdf_table(mean, scale, Q, min_v, max_v, q_div=1):

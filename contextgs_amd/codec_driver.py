@@ -5,10 +5,17 @@
 Same container as the reference — anchor.npy (uint16 [N_valid,3]), hyper.b,
 feat{l}.b / scaling{l}.b / offsets{l}.b (1000-anchor chunk streams concatenated,
 byte lengths in meta), masks.b, meta.b (a torch.save'd 14-item list, :1277), mlp.pt —
-and the same level / chunk / mask order.  What differs is how a level is coded: instead
+and the same level / chunk / mask order.  What differs is how it is scheduled: instead
 of a Python loop of ~3 N/1000 serial torchac calls, each shipping a [50 000, L] float
-table over PCIe (:1192-1232), all chunk streams of a level+attribute are coded by ONE
-device launch, one lane per stream (codec.gaussian_encode_streams).
+table over PCIe (:1192-1232), chunk streams are coded concurrently by device launches,
+one wave per stream (codec.gaussian_encode_groups / gaussian_decode_groups):
+  * encoding never reads coded bytes back, so the level loop only predicts and
+    quantises, and ALL streams (3 levels x feat/scaling/offsets) go through one launch
+    whose duration is that of its longest stream;
+  * decoding needs level l's feat+scaling before level l+1's context, so those are one
+    launch per level; offsets feed no context and are decoded for all levels at the end;
+  * the format's serial host streams (the mask stream, the 10 000-anchor hyper rANS
+    strings) run on host threads next to the device work (codec.host_pool).
 
 Deliberate deviation: the reference's decoder raises IndexError when fewer
 than 10 000 anchors are valid (:1322-1331); this one decodes any size.
@@ -83,10 +90,10 @@ def _predict(pc, level, feat_in):
 def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     torch.cuda.synchronize(); t1 = time.time()
     print("Start encoding ...")
-    t_codec = 0.0
     os.makedirs(pre_path_name, exist_ok=True)
     pc.latent_codec.update(force=True)
     K, D = pc.n_offsets, pc.feat_dim
+    path = lambda name: os.path.join(pre_path_name, name)
 
     mask_anchor = pc.get_mask_anchor
     _anchor, quantized_anchor = Quantize_anchor.apply(pc._anchor[mask_anchor], pc.x_bound_min, pc.x_bound_max)
@@ -95,6 +102,15 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     _scaling = pc.get_scaling[mask_anchor]
     _mask = pc.get_mask[mask_anchor]
     _hyper_latent = pc._hyper_latent[mask_anchor]
+
+    # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream: start it on a host thread now
+    prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
+    mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+    mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
+    # hyper: 10 000-anchor rANS chunks (:1082-1098), also on host threads
+    hyper_bytes = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10)
+    bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
+
     # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
     hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
     if pc.level_scale is None:
@@ -104,24 +120,12 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
-
-    # hyper: 10 000-anchor rANS chunks (:1082-1098)
-    N_anchor = _anchor.shape[0]
-    hyper_bytes, bit_hyper_list = [], []
-    for s0 in range(0, N_anchor, MAX_BATCH * 10):
-        b = pc.latent_codec.compress(_hyper_latent[s0:s0 + MAX_BATCH * 10].t().unsqueeze(0))[0]
-        hyper_bytes.append(b)
-        bit_hyper_list.append(len(b) * 8)
-    np.save(os.path.join(pre_path_name, "anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))   # :1100-1101
-    with open(os.path.join(pre_path_name, "hyper.b"), "wb") as f:
+    np.save(path("anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))          # :1100-1101
+    with open(path("hyper.b"), "wb") as f:
         f.write(b"".join(hyper_bytes))
 
-    bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
-    min_d = {"feat": {}, "scaling": {}, "offsets": {}}
-    max_d = {"feat": {}, "scaling": {}, "offsets": {}}
-    N_levels_list = []
+    N_levels_list, groups, tags = [], [], []
     content_pre_gathered = None
-
     for (level, to_code, orig, hybrid_anchor) in plan:                                   # :1112
         n_l = int(orig.shape[0])
         N_levels_list.append(n_l)
@@ -143,20 +147,11 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         mflat = m30.reshape(-1)
         Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
 
-        torch.cuda.synchronize(); t0 = time.time()
-        s_feat, mn_f, mx_f = codec.gaussian_encode_streams(feat_q, mean_feat, scale_feat, Qf, rows * D, q_div=D)
-        s_scal, mn_s, mx_s = codec.gaussian_encode_streams(scal_q, mean_scaling, scale_scaling, Qs, rows * 6, q_div=6)
-        s_off, mn_o, mx_o = codec.gaussian_encode_streams(off_q.reshape(-1)[mflat], mean_offsets.reshape(-1)[mflat],
-                                                          scale_offsets.reshape(-1)[mflat], Qo30[mflat], off_edges)
-        torch.cuda.synchronize(); t_codec += time.time() - t0
-
-        for name, streams, mn, mx in (("feat", s_feat, mn_f, mx_f), ("scaling", s_scal, mn_s, mx_s),
-                                      ("offsets", s_off, mn_o, mx_o)):
-            with open(os.path.join(pre_path_name, f"{name}{level}.b"), "wb") as f:      # :1235-1238
-                f.write(b"".join(streams))
-            bit_d[name][level] = [len(b) * 8 for b in streams]
-            min_d[name][level] = [int(v) for v in mn]
-            max_d[name][level] = [int(v) for v in mx]
+        groups += [(feat_q, mean_feat, scale_feat, Qf, rows * D, D),
+                   (scal_q, mean_scaling, scale_scaling, Qs, rows * 6, 6),
+                   (off_q.reshape(-1)[mflat], mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat],
+                    Qo30[mflat], off_edges, 1)]
+        tags += [("feat", level), ("scaling", level), ("offsets", level)]
 
         feat_after_Q[orig] = feat_q                                                      # :1240-1242
         grid_scaling_after_Q[orig] = scal_q
@@ -165,25 +160,39 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
             content_pre_gathered = extract_context_feat(_anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
                                                         inverse_indices_list, mapping_list, level)
 
+    torch.cuda.synchronize(); t0 = time.time()
+    coded = codec.gaussian_encode_groups(groups)
+    torch.cuda.synchronize(); t_codec = time.time() - t0
+
+    bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    min_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    max_d = {"feat": {}, "scaling": {}, "offsets": {}}
+    for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
+        blob.tofile(path(f"{name}{level}.b"))                                            # :1235-1238
+        bit_d[name][level] = (lens * 8).tolist()
+        min_d[name][level] = mn.astype(np.int64).tolist()
+        max_d[name][level] = mx.astype(np.int64).tolist()
+
     bit_anchor = _anchor.numel() * 16
     bit_hyper = sum(bit_hyper_list)
     bit_feat = sum(sum(v) for v in bit_d["feat"].values())
     bit_scaling = sum(sum(v) for v in bit_d["scaling"].values())
     bit_offsets = sum(sum(v) for v in bit_d["offsets"].values())
 
-    prob_masks = (_mask.sum() / _mask.numel()).item()                                     # :1265-1269
-    p = torch.full_like(_mask, prob_masks, dtype=torch.float32)
-    bit_masks = encoder((_mask * 2 - 1).view(-1), p.view(-1), file_name=os.path.join(pre_path_name, "masks.b"))
+    mask_bytes = mask_job.result()
+    with open(path("masks.b"), "wb") as f:
+        f.write(mask_bytes)
+    bit_masks = len(mask_bytes) * 8
 
     torch.cuda.synchronize(); t2 = time.time()
     print("encoding time:", t2 - t1)
     print("codec time:", t_codec)
 
-    meta_path = os.path.join(pre_path_name, "meta.b")                                     # :1276-1277
+    meta_path = path("meta.b")                                                            # :1276-1277
     torch.save([pc._anchor.shape[0], MAX_BATCH, min_d["feat"], max_d["feat"], min_d["scaling"], max_d["scaling"],
                 min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
                 bit_d["offsets"], N_levels_list], meta_path)
-    save_mlp_checkpoints(pc, os.path.join(pre_path_name, "mlp.pt"))
+    save_mlp_checkpoints(pc, path("mlp.pt"))
     bit_meta = os.path.getsize(meta_path) * 8
     mlp = pc.get_mlp_size()[0]
     r = lambda v: round(v / bit2MB_scale, 4)
@@ -197,27 +206,31 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
 def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     torch.cuda.synchronize(); t1 = time.time()
     print("Start decoding ...")
+    path = lambda name: os.path.join(pre_path_name, name)
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
-     bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(
-        os.path.join(pre_path_name, "meta.b"), weights_only=False)
-    load_mlp_checkpoints(pc, os.path.join(pre_path_name, "mlp.pt"))
-    pc.latent_codec.update(force=True)
-    dev = pc.x_bound_min.device
+     bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(path("meta.b"),
+                                                                                          weights_only=False)
     K, D, H = pc.n_offsets, pc.feat_dim, pc.feat_dim // pc.hyper_divisor
     N_levels_list = list(reversed(N_levels_list))
     N_valid = sum(N_levels_list)
+    # the mask stream (:1348-1353) is serial and only the offsets need it: decode it on a host thread meanwhile
+    mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
+                                        N_valid * K, float(prob_masks))
+    load_mlp_checkpoints(pc, path("mlp.pt"))
+    pc.latent_codec.update(force=True)
+    dev = pc.x_bound_min.device
 
-    with open(os.path.join(pre_path_name, "hyper.b"), "rb") as f:
+    with open(path("hyper.b"), "rb") as f:
         hyper_stream = f.read()
-    pos, parts = 0, []
+    pos, strings, sizes = 0, [], []
     for s, s0 in enumerate(range(0, N_valid, max_batch * 10)):                           # :1326-1336 (any N_valid, Q2)
-        n = min(max_batch * 10, N_valid - s0)
         nb = bit_hyper_list[s] // 8
-        parts.append(pc.latent_codec.decompress([hyper_stream[pos:pos + nb]], [n])[0].t())
+        strings.append(hyper_stream[pos:pos + nb])
+        sizes.append(min(max_batch * 10, N_valid - s0))
         pos += nb
-    hyper_decoded = torch.cat(parts, dim=0) if parts else torch.zeros(0, H, device=dev)
+    hyper_decoded = pc.latent_codec.decompress_chunks(strings, sizes).t().contiguous()   # [N_valid, H]
 
-    q = torch.from_numpy(np.load(os.path.join(pre_path_name, "anchor.npy")).astype(np.int32)).to(dev)   # :1340-1342
+    q = torch.from_numpy(np.load(path("anchor.npy")).astype(np.int32)).to(dev)           # :1340-1342
     interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
     anchor_decoded = q * interval + pc.x_bound_min
 
@@ -225,31 +238,22 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
     plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
 
-    p = torch.full((N_valid, K, 1), float(prob_masks), dtype=torch.float32, device=dev)   # :1348-1353
-    masks_decoded = (decoder(p.view(-1), os.path.join(pre_path_name, "masks.b")) + 1) / 2
-    masks_decoded = masks_decoded.view(-1, K, 1)
-
     feat_after_Q = torch.zeros(N_valid, D, device=dev)
     grid_scaling_after_Q = torch.zeros(N_valid, 6, device=dev)
     grid_offset_after_Q = torch.zeros(N_valid, K, 3, device=dev)
     already_coded = torch.zeros(N_valid, dtype=torch.bool, device=dev)
     content_pre_gathered = None
 
-    def split_stream(blob, bit_list):
-        out, pos_ = [], 0
-        for b in bit_list:
-            out.append(blob[pos_:pos_ + b // 8])
-            pos_ += b // 8
-        assert pos_ == len(blob)                                                          # :1479-1481
-        return out
+    def chunk_lens(name, level, bit_list):
+        blob = np.fromfile(path(f"{name}{level}.b"), dtype=np.uint8)
+        lens = np.asarray(bit_list, dtype=np.int64) // 8
+        assert int(lens.sum()) == blob.size                                              # :1479-1481
+        return blob, lens
 
+    pending_offsets = []
     for (level, to_code, orig, hybrid_anchor) in plan:
         n_l = int(orig.shape[0])
         assert n_l == N_levels_list[level]
-        blobs = {}
-        for name in ("feat", "scaling", "offsets"):
-            with open(os.path.join(pre_path_name, f"{name}{level}.b"), "rb") as f:
-                blobs[name] = f.read()
         if content_pre_gathered is None:
             feat_in = torch.cat([anchor_decoded[orig], hyper_decoded[orig].float()], dim=1)
         else:
@@ -257,30 +261,36 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
-        feat_dec = codec.gaussian_decode_streams(mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
-                                                 split_stream(blobs["feat"], bit_feat_d[level]), q_div=D).view(n_l, D)
-        scal_dec = codec.gaussian_decode_streams(mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level],
-                                                 max_scaling_d[level], split_stream(blobs["scaling"], bit_scaling_d[level]),
-                                                 q_div=6).view(n_l, 6)
+        feat_dec, scal_dec = codec.gaussian_decode_groups([
+            (mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
+             *chunk_lens("feat", level, bit_feat_d[level]), D),
+            (mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level], max_scaling_d[level],
+             *chunk_lens("scaling", level, bit_scaling_d[level]), 6)])
+        pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
+
+        feat_after_Q[orig] = feat_dec.view(n_l, D)
+        grid_scaling_after_Q[orig] = scal_dec.view(n_l, 6)
+        if level != 0:
+            already_coded[orig] = True
+            content_pre_gathered = extract_context_feat(anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
+                                                        inverse_indices_list, mapping_list, level)
+
+    masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
+    groups, fills = [], []
+    for (level, orig, n_l, rows, mean_offsets, scale_offsets, Qo) in pending_offsets:
         m30 = masks_decoded[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)
         cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=dev)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         off_edges = cnt[rows.to(dev)].cpu()
         mflat = m30.reshape(-1)
         Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
-        off_vals = codec.gaussian_decode_streams(mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat],
-                                                 Qo30[mflat], off_edges, min_offsets_d[level], max_offsets_d[level],
-                                                 split_stream(blobs["offsets"], bit_offsets_d[level]))
+        groups.append((mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat], Qo30[mflat], off_edges,
+                       min_offsets_d[level], max_offsets_d[level], *chunk_lens("offsets", level, bit_offsets_d[level]), 1))
+        fills.append((orig, n_l, mflat))
+    for (orig, n_l, mflat), off_vals in zip(fills, codec.gaussian_decode_groups(groups)):
         off_dec = torch.zeros(n_l * 3 * K, device=dev)
         off_dec[mflat] = off_vals
-
-        feat_after_Q[orig] = feat_dec
-        grid_scaling_after_Q[orig] = scal_dec
         grid_offset_after_Q[orig] = off_dec.view(n_l, K, 3)
-        if level != 0:
-            already_coded[orig] = True
-            content_pre_gathered = extract_context_feat(anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
-                                                        inverse_indices_list, mapping_list, level)
     torch.cuda.synchronize(); t2 = time.time()
     print("decoding time:", t2 - t1)
 

@@ -18,6 +18,7 @@
 // 3. A range-ANS coder for the hyper-prior symbols (EntropyBottleneck.compress /
 //    decompress; compressai is NOT in the mount): per-channel frequency tables,
 //    escape symbol + Elias-gamma style bypass for out-of-support values.
+#include <cstring>
 #include <vector>
 #include "cgs_internal.h"
 
@@ -63,6 +64,7 @@ struct BitWriter {
         }
     }
     __host__ __device__ void flush() { if (nacc > 0) put_bits(0u, 8 - nacc); }
+    __host__ __device__ size_t finish(uint8_t *base) { flush(); return (size_t)(p - base); }
 };
 
 struct BitReader {
@@ -120,24 +122,69 @@ struct WaveBitReader {
 struct AcRenorm { int k, u; };
 
 __host__ __device__ inline AcRenorm ac_renorm(uint32_t &low, uint32_t &high) {
+    // Branch-free (the coders run this once per symbol on a lone wave, where a taken branch costs more than the
+    // arithmetic it skips).  k in [0, 32]: 64-bit shifts make k = 32 (low == high) come out as low = 0,
+    // high = 2^32 - 1.  After the k step low's top bit is 0 and high's is 1, so the u step's mask / or are
+    // no-ops when u = 0.
     AcRenorm r;
     r.k = clz32(low ^ high);
-    if (r.k >= 32) { low = 0; high = 0xFFFFFFFFu; r.u = 0; return r; }
-    if (r.k > 0) { low <<= r.k; high = (high << r.k) | ((1u << r.k) - 1u); }
+    low = (uint32_t)((uint64_t)low << r.k);
+    high = (uint32_t)(((uint64_t)high << r.k) | ((1ull << r.k) - 1ull));
     const uint32_t hs = high << 1;
     const int ones = clz32(~(low << 1)), zeros = hs ? clz32(hs) : 31;
     r.u = ones < zeros ? ones : zeros;
-    if (r.u > 0) {
-        low = (low << r.u) & 0x7FFFFFFFu;
-        high = (high << r.u) | 0x80000000u | ((1u << r.u) - 1u);
-    }
+    low = (low << r.u) & 0x7FFFFFFFu;
+    high = (high << r.u) | 0x80000000u | ((1u << r.u) - 1u);
     return r;
 }
 
-struct AcEncoder {
+// Device encoder output: bits collect in a 64-bit accumulator and leave as whole big-endian dwords, so the
+// per-symbol path is shift / or / add and one predictable branch instead of a byte loop.  The state is wave-uniform
+// and EVERY lane stores the same dword to the same address (one write for the memory system): a `lane == 0`
+// predicate around the store makes the compiler keep cursor and accumulator in vector registers behind exec-mask
+// branches, which tripled the per-symbol instruction count.  The slot must be 4-byte aligned (the launchers hand
+// out 8-byte aligned slots).
+struct WaveBitWriter {
+    uint32_t *p;
+    uint8_t *end;
+    uint64_t acc;     // the low nacc bits are pending output (nacc < 32 between calls); bits above them are stale
+    int nacc;
+    bool overflow;
+    __host__ __device__ void init(uint8_t *buf, size_t cap) { p = (uint32_t *)buf; end = buf + cap; acc = 0; nacc = 0; overflow = false; }
+    __host__ __device__ void put_bits(uint32_t v, int n) {          // low n bits of v (0 <= n <= 32, v < 2^n), MSB first
+        acc = (acc << n) | (uint64_t)v;
+        nacc += n;
+        if (nacc >= 32) {
+            const uint32_t w = (uint32_t)(acc >> (nacc - 32));
+            nacc -= 32;
+            if ((uint8_t *)(p + 1) <= end) { *p = __builtin_bswap32(w); ++p; } else overflow = true;
+        }
+    }
+    __host__ __device__ void put_with_pending(int bit, uint64_t &pending) {
+        put_bits((uint32_t)bit, 1);
+        while (pending > 0) {
+            const int n = pending > 31 ? 31 : (int)pending;
+            put_bits(bit ? 0u : ((1u << n) - 1u), n);
+            pending -= (uint64_t)n;
+        }
+    }
+    // pad to a byte boundary with zeros and store the tail bytes; returns the stream length in bytes
+    __host__ __device__ size_t finish(uint8_t *base) {
+        uint8_t *q = (uint8_t *)p;
+        const int nbytes = (nacc + 7) >> 3;
+        const uint32_t tail = nacc ? (uint32_t)(acc << (32 - nacc)) : 0u;    // pending bits left-aligned in 32
+        for (int t = 0; t < nbytes; ++t) {
+            if (q < end) { *q = (uint8_t)(tail >> (24 - 8 * t)); ++q; } else overflow = true;
+        }
+        return (size_t)(q - base);
+    }
+};
+
+template <class Writer>
+struct AcEncoderT {
     uint32_t low, high;
     uint64_t pending;
-    BitWriter out;
+    Writer out;
     __host__ __device__ void init(uint8_t *buf, size_t cap) { low = 0; high = 0xFFFFFFFFu; pending = 0; out.init(buf, cap); }
     __host__ __device__ void encode(uint32_t c_low, uint32_t c_high) {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
@@ -145,20 +192,25 @@ struct AcEncoder {
         low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
         const uint32_t settled = low;            // its top k bits are the bits to emit
         const AcRenorm r = ac_renorm(low, high);
-        if (r.k > 0) {
-            const uint32_t bits = r.k >= 32 ? settled : (settled >> (32 - r.k));
+        const uint32_t bits = (uint32_t)(((uint64_t)settled << r.k) >> 32);     // top k bits of settled (0 if k = 0)
+        if (pending == 0 || r.k == 0) {
+            out.put_bits(bits, r.k);             // first bit + (no pending run) + the other k - 1 bits
+        } else {
             out.put_with_pending((int)((bits >> (r.k - 1)) & 1u), pending);
             if (r.k > 1) out.put_bits(bits & ((1u << (r.k - 1)) - 1u), r.k - 1);
         }
         pending += (uint64_t)r.u;
     }
-    __host__ __device__ size_t finish(uint8_t *base) {
+    __host__ __device__ void finish_bits() {
         ++pending;
         out.put_with_pending(low < 0x40000000u ? 0 : 1, pending);
-        out.flush();
-        return (size_t)(out.p - base);
+    }
+    __host__ __device__ size_t finish(uint8_t *base) {
+        finish_bits();
+        return out.finish(base);
     }
 };
+typedef AcEncoderT<BitWriter> AcEncoder;
 
 template <class Reader>
 struct AcDecoderT {
@@ -276,9 +328,73 @@ extern "C" int cgs_ac_encode_const_host(const uint16_t *row, int Lp, const int16
     return CGS_OK;
 }
 
+// Two-symbol constant row: the mask stream is ONE serial stream of N*K symbols (10 M at 1 M anchors) and sits on the
+// decoder's critical path, so it gets its own loop: no division (cdf[1] <= floor(num / span)  <=>  cdf[1] * span <= num),
+// no search, a 64-bit bit buffer refilled eight bytes at a time.  Same symbols as the generic loop below.
+struct HostBitSource {
+    const uint8_t *buf;
+    size_t len, pos;
+    uint64_t bb;          // next bits, MSB first; the top nb are accounted for (bits below them are a harmless preview)
+    int nb;
+    void init(const uint8_t *b, size_t n) { buf = b; len = n; pos = 0; bb = 0; nb = 0; }
+    inline void refill() {
+        if (pos + 8 <= len) {
+            uint64_t w;
+            memcpy(&w, buf + pos, 8);
+            bb |= __builtin_bswap64(w) >> nb;
+            const int adv = (63 - nb) >> 3;
+            pos += (size_t)adv;
+            nb += adv * 8;
+        } else {
+            while (nb <= 56) {                       // zeros past the end of the stream
+                bb |= (uint64_t)(pos < len ? buf[pos] : 0) << (56 - nb);
+                ++pos;
+                nb += 8;
+            }
+        }
+    }
+    inline uint32_t get_bits(int n) {               // 1 <= n <= 32
+        if (nb < n) refill();
+        const uint32_t r = (uint32_t)(bb >> (64 - n));
+        bb <<= n;
+        nb -= n;
+        return r;
+    }
+};
+
+static int ac_decode_binary_host(const uint16_t *row, int64_t n_sym, const uint8_t *in, size_t in_len, int16_t *sym_out) {
+    HostBitSource src;
+    src.init(in, in_len);
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = src.get_bits(32);
+    const uint32_t c0 = row[0], c1 = row[1];
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const uint32_t span_m1 = high - low;
+        const uint64_t num = (((uint64_t)value - (uint64_t)low + 1) << AC_PRECISION) - 1;
+        const bool one = (uint64_t)c1 * span_m1 + c1 <= num;
+        sym_out[i] = (int16_t)one;
+        if (i == n_sym - 1) break;
+        const uint64_t span = (uint64_t)span_m1 + 1;
+        const uint32_t c_low = one ? c1 : c0, c_high = one ? AC_TOP : c1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        const AcRenorm r = ac_renorm(low, high);
+        const int n = r.k + r.u;
+        if (n == 0) continue;
+        if (n <= 32) {
+            value = (uint32_t)(((uint64_t)value << n) | (uint64_t)src.get_bits(n));
+            if (r.u > 0) value ^= 0x80000000u;
+        } else {
+            value = r.k >= 32 ? src.get_bits(32) : ((value << r.k) | src.get_bits(r.k));
+            value = ((value << r.u) ^ 0x80000000u) | src.get_bits(r.u);
+        }
+    }
+    return CGS_OK;
+}
+
 extern "C" int cgs_ac_decode_const_host(const uint16_t *row, int Lp, int64_t n_sym, const uint8_t *in, size_t in_len,
                                         int16_t *sym_out) {
     if (!row || !sym_out || Lp < 2) { cgs_set_error("ac_decode_const: bad args"); return CGS_ERR_ARG; }
+    if (Lp == 3) return ac_decode_binary_host(row, n_sym, in, in_len, sym_out);
     AcDecoder dec;
     dec.init(in, in_len);
     const int max_sym = Lp - 2;
@@ -302,7 +418,8 @@ extern "C" int cgs_ac_decode_const_host(const uint16_t *row, int Lp, int64_t n_s
 __device__ __forceinline__ uint32_t gaussian_cdf_int(int j, int min_v, float norm, float mean, float inv_scale,
                                                      float q) {
     const float sample = ((float)(min_v + j) - 0.5f) * q;
-    const float z = (sample - mean) * inv_scale / SQRT2F;
+    // torch divides a device tensor by the host scalar sqrt(2) as a multiplication by its reciprocal
+    const float z = (sample - mean) * inv_scale * (1.f / SQRT2F);
     const float c = 0.5f * (1.f + erff(z));
     return (uint32_t)((int32_t)rintf(c * norm) + j) & 0xFFFFu;
 }
@@ -362,9 +479,8 @@ __global__ void __launch_bounds__(64)
     if (s >= n_streams) return;
     const int64_t b = stream_off[s], e = stream_off[s + 1];
     uint8_t *base = out + out_off[s];
-    AcEncoder enc;
+    AcEncoderT<WaveBitWriter> enc;
     enc.init(base, (size_t)(out_off[s + 1] - out_off[s]));
-    enc.out.writer = (lane == 0);
     const int lo = min_v[s];
     const int Lp = max_v[s] - lo + 2;
     const int max_sym = Lp - 2;
@@ -398,9 +514,82 @@ __global__ void __launch_bounds__(64)
     }
 }
 
-// Decoder, same mapping: per symbol the 64 lanes evaluate 64 consecutive CDF entries at once and a ballot
-// replaces the binary search (one erff of latency instead of log2(L) dependent ones); distribution
-// parameters are fetched 64 symbols at a time, coalesced, and broadcast with v_readlane.
+// Device decoder input: MSB-first bit source with a wave-uniform 64-bit bit buffer fed from a 256-byte register
+// window of the stream (lane l = big-endian dword l of the window): get_bits is shift / subtract, a refill is one
+// v_readlane, and memory is touched once per 256 stream bytes.  Zeros past the end of the stream.
+struct WaveBitSource {
+    const uint8_t *buf;
+    uint64_t len, next;      // stream bytes; byte offset of the next window
+    uint32_t win;
+    int d;                   // next dword of the window to shift in
+    uint64_t bb;             // bit buffer, the top nb bits are valid, the rest are zero
+    int nb;
+    __device__ void fill() {
+        const uint64_t o = next + 4ull * (threadIdx.x & 63);
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w = (w << 8) | (o + t < len ? (uint32_t)buf[o + t] : 0u);
+        win = w;
+        next += 256;
+        d = 0;
+    }
+    __device__ void init(const uint8_t *b, size_t n) { buf = b; len = (uint64_t)n; next = 0; bb = 0; nb = 0; fill(); }
+    __device__ uint32_t get_bits(int n) {           // 1 <= n <= 32
+        if (nb < 32) {
+            if (d == 64) fill();
+            bb |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, d) << (32 - nb);
+            ++d;
+            nb += 32;
+        }
+        const uint32_t r = (uint32_t)(bb >> (64 - n));
+        bb <<= n;
+        nb -= n;
+        return r;
+    }
+};
+
+struct WaveAcDecoder {
+    uint32_t low, high, value;
+    WaveBitSource in;
+    __device__ void init(const uint8_t *buf, size_t len) {
+        low = 0; high = 0xFFFFFFFFu;
+        in.init(buf, len);
+        value = in.get_bits(32);
+    }
+    // cdf <= target  <=>  cdf * span <= num  (target = floor(num / span), AcDecoderT::target): the per-lane test
+    // is one 64-bit multiply-add and a compare, no division on the per-symbol path
+    __device__ uint64_t num() const { return (((uint64_t)value - (uint64_t)low + 1) << AC_PRECISION) - 1; }
+    __device__ uint32_t span_m1() const { return high - low; }
+    __device__ void consume(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        const AcRenorm r = ac_renorm(low, high);
+        const int n = r.k + r.u;
+        if (n == 0) return;
+        if (n <= 32) {
+            // k settled bits then u underflow steps (each value = ((value - 2^30) << 1) | bit) in one read:
+            // ((value << k | bits_k) << u ^ 2^31) | bits_u  ==  (value << n | bits_n) ^ (u ? 2^31 : 0)
+            value = (uint32_t)(((uint64_t)value << n) | (uint64_t)in.get_bits(n));
+            if (r.u > 0) value ^= 0x80000000u;
+        } else {
+            value = r.k >= 32 ? in.get_bits(32) : ((value << r.k) | in.get_bits(r.k));
+            value = ((value << r.u) ^ 0x80000000u) | in.get_bits(r.u);
+        }
+    }
+};
+
+__device__ __forceinline__ bool cdf_le_target(uint32_t cdf, uint32_t span_m1, uint64_t num) {
+    return (uint64_t)cdf * (uint64_t)span_m1 + (uint64_t)cdf <= num;
+}
+
+// Decoder, ONE WAVE PER STREAM.  The integer CDF entries a symbol needs do not depend on the coder state, so they
+// are evaluated ahead of it: the four 16-lane rows of the wave evaluate 16-entry windows (centred on the Gaussian's
+// mean, where the mass is) of FOUR consecutive symbols with one erff, then the coder walks the four symbols; per
+// symbol a ballot over `cdf * span <= num` replaces the binary search.  A symbol whose target falls outside its
+// window takes the 64-wide search (all lanes on that one symbol, moving window).  Distribution parameters are
+// fetched 64 symbols at a time, coalesced; decoded symbols collect in a register (v_writelane) and are dequantised
+// and stored 64 at a time.
 __global__ void __launch_bounds__(64)
     gaussian_decode_kernel(const float *__restrict__ mean, const float *__restrict__ scale,
                            const float *__restrict__ Q, int64_t q_div, const int64_t *__restrict__ stream_off,
@@ -411,12 +600,13 @@ __global__ void __launch_bounds__(64)
     const int lane = threadIdx.x;
     if (s >= n_streams) return;
     const int64_t b = stream_off[s], e = stream_off[s + 1];
-    AcDecoderT<WaveBitReader> dec;
+    WaveAcDecoder dec;
     dec.init(in + in_off[s], (size_t)(in_off[s + 1] - in_off[s]));
     const int lo = min_v[s];
     const int Lp = max_v[s] - lo + 2;
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
+    const int row = lane >> 4, col = lane & 15;
     for (int64_t i0 = b; i0 < e; i0 += 64) {
         const int64_t i = i0 + lane;
         float q_l = 1.f, m_l = 0.f, inv_l = 1.f;
@@ -425,48 +615,67 @@ __global__ void __launch_bounds__(64)
             m_l = mean[i];
             inv_l = 1.f / scale[i];
         }
-        float x_l = 0.f;
+        const int mid_l = (int)rintf(m_l / q_l) - lo;        // symbol index nearest to the mean
+        int sym_l = 0;
         const int cnt = (int)min((int64_t)64, e - i0);
-        for (int j = 0; j < cnt; ++j) {
-            const float q = bcast_f(q_l, j), m = bcast_f(m_l, j), inv = bcast_f(inv_l, j);
-            const uint32_t target = dec.target();
-            // sym = largest candidate with cdf[cand] <= target (the CDF is strictly increasing, so the lanes that
-            // pass form a prefix).  The 64-candidate window starts around the Gaussian's mean, where the mass is:
-            // wide grids (scaling: Q = 1e-3, thousands of symbols) otherwise cost max_sym/64 erff rounds per symbol.
-            int sym = 0;
-            int cb = (int)rintf(m / q) - lo - 32;
-            cb = max(0, min(cb, max_sym - 63));
-            uint32_t cdf_l = 0;
-            for (;;) {
-                const int cand = cb + lane;
-                cdf_l = gaussian_cdf_int(cand, lo, norm, m, inv, q);
-                const bool le = cand <= max_sym && cdf_l <= target;
-                const int n_le = __builtin_popcountll(__ballot(le));
-                if (n_le == 0) {
-                    if (cb == 0) { sym = 0; break; }
-                    cb = max(0, cb - 64);                 // everything in the window is above the target
-                } else if (n_le == 64 && cb + 64 <= max_sym) {
-                    cb += 63;                             // keep the last passing candidate in the next window
+        for (int jb = 0; jb < cnt; jb += 4) {
+            const int src = jb + row;
+            const float q4 = __shfl(q_l, src), m4 = __shfl(m_l, src), inv4 = __shfl(inv_l, src);
+            const int cb4 = max(0, min(__shfl(mid_l, src) - 8, max_sym - 15));
+            const int cand4 = cb4 + col;
+            const uint32_t cdf4 = gaussian_cdf_int(cand4, lo, norm, m4, inv4, q4);
+            const bool ok4 = cand4 <= max_sym;
+            const int jn = min(4, cnt - jb);
+            for (int r = 0; r < jn; ++r) {
+                const int j = jb + r;
+                const uint64_t num = dec.num();
+                const uint32_t sm1 = dec.span_m1();
+                const uint32_t rowbits = (uint32_t)(__ballot(ok4 && cdf_le_target(cdf4, sm1, num)) >> (16 * r)) & 0xFFFFu;
+                const int n_le = __builtin_popcount(rowbits);
+                const int cbs = __builtin_amdgcn_readlane(cb4, 16 * r);
+                int sym;
+                uint32_t c_low, c_high;
+                if ((n_le >= 1 && (n_le <= 15 || cbs + 15 >= max_sym)) || (n_le == 0 && cbs == 0)) {
+                    // passing lanes form a prefix of the row (the CDF is strictly increasing): the symbol is the
+                    // last of them and both of its bounds are in the window
+                    const int rel = max(n_le - 1, 0);
+                    sym = cbs + rel;
+                    c_low = bcast_u(cdf4, 16 * r + rel);
+                    c_high = sym >= max_sym ? AC_TOP : bcast_u(cdf4, 16 * r + rel + 1);
                 } else {
-                    sym = cb + n_le - 1;
-                    break;
+                    const float q = bcast_f(q_l, j), m = bcast_f(m_l, j), inv = bcast_f(inv_l, j);
+                    int cb = n_le == 0 ? cbs - 64 : cbs + 15;
+                    cb = max(0, min(cb, max_sym - 63));
+                    uint32_t cdf_l = 0;
+                    for (;;) {
+                        const int cand = cb + lane;
+                        cdf_l = gaussian_cdf_int(cand, lo, norm, m, inv, q);
+                        const bool le = cand <= max_sym && cdf_le_target(cdf_l, sm1, num);
+                        const int n64 = __builtin_popcountll(__ballot(le));
+                        if (n64 == 0) {
+                            if (cb == 0) { sym = 0; break; }
+                            cb = max(0, cb - 64);             // everything in the window is above the target
+                        } else if (n64 == 64 && cb + 64 <= max_sym) {
+                            cb += 63;                         // keep the last passing candidate in the next window
+                        } else {
+                            sym = cb + n64 - 1;
+                            break;
+                        }
+                    }
+                    const int rel = __builtin_amdgcn_readfirstlane(sym - cb);
+                    if (rel >= 0 && rel < 63) {
+                        c_low = bcast_u(cdf_l, rel);
+                        c_high = sym == max_sym ? AC_TOP : bcast_u(cdf_l, rel + 1);
+                    } else {
+                        c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+                        c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+                    }
                 }
+                sym_l = lane == j ? sym : sym_l;
+                if (i0 + j != e - 1) dec.consume(c_low, c_high);
             }
-            if (lane == j) x_l = (float)(sym + lo) * q;
-            if (i0 + j == e - 1) break;
-            // the symbol's two CDF entries were just evaluated by lanes sym - cb and sym + 1 - cb of the window
-            const int rel = __builtin_amdgcn_readfirstlane(sym - cb);
-            uint32_t c_low, c_high;
-            if (rel >= 0 && rel < 63) {
-                c_low = bcast_u(cdf_l, rel);
-                c_high = sym == max_sym ? AC_TOP : bcast_u(cdf_l, rel + 1);
-            } else {
-                c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
-                c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
-            }
-            dec.consume(c_low, c_high);
         }
-        if (i < e) x_out[i] = x_l;
+        if (i < e) x_out[i] = (float)(sym_l + lo) * q_l;
     }
 }
 

@@ -246,6 +246,39 @@ class EntropyBottleneck(nn.Module):
         return out.unsqueeze(0)
 
 
+    # The container codes the hyper latents as independent 10 000-anchor rANS strings
+    # (scene/gaussian_model.py:1082-1098, 1326-1336).  The strings are serial inside and independent of each other,
+    # so the chunk forms below quantise / dequantise ONCE on the device and run the strings concurrently on host
+    # threads (the ctypes calls into libcgs release the GIL).  Byte-identical to a loop of compress()/decompress().
+    @torch.no_grad()
+    def compress_chunks(self, x: torch.Tensor, chunk: int) -> list[bytes]:
+        """x [C, N] -> [compress(x[None, :, s:s+chunk])[0] for s in range(0, N, chunk)]."""
+        from . import codec
+        assert x.dim() == 2 and x.shape[0] == self.channels
+        if self._offset.numel() == 0:
+            self.update()
+        sym = self.quantize(x, "symbols", self._get_medians()[:, 0]).cpu().numpy()            # [C, N] int32
+        tabs = (self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy())
+        jobs = [codec.host_pool().submit(codec.rans_encode_channels, sym[:, s:s + chunk], *tabs, self.precision)
+                for s in range(0, sym.shape[1], chunk)]
+        return [j.result() for j in jobs]
+
+    @torch.no_grad()
+    def decompress_chunks(self, strings: list[bytes], sizes: list[int]) -> torch.Tensor:
+        """inverse of compress_chunks -> [C, sum(sizes)] dequantised, on the module's device."""
+        from . import codec
+        if self._offset.numel() == 0:
+            self.update()
+        dev = self.quantiles.device
+        if not strings:
+            return torch.zeros(self.channels, 0, dtype=self.quantiles.dtype, device=dev)
+        tabs = (self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy())
+        jobs = [codec.host_pool().submit(codec.rans_decode_channels, b, self.channels, int(n), *tabs, self.precision)
+                for b, n in zip(strings, sizes)]
+        sym = np.concatenate([j.result() for j in jobs], axis=1)
+        return torch.from_numpy(sym).to(dev).to(self.quantiles.dtype) + self._get_medians()[:, 0]
+
+
 def pmf_to_quantized_cdf(pmf: np.ndarray, precision: int = 16) -> np.ndarray:
     """Probabilities -> strictly increasing integer CDF with total 2**precision
     (every symbol keeps frequency >= 1; the excess is taken from the symbols that lose

@@ -384,6 +384,14 @@ int cgs_gaussian_ac_decode(const float *mean, const float *scale,
                            const int32_t *min_v, const int32_t *max_v,
                            const uint8_t *in, const int64_t *in_off,
                            float *x_out, void *stream);
+/* Pack the chunk streams a coder launch left in their worst-case slots
+ * (src + src_off[s], len[s] bytes) back to back at dst + dst_off[s]: the
+ * on-disk layout of featN.b / scalingN.b / offsetsN.b
+ * (scene/gaussian_model.py:1235-1238, b"".join of the chunk strings).  `src`
+ * must be readable 8 bytes past its last slot. */
+int cgs_streams_compact(const uint8_t *src, const int64_t *src_off,
+                        const uint32_t *len, const int64_t *dst_off,
+                        int n_streams, uint8_t *dst, void *stream);
 /* test hook: the integer CDF table [n, max_v-min_v+2] of one stream */
 int cgs_gaussian_cdf_table(const float *mean, const float *scale,
                            const float *Q, int64_t q_div, int64_t n, int min_v,

@@ -128,3 +128,39 @@ def test_entropy_bottleneck_density_and_codec():
     y = eb.decompress(s, [500])
     assert torch.equal(y[0].t(), torch.round(x))
     assert eb.quantize(x, "symbols", eb._get_medians()[:, 0, 0]).dtype == torch.int32
+
+
+def test_entropy_bottleneck_chunk_forms_equal_the_per_chunk_loop():
+    """compress_chunks / decompress_chunks (host threads over the container's independent hyper strings) give the
+    same bytes / values as a loop of compress() / decompress() (scene/gaussian_model.py:1082-1098, 1326-1336)."""
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    torch.manual_seed(5)
+    eb = EntropyBottleneck(12)
+    eb.eval()
+    x = torch.randn(2350, 12) * 4                       # ragged last chunk; a few escapes
+    x[7, 3] = 4000.0
+    loop = [eb.compress(x[s:s + 1000].t().unsqueeze(0))[0] for s in range(0, 2350, 1000)]
+    assert eb.compress_chunks(x.t(), 1000) == loop
+    sizes = [1000, 1000, 350]
+    y = eb.decompress_chunks(loop, sizes)
+    ref_y = torch.cat([eb.decompress([b], [n])[0] for b, n in zip(loop, sizes)], dim=1)
+    assert torch.equal(y, ref_y) and torch.equal(y.t(), torch.round(x))
+    assert eb.compress_chunks(x[:0].t(), 1000) == [] and eb.decompress_chunks([], []).shape == (12, 0)
+
+
+@pytest.mark.parametrize("p1,n,seed", [(0.7, 5000, 1), (0.999, 20000, 2), (0.002, 20000, 3), (0.5, 3, 4), (0.35, 1, 5)])
+def test_binary_mask_decoder_equals_generic_table_decoder(p1, n, seed):
+    """The dedicated two-symbol loop behind the mask stream (no division / search, 64-bit bit buffer) returns the
+    symbols of the generic table decoder and of the pure-Python oracle, incl. heavily skewed rows (long underflow
+    runs), tiny streams, and streams cut short (zeros past the end)."""
+    rng = np.random.default_rng(seed)
+    sym = (rng.random(n) < p1).astype(np.int16)
+    data = codec.bernoulli_encode_host(sym, p1)
+    row = ref.float_cdf_to_int([0.0, 1 - float(np.float32(p1)), 1.0])
+    assert data == ref.ac_encode([row] * n, sym.tolist())
+    assert np.array_equal(codec.bernoulli_decode_host(data, n, p1), sym)
+    table = torch.tensor([[0.0, 1 - float(np.float32(p1)), 1.0]], dtype=torch.float32).repeat(n, 1)
+    for cut in (len(data), max(len(data) - 3, 0), len(data) // 2):
+        fast = codec.bernoulli_decode_host(data[:cut], n, p1)
+        generic = codec.decode_float_cdf(table, data[:cut]).numpy()
+        assert np.array_equal(fast, generic)

@@ -161,3 +161,32 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed):
                                      return_sum_bits=True)
     est_bits = sums[2] + sums[3] + sums[4]
     assert 0.65 * est_bits <= coded <= 1.08 * est_bits
+
+
+def test_grouped_launch_is_byte_identical_to_per_group_launches():
+    """gaussian_encode_groups / gaussian_decode_groups (all streams of several attribute groups in ONE coder launch,
+    row-broadcast Q expanded per symbol) give the bytes / values of separate gaussian_encode_streams calls, incl. an
+    empty group and an empty stream; the packed blob is the b"".join of the chunk strings."""
+    from contextgs_amd import codec
+    dev = "cuda"
+    specs = [(50, [0, 50 * 40, 50 * 100, 50 * 137]), (6, [0, 6 * 100, 6 * 100, 6 * 137]), (1, [0, 811, 2000]), (1, [0])]
+    groups, singles = [], []
+    for gi_, (q_div, edges) in enumerate(specs):
+        n = edges[-1]
+        xq, mean, scale, Qs = _params(n, 20 + gi_)
+        rows = max(n // q_div, 0)
+        Qrow = Qs[:rows].copy()
+        Qfull = np.repeat(Qrow, q_div)
+        xq = (np.round((mean + (xq - mean)) / np.maximum(Qfull, 1e-3)) * Qfull).astype(np.float32) if n else xq
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        g = (t(xq), t(mean), t(scale), t(Qrow), edges, q_div)
+        groups.append(g)
+        singles.append(codec.gaussian_encode_streams(*g[:5], q_div=q_div))
+    packed = codec.gaussian_encode_groups(groups)
+    dec_groups = []
+    for g, (streams, mn, mx), (blob, lens, mn2, mx2) in zip(groups, singles, packed):
+        assert blob.tobytes() == b"".join(streams) and lens.tolist() == [len(b) for b in streams]
+        assert np.array_equal(mn, mn2) and np.array_equal(mx, mx2)
+        dec_groups.append((g[1], g[2], g[3], g[4], mn2, mx2, blob, lens, g[5]))
+    for g, out in zip(groups, codec.gaussian_decode_groups(dec_groups)):
+        assert torch.equal(out, g[0])
