@@ -271,7 +271,9 @@ def main():
         cpu = None
         with contextlib.redirect_stdout(sys.stderr):
             if not args.no_codec:
-                codec = codec_bench(pc)
+                from contextgs_amd.dist import local_only
+                with local_only():          # rank 0 alone runs this leg: no collectives while the others wait
+                    codec = codec_bench(pc)
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
 

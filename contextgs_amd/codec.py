@@ -224,8 +224,22 @@ def gaussian_encode_groups(groups):
         edges.append(off[1:] + base)
         counts.append(max(int(off.numel()) - 1, 0))
         base += int(xs[-1].numel())
-    blob, lens, mn, mx = gaussian_encode_packed(torch.cat(xs), torch.cat(ms), torch.cat(ss), torch.cat(qs),
-                                                torch.cat(edges), 1)
+    X, M, Sc, Qe, E = torch.cat(xs), torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges)
+    from . import dist as D
+    if D.world() > 1:
+        # multi-GPU: rank r codes a contiguous block of the stream list; the ranks' packed bytes in rank
+        # order ARE the single-GPU bytes, so rank 0 just concatenates.  No exchange is needed while encoding (every
+        # rank predicts and quantises all levels itself; the coder never feeds back into the context).
+        b = D.stream_blocks(E)
+        s0, s1 = b[D.rank()], b[D.rank() + 1]
+        e0, e1 = int(E[s0]), int(E[s1])
+        part = gaussian_encode_packed(X[e0:e1], M[e0:e1], Sc[e0:e1], Qe[e0:e1], E[s0:s1 + 1] - e0, 1)
+        parts = D.gather_objects(part, dst=0)
+        if parts is None:
+            return None
+        blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
+    else:
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1)
     out, s0, b0 = [], 0, 0
     for c in counts:
         nb = int(lens[s0:s0 + c].sum())
@@ -254,7 +268,7 @@ def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens,
     assert buf.size == int(in_off_h[-1]), "stream lengths do not add up to the blob"
     in_d = torch.empty(buf.size + 16, dtype=torch.uint8, device=dev)
     if buf.size:
-        in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf)))
+        in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
     in_off = torch.from_numpy(in_off_h).to(dev)
     mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
     mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
@@ -286,8 +300,21 @@ def gaussian_decode_groups(groups):
         lns.append(np.asarray(lens, dtype=np.int64).reshape(-1))
         sizes.append(int(ms[-1].numel()))
         base += sizes[-1]
-    flat = gaussian_decode_packed(torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges), np.concatenate(mns),
-                                  np.concatenate(mxs), np.concatenate(blobs), np.concatenate(lns), 1)
+    M, Sc, Qe, E = torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges)
+    mn, mx, blob, lens = np.concatenate(mns), np.concatenate(mxs), np.concatenate(blobs), np.concatenate(lns)
+    from . import dist as D
+    if D.world() > 1:
+        # multi-GPU: rank r decodes a contiguous block of the streams, then ONE all-gather hands every rank all
+        # decoded values (they are the next level's context and the final parameters on every replica)
+        b = D.stream_blocks(E)
+        s0, s1 = b[D.rank()], b[D.rank() + 1]
+        e0, e1 = int(E[s0]), int(E[s1])
+        cum = np.concatenate([[0], np.cumsum(lens)])
+        local = gaussian_decode_packed(M[e0:e1], Sc[e0:e1], Qe[e0:e1], E[s0:s1 + 1] - e0, mn[s0:s1], mx[s0:s1],
+                                       blob[int(cum[s0]):int(cum[s1])], lens[s0:s1], 1)
+        flat = D.all_gather_rows(local, [int(E[b[r + 1]]) - int(E[b[r]]) for r in range(D.world())])
+    else:
+        flat = gaussian_decode_packed(M, Sc, Qe, E, mn, mx, blob, lens, 1)
     return list(torch.split(flat, sizes))
 
 

@@ -30,6 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import codec
+from . import dist as mgpu
 from .context_model import (extract_context_feat, find_divide_scale, grid_mlp, level_plan, multi_scale_generating,
                             split_prediction)
 from .encodings import Q_anchor, Quantize_anchor, STE_multistep, decoder, encoder
@@ -90,6 +91,7 @@ def _predict(pc, level, feat_in):
 def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     torch.cuda.synchronize(); t1 = time.time()
     print("Start encoding ...")
+    root = mgpu.rank() == 0          # multi-GPU: every rank predicts/quantises, codes its block of streams; rank 0 writes
     os.makedirs(pre_path_name, exist_ok=True)
     pc.latent_codec.update(force=True)
     K, D = pc.n_offsets, pc.feat_dim
@@ -105,11 +107,12 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
 
     # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream: start it on a host thread now
     prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
-    mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
-    mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
-    # hyper: 10 000-anchor rANS chunks (:1082-1098), also on host threads
-    hyper_bytes = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10)
-    bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
+    if root:
+        mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+        mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
+        # hyper: 10 000-anchor rANS chunks (:1082-1098), also on host threads
+        hyper_bytes = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10)
+        bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
 
     # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
     hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
@@ -120,9 +123,10 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
-    np.save(path("anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))          # :1100-1101
-    with open(path("hyper.b"), "wb") as f:
-        f.write(b"".join(hyper_bytes))
+    if root:
+        np.save(path("anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))      # :1100-1101
+        with open(path("hyper.b"), "wb") as f:
+            f.write(b"".join(hyper_bytes))
 
     N_levels_list, groups, tags = [], [], []
     content_pre_gathered = None
@@ -163,6 +167,8 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     torch.cuda.synchronize(); t0 = time.time()
     coded = codec.gaussian_encode_groups(groups)
     torch.cuda.synchronize(); t_codec = time.time() - t0
+    if not root:
+        return mgpu.broadcast_object(None)            # the summary string of rank 0
 
     bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
     min_d = {"feat": {}, "scaling": {}, "offsets": {}}
@@ -196,7 +202,8 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     bit_meta = os.path.getsize(meta_path) * 8
     mlp = pc.get_mlp_size()[0]
     r = lambda v: round(v / bit2MB_scale, 4)
-    return (f"\nEncoded sizes in MB: meta {r(bit_meta)}, hyper {r(bit_hyper)}, anchor {r(bit_anchor)}, "
+    return mgpu.broadcast_object(
+            f"\nEncoded sizes in MB: meta {r(bit_meta)}, hyper {r(bit_hyper)}, anchor {r(bit_anchor)}, "
             f"feat {r(bit_feat)}, scaling {r(bit_scaling)}, offsets {r(bit_offsets)}, masks {r(bit_masks)}, "
             f"MLPs {r(mlp)}, Total {r(bit_meta + bit_hyper + bit_anchor + bit_feat + bit_scaling + bit_offsets + bit_masks + mlp)}, "
             f"EncTime {round(t2 - t1, 4)}")

@@ -15,18 +15,35 @@ works with the gloo backend on CPU tensors too, which is how tests/test_dist.py 
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Sequence
 
 import torch
 import torch.distributed as dist
 
 
+_LOCAL_ONLY = 0
+
+
+@contextlib.contextmanager
+def local_only():
+    """Inside this block the helpers of this module behave as in a single process (world 1, rank 0, no
+    collectives) even though a process group exists: for work ONE rank does on its own, e.g. bench.py's codec leg
+    on rank 0 while the other ranks wait at the next barrier."""
+    global _LOCAL_ONLY
+    _LOCAL_ONLY += 1
+    try:
+        yield
+    finally:
+        _LOCAL_ONLY -= 1
+
+
 def world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size() if not _LOCAL_ONLY and dist.is_available() and dist.is_initialized() else 1
 
 
 def rank():
-    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return dist.get_rank() if not _LOCAL_ONLY and dist.is_available() and dist.is_initialized() else 0
 
 
 def view_for(step: int, n_views: int, r: int | None = None, w: int | None = None) -> int:
@@ -101,6 +118,59 @@ def broadcast_parameters(params: Iterable[torch.nn.Parameter], src: int = 0) -> 
         return
     for p in params:
         dist.broadcast(p.data, src=src)
+
+
+def stream_blocks(edges, w: int | None = None) -> list[int]:
+    """Split S consecutive streams (edges: S+1 non-decreasing element offsets) into `w` CONTIGUOUS blocks of about
+    equal element count: returns w+1 stream indices, rank r codes streams [b[r], b[r+1]).  Contiguous blocks keep a
+    rank's elements one slice of the flat arrays and make the concatenation of the ranks' byte streams in rank order
+    the single-GPU file."""
+    w = world() if w is None else w
+    e = torch.as_tensor(edges, dtype=torch.int64).cpu()
+    S = int(e.numel()) - 1
+    if S <= 0:
+        return [0] * (w + 1)
+    total = int(e[-1] - e[0])
+    targets = e[0] + (torch.arange(1, w, dtype=torch.int64) * total) // w
+    cuts = torch.searchsorted(e, targets, right=False).clamp_(0, S).tolist()
+    b = [0] + cuts + [S]
+    for i in range(1, len(b)):                       # monotone even for degenerate (empty) streams
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+def all_gather_rows(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
+    """Concatenate every rank's 1-D `local` (rank r holds counts[r] elements) in rank order on every rank: the
+    exchange step of the sharded decoder (a level's decoded values are the next level's context on all ranks).
+    One padded all_gather over RCCL; gloo has no device all_gather, so there the data takes the host path."""
+    w = world()
+    if w == 1:
+        return local
+    m = max(int(c) for c in counts)
+    on_host = dist.get_backend() != "nccl" and local.is_cuda
+    buf = torch.zeros(m, dtype=local.dtype, device="cpu" if on_host else local.device)
+    buf[: local.numel()].copy_(local)
+    out = [torch.empty_like(buf) for _ in range(w)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[: int(c)] for o, c in zip(out, counts)]).to(local.device)
+
+
+def gather_objects(obj, dst: int = 0):
+    """Python objects of all ranks on rank dst (list in rank order), None elsewhere."""
+    w, r = world(), rank()
+    if w == 1:
+        return [obj]
+    out = [None] * w if r == dst else None
+    dist.gather_object(obj, out, dst=dst)
+    return out
+
+
+def broadcast_object(obj, src: int = 0):
+    if world() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
 
 
 def gather_bytes(chunks: List[bytes], dst: int = 0) -> List[bytes] | None:

@@ -41,8 +41,14 @@ def _worker(rank, world, port, q):
         cd.broadcast_parameters([p2], src=1)
         chunks = cd.shard([bytes([i]) for i in range(7)])
         merged = cd.gather_bytes(chunks, dst=0)
+        # the sharded decoder's exchange step and the encoder's byte gather
+        rows = cd.all_gather_rows(torch.arange(3 + 2 * rank, dtype=torch.float32) + 10 * rank, [3, 5])
+        objs = cd.gather_objects(("r", rank), dst=0)
+        word = cd.broadcast_object("from0" if rank == 0 else None)
+        with cd.local_only():
+            alone = (cd.world(), cd.rank(), cd.all_gather_rows(torch.ones(2), [2]).tolist())
         q.put((rank, views, n, lin.weight.grad.clone(), extra.grad.clone(), stats[0].clone(), int(stats[1]),
-               p2.data.clone(), merged))
+               p2.data.clone(), merged, rows, objs, word, alone))
     finally:
         dist.destroy_process_group()
 
@@ -72,3 +78,24 @@ def test_world_size_2_gradient_sync_and_sharding():
         assert torch.equal(res[r][5], torch.full((3, 1), 3.0)) and res[r][6] == 1
         assert torch.equal(res[r][7], torch.full((3,), 1.0))
     assert res[0][8] == [bytes([i]) for i in range(7)] and res[1][8] is None
+    for r in (0, 1):
+        assert res[r][9].tolist() == [0, 1, 2, 10, 11, 12, 13, 14] and res[r][11] == "from0"
+        assert res[r][12] == (1, 0, [1.0, 1.0])
+    assert res[0][10] == [("r", 0), ("r", 1)] and res[1][10] is None
+
+
+def test_stream_blocks_are_contiguous_balanced_and_cover_everything():
+    from contextgs_amd import dist as mgpu
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for w in (1, 2, 3, 8):
+        for S in (0, 1, 5, 100):
+            lens = rng.integers(0, 50, S)
+            edges = np.concatenate([[0], np.cumsum(lens)])
+            b = mgpu.stream_blocks(edges, w)
+            assert len(b) == w + 1 and b[0] == 0 and b[-1] == S and all(x <= y for x, y in zip(b, b[1:]))
+            if S >= 20:
+                sizes = [edges[b[i + 1]] - edges[b[i]] for i in range(w)]
+                assert max(sizes) - min(sizes) <= 2 * 50
+    with mgpu.local_only():
+        assert mgpu.world() == 1 and mgpu.rank() == 0
