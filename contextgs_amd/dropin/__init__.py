@@ -21,7 +21,7 @@ def install(patch_reference_python: bool = True) -> list[str]:
     if HERE not in sys.path:
         sys.path.insert(0, HERE)
     for name in ("diff_gaussian_rasterization", "torchac", "compressai", "compressai.entropy_models",
-                 "compressai.latent_codecs", "torch_scatter"):
+                 "compressai.latent_codecs", "torch_scatter", "simple_knn", "simple_knn._C"):
         importlib.import_module(name)
     patched = []
     if not patch_reference_python:

@@ -4,8 +4,10 @@ Carries exactly the state tensors, accessors and MLP definitions the
 render-and-compress path reads (SURVEY §8a rows a6/a7 and the state-tensor
 table): same attribute and property names, same shapes, same activations, so
 `render()` / `multi_scale_generating()` / the codec accept either this class
-or the reference's own GaussianModel.  Optimiser, densification, ply I/O stay
-in the reference (out of scope).
+or the reference's own GaussianModel.  The optimiser stays in the reference
+(out of scope); the SURVEY §8(f) widenings live next to this class:
+densification (densify.py), anchor initialisation (knn.py, `create_from_pcd`)
+and the ply files (ply_io.py, `save_ply` / `load_ply_sparse_gaussian`).
 
 Cited lines are scene/gaussian_model.py unless stated otherwise.
 """
@@ -140,6 +142,41 @@ class GaussianModel(nn.Module):
         self._rotation = P(rotation, False)
         self._opacity = P(torch.zeros(N, 1), False)
         self._level_cache = None
+        return self
+
+    # ---- initialisation and ply I/O --------------------------
+    def create_from_pcd(self, pcd, spatial_lr_scale: float = 1.0):      # :382-423
+        """pcd: a BasicPointCloud (uses .points) or an [N,3] array / tensor.  voxel_size <= 0 selects the median
+        3-NN distance (:388-391).  kNN and voxelisation run on the device (knn.py, csrc/knn.hip)."""
+        from . import knn
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = getattr(pcd, "points", pcd)
+        pts = pts if isinstance(pts, torch.Tensor) else torch.as_tensor(pts)
+        dev = self.x_bound_min.device
+        H = self.feat_dim // self.hyper_divisor
+        (self.voxel_size, anchor, offset, mask, feat, hyper, scaling, rot, opacity) = knn.init_from_points(
+            pts.to(dev), float(self.voxel_size), self.n_offsets, self.feat_dim, H)
+        print(f"Initial voxel_size: {self.voxel_size}")
+        print("Number of points at initialisation : ", anchor.shape[0])
+        self.set_state(anchor, offset, mask, feat, hyper, scaling, rot)
+        self._opacity = nn.Parameter(opacity, requires_grad=False)
+        self.max_radii2D = torch.zeros(anchor.shape[0], device=dev)
+        return self
+
+    def save_ply(self, path):                                           # :579-598
+        import os
+        from . import ply_io
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        ply_io.save_model_ply(path, self._anchor, self._offset, self._mask, self._anchor_feat, self._hyper_latent,
+                              self._opacity, self._scaling, self._rotation)
+
+    def load_ply_sparse_gaussian(self, path):                           # :600-654
+        from . import ply_io
+        d = ply_io.load_model_ply(path)
+        self.set_state(d["anchor"], d["offset"], d["mask"], d["feat"], d["hyper"], d["scaling"], torch.from_numpy(d["rotation"]))
+        dev = self.x_bound_min.device
+        self._rotation.requires_grad_(True)                              # the reference re-enables both on load
+        self._opacity = nn.Parameter(torch.from_numpy(d["opacity"]).to(dev), requires_grad=True)
         return self
 
     # the codec / rate-report methods live in codec_driver.py and are bound here so the

@@ -451,6 +451,15 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         float *d_op_raw, float *d_mask, float *d_color_in,
                         float *d_cov_in, const int64_t *src_row, void *stream);
 
+/* ---- anchor-initialisation kNN ----
+ * `distCUDA2` of the simple_knn wheel (called at scene/gaussian_model.py:389,407; the wheel's source is not in
+ * the reference checkout): mean_dist2[i] = mean of the squared fp32 distances from points[i] ([n,3], device) to
+ * its 3 nearest OTHER points (exact search; coincident points count at distance 0).  Fewer than 4 points leave
+ * FLT_MAX terms in the mean (inf), as an empty best-list does upstream.  scratch from cgs_knn_scratch_bytes(n). */
+size_t cgs_knn_scratch_bytes(int64_t n);
+int cgs_knn_mean_dist2(const float *points, int64_t n, float *mean_dist2,
+                       void *scratch, size_t scratch_bytes, void *stream);
+
 /* ---- densification statistics ----
  * scene/gaussian_model.py:696-713 (training_statis) in one pass over the n_vis*K slots of the visible
  * anchors vis_idx [n_vis] (ascending anchor rows): opacity_accum[a] += sum_k max(opacity[.,k], 0),
