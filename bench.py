@@ -246,7 +246,10 @@ def main():
             if name in traffic:
                 k["pmc_hbm_bytes"] = traffic[name]
             kernels[name] = k
-        dom = max(kernels, key=lambda n_: kernels[n_]["total_ms"]) if kernels else None
+        # dominant KERNEL: the scopes with algorithmic bytes are single kernels; mlp_* / ctx_* / rate_* are families of
+        # several kernels and many launches per step (their totals are in `kernels`), not candidates
+        single = [n_ for n_ in kernels if "alg_bytes" in kernels[n_]]
+        dom = max(single, key=lambda n_: kernels[n_]["total_ms"]) if single else None
         roofline = None
         if dom and "GBps" in kernels[dom]:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
