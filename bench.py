@@ -122,11 +122,18 @@ def main():
     dist_on = world > 1
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # CGS_BENCH_BACKEND=gloo (+ fewer GPUs than ranks) is the 1-GPU rehearsal of the multi-rank control flow
+    # (tools/bench_rehearsal.sh); the measured configuration is one rank per GPU over RCCL
+    backend = os.environ.get("CGS_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__
     if rank == 0:
@@ -277,7 +284,7 @@ def main():
                 from contextgs_amd.dist import local_only
                 with local_only():          # rank 0 alone runs this leg: no collectives while the others wait
                     codec = codec_bench(pc)
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (torchrun also pins OMP to 1 thread)
                 cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
 
         result = {

@@ -3,11 +3,12 @@
 The reference is single-process / single-GPU (no torch.distributed anywhere, SURVEY §2);
 this is new work, designed for MI355X: one process per GPU, RCCL (`backend="nccl"`) over
 xGMI.  The path shards over VIEWS: every rank holds a full replica of the anchors + MLPs,
-rank r renders view (step * world + r), and ONE sum all-reduce of the flattened gradient
-per step keeps the replicas identical (444 B per anchor + 0.33 MB of MLP weights: 0.44 GB
-at 1 M anchors).  A single flat bucket is used on purpose: xGMI is point-to-point, a ring
-all-reduce is bound by one ~153 GB/s link per hop, and many small buckets would pay the
-per-collective latency once each without adding bandwidth.
+rank r renders view (step * world + r), and a sum all-reduce of the gradient per step keeps
+the replicas identical (444 B per anchor + 0.33 MB of MLP weights: 0.44 GB at 1 M anchors).
+Few, large collectives on purpose: xGMI is point-to-point, a ring all-reduce is bound by one
+~153 GB/s link per hop, and many small buckets would pay the per-collective latency once
+each without adding bandwidth — the six per-anchor tensors go in place, the ~40 small MLP
+tensors as one flat bucket.
 
 No collective is needed inside a view (prefilter -> expand -> rasterize -> backward is
 rank-local), and encode/decode shard over chunk streams (codec_driver).  Everything here
@@ -62,39 +63,53 @@ def shard(items: Sequence, r: int | None = None, w: int | None = None) -> list:
     return [it for i, it in enumerate(items) if i % w == r]
 
 
+BIG_TENSOR = 1 << 20        # elements; per-anchor tensors are far above, MLP weights far below
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
-    """Sum (or average) .grad of every parameter across ranks with ONE flat all-reduce.
-    Parameters whose .grad is None on this rank contribute zeros, so ranks may differ in
-    which parameters received gradients (e.g. anchors invisible from one view).  Returns the
-    number of elements reduced."""
+    """Sum (or average) .grad of every parameter across ranks.  The per-anchor tensors (tens to hundreds of MB
+    each, 99.9 % of the bytes) are reduced IN PLACE, one collective each — large enough to run at link
+    bandwidth, and nothing is copied into or out of a bucket; the many small MLP tensors share ONE flat bucket.
+    Which path a parameter takes depends on its SIZE only, so every rank issues the same collectives in the same
+    order.  Parameters whose .grad is None on this rank contribute zeros, so ranks may differ in which parameters
+    received gradients (e.g. anchors invisible from one view).  Returns the number of elements reduced."""
     w = world()
     params = [p for p in params if p.requires_grad]
     if w == 1 or not params:
         return 0
     dev = params[0].device
-    sizes = [p.numel() for p in params]
-    # one bucket, as few passes over it as possible: no zero fill (only gradient-less parameters are zeroed), the
-    # average is part of the collective where the backend has it (RCCL: ReduceOp.AVG), and the reduced bucket
-    # BECOMES the gradients (views) instead of being copied back
-    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    off = 0
-    for p, n in zip(params, sizes):
-        if p.grad is not None:
-            flat[off:off + n].copy_(p.grad.reshape(-1))
-        else:
-            flat[off:off + n].zero_()
-        off += n
-    if average and dist.get_backend() == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        if average:
-            flat /= w
-    off = 0
-    for p, n in zip(params, sizes):
-        p.grad = flat[off:off + n].view_as(p)
-        off += n
-    return int(flat.numel())
+    avg_in_collective = average and dist.get_backend() == "nccl"       # RCCL averages inside the collective
+    op = dist.ReduceOp.AVG if avg_in_collective else dist.ReduceOp.SUM
+    pending = []
+    for p in params:
+        if p.numel() >= BIG_TENSOR:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            elif not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            pending.append((p.grad, dist.all_reduce(p.grad, op=op, async_op=True)))
+    small = [p for p in params if p.numel() < BIG_TENSOR]
+    sizes = [p.numel() for p in small]
+    if small:
+        # no zero fill (only gradient-less parameters are zeroed) and the reduced bucket BECOMES the gradients (views)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for p, n in zip(small, sizes):
+            if p.grad is not None:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                flat[off:off + n].zero_()
+            off += n
+        pending.append((flat, dist.all_reduce(flat, op=op, async_op=True)))
+        off = 0
+        for p, n in zip(small, sizes):
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+    for t, work in pending:
+        work.wait()
+        if average and not avg_in_collective:
+            t /= w
+    return int(sum(p.numel() for p in params))
 
 
 def allreduce_stats(tensors: List[torch.Tensor]) -> None:

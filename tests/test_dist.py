@@ -26,13 +26,15 @@ def _worker(rank, world, port, q):
         lin = torch.nn.Linear(4, 3)
         extra = torch.nn.Parameter(torch.zeros(5))            # gets a gradient on rank 1 only
         frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
-        params = list(lin.parameters()) + [extra, frozen]
+        big1 = torch.nn.Parameter(torch.zeros(10))            # "per-anchor" size class, gradient on rank 1 only
+        cd.BIG_TENSOR = 8                                     # lin.weight (12) and big1 (10) go in place, the rest in the bucket
+        params = list(lin.parameters()) + [extra, frozen, big1]
         # each rank "renders" a different view
         views = [cd.view_for(step, 8) for step in range(4)]
         x = torch.full((2, 4), float(rank + 1))
         loss = lin(x).sum()
         if rank == 1:
-            loss = loss + (extra * torch.arange(5.0)).sum()
+            loss = loss + (extra * torch.arange(5.0)).sum() + (big1 * torch.arange(10.0)).sum()
         loss.backward()
         n = cd.allreduce_gradients(params, average=True)
         stats = [torch.full((3, 1), float(rank + 1)), torch.tensor([rank], dtype=torch.int32)]
@@ -48,7 +50,7 @@ def _worker(rank, world, port, q):
         with cd.local_only():
             alone = (cd.world(), cd.rank(), cd.all_gather_rows(torch.ones(2), [2]).tolist())
         q.put((rank, views, n, lin.weight.grad.clone(), extra.grad.clone(), stats[0].clone(), int(stats[1]),
-               p2.data.clone(), merged, rows, objs, word, alone))
+               p2.data.clone(), merged, rows, objs, word, alone, big1.grad.clone()))
     finally:
         dist.destroy_process_group()
 
@@ -70,7 +72,7 @@ def test_world_size_2_gradient_sync_and_sharding():
         assert p.exitcode == 0
     # views: step s -> ranks take views 2s and 2s+1
     assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
-    assert res[0][2] == res[1][2] == 4 * 3 + 3 + 5
+    assert res[0][2] == res[1][2] == 4 * 3 + 3 + 5 + 10
     # d/dW of sum(W x + b) over 2 rows of constant x = 2 * x ; averaged over x=1 and x=2 -> 3
     for r in (0, 1):
         assert torch.allclose(res[r][3], torch.full((3, 4), 3.0))
@@ -81,6 +83,7 @@ def test_world_size_2_gradient_sync_and_sharding():
     for r in (0, 1):
         assert res[r][9].tolist() == [0, 1, 2, 10, 11, 12, 13, 14] and res[r][11] == "from0"
         assert res[r][12] == (1, 0, [1.0, 1.0])
+        assert torch.allclose(res[r][13], torch.arange(10.0) / 2)      # in-place path, None on rank 0
     assert res[0][10] == [("r", 0), ("r", 1)] and res[1][10] is None
 
 
