@@ -618,6 +618,7 @@ __global__ void __launch_bounds__(64)
         const int mid_l = (int)rintf(m_l / q_l) - lo;        // symbol index nearest to the mean
         int sym_l = 0;
         const int cnt = (int)min((int64_t)64, e - i0);
+        const int last_j = (int)min((int64_t)64, e - 1 - i0);   // the stream's final symbol is not consumed
         for (int jb = 0; jb < cnt; jb += 4) {
             const int src = jb + row;
             const float q4 = __shfl(q_l, src), m4 = __shfl(m_l, src), inv4 = __shfl(inv_l, src);
@@ -630,15 +631,16 @@ __global__ void __launch_bounds__(64)
                 const int j = jb + r;
                 const uint64_t num = dec.num();
                 const uint32_t sm1 = dec.span_m1();
-                const uint32_t rowbits = (uint32_t)(__ballot(ok4 && cdf_le_target(cdf4, sm1, num)) >> (16 * r)) & 0xFFFFu;
+                const uint32_t rowbits = (uint32_t)(__ballot(cdf_le_target(cdf4, sm1, num) & ok4) >> (16 * r)) & 0xFFFFu;
                 const int n_le = __builtin_popcount(rowbits);
                 const int cbs = __builtin_amdgcn_readlane(cb4, 16 * r);
                 int sym;
                 uint32_t c_low, c_high;
-                if ((n_le >= 1 && (n_le <= 15 || cbs + 15 >= max_sym)) || (n_le == 0 && cbs == 0)) {
-                    // passing lanes form a prefix of the row (the CDF is strictly increasing): the symbol is the
-                    // last of them and both of its bounds are in the window
-                    const int rel = max(n_le - 1, 0);
+                if ((uint32_t)(n_le - 1) < 15u) {
+                    // 1..15 lanes pass and they form a prefix of the row (the CDF is strictly increasing): the symbol
+                    // is the last of them and both of its bounds are in the window.  0 or 16 passing lanes (target
+                    // outside the window, or the window touching an end of the alphabet) take the search below.
+                    const int rel = n_le - 1;
                     sym = cbs + rel;
                     c_low = bcast_u(cdf4, 16 * r + rel);
                     c_high = sym >= max_sym ? AC_TOP : bcast_u(cdf4, 16 * r + rel + 1);
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(64)
                     }
                 }
                 sym_l = lane == j ? sym : sym_l;
-                if (i0 + j != e - 1) dec.consume(c_low, c_high);
+                if (j != last_j) dec.consume(c_low, c_high);
             }
         }
         if (i < e) x_out[i] = (float)(sym_l + lo) * q_l;
