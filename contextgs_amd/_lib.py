@@ -82,10 +82,12 @@ SIGNATURES = {
     "cgs_rowcat_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_ctx_gather_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p]),
-    "cgs_noise_quant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, C.c_uint64,
-                                    c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_noise_quant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                    C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "cgs_noise_quant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                    C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p]),
+                                    C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "cgs_level_rate_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "cgs_level_rate_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64] + [c_void_p] * 8),
     "cgs_eb_likelihood_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

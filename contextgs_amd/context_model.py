@@ -37,6 +37,7 @@ Q_FEAT0, Q_SCALING0, Q_OFFSETS0 = 1, 0.001, 0.2      # :1564-1566
 import os as _os
 LAZY_MODE = int(_os.environ.get("CGS_LAZY_MODE", "2"))   # tuning knob: 0 gather all, 1 defer feat, 2 defer feat+scaling+offsets
 FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip it to compare with the torch composition)
+ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = gather into coding order first
 
 
 def mapping_to_orign(mapping_list, L, mask=None):                       # :1768-1787
@@ -371,15 +372,24 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         in_order = lambda t: t
     else:
         in_order = lambda t: gather_unique(t, perm, full)
-    feat_l = torch.split(in_order(feat), sizes)
-    scal_l = torch.split(in_order(grid_scaling), sizes)
-    off_l = torch.split(in_order(grid_offsets), sizes)
+    # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
+    fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
+    # When every level takes the fused path, features / scaling / offsets are not gathered at all: the level kernels
+    # read their rows of the parameter tensors through perm[lo:hi] and scatter the gradients back (ctx_ops.RowSource)
+    row_src = None
+    if (fused and ROW_SOURCE and not c.get("identity") and (not keep_stats or choose_mask is not None)
+            and all(_mlp.supported(pc.get_grid_mlp[i_]) for (i_, _t, _o, _a) in c["plan"])
+            and grid_offsets.dim() == 3 and (feat.requires_grad or grid_scaling.requires_grad or grid_offsets.requires_grad)):
+        row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, full)
+        feat_l = scal_l = off_l = None
+    else:
+        feat_l = torch.split(in_order(feat), sizes)
+        scal_l = torch.split(in_order(grid_scaling), sizes)
+        off_l = torch.split(in_order(grid_offsets), sizes)
     hyp_l = torch.split(in_order(hyper_feat), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
-    # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
-    fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
     # the fused levels write their outputs side by side into these (coding order), so no cat is needed at the end
     n_tot, row_off, joined = int(perm.shape[0]), 0, fused
     if fused:
@@ -421,9 +431,13 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             if use_fused:
                 # step sizes + noise (:1603-1616) in one launch; the rate of the chosen rows is one more (rate_model)
                 sl = slice(row_off, row_off + n_l)
-                hf, hs, ho, Q_all = _ctx.noise_quant(feat_l[j], scal_l[j], off_l[j].reshape(n_l, 3 * K), qadj,
-                                                     (Q_FEAT0, Q_SCALING0, Q_OFFSETS0),
-                                                     outs=(big_f[sl], big_s[sl], big_o[sl]) if joined else None)
+                outs = (big_f[sl], big_s[sl], big_o[sl]) if joined else None
+                if row_src is not None:
+                    hf, hs, ho, Q_all = _ctx.noise_quant(None, None, None, qadj, (Q_FEAT0, Q_SCALING0, Q_OFFSETS0),
+                                                         outs=outs, src=row_src, rows=perm[row_off:row_off + n_l])
+                else:
+                    hf, hs, ho, Q_all = _ctx.noise_quant(feat_l[j], scal_l[j], off_l[j].reshape(n_l, 3 * K), qadj,
+                                                         (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), outs=outs)
                 row_off += n_l
                 if keep_stats:
                     # chosen_rows lists the chosen anchors level by level: this level's are [lo, lo + len(loc))

@@ -127,17 +127,18 @@ __device__ __forceinline__ float ctx_step(float q0, float qadj) { return fmaxf(q
 // 16 lanes per row: a wave instruction touches 4 rows x 64 contiguous bytes of each tensor
 __global__ void __launch_bounds__(256)
     noise_quant_fwd_kernel(const float *__restrict__ xf, const float *__restrict__ xs, const float *__restrict__ xo,
-                           const float *__restrict__ qadj, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
-                           float q0s, float q0o, float *__restrict__ yf, float *__restrict__ ys,
-                           float *__restrict__ yo, float *__restrict__ Q) {
+                           const float *__restrict__ qadj, const int64_t *__restrict__ rows, int64_t n, int D, int S,
+                           int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ yf,
+                           float *__restrict__ ys, float *__restrict__ yo, float *__restrict__ Q) {
     const int l = threadIdx.x & 15;
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
         const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
                     qo = ctx_step(q0o, qadj[r * 3 + 2]);
         if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);
-        for (int c = l; c < D; c += 16) yf[r * D + c] = xf[r * D + c] + ctx_noise(seed, 0, (uint64_t)r * D + c) * qf;
-        for (int c = l; c < S; c += 16) ys[r * S + c] = xs[r * S + c] + ctx_noise(seed, 1, (uint64_t)r * S + c) * qs;
-        for (int c = l; c < O; c += 16) yo[r * O + c] = xo[r * O + c] + ctx_noise(seed, 2, (uint64_t)r * O + c) * qo;
+        const int64_t sr = rows ? rows[r] : r;        // source row: the level's slice of the coding-order permutation
+        for (int c = l; c < D; c += 16) yf[r * D + c] = xf[sr * D + c] + ctx_noise(seed, 0, (uint64_t)r * D + c) * qf;
+        for (int c = l; c < S; c += 16) ys[r * S + c] = xs[sr * S + c] + ctx_noise(seed, 1, (uint64_t)r * S + c) * qs;
+        for (int c = l; c < O; c += 16) yo[r * O + c] = xo[sr * O + c] + ctx_noise(seed, 2, (uint64_t)r * O + c) * qo;
     }
 }
 
@@ -149,17 +150,28 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
-// d_x = d_y (identity, done by the caller);  d_qadj[r,k] = (sum_c d_y[r,c] u[r,c] + dQ_ext[r,k]) * dQ/dqadj
+// d_x = d_y: identity, left to the caller — or, when the forward read its rows through `rows`, scattered here into the
+// FULL-size gradients dxf/dxs/dxo at those rows (a missing d_y scatters zeros);
+// d_qadj[r,k] = (sum_c d_y[r,c] u[r,c] + dQ_ext[r,k]) * dQ/dqadj
 __global__ void __launch_bounds__(256)
     noise_quant_bwd_kernel(const float *__restrict__ dyf, const float *__restrict__ dys, const float *__restrict__ dyo,
                            const float *__restrict__ dQ_ext, const float *__restrict__ qadj, int64_t n, int D, int S,
-                           int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ dqadj) {
+                           int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ dqadj,
+                           const int64_t *__restrict__ rows, float *__restrict__ dxf, float *__restrict__ dxs,
+                           float *__restrict__ dxo) {
     const int l = threadIdx.x & 15;
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
         float af = 0.f, as = 0.f, ao = 0.f;
-        if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise(seed, 0, (uint64_t)r * D + c);
-        if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise(seed, 1, (uint64_t)r * S + c);
-        if (dyo) for (int c = l; c < O; c += 16) ao += dyo[r * O + c] * ctx_noise(seed, 2, (uint64_t)r * O + c);
+        if (rows) {
+            const int64_t sr = rows[r];
+            for (int c = l; c < D; c += 16) { const float g = dyf ? dyf[r * D + c] : 0.f; dxf[sr * D + c] = g; af += g * ctx_noise(seed, 0, (uint64_t)r * D + c); }
+            for (int c = l; c < S; c += 16) { const float g = dys ? dys[r * S + c] : 0.f; dxs[sr * S + c] = g; as += g * ctx_noise(seed, 1, (uint64_t)r * S + c); }
+            for (int c = l; c < O; c += 16) { const float g = dyo ? dyo[r * O + c] : 0.f; dxo[sr * O + c] = g; ao += g * ctx_noise(seed, 2, (uint64_t)r * O + c); }
+        } else {
+            if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise(seed, 0, (uint64_t)r * D + c);
+            if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise(seed, 1, (uint64_t)r * S + c);
+            if (dyo) for (int c = l; c < O; c += 16) ao += dyo[r * O + c] * ctx_noise(seed, 2, (uint64_t)r * O + c);
+        }
         af = sum16(af);
         as = sum16(as);
         ao = sum16(ao);
@@ -173,28 +185,30 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo, const float *qadj, int64_t n,
-                                   int D, int S, int O, uint64_t seed, float q0f, float q0s, float q0o, float *yf,
-                                   float *ys, float *yo, float *Q, void *stream) {
+extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo, const float *qadj,
+                                   const int64_t *rows, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
+                                   float q0s, float q0o, float *yf, float *ys, float *yo, float *Q, void *stream) {
     if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_fwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!xf || !xs || !xo || !qadj || !yf || !ys || !yo || !Q) { cgs_set_error("noise_quant_fwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(noise_quant_fwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
-                       xo, qadj, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q);
+                       xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
 
 extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
                                    const float *qadj, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
-                                   float q0s, float q0o, float *dqadj, void *stream) {
+                                   float q0s, float q0o, float *dqadj, const int64_t *rows, float *dxf, float *dxs,
+                                   float *dxo, void *stream) {
     if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_bwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!qadj || !dqadj) { cgs_set_error("noise_quant_bwd: NULL"); return CGS_ERR_ARG; }
+    if (rows && (!dxf || !dxs || !dxo)) { cgs_set_error("noise_quant_bwd: rows without dxf/dxs/dxo"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(noise_quant_bwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dyf,
-                       dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj);
+                       dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj, rows, dxf, dxs, dxo);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -83,50 +83,114 @@ _seed_counter = itertools.count(1)
 
 
 def next_seed() -> int:
-    """A fresh 64-bit stream id per call, derived from torch's seed without a device sync."""
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+    """A fresh 63-bit stream id per call, derived from torch's seed without a device sync (63 bits: the value
+    travels through autograd.Function.apply, whose argument recorder (torch.profiler record_shapes) only takes int64)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
+
+
+class RowSource:
+    """The three per-anchor parameter tensors (features [N,D], scaling [N,S], offsets [N,K,3]) read THROUGH a row
+    index by the level kernels, instead of being gathered into coding order first.
+
+    Forward: `noise_quant(..., src=self, rows=perm[lo:hi])` reads rows perm[lo:hi] in place.  Backward: every
+    level scatters the gradients of its (distinct) rows straight into one full-size buffer per tensor, and the
+    node behind `self.token` — which autograd runs after all the levels, because each of them consumed the token —
+    hands the three buffers to the parameters.  Compared with gather -> split -> ... -> cat -> index_copy this
+    drops a full read+write pass over the tensors in each direction and the per-level gradient concatenation."""
+
+    def __init__(self, feat, scal, off, complete: bool):
+        self.shapes = (feat.shape, scal.shape, off.shape)
+        self.f, self.s = _c(feat.detach()), _c(scal.detach())
+        self.o = _c(off.detach()).reshape(off.shape[0], -1)
+        _lib.require_device(self.f, self.s, self.o)
+        self.complete = bool(complete)          # the levels' rows cover every row: no zero fill needed
+        self.rows_read = self.rows_written = 0
+        self.grads = None
+        self.token = _RowSourceFn.apply(self, feat, scal, off)
+
+    def grad_buffers(self):
+        if self.grads is None:
+            n, (D, S, O) = self.f.shape[0], (self.f.shape[1], self.s.shape[1], self.o.shape[1])
+            flat = (torch.empty if self.complete else torch.zeros)(n * (D + S + O), dtype=_f32, device=self.f.device)
+            gf, gs, go = torch.split(flat, [n * D, n * S, n * O])
+            self.grads = (gf.view(n, D), gs.view(n, S), go.view(n, O))
+        return self.grads
+
+
+class _RowSourceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, feat, scal, off):
+        ctx.src = src
+        return feat.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _g):
+        src = ctx.src
+        if src.rows_written != src.rows_read:
+            raise RuntimeError("RowSource: a level that read rows in the forward did not run its backward "
+                               f"({src.rows_written} of {src.rows_read} rows have gradients)")
+        gf, gs, go = src.grad_buffers()
+        src.grads = None
+        need = ctx.needs_input_grad
+        return (None, gf.view(src.shapes[0]) if need[1] else None, gs.view(src.shapes[1]) if need[2] else None,
+                go.view(src.shapes[2]) if need[3] else None)
 
 
 class _NoiseQuant(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xf, xs, xo, qadj, seed, q0, outs):
-        xf, xs, xo, qadj = _c(xf), _c(xs), _c(xo), _c(qadj)
+    def forward(ctx, xf, xs, xo, qadj, seed, q0, outs, src, rows, token):
+        qadj = _c(qadj)
+        if src is not None:
+            xf, xs, xo = src.f, src.s, src.o
+            n = int(rows.shape[0])
+            assert rows.dtype == torch.int64 and rows.is_contiguous()
+            src.rows_read += n
+        else:
+            xf, xs, xo = _c(xf), _c(xs), _c(xo)
+            n = xf.shape[0]
         _lib.require_device(xf, xs, xo, qadj)
-        n = xf.shape[0]
+        D, S, O = xf.shape[1], xs.shape[1], xo.shape[1]
         if outs is None:
-            yf, ys, yo = torch.empty_like(xf), torch.empty_like(xs), torch.empty_like(xo)
+            mk = lambda w: torch.empty(n, w, dtype=_f32, device=qadj.device)
+            yf, ys, yo = mk(D), mk(S), mk(O)
         else:           # row slices of caller-owned buffers (the level outputs land side by side: no cat afterwards)
             yf, ys, yo = outs
-            assert yf.shape == xf.shape and ys.shape == xs.shape and yo.shape == xo.shape
+            assert yf.shape == (n, D) and ys.shape == (n, S) and yo.shape == (n, O)
             assert yf.is_contiguous() and ys.is_contiguous() and yo.is_contiguous()
-        Q = torch.empty(n, 3, dtype=_f32, device=xf.device)
+        Q = torch.empty(n, 3, dtype=_f32, device=qadj.device)
         _lib.check(_lib.lib().cgs_noise_quant_fwd(
-            _lib.ptr(xf), _lib.ptr(xs), _lib.ptr(xo), _lib.ptr(qadj), n, xf.shape[1], xs.shape[1], xo.shape[1], seed,
+            _lib.ptr(xf), _lib.ptr(xs), _lib.ptr(xo), _lib.ptr(qadj), _lib.ptr(rows), n, D, S, O, seed,
             q0[0], q0[1], q0[2], _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.current_stream()),
             "cgs_noise_quant_fwd")
-        ctx.save_for_backward(qadj)
-        ctx.dims, ctx.seed, ctx.q0 = (n, xf.shape[1], xs.shape[1], xo.shape[1]), seed, q0
+        ctx.save_for_backward(qadj, rows)
+        ctx.dims, ctx.seed, ctx.q0, ctx.src = (n, D, S, O), seed, q0, src
         return yf, ys, yo, Q
 
     @staticmethod
     def backward(ctx, gf, gs, go, gQ):
-        (qadj,) = ctx.saved_tensors
+        qadj, rows = ctx.saved_tensors
         n, D, S, O = ctx.dims
+        src = ctx.src
         gf, gs, go, gQ = (None if t is None else _c(t) for t in (gf, gs, go, gQ))
-        dq = None
-        if ctx.needs_input_grad[3]:
-            dq = torch.empty(n, 3, dtype=_f32, device=qadj.device)
+        dq = torch.empty(n, 3, dtype=_f32, device=qadj.device) if (ctx.needs_input_grad[3] or src is not None) else None
+        dx = src.grad_buffers() if src is not None else (None, None, None)
+        if dq is not None:
             _lib.check(_lib.lib().cgs_noise_quant_bwd(
                 _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), _lib.ptr(qadj), n, D, S, O, ctx.seed, ctx.q0[0],
-                ctx.q0[1], ctx.q0[2], _lib.ptr(dq), _lib.current_stream()), "cgs_noise_quant_bwd")
-        return gf, gs, go, dq, None, None, None
+                ctx.q0[1], ctx.q0[2], _lib.ptr(dq), _lib.ptr(rows) if src is not None else None, _lib.ptr(dx[0]),
+                _lib.ptr(dx[1]), _lib.ptr(dx[2]), _lib.current_stream()), "cgs_noise_quant_bwd")
+        if src is not None:
+            src.rows_written += n
+            return None, None, None, dq, None, None, None, None, None, qadj.new_zeros(1)
+        return gf, gs, go, dq, None, None, None, None, None, None
 
 
-def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None):
+def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None, src=None, rows=None):
     """(xf + u Qf, xs + u Qs, xo + u Qo, Q[n,3]) with Q = clamp(q0 (1 + tanh(qadj)), 1e-9), u ~ U[-0.5, 0.5).
-    outs = (yf, ys, yo) optionally names the (contiguous) tensors to write the three results into."""
+    outs = (yf, ys, yo) optionally names the (contiguous) tensors to write the three results into.
+    src / rows: read x from rows `rows` of a RowSource instead of xf/xs/xo (which are then ignored)."""
     return _NoiseQuant.apply(xf, xs, xo, qadj, next_seed() if seed is None else int(seed),
-                             tuple(float(v) for v in q0), outs)
+                             tuple(float(v) for v in q0), outs, src, rows, None if src is None else src.token)
 
 
 class _LevelRate(torch.autograd.Function):

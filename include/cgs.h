@@ -261,17 +261,23 @@ int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
  *   yf = xf + u * Q[r,0], ys = xs + u * Q[r,1], yo = xo + u * Q[r,2],  u ~ U[-0.5, 0.5)
  * xf [n,D], xs [n,S], xo [n,O], qadj/Q [n,3].  u is a counter-based hash of (seed, tensor,
  * element) that the backward regenerates; the reference draws it with torch's Philox
- * uniform_, so streams differ while the distribution is the same.  The backward returns
- * d_qadj only (d_x == d_y): dy* may be NULL (no gradient), dQ_ext [n,3] is the gradient
- * that reaches Q from elsewhere (the rate term), may be NULL. */
+ * uniform_, so streams differ while the distribution is the same.
+ * rows (may be NULL): int64 [n], the forward reads row rows[r] of xf/xs/xo instead of row r — the
+ * level's slice of the coding-order permutation, so the permuted copies of the parameter tensors
+ * are never materialised; noise and outputs stay indexed by r.
+ * The backward returns d_qadj; d_x == d_y is left to the caller unless rows is given, in which case
+ * the rows of the FULL-size gradients dxf/dxs/dxo named by rows are written here (distinct rows; a
+ * NULL dy* scatters zeros).  dy* may be NULL (no gradient); dQ_ext [n,3] is the gradient that
+ * reaches Q from elsewhere (the rate term), may be NULL. */
 int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo,
-                        const float *qadj, int64_t n, int D, int S, int O,
-                        uint64_t seed, float q0f, float q0s, float q0o, float *yf,
-                        float *ys, float *yo, float *Q, void *stream);
+                        const float *qadj, const int64_t *rows, int64_t n, int D,
+                        int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
+                        float *yf, float *ys, float *yo, float *Q, void *stream);
 int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
                         const float *dQ_ext, const float *qadj, int64_t n, int D,
                         int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
-                        float *dqadj, void *stream);
+                        float *dqadj, const int64_t *rows, float *dxf, float *dxs,
+                        float *dxo, void *stream);
 /* Bits of the chosen rows of one level (:1658-1669 with utils/entropy_models.py:30-50):
  * for s < n_sub, r = loc[s] (row inside the level; NULL = s):
  *   sums[0] += bits(yf[r], mean_f, scale_f, Q[r,0])      sums[1] += bits(ys[r], ..., Q[r,1])

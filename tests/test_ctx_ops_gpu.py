@@ -159,3 +159,50 @@ def test_ctx_assemble_csr_backward_equals_scatter_add(n_par, n_child):
     exp = torch.autograd.grad((ref * w).sum(), [anchor, base_f, base_s, own])
     for a, b in zip(got, exp):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("complete", [True, False])
+def test_noise_quant_row_source_equals_gather_then_noise_quant(complete):
+    """RowSource path (the level kernels read rows of the parameter tensors through perm[lo:hi] and scatter the
+    gradients back) == gather into coding order, split, noise_quant per level, cat, index_copy: same outputs with
+    the same seeds, same parameter gradients bit for bit, incl. a row set that does not cover every row."""
+    from contextgs_amd import ctx_ops as ops
+    torch.manual_seed(3)
+    N, D, S, K = 700, 50, 6, 10
+    dev = "cuda"
+    perm_all = torch.randperm(N, device=dev)
+    perm = perm_all if complete else perm_all[: N - 90]
+    sizes = [120, 0, perm.shape[0] - 120]
+    mk = lambda *s: torch.randn(*s, device=dev)
+    base = [mk(N, D), mk(N, S), mk(N, K, 3)]
+    qadjs = [mk(n, 3) for n in sizes]
+    wf, ws, wo = mk(perm.shape[0], D), mk(perm.shape[0], S), mk(perm.shape[0], 3 * K)
+    q0 = (1.0, 0.001, 0.2)
+
+    def run(row_source):
+        feat, scal, off = (t.clone().requires_grad_(True) for t in base)
+        qs = [q.clone().requires_grad_(True) for q in qadjs]
+        outs, lo = [], 0
+        if row_source:
+            src = ops.RowSource(feat, scal, off, complete)
+            for j, n in enumerate(sizes):
+                outs.append(ops.noise_quant(None, None, None, qs[j], q0, seed=100 + j, src=src, rows=perm[lo:lo + n]))
+                lo += n
+        else:
+            fp, sp, op = feat[perm], scal[perm], off[perm].reshape(-1, 3 * K)
+            for j, n in enumerate(sizes):
+                outs.append(ops.noise_quant(fp[lo:lo + n], sp[lo:lo + n], op[lo:lo + n], qs[j], q0, seed=100 + j))
+                lo += n
+        yf, ys, yo = (torch.cat([o[t] for o in outs]) for t in range(3))
+        Q = torch.cat([o[3] for o in outs])
+        loss = (yf * wf).sum() + (ys * ws).sum() + (yo * wo).sum() + (Q * Q).sum()
+        loss.backward()
+        return (yf, ys, yo, Q), (feat.grad, scal.grad, off.grad), [q.grad for q in qs]
+
+    a, b = run(True), run(False)
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[1], b[1]):
+        assert x.shape == y.shape and torch.equal(x, y)
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
