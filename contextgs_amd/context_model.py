@@ -38,6 +38,7 @@ import os as _os
 LAZY_MODE = int(_os.environ.get("CGS_LAZY_MODE", "2"))   # tuning knob: 0 gather all, 1 defer feat, 2 defer feat+scaling+offsets
 FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip it to compare with the torch composition)
 ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = gather into coding order first
+RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
 
 
 def mapping_to_orign(mapping_list, L, mask=None):                       # :1768-1787
@@ -309,6 +310,33 @@ def _rowcat_ok(x):
             and (x[0].numel() * 4) % 16 == 0)
 
 
+class _SplitUse(torch.autograd.Function):
+    """x -> (x, x[loc]) for a tensor with exactly two consumers: one takes every row, one the DISTINCT rows `loc`.
+    The backward adds the second consumer's row gradients into the first one's buffer in place (index_add_ on the
+    chosen rows only) instead of scattering them into an N-row zero buffer that autograd then adds in full."""
+
+    @staticmethod
+    def forward(ctx, x, loc):
+        ctx.save_for_backward(loc)
+        ctx.shape = x.shape
+        return x.view_as(x), x.index_select(0, loc)
+
+    @staticmethod
+    def backward(ctx, g_all, g_sub):
+        (loc,) = ctx.saved_tensors
+        if g_all is None:
+            g_all = torch.zeros(ctx.shape, dtype=g_sub.dtype, device=g_sub.device)
+        elif not g_all.is_contiguous():
+            g_all = g_all.contiguous()
+        if g_sub is not None:
+            g_all.index_add_(0, loc, g_sub)
+        return g_all, None
+
+
+def split_use(x, loc):
+    return _SplitUse.apply(x, loc)
+
+
 def gather_unique(x, idx, complete=False):
     """x[idx] for distinct rows idx; complete = idx is a permutation of ALL rows of x."""
     if _rowcat_ok(x):                # one-source rowcat: row gather forward, plain row scatter backward (HIP)
@@ -423,6 +451,11 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             # reference evaluates all 175 outputs for all rows and throws 85-100 % of them away; here the
             # second layer runs with its 3 step-size rows on every anchor and with all rows on the chosen
             # anchors only (identical values: the same fp32 fma chains).
+            feat_sub = None
+            if use_fused and keep_stats and feat_in.requires_grad:
+                # feat_in has two consumers, the step-size MLP on every row and the 172-output MLP on the chosen rows:
+                # one node hands both their inputs and merges the two gradients row-wise (no N-row buffer + add)
+                feat_in, feat_sub = split_use(feat_in, loc)
             if subset_mode:
                 seq = pc.get_grid_mlp[i]
                 D_ = pc.feat_dim
@@ -432,9 +465,11 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 # step sizes + noise (:1603-1616) in one launch; the rate of the chosen rows is one more (rate_model)
                 sl = slice(row_off, row_off + n_l)
                 outs = (big_f[sl], big_s[sl], big_o[sl]) if joined else None
+                side = None
                 if row_src is not None:
+                    side = _ctx.RateSide() if (keep_stats and RATE_SIDE) else None
                     hf, hs, ho, Q_all = _ctx.noise_quant(None, None, None, qadj, (Q_FEAT0, Q_SCALING0, Q_OFFSETS0),
-                                                         outs=outs, src=row_src, rows=perm[row_off:row_off + n_l])
+                                                         outs=outs, src=row_src, rows=perm[row_off:row_off + n_l], side=side)
                 else:
                     hf, hs, ho, Q_all = _ctx.noise_quant(feat_l[j], scal_l[j], off_l[j].reshape(n_l, 3 * K), qadj,
                                                          (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), outs=outs)
@@ -446,7 +481,8 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                         lo_ = sum(int(l_.shape[0]) for l_ in locs[:j])
                         span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
                     levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
-                                       yo=ho, Q=Q_all, pred=grid_mlp(pc, i, gather_unique(feat_in, loc)), chosen=span))
+                                       yo=ho, Q=Q_all, chosen=span, side=side,
+                                       pred=grid_mlp(pc, i, feat_sub if feat_sub is not None else gather_unique(feat_in, loc))))
                 feat_q.append(hf)
                 scal_q.append(hs)
                 off_q.append(ho)
@@ -556,7 +592,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
             else:
                 m_rows, g_rows = binary_grid_masks.reshape(n, K), L["rows"]
             sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"], m_rows, g_rows, x_means,
-                                   _enc.use_clamp, K)
+                                   _enc.use_clamp, K, side=L.get("side"))
             fused_sums.append(sums)
             n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
             level_rows.append(n_sub)

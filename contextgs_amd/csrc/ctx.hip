@@ -158,15 +158,20 @@ __global__ void __launch_bounds__(256)
                            const float *__restrict__ dQ_ext, const float *__restrict__ qadj, int64_t n, int D, int S,
                            int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ dqadj,
                            const int64_t *__restrict__ rows, float *__restrict__ dxf, float *__restrict__ dxs,
-                           float *__restrict__ dxo) {
+                           float *__restrict__ dxo, const int32_t *__restrict__ side_map,
+                           const float *__restrict__ sf, const float *__restrict__ ss, const float *__restrict__ so,
+                           const float *__restrict__ sQ) {
     const int l = threadIdx.x & 15;
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
-        float af = 0.f, as = 0.f, ao = 0.f;
+        float af = 0.f, as = 0.f, ao = 0.f, side_q = 0.f;
         if (rows) {
             const int64_t sr = rows[r];
-            for (int c = l; c < D; c += 16) { const float g = dyf ? dyf[r * D + c] : 0.f; dxf[sr * D + c] = g; af += g * ctx_noise(seed, 0, (uint64_t)r * D + c); }
-            for (int c = l; c < S; c += 16) { const float g = dys ? dys[r * S + c] : 0.f; dxs[sr * S + c] = g; as += g * ctx_noise(seed, 1, (uint64_t)r * S + c); }
-            for (int c = l; c < O; c += 16) { const float g = dyo ? dyo[r * O + c] : 0.f; dxo[sr * O + c] = g; ao += g * ctx_noise(seed, 2, (uint64_t)r * O + c); }
+            // sm >= 0: this row is in the rate subset and its rate gradients sit in row sm of the compact side arrays
+            const int64_t sm = side_map ? (int64_t)side_map[r] : -1;
+            for (int c = l; c < D; c += 16) { float g = dyf ? dyf[r * D + c] : 0.f; if (sm >= 0) g += sf[sm * D + c]; dxf[sr * D + c] = g; af += g * ctx_noise(seed, 0, (uint64_t)r * D + c); }
+            for (int c = l; c < S; c += 16) { float g = dys ? dys[r * S + c] : 0.f; if (sm >= 0) g += ss[sm * S + c]; dxs[sr * S + c] = g; as += g * ctx_noise(seed, 1, (uint64_t)r * S + c); }
+            for (int c = l; c < O; c += 16) { float g = dyo ? dyo[r * O + c] : 0.f; if (sm >= 0) g += so[sm * O + c]; dxo[sr * O + c] = g; ao += g * ctx_noise(seed, 2, (uint64_t)r * O + c); }
+            if (sm >= 0 && l < 3) side_q = sQ[sm * 3 + l];
         } else {
             if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise(seed, 0, (uint64_t)r * D + c);
             if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise(seed, 1, (uint64_t)r * S + c);
@@ -179,6 +184,7 @@ __global__ void __launch_bounds__(256)
             const float q0 = l == 0 ? q0f : (l == 1 ? q0s : q0o);
             float g = l == 0 ? af : (l == 1 ? as : ao);
             if (dQ_ext) g += dQ_ext[r * 3 + l];
+            g += side_q;
             const float t = tanhf(qadj[r * 3 + l]);
             dqadj[r * 3 + l] = (q0 * (1.f + t) >= 1e-9f) ? g * q0 * (1.f - t * t) : 0.f;
         }
@@ -201,14 +207,16 @@ extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float
 extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
                                    const float *qadj, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
                                    float q0s, float q0o, float *dqadj, const int64_t *rows, float *dxf, float *dxs,
-                                   float *dxo, void *stream) {
+                                   float *dxo, const int32_t *side_map, const float *side_f, const float *side_s,
+                                   const float *side_o, const float *side_Q, void *stream) {
     if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_bwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!qadj || !dqadj) { cgs_set_error("noise_quant_bwd: NULL"); return CGS_ERR_ARG; }
     if (rows && (!dxf || !dxs || !dxo)) { cgs_set_error("noise_quant_bwd: rows without dxf/dxs/dxo"); return CGS_ERR_ARG; }
+    if (side_map && (!rows || !side_f || !side_s || !side_o || !side_Q)) { cgs_set_error("noise_quant_bwd: side_map needs rows and the four side arrays"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(noise_quant_bwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dyf,
-                       dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj, rows, dxf, dxs, dxo);
+                       dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj, rows, dxf, dxs, dxo, side_map, side_f, side_s, side_o, side_Q);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -288,12 +296,13 @@ __global__ void __launch_bounds__(256)
                           const float *__restrict__ x_means, int use_clamp, int64_t n_sub, int D, int K,
                           int64_t ldp, const float *__restrict__ g_sums, float *__restrict__ d_pred, float *__restrict__ d_yf,
                           float *__restrict__ d_ys, float *__restrict__ d_yo, float *__restrict__ dQ,
-                          float *__restrict__ d_masks) {
+                          float *__restrict__ d_masks, int compact) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = D + 6 + 3 * K, P = 2 * E;
     const float g0 = g_sums[0], g1 = g_sums[1], g2 = g_sums[2];
     for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
         const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : s;
+        const int64_t ro = compact ? s : r;         // output row of d_yf / d_ys / d_yo / dQ
         float gq[3] = {0.f, 0.f, 0.f};
         if (lane < ldp - P) d_pred[s * ldp + P + lane] = 0.f;   // outputs beyond the mean/scale block (the step sizes)
         for (int e = lane; e < E; e += 64) {
@@ -304,7 +313,7 @@ __global__ void __launch_bounds__(256)
             d_pred[s * ldp + t.mcol] = g.gm;
             d_pred[s * ldp + t.scol] = g.gs;
             float *dx = t.kind == 0 ? d_yf : (t.kind == 1 ? d_ys : d_yo);
-            dx[t.xoff] = g.gx;
+            dx[t.xoff + (ro - r) * (t.kind == 0 ? D : (t.kind == 1 ? 6 : 3 * K))] = g.gx;
             // the offsets' bits are weighted by the (straight-through) binary mask: d bits*w / d w = bits (:1664)
             if (d_masks && t.kind == 2) atomicAdd(&d_masks[t.moff], g2 * rate_bits(rt));
             gq[0] += t.kind == 0 ? g.gq : 0.f;
@@ -314,7 +323,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float v = wave_sum(gq[k]);
-            if (lane == 0) dQ[r * 3 + k] = v;
+            if (lane == 0) dQ[ro * 3 + k] = v;
         }
     }
 }
@@ -345,7 +354,7 @@ extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float 
                                   const float *pred, const float *masks, const int64_t *grows, const float *x_means,
                                   int use_clamp, int64_t n_sub, int D, int K, int64_t ldpred, const float *g_sums,
                                   float *d_pred, float *d_yf, float *d_ys, float *d_yo, float *dQ, float *d_masks,
-                                  void *stream) {
+                                  int compact, void *stream) {
     int rc = level_rate_check(yf, ys, yo, Q, pred, n_sub, D, K, ldpred, "level_rate_bwd");
     if (rc) return rc;
     if (n_sub == 0) return CGS_OK;
@@ -356,7 +365,7 @@ extern "C" int cgs_level_rate_bwd(const float *yf, const float *ys, const float 
     CgsProfScope prof(CGS_PROF_RATE_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(level_rate_bwd_kernel, dim3(stream_grid(n_sub, 4 * 4)), dim3(256), 0, (hipStream_t)stream, yf, ys, yo,
                        Q, loc, pred, masks, grows, use_clamp ? x_means : nullptr, use_clamp, n_sub, D, K, ldpred, g_sums, d_pred,
-                       d_yf, d_ys, d_yo, dQ, masks ? d_masks : nullptr);
+                       d_yf, d_ys, d_yo, dQ, masks ? d_masks : nullptr, compact);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -136,9 +136,22 @@ class _RowSourceFn(torch.autograd.Function):
                 go.view(src.shapes[2]) if need[3] else None)
 
 
+class RateSide:
+    """Hand-over of one level's rate gradients from _LevelRate.backward to _NoiseQuant.backward.
+
+    The level outputs have two consumers: everything downstream (dense gradients) and the rate of the ~15 % chosen
+    rows.  Instead of scattering the rate gradients into N-row zero buffers that autograd then adds to the dense
+    ones (a fill and three full-size adds per level), _LevelRate leaves them COMPACT here and returns no gradient;
+    the noise_quant backward — which autograd runs after every consumer of its outputs, so after _LevelRate — adds
+    row map[r] of them on the fly.  Needs the RowSource path (the kernel that scatters is the one that adds)."""
+
+    def __init__(self):
+        self.map = self.f = self.s = self.o = self.q = None
+
+
 class _NoiseQuant(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xf, xs, xo, qadj, seed, q0, outs, src, rows, token):
+    def forward(ctx, xf, xs, xo, qadj, seed, q0, outs, src, rows, token, side):
         qadj = _c(qadj)
         if src is not None:
             xf, xs, xo = src.f, src.s, src.o
@@ -163,7 +176,7 @@ class _NoiseQuant(torch.autograd.Function):
             q0[0], q0[1], q0[2], _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.current_stream()),
             "cgs_noise_quant_fwd")
         ctx.save_for_backward(qadj, rows)
-        ctx.dims, ctx.seed, ctx.q0, ctx.src = (n, D, S, O), seed, q0, src
+        ctx.dims, ctx.seed, ctx.q0, ctx.src, ctx.side = (n, D, S, O), seed, q0, src, side
         return yf, ys, yo, Q
 
     @staticmethod
@@ -174,28 +187,34 @@ class _NoiseQuant(torch.autograd.Function):
         gf, gs, go, gQ = (None if t is None else _c(t) for t in (gf, gs, go, gQ))
         dq = torch.empty(n, 3, dtype=_f32, device=qadj.device) if (ctx.needs_input_grad[3] or src is not None) else None
         dx = src.grad_buffers() if src is not None else (None, None, None)
+        side = ctx.side if (ctx.side is not None and ctx.side.map is not None and src is not None) else None
+        sd = (side.map, side.f, side.s, side.o, side.q) if side is not None else (None,) * 5
         if dq is not None:
             _lib.check(_lib.lib().cgs_noise_quant_bwd(
                 _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), _lib.ptr(qadj), n, D, S, O, ctx.seed, ctx.q0[0],
                 ctx.q0[1], ctx.q0[2], _lib.ptr(dq), _lib.ptr(rows) if src is not None else None, _lib.ptr(dx[0]),
-                _lib.ptr(dx[1]), _lib.ptr(dx[2]), _lib.current_stream()), "cgs_noise_quant_bwd")
+                _lib.ptr(dx[1]), _lib.ptr(dx[2]), *[_lib.ptr(t) for t in sd], _lib.current_stream()), "cgs_noise_quant_bwd")
+        if side is not None:
+            side.map = side.f = side.s = side.o = side.q = None
         if src is not None:
             src.rows_written += n
-            return None, None, None, dq, None, None, None, None, None, qadj.new_zeros(1)
-        return gf, gs, go, dq, None, None, None, None, None, None
+            return None, None, None, dq, None, None, None, None, None, qadj.new_zeros(1), None
+        return gf, gs, go, dq, None, None, None, None, None, None, None
 
 
-def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None, src=None, rows=None):
+def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None, src=None, rows=None, side=None):
     """(xf + u Qf, xs + u Qs, xo + u Qo, Q[n,3]) with Q = clamp(q0 (1 + tanh(qadj)), 1e-9), u ~ U[-0.5, 0.5).
     outs = (yf, ys, yo) optionally names the (contiguous) tensors to write the three results into.
-    src / rows: read x from rows `rows` of a RowSource instead of xf/xs/xo (which are then ignored)."""
+    src / rows: read x from rows `rows` of a RowSource instead of xf/xs/xo (which are then ignored).
+    side: a RateSide that level_rate(..., side=side) of the same level fills in its backward (needs src)."""
+    assert side is None or src is not None
     return _NoiseQuant.apply(xf, xs, xo, qadj, next_seed() if seed is None else int(seed),
-                             tuple(float(v) for v in q0), outs, src, rows, None if src is None else src.token)
+                             tuple(float(v) for v in q0), outs, src, rows, None if src is None else src.token, side)
 
 
 class _LevelRate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):
+    def forward(ctx, yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side):
         yf, ys, yo, Q, pred = _c(yf), _c(ys), _c(yo), _c(Q), _c(pred)
         _lib.require_device(yf, pred)
         n_sub, D = pred.shape[0], yf.shape[1]
@@ -208,6 +227,7 @@ class _LevelRate(torch.autograd.Function):
             _lib.current_stream()), "cgs_level_rate_fwd")
         ctx.save_for_backward(yf, ys, yo, Q, pred, loc, masks, grows, x_means)
         ctx.cfg = (int(use_clamp), n_sub, D, K)
+        ctx.side = side
         return sums
 
     @staticmethod
@@ -215,23 +235,33 @@ class _LevelRate(torch.autograd.Function):
         yf, ys, yo, Q, pred, loc, masks, grows, x_means = ctx.saved_tensors
         use_clamp, n_sub, D, K = ctx.cfg
         n_l = yf.shape[0]
-        # one zero fill for the four row-scattered gradients
-        flat = torch.zeros(n_l * (D + 6 + 3 * K + 3), dtype=_f32, device=yf.device)
-        d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_l * D, n_l * 6, n_l * 3 * K, n_l * 3])
-        d_yf, d_ys, d_yo, dQ = d_yf.view(n_l, D), d_ys.view(n_l, 6), d_yo.view(n_l, 3 * K), dQ.view(n_l, 3)
+        side = ctx.side if loc is not None else None
+        # row-scattered gradients: one zero fill for the four N-row buffers — or, with a RateSide, compact
+        # [n_sub, .] arrays (every row written, no fill) that the level's noise_quant backward adds in
+        n_o = n_sub if side is not None else n_l
+        flat = (torch.empty if side is not None else torch.zeros)(n_o * (D + 6 + 3 * K + 3), dtype=_f32, device=yf.device)
+        d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_o * D, n_o * 6, n_o * 3 * K, n_o * 3])
+        d_yf, d_ys, d_yo, dQ = d_yf.view(n_o, D), d_ys.view(n_o, 6), d_yo.view(n_o, 3 * K), dQ.view(n_o, 3)
         d_pred = torch.empty_like(pred)
         d_masks = torch.zeros_like(masks) if (masks is not None and ctx.needs_input_grad[6]) else None
         _lib.check(_lib.lib().cgs_level_rate_bwd(
             _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred), _lib.ptr(masks),
             _lib.ptr(grows), _lib.ptr(x_means), use_clamp, n_sub, D, K, pred.shape[1], _lib.ptr(_c(g)), _lib.ptr(d_pred),
-            _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.ptr(d_masks), _lib.current_stream()),
-            "cgs_level_rate_bwd")
-        return d_yf, d_ys, d_yo, dQ, d_pred, None, d_masks, None, None, None, None
+            _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.ptr(d_masks), int(side is not None),
+            _lib.current_stream()), "cgs_level_rate_bwd")
+        if side is not None:
+            m = torch.full((n_l,), -1, dtype=torch.int32, device=yf.device)
+            m[loc] = torch.arange(n_sub, dtype=torch.int32, device=yf.device)
+            side.map, side.f, side.s, side.o, side.q = m, d_yf, d_ys, d_yo, dQ
+            return None, None, None, None, d_pred, None, d_masks, None, None, None, None, None
+        return d_yf, d_ys, d_yo, dQ, d_pred, None, d_masks, None, None, None, None, None
 
 
-def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K):
-    """[bits_feat, bits_scaling, bits_offsets (mask-weighted)] summed over the chosen rows `loc` of a level."""
-    return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K))
+def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side=None):
+    """[bits_feat, bits_scaling, bits_offsets (mask-weighted)] summed over the chosen rows `loc` of a level.
+    side: the RateSide given to the noise_quant call that produced yf/ys/yo/Q (their rate gradients then travel
+    through it instead of through autograd)."""
+    return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K), side)
 
 
 class _CtxAssemble(torch.autograd.Function):

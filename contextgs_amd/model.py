@@ -73,7 +73,7 @@ class GaussianModel(nn.Module):
     def get_scaling(self):
         if self.decoded_version:
             return self._scaling
-        return 1.0 * torch.exp(self._scaling)
+        return torch.exp(self._scaling)          # the reference's `1.0 *` (:291) is an exact no-op: not launched
 
     @property
     def get_mask(self):

@@ -268,7 +268,11 @@ int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
  * The backward returns d_qadj; d_x == d_y is left to the caller unless rows is given, in which case
  * the rows of the FULL-size gradients dxf/dxs/dxo named by rows are written here (distinct rows; a
  * NULL dy* scatters zeros).  dy* may be NULL (no gradient); dQ_ext [n,3] is the gradient that
- * reaches Q from elsewhere (the rate term), may be NULL. */
+ * reaches Q from elsewhere (the rate term), may be NULL.
+ * side_map (may be NULL; needs rows): int32 [n], side_map[r] = s >= 0 says row r is in the rate
+ * subset and its rate gradients are row s of the COMPACT arrays side_f [n_sub,D], side_s [n_sub,S],
+ * side_o [n_sub,O], side_Q [n_sub,3] (cgs_level_rate_bwd with compact != 0); they are added to
+ * dy* / dQ_ext on the fly, so no N-row buffer is filled, scattered into and added. */
 int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo,
                         const float *qadj, const int64_t *rows, int64_t n, int D,
                         int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
@@ -277,7 +281,9 @@ int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
                         const float *dQ_ext, const float *qadj, int64_t n, int D,
                         int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
                         float *dqadj, const int64_t *rows, float *dxf, float *dxs,
-                        float *dxo, void *stream);
+                        float *dxo, const int32_t *side_map, const float *side_f,
+                        const float *side_s, const float *side_o,
+                        const float *side_Q, void *stream);
 /* Bits of the chosen rows of one level (:1658-1669 with utils/entropy_models.py:30-50):
  * for s < n_sub, r = loc[s] (row inside the level; NULL = s):
  *   sums[0] += bits(yf[r], mean_f, scale_f, Q[r,0])      sums[1] += bits(ys[r], ..., Q[r,1])
@@ -288,7 +294,9 @@ int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
  * centres when use_clamp != 0.  sums [3] is ACCUMULATED into.  The backward takes
  * g_sums [3] (device) and writes d_pred (all of it), rows loc[s] of d_yf/d_ys/d_yo and
  * of dQ [n_level,3] (the caller zero-fills the other rows); d_masks [N,K] (may be NULL,
- * pre-zeroed) receives the gradient of the mask weights (+= g_sums[2] * bits). */
+ * pre-zeroed) receives the gradient of the mask weights (+= g_sums[2] * bits).
+ * compact != 0: d_yf/d_ys/d_yo/dQ are [n_sub, .] arrays and row s (not loc[s]) is written —
+ * the side arrays of cgs_noise_quant_bwd. */
 int cgs_level_rate_fwd(const float *yf, const float *ys, const float *yo,
                        const float *Q, const int64_t *loc, const float *pred,
                        const float *masks, const int64_t *grows,
@@ -300,7 +308,7 @@ int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
                        const float *x_means, int use_clamp, int64_t n_sub, int D,
                        int K, int64_t ldpred, const float *g_sums, float *d_pred, float *d_yf,
                        float *d_ys, float *d_yo, float *dQ, float *d_masks,
-                       void *stream);
+                       int compact, void *stream);
 
 /* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
  * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on
