@@ -571,7 +571,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
     eg = pc.entropy_gaussian
     xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
-    masks30 = binary_grid_masks.repeat(1, 1, 3).view(-1, 3 * K)
+    masks30 = None                              # [N, 3K] mask weights, only the unfused levels read it
     zero = torch.zeros((), device=dev)
     s_feat, s_scaling, s_offsets = zero, zero, zero
     n_feat = n_scaling = n_offsets = 0
@@ -606,6 +606,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
             g = lambda t, loc=loc: gather_unique(t, loc)
         bf = eg(g(L["feat"]), g(L["mf"]), g(L["sf"]), g(L["qf"]), xm_feat)
         bs = eg(g(L["scaling"]), g(L["ms"]), g(L["ss"]), g(L["qs"]), xm_scaling)
+        if masks30 is None:
+            masks30 = binary_grid_masks.repeat(1, 1, 3).view(-1, 3 * K)
         bo = eg(g(L["offsets"]), g(L["mo"]), g(L["so"]), g(L["qo"]), xm_offsets) * gather_unique(masks30, rows)
         s_feat, s_scaling, s_offsets = s_feat + bf.sum(), s_scaling + bs.sum(), s_offsets + bo.sum()
         n_feat, n_scaling, n_offsets = n_feat + bf.numel(), n_scaling + bs.numel(), n_offsets + bo.numel()

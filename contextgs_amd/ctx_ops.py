@@ -312,3 +312,34 @@ def ctx_assemble(anchor, base_f, base_s, own, idx, pos, csr):
     """The MLP input rows of a level: parent anchor / coded feature / coded scaling rows + the level's own hyper
     rows.  csr = (offs[n_parents+1], order[n_children], parent_row[n_parents]) lists every parent's children."""
     return _CtxAssemble.apply(anchor, base_f, base_s, own, idx, pos, csr)
+
+
+class _MaskSTE(torch.autograd.Function):
+    """get_mask / get_mask_anchor of the model in one launch each way (cgs_mask_ste_*, csrc/mask.hip)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        x = _c(logits)
+        _lib.require_device(x)
+        n, K = x.shape[0], x[0].numel() if x.shape[0] else 1
+        mask = torch.empty_like(x)
+        alive = torch.empty(n, dtype=torch.bool, device=x.device)
+        _lib.check(_lib.lib().cgs_mask_ste_fwd(_lib.ptr(x), n, K, _lib.ptr(mask), _lib.ptr(alive), _lib.current_stream()),
+                   "cgs_mask_ste_fwd")
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(alive)
+        return mask, alive
+
+    @staticmethod
+    def backward(ctx, g, _g_alive):
+        (x,) = ctx.saved_tensors
+        d = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_mask_ste_bwd(_lib.ptr(x), _lib.ptr(_c(g)), x.numel(), _lib.ptr(d), _lib.current_stream()),
+                   "cgs_mask_ste_bwd")
+        return d
+
+
+def mask_ste(logits):
+    """(mask, any_alive): mask = ((sigmoid(m) > 0.01) - sigmoid(m)) + sigmoid(m) with the sigmoid's gradient
+    (scene/gaussian_model.py:295-299), any_alive[a] = some offset of anchor a has mask > 0 (:302-310)."""
+    return _MaskSTE.apply(logits)

@@ -75,21 +75,25 @@ class GaussianModel(nn.Module):
             return self._scaling
         return torch.exp(self._scaling)          # the reference's `1.0 *` (:291) is an exact no-op: not launched
 
+    def get_mask_pair(self):
+        """(get_mask, get_mask_anchor) from ONE evaluation (:295-310): the training step needs both."""
+        if self.decoded_version:
+            return self._mask, torch.sum(self._mask.detach(), dim=1)[:, 0] > 0
+        if self._mask.is_cuda:
+            from .ctx_ops import mask_ste
+            return mask_ste(self._mask)                   # one HIP launch each way (csrc/mask.hip)
+        s = torch.sigmoid(self._mask)
+        m = ((s > 0.01).float() - s).detach() + s
+        return m, torch.sum(m.detach(), dim=1)[:, 0] > 0
+
     @property
     def get_mask(self):
-        if self.decoded_version:
-            return self._mask
-        s = torch.sigmoid(self._mask)
-        return ((s > 0.01).float() - s).detach() + s
+        return self.get_mask_pair()[0]
 
     @property
     def get_mask_anchor(self):
         with torch.no_grad():
-            if self.decoded_version:
-                return torch.sum(self._mask, dim=1)[:, 0] > 0
-            s = torch.sigmoid(self._mask)
-            m = ((s > 0.01).float() - s).detach() + s
-            return torch.sum(m, dim=1)[:, 0] > 0
+            return self.get_mask_pair()[1]
 
     @property
     def get_opacity_mlp(self): return self.mlp_opacity

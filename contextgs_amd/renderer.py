@@ -152,10 +152,13 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if is_training and step == 10000:                                                   # :60-61
         pc.update_anchor_bound()
     if use_context:                                                                     # :63-81 (train) / :83-101 (eval)
-        binary_all = pc.get_mask
-        # get_mask_anchor (scene/gaussian_model.py:302-310) is "any offset alive" of the SAME mask values: derive it
-        # from them instead of evaluating the sigmoid / threshold / STE chain a second time
-        mask_anchor_bool = binary_all.detach().sum(dim=1)[:, 0] > 0
+        # get_mask_anchor (scene/gaussian_model.py:302-310) is "any offset alive" of the SAME mask values: take both
+        # from one evaluation instead of running the sigmoid / threshold / STE chain twice
+        if hasattr(pc, "get_mask_pair"):
+            binary_all, mask_anchor_bool = pc.get_mask_pair()
+        else:                                   # the reference's own GaussianModel
+            binary_all = pc.get_mask
+            mask_anchor_bool = binary_all.detach().sum(dim=1)[:, 0] > 0
         res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
                                              pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
                                              training=is_training, predict_bpp=is_training, defer_feat=True)

@@ -465,6 +465,15 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         float *d_op_raw, float *d_mask, float *d_color_in,
                         float *d_cov_in, const int64_t *src_row, void *stream);
 
+/* Offset-mask accessors of the model (scene/gaussian_model.py:295-310) in one pass:
+ *   s = sigmoid(logits), mask = ((s > 0.01) - s) + s  (get_mask's straight-through value, [n,K])
+ *   any_alive[a] = sum_k mask[a,k] > 0                (get_mask_anchor, uint8 [n])
+ * Either output may be NULL.  Backward: d_logits = (g * (1 - s)) * s over all n*K elements. */
+int cgs_mask_ste_fwd(const float *logits, int64_t n, int K, float *mask,
+                     uint8_t *any_alive, void *stream);
+int cgs_mask_ste_bwd(const float *logits, const float *g, int64_t n_elements,
+                     float *d_logits, void *stream);
+
 /* ---- anchor-initialisation kNN ----
  * `distCUDA2` of the simple_knn wheel (called at scene/gaussian_model.py:389,407; the wheel's source is not in
  * the reference checkout): mean_dist2[i] = mean of the squared fp32 distances from points[i] ([n,3], device) to

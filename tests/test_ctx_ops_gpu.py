@@ -206,3 +206,24 @@ def test_noise_quant_row_source_equals_gather_then_noise_quant(complete):
         assert x.shape == y.shape and torch.equal(x, y)
     for x, y in zip(a[2], b[2]):
         assert torch.equal(x, y)
+
+
+def test_mask_ste_equals_the_torch_accessors():
+    """cgs_mask_ste_{fwd,bwd} == get_mask / get_mask_anchor as the reference writes them (:295-310): values bit for
+    bit (same fp32 expression), gradient = sigmoid backward."""
+    from contextgs_amd.ctx_ops import mask_ste
+    torch.manual_seed(0)
+    m = (torch.randn(5000, 10, 1, device="cuda") * 4 - 2).requires_grad_(True)
+    with torch.no_grad():
+        m[:40] = -20.0                                   # dead anchors
+        m[40:80, 3] = torch.log(torch.tensor(0.01 / 0.99)) + torch.linspace(-1e-3, 1e-3, 40, device="cuda")[:, None]  # at the threshold
+    s = torch.sigmoid(m)
+    ref_mask = ((s > 0.01).float() - s).detach() + s
+    ref_any = torch.sum(ref_mask, dim=1)[:, 0] > 0
+    w = torch.randn_like(m)
+    (g_ref,) = torch.autograd.grad((ref_mask * w).sum(), m)
+    mask, alive = mask_ste(m)
+    assert torch.equal(alive, ref_any) and not bool(alive[:40].any())
+    assert torch.equal(mask, ref_mask)
+    (g,) = torch.autograd.grad((mask * w).sum(), m)
+    assert torch.allclose(g, g_ref, rtol=1e-6, atol=1e-9)
