@@ -205,14 +205,38 @@ __global__ void __launch_bounds__(SORT_THREADS)
         }
     }
     __syncthreads();
+    // Thread t owns digit t.  Items are first placed in LDS in (digit, wave, round, lane) order — the order they
+    // must have in the output — and then streamed out: consecutive LDS slots of one digit go to consecutive global
+    // addresses, so a wave writes a few contiguous runs (avg. SORT_TILE / RADIX items each) instead of 64 isolated
+    // 4-byte stores per instruction.
+    __shared__ uint32_t lstart[RADIX];     // first LDS slot of the digit
+    __shared__ uint32_t gbase[RADIX];      // first global position of this block's items of the digit
+    __shared__ uint32_t wsum[SORT_WAVES];
+    __shared__ uint32_t skey[SORT_TILE], sval[SORT_TILE];
     {
-        // thread t owns digit t: turn per-wave counts into absolute bases.
         const int d = threadIdx.x;
-        uint32_t run = hist_scanned[(int64_t)d * gridDim.x + blockIdx.x];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) tot += wcnt[w][d];
+        // exclusive scan of tot over the 256 digits: inclusive wave scan + wave offsets
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) woff += (w < wave) ? wsum[w] : 0u;
+        uint32_t run = woff + inc - tot;
+        lstart[d] = run;
+        gbase[d] = hist_scanned[(int64_t)d * gridDim.x + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
-            uint32_t c = wcnt[w][d];
-            wcnt[w][d] = run;
+            const uint32_t c = wcnt[w][d];
+            wcnt[w][d] = run;              // LDS slot of wave w's first item with digit d
             run += c;
         }
     }
@@ -222,10 +246,20 @@ __global__ void __launch_bounds__(SORT_THREADS)
         const int64_t idx = wbase + (int64_t)r * 64 + lane;
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & digit_mask;
-            const uint32_t pos = wcnt[wave][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
+            const uint32_t slot = wcnt[wave][d] + rank[r];
+            skey[slot] = key[r];
+            sval[slot] = val[r];
         }
+    }
+    __syncthreads();
+    const int64_t tile_base = (int64_t)blockIdx.x * SORT_TILE;
+    const int count = (int)((n - tile_base) < (int64_t)SORT_TILE ? (n - tile_base) : (int64_t)SORT_TILE);
+    for (int j = threadIdx.x; j < count; j += SORT_THREADS) {
+        const uint32_t k = skey[j];
+        const uint32_t d = (k >> shift) & digit_mask;
+        const uint32_t pos = gbase[d] + ((uint32_t)j - lstart[d]);
+        keys_out[pos] = k;
+        vals_out[pos] = sval[j];
     }
 }
 
