@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(256)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const uint32_t g = order[i];
-    if (tiles[g] == 0) return;
-    const uint2 rc = rect[g];
+    const uint2 rc = rect[g];          // (0,0) for a Gaussian that touches no tile: the loops below do not run
+                                       // (one random gather per Gaussian instead of two: tiles[g] is not needed)
     const int x0 = rc.x & 0xFFFF, y0 = rc.x >> 16, x1 = rc.y & 0xFFFF, y1 = rc.y >> 16;
     uint32_t off = offsets[i];
     for (int y = y0; y < y1; ++y)
