@@ -6,9 +6,11 @@ entry points (csrc/codec.hip):
   * `encoder_gaussian` / `decoder_gaussian`         — utils/encodings.py:83-144, same
     signatures and return values, but the per-symbol integer CDF is evaluated inside
     the device coder (no [n_sym, L] float table, no PCIe round trip);
-  * `gaussian_encode_streams` / `gaussian_decode_streams` — the batched form the
-    container driver uses: every 1000-anchor chunk stream of a level/attribute is coded
-    concurrently, one lane per stream;
+  * `gaussian_encode_packed` / `gaussian_decode_packed` (+ `_streams`, `_groups` forms) —
+    the batched form the container driver uses: any number of 1000-anchor chunk streams,
+    of any mix of levels / attributes, coded by ONE launch, one wave per stream, the
+    byte streams packed back to back on the device (`_groups` also shards the streams
+    over the ranks of a process group);
   * `encoder` / `decoder`                           — Bernoulli mask stream, :147-180;
   * `rans_encode_channels` / `rans_decode_channels` — hyper-prior symbols.
 
@@ -212,7 +214,7 @@ def gaussian_encode_groups(groups):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
     lasts as long as its longest stream however many streams it holds."""
-    groups = [g for g in groups]
+    groups = list(groups)
     if not groups:
         return []
     xs, ms, ss, qs, edges, counts, base = [], [], [], [], [torch.zeros(1, dtype=torch.int64)], [], 0
@@ -220,7 +222,9 @@ def gaussian_encode_groups(groups):
         off = torch.as_tensor(off, dtype=torch.int64).cpu()
         xs.append(_f(x).reshape(-1)); ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1))
         qs.append(_expand_q(Q, q_div))
-        assert xs[-1].numel() == qs[-1].numel() == int(off[-1]) if off.numel() else True
+        n_sym = int(off[-1]) if off.numel() else 0
+        if not (xs[-1].numel() == ms[-1].numel() == ss[-1].numel() == qs[-1].numel() == n_sym) or (off.numel() and int(off[0])):
+            raise ValueError("gaussian_encode_groups: a group's x / mean / scale / Q sizes do not match its stream offsets")
         edges.append(off[1:] + base)
         counts.append(max(int(off.numel()) - 1, 0))
         base += int(xs[-1].numel())
