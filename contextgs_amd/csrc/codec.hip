@@ -9,12 +9,12 @@
 //      * the table-driven host coder (torchac drop-in; Bernoulli mask stream), and
 //      * the batched GPU Gaussian codec below.
 // 2. The Gaussian codec of encoder_gaussian / decoder_gaussian
-//    (utils/encodings.py:83-144) WITHOUT the [n_sym, L] float table: one lane per
-//    1000-anchor chunk stream; the lane evaluates the integer CDF of exactly the
-//    entries it needs (2 per symbol when encoding, ~log2(L) when decoding) with the
-//    same device erff on both sides, so encode -> decode is bit-exact by
-//    construction and nothing crosses PCIe but the bitstream.  All chunk streams of
-//    a level/attribute run concurrently.
+//    (utils/encodings.py:83-144) WITHOUT the [n_sym, L] float table: one WAVE per
+//    1000-anchor chunk stream; the lanes evaluate the integer CDF entries the coder
+//    needs (the two bounds of 64 symbols at a time when encoding, 16-entry windows of
+//    four symbols at a time when decoding) with the same device erff on both sides, so
+//    encode -> decode is bit-exact by construction and nothing crosses PCIe but the
+//    bitstream.  Any number of streams (all levels and attributes) share a launch.
 // 3. A range-ANS coder for the hyper-prior symbols (EntropyBottleneck.compress /
 //    decompress; compressai is NOT in the mount): per-channel frequency tables,
 //    escape symbol + Elias-gamma style bypass for out-of-support values.
@@ -80,34 +80,6 @@ struct BitReader {
         const int shift = 40 - (int)(pos & 7u) - n;
         pos += (uint64_t)n;
         return (uint32_t)((w >> shift) & ((1ull << n) - 1ull));
-    }
-};
-
-// Device decoder input: the wave keeps a 256-byte window of the stream in one register (lane l = big-endian dword
-// l of the window) and the wave-uniform bit cursor picks its bits with two v_readlane — no memory access on the
-// per-symbol path (the byte-wise reader above costs one or two dependent global-load latencies per symbol).
-struct WaveBitReader {
-    const uint8_t *buf;
-    uint64_t len, pos, base;     // bytes, bit cursor, byte offset of the window
-    uint32_t win;
-    __device__ void fill(uint64_t b) {
-        base = b;
-        const uint64_t o = b + 4ull * (threadIdx.x & 63);
-        uint32_t w = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w = (w << 8) | (o + t < len ? (uint32_t)buf[o + t] : 0u);
-        win = w;
-    }
-    __device__ void init(const uint8_t *b, size_t n) { buf = b; len = (uint64_t)n; pos = 0; fill(0); }
-    __device__ uint32_t get_bits(int n) {
-        const uint64_t idx = pos >> 3;
-        if (idx - base > 247) fill(idx & ~3ull);                 // needs dwords d and d + 1 inside the window
-        const int d = __builtin_amdgcn_readfirstlane((int)((idx - base) >> 2));
-        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, d) << 32) |
-                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)win, d + 1);
-        const int off = (int)((idx - base) & 3) * 8 + (int)(pos & 7u);
-        pos += (uint64_t)n;
-        return (uint32_t)((v << off) >> (64 - n));
     }
 };
 
