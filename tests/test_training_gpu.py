@@ -161,6 +161,48 @@ def test_fused_context_training_path_equals_torch_composition(monkeypatch):
         assert err < 2e-3, (n, err)
 
 
+@pytest.mark.parametrize("loss_kind", ["render+rate", "rate_only", "render_only"])
+def test_row_source_and_rate_side_equal_the_autograd_formulation(monkeypatch, loss_kind):
+    """The two backward short-cuts of the fused level loop — parameter rows read / gradients scattered through the
+    coding-order permutation inside the level kernels (ctx_ops.RowSource) and the rate gradients handed to the
+    noise_quant backward in compact form (ctx_ops.RateSide) — against the plain autograd formulation they replace
+    (gather -> split -> ... -> cat -> index_copy, N-row rate gradients + adds), same seeds: the same sums in another
+    order, so gradients agree to rounding, also when one of the two loss branches is absent."""
+    from contextgs_amd import context_model as cm
+    from contextgs_amd import ctx_ops
+    from contextgs_amd.renderer import prefilter_voxel, render
+    pc, cams, pipe, bg = _setup(N=30000)
+    vis = prefilter_voxel(cams[2], pc, pipe, bg)
+    params = [p for p in pc.parameters() if p.requires_grad]
+    names = [n for n, p in pc.named_parameters() if p.requires_grad]
+
+    def run(short_cuts):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(9)
+        it = iter(range(100, 200))
+        monkeypatch.setattr(ctx_ops, "next_seed", lambda: next(it))
+        monkeypatch.setattr(cm, "ROW_SOURCE", short_cuts)
+        monkeypatch.setattr(cm, "RATE_SIDE", short_cuts)
+        pkg = render(cams[2], pc, pipe, bg, visible_mask=vis, step=20000)
+        loss = 0.0
+        if loss_kind != "rate_only":
+            loss = loss + (1.0 - pkg["render"]).abs().mean()
+        if loss_kind != "render_only":
+            loss = loss + 0.05 * pkg["bit_per_param"]
+        loss.backward()
+        return pkg["render"].detach().clone(), [None if p.grad is None else p.grad.clone() for p in params]
+
+    img_a, g_a = run(True)
+    img_b, g_b = run(False)
+    assert torch.equal(img_a, img_b)
+    for n, a, b in zip(names, g_a, g_b):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            scale = float(b.abs().max()) + 1e-20
+            assert float((a - b).abs().max()) <= 1e-5 * scale, (n, float((a - b).abs().max()) / scale)
+
+
 def test_bench_scene_full_size_properties(tmp_path):
     """The bench workload itself (1 M anchors, 1920x1080) through properties that need no oracle:
     * the deterministic phase (step <= 3000) renders bit-identically twice and its backward is LINEAR in dL/dimage
