@@ -288,7 +288,7 @@ def main():
                 cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
 
         result = {
-            "metric": "views/sec fwd+bwd @1920x1080, 1M anchors", "value": round(value, 3), "unit": "views/s",
+            "metric": "views/sec fwd+bwd @1920\u00d71080, 1M anchors", "value": round(value, 3), "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N}-anchor synthetic scene (seed 0), {W}x{H}, prefilter_voxel + "
