@@ -329,6 +329,10 @@ def codec_bench(pc):
         pc.conduct_encoding(d)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+        warm = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
+        warm.eval()
+        warm.conduct_decoding(d)                    # untimed warm-up, like the encoder's (first-touch allocations, tables)
+        del warm
         dec = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
         dec.eval()
         torch.cuda.synchronize(); t2 = time.perf_counter()
