@@ -104,7 +104,10 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_gaussian_ac_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
-    "cgs_mask_ste_fwd": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "cgs_means3_scratch_bytes": (c_size_t, []),
+    "cgs_means3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                           c_void_p]),
+    "cgs_mask_ste_fwd":(c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_mask_ste_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_knn_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_knn_mean_dist2": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -570,7 +570,14 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     else:
         bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
     eg = pc.entropy_gaussian
-    xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
+    all_fused = bool(levels) and all(L.get("fused") for L in levels) and pc._anchor_feat.is_cuda
+    if all_fused:
+        # every level goes through the fused rate kernel, which takes the three clamp centres as constants: one
+        # launch over the three parameter tensors (exp of the scaling logits on the fly) instead of exp + 3 reductions
+        xm_feat = xm_scaling = xm_offsets = None
+        x_means_fused = _ctx.means3(pc._anchor_feat, pc._scaling, pc._offset, exp_b=not pc.decoded_version)
+    else:
+        xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
     masks30 = None                              # [N, 3K] mask weights, only the unfused levels read it
     zero = torch.zeros((), device=dev)
     s_feat, s_scaling, s_offsets = zero, zero, zero
@@ -581,7 +588,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     for L in levels:
         if L.get("fused"):                      # one launch: gathers of the chosen rows + the three rate terms + sums
             if x_means is None:
-                x_means = torch.stack([xm_feat, xm_scaling, xm_offsets]).detach()
+                x_means = x_means_fused if all_fused else torch.stack([xm_feat, xm_scaling, xm_offsets]).detach()
             n_sub = int(L["loc"].shape[0])
             if L.get("chosen") is not None:
                 # the mask rows of ALL levels' chosen anchors in one gather (one scatter + one zero fill on the way

@@ -343,3 +343,21 @@ def mask_ste(logits):
     """(mask, any_alive): mask = ((sigmoid(m) > 0.01) - sigmoid(m)) + sigmoid(m) with the sigmoid's gradient
     (scene/gaussian_model.py:295-299), any_alive[a] = some offset of anchor a has mask > 0 (:302-310)."""
     return _MaskSTE.apply(logits)
+
+
+_means3_ws = {}
+
+
+def means3(a, b, c, exp_b=False):
+    """float32 [3] = (a.mean(), (exp(b) if exp_b else b).mean(), c.mean()) in one launch, no autograd (the clamp
+    centres of the rate model, scene/gaussian_model.py:1664-1668, as the fused rate kernel consumes them)."""
+    a, b, c = _c(a.detach()), _c(b.detach()), _c(c.detach())
+    _lib.require_device(a, b, c)
+    L = _lib.lib()
+    ws = _means3_ws.get(a.device)
+    if ws is None:
+        ws = _means3_ws[a.device] = torch.empty(L.cgs_means3_scratch_bytes(), dtype=torch.uint8, device=a.device)
+    out = torch.empty(3, dtype=_f32, device=a.device)
+    _lib.check(L.cgs_means3(_lib.ptr(a), a.numel(), _lib.ptr(b), b.numel(), int(bool(exp_b)), _lib.ptr(c), c.numel(),
+                            _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.current_stream()), "cgs_means3")
+    return out

@@ -465,6 +465,14 @@ int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
                         float *d_op_raw, float *d_mask, float *d_color_in,
                         float *d_cov_in, const int64_t *src_row, void *stream);
 
+/* The three clamp centres of the rate model (scene/gaussian_model.py:1664-1668: _anchor_feat.mean(),
+ * get_scaling.mean(), _offset.mean()) in one launch: out3 = (mean a, mean (exp_b ? exp(b) : b), mean c),
+ * accumulated in double, deterministic.  scratch from cgs_means3_scratch_bytes(). */
+size_t cgs_means3_scratch_bytes(void);
+int cgs_means3(const float *a, int64_t na, const float *b, int64_t nb, int exp_b,
+               const float *c, int64_t nc, void *scratch, size_t scratch_bytes,
+               float *out3, void *stream);
+
 /* Offset-mask accessors of the model (scene/gaussian_model.py:295-310) in one pass:
  *   s = sigmoid(logits), mask = ((s > 0.01) - s) + s  (get_mask's straight-through value, [n,K])
  *   any_alive[a] = sum_k mask[a,k] > 0                (get_mask_anchor, uint8 [n])

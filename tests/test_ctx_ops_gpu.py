@@ -227,3 +227,15 @@ def test_mask_ste_equals_the_torch_accessors():
     assert torch.equal(mask, ref_mask)
     (g,) = torch.autograd.grad((mask * w).sum(), m)
     assert torch.allclose(g, g_ref, rtol=1e-6, atol=1e-9)
+
+
+def test_means3_equals_torch_means():
+    from contextgs_amd.ctx_ops import means3
+    torch.manual_seed(1)
+    a, b, c = torch.randn(40000, 50, device="cuda") + 0.3, torch.randn(40000, 6, device="cuda") * 0.5 - 4, torch.randn(40000, 10, 3, device="cuda") * 0.2
+    got = means3(a, b, c, exp_b=True)
+    want = torch.stack([a.double().mean(), torch.exp(b).double().mean(), c.double().mean()]).float()
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-8)
+    assert torch.equal(means3(a, b, c, exp_b=True), got)                      # deterministic
+    got2 = means3(a[:1], b[:0], c, exp_b=False)
+    assert torch.allclose(got2[0], a[:1].mean()) and float(got2[1]) == 0.0
