@@ -92,6 +92,44 @@ def _rows_of(x, rows):
     return _RowsOf.apply(x, rows)
 
 
+def cumulative_logits(matrices, biases, factors, x, stop_gradient: bool = False):
+    """Cumulative logits of the factorised prior: x [C,1,M] -> [C,1,M] through per-channel layers
+    logits <- softplus(M_i) @ logits + b_i (+ tanh(a_i) * tanh(logits) on all but the last).  The one torch
+    statement of this density in the package: EntropyBottleneck and utils.entropy_models.Entropy_factorized both
+    call it; pinned against the reference's own `_logits_cumulative` by tests/golden/entropy_api.npz."""
+    take = (lambda p: p.detach()) if stop_gradient else (lambda p: p)
+    logits = x
+    for i, (m, b) in enumerate(zip(matrices, biases)):
+        logits = torch.matmul(F.softplus(take(m)), logits) + take(b)
+        if i < len(factors):
+            logits = logits + torch.tanh(take(factors[i])) * torch.tanh(logits)
+    return logits
+
+
+def interval_likelihood(matrices, biases, factors, x, half_width, stop_gradient: bool = False):
+    """P(x - h < X < x + h) = |sigmoid(s u) - sigmoid(s l)|, s = -sign(l + u) (the numerically safe tail side)."""
+    lower = cumulative_logits(matrices, biases, factors, x - half_width, stop_gradient)
+    upper = cumulative_logits(matrices, biases, factors, x + half_width, stop_gradient)
+    sign = -torch.sign(lower + upper).detach()
+    return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+
+
+def pack_density_params(matrices, biases, factors, channels):
+    """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat); filters (3,3,3,3) only."""
+    parts = []
+    for i in range(5):
+        parts.append(matrices[i].reshape(channels, -1))
+        parts.append(biases[i].reshape(channels, -1))
+        if i < 4:
+            parts.append(factors[i].reshape(channels, -1))
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def fused_likelihood(v, packed):
+    """likelihood [N,C] (floored at 1e-9) of values v [N,C] under the filters-(3,3,3,3) prior: one HIP launch each way."""
+    return _FusedLikelihood.apply(v, packed)
+
+
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10.0,
                  filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9, entropy_coder_precision: int = 16):
@@ -123,22 +161,10 @@ class EntropyBottleneck(nn.Module):
     # ---- density ---------------------------------------------------------------
     def _logits_cumulative(self, x: torch.Tensor, stop_gradient: bool = False) -> torch.Tensor:
         """x: [C, 1, M] -> cumulative logits [C, 1, M]."""
-        logits = x
-        for i in range(len(self.filters) + 1):
-            m, b = self.matrices[i], self.biases[i]
-            if stop_gradient:
-                m, b = m.detach(), b.detach()
-            logits = torch.matmul(F.softplus(m), logits) + b
-            if i < len(self.filters):
-                a = self.factors[i].detach() if stop_gradient else self.factors[i]
-                logits = logits + torch.tanh(a) * torch.tanh(logits)
-        return logits
+        return cumulative_logits(self.matrices, self.biases, self.factors, x, stop_gradient)
 
     def _likelihood(self, x: torch.Tensor, stop_gradient: bool = False) -> torch.Tensor:
-        lower = self._logits_cumulative(x - 0.5, stop_gradient)
-        upper = self._logits_cumulative(x + 0.5, stop_gradient)
-        sign = -torch.sign(lower + upper).detach()
-        return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        return interval_likelihood(self.matrices, self.biases, self.factors, x, 0.5, stop_gradient)
 
     def _get_medians(self) -> torch.Tensor:
         return self.quantiles[:, :, 1:2].detach()     # [C,1,1]
@@ -181,14 +207,7 @@ class EntropyBottleneck(nn.Module):
 
     def _packed_params(self) -> torch.Tensor:
         """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat)."""
-        C = self.channels
-        parts = []
-        for i in range(5):
-            parts.append(self.matrices[i].reshape(C, -1))
-            parts.append(self.biases[i].reshape(C, -1))
-            if i < 4:
-                parts.append(self.factors[i].reshape(C, -1))
-        return torch.cat(parts, dim=1).contiguous()
+        return pack_density_params(self.matrices, self.biases, self.factors, self.channels)
 
     # ---- tables --------------------------------------------------------------------
     @torch.no_grad()

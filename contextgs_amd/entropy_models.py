@@ -10,10 +10,8 @@ Cited lines are utils/entropy_models.py.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as nnf
 
 from . import _lib
 from . import encodings as _enc
@@ -102,56 +100,59 @@ class Low_bound(torch.autograd.Function):                    # :141-156 (device-
 
 
 class Entropy_factorized(nn.Module):                         # :67-138
+    """Fully factorised learned prior, one density network per channel (never instantiated by ContextGS, kept for
+    API parity).  Same constructor, parameter lists (`_matrices`, `_bias`, `_factor`) and initialisation as the
+    reference; the density itself is NOT restated here: `_logits_cumulative` and `forward` call the package's one
+    implementation (entropy_bottleneck.cumulative_logits / interval_likelihood; on the device with filters
+    (3,3,3,3) and Q = 1 the fused kernel of csrc/eb.hip).
+
+    forward(x [N,C], Q) -> bits [N,C] = -log2(max(P(x - 1/(2Q) < X < x + 1/(2Q)), likelihood_bound)).  The
+    reference's forward (:121-138) cannot be pinned: it raises for every input (its `[C,N]` tensor meets `[C,f,1]`
+    matrices in a matmul without the singleton axis; with channel=1 the final `permute(1, 0)` is applied to a
+    3-D tensor) — this is the [N,C] semantics its comments state.  The part that does run there,
+    `_logits_cumulative` on `[C,1,M]`, is what tests/golden/entropy_api.npz pins."""
+
     def __init__(self, channel=32, init_scale=10, filters=(3, 3, 3), likelihood_bound=1e-6, tail_mass=1e-9,
                  optimize_integer_offset=True, Q=1):
         super().__init__()
+        from .entropy_bottleneck import EntropyBottleneck
         self.filters = tuple(int(t) for t in filters)
-        self.init_scale = float(init_scale)
-        self.likelihood_bound = float(likelihood_bound)
-        self.tail_mass = float(tail_mass)
+        self.init_scale, self.likelihood_bound, self.tail_mass = float(init_scale), float(likelihood_bound), float(tail_mass)
         self.optimize_integer_offset = bool(optimize_integer_offset)
         self.Q = Q
+        self.channel = int(channel)
         if not 0 < self.tail_mass < 1:
             raise ValueError("`tail_mass` must be between 0 and 1")
-        f = (1,) + self.filters + (1,)
-        scale = self.init_scale ** (1.0 / (len(self.filters) + 1))
-        self._matrices, self._bias, self._factor = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
-        for i in range(len(self.filters) + 1):
-            init = np.log(np.expm1(1.0 / scale / f[i + 1]))
-            self._matrices.append(nn.Parameter(torch.full((channel, f[i + 1], f[i]), float(init))))
-            self._bias.append(nn.Parameter(torch.empty(channel, f[i + 1], 1).uniform_(-0.5, 0.5)))
-            if i < len(self.filters):
-                self._factor.append(nn.Parameter(torch.zeros(channel, f[i + 1], 1)))
+        # the bottleneck's constructor already builds this exact parameter set (same shapes, same init rule):
+        # adopt its lists under the reference's attribute names
+        proto = EntropyBottleneck(self.channel, tail_mass=self.tail_mass, init_scale=self.init_scale, filters=self.filters)
+        self._matrices, self._bias, self._factor = proto.matrices, proto.biases, proto.factors
 
     def _logits_cumulative(self, logits, stop_gradient):
-        for i in range(len(self.filters) + 1):
-            matrix = nnf.softplus(self._matrices[i])
-            bias = self._bias[i]
-            if stop_gradient:
-                matrix, bias = matrix.detach(), bias.detach()
-            logits = torch.matmul(matrix, logits) + bias
-            if i < len(self._factor):
-                factor = torch.tanh(self._factor[i])
-                if stop_gradient:
-                    factor = factor.detach()
-                logits = logits + factor * torch.tanh(logits)
-        return logits
+        from .entropy_bottleneck import cumulative_logits
+        return cumulative_logits(self._matrices, self._bias, self._factor, logits, stop_gradient)
 
     def forward(self, x, Q=None):
-        Q = self.Q if Q is None else Q.permute(1, 0).contiguous()
-        x = x.permute(1, 0).contiguous()
-        lower = self._logits_cumulative(x - 0.5 * (1 / Q), stop_gradient=False)
-        upper = self._logits_cumulative(x + 0.5 * (1 / Q), stop_gradient=False)
-        sign = -torch.sign(lower + upper).detach()
-        likelihood = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
-        bits = -torch.log2(Low_bound.apply(likelihood))
-        return bits.permute(1, 0).contiguous()
+        from . import entropy_bottleneck as eb
+        assert x.dim() == 2 and x.shape[1] == self.channel, "expects [N, C]"
+        Q = self.Q if Q is None else Q
+        unit_q = not isinstance(Q, torch.Tensor) and float(Q) == 1.0
+        if x.is_cuda and self.filters == (3, 3, 3, 3) and unit_q:
+            lik = eb.fused_likelihood(_c(x), eb.pack_density_params(self._matrices, self._bias, self._factor, self.channel))
+        else:
+            half = 0.5 / Q if not isinstance(Q, torch.Tensor) else (0.5 / Q.expand(x.shape)).t().reshape(self.channel, 1, -1)
+            v = x.t().reshape(self.channel, 1, -1)
+            lik = eb.interval_likelihood(self._matrices, self._bias, self._factor, v, half).reshape(self.channel, -1).t()
+        return -torch.log2(Low_bound.apply(lik) if self.likelihood_bound == 1e-6
+                           else eb._LowerBound.apply(lik, self.likelihood_bound))
 
 
 class UniverseQuant(torch.autograd.Function):                # :159-171
+    """round(x + u) - u with u ~ U(-1/2, 1/2) drawn per element (subtractive dither); identity gradient."""
+
     @staticmethod
     def forward(ctx, x):
-        u = torch.empty_like(x).uniform_(-0.5, 0.5)
+        u = torch.rand_like(x) - 0.5
         return torch.round(x + u) - u
 
     @staticmethod

@@ -57,6 +57,15 @@ def ste_binary(x):
     return np.where(x >= 0, f32(1), f32(-1)).astype(f32)
 
 
+def binary_vxl_size(binary_vxl):
+    """get_binary_vxl_size, utils/encodings.py:15-32 -> (Pg, ttl_bit, MB, ttl_num)."""
+    m = np.asarray(binary_vxl).astype(np.float64)
+    pos = m.sum()
+    pg = np.clip(f32(pos / m.size), f32(1e-6), f32(1 - 1e-6))
+    ttl_bit = float(f32(pos) * -np.log2(pg) + f32(m.size - pos) * -np.log2(f32(1) - pg) + 32)
+    return float(pg), ttl_bit, ttl_bit / 8.0 / 1024 / 1024, m.size
+
+
 # ---- utils/entropy_models.py ------------------------------------------------------------
 def _normal_cdf(v, mean, scale):
     return (f32(0.5) * (f32(1) + erf(((v - mean) * (f32(1) / scale) / f32(np.sqrt(2.0))).astype(f32)))).astype(f32)
@@ -228,18 +237,59 @@ def bottleneck_eval(hyper, W):
     return back(out), back(lik)
 
 
-# ---- scene/gaussian_model.py:1541-1707 (eval variants) ----------------------------------------
+def bottleneck_train(hyper, W, noise):
+    """EntropyBottleneck.forward(x, training=True): x + U(-1/2, 1/2) noise (given, [N,C]) + likelihood."""
+    v = (hyper.astype(f32) + noise.astype(f32)).astype(f32)
+    lik = bottleneck_likelihood(v, W)
+    return v, lik
+
+
+def bottleneck_likelihood(v, W):
+    """|sigmoid(s u) - sigmoid(s l)| with s = -sign(l + u), floored at 1e-9, of values v [N,C] (the density of
+    utils/entropy_models.py:121-138 with Q = 1 and compressai's 1e-9 bound)."""
+    x = v.T.reshape(v.shape[1], 1, -1).astype(f32)
+    lower = bottleneck_logits(x - f32(0.5), W)
+    upper = bottleneck_logits(x + f32(0.5), W)
+    sign = -np.sign(lower + upper)
+    sig = lambda t: (1 / (1 + np.exp(-t))).astype(f32)
+    lik = np.maximum(np.abs(sig(sign * upper) - sig(sign * lower)), f32(1e-9))
+    return lik.reshape(v.shape[1], -1).T
+
+
+def ctx_noise(seed, tensor, count):
+    """u in [-0.5, 0.5) for element 0..count-1 of tensor `tensor` (0 feat, 1 scaling, 2 offsets, 3 hyper) of the
+    counter-based training noise stream `seed`: splitmix64 of seed + golden * (4 e + tensor + 1), top 24 bits.
+    NOT a reference function (the reference draws torch.uniform_, scene/gaussian_model.py:1610-1616): this restates
+    the build's own generator (csrc/ctx.hip ctx_noise) so that fixtures can feed the SAME noise to the reference."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    e = np.arange(count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (e * np.uint64(4) + np.uint64(tensor + 1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.uint32).astype(f32) * f32(1.0 / 16777216.0) - f32(0.5)).astype(f32)
+
+
+# ---- scene/gaussian_model.py:1541-1707 ------------------------------------------------------------
 def multi_scale_generating(W, anchor, hyper, feat, offsets, scaling, masks, mask_anchor_bool, voxel_size, level_scale,
-                           level_num=3, D=50, K=10, return_sum_bits=False, x_means=None):
+                           level_num=3, D=50, K=10, return_sum_bits=False, x_means=None, train=None):
+    """Eval variants by default.  train = dict(seeds=[one per coded level, L-1 first], hyper_seed=int,
+    choose_mask=bool[N]) selects the TRAINING variant (training=True, predict_bpp=True, :1610-1616, :1686-1705)
+    with the noise of ctx_noise() and returns (feat_Q, scaling_Q, offsets_Q, rates dict, per-level stats)."""
     n = anchor.shape[0]
     feat_Q, scaling_Q = np.zeros_like(feat), np.zeros_like(scaling)
     offsets_Q = np.zeros_like(offsets)
     already = np.zeros(n, bool)
     stats = {k: np.zeros((n, d), f32) for k, d in (("mf", D), ("sf", D), ("qf", 1), ("ms", 6), ("ss", 6), ("qs", 1),
                                                     ("mo", 3 * K), ("so", 3 * K), ("qo", 1))}
-    hyper_feat, lik_hyper = bottleneck_eval(hyper, W)
+    if train is None:
+        hyper_feat, lik_hyper = bottleneck_eval(hyper, W)
+    else:
+        hyper_feat, lik_hyper = bottleneck_train(hyper, W, ctx_noise(train["hyper_seed"], 3, hyper.size).reshape(hyper.shape))
     anchors_l, inverse_list, mapping_list, _last = divide_levels(anchor, voxel_size, level_scale, level_num, mask_anchor_bool)
     context = None
+    coded, level_rows, preds = 0, [], []
     for i in reversed(range(level_num)):
         n_level = n if i == 0 else mapping_list[i - 1].shape[0]
         to_code = np.ones(n_level, bool)
@@ -255,27 +305,50 @@ def multi_scale_generating(W, anchor, hyper, feat, offsets, scaling, masks, mask
             Qf = np.maximum(f32(1) * (1 + np.tanh(aqf)), f32(1e-9)).astype(f32)
             Qs = np.maximum(f32(0.001) * (1 + np.tanh(aqs)), f32(1e-9)).astype(f32)
             Qo = np.maximum(f32(0.2) * (1 + np.tanh(aqo)), f32(1e-9)).astype(f32)
-            feat_Q[orig] = ste_multistep(feat[orig], Qf)
-            scaling_Q[orig] = ste_multistep(scaling[orig], Qs)
-            offsets_Q[orig] = ste_multistep(offsets[orig], Qo[:, None, :])
+            if train is None:
+                feat_Q[orig] = ste_multistep(feat[orig], Qf)
+                scaling_Q[orig] = ste_multistep(scaling[orig], Qs)
+                offsets_Q[orig] = ste_multistep(offsets[orig], Qo[:, None, :])
+            else:
+                sd, m = train["seeds"][coded], orig.shape[0]
+                feat_Q[orig] = (feat[orig] + ctx_noise(sd, 0, m * D).reshape(m, D) * Qf).astype(f32)
+                scaling_Q[orig] = (scaling[orig] + ctx_noise(sd, 1, m * 6).reshape(m, 6) * Qs).astype(f32)
+                offsets_Q[orig] = (offsets[orig] + ctx_noise(sd, 2, m * 3 * K).reshape(m, K, 3) * Qo[:, None, :]).astype(f32)
+            coded += 1
+            level_rows.append(orig)
+            preds.append(pred)
             for k, v in (("mf", mf), ("sf", sf), ("qf", Qf), ("ms", ms), ("ss", ss), ("qs", Qs), ("mo", mo), ("so", so), ("qo", Qo)):
                 stats[k][orig] = v
             already[orig] = True
         if i != 0:
             context = extract_context_feat(anchor, feat_Q, scaling_Q, already, inverse_list, mapping_list, i)
-    if not return_sum_bits:
+    if not return_sum_bits and train is None:
         return feat_Q, scaling_Q, offsets_Q
-    # :1657-1685 with chosse_random_thresh = 1 (every anchor chosen)
-    sel = np.ones(n, bool) if mask_anchor_bool is None else mask_anchor_bool.copy()
+    # :1657-1685 with chosse_random_thresh = 1 (every anchor chosen) / the given subset in training
+    sel = np.ones(n, bool) if train is None else train["choose_mask"].copy()
+    if mask_anchor_bool is not None:
+        sel &= mask_anchor_bool
     bit_hyper = -np.log2(lik_hyper[sel])
     bf = entropy_gaussian(feat_Q[sel], stats["mf"][sel], stats["sf"][sel], stats["qf"][sel], x_means[0])
     bs = entropy_gaussian(scaling_Q[sel], stats["ms"][sel], stats["ss"][sel], stats["qs"][sel], x_means[1])
     bo = entropy_gaussian(offsets_Q[sel].reshape(-1, 3 * K), stats["mo"][sel], stats["so"][sel], stats["qo"][sel], x_means[2])
     bo = bo * np.tile(masks[sel], (1, 1, 3)).reshape(-1, 3 * K)
-    m = masks.astype(np.float64)
-    pos = m.sum()
-    pg = np.clip(f32(pos / m.size), f32(1e-6), f32(1 - 1e-6))
-    bit_masks = float(f32(pos) * -np.log2(pg) + f32(m.size - pos) * -np.log2(f32(1) - pg) + 32)
+    if train is not None:                                   # :1687-1705
+        f64 = np.float64
+        rate = f64(mask_anchor_bool.sum()) / mask_anchor_bool.size if mask_anchor_bool is not None else 1.0
+        S = lambda a: a.sum(dtype=f64)
+        rates = dict(bit_per_param=(S(bf) + S(bs) + S(bo) + S(bit_hyper)) / (bf.size + bs.size + bo.size) * rate,
+                     bit_per_feat_param=S(bf) / bf.size * rate, bit_per_scaling_param=S(bs) / bs.size * rate,
+                     bit_per_offsets_param=S(bo) / bo.size * rate, bit_per_hyper_param=S(bit_hyper) / bit_hyper.size * rate)
+        bpp_map = bo.sum(1, dtype=f64) + bs.sum(1, dtype=f64) + bf.sum(1, dtype=f64)
+        each = [1 - (mask_anchor_bool.astype(f32).mean() if mask_anchor_bool is not None else 1.0), rates["bit_per_hyper_param"]]
+        for orig in level_rows:
+            lm = np.zeros(n, bool)
+            lm[orig] = True
+            each.append([orig.shape[0] / n, bpp_map[lm[sel]].mean() / (D + 6 + 3 * K)])
+        rates["each_level_bpp"] = each
+        return feat_Q, scaling_Q, offsets_Q, rates, dict(level_rows=level_rows, preds=preds, hyper_feat=hyper_feat)
+    bit_masks = binary_vxl_size(masks)[1]
     return (bit_hyper.shape[0] * 3 * 16, float(bit_hyper.sum(dtype=np.float64)), float(bf.sum(dtype=np.float64)),
             float(bs.sum(dtype=np.float64)), float(bo.sum(dtype=np.float64)), bit_masks)
 

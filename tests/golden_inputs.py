@@ -83,3 +83,14 @@ def elementwise_inputs(n, seed):
     Q = (1.0 * (1 + np.tanh(rng.normal(0, 0.5, size=(n, 1))))).clip(1e-9).astype(np.float32)
     x[1, :3] = 9e4                               # exercises the +-15000 Q clamp
     return x, mean, scale, Q
+
+
+def factorized_inputs(seed, M=1537):
+    """Values [M, H] fed to the factorised-prior density: N(0, 4^2) bulk (support +-10 and a little beyond) plus exact
+    integers and half-integers around 0, where sign(lower + upper) flips."""
+    rng = np.random.default_rng(seed + 40)
+    v = rng.normal(0, 4.0, size=(M, H)).astype(np.float32)
+    v[:21, 0] = np.arange(-10, 11, dtype=np.float32)
+    v[:21, 1] = np.arange(-10, 11, dtype=np.float32) + np.float32(0.5)
+    v[21, :] = 0
+    return v

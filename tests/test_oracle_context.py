@@ -129,3 +129,126 @@ def test_expansion_forward(tag, N, seed):
                                                    g["msg_scaling"][vis], mask[vis], cam)
     for a, b in ((xyz, g["ev_xyz"]), (color, g["ev_color"]), (op, g["ev_opacity"]), (sc, g["ev_scaling"]), (rot, g["ev_rot"])):
         assert a.shape == b.shape and np.allclose(a, b, rtol=1e-4, atol=2e-6)
+
+
+def _strided(g, key, a):
+    """Compare helper for fixtures written by tools/make_goldens.pack: (rows the fixture holds, the same rows of a)."""
+    stride = int(g["stride"]) if "stride" in g.files else 1
+    return g[key], a.reshape(a.shape[0], -1)[::stride].reshape(g[key].shape)
+
+
+@pytest.mark.parametrize("tag,N,seed", [("n3000", 3000, 2), ("n10000", 10000, 4)])
+def test_training_variant_forward(tag, N, seed):
+    """Oracle of the TRAINING context / rate path (scene/gaussian_model.py:1594-1707, training=True,
+    predict_bpp=True) against the reference run with the same fixed noise (tests/golden/train_*.npz)."""
+    g = _load(f"train_{tag}.npz")
+    W = gi.mlp_weights(seed)
+    st = gi.anchor_state(N, seed)
+    s = (1 / (1 + np.exp(-st["mask"].astype(np.float32)))).astype(np.float32)
+    mask = (s > 0.01).astype(np.float32)
+    mab = mask.sum(1)[:, 0] > 0
+    lo = st["anchor"].min(0, keepdims=True)
+    hi = st["anchor"].max(0, keepdims=True)
+    lo = np.where(lo < 0, lo * np.float32(1.2), lo * np.float32(0.8)).astype(np.float32)
+    hi = np.where(hi > 0, hi * np.float32(1.2), hi * np.float32(0.8)).astype(np.float32)
+    anchor, _q = cr.quantize_anchor(st["anchor"], lo, hi)
+    scaling = np.exp(st["scaling"]).astype(np.float32)
+    ls = [float(v) for v in g["level_scale"]]
+    train = dict(seeds=[int(v) for v in g["level_seeds"]], hyper_seed=int(g["hyper_seed"]), choose_mask=g["choose_mask"])
+    fq, sq, oq, rates, extra = cr.multi_scale_generating(
+        W, anchor, st["hyper"], st["feat"], st["offset"], scaling, mask, mab, 0.01, ls, train=train,
+        x_means=(st["feat"].mean(dtype=np.float32), scaling.mean(dtype=np.float32), st["offset"].mean(dtype=np.float32)))
+    # noisy "quantised" tensors: x + u Q with Q from the level MLP -> fp32 round-off of the MLP only
+    for key, a, step in (("msg_feat", fq, 1.0), ("msg_scaling", sq, 1e-3), ("msg_offsets", oq.reshape(N, -1), 0.2)):
+        ref, got = _strided(g, key, a)
+        assert np.abs(got - ref).max() <= 2e-5 * step * (1 + np.abs(ref).max()), key
+    # the level MLP outputs themselves (mu, sigma, step-size logits), rows strided by max(stride, 4)
+    lvl_stride = max(int(g["stride"]), 4)
+    for j, i in enumerate(reversed(range(3))):
+        ref = g[f"pred_level{i}"]
+        got = extra["preds"][j][::lvl_stride]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-5 * (1 + np.abs(ref).max())
+    got = [rates["bit_per_param"], rates["bit_per_feat_param"], rates["bit_per_scaling_param"], rates["bit_per_offsets_param"]]
+    assert np.allclose(got, g["bits"], rtol=2e-4), (got, g["bits"])
+    assert np.allclose(rates["each_level_bpp"][:2], g["bpp_head"], rtol=2e-4)
+    assert np.allclose(np.array(rates["each_level_bpp"][2:]), g["bpp_levels"], rtol=2e-4)
+
+
+def test_ctx_noise_is_uniform_and_keyed():
+    """The build's counter-based noise (restated in the oracle, fed to the reference by make_goldens): range,
+    moments, and independence of (seed, tensor)."""
+    u = cr.ctx_noise(12345, 0, 200000)
+    assert u.dtype == np.float32 and u.min() >= -0.5 and u.max() < 0.5
+    assert abs(float(u.mean())) < 3e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    v = cr.ctx_noise(12345, 1, 200000)
+    w = cr.ctx_noise(12346, 0, 200000)
+    assert abs(float(np.corrcoef(u, v)[0, 1])) < 0.01 and abs(float(np.corrcoef(u, w)[0, 1])) < 0.01
+    assert abs(float(np.corrcoef(u[:-1], u[1:])[0, 1])) < 0.01
+
+
+def test_entropy_api_goldens():
+    """b5 / b8 / b10 (dead-but-public API + the factorised-prior density): oracle vs the reference's outputs."""
+    g = _load("entropy_api.npz")
+    x, mean, scale, Q = gi.elementwise_inputs(193, 6)
+    close = lambda a, b: np.abs(np.exp2(-a) - np.exp2(-b)).max() <= 3e-7 and np.abs(a - b).max() <= 0.1
+    assert close(cr.entropy_gaussian(x, mean, scale, Q), g["egc_bits"])                    # Entropy_gaussian_clamp
+    assert close(cr.entropy_gaussian(x, mean, scale, np.float32(0.25)), g["egc_bits_scalarQ"])
+    gx, gm, gs, gq = cr.entropy_gaussian_grads(x, mean, scale, Q, x.mean(dtype=np.float32), g["egc_gw"])
+    well = g["egc_bits"] < 10
+    for a, b in ((gx, g["egc_gx"]), (gm, g["egc_gmean"]), (gs, g["egc_gscale"])):
+        assert np.allclose(a[well], b[well], rtol=2e-3, atol=1e-5 * np.abs(b).max())
+    rng = np.random.default_rng(21)
+    for k, (n, p1) in enumerate(((1000, 0.7), (30, 0.0), (30, 1.0), (77777, 0.013))):
+        m = (rng.random((n, 10, 1)) < p1).astype(np.float32)
+        got = cr.binary_vxl_size(m)
+        assert np.allclose(got, g[f"bvs_{k}"][:4], rtol=1e-6), (k, got, g[f"bvs_{k}"])
+    # UniverseQuant: subtractive dither -> error uniform on [-1/2, 1/2]
+    assert abs(g["uq_err_mean"]) < 3e-3 and abs(g["uq_err_var"] - 1 / 12) < 1e-3 and g["uq_err_absmax"] <= 0.5
+    assert bool(g["uq_grad_is_one"])
+    for seed in (2, 7):
+        W = gi.mlp_weights(seed)
+        v = gi.factorized_inputs(seed)
+        x3 = v.T.reshape(gi.H, 1, -1)
+        back = lambda t: t.reshape(gi.H, -1).T
+        lower, upper = back(cr.bottleneck_logits(x3 - np.float32(0.5), W)), back(cr.bottleneck_logits(x3 + np.float32(0.5), W))
+        assert np.abs(lower - g[f"fz{seed}_lower"]).max() <= 2e-5 * (1 + np.abs(g[f"fz{seed}_lower"]).max())
+        assert np.abs(upper - g[f"fz{seed}_upper"]).max() <= 2e-5 * (1 + np.abs(g[f"fz{seed}_upper"]).max())
+        lik = cr.bottleneck_likelihood(v, W)
+        assert np.abs(lik - g[f"fz{seed}_lik"]).max() <= 3e-7
+        assert np.abs(-np.log2(np.maximum(lik, 1e-6)) - g[f"fz{seed}_bits"]).max() <= 1e-3
+
+
+def test_host_density_classes_match_reference():
+    """The torch statement of the factorised density (entropy_bottleneck.cumulative_logits, shared by
+    EntropyBottleneck and utils.entropy_models.Entropy_factorized) against the reference's `_logits_cumulative`
+    outputs and autograd gradients — on CPU tensors: this is host code, no kernel involved."""
+    import torch
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    from contextgs_amd.entropy_models import Entropy_factorized
+    g = _load("entropy_api.npz")
+    for seed in (2, 7):
+        W = gi.mlp_weights(seed)
+        m = Entropy_factorized(channel=gi.H, filters=(3, 3, 3, 3))
+        eb = EntropyBottleneck(gi.H)
+        with torch.no_grad():
+            for i in range(5):
+                for dst in (m._matrices[i], eb.matrices[i]):
+                    dst.copy_(torch.from_numpy(W[f"latent_codec.matrices.{i}"]))
+                for dst in (m._bias[i], eb.biases[i]):
+                    dst.copy_(torch.from_numpy(W[f"latent_codec.biases.{i}"]))
+                if i < 4:
+                    for dst in (m._factor[i], eb.factors[i]):
+                        dst.copy_(torch.from_numpy(W[f"latent_codec.factors.{i}"]))
+        v = torch.from_numpy(gi.factorized_inputs(seed)).requires_grad_(True)
+        x3 = v.t().reshape(gi.H, 1, -1)
+        back = lambda t: t.detach().numpy().reshape(gi.H, -1).T
+        assert np.allclose(back(m._logits_cumulative(x3 - 0.5, False)), g[f"fz{seed}_lower"], rtol=1e-5, atol=1e-5)
+        lik = eb._likelihood(x3)
+        assert np.abs(back(lik) - g[f"fz{seed}_lik"]).max() <= 2e-7
+        (lik * torch.from_numpy(g[f"fz{seed}_gw"].T.reshape(gi.H, 1, -1).copy())).sum().backward()
+        assert np.allclose(v.grad.numpy(), g[f"fz{seed}_gv"], rtol=1e-3, atol=1e-7)
+        for i in range(5):
+            assert np.allclose(eb.matrices[i].grad.numpy(), g[f"fz{seed}_g_matrices.{i}"], rtol=1e-3, atol=1e-5)
+            assert np.allclose(eb.biases[i].grad.numpy(), g[f"fz{seed}_g_biases.{i}"], rtol=1e-3, atol=1e-5)
+        bits = m.forward(v.detach())                           # [N,C] semantics, bound 1e-6
+        assert np.abs(bits.detach().numpy() - g[f"fz{seed}_bits"]).max() <= 1e-4

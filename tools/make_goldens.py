@@ -201,6 +201,182 @@ def golden_model(N, seed, tag):
     np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
 
 
+TRAIN_SEEDS = dict(hyper_seed=0x5EED0003, seeds=[0x5EED1002, 0x5EED2001, 0x5EED3000])
+
+
+def pack(out, name, arr, stride):
+    """Store arr (rows strided by `stride` when > 1) plus fp64 column sums / abs-sums of ALL rows, so that a large
+    per-anchor tensor is pinned without shipping every row."""
+    a = npy(arr)
+    out[name] = a[::stride] if stride > 1 else a
+    if stride > 1:
+        flat = a.reshape(a.shape[0], -1).astype(np.float64)
+        out[name + "__colsum"] = flat.sum(0)
+        out[name + "__abssum"] = np.abs(flat).sum(0)
+
+
+def golden_training(N, seed, tag, stride):
+    """The TRAINING variant of the context / rate path (scene/gaussian_model.py:1594-1707 with training=True,
+    predict_bpp=True) as gaussian_renderer/__init__.py:63-81 calls it at step > 10000, then the expansion, with
+    FIXED noise: every torch uniform_ / rand_like the reference draws is replaced by the arrays of
+    oracle.context_ref.ctx_noise(seed, tensor, .) (the build's counter-based generator), so the HIP path can be
+    driven with bit-identical noise.  Outputs, rate terms and the gradient of every parameter are recorded."""
+    import golden_inputs as gi
+    import gaussian_renderer as gr
+    from scene import gaussian_model as gm
+    from oracle.context_ref import ctx_noise
+    pc = build_reference_model(N, seed)
+    pc.train()
+    out = {"_meta": np.array(f"training variant, step=20000, N={N} seed={seed} stride={stride}; noise = "
+                             f"oracle.context_ref.ctx_noise; EntropyBottleneck stub = contextgs_amd.entropy_bottleneck"),
+           "hyper_seed": np.uint64(TRAIN_SEEDS["hyper_seed"]), "level_seeds": np.array(TRAIN_SEEDS["seeds"], np.uint64),
+           "stride": np.int64(stride)}
+    with torch.no_grad():
+        anchor = pc.get_anchor
+        mab = pc.get_mask_anchor.to(torch.bool)
+        pc.level_scale = gm.find_divide_scale(pc, anchor[mab], pc.target_ratio, pc.level_num)
+    out["level_scale"] = np.asarray(pc.level_scale, dtype=np.float64)
+    choose_rand = np.random.default_rng(seed + 21).random(N).astype(np.float32)
+    out["choose_mask"] = choose_rand <= np.float32(0.15)
+
+    calls = {"uniform": 0, "rand": 0}
+    real_uniform, real_rand_like = torch.Tensor.uniform_, torch.rand_like
+
+    def fake_uniform_(self, a=0.0, b=1.0, **kw):
+        assert (a, b) == (-0.5, 0.5), (a, b)
+        k = calls["uniform"]
+        calls["uniform"] += 1
+        if k == 0:          # EntropyBottleneck stub: [C,1,N] view of the [N,C] hyper noise
+            C = self.shape[0]
+            u = ctx_noise(TRAIN_SEEDS["hyper_seed"], 3, N * C).reshape(N, C).T.reshape(C, 1, N)
+        else:               # levels L-1..0, (feat, scaling, offsets) each
+            lvl, t = divmod(k - 1, 3)
+            u = ctx_noise(TRAIN_SEEDS["seeds"][lvl], t, self.numel()).reshape(tuple(self.shape))
+        assert tuple(u.shape) == tuple(self.shape), (k, u.shape, self.shape)
+        with torch.no_grad():
+            self.copy_(torch.from_numpy(np.ascontiguousarray(u)))
+        return self
+
+    def fake_rand_like(t, **kw):
+        calls["rand"] += 1
+        assert t.shape == (N,)
+        return torch.from_numpy(choose_rand.copy())
+
+    preds = {}
+    hooks = [pc.mlp_grid[i].register_forward_hook(lambda m, a, o, i=i: preds.__setitem__(i, o.detach().clone()))
+             for i in range(pc.level_num)]
+    cam = types.SimpleNamespace(camera_center=torch.from_numpy(gi.camera_center(seed)))
+    vis = torch.from_numpy(np.random.default_rng(seed + 3).random(N) < 0.8)
+    out["visible_mask"] = npy(vis)
+    torch.Tensor.uniform_, torch.rand_like = fake_uniform_, fake_rand_like
+    captured = {}
+    real_msg = gr.multi_scale_generating
+
+    def spy_msg(*a, **k):
+        r = real_msg(*a, **k)
+        captured["msg"] = r
+        return r
+
+    gr.multi_scale_generating = spy_msg
+    try:
+        res = gr.generate_neural_gaussians(cam, pc, vis, is_training=True, step=20000)
+    finally:
+        torch.Tensor.uniform_, torch.rand_like = real_uniform, real_rand_like
+        gr.multi_scale_generating = real_msg
+        for h in hooks:
+            h.remove()
+    assert calls["uniform"] == 1 + 3 * pc.level_num and calls["rand"] == 1, calls
+    (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, bpa, bit_per_feat_param, bit_per_scaling_param,
+     bit_per_offsets_param, bpp_per_level) = res
+    assert bpa == 16
+    fq, sq, oq = captured["msg"][:3]
+    pack(out, "msg_feat", fq, stride)
+    pack(out, "msg_scaling", sq, stride)
+    pack(out, "msg_offsets", oq.reshape(N, -1), stride)
+    for i in range(pc.level_num):
+        pack(out, f"pred_level{i}", preds[i], max(stride, 4))
+    rng = np.random.default_rng(seed + 11)
+    ws = [torch.from_numpy(rng.normal(size=tuple(t.shape)).astype(np.float32)) for t in (xyz, color, opacity, scaling, rot)]
+    RW = (50.0, 30.0, 20.0, 10.0)        # weights of the four rate terms in the test loss
+    loss = sum((t * w).sum() for t, w in zip((xyz, color, opacity, scaling, rot), ws))
+    loss = loss + RW[0] * bit_per_param + RW[1] * bit_per_feat_param + RW[2] * bit_per_scaling_param + RW[3] * bit_per_offsets_param
+    loss.backward()
+    out.update(tr_mask=npy(mask), tr_loss=np.float64(loss.item()), rate_weights=np.array(RW),
+               bits=np.array([bit_per_param.item(), bit_per_feat_param.item(), bit_per_scaling_param.item(),
+                              bit_per_offsets_param.item()], np.float64),
+               bpp_head=np.array(bpp_per_level[:2], np.float64), bpp_levels=np.array(bpp_per_level[2:], np.float64))
+    for k, t in (("tr_xyz", xyz), ("tr_color", color), ("tr_opacity", opacity), ("tr_scaling", scaling), ("tr_rot", rot),
+                 ("tr_neural_opacity", neural_opacity)):
+        pack(out, k, t, stride)
+    for k, p in (("g_anchor", pc._anchor), ("g_offset", pc._offset), ("g_mask", pc._mask), ("g_feat", pc._anchor_feat),
+                 ("g_hyper", pc._hyper_latent), ("g_scaling", pc._scaling)):
+        pack(out, k, p.grad.reshape(N, -1), stride)
+    for name, p in pc.named_parameters():
+        if name.split(".")[0] in ("mlp_opacity", "mlp_cov", "mlp_color", "mlp_grid", "latent_codec") and p.grad is not None:
+            out["gw_" + name] = npy(p.grad)
+    np.savez_compressed(os.path.join(OUT, f"train_{tag}.npz"), **out)
+
+
+def golden_entropy_api():
+    """b5 / b10: the rest of utils.entropy_models + get_binary_vxl_size, and the factorised-prior DENSITY
+    (Entropy_factorized._logits_cumulative + the sigmoid-difference likelihood, utils/entropy_models.py:103-135)
+    with the hyper prior's weights of golden_inputs.mlp_weights — the in-mount maths that pins csrc/eb.hip."""
+    import golden_inputs as gi
+    from utils.encodings import get_binary_vxl_size
+    from utils.entropy_models import Entropy_factorized, Entropy_gaussian_clamp, Low_bound, UniverseQuant
+    out = {}
+    # -- Entropy_gaussian_clamp (clamp centre = x.mean(), :8-27): values + 4 gradients
+    x, mean, scale, Q = (torch.from_numpy(v).clone().requires_grad_(True) for v in gi.elementwise_inputs(193, 6))
+    bits = Entropy_gaussian_clamp(Q=1).forward(x, mean, scale, Q)
+    gw = torch.from_numpy(np.random.default_rng(19).normal(size=tuple(bits.shape)).astype(np.float32))
+    (bits * gw).sum().backward()
+    out.update(egc_bits=npy(bits), egc_gw=npy(gw), egc_gx=npy(x.grad), egc_gmean=npy(mean.grad), egc_gscale=npy(scale.grad),
+               egc_gQ=npy(Q.grad))
+    out["egc_bits_scalarQ"] = npy(Entropy_gaussian_clamp(Q=0.25).forward(x.detach(), mean.detach(), scale.detach()))
+    # -- UniverseQuant (:159-171): a random draw per call -> statistics of the quantisation error + identity gradient
+    torch.manual_seed(123)
+    xu = torch.from_numpy(np.random.default_rng(20).normal(0, 3, size=(400, 250)).astype(np.float32)).requires_grad_(True)
+    yu = UniverseQuant.apply(xu)
+    yu.sum().backward()
+    e = (yu - xu).detach().double()
+    out.update(uq_err_mean=np.float64(e.mean()), uq_err_var=np.float64(e.var()), uq_err_absmax=np.float64(e.abs().max()),
+               uq_grad_is_one=np.bool_(bool((xu.grad == 1).all())))
+    # -- get_binary_vxl_size (utils/encodings.py:15-32)
+    rng = np.random.default_rng(21)
+    for k, (n, p1) in enumerate(((1000, 0.7), (30, 0.0), (30, 1.0), (77777, 0.013))):
+        m = (rng.random((n, 10, 1)) < p1).astype(np.float32)
+        Pg, ttl_bit, mb, ttl_num = get_binary_vxl_size(torch.from_numpy(m))
+        out[f"bvs_{k}"] = np.array([Pg.item(), ttl_bit.item(), mb, ttl_num, n, p1], np.float64)
+    # -- factorised prior density with the latent_codec weights (C = 12 channels, filters 3,3,3,3)
+    for seed in (2, 7):
+        W = gi.mlp_weights(seed)
+        m = Entropy_factorized(channel=gi.H, filters=(3, 3, 3, 3))
+        with torch.no_grad():
+            for i in range(5):
+                m._matrices[i].copy_(torch.from_numpy(W[f"latent_codec.matrices.{i}"]))
+                m._bias[i].copy_(torch.from_numpy(W[f"latent_codec.biases.{i}"]))
+                if i < 4:
+                    m._factor[i].copy_(torch.from_numpy(W[f"latent_codec.factors.{i}"]))
+        v = torch.from_numpy(gi.factorized_inputs(seed)).requires_grad_(True)             # [M, C]
+        x3 = v.t().reshape(gi.H, 1, -1)                                                     # [C,1,M] as the class uses it
+        lower = m._logits_cumulative(x3 - 0.5, stop_gradient=False)
+        upper = m._logits_cumulative(x3 + 0.5, stop_gradient=False)
+        sign = -torch.sign(torch.add(lower, upper)).detach()                               # :129-133
+        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        bits = -torch.log2(Low_bound.apply(lik))                                          # :134-135 (bound 1e-6)
+        gwl = torch.from_numpy(np.random.default_rng(seed + 30).normal(size=tuple(lik.shape)).astype(np.float32))
+        (lik * gwl).sum().backward()
+        back = lambda t: npy(t).reshape(gi.H, -1).T                                         # -> [M, C]
+        out.update({f"fz{seed}_lower": back(lower), f"fz{seed}_upper": back(upper), f"fz{seed}_lik": back(lik),
+                    f"fz{seed}_bits": back(bits), f"fz{seed}_gw": back(gwl), f"fz{seed}_gv": npy(v.grad)})
+        for i in range(5):
+            out[f"fz{seed}_g_matrices.{i}"] = npy(m._matrices[i].grad)
+            out[f"fz{seed}_g_biases.{i}"] = npy(m._bias[i].grad)
+            if i < 4:
+                out[f"fz{seed}_g_factors.{i}"] = npy(m._factor[i].grad)
+    np.savez_compressed(os.path.join(OUT, "entropy_api.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF), "the reference mount is required"
     os.makedirs(OUT, exist_ok=True)
@@ -210,8 +386,11 @@ def main():
     torch.manual_seed(0)
     with CudaToCpu():
         golden_elementwise()
+        golden_entropy_api()
         golden_model(64, 1, "n64")
         golden_model(3000, 2, "n3000")
+        golden_training(3000, 2, "n3000", 1)
+        golden_training(10000, 4, "n10000", 5)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
