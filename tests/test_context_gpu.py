@@ -22,6 +22,43 @@ def _load(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
+def _sub(g, a):
+    """Rows of a full-size array that a (possibly row-strided, tools/make_goldens.pack) fixture holds."""
+    return a[::int(g["stride"])] if "stride" in g.files else a
+
+
+def _colsums_ok(g, key, a, rtol):
+    """All rows of a strided fixture through the fp64 column sums it carries."""
+    if "stride" not in g.files:
+        return True
+    a2 = a.reshape(a.shape[0], -1).astype(np.float64)
+    return bool(np.all(np.abs(a2.sum(0) - g[key + "__colsum"]) <= rtol * g[key + "__abssum"] + 1e-9))
+
+
+def _align(a, b, tol, max_skips):
+    """Index pairs (i, j) of rows a[i] ~ b[j] of two compacted row lists that differ by a few inserted / dropped rows
+    (two-pointer walk on row equality within tol)."""
+    i = j = skips = 0
+    pairs = []
+    while i < a.shape[0] and j < b.shape[0]:
+        if np.all(np.abs(a[i] - b[j]) <= tol * (1 + np.abs(b[j]))):
+            pairs.append((i, j)); i += 1; j += 1
+            continue
+        skips += 1
+        assert skips <= max_skips, "too many unmatched rows"
+        # which side holds the extra row?  the one whose NEXT row matches the other's current row
+        if i + 1 < a.shape[0] and np.all(np.abs(a[i + 1] - b[j]) <= tol * (1 + np.abs(b[j]))):
+            i += 1
+        elif j + 1 < b.shape[0] and np.all(np.abs(a[i] - b[j + 1]) <= tol * (1 + np.abs(b[j + 1]))):
+            j += 1
+        else:                # a substituted row (its values moved by a quantisation step): skip both
+            i += 1; j += 1
+    return np.array(pairs, dtype=np.int64).reshape(-1, 2)
+
+
+MODEL_CASES = [("n64", 64, 1), ("n3000", 3000, 2), ("n10000", 10000, 4)]
+
+
 def _model(N, seed):
     from contextgs_amd.model import GaussianModel
     pc = GaussianModel(feat_dim=gi.D, n_offsets=gi.K, voxel_size=0.01, level_num=gi.LEVELS, target_ratio=0.2)
@@ -80,7 +117,7 @@ def test_entropy_gaussian_matches_reference():
     assert np.allclose(eb.cpu().numpy(), g["eb_bits"], atol=1e-6)
 
 
-@pytest.mark.parametrize("tag,N,seed", [("n64", 64, 1), ("n3000", 3000, 2)])
+@pytest.mark.parametrize("tag,N,seed", MODEL_CASES)
 def test_levels_and_context_model(tag, N, seed):
     from contextgs_amd import context_model as cm
     from contextgs_amd.multi_level import torch_unique_with_indices
@@ -112,8 +149,10 @@ def test_levels_and_context_model(tag, N, seed):
         f, s, o = cm.multi_scale_generating(pc, anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
                                             T(g["get_scaling"]), pc.get_mask, mab, predict_bpp=False, training=False)
         for a, b, step in ((f, g["msg_feat"], 1.0), (s, g["msg_scaling"], 1e-3), (o, g["msg_offsets"], 0.2)):
-            bad = np.abs(a.cpu().numpy() - b) > 1e-4 * step
-            assert bad.mean() <= 5e-4, bad.mean()          # rounding-boundary flips only
+            d = np.abs(_sub(g, a.cpu().numpy()) - b)
+            bad = d > 1e-4 * step
+            assert bad.mean() <= 5e-4, bad.mean()          # rounding-boundary flips only ...
+            assert d.max() <= 2.02 * step                  # ... and a flip moves a value by ONE step Q < 2 Q0
         sums = cm.multi_scale_generating(pc, anchor[mab], pc._hyper_latent[mab], pc._anchor_feat[mab], pc._offset[mab],
                                          T(g["get_scaling"])[mab], binary_grid_masks=pc.get_mask[mab], predict_bpp=True,
                                          return_sum_bits=True)
@@ -121,7 +160,7 @@ def test_levels_and_context_model(tag, N, seed):
         assert np.allclose(sums[1:], g["msg_sum_bits"][1:], rtol=2e-3)
 
 
-@pytest.mark.parametrize("tag,N,seed", [("n64", 64, 1), ("n3000", 3000, 2)])
+@pytest.mark.parametrize("tag,N,seed", MODEL_CASES)
 def test_generate_neural_gaussians(tag, N, seed):
     from contextgs_amd.renderer import generate_neural_gaussians
     g = _load(f"model_{tag}.npz")
@@ -133,22 +172,33 @@ def test_generate_neural_gaussians(tag, N, seed):
     with torch.no_grad():
         pc.eval()
         xyz, color, opacity, scaling, rot, _ = generate_neural_gaussians(cam, pc, vis, is_training=False)
-    n_ref, n_got = g["ev_xyz"].shape[0], xyz.shape[0]
-    if n_got == n_ref:     # a rounding-boundary flip in the context model can change a borderline opacity sign
-        for a, b in ((xyz, g["ev_xyz"]), (color, g["ev_color"]), (opacity, g["ev_opacity"]), (rot, g["ev_rot"])):
-            d = np.abs(a.cpu().numpy() - b)
-            assert (d > 1e-4 * (1 + np.abs(b))).mean() <= 2e-3
+    n_ref, n_got = int(g["ev_count"]), xyz.shape[0]
+    outs = [(xyz, "ev_xyz"), (color, "ev_color"), (opacity, "ev_opacity"), (scaling, "ev_scaling"), (rot, "ev_rot")]
+    if n_got == n_ref:
+        for a, key in outs:
+            b = g[key]
+            d = np.abs(_sub(g, a.cpu().numpy()) - b)
+            assert (d > 1e-4 * (1 + np.abs(b))).mean() <= 2e-3, key
     else:
+        # a rounding-boundary flip in the context model moved a borderline opacity across 0: a Gaussian appears or
+        # disappears.  At most a handful, and every OTHER row must still match: align the two row lists on xyz
         assert abs(n_got - n_ref) <= max(2, n_ref // 2000)
+        assert "stride" not in g.files, "row alignment needs the full fixture"
+        pairs = _align(xyz.cpu().numpy(), g["ev_xyz"], 1e-4, max(4, n_ref // 1000))
+        assert pairs.shape[0] >= n_ref - max(4, n_ref // 1000)
+        for a, key in outs[1:]:
+            a_, b_ = a.cpu().numpy()[pairs[:, 0]], g[key][pairs[:, 1]]
+            assert (np.abs(a_ - b_) > 1e-4 * (1 + np.abs(b_))).mean() <= 2e-3, key
 
     pc.train()
     res = generate_neural_gaussians(cam, pc, vis, is_training=True, step=1000)
     xyz, color, opacity, scaling, rot, neural_opacity, mask = res[:7]
     assert res[7] is None and res[8] == 16
     assert np.array_equal(mask.cpu().numpy(), g["tr_mask"])
-    for a, b in ((xyz, g["tr_xyz"]), (color, g["tr_color"]), (opacity, g["tr_opacity"]), (scaling, g["tr_scaling"]),
-                 (rot, g["tr_rot"]), (neural_opacity, g["tr_neural_opacity"])):
-        assert close(a.detach().cpu().numpy(), b)
+    for a, key in ((xyz, "tr_xyz"), (color, "tr_color"), (opacity, "tr_opacity"), (scaling, "tr_scaling"),
+                   (rot, "tr_rot"), (neural_opacity, "tr_neural_opacity")):
+        a = a.detach().cpu().numpy()
+        assert close(_sub(g, a), g[key]) and _colsums_ok(g, key, a, 1e-4), key
     rng = np.random.default_rng(seed + 11)
     ws = [T(rng.normal(size=tuple(t.shape)).astype(np.float32)) for t in (xyz, color, opacity, scaling, rot)]
     loss = sum((t * w).sum() for t, w in zip((xyz, color, opacity, scaling, rot), ws))
@@ -160,5 +210,8 @@ def test_generate_neural_gaussians(tag, N, seed):
                      (pc.mlp_color[2].bias.grad, "g_color_b2")):
         ref = g[key]
         a = got.cpu().numpy()
+        if key in ("g_anchor", "g_offset", "g_mask", "g_feat", "g_scaling"):
+            assert _colsums_ok(g, key, a, 1e-3), key
+            a = _sub(g, a)
         assert a.shape == ref.shape, key
         assert np.abs(a - ref).max() <= 2e-4 * max(1e-6, np.abs(ref).max()), (key, np.abs(a - ref).max(), np.abs(ref).max())

@@ -137,13 +137,16 @@ def golden_elementwise():
     np.savez_compressed(os.path.join(OUT, "elementwise.npz"), **out)
 
 
-def golden_model(N, seed, tag):
+def golden_model(N, seed, tag, stride=1):
     import golden_inputs as gi
     import gaussian_renderer as gr
     from scene import gaussian_model as gm
     from utils.multi_level import torch_unique_with_indices
     pc = build_reference_model(N, seed)
     out = {"_meta": np.array(f"N={N} seed={seed}; EntropyBottleneck stub = contextgs_amd.entropy_bottleneck")}
+    if stride > 1:      # large case: float tensors with one row per anchor / Gaussian keep every stride-th row + fp64 column sums
+        out["stride"] = np.int64(stride)
+    P_ = lambda name, arr: pack(out, name, arr, stride)
     with torch.no_grad():
         out.update(get_mask=npy(pc.get_mask), get_mask_anchor=npy(pc.get_mask_anchor), get_scaling=npy(pc.get_scaling),
                    get_anchor=npy(pc.get_anchor), x_bound_min=npy(pc.x_bound_min), x_bound_max=npy(pc.x_bound_max))
@@ -165,7 +168,7 @@ def golden_model(N, seed, tag):
         pc.eval()
         f, s, o = gm.multi_scale_generating(pc, anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, pc.get_scaling,
                                             pc.get_mask, mab, predict_bpp=False, training=False)
-        out.update(msg_feat=npy(f), msg_scaling=npy(s), msg_offsets=npy(o))
+        P_("msg_feat", f), P_("msg_scaling", s), P_("msg_offsets", o)
         cwd = os.getcwd()
         with tempfile.TemporaryDirectory() as td:      # return_sum_bits writes data_for_vis.pt into cwd
             os.chdir(td)
@@ -184,7 +187,9 @@ def golden_model(N, seed, tag):
     with torch.no_grad():
         pc.eval()
         xyz, color, opacity, scaling, rot, _ = gr.generate_neural_gaussians(cam, pc, vis, is_training=False)
-        out.update(ev_xyz=npy(xyz), ev_color=npy(color), ev_opacity=npy(opacity), ev_scaling=npy(scaling), ev_rot=npy(rot))
+        for k_, t_ in (("ev_xyz", xyz), ("ev_color", color), ("ev_opacity", opacity), ("ev_scaling", scaling), ("ev_rot", rot)):
+            P_(k_, t_)
+        out["ev_count"] = np.int64(xyz.shape[0])
     pc.train()
     res = gr.generate_neural_gaussians(cam, pc, vis, is_training=True, step=1000)
     xyz, color, opacity, scaling, rot, neural_opacity, mask = res[:7]
@@ -192,10 +197,11 @@ def golden_model(N, seed, tag):
     ws = [torch.from_numpy(rng.normal(size=tuple(t.shape)).astype(np.float32)) for t in (xyz, color, opacity, scaling, rot)]
     loss = sum((t * w).sum() for t, w in zip((xyz, color, opacity, scaling, rot), ws))
     loss.backward()
-    out.update(tr_xyz=npy(xyz), tr_color=npy(color), tr_opacity=npy(opacity), tr_scaling=npy(scaling), tr_rot=npy(rot),
-               tr_neural_opacity=npy(neural_opacity), tr_mask=npy(mask), tr_loss=np.float64(loss.item()),
-               g_anchor=npy(pc._anchor.grad), g_offset=npy(pc._offset.grad), g_mask=npy(pc._mask.grad),
-               g_feat=npy(pc._anchor_feat.grad), g_scaling=npy(pc._scaling.grad),
+    for k_, t_ in (("tr_xyz", xyz), ("tr_color", color), ("tr_opacity", opacity), ("tr_scaling", scaling), ("tr_rot", rot),
+                   ("tr_neural_opacity", neural_opacity), ("g_anchor", pc._anchor.grad), ("g_offset", pc._offset.grad),
+                   ("g_mask", pc._mask.grad), ("g_feat", pc._anchor_feat.grad), ("g_scaling", pc._scaling.grad)):
+        P_(k_, t_)
+    out.update(tr_mask=npy(mask), tr_loss=np.float64(loss.item()),
                g_op_w2=npy(pc.mlp_opacity[2].weight.grad), g_cov_w0=npy(pc.mlp_cov[0].weight.grad),
                g_color_b2=npy(pc.mlp_color[2].bias.grad))
     np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
@@ -389,6 +395,7 @@ def main():
         golden_entropy_api()
         golden_model(64, 1, "n64")
         golden_model(3000, 2, "n3000")
+        golden_model(10000, 4, "n10000", 5)
         golden_training(3000, 2, "n3000", 1)
         golden_training(10000, 4, "n10000", 5)
     for f in sorted(os.listdir(OUT)):
