@@ -1,0 +1,153 @@
+"""BASELINE.json's configurations c2, c3 and c5 at FULL size on one MI355X (c1 is the CPU oracle's plumbing case,
+tests/test_oracle_raster.py; c4's single-GPU training step runs in tests/test_training_gpu.py, its 8-GPU half is the
+driver's scaling run).
+
+c2: ~100 k anchors, 800x800, forward + backward: the visibility filter, the anchor -> Gaussian expansion and the
+    rasterizer (image + six gradient tensors) against the CPU oracles on the SAME full-size inputs.
+c3: ~500 k anchors, 1920x1080, 3-level context entropy encode + decode: every decoded attribute equals the encoder's
+    quantised value bit for bit, and the decoded model renders the encoder-side image.
+c5: ~3 M anchors, rate sweep (feature spread as the lambda proxy), encode -> files -> decode round trip.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, bg):
+    from contextgs_amd.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=1, campos=cam.camera_center, prefiltered=False, debug=False)
+
+
+def test_c2_100k_anchors_800x800_forward_backward_vs_oracles(oracle32):
+    from contextgs_amd.rasterizer import GaussianRasterizer
+    from contextgs_amd.renderer import generate_neural_gaussians, prefilter_voxel
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    from oracle import context_ref as cr
+    N, W, H = 100_000, 800, 800
+    pc = make_scene(N, seed=0)
+    pc.train()
+    cam_np = orbit_cameras(8, W, H)[3]
+    cam = cam_np.to_torch("cuda")
+    bg = torch.zeros(3, device="cuda")
+    f = lambda t: t.detach().cpu().numpy()
+
+    # a1: anchor-level cull, bit-exact radii>0 against the oracle's preprocess on all 100 k anchors
+    vis = prefilter_voxel(cam, pc, SynthPipe(), bg)
+    with torch.no_grad():
+        rot0 = pc.get_rotation[[0], :].repeat(N, 1)
+        ref_r = oracle32.visible_filter(cam_np.oracle_dict(), f(pc.get_anchor), f(pc.get_scaling[:, :3]), f(rot0))
+    assert np.array_equal(f(vis), ref_r > 0) and 0.5 * N < int(vis.sum()) <= N
+
+    # a2: expansion (training phase, step <= 3000) against the numpy oracle on every visible anchor
+    xyz, color, opacity, scaling, rot, neural_opacity, mask = generate_neural_gaussians(
+        cam, pc, vis, is_training=True, step=1000)[:7]
+    Wd = {k: f(v) for k, v in pc.state_dict().items()}
+    v = f(vis)
+    o_xyz, o_color, o_op, o_sc, o_rot, o_no, o_sel = cr.expand(
+        Wd, f(pc.get_anchor)[v], f(pc._anchor_feat)[v], f(pc._offset)[v], f(pc.get_scaling)[v], f(pc.get_mask)[v],
+        f(cam.camera_center))
+    flips = int((f(mask) != o_sel).sum())
+    assert flips <= 2, flips                                   # sign of a tanh output sitting at 0
+    P = xyz.shape[0]
+    assert 0.4e6 < P < 0.8e6, P
+    if flips == 0:
+        for a, b in ((xyz, o_xyz), (color, o_color), (opacity, o_op), (scaling, o_sc), (rot, o_rot)):
+            assert np.allclose(f(a), b, rtol=1e-4, atol=3e-6)
+
+    # a4/a5: rasterizer forward + backward on these P Gaussians at 800x800 against the C oracle
+    leaves = [t.detach().clone().requires_grad_(True) for t in (xyz, color, opacity, scaling, rot)]
+    m2d = torch.zeros_like(leaves[0], requires_grad=True)
+    img, radii = GaussianRasterizer(_settings(cam, bg))(
+        means3D=leaves[0], means2D=m2d, shs=None, colors_precomp=leaves[1], opacities=leaves[2], scales=leaves[3],
+        rotations=leaves[4], cov3D_precomp=None)
+    w = np.random.default_rng(2).normal(size=(3, H, W)).astype(np.float32)
+    (img * torch.from_numpy(w).cuda()).sum().backward()
+    ref = oracle32.render(cam_np.oracle_dict(bg=(0, 0, 0)), f(leaves[0]), f(leaves[1]), f(leaves[2]), f(leaves[3]),
+                          f(leaves[4]), dL_dout=w)
+    assert np.array_equal(f(radii), ref["radii"])
+    d = np.abs(f(img) - ref["color"])
+    assert float(np.sqrt((d ** 2).mean())) <= 1e-5 and float((d > 2e-5).mean()) <= 1e-4 and d.max() <= 1 / 255 + 1e-4
+    got = dict(dL_dmeans3D=leaves[0].grad, dL_dmeans2D=m2d.grad, dL_dcolors=leaves[1].grad,
+               dL_dopacities=leaves[2].grad.reshape(-1), dL_dscales=leaves[3].grad, dL_drotations=leaves[4].grad)
+    for k, a in got.items():
+        b = ref[k]
+        err = np.abs(f(a) - b) / max(1e-6, float(np.abs(b).max()))
+        assert float((err > 2e-4).mean()) <= 2e-3 and float(np.median(err)) <= 1e-6, (k, float(err.max()))
+
+
+def _roundtrip(pc, tmpdir, render_check=None):
+    """conduct_encoding -> files -> conduct_decoding on a fresh model; value-level equality of every attribute."""
+    from contextgs_amd import context_model as cm
+    from contextgs_amd.synth import make_scene
+    pc.eval()
+    d = str(tmpdir)
+    pc.conduct_encoding(d)
+    size = sum(os.path.getsize(os.path.join(d, x)) for x in os.listdir(d))
+    N = pc._anchor.shape[0]
+    dec = make_scene(N, seed=0, voxel_size=pc.voxel_size, requires_grad=False)
+    with torch.no_grad():           # scramble: everything must come from the files
+        dec._anchor_feat.zero_(); dec._offset.zero_(); dec._hyper_latent.zero_(); dec._scaling.zero_(); dec._anchor.zero_()
+        for p in dec.mlp_grid.parameters():
+            p.zero_()
+    dec.eval()
+    dec.conduct_decoding(d)
+    assert dec.decoded_version
+    with torch.no_grad():
+        m = pc.get_mask_anchor
+        nv = int(m.sum())
+        anchor = pc.get_anchor[m]
+        fq, sq, oq = cm.multi_scale_generating(pc, anchor, pc._hyper_latent[m], pc._anchor_feat[m], pc._offset[m],
+                                               pc.get_scaling[m], pc.get_mask[m], None, predict_bpp=False, training=False)
+        assert torch.equal(dec._anchor[:nv], anchor)
+        assert torch.equal(dec._mask[:nv], pc.get_mask[m])
+        assert torch.equal(dec._hyper_latent[:nv], torch.round(pc._hyper_latent[m]))
+        assert torch.equal(dec._anchor_feat[:nv], fq)
+        assert torch.equal(dec._scaling[:nv], sq)
+        assert torch.equal(dec._offset[:nv], oq * pc.get_mask[m])
+        if render_check is not None:
+            render_check(pc, dec)
+    return size, nv
+
+
+def test_c3_500k_anchors_1080p_encode_decode(tmp_path):
+    from contextgs_amd.renderer import prefilter_voxel, render
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    pc = make_scene(500_000, seed=0, requires_grad=False)
+    cam = orbit_cameras(8, 1920, 1080)[1].to_torch("cuda")
+    bg = torch.zeros(3, device="cuda")
+
+    def render_check(enc, dec):
+        # the decoded model (decoded_version: parameters ARE the quantised values) renders what the encoder-side model
+        # renders through its context model (gaussian_renderer/__init__.py:83-101); anchors are stored valid-first in
+        # the decoded model, so equal-depth ties may blend in another order: 1e-5 RMSE, not bit equality
+        imgs = []
+        for m in (enc, dec):
+            vis = prefilter_voxel(cam, m, SynthPipe(), bg)
+            imgs.append(render(cam, m, SynthPipe(), bg, visible_mask=vis)["render"])
+        d = (imgs[0] - imgs[1]).abs()
+        assert float(d.pow(2).mean().sqrt()) <= 1e-5 and float((d > 2e-5).float().mean()) <= 1e-4, float(d.max())
+
+    size, nv = _roundtrip(pc, tmp_path / "c3", render_check)
+    assert nv > 400_000 and 20e6 < size < 120e6
+
+
+def test_c5_3M_anchors_rate_sweep_roundtrip(tmp_path):
+    from contextgs_amd.synth import make_scene
+    pc = make_scene(3_000_000, seed=0, requires_grad=False)
+    rng = torch.Generator(device="cuda").manual_seed(11)
+    sizes = []
+    for k, sigma in enumerate((1.0, 5.0)):          # feature spread as the rate proxy of the lambda sweep
+        with torch.no_grad():
+            pc._anchor_feat.copy_(torch.round(torch.randn(pc._anchor_feat.shape, device="cuda", generator=rng) * sigma))
+        size, nv = _roundtrip(pc, tmp_path / f"c5_{k}")
+        assert nv > 2_400_000
+        sizes.append(size)
+    assert sizes[1] > 1.3 * sizes[0]                # more spread -> more bits
