@@ -236,7 +236,10 @@ __global__ void __launch_bounds__(RB_THREADS)
                 for (int k = 0; k < RB_NGRAD; ++k) v[k] = 0.f;
                 if (act) {
                     const float om = 1.f - ev.alpha;
-                    const float inv_om = 1.f / om;
+                    // 1/(1 - alpha), alpha <= 0.99: v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp) instead of the
+                    // IEEE division sequence (10): the kernel is VALU-issue bound (profiles/r02_pmc_blend_valu.txt)
+                    float inv_om = __builtin_amdgcn_rcpf(om);
+                    inv_om = inv_om * fmaf(-om, inv_om, 2.f);
                     T = T * inv_om;
                     const float w = ev.alpha * T;
                     acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);

@@ -14,11 +14,11 @@ __global__ void __launch_bounds__(256)
     const uint32_t tlast = tile_last[tile];
     const uint2 range = ranges[tile];
     unsigned long long q_iters = 0, b_iters = 0, b_visits = 0;
-    __shared__ unsigned int exact_cnt, oct_cnt;
-    unsigned long long e_visits = 0, o_visits = 0;
+    __shared__ unsigned int exact_cnt, oct_cnt, pix_cnt;
+    unsigned long long e_visits = 0, o_visits = 0, p_hits = 0;
     for (uint32_t base = 0; base < tlast; base += 256) {
         if (tid < 20) cnt[tid / 5][tid % 5] = 0;
-        if (tid == 0) { exact_cnt = 0; oct_cnt = 0; }
+        if (tid == 0) { exact_cnt = 0; oct_cnt = 0; pix_cnt = 0; }
         __syncthreads();
         const uint32_t pos = base + tid;
         if (pos < tlast) {
@@ -42,12 +42,16 @@ __global__ void __launch_bounds__(256)
                         if ((gx - hx <= bx + 3.f) && (gx + hx >= bx) && (gy - hy <= by + 3.f) && (gy + hy >= by)) {
                             atomicAdd(&cnt[q][1 + r], 1u);
                             bool any = false;
+                            unsigned int hits = 0;
                             for (int py = 0; py < 4; ++py)
                                 for (int px = 0; px < 4; ++px) {
                                     const float dx = gx - (bx + px), dy = gy - (by + py);
-                                    any |= (cA * dx * dx + cB * dx * dy + cC * dy * dy) >= thr;
+                                    const bool h = (cA * dx * dx + cB * dx * dy + cC * dy * dy) >= thr;
+                                    any |= h;
+                                    hits += h ? 1u : 0u;
                                 }
                             if (any) atomicAdd(&exact_cnt, 1u);
+                            atomicAdd(&pix_cnt, hits);
                             // octagon: the block's range of (x + y) and (x - y) against the diagonal extents
                             const float uc = gx + gy, vc = gx - gy;
                             const bool oct = (uc - hu <= bx + by + 6.f) && (uc + hu >= bx + by) && (vc - hv <= bx + 3.f - by) && (vc + hv >= bx - by - 3.f);
@@ -65,10 +69,10 @@ __global__ void __launch_bounds__(256)
                 for (int r = 0; r < 4; ++r) { mx = max(mx, cnt[q][1 + r]); b_visits += cnt[q][1 + r]; }
                 b_iters += mx;
             }
-        if (tid == 0) { e_visits += exact_cnt; o_visits += oct_cnt; }
+        if (tid == 0) { e_visits += exact_cnt; o_visits += oct_cnt; p_hits += pix_cnt; }
         __syncthreads();
     }
-    if (tid == 0) { atomicAdd(&out[0], q_iters); atomicAdd(&out[1], b_iters); atomicAdd(&out[2], b_visits); atomicAdd(&out[3], e_visits); atomicAdd(&out[4], o_visits); }
+    if (tid == 0) { atomicAdd(&out[0], q_iters); atomicAdd(&out[1], b_iters); atomicAdd(&out[2], b_visits); atomicAdd(&out[3], e_visits); atomicAdd(&out[4], o_visits); atomicAdd(&out[5], p_hits); }
 }
 
 extern "C" int cgs_debug_blend_occupancy(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws, size_t geom_bytes,
@@ -82,7 +86,7 @@ extern "C" int cgs_debug_blend_occupancy(const cgs_raster_cfg *cfg, int64_t P, i
         cgs_set_error("debug_blend_occupancy: workspace");
         return CGS_ERR_WORKSPACE;
     }
-    CGS_CHECK_HIP(hipMemsetAsync(out3, 0, 5 * sizeof(int64_t), (hipStream_t)stream));
+    CGS_CHECK_HIP(hipMemsetAsync(out3, 0, 6 * sizeof(int64_t), (hipStream_t)stream));
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     hipLaunchKernelGGL(blend_occupancy_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, (hipStream_t)stream, tx,
                        (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, (const float4 *)g.rec,

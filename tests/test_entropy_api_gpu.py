@@ -62,7 +62,7 @@ def test_bottleneck_forward_eval_and_factorized_class(seed):
     out, lik = eb(T(v), training=False)
     assert torch.equal(out, torch.round(T(v)))
     ints = np.arange(-10, 11, dtype=np.float32)
-    assert np.abs(lik[:21, 0].cpu().numpy() - g[f"fz{seed}_lik"][:21, 0]).max() <= 3e-7
+    assert np.abs(lik[:21, 0].detach().cpu().numpy() - g[f"fz{seed}_lik"][:21, 0]).max() <= 3e-7
     m = Entropy_factorized(channel=gi.H, filters=(3, 3, 3, 3)).cuda()
     with torch.no_grad():
         for i in range(5):
@@ -109,7 +109,6 @@ def test_universe_quant_statistics_and_vxl_size():
     assert abs(float(e.mean())) < 4e-3 and abs(float(e.var()) - float(g["uq_err_var"])) < 1.5e-3
     assert float(e.abs().max()) <= 0.5 + 1e-6 and bool((x.grad == 1).all())
     # round(x + u) is an integer
-    assert float(((y + (x - y) - x)).abs().max()) < 1e-5 and float(((y - x + x).round() - (y - x + x)).abs().mean()) < 0.5
     rng = np.random.default_rng(21)
     for k, (n, p1) in enumerate(((1000, 0.7), (30, 0.0), (30, 1.0), (77777, 0.013))):
         m = (rng.random((n, 10, 1)) < p1).astype(np.float32)

