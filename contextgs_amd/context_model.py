@@ -41,64 +41,78 @@ ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = 
 RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
 
 
+def _compose_down(index, maps):
+    """index (into level len(maps)) -> original-space index: index -> maps[-1][index] -> maps[-2][.] -> ... -> maps[0][.]"""
+    for m in reversed(maps):
+        index = m[index]
+    return index
+
+
 def mapping_to_orign(mapping_list, L, mask=None):                       # :1768-1787
-    assert L > 0, "If L=0, the orgin space can be directly obtained"
-    level = L - 1
-    mapping_prev = mapping_list[level] if mask is None else mapping_list[level][mask]
-    for i in reversed(range(level)):
-        mapping_prev = mapping_list[i][mapping_prev]
-    return mapping_prev
+    """Original-space indices of the anchors of level L (of those selected by `mask`).  mapping_list[k] holds, for
+    every anchor of level k+1, its representative's index in level k."""
+    if L <= 0:
+        raise AssertionError("If L=0, the orgin space can be directly obtained")
+    top = mapping_list[L - 1]
+    return _compose_down(top if mask is None else top[mask], mapping_list[:L - 1])
 
 
 def index_of_level_L_in_orign(mapping_list, inverse_indices_list, to_be_gathered_index, L):   # :1789-1792
-    tmp = to_be_gathered_index
-    for i in range(L):
-        tmp = inverse_indices_list[i][tmp]
-    for i in reversed(range(L)):
-        tmp = mapping_list[i][tmp]
-    return tmp
+    """Original-space index of the level-L ancestor of each original anchor: L hops up through the voxel
+    membership tables, then L hops back down through the representatives."""
+    up = to_be_gathered_index
+    for inv in inverse_indices_list[:L]:
+        up = inv[up]
+    return _compose_down(up, mapping_list[:L])
+
+
+def _voxel_keys(anchor, voxel_size, scale):
+    """Level key of every anchor (:1732,1760; quirk Q5): fp32, two divisions left to right, round half to even.
+    `scale` is a 0-d tensor in the scale search and a Python float afterwards, exactly as in the reference — the two
+    are NOT the same fp32 operation on the device (a host scalar divides as a reciprocal multiplication)."""
+    return torch.round(anchor / voxel_size / scale)
 
 
 def find_divide_scale(pc, anchor, target_ratio, level_num):             # :1726-1749
-    scale_upper = ((pc.x_bound_max - pc.x_bound_min) / pc.voxel_size).max()
-
-    def binary_search(scale_upper, scale_lower, anchor, target_ratio):
+    """One voxel-scale multiplier per coarser level: bisection on the scale until the level keeps
+    target_ratio +- 0.01 of the previous level's anchors (or the bracket is narrower than 1).  The bracket of level
+    k+1 starts at level k's result; levels are nested (level k+1 is searched on level k's voxel centres)."""
+    hi0 = ((pc.x_bound_max - pc.x_bound_min) / pc.voxel_size).max()        # 0-d tensor: the bracket stays on the device
+    scales, lo, pts = [], 1, anchor
+    for _level in range(level_num - 1):
+        hi = hi0
         while True:
-            scale = (scale_upper + scale_lower) / 2
-            anchor_unique = torch_unique_with_indices(torch.round(anchor / pc.voxel_size / scale), dim=0)[0] * pc.voxel_size * scale
-            ratio = anchor_unique.shape[0] / anchor.shape[0]
-            if abs(ratio - target_ratio) < 0.01 or (scale_upper - scale_lower).abs() < 1:
+            mid = (hi + lo) / 2
+            cells = torch_unique_with_indices(_voxel_keys(pts, pc.voxel_size, mid), dim=0)[0]
+            kept = cells.shape[0] / pts.shape[0]
+            if abs(kept - target_ratio) < 0.01 or (hi - lo).abs() < 1:
                 break
-            if ratio < target_ratio:
-                scale_upper = scale
+            if kept < target_ratio:
+                hi = mid          # too few cells: voxels too large
             else:
-                scale_lower = scale
-        return scale, anchor_unique
-
-    anchor_unique = anchor
-    scale_list = []
-    scale_lower = 1
-    for _ in range(level_num - 1):
-        scale, anchor_unique = binary_search(scale_upper, scale_lower, anchor_unique, target_ratio)
-        scale_lower = scale
-        scale_list.append(scale.item())
-    return scale_list
+                lo = mid
+        pts = cells * pc.voxel_size * mid                                  # next level is searched on these centres
+        lo = mid
+        scales.append(mid.item())
+    return scales
 
 
 def divide_levels(pc, anchor, mask_anchor_bool=None):                   # :1751-1765
-    hybrid_anchor_list = [anchor]
-    inverse_indices_list, mapping_list = [], []
-    hybrid_anchor = anchor
-    for i in range(1, pc.level_num):
-        if i == 1 and mask_anchor_bool is not None:
-            hybrid_anchor = hybrid_anchor * mask_anchor_bool.unsqueeze(1)
-        _u, inverse_indices, mapping, _c = torch_unique_with_indices(
-            torch.round(hybrid_anchor / pc.voxel_size / pc.level_scale[i - 1]), dim=0)
-        hybrid_anchor = hybrid_anchor[mapping]
-        hybrid_anchor_list.append(hybrid_anchor)
-        inverse_indices_list.append(inverse_indices)
-        mapping_list.append(mapping)
-    return hybrid_anchor_list, inverse_indices_list, mapping_list, hybrid_anchor
+    """Per level k >= 1: the voxel representatives (`mapping`: smallest original index of each occupied voxel, in
+    lexicographic voxel order) and every level-(k-1) anchor's voxel (`inverse`).  Training variant (mask given, quirk
+    Q4): masked anchors are moved to the origin before level 1 instead of being dropped."""
+    level_anchor = anchor
+    anchors, inverses, mappings = [anchor], [], []
+    for k in range(1, pc.level_num):
+        if k == 1 and mask_anchor_bool is not None:
+            level_anchor = level_anchor * mask_anchor_bool.unsqueeze(1)
+        _cells, inverse, first, _counts = torch_unique_with_indices(
+            _voxel_keys(level_anchor, pc.voxel_size, pc.level_scale[k - 1]), dim=0)
+        level_anchor = level_anchor[first]
+        anchors.append(level_anchor)
+        inverses.append(inverse)
+        mappings.append(first)
+    return anchors, inverses, mappings, level_anchor
 
 
 def _context_index(n, already_coded, inverse_indices_list, mapping_list, i):

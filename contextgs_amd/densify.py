@@ -17,6 +17,7 @@ import math
 import torch
 
 from . import _lib
+from . import dist as _dist
 from .encodings import Quantize_anchor
 
 
@@ -107,7 +108,7 @@ def growing_rounds(anchor, offset, scaling, feat, hyper, x_bound_min, x_bound_ma
     """Functional form of anchor_growing (:762-855): the per-round new-anchor dicts, the model tensors being
     extended between rounds exactly as cat_tensors_to_optimizer would."""
     _lib.require_device(anchor, grads)
-    rand_fn = rand_fn or (lambda i, like: torch.rand_like(like))
+    rand_fn = rand_fn or (lambda i, like: _dist.shared_rand_like(like))     # the same draw on every replica
     init_length = anchor.shape[0] * K
     rounds = []
     for i in range(update_depth):
@@ -137,7 +138,7 @@ def anchor_growing(pc, grads, threshold, offset_mask):
     K = int(pc.n_offsets)
     init_length = pc.get_anchor.shape[0] * K
     for i in range(pc.update_depth):
-        cand = _candidates(i, grads, threshold, offset_mask, pc.update_hierachy_factor, torch.rand_like(grads))
+        cand = _candidates(i, grads, threshold, offset_mask, pc.update_hierachy_factor, _dist.shared_rand_like(grads))
         length_inc = pc.get_anchor.shape[0] * K - init_length
         if length_inc == 0:
             if i > 0:

@@ -112,6 +112,165 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
     return int(sum(p.numel() for p in params))
 
 
+class GradientSync:
+    """Gradient all-reduce that starts DURING the backward (SURVEY 8e "overlap with the tail of backward").
+
+    Every parameter gets a post-accumulate-grad hook; a parameter whose gradient is final is reduced as soon as all
+    parameters BEFORE it in a fixed issue order have been issued (head-of-line), so that every rank issues the same
+    collectives in the same order whatever order its own autograd engine finishes them in — and even if one of them
+    never receives a gradient on some rank (that rank contributes zeros from `finish()`).  The issue order starts
+    as the parameter order and is replaced after the first step by the order in which rank 0 saw the gradients
+    become final (broadcast once), which removes the head-of-line waits.  Large tensors (the per-anchor ones) go in
+    place, one collective each; the small MLP / prior tensors are packed into one flat bucket in `finish()`.
+    On RCCL the collectives run on the process group's own stream behind the producing kernels, i.e. beside the
+    rest of the backward; what this buys on the ContextGS step is bounded — the six per-anchor gradients receive
+    their last contribution from the context model's backward, the final nodes of the graph — and is measured by
+    the driver's scaling run, not here.
+
+    sparse: optional callable(param) -> bool row mask (or None) of the rows this rank touched; parameters for which
+    every rank touched at most `sparse_below` of the rows are reduced over the UNION of touched rows only (one
+    byte-mask all-reduce + a compact all-reduce), e.g. before iteration 10 000, when a view only produces gradients
+    for the anchors it sees."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], average: bool = True, sparse=None,
+                 sparse_below: float = 0.5):
+        self.params = [p for p in params if p.requires_grad]
+        self.average, self.sparse, self.sparse_below = average, sparse, sparse_below
+        self.big = [p for p in self.params if p.numel() >= BIG_TENSOR]
+        self.small = [p for p in self.params if p.numel() < BIG_TENSOR]
+        self.order = list(range(len(self.big)))              # issue order = indices into self.big
+        self._pos = {id(p): k for k, p in enumerate(self.big)}
+        self._ready, self._seen, self._next, self._pending = set(), [], 0, []
+        self._order_synced = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.big]
+        self.bytes_reduced = 0
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    # -- internals ------------------------------------------------------------------------------------------------
+    def _op(self):
+        in_coll = self.average and dist.get_backend() == "nccl"
+        return (dist.ReduceOp.AVG if in_coll else dist.ReduceOp.SUM), in_coll
+
+    def _issue(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        elif not p.grad.is_contiguous():
+            p.grad = p.grad.contiguous()
+        op, in_coll = self._op()
+        rows = None
+        if self.sparse is not None and p.dim() >= 1 and p.shape[0] > 1:
+            rows = self.sparse(p)
+        if rows is not None:
+            self._pending.append(("rows", p, *self._issue_rows(p, rows, op)))
+        else:
+            self._pending.append(("dense", p, p.grad, dist.all_reduce(p.grad, op=op, async_op=True)))
+            self.bytes_reduced += p.grad.numel() * p.grad.element_size()
+
+    def _issue_rows(self, p, rows, op):
+        """Union of the ranks' touched rows (byte mask, MAX), then a compact all-reduce of those rows if it pays."""
+        m = rows.to(torch.uint8).contiguous()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        idx = torch.nonzero(m)[:, 0]
+        self.bytes_reduced += m.numel()
+        if idx.numel() > self.sparse_below * p.shape[0]:
+            self.bytes_reduced += p.grad.numel() * p.grad.element_size()
+            return None, p.grad, dist.all_reduce(p.grad, op=op, async_op=True)
+        compact = p.grad.index_select(0, idx).contiguous()
+        self.bytes_reduced += compact.numel() * compact.element_size()
+        return idx, compact, dist.all_reduce(compact, op=op, async_op=True)
+
+    def _drain_ready(self):
+        while self._next < len(self.order) and self.order[self._next] in self._ready:
+            self._issue(self.big[self.order[self._next]])
+            self._next += 1
+
+    def _on_grad(self, p):
+        if world() == 1:
+            return
+        k = self._pos[id(p)]
+        self._ready.add(k)
+        self._seen.append(k)
+        self._drain_ready()
+
+    # -- API ----------------------------------------------------------------------------------------------------------
+    def finish(self) -> int:
+        """Call after loss.backward(): issues whatever is left (parameters without a gradient contribute zeros), reduces
+        the small-tensor bucket, waits for everything.  Returns the number of bytes that went through collectives."""
+        w = world()
+        self.bytes_reduced = self.bytes_reduced if w > 1 else 0
+        if w == 1:
+            self._reset()
+            return 0
+        while self._next < len(self.order):                  # gradient-less (on this rank) or out-of-order leftovers
+            self._issue(self.big[self.order[self._next]])
+            self._next += 1
+        op, in_coll = self._op()
+        flat = None
+        if self.small:
+            sizes = [p.numel() for p in self.small]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.small[0].device)
+            off = 0
+            for p, n in zip(self.small, sizes):
+                if p.grad is not None:
+                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                else:
+                    flat[off:off + n].zero_()
+                off += n
+            work = dist.all_reduce(flat, op=op, async_op=True)
+            self.bytes_reduced += flat.numel() * 4
+            off = 0
+            for p, n in zip(self.small, sizes):
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+            self._pending.append(("dense", None, flat, work))
+        for kind, p, *rest in self._pending:
+            if kind == "dense":
+                t, work = rest
+                work.wait()
+                if self.average and not in_coll:
+                    t /= w
+            else:
+                idx, t, work = rest
+                work.wait()
+                if self.average and not in_coll:
+                    t /= w
+                if idx is not None:                           # rows outside the union are zero on every rank already
+                    p.grad.index_copy_(0, idx, t)
+        if not self._order_synced:                            # adopt rank 0's completion order from now on
+            seen = self._seen + [k for k in range(len(self.big)) if k not in self._seen]
+            self.order = broadcast_object(seen, src=0)
+            self._order_synced = True
+        n = self.bytes_reduced
+        self._reset()
+        return n
+
+    def _reset(self):
+        self._ready, self._seen, self._next, self._pending, self.bytes_reduced = set(), [], 0, [], 0
+
+
+_shared_rng_counter = [0]
+
+
+def shared_rand_like(t: torch.Tensor) -> torch.Tensor:
+    """torch.rand_like(t) with the SAME values on every rank (rank 0 draws, the others receive): for random decisions
+    that must not differ between replicas, e.g. the candidate sub-sampling of anchor growing
+    (scene/gaussian_model.py:769).  The per-rank device generators cannot be relied on for that: ranks render
+    different views and draw different amounts of visible-sized noise, so their streams have diverged."""
+    u = torch.rand_like(t)
+    if world() > 1:
+        if dist.get_backend() != "nccl" and u.is_cuda:       # gloo: through the host
+            h = u.cpu()
+            dist.broadcast(h, src=0)
+            u.copy_(h)
+        else:
+            dist.broadcast(u, src=0)
+    return u
+
+
 def allreduce_stats(tensors: List[torch.Tensor]) -> None:
     """Sum densification statistics in place across ranks (offset_gradient_accum,
     offset_denom, opacity_accum, anchor_demon; scene/gaussian_model.py:696-713) so that

@@ -102,3 +102,84 @@ def test_stream_blocks_are_contiguous_balanced_and_cover_everything():
                 assert max(sizes) - min(sizes) <= 2 * 50
     with mgpu.local_only():
         assert mgpu.world() == 1 and mgpu.rank() == 0
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        cd.BIG_TENSOR = 8
+        torch.manual_seed(0)                                  # identical replicas
+        a = torch.nn.Parameter(torch.randn(40, 3))            # "per-anchor" tensors: in place, hook-driven
+        b = torch.nn.Parameter(torch.randn(40, 2))
+        c = torch.nn.Parameter(torch.randn(40, 1))            # no gradient on rank 0
+        lin = torch.nn.Linear(3, 2)                           # small: flat bucket
+        params = [a, b, c] + list(lin.parameters())
+        touched = {}
+
+        def rows_of(p):                                       # rows this rank's "view" produced gradients for
+            return touched.get(id(p))
+
+        sync = cd.GradientSync(params, average=True, sparse=rows_of, sparse_below=0.6)
+        out = []
+        for step in range(3):                                 # step 0 uses the parameter order, later steps rank 0's order
+            for p in params:
+                p.grad = None
+            torch.manual_seed(100 + 10 * step + rank)         # different "views": RNG streams diverge between ranks
+            vis = torch.zeros(40, dtype=torch.bool)
+            vis[torch.randperm(40)[:8 + 4 * rank]] = True     # each rank sees a few rows -> union below 60 %
+            touched[id(a)] = vis
+            x = torch.randn(40, 3)
+            # b is used BEFORE a in the graph so that gradients become final in the order a, b (reverse of use) or not:
+            loss = (lin(a * vis[:, None].float()) * x[:, :2]).sum() + (b * float(rank + 1)).sum()
+            if rank == 1:
+                loss = loss + (c * torch.arange(40.0)[:, None]).sum()
+            # reference: plain dense average of the local gradients; torch.autograd.grad does not touch .grad, so the
+            # hooks (which start reducing in place DURING loss.backward()) do not see this pass
+            local = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+            loss.backward()
+            nbytes = sync.finish()
+            ref = []
+            for g, p in zip(local, params):
+                g = torch.zeros_like(p) if g is None else g.clone()
+                dist.all_reduce(g)
+                ref.append(g / world)
+            out.append(([p.grad.tolist() for p in params], [t.tolist() for t in ref], nbytes, list(sync.order)))
+        # same random draw on both ranks although their generators have diverged
+        shared = cd.shared_rand_like(torch.empty(5))
+        own = torch.rand(5)
+        sync.close()
+        q.put((rank, out, shared.tolist(), own.tolist()))             # plain lists: no tensor fd passing at exit
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_sync_hooks_sparse_rows_and_shared_rng():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for grads, ref, nbytes, order in res[r][1]:
+            for g, e in zip(grads, ref):
+                assert torch.allclose(torch.tensor(g), torch.tensor(e), atol=1e-6), (g, e)
+            assert nbytes > 0 and sorted(order) == [0, 1, 2]
+    for step in range(3):                                     # replicas hold identical reduced gradients
+        for g0, g1 in zip(res[0][1][step][0], res[1][1][step][0]):
+            assert g0 == g1
+    # the sparse path moved fewer bytes than a dense reduction of `a` would have (40 x 3 floats = 480 B of the total)
+    dense_total = (40 * 3 + 40 * 2 + 40 * 1) * 4 + (6 + 2) * 4
+    assert res[0][1][0][2] < dense_total
+    assert res[0][2] == res[1][2] and res[0][3] != res[1][3]
