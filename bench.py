@@ -33,8 +33,8 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--anchors", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-raster-only", action="store_true")
     ap.add_argument("--no-codec", action="store_true")
     ap.add_argument("--no-image-loss", action="store_true")
+    ap.add_argument("--no-heavy", action="store_true", help="skip the heavy-pair variant (1 M anchors on the 0.01 voxel grid)")
+    ap.add_argument("--no-eval-fps", action="store_true")
     return ap.parse_args()
 
 
@@ -52,7 +54,7 @@ def flat_grads(params):
     return [p.grad for p in params if p.grad is not None]
 
 
-def one_step(pc, cam, pipe, bg, w, step_sem, params, dist_on, gt=None):
+def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
     """prefilter -> render -> backward (-> all-reduce). Returns the render dict.  gt: use the training image loss
     of train.py:199-209 (L1 + SSIM + scaling / rate / mask regularisers) instead of the fixed linear loss."""
     import torch
@@ -71,9 +73,8 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, dist_on, gt=None):
         if pkg["bit_per_param"] is not None:
             loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
     loss.backward()
-    if dist_on:
-        from contextgs_amd.dist import allreduce_gradients
-        allreduce_gradients(params, average=True)             # RCCL over xGMI: one flat bucket per step
+    if sync is not None:
+        sync.finish()        # RCCL over xGMI: per-anchor tensors in place (started from gradient hooks), MLPs as one bucket
     return pkg
 
 
@@ -159,8 +160,13 @@ def main():
     def cam_of(i):
         return cams[(i * world + rank) % n_views]
 
-    full = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, dist_on)
-    raster = lambda i: one_step(pc, cam_of(i), pipe, bg, w, 1000, params, dist_on)
+    sync = None
+    if dist_on:
+        from contextgs_amd.dist import GradientSync
+        sync = GradientSync(params, average=True)
+
+    full = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, sync)
+    raster = lambda i: one_step(pc, cam_of(i), pipe, bg, w, 1000, params, sync)
 
     pkg_full = None
     for i in range(args.warmup):
@@ -184,7 +190,7 @@ def main():
     value_img_loss = None
     if not args.no_image_loss:
         gt_img = torch.rand(3, H, W, device="cuda", generator=g)
-        with_loss = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, dist_on, gt=gt_img)
+        with_loss = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, sync, gt=gt_img)
         for i in range(max(1, args.warmup // 2)):
             with_loss(i)
         value_img_loss = views / timed(with_loss, args.steps, dist_on)
@@ -235,10 +241,16 @@ def main():
                 mlp_flops += 2.0 * 0.15 * ratio * N * (i_ * h_ + h_ * 175)
         for o_ in (10, 30, 70):
             mlp_flops += 2.0 * n_vis * (54 * 50 + 50 * o_)
-        traffic = {}
+        # PMC figures are NOT measured in this run (counters need their own rocprofv3 passes): they are read from the
+        # committed profiles of the same workload (tools/pmc_gpu.sh, tools/pmc_blend.sh) and only attached at it
+        traffic, valu = {}, {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and N == 1_000_000 and (W, H) == (1920, 1080):
-            traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if N == 1_000_000 and (W, H) == (1920, 1080):
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+            if os.path.exists(vpath):
+                valu = json.load(open(vpath)).get("valu_busy_frac", {})
         kernels = {}
         for name, (ms, n) in prof.items():
             avg_us = ms / n * 1e3
@@ -262,7 +274,11 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
                         "traffic": traffic.get(dom), "alg_bytes_per_launch": kernels[dom]["alg_bytes"],
-                        "avg_launch_us": kernels[dom]["avg_us"]}
+                        "avg_launch_us": kernels[dom]["avg_us"],
+                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not this run)",
+                        # the kernel's real bound: fraction of the kernel's duration its SIMDs' VALU is issuing
+                        # (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x duration), profiles/r02_pmc_blend_valu.txt)
+                        "valu_frac": valu.get(dom), "valu_frac_source": "profiles/pmc_valu.json (not this run)"}
         elif dom and "TFLOPs" in kernels[dom]:
             roofline = {"kernel": dom + " (fused fp32-MFMA MLP family, all launches of a step)", "bound": "mfma",
                         "achieved": kernels[dom]["TFLOPs"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -271,7 +287,8 @@ def main():
         # the north star's kernel, always reported
         blend = {n_: {"achieved_GBps": kernels[n_]["GBps"], "frac_of_hbm_peak": round(kernels[n_]["GBps"] / HBM_PEAK_GBS, 4),
                       "alg_bytes": kernels[n_]["alg_bytes"], "avg_us": kernels[n_]["avg_us"],
-                      "pmc_hbm_bytes": traffic.get(n_)} for n_ in ("blend_fwd", "blend_bwd") if n_ in kernels}
+                      "pmc_hbm_bytes": traffic.get(n_), "valu_frac": valu.get(n_)}
+                 for n_ in ("blend_fwd", "blend_bwd") if n_ in kernels}
         lib_ms = sum(k["total_ms"] for k in kernels.values()) / max(1, args.steps)
 
         # stdout carries exactly ONE line (the JSON below): the codec driver's progress prints (they mirror the
@@ -279,13 +296,16 @@ def main():
         import contextlib
         codec = None
         cpu = None
+        extra = {}
         with contextlib.redirect_stdout(sys.stderr):
             if not args.no_codec:
                 from contextgs_amd.dist import local_only
                 with local_only():          # rank 0 alone runs this leg: no collectives while the others wait
-                    codec = codec_bench(pc)
+                    codec = codec_bench(pc, cams if not args.no_eval_fps else None, pipe, bg)
             if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (torchrun also pins OMP to 1 thread)
                 cpu = cpu_baseline(pc, cam, pipe, bg, w, pkg)
+            if not args.no_heavy and world == 1 and N == 1_000_000:
+                extra["heavy_pairs"] = heavy_variant(args, L, pipe, bg, w, cams)
 
         result = {
             "metric": "views/sec fwd+bwd @1920\u00d71080, 1M anchors", "value": round(value, 3), "unit": "views/s",
@@ -302,6 +322,7 @@ def main():
             "hip_kernel_ms_per_step": round(lib_ms, 3),
             "cpu_baseline": cpu,
             "codec": codec,
+            "extra": extra,
         }
     if dist_on:
         import torch.distributed as dist
@@ -311,7 +332,58 @@ def main():
         print(json.dumps(result))
 
 
-def codec_bench(pc):
+def eval_fps(model, cams, pipe, bg, n=24):
+    """`Test FPS` of the reference (train.py:406-414, render_set): eval-mode views per second, no gradients."""
+    import torch
+    from contextgs_amd.renderer import prefilter_voxel, render
+    with torch.no_grad():
+        for c in cams[:2]:
+            render(c, model, pipe, bg, visible_mask=prefilter_voxel(c, model, pipe, bg))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(n):
+            c = cams[i % len(cams)]
+            render(c, model, pipe, bg, visible_mask=prefilter_voxel(c, model, pipe, bg))
+        torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
+def heavy_variant(args, L, pipe, bg, w, cams, steps=20):
+    """The same step on a blend-HEAVY scene: 1 M anchors on the 0.01 voxel grid (the headline generator switches to a
+    0.001 voxel above 500 k anchors, which makes the Gaussians tiny: ~2 tiles each).  Reported next to the headline,
+    never instead of it."""
+    import torch
+    from contextgs_amd.rasterizer import last_call, raster_stats
+    from contextgs_amd.renderer import _raster_settings
+    from contextgs_amd.synth import make_scene
+    pc = make_scene(args.anchors, seed=0, voxel_size=0.01)
+    pc.train()
+    params = [p for p in pc.parameters() if p.requires_grad]
+    step = lambda i: one_step(pc, cams[i % len(cams)], pipe, bg, w, args.step_semantics, params, None)
+    for i in range(3):
+        pkg = step(i)
+    L.cgs_prof_enable(1)
+    dt = timed(step, steps, False)
+    prof = read_prof()
+    L.cgs_prof_enable(0)
+    st = raster_stats(_raster_settings(cams[0], pipe, bg, 1.0), last_call["img_ws"]).cpu().tolist()
+    out = {"workload": f"{args.anchors} anchors, voxel 0.01, {args.width}x{args.height}, step={args.step_semantics}",
+           "value": round(steps / dt, 3), "unit": "views/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "gaussians_per_view": int(pkg["radii"].numel()), "tile_pairs_per_view": int(last_call["num_rendered"]),
+           "R_eff": int(st[0])}
+    for k in ("blend_fwd", "blend_bwd", "tile_sort", "emit_pairs"):
+        if k in prof:
+            out[k + "_avg_us"] = round(prof[k][0] / prof[k][1] * 1e3, 1)
+    H, W = args.height, args.width
+    if "blend_bwd" in prof:
+        out["blend_bwd_GBps"] = round((76 * out["R_eff"] + 20 * H * W) / (prof["blend_bwd"][0] / prof["blend_bwd"][1] * 1e-3) / 1e9, 1)
+    if "blend_fwd" in prof:
+        out["blend_fwd_GBps"] = round((40 * out["R_eff"] + 20 * H * W) / (prof["blend_fwd"][0] / prof["blend_fwd"][1] * 1e-3) / 1e9, 1)
+    del pc
+    torch.cuda.empty_cache()
+    return out
+
+
+def codec_bench(pc, cams=None, pipe=None, bg=None):
     """Second half of BASELINE.json's metric: "encode Manchors/sec" — the full conduct_encoding ->
     files -> conduct_decoding round trip of the bench scene (3-level context codec), bit-exactness
     checked on the way.  Reported next to the headline value, not part of the timed steps."""
@@ -342,45 +414,74 @@ def codec_bench(pc):
             m = pc.get_mask_anchor
             exact = bool(torch.equal(dec._anchor[:n_valid], pc.get_anchor[m])) and \
                 bool(torch.equal(dec._mask[:n_valid], pc.get_mask[m]))
+        fps = None
+        if cams is not None:        # eval-path throughput: decoded model (parameters ARE the values) vs non-decoded
+            fps = {"decoded_views_per_s": round(eval_fps(dec, cams, pipe, bg), 2),       # (context model per view, Q7)
+                   "not_decoded_views_per_s": round(eval_fps(pc, cams, pipe, bg), 2)}
         if was:
             pc.train()
-        return {"encode_Manchors_per_s": round(n_valid / (t1 - t0) / 1e6, 4), "decode_Manchors_per_s": round(n_valid / (t3 - t2) / 1e6, 4),
+        return {"test_fps": fps, "encode_Manchors_per_s": round(n_valid / (t1 - t0) / 1e6, 4), "decode_Manchors_per_s": round(n_valid / (t3 - t2) / 1e6, 4),
                 "encode_s": round(t1 - t0, 3), "decode_s": round(t3 - t2, 3), "valid_anchors": n_valid,
                 "bitstream_MB": round(size / 2**20, 3), "decoded_anchor_and_masks_bit_exact": exact}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(pc, cam, pipe, bg, w, pkg):
-    """The oracle (oracle/raster_ref.c, OpenMP) timed on the host cores on ONE view's
-    rasterizer work (fwd+bwd) of the same workload.  The reference has no CPU rasterize
-    path, so this is kind="port".  Bounded: if the view has more than
-    1.5 M Gaussians a seeded random subset of 1.5 M is used (stated in `sample`)."""
+def cpu_baseline(pc, cam, pipe, bg, w, pkg, ctx_sample=200_000):
+    """The oracle timed on the host cores on ONE view of the same workload; the reference has no CPU rasterize path
+    (SURVEY §0 fact 3), so this is kind="port".  Two legs, both stated in `sample`:
+      * rasterizer stages R1-R8 forward + backward of the FULL view (oracle/raster_ref.c, OpenMP, all host threads);
+      * context model + rate (training variant, forward only — the numpy oracle has no backward) and the anchor ->
+        Gaussian expansion (oracle/context_ref.py, numpy) on the first `ctx_sample` anchors, scaled linearly to N.
+    value = 1 / (sum of the legs): an UPPER bound of what the port does per second (no context-model backward)."""
     import numpy as np
     import torch
     from contextgs_amd.renderer import generate_neural_gaussians
+    from oracle import context_ref as cr
     from oracle.raster_oracle import RasterOracle
     with torch.no_grad():
-        was_training = pc.get_color_mlp.training
         xyz, color, opacity, scaling, rot, *_ = generate_neural_gaussians(
             cam, pc, None, is_training=True, step=1000)
     P = xyz.shape[0]
-    cap = 1_500_000
-    if P > cap:
-        idx = torch.randperm(P, device=xyz.device, generator=torch.Generator(device=xyz.device).manual_seed(7))[:cap]
-        idx = idx.sort().values
-        xyz, color, opacity, scaling, rot = xyz[idx], color[idx], opacity[idx], scaling[idx], rot[idx]
     f = lambda t: t.detach().cpu().numpy()
     oracle = RasterOracle(np.float32)
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     cd = cam.oracle_dict(bg=f(bg))
+    args_np = [f(t) for t in (xyz, color, opacity, scaling, rot)]
+    w_np = f(w)
     t0 = time.perf_counter()
-    oracle.render(cd, f(xyz), f(color), f(opacity), f(scaling), f(rot), dL_dout=f(w))
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"1 view fwd+bwd, rasterizer stages only (R1-R8), {xyz.shape[0]} of {P} Gaussians of the "
-                      f"bench view at {cam.image_width}x{cam.image_height}; {dt:.1f} s wall"}
+    oracle.render(cd, *args_np, dL_dout=w_np)
+    t_raster = time.perf_counter() - t0
+    # context model + expansion on a prefix of the anchors
+    N = pc._anchor.shape[0]
+    n = min(ctx_sample, N)
+    with torch.no_grad():
+        Wd = {k: f(v) for k, v in pc.state_dict().items()}
+        anchor = f(pc.get_anchor[:n])
+        mask = f(pc.get_mask[:n])
+        st = {k: f(getattr(pc, "_" + k)[:n]) for k in ("hyper_latent", "anchor_feat", "offset")}
+        scal = f(pc.get_scaling[:n])
+        lo, hi = f(pc.x_bound_min), f(pc.x_bound_max)
+    mab = mask.sum(1)[:, 0] > 0
+    t0 = time.perf_counter()
+    ls = cr.find_divide_scale(anchor[mab], lo, hi, float(pc.voxel_size), float(pc.target_ratio), int(pc.level_num))
+    train = dict(seeds=[11, 12, 13], hyper_seed=14, choose_mask=np.random.default_rng(0).random(n) <= 0.15)
+    fq, sq, oq, _rates, _x = cr.multi_scale_generating(
+        Wd, anchor, st["hyper_latent"], st["anchor_feat"], st["offset"], scal, mask, mab, float(pc.voxel_size), ls, train=train,
+        x_means=(st["anchor_feat"].mean(dtype=np.float32), scal.mean(dtype=np.float32), st["offset"].mean(dtype=np.float32)))
+    t_ctx = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cr.expand(Wd, anchor, fq, oq, sq, mask, f(cam.camera_center))
+    t_exp = time.perf_counter() - t0
+    scale = N / n
+    total = t_raster + (t_ctx + t_exp) * scale
+    return {"value": round(1.0 / total, 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "seconds": {"rasterizer_fwd_bwd_full_view": round(t_raster, 2), "context_model_fwd_sample": round(t_ctx, 2),
+                        "expansion_fwd_sample": round(t_exp, 2), "sample_to_full_scale": round(scale, 2)},
+            "sample": f"1 view: rasterizer stages R1-R8 fwd+bwd of all {P} Gaussians at {cam.image_width}x{cam.image_height} "
+                      f"(C/OpenMP, {cores} threads, {t_raster:.1f} s) + context model/rate (training variant, forward only) and "
+                      f"expansion on the first {n} of {N} anchors (numpy, {t_ctx + t_exp:.1f} s) scaled x{scale:.1f}"}
 
 
 if __name__ == "__main__":
