@@ -17,9 +17,14 @@ def _linear(rng, fan_in, fan_out):
             rng.uniform(-b, b, size=(fan_out,)).astype(np.float32))
 
 
-def mlp_weights(seed):
+def mlp_weights(seed, positive_scales=False):
     """State dicts (numpy) for mlp_opacity / mlp_cov / mlp_color / mlp_grid[0..2] with the
-    shapes of scene/gaussian_model.py:153-188, and the latent_codec parameters."""
+    shapes of scene/gaussian_model.py:153-188, and the latent_codec parameters.
+
+    positive_scales: shift the biases of the level MLPs' SCALE outputs so that the predicted sigmas are positive and of
+    the order of the data's spread, as in a trained model.  With plain random weights half of the sigmas are negative,
+    i.e. clamped to 1e-9, and most symbols sit on the rate model's 1e-6 likelihood floor, where the fp32 gradient is
+    rounding noise on BOTH sides of a comparison (used by the training-mode fixtures, which compare gradients)."""
     rng = np.random.default_rng(seed + 1000)
     w = {}
     for name, out in (("mlp_opacity", K), ("mlp_cov", 7 * K), ("mlp_color", 3 * K)):
@@ -31,6 +36,16 @@ def mlp_weights(seed):
         in_dim = H + 3 if i == LEVELS - 1 else (D + 6 + 3) + H
         w[f"mlp_grid.{i}.0.weight"], w[f"mlp_grid.{i}.0.bias"] = _linear(rng, in_dim, 2 * D)
         w[f"mlp_grid.{i}.2.weight"], w[f"mlp_grid.{i}.2.bias"] = _linear(rng, 2 * D, out_dim)
+        if positive_scales:         # output layout: [mean_f D | scale_f D | mean_s 6 | scale_s 6 | mean_o 3K | scale_o 3K | 3]
+            b = w[f"mlp_grid.{i}.2.bias"]
+            w[f"mlp_grid.{i}.2.weight"][D:2 * D] *= np.float32(0.5)
+            b[D:2 * D] += np.float32(3.0)
+            w[f"mlp_grid.{i}.2.weight"][2 * D + 6:2 * D + 12] *= np.float32(0.01)
+            b[2 * D + 6:2 * D + 12] = np.float32(0.02)
+            w[f"mlp_grid.{i}.2.weight"][2 * D + 12 + 3 * K:2 * D + 12 + 6 * K] *= np.float32(0.3)
+            b[2 * D + 12 + 3 * K:2 * D + 12 + 6 * K] += np.float32(0.8)
+            w[f"mlp_grid.{i}.2.weight"][2 * D:2 * D + 6] *= np.float32(0.02)      # scaling means near the data (~0.01-0.06)
+            b[2 * D:2 * D + 6] = np.float32(0.02)
     # factorised prior (filters 3,3,3,3): perturbed around the standard init so that likelihoods vary
     f = (1, 3, 3, 3, 3, 1)
     scale = 10.0 ** (1.0 / 5)

@@ -162,7 +162,7 @@ def test_training_variant_forward(tag, N, seed):
     """Oracle of the TRAINING context / rate path (scene/gaussian_model.py:1594-1707, training=True,
     predict_bpp=True) against the reference run with the same fixed noise (tests/golden/train_*.npz)."""
     g = _load(f"train_{tag}.npz")
-    W = gi.mlp_weights(seed)
+    W = gi.mlp_weights(seed, positive_scales=True)
     st = gi.anchor_state(N, seed)
     s = (1 / (1 + np.exp(-st["mask"].astype(np.float32)))).astype(np.float32)
     mask = (s > 0.01).astype(np.float32)

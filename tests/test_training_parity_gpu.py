@@ -27,7 +27,7 @@ def _model(N, seed):
     from contextgs_amd.model import GaussianModel
     pc = GaussianModel(feat_dim=gi.D, n_offsets=gi.K, voxel_size=0.01, level_num=gi.LEVELS, target_ratio=0.2)
     sd = pc.state_dict()
-    for k, v in gi.mlp_weights(seed).items():
+    for k, v in gi.mlp_weights(seed, positive_scales=True).items():
         sd[k] = T(v)
     pc.load_state_dict(sd, strict=False)
     st = gi.anchor_state(N, seed)
@@ -77,6 +77,7 @@ def _cmp(g, key, got, rtol, atol_of_max=0.0, outliers=0.0):
     sub = a2[::stride].reshape(ref.shape) if stride > 1 else a.reshape(ref.shape)
     tol = rtol * np.abs(ref) + atol_of_max * max(1e-12, float(np.abs(ref).max()))
     bad = np.abs(sub - ref) > tol
+    print(f"{key:20s} max|ref| {float(np.abs(ref).max()):10.4g}  max err {float(np.abs(sub - ref).max()):9.3g}  outside tol {int(bad.sum())}/{bad.size}")
     assert bad.mean() <= outliers, (key, int(bad.sum()), float(np.abs(sub - ref).max()), float(np.abs(ref).max()))
     assert np.abs(sub - ref).max() <= max(tol.max(), 0.02 * float(np.abs(ref).max())), key
     if stride > 1:      # all rows through their column sums
@@ -153,10 +154,13 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
     loss = loss + float(RW[0]) * bpp + float(RW[1]) * bf + float(RW[2]) * bs + float(RW[3]) * bo
     loss.backward()
     assert abs(loss.item() - float(g["tr_loss"])) <= 1e-4 * abs(float(g["tr_loss"])) + 1e-3
-    # per-anchor parameters: within 3e-4 of the tensor's largest gradient entry (fp32 accumulation order of the
-    # MLP backward).  The rate gradient carries 1/likelihood, and where the likelihood is tiny (> 10 bits) the fp32
-    # cancellation of its two CDFs dominates (tests/test_context_gpu.py allows 15 % on exactly those entries of
-    # Entropy_gaussian's own gradient): at most 1e-4 of the entries may sit outside, each within 2 % of the maximum
+    # per-anchor parameters: within 3e-4 of the tensor's largest gradient entry (fp32 accumulation order of the MLP
+    # backward; measured: <= 7e-5 except for a handful of entries).  The rate gradient carries 1/likelihood, and where
+    # the likelihood is tiny the fp32 cancellation of its two CDFs dominates (tests/test_context_gpu.py allows 15 % on
+    # exactly those entries of Entropy_gaussian's own gradient): at most 1e-4 of the entries may sit outside, each
+    # within 2 % of the maximum.  The fixture's level MLPs predict trained-like positive sigmas
+    # (golden_inputs.mlp_weights(positive_scales=True)); with raw random weights most symbols sit on the 1e-6
+    # likelihood floor and the fp32 gradient of BOTH implementations is rounding noise there
     for key, p in (("g_anchor", pc._anchor), ("g_offset", pc._offset), ("g_mask", pc._mask), ("g_feat", pc._anchor_feat),
                    ("g_hyper", pc._hyper_latent), ("g_scaling", pc._scaling)):
         assert p.grad is not None, key
@@ -171,6 +175,7 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
         a = p.grad.cpu().numpy()
         assert a.shape == ref.shape, name
         err, big = float(np.abs(a - ref).max()), float(np.abs(ref).max())
+        print(f"{name:32s} max|ref| {big:10.4g}  max err {err:9.3g}  rel {err / max(big, 1e-12):8.2e}")
         assert err <= 5e-4 * max(big, 1e-6), (name, err, big)
         checked += 1
     assert checked >= 3 * 4 + 3 * 4 + 14, checked       # anchor MLPs, level MLPs, hyper-prior matrices/biases/factors

@@ -74,12 +74,12 @@ def patch_cuda():
     torch.cuda.empty_cache = lambda *a, **k: None
 
 
-def build_reference_model(N, seed):
+def build_reference_model(N, seed, positive_scales=False):
     import golden_inputs as gi
     from scene.gaussian_model import GaussianModel
     pc = GaussianModel(feat_dim=gi.D, n_offsets=gi.K, voxel_size=0.01, level_num=gi.LEVELS, hyper_divisor=4,
                        target_ratio=0.2)
-    w = gi.mlp_weights(seed)
+    w = gi.mlp_weights(seed, positive_scales)
     sd = pc.state_dict()
     for k, v in w.items():
         assert k in sd, k
@@ -231,7 +231,7 @@ def golden_training(N, seed, tag, stride):
     import gaussian_renderer as gr
     from scene import gaussian_model as gm
     from oracle.context_ref import ctx_noise
-    pc = build_reference_model(N, seed)
+    pc = build_reference_model(N, seed, positive_scales=True)      # trained-like sigmas: see golden_inputs.mlp_weights
     pc.train()
     out = {"_meta": np.array(f"training variant, step=20000, N={N} seed={seed} stride={stride}; noise = "
                              f"oracle.context_ref.ctx_noise; EntropyBottleneck stub = contextgs_amd.entropy_bottleneck"),
