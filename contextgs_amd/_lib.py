@@ -84,7 +84,21 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_void_p]),
     "cgs_noise_quant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p]),
+                                    c_void_p, c_void_p]),
+    "cgs_hyper_noise_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int, C.c_uint64, c_void_p, c_void_p]),
+    "cgs_eb_bits_scratch_bytes": (c_size_t, []),
+    "cgs_eb_bits_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_eb_bits_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "cgs_rate_finish_fwd": (c_int, [c_void_p, c_int, c_void_p, c_float, C.c_double, C.c_double, C.c_double, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
+    "cgs_rate_finish_bwd": (c_int, [c_void_p, c_int, c_float, C.c_double, C.c_double, C.c_double, c_void_p, c_void_p, c_void_p]),
+    "cgs_ctx_choose_blocks": (c_size_t, [c_int64]),
+    "cgs_ctx_choose_flags": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, C.c_uint64, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_ctx_choose_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "cgs_means_accum_doubles": (c_size_t, []),
+    "cgs_means_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "cgs_noise_quant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -175,7 +189,18 @@ def current_stream() -> int:
 
 
 def require_device(*tensors) -> None:
+    """Operands must live on the process's CURRENT HIP device: kernels are enqueued on that device's current stream
+    (current_stream()), so a tensor of another GPU would be a foreign pointer on an unrelated stream."""
+    import torch
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("contextgs_amd operators run on the HIP device only (tensor on %s); "
                                "there is no CPU path" % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: call "
+                               "torch.cuda.set_device(local_rank) first (one process per GPU)")

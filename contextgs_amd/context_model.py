@@ -201,41 +201,73 @@ def _plan_key(pc, anchor, mask_anchor_bool):
             tuple(anchor.shape), mask_anchor_bool is None)
 
 
-def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask):
+class _LazyChooseMask:
+    """The rate subset as the kernels produced it (a list of chosen anchor indices); the bool [N] mask of :1659 is only
+    materialised if a level falls off the fused path and asks for it."""
+
+    def __init__(self, n, rows, device):
+        self.n, self.rows, self.device, self._t = n, rows, device, None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+            self._t[self.rows] = True
+        return self._t
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+
+def _as_mask(cm):
+    return cm.tensor() if isinstance(cm, _LazyChooseMask) else cm
+
+
+choose_mask_provider = None      # test hook: callable(anchor, mask_anchor_bool) -> bool [N], replaces the random draw of the rate subset
+
+
+def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False):
     """(_cached_plan(...), per-level row lists of the rate subset, all chosen rows) with ONE host read.
 
-    The cache check ("are anchor and mask what the plan was built from?") and the sizes of the per-level
-    subsets (nonzero needs them to size its output) are device results the host has to wait for; each wait
-    drains the launch queue, so they are fetched together: the plan is used speculatively, the per-level counts
-    come from one cumulative sum over choose_mask in coding order, and nonzero_static(size=known) needs no
-    further read.  Per level this equals nonzero(choose_mask[orig]) (:1658-1669 restricted to the level)."""
+    The cache check ("are anchor and mask what the plan was built from?"), the draw of the subset (when `draw`: the
+    15 % of :1658-1659 from the counter-based generator, keyed by the anchor index) and the sizes of the per-level
+    subsets are one launch + one read-back; a second launch compacts the chosen rows in coding order
+    (ctx_ops.choose_rows).  Per level this equals nonzero(choose_mask[orig]) (:1658-1669 restricted to the level).
+    Also leaves the number of live anchors in cache['live_count'] (the mask_anchor_rate of :1661 without a reduction)."""
     cache = getattr(pc, "_level_cache", None)
-    if (choose_mask is None or cache is None or cache["key"] != _plan_key(pc, anchor, mask_anchor_bool)
-            or not cache["covers_all"] or not hasattr(torch, "nonzero_static")):
-        c = _cached_plan(pc, anchor, mask_anchor_bool)
-        return c, None, None
-    same = (anchor == cache["anchor"]).all()
-    if mask_anchor_bool is not None:
-        same = same & (mask_anchor_bool == cache["mask"]).all()
-    perm, sizes = cache["perm"], cache["sizes"]
-    if "bounds" not in cache:
-        b = [0]
-        for s in sizes:
-            b.append(b[-1] + s)
-        cache["bounds"] = torch.tensor(b, dtype=torch.long, device=perm.device)
-    cm_p = choose_mask if cache.get("identity") else choose_mask.index_select(0, perm)
-    csum = torch.cat([torch.zeros(1, dtype=torch.long, device=perm.device), cm_p.cumsum(0)])
-    host = torch.cat([same.reshape(1).long(), csum.index_select(0, cache["bounds"])]).tolist()   # the one sync
-    if not host[0]:
-        c = _cached_plan(pc, anchor, mask_anchor_bool)       # rebuilds (rare: anchors / anchor mask changed)
-        return c, None, None
-    cum = host[1:]
-    nz = torch.nonzero_static(cm_p, size=cum[-1])[:, 0]
-    locs, off = [], 0
-    for j, n_l in enumerate(sizes):
-        locs.append(nz[cum[j]:cum[j + 1]] - off)
-        off += n_l
-    return cache, locs, (nz if cache.get("identity") else perm.index_select(0, nz))
+    if cache is not None:
+        cache.pop("live_count", None)
+        cache.pop("_choose_mask", None)
+        cache.pop("_nz", None)
+    if (choose_mask is None and not draw) or not anchor.is_cuda:
+        return _cached_plan(pc, anchor, mask_anchor_bool), None, None
+    fresh = cache is None or cache["key"] != _plan_key(pc, anchor, mask_anchor_bool)
+    if fresh:
+        cache = _cached_plan(pc, anchor, mask_anchor_bool)               # builds (device sorts + host reads)
+    if not cache["covers_all"]:
+        return cache, None, None
+    seed = _ctx.next_seed() if draw else 0
+    n = int(anchor.shape[0])
+    for attempt in range(2):
+        perm, sizes = cache["perm"], cache["sizes"]
+        bounds = [0]
+        for s_ in sizes:
+            bounds.append(bounds[-1] + s_)
+        check = not fresh and attempt == 0
+        stale, live, per_level, nz, rows, loc = _ctx.choose_rows(
+            None if cache.get("identity") else perm, n, mask_anchor_bool, choose_mask, seed, 0.15,
+            anchor if check else None, cache["anchor"] if check else None,
+            cache["mask"] if (check and mask_anchor_bool is not None) else None, bounds)
+        if not stale:
+            break
+        cache = _cached_plan(pc, anchor, mask_anchor_bool)               # rebuilds (rare: anchors / anchor mask changed)
+        fresh = True
+    cache["live_count"] = live if mask_anchor_bool is not None else n
+    cache["_nz"] = nz                       # coding-order positions of the chosen rows (this step)
+    cum = [0]
+    for v in per_level:
+        cum.append(cum[-1] + v)
+    locs = [loc[cum[j]:cum[j + 1]] for j in range(len(sizes))]
+    return cache, locs, rows
 
 
 def _level_plan_uncached(pc, anchor, mask_anchor_bool):
@@ -383,7 +415,7 @@ def gather_rows(x, idx):
 
 
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
-                               keep_stats, choose_mask=None):
+                               keep_stats, choose_mask=None, draw_choose=False):
     """The level loop of multi_scale_generating (:1556-1652) in coding order.
 
     Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
@@ -395,17 +427,33 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
     # level plan (cached) + the rate subset's rows per level, with one host read for both
     c, locs, chosen_rows = _plan_and_chosen(pc, anchor, mask_anchor_bool,
-                                            choose_mask if (keep_stats and anchor.is_cuda) else None)
+                                            choose_mask if (keep_stats and anchor.is_cuda) else None,
+                                            draw=draw_choose and keep_stats and choose_mask is None)
+    if draw_choose and keep_stats and choose_mask is None:
+        # the kernels drew the subset: keep a bool mask around for the (rare) level that does not take the fused path
+        if chosen_rows is None:            # anchors the plan does not cover: the torch draw
+            choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False)
+        else:
+            choose_mask = _LazyChooseMask(int(anchor.shape[0]), chosen_rows, anchor.device)
+        c["_choose_mask"] = choose_mask
     perm, sizes = c["perm"], c["sizes"]
-    # :1556.  Only the rate subset's hyper likelihood is ever read (:1662): ask the bottleneck for those rows only
-    # (likelihood_hyper is then [n_chosen, C] in `chosen_rows` order; rate_model recognises it by its length)
-    if (FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda
-            and isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3)):
-        rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(choose_mask)[:, 0]
+    # :1556.  Only the rate subset's hyper likelihood is ever read (:1662), and only as a sum of bits: on the fused
+    # training path the bottleneck returns the noisy latents already in coding order plus that sum (two launches);
+    # otherwise the likelihood of the chosen rows / of all rows as a tensor
+    hyp_p = None
+    eb_mine = isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3)
+    if (FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine
+            and not pc.disable_hyper and c.get("_nz") is not None and c["covers_all"] and hyper.dtype == torch.float32):
+        hyp_p, likelihood_hyper = pc.latent_codec.training_step_forms(
+            hyper, None if c.get("identity") else perm, None if c.get("identity") else c["inv_perm"], c["_nz"],
+            _ctx.next_seed())
+        hyper_feat = None
+    elif FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine:
+        rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(_as_mask(choose_mask))[:, 0]
         hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training, rows=rows_h)
     else:
         hyper_feat, likelihood_hyper = pc.latent_codec(hyper, training=training)
-    if pc.disable_hyper:
+    if pc.disable_hyper and hyper_feat is not None:
         hyper_feat = hyper_feat * 0
 
     # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
@@ -428,7 +476,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         feat_l = torch.split(in_order(feat), sizes)
         scal_l = torch.split(in_order(grid_scaling), sizes)
         off_l = torch.split(in_order(grid_offsets), sizes)
-    hyp_l = torch.split(in_order(hyper_feat), sizes)
+    hyp_l = torch.split(hyp_p if hyp_p is not None else in_order(hyper_feat), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
@@ -495,7 +543,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                         lo_ = sum(int(l_.shape[0]) for l_ in locs[:j])
                         span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
                     levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
-                                       yo=ho, Q=Q_all, chosen=span, side=side,
+                                       yo=ho, Q=Q_all, chosen=span, side=side, side_src=row_src,
                                        pred=grid_mlp(pc, i, feat_sub if feat_sub is not None else gather_unique(feat_in, loc))))
                 feat_q.append(hf)
                 scal_q.append(hs)
@@ -571,25 +619,42 @@ def draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits):
 
 
 def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, return_sum_bits,
-               choose_mask=None):
+               choose_mask=None, live_count=None):
     """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows."""
     K = pc.n_offsets
     n = anchor.shape[0]
     dev = anchor.device
     if choose_mask is None:
         choose_mask = draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits)
-    mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach() if mask_anchor_bool is not None else 1
-    if likelihood_hyper.shape[0] != n:          # already restricted to the chosen rows (context_model_coding_order)
+    if mask_anchor_bool is None:
+        mask_anchor_rate = 1
+    elif live_count is not None:                # counted by the step's bookkeeping kernel: no reduction, a host scalar
+        mask_anchor_rate = live_count / mask_anchor_bool.numel()
+    else:
+        mask_anchor_rate = (mask_anchor_bool.sum() / mask_anchor_bool.numel()).detach()
+    from .entropy_bottleneck import HyperBitSum
+    hyper_sum = bit_hyper = None
+    if isinstance(likelihood_hyper, HyperBitSum):       # the fused training path already summed the bits
+        hyper_sum, n_hyper = likelihood_hyper.total, likelihood_hyper.numel
+    elif likelihood_hyper.shape[0] != n:        # already restricted to the chosen rows (context_model_coding_order)
         bit_hyper = -torch.log2(likelihood_hyper)
     else:
-        bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(choose_mask)[:, 0]))
+        bit_hyper = -torch.log2(gather_unique(likelihood_hyper, torch.nonzero(_as_mask(choose_mask))[:, 0]))
+    if bit_hyper is not None:
+        hyper_sum, n_hyper = torch.sum(bit_hyper).reshape(1), bit_hyper.numel()
     eg = pc.entropy_gaussian
     all_fused = bool(levels) and all(L.get("fused") for L in levels) and pc._anchor_feat.is_cuda
     if all_fused:
         # every level goes through the fused rate kernel, which takes the three clamp centres as constants: one
         # launch over the three parameter tensors (exp of the scaling logits on the fly) instead of exp + 3 reductions
         xm_feat = xm_scaling = xm_offsets = None
-        x_means_fused = _ctx.means3(pc._anchor_feat, pc._scaling, pc._offset, exp_b=not pc.decoded_version)
+        src0 = next((L["side_src"] for L in levels if L.get("side_src") is not None), None)
+        # (valid when the level kernels read exactly pc's parameters: multi_scale_generating is also callable on other tensors)
+        if (src0 is not None and src0.rows_read == n and src0.f.data_ptr() == pc._anchor_feat.data_ptr()
+                and src0.o.data_ptr() == pc._offset.data_ptr() and src0.s.shape == pc._scaling.shape):
+            x_means_fused = src0.means()        # accumulated by the level kernels while they read the rows
+        else:
+            x_means_fused = _ctx.means3(pc._anchor_feat, pc._scaling, pc._offset, exp_b=not pc.decoded_version)
     else:
         xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
     masks30 = None                              # [N, 3K] mask weights, only the unfused levels read it
@@ -599,6 +664,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
     level_bpp_sums, level_rows = [], []
     x_means = masks_chosen = None
     fused_sums = []
+    # the fused levels write their three sums into consecutive rows of one zeroed table (rate_finish reads it whole)
+    S_table = torch.zeros(len(levels), 3, dtype=torch.float32, device=dev) if all_fused else None
     for L in levels:
         if L.get("fused"):                      # one launch: gathers of the chosen rows + the three rate terms + sums
             if x_means is None:
@@ -613,7 +680,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
             else:
                 m_rows, g_rows = binary_grid_masks.reshape(n, K), L["rows"]
             sums = _ctx.level_rate(L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"], m_rows, g_rows, x_means,
-                                   _enc.use_clamp, K, side=L.get("side"))
+                                   _enc.use_clamp, K, side=L.get("side"),
+                                   out=S_table[len(fused_sums)] if S_table is not None else None)
             fused_sums.append(sums)
             n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
             level_rows.append(n_sub)
@@ -636,11 +704,19 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         level_bpp_sums.append((bf.detach().sum() + bs.detach().sum() + bo.detach().sum()))
 
     if fused_sums and len(fused_sums) == len(levels) and not return_sum_bits:
-        # all levels came from the fused rate kernel: the scalar bookkeeping below as a handful of [3]-vector ops
-        # (the element-by-element version is ~60 one-element launches per step, forward and backward)
+        feat_dim = pc.feat_dim + 6 + 3 * K
+        divisors = [1.0, float(max(1, n_hyper))] + [float(max(1, r) * feat_dim) for r in level_rows]
+        if S_table is not None and (mask_anchor_bool is None or live_count is not None):
+            # all levels came from the fused rate kernel and the live fraction is a host number: the whole scalar tail
+            # of :1687-1705 is one launch (forward) / one launch (backward)
+            dead = 0.0 if mask_anchor_bool is None else 1.0 - live_count / mask_anchor_bool.numel()
+            out4, raw = _ctx.rate_finish(fused_sums, hyper_sum, mask_anchor_rate, n_feat, n_scaling, n_offsets, dead)
+            each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
+            return out4[0], out4[1], out4[2], out4[3], each_level_bpp
+        # the same as a handful of [3]-vector ops (the element-by-element version is ~60 one-element launches per step)
         S = torch.stack(fused_sums)                               # [levels, 3] = (feat, scaling, offsets) bits
         tot = S.sum(dim=0) * mask_anchor_rate
-        s_hyper = torch.sum(bit_hyper) * mask_anchor_rate
+        s_hyper = hyper_sum.reshape(()) * mask_anchor_rate
         bit_per_feat_param = tot[0] / max(1, n_feat)
         bit_per_scaling_param = tot[1] / max(1, n_scaling)
         bit_per_offsets_param = tot[2] / max(1, n_offsets)
@@ -648,8 +724,6 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         with torch.no_grad():
             raw = torch.cat([(1 - mask_anchor_bool.float().mean()).reshape(1) if mask_anchor_bool is not None
                              else torch.zeros(1, device=dev), s_hyper.detach().reshape(1), S.detach().sum(dim=1)])
-        feat_dim = pc.feat_dim + 6 + 3 * K
-        divisors = [1.0, float(max(1, bit_hyper.numel()))] + [float(max(1, r) * feat_dim) for r in level_rows]
         each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
         return bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, each_level_bpp
     for sums in fused_sums:                     # mixed fused / unfused levels: element-wise bookkeeping
@@ -657,12 +731,13 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         level_bpp_sums.append(sums.detach().sum())
 
     if return_sum_bits:                                                                # :1672-1685
-        bit_anchor = bit_hyper.shape[0] * 3 * 16
+        bit_anchor = (n_hyper // max(1, pc.latent_codec.channels if hasattr(pc.latent_codec, "channels") else 1)
+                      if bit_hyper is None else bit_hyper.shape[0]) * 3 * 16
         bit_masks_sum = get_binary_vxl_size(binary_grid_masks)[1].item()
-        return (bit_anchor, torch.sum(bit_hyper).item(), s_feat.item(), s_scaling.item(), s_offsets.item(), bit_masks_sum)
+        return (bit_anchor, hyper_sum.sum().item(), s_feat.item(), s_scaling.item(), s_offsets.item(), bit_masks_sum)
 
-    s_hyper = torch.sum(bit_hyper)
-    bit_per_hyper_param = s_hyper / max(1, bit_hyper.numel()) * mask_anchor_rate
+    s_hyper = hyper_sum.reshape(())
+    bit_per_hyper_param = s_hyper / max(1, n_hyper) * mask_anchor_rate
     bit_per_feat_param = s_feat / max(1, n_feat) * mask_anchor_rate
     bit_per_scaling_param = s_scaling / max(1, n_scaling) * mask_anchor_rate
     bit_per_offsets_param = s_offsets / max(1, n_offsets) * mask_anchor_rate
@@ -720,7 +795,10 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
                            mask_anchor_bool=None, training=False, predict_bpp=False, return_sum_bits=False):   # :1541-1707
     # The rate subset is drawn BEFORE the level loop (the reference draws it after, :1659) so that the loop can
     # skip the mean/scale outputs of unchosen anchors; same distribution, different position in the RNG stream.
-    choose_mask = draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits) if predict_bpp else None
+    choose_mask = None
+    if predict_bpp:
+        choose_mask = (choose_mask_provider(anchor, mask_anchor_bool) if (choose_mask_provider is not None and not return_sum_bits)
+                       else draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits))
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
         choose_mask=choose_mask)
@@ -752,10 +830,21 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
     two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]].  defer_feat: return the
     feature rows as a LazyRows (source + row index) so that the caller can fuse the gather into its own kernel."""
-    choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False) if predict_bpp else None
+    # the rate subset (:1658-1661): drawn inside the step's bookkeeping kernel on the device (same distribution, the
+    # build's counter-based generator instead of torch's Philox stream), by torch otherwise
+    choose_mask, draw = None, False
+    if predict_bpp:
+        if choose_mask_provider is not None:
+            choose_mask = choose_mask_provider(anchor, mask_anchor_bool)
+        elif anchor.is_cuda:
+            draw = True
+        else:
+            choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False)
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
-        choose_mask=choose_mask)
+        choose_mask=choose_mask, draw_choose=draw)
+    if draw:
+        choose_mask = c.get("_choose_mask")
     if c["covers_all"]:
         pos = c["inv_perm"][vis_idx]
         lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32 and LAZY_MODE > 0
@@ -770,4 +859,4 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     if not predict_bpp:
         return outs
     return outs + tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False,
-                                   choose_mask))
+                                   choose_mask, live_count=c.get("live_count")))

@@ -114,32 +114,90 @@ extern "C" int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const
 
 // ------------------------------------------------------------------------------------------------------------
 // Counter-based noise: u(seed, tensor, element) in [-0.5, 0.5), regenerated (not stored) by the backward.
+// 32-bit arithmetic on purpose (two v_mul_lo_u32 per value): the first version was splitmix64, whose three 64-bit
+// multiplications (twelve quarter-rate 32-bit multiplies) made the noise kernels compute-bound at ~1.9 TB/s.
+// key = lowbias32(seed_lo ^ golden * (tensor + 1)) ^ seed_hi;  u = lowbias32(elem_lo + key + elem_hi * c) >> 8.
+// Restated in oracle/context_ref.py:ctx_noise (the fixtures feed the same values to the reference).
+__device__ __forceinline__ uint32_t ctx_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t ctx_noise_key(uint64_t seed, uint32_t tensor) {
+    return ctx_mix32((uint32_t)seed ^ (0x9E3779B9u * (tensor + 1u))) ^ (uint32_t)(seed >> 32);
+}
+__device__ __forceinline__ float ctx_noise_k(uint32_t key, uint64_t elem) {
+    const uint32_t h = ctx_mix32((uint32_t)elem + key + (uint32_t)(elem >> 32) * 0x632BE5ABu);
+    return (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
 __device__ __forceinline__ float ctx_noise(uint64_t seed, uint32_t tensor, uint64_t elem) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (elem * 4 + tensor + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f) - 0.5f;
+    return ctx_noise_k(ctx_noise_key(seed, tensor), elem);
 }
 
 __device__ __forceinline__ float ctx_step(float q0, float qadj) { return fmaxf(q0 * (1.f + tanhf(qadj)), 1e-9f); }
 
-// 16 lanes per row: a wave instruction touches 4 rows x 64 contiguous bytes of each tensor
+#define CTX_SUM_SLOTS 64
+#define CTX_SUM_STRIDE 16        // doubles: one 128-byte line per slot
+
+__device__ __forceinline__ double ctx_wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// 16 lanes per row: a wave instruction touches 4 rows x 64 contiguous bytes of each tensor.
+// sums (may be NULL): double [3], += the sums of the SOURCE values read (features, scaling, offsets): the levels of a
+// step together read every row of the three parameter tensors exactly once, which makes these the numerators of the
+// rate model's three clamp centres (scene/gaussian_model.py:1664-1668) without a separate pass over 344 B per anchor.
 __global__ void __launch_bounds__(256)
     noise_quant_fwd_kernel(const float *__restrict__ xf, const float *__restrict__ xs, const float *__restrict__ xo,
                            const float *__restrict__ qadj, const int64_t *__restrict__ rows, int64_t n, int D, int S,
                            int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ yf,
-                           float *__restrict__ ys, float *__restrict__ yo, float *__restrict__ Q) {
+                           float *__restrict__ ys, float *__restrict__ yo, float *__restrict__ Q,
+                           double *__restrict__ sums) {
     const int l = threadIdx.x & 15;
+    const uint32_t kf = ctx_noise_key(seed, 0), ks = ctx_noise_key(seed, 1), ko = ctx_noise_key(seed, 2);
+    float pf = 0.f, ps = 0.f, po = 0.f;
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
         const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
                     qo = ctx_step(q0o, qadj[r * 3 + 2]);
         if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);
         const int64_t sr = rows ? rows[r] : r;        // source row: the level's slice of the coding-order permutation
-        for (int c = l; c < D; c += 16) yf[r * D + c] = xf[sr * D + c] + ctx_noise(seed, 0, (uint64_t)r * D + c) * qf;
-        for (int c = l; c < S; c += 16) ys[r * S + c] = xs[sr * S + c] + ctx_noise(seed, 1, (uint64_t)r * S + c) * qs;
-        for (int c = l; c < O; c += 16) yo[r * O + c] = xo[sr * O + c] + ctx_noise(seed, 2, (uint64_t)r * O + c) * qo;
+        for (int c = l; c < D; c += 16) { const float v = xf[sr * D + c]; pf += v; yf[r * D + c] = v + ctx_noise_k(kf, (uint64_t)r * D + c) * qf; }
+        for (int c = l; c < S; c += 16) { const float v = xs[sr * S + c]; ps += v; ys[r * S + c] = v + ctx_noise_k(ks, (uint64_t)r * S + c) * qs; }
+        for (int c = l; c < O; c += 16) { const float v = xo[sr * O + c]; po += v; yo[r * O + c] = v + ctx_noise_k(ko, (uint64_t)r * O + c) * qo; }
     }
+    if (sums) {        // one atomic per block and quantity, spread over CTX_SUM_SLOTS cache lines (same-address atomics serialise)
+        __shared__ double part[4][3];
+        const double a = ctx_wave_sum((double)pf), b = ctx_wave_sum((double)ps), c = ctx_wave_sum((double)po);
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k = threadIdx.x;
+            atomicAdd(&sums[(blockIdx.x % CTX_SUM_SLOTS) * CTX_SUM_STRIDE + k], part[0][k] + part[1][k] + part[2][k] + part[3][k]);
+        }
+    }
+}
+
+// out3 = (sum over the slots) / counts (float), then the slots are zeroed for the next step's accumulation
+__global__ void means_finalize_kernel(double *__restrict__ sums, double ia, double ib, double ic, float *__restrict__ out) {
+    const int k = threadIdx.x;
+    if (k < 3) {
+        double v = 0.0;
+        for (int s = 0; s < CTX_SUM_SLOTS; ++s) { v += sums[s * CTX_SUM_STRIDE + k]; sums[s * CTX_SUM_STRIDE + k] = 0.0; }
+        out[k] = (float)(v * (k == 0 ? ia : (k == 1 ? ib : ic)));
+    }
+}
+
+extern "C" size_t cgs_means_accum_doubles(void) { return (size_t)CTX_SUM_SLOTS * CTX_SUM_STRIDE; }
+
+extern "C" int cgs_means_finalize(double *sums3, int64_t na, int64_t nb, int64_t nc, float *out3, void *stream) {
+    if (!sums3 || !out3 || na < 0 || nb < 0 || nc < 0) { cgs_set_error("means_finalize: bad args"); return CGS_ERR_ARG; }
+    hipLaunchKernelGGL(means_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums3, na ? 1.0 / (double)na : 0.0,
+                       nb ? 1.0 / (double)nb : 0.0, nc ? 1.0 / (double)nc : 0.0, out3);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
 }
 
 __device__ __forceinline__ float sum16(float v) {
@@ -162,20 +220,21 @@ __global__ void __launch_bounds__(256)
                            const float *__restrict__ sf, const float *__restrict__ ss, const float *__restrict__ so,
                            const float *__restrict__ sQ) {
     const int l = threadIdx.x & 15;
+    const uint32_t kf = ctx_noise_key(seed, 0), ks = ctx_noise_key(seed, 1), ko = ctx_noise_key(seed, 2);
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
         float af = 0.f, as = 0.f, ao = 0.f, side_q = 0.f;
         if (rows) {
             const int64_t sr = rows[r];
             // sm >= 0: this row is in the rate subset and its rate gradients sit in row sm of the compact side arrays
             const int64_t sm = side_map ? (int64_t)side_map[r] : -1;
-            for (int c = l; c < D; c += 16) { float g = dyf ? dyf[r * D + c] : 0.f; if (sm >= 0) g += sf[sm * D + c]; dxf[sr * D + c] = g; af += g * ctx_noise(seed, 0, (uint64_t)r * D + c); }
-            for (int c = l; c < S; c += 16) { float g = dys ? dys[r * S + c] : 0.f; if (sm >= 0) g += ss[sm * S + c]; dxs[sr * S + c] = g; as += g * ctx_noise(seed, 1, (uint64_t)r * S + c); }
-            for (int c = l; c < O; c += 16) { float g = dyo ? dyo[r * O + c] : 0.f; if (sm >= 0) g += so[sm * O + c]; dxo[sr * O + c] = g; ao += g * ctx_noise(seed, 2, (uint64_t)r * O + c); }
+            for (int c = l; c < D; c += 16) { float g = dyf ? dyf[r * D + c] : 0.f; if (sm >= 0) g += sf[sm * D + c]; dxf[sr * D + c] = g; af += g * ctx_noise_k(kf, (uint64_t)r * D + c); }
+            for (int c = l; c < S; c += 16) { float g = dys ? dys[r * S + c] : 0.f; if (sm >= 0) g += ss[sm * S + c]; dxs[sr * S + c] = g; as += g * ctx_noise_k(ks, (uint64_t)r * S + c); }
+            for (int c = l; c < O; c += 16) { float g = dyo ? dyo[r * O + c] : 0.f; if (sm >= 0) g += so[sm * O + c]; dxo[sr * O + c] = g; ao += g * ctx_noise_k(ko, (uint64_t)r * O + c); }
             if (sm >= 0 && l < 3) side_q = sQ[sm * 3 + l];
         } else {
-            if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise(seed, 0, (uint64_t)r * D + c);
-            if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise(seed, 1, (uint64_t)r * S + c);
-            if (dyo) for (int c = l; c < O; c += 16) ao += dyo[r * O + c] * ctx_noise(seed, 2, (uint64_t)r * O + c);
+            if (dyf) for (int c = l; c < D; c += 16) af += dyf[r * D + c] * ctx_noise_k(kf, (uint64_t)r * D + c);
+            if (dys) for (int c = l; c < S; c += 16) as += dys[r * S + c] * ctx_noise_k(ks, (uint64_t)r * S + c);
+            if (dyo) for (int c = l; c < O; c += 16) ao += dyo[r * O + c] * ctx_noise_k(ko, (uint64_t)r * O + c);
         }
         af = sum16(af);
         as = sum16(as);
@@ -193,13 +252,14 @@ __global__ void __launch_bounds__(256)
 
 extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo, const float *qadj,
                                    const int64_t *rows, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
-                                   float q0s, float q0o, float *yf, float *ys, float *yo, float *Q, void *stream) {
+                                   float q0s, float q0o, float *yf, float *ys, float *yo, float *Q, double *sums3,
+                                   void *stream) {
     if (n < 0 || D < 1 || S < 1 || O < 1) { cgs_set_error("noise_quant_fwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!xf || !xs || !xo || !qadj || !yf || !ys || !yo || !Q) { cgs_set_error("noise_quant_fwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(noise_quant_fwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
-                       xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q);
+                       xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q, sums3);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -416,6 +476,64 @@ extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_pare
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(ctx_gather_bwd_kernel, dim3(stream_grid(n_parents, 4 * 8)), dim3(256), 0, (hipStream_t)stream, dout,
                        ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The scalar bookkeeping at the end of the rate model (scene/gaussian_model.py:1687-1694) as one launch each way:
+//   tot_k = rate * sum_l S[l,k];  out = [ (tot_f + tot_s + tot_o + rate * h) / n_tot,  tot_f / n_f,  tot_s / n_s,  tot_o / n_o ]
+//   raw   = [ 1 - live fraction, rate * h, S[0,:].sum(), S[1,:].sum(), ... ]   (the per-level report, :1697-1705)
+// As torch ops on one-element tensors this was ~25 launches forward and ~20 backward per step.
+struct RateFinishArgs { float rate, inv_nf, inv_ns, inv_no, inv_ntot, dead_frac; int L; };
+
+__global__ void rate_finish_fwd_kernel(const float *__restrict__ S, const float *__restrict__ hsum, RateFinishArgs a,
+                                       float *__restrict__ out4, float *__restrict__ raw) {
+    if (threadIdx.x != 0) return;
+    float tf = 0.f, ts = 0.f, to = 0.f;
+    for (int l = 0; l < a.L; ++l) {
+        tf += S[3 * l]; ts += S[3 * l + 1]; to += S[3 * l + 2];
+        raw[2 + l] = S[3 * l] + S[3 * l + 1] + S[3 * l + 2];
+    }
+    tf *= a.rate; ts *= a.rate; to *= a.rate;
+    const float sh = hsum[0] * a.rate;
+    out4[0] = (tf + ts + to + sh) * a.inv_ntot;
+    out4[1] = tf * a.inv_nf;
+    out4[2] = ts * a.inv_ns;
+    out4[3] = to * a.inv_no;
+    raw[0] = a.dead_frac;
+    raw[1] = sh;
+}
+
+__global__ void rate_finish_bwd_kernel(const float *__restrict__ g4, RateFinishArgs a, float *__restrict__ dS,
+                                       float *__restrict__ dh) {
+    const int i = threadIdx.x;
+    const float g0 = g4[0] * a.rate * a.inv_ntot;
+    if (i < 3 * a.L) {
+        const int k = i % 3;
+        dS[i] = g0 + g4[1 + k] * a.rate * (k == 0 ? a.inv_nf : (k == 1 ? a.inv_ns : a.inv_no));
+    }
+    if (i == 0) dh[0] = g0;
+}
+
+extern "C" int cgs_rate_finish_fwd(const float *S, int L, const float *hsum, float rate, double n_feat, double n_scaling,
+                                   double n_offsets, float dead_frac, float *out4, float *raw, void *stream) {
+    if (L < 0 || L > 16 || !S || !hsum || !out4 || !raw) { cgs_set_error("rate_finish_fwd: bad args"); return CGS_ERR_ARG; }
+    const double nt = n_feat + n_scaling + n_offsets;
+    RateFinishArgs a{rate, (float)(1.0 / (n_feat > 1 ? n_feat : 1)), (float)(1.0 / (n_scaling > 1 ? n_scaling : 1)),
+                     (float)(1.0 / (n_offsets > 1 ? n_offsets : 1)), (float)(1.0 / (nt > 1 ? nt : 1)), dead_frac, L};
+    hipLaunchKernelGGL(rate_finish_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, S, hsum, a, out4, raw);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_rate_finish_bwd(const float *g4, int L, float rate, double n_feat, double n_scaling, double n_offsets,
+                                   float *dS, float *dh, void *stream) {
+    if (L < 0 || L > 16 || !g4 || !dS || !dh) { cgs_set_error("rate_finish_bwd: bad args"); return CGS_ERR_ARG; }
+    const double nt = n_feat + n_scaling + n_offsets;
+    RateFinishArgs a{rate, (float)(1.0 / (n_feat > 1 ? n_feat : 1)), (float)(1.0 / (n_scaling > 1 ? n_scaling : 1)),
+                     (float)(1.0 / (n_offsets > 1 ? n_offsets : 1)), (float)(1.0 / (nt > 1 ? nt : 1)), 0.f, L};
+    hipLaunchKernelGGL(rate_finish_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g4, a, dS, dh);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -1,0 +1,198 @@
+// Per-step bookkeeping of the training context model as two launches (scene/gaussian_model.py:1658-1661 and the
+// plan cache of context_model.py): which anchors enter the rate estimate, where they sit in coding order, and
+// whether the cached level plan is still valid.
+//
+// The torch composition this replaces was ~35 launches per step: rand_like, <=, &, two (==).all() reductions,
+// index_select by the permutation, cumsum, cat, index_select of the level bounds, one read-back, nonzero_static
+// (four kernels), three offset subtractions and a gather — all over N-element vectors, all bound by launch latency.
+//
+//   choose_flags    r in coding order, a = perm[r]:  flag[r] = (u(seed, a) <= thresh  or  given[a]) and mask[a];
+//                   per-4096-row block counts; per-level counts, the number of live anchors and the plan-validity
+//                   flag (anchor / mask still equal to the copies the plan was built from) into `meta`.
+//   choose_compact  ordered compaction of the flagged rows: coding-order position, original index and level-local
+//                   position of every chosen anchor (the block bases are the prefix of the block counts, summed
+//                   by the block itself: at most N / 4096 values).
+// The host reads `meta` (ONE synchronisation, the sizes of the level subsets) between the two.
+#include "cgs_internal.h"
+
+#define CP_THREADS 256
+#define CP_PER_THREAD 4
+#define CP_CHUNK (CP_THREADS * CP_PER_THREAD)
+#define CP_MAX_LEVELS 8
+
+namespace {
+
+__device__ __forceinline__ uint32_t cp_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+struct CpBounds { int64_t b[CP_MAX_LEVELS + 1]; int n; };
+
+__device__ __forceinline__ int cp_level(const CpBounds &B, int64_t r) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < CP_MAX_LEVELS; ++k)
+        if (k < B.n && r >= B.b[k]) l = k;
+    return l;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(CP_THREADS)
+    ctx_choose_flags_kernel(const int64_t *__restrict__ perm, int64_t n, const uint8_t *__restrict__ mask,
+                            const uint8_t *__restrict__ given, uint64_t seed, float thresh,
+                            const float *__restrict__ anchor, const float *__restrict__ anchor_ref,
+                            const uint8_t *__restrict__ mask_ref, CpBounds B, uint8_t *__restrict__ flags,
+                            uint32_t *__restrict__ block_counts, int32_t *__restrict__ meta) {
+    // per-thread tallies, reduced once per block: [0] chosen, [1] live, [2] stale, [3 + l] chosen of level l
+    __shared__ uint32_t tally[3 + CP_MAX_LEVELS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t key = cp_mix32((uint32_t)seed ^ 0x9E3779B9u) ^ (uint32_t)(seed >> 32);
+    const int64_t base = (int64_t)blockIdx.x * CP_CHUNK;
+    if (tid < 3 + CP_MAX_LEVELS) tally[tid] = 0;
+    __syncthreads();
+    uint32_t mine = 0, live_n = 0, stale_n = 0, lvl_n[CP_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < CP_MAX_LEVELS; ++l) lvl_n[l] = 0;
+    for (int k = 0; k < CP_PER_THREAD; ++k) {
+        const int64_t r = base + (int64_t)k * CP_THREADS + tid;
+        if (r >= n) continue;
+        const int64_t a = perm ? perm[r] : r;
+        const bool live = mask ? mask[a] != 0 : true;
+        bool f;
+        if (given) f = given[a] != 0;
+        else f = (float)(cp_mix32((uint32_t)a + key + (uint32_t)((uint64_t)a >> 32) * 0x632BE5ABu) >> 8) * (1.0f / 16777216.0f) <= thresh;
+        f = f && live;
+        flags[r] = f ? 1 : 0;
+        bool stale = false;
+        if (anchor_ref)
+            stale = anchor[3 * a] != anchor_ref[3 * a] || anchor[3 * a + 1] != anchor_ref[3 * a + 1] ||
+                    anchor[3 * a + 2] != anchor_ref[3 * a + 2];
+        if (mask_ref) stale = stale || ((mask[a] != 0) != (mask_ref[a] != 0));
+        mine += f ? 1u : 0u;
+        live_n += live ? 1u : 0u;
+        stale_n += stale ? 1u : 0u;
+        const int lvl = cp_level(B, r);
+#pragma unroll
+        for (int l = 0; l < CP_MAX_LEVELS; ++l) lvl_n[l] += (f && lvl == l) ? 1u : 0u;
+    }
+    auto wave_sum = [](uint32_t v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        return v;
+    };
+    mine = wave_sum(mine);
+    live_n = wave_sum(live_n);
+    stale_n = wave_sum(stale_n);
+#pragma unroll
+    for (int l = 0; l < CP_MAX_LEVELS; ++l) lvl_n[l] = wave_sum(lvl_n[l]);
+    if (lane == 0) {
+        atomicAdd(&tally[0], mine);
+        atomicAdd(&tally[1], live_n);
+        atomicAdd(&tally[2], stale_n);
+#pragma unroll
+        for (int l = 0; l < CP_MAX_LEVELS; ++l)
+            if (l < B.n) atomicAdd(&tally[3 + l], lvl_n[l]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        block_counts[blockIdx.x] = tally[0];
+        if (tally[1]) atomicAdd(&meta[1], (int32_t)tally[1]);
+        if (tally[2]) atomicOr(&meta[0], 1);
+    }
+    if (tid >= 1 && tid <= B.n && tally[3 + tid - 1]) atomicAdd(&meta[2 + tid - 1], (int32_t)tally[3 + tid - 1]);
+}
+
+__global__ void __launch_bounds__(CP_THREADS)
+    ctx_choose_compact_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ block_counts,
+                              const int64_t *__restrict__ perm, int64_t n, CpBounds B, int64_t *__restrict__ nz,
+                              int64_t *__restrict__ rows, int64_t *__restrict__ loc) {
+    __shared__ uint32_t part[CP_THREADS];
+    __shared__ uint32_t wave_cnt[CP_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // base = number of chosen rows in the blocks before this one
+    uint32_t s = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += CP_THREADS) s += block_counts[j];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = CP_THREADS / 2; d >= 1; d >>= 1) {
+        if (tid < d) part[tid] += part[tid + d];
+        __syncthreads();
+    }
+    uint32_t running = part[0];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * CP_CHUNK;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int k = 0; k < CP_PER_THREAD; ++k) {
+        const int64_t r = base + (int64_t)k * CP_THREADS + tid;
+        const bool f = r < n && flags[r] != 0;
+        const uint64_t bal = __ballot(f);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = (uint32_t)__popcll(bal & lt);
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < CP_THREADS / 64; ++w) {
+            const uint32_t c = wave_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        if (f) {
+            const uint32_t p = running + before;
+            nz[p] = r;
+            rows[p] = perm ? perm[r] : r;
+            loc[p] = r - B.b[cp_level(B, r)];
+        }
+        running += total;
+        __syncthreads();
+    }
+}
+
+extern "C" size_t cgs_ctx_choose_blocks(int64_t n) { return (size_t)((n + CP_CHUNK - 1) / CP_CHUNK); }
+
+// meta: int32 [2 + nlevels], ZEROED by this call before the kernel: [0] != 0 <=> anchor / mask differ from the
+// reference copies, [1] = number of live (mask != 0) anchors, [2 + l] = chosen rows of level l (coding order).
+// bounds_host: int64 [nlevels + 1], coding-order level boundaries (bounds[0] = 0, bounds[nlevels] = n).
+extern "C" int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask, const uint8_t *given,
+                                    uint64_t seed, float thresh, const float *anchor, const float *anchor_ref,
+                                    const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels, uint8_t *flags,
+                                    uint32_t *block_counts, int32_t *meta, void *stream) {
+    if (n < 0 || nlevels < 1 || nlevels > CP_MAX_LEVELS || !bounds_host || !flags || !block_counts || !meta) {
+        cgs_set_error("ctx_choose_flags: bad args");
+        return CGS_ERR_ARG;
+    }
+    if ((anchor_ref && !anchor) || (mask_ref && !mask)) { cgs_set_error("ctx_choose_flags: reference without live tensor"); return CGS_ERR_ARG; }
+    CGS_CHECK_HIP(hipMemsetAsync(meta, 0, (size_t)(2 + nlevels) * sizeof(int32_t), (hipStream_t)stream));
+    if (n == 0) return CGS_OK;
+    CpBounds B;
+    B.n = nlevels;
+    for (int l = 0; l <= nlevels; ++l) B.b[l] = bounds_host[l];
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(ctx_choose_flags_kernel, dim3((unsigned)cgs_ctx_choose_blocks(n)), dim3(CP_THREADS), 0,
+                       (hipStream_t)stream, perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, B, flags,
+                       block_counts, meta);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// nz / rows / loc: int64 [>= number of chosen rows]; entries appear in coding order.
+extern "C" int cgs_ctx_choose_compact(const uint8_t *flags, const uint32_t *block_counts, const int64_t *perm, int64_t n,
+                                      const int64_t *bounds_host, int nlevels, int64_t *nz, int64_t *rows, int64_t *loc,
+                                      void *stream) {
+    if (n < 0 || nlevels < 1 || nlevels > CP_MAX_LEVELS || !bounds_host || !flags || !block_counts || !nz || !rows || !loc) {
+        cgs_set_error("ctx_choose_compact: bad args");
+        return CGS_ERR_ARG;
+    }
+    if (n == 0) return CGS_OK;
+    CpBounds B;
+    B.n = nlevels;
+    for (int l = 0; l <= nlevels; ++l) B.b[l] = bounds_host[l];
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(ctx_choose_compact_kernel, dim3((unsigned)cgs_ctx_choose_blocks(n)), dim3(CP_THREADS), 0,
+                       (hipStream_t)stream, flags, block_counts, perm, n, B, nz, rows, loc);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

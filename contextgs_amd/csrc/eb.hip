@@ -231,3 +231,172 @@ extern "C" int cgs_eb_likelihood_bwd(const float *v, const float *raw, const flo
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ---- training-step forms -----------------------------------------------------------------------------------------------
+// The training step consumes the hyper prior in exactly two ways (scene/gaussian_model.py:1556, 1662, 1689):
+// the noisy latents as an input of every level MLP, and the SUM of -log2(likelihood) over the rate subset.  These
+// entry points produce just that: the noisy latents directly in coding order, and the bit sum of a row subset read
+// through an index (no [n_sub, C] likelihood tensor, no log2 / neg / sum launches, no autograd chain through them).
+
+// out[r, c] = hyper[a, c] + u(seed, tensor 3, a * C + c), a = perm[r] (perm NULL: a = r).  The noise is keyed by the
+// ORIGINAL anchor index, i.e. it is EntropyBottleneck's x + U(-1/2, 1/2) on the [N, C] latents, then permuted.
+__global__ void __launch_bounds__(256)
+    hyper_noise_gather_kernel(const float *__restrict__ hyper, const int64_t *__restrict__ perm, int64_t n, int C,
+                              uint32_t key, float *__restrict__ out) {
+    const int64_t total = n * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        const uint64_t e = (uint64_t)(perm ? perm[r] : r) * (uint64_t)C + (uint64_t)c;
+        uint32_t h = (uint32_t)e + key + (uint32_t)(e >> 32) * 0x632BE5ABu;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        out[i] = hyper[e] + ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f);
+    }
+}
+
+static uint32_t eb_noise_key(uint64_t seed, uint32_t tensor) {     // == ctx_noise_key of csrc/ctx.hip
+    uint32_t x = (uint32_t)seed ^ (0x9E3779B9u * (tensor + 1u));
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x ^ (uint32_t)(seed >> 32);
+}
+
+extern "C" int cgs_hyper_noise_gather(const float *hyper, const int64_t *perm, int64_t n, int C, uint64_t seed, float *out,
+                                      void *stream) {
+    if (n < 0 || C < 1) { cgs_set_error("hyper_noise_gather: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!hyper || !out) { cgs_set_error("hyper_noise_gather: NULL"); return CGS_ERR_ARG; }
+    int64_t blocks = (n * C + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(hyper_noise_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hyper, perm, n, C,
+                       eb_noise_key(seed, 3), out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+#define EB_LN2 0.6931471805599453f
+
+// sum over the rows `rows[0..n)` (NULL: rows 0..n) and all channels of -log2(max(likelihood, 1e-9)); per-block partial
+// sums in double, the last block to finish adds them in block order (deterministic) and writes the float result
+__global__ void __launch_bounds__(256)
+    eb_bits_fwd_kernel(const float *__restrict__ v, const int64_t *__restrict__ rows, const float *__restrict__ raw,
+                       int64_t n, int C, double *__restrict__ partial, unsigned int *__restrict__ counter,
+                       float *__restrict__ out) {
+    __shared__ double sh[4];
+    __shared__ bool last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (int)(blockIdx.x % C);
+    const int64_t w_in_c = (int64_t)(blockIdx.x / C) * 4 + wave, waves_per_c = (int64_t)(gridDim.x / C) * 4;
+    float p[EB_P];
+    eb_load_params(raw, c, p);
+    float acc = 0.f;
+    for (int64_t row = w_in_c * 64 + lane; row < n; row += waves_per_c * 64) {
+        const float x = v[(rows ? rows[row] : row) * C + c];
+        EbTrace tl, tu;
+        const float lo = eb_eval(p, x - 0.5f, tl), up = eb_eval(p, x + 0.5f, tu);
+        const float sm = lo + up;
+        const float s = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+        acc -= log2f(fmaxf(fabsf(sigmoidf(s * up) - sigmoidf(s * lo)), EB_BOUND));
+    }
+    double d = (double)acc;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) d += __shfl_xor(d, k, 64);
+    if (lane == 0) sh[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double t = 0.0;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) t += ((volatile double *)partial)[j];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) t += __shfl_xor(t, k, 64);
+    __syncthreads();
+    if (lane == 0) sh[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { *out = (float)((sh[0] + sh[1]) + (sh[2] + sh[3])); *counter = 0u; }
+}
+
+// backward of the above for an upstream gradient *g_sum (device scalar): g_v_sub [n, C] (row r <-> rows[r]) and g_raw += .
+__global__ void __launch_bounds__(256)
+    eb_bits_bwd_kernel(const float *__restrict__ v, const int64_t *__restrict__ rows, const float *__restrict__ raw,
+                       const float *__restrict__ g_sum, int64_t n, int C, float *__restrict__ g_v, float *__restrict__ g_raw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (int)(blockIdx.x % C);
+    const int64_t w_in_c = (int64_t)(blockIdx.x / C) * 4 + wave, waves_per_c = (int64_t)(gridDim.x / C) * 4;
+    float p[EB_P], gp[EB_P];
+    eb_load_params(raw, c, p);
+    const float gs = *g_sum;
+#pragma unroll
+    for (int i = 0; i < EB_P; ++i) gp[i] = 0.f;
+    for (int64_t row = w_in_c * 64 + lane; row < n; row += waves_per_c * 64) {
+        const float x = v[(rows ? rows[row] : row) * C + c];
+        EbTrace tl, tu;
+        const float lo = eb_eval(p, x - 0.5f, tl), up = eb_eval(p, x + 0.5f, tu);
+        const float sm = lo + up;
+        const float s = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
+        const float su = sigmoidf(s * up), sl = sigmoidf(s * lo);
+        const float d = su - sl;
+        const float lik = fmaxf(fabsf(d), EB_BOUND);
+        const float g = -gs / (lik * EB_LN2);                       // d(-log2 lik)/d lik
+        const bool pass = (fabsf(d) >= EB_BOUND) || (g < 0.f);      // LowerBound: as eb_likelihood_bwd_kernel
+        const float gd = pass ? g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 0.f;
+        const float g_up = gd * su * (1.f - su) * s;
+        const float g_lo = -gd * sl * (1.f - sl) * s;
+        float dx = eb_eval_bwd(p, tu, g_up, gp);
+        dx += eb_eval_bwd(p, tl, g_lo, gp);
+        g_v[row * C + c] = dx;
+    }
+    __shared__ float part[4][EB_P];
+#pragma unroll
+    for (int i = 0; i < EB_P; ++i) {
+        const float tot = eb_wave_sum63(gp[i]);
+        if (lane == 63) part[wave][i] = tot;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < EB_P) {
+        const float tot = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+        const float rv = raw[c * EB_P + i];
+        const bool is_f = (i >= OFF_F0 && i < OFF_F0 + 3) || (i >= OFF_F(1) && i < OFF_F(1) + 3) ||
+                          (i >= OFF_F(2) && i < OFF_F(2) + 3) || (i >= OFF_F(3) && i < OFF_F(3) + 3);
+        const bool is_b = (i >= OFF_B0 && i < OFF_B0 + 3) || (i >= OFF_B(1) && i < OFF_B(1) + 3) ||
+                          (i >= OFF_B(2) && i < OFF_B(2) + 3) || (i >= OFF_B(3) && i < OFF_B(3) + 3) || i == OFF_B4;
+        const float pv = is_b ? rv : (is_f ? tanhf(rv) : softplusf(rv));
+        const float chain = is_b ? 1.f : (is_f ? (1.f - pv * pv) : sigmoidf(rv));
+        atomicAdd(&g_raw[c * EB_P + i], tot * chain);
+    }
+}
+
+#define EB_BITS_MAX_BLOCKS 2048
+extern "C" size_t cgs_eb_bits_scratch_bytes(void) { return (size_t)EB_BITS_MAX_BLOCKS * sizeof(double) + 256; }
+
+// scratch: cgs_eb_bits_scratch_bytes() bytes whose last 256 bytes (the arrival counter) are ZERO before the first use (the
+// kernel leaves them zero); out: float [1]
+extern "C" int cgs_eb_bits_fwd(const float *v, const int64_t *rows, const float *raw, int64_t n, int C, void *scratch,
+                               size_t scratch_bytes, float *out, void *stream) {
+    if (n < 0 || C < 1 || !out || !scratch || scratch_bytes < cgs_eb_bits_scratch_bytes()) { cgs_set_error("eb_bits_fwd: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) { CGS_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream)); return CGS_OK; }
+    if (!v || !raw) { cgs_set_error("eb_bits_fwd: NULL"); return CGS_ERR_ARG; }
+    int grid = eb_grid(n, C, 8);
+    if (grid > EB_BITS_MAX_BLOCKS) grid = EB_BITS_MAX_BLOCKS / C * C;
+    hipLaunchKernelGGL(eb_bits_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, rows, raw, n, C, (double *)scratch,
+                       (unsigned int *)((char *)scratch + (size_t)EB_BITS_MAX_BLOCKS * sizeof(double)), out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_eb_bits_bwd(const float *v, const int64_t *rows, const float *raw, const float *g_sum, int64_t n, int C,
+                               float *g_v_sub, float *g_raw, void *stream) {
+    if (n < 0 || C < 1) { cgs_set_error("eb_bits_bwd: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!v || !raw || !g_sum || !g_v_sub || !g_raw) { cgs_set_error("eb_bits_bwd: NULL"); return CGS_ERR_ARG; }
+    hipLaunchKernelGGL(eb_bits_bwd_kernel, dim3(eb_grid(n, C, 2)), dim3(256), 0, (hipStream_t)stream, v, rows, raw, g_sum, n, C,
+                       g_v_sub, g_raw);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -88,6 +88,9 @@ def next_seed() -> int:
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
 
 
+_sums_ws = {}
+
+
 class RowSource:
     """The three per-anchor parameter tensors (features [N,D], scaling [N,S], offsets [N,K,3]) read THROUGH a row
     index by the level kernels, instead of being gathered into coding order first.
@@ -106,7 +109,33 @@ class RowSource:
         self.complete = bool(complete)          # the levels' rows cover every row: no zero fill needed
         self.rows_read = self.rows_written = 0
         self.grads = None
+        self.sums = None            # device double [3]: sums of the values the levels read (RowSource.means())
         self.token = _RowSourceFn.apply(self, feat, scal, off)
+
+    def sums_buffer(self):
+        """The accumulator the level kernels add the sums of their source rows to (zeroed by means())."""
+        if self.sums is None:
+            dev = self.f.device
+            ws = _sums_ws.get(dev)
+            if ws is None:
+                ws = _sums_ws[dev] = [torch.zeros(int(_lib.lib().cgs_means_accum_doubles()), dtype=torch.float64, device=dev), False]
+            if ws[1]:                   # a previous step accumulated but never finalised (it raised): start clean
+                ws[0].zero_()
+            ws[1] = True
+            self.sums = ws[0]
+        return self.sums
+
+    def means(self):
+        """float32 [3] = (features.mean(), scaling.mean(), offsets.mean()) once every row has been read by a level:
+        the three clamp centres of the rate model (scene/gaussian_model.py:1664-1668) without a pass of their own."""
+        n = self.f.shape[0]
+        if self.sums is None or self.rows_read != n:
+            raise RuntimeError("RowSource.means(): the levels have not read every row")
+        out = torch.empty(3, dtype=_f32, device=self.f.device)
+        _lib.check(_lib.lib().cgs_means_finalize(_lib.ptr(self.sums), self.f.numel(), self.s.numel(), self.o.numel(),
+                                                 _lib.ptr(out), _lib.current_stream()), "cgs_means_finalize")
+        _sums_ws[self.f.device][1] = False
+        return out
 
     def grad_buffers(self):
         if self.grads is None:
@@ -173,8 +202,8 @@ class _NoiseQuant(torch.autograd.Function):
         Q = torch.empty(n, 3, dtype=_f32, device=qadj.device)
         _lib.check(_lib.lib().cgs_noise_quant_fwd(
             _lib.ptr(xf), _lib.ptr(xs), _lib.ptr(xo), _lib.ptr(qadj), _lib.ptr(rows), n, D, S, O, seed,
-            q0[0], q0[1], q0[2], _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.current_stream()),
-            "cgs_noise_quant_fwd")
+            q0[0], q0[1], q0[2], _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q),
+            _lib.ptr(src.sums_buffer()) if src is not None else None, _lib.current_stream()), "cgs_noise_quant_fwd")
         ctx.save_for_backward(qadj, rows)
         ctx.dims, ctx.seed, ctx.q0, ctx.src, ctx.side = (n, D, S, O), seed, q0, src, side
         return yf, ys, yo, Q
@@ -214,11 +243,15 @@ def noise_quant(xf, xs, xo, qadj, q0, seed=None, outs=None, src=None, rows=None,
 
 class _LevelRate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side):
+    def forward(ctx, yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side, out):
         yf, ys, yo, Q, pred = _c(yf), _c(ys), _c(yo), _c(Q), _c(pred)
         _lib.require_device(yf, pred)
         n_sub, D = pred.shape[0], yf.shape[1]
-        sums = torch.zeros(3, dtype=_f32, device=yf.device)
+        # out: a ZEROED float [3] the caller owns (a row of the step's [levels, 3] table: one fill for all levels)
+        if out is not None:     # an independent tensor object on the caller's storage (not an autograd view of it)
+            sums = torch.empty(0, dtype=_f32, device=yf.device).set_(out.untyped_storage(), out.storage_offset(), (3,), (1,))
+        else:
+            sums = torch.zeros(3, dtype=_f32, device=yf.device)
         masks = None if masks is None else _c(masks)
         x_means = None if x_means is None else _c(x_means)
         _lib.check(_lib.lib().cgs_level_rate_fwd(
@@ -253,15 +286,53 @@ class _LevelRate(torch.autograd.Function):
             m = torch.full((n_l,), -1, dtype=torch.int32, device=yf.device)
             m[loc] = torch.arange(n_sub, dtype=torch.int32, device=yf.device)
             side.map, side.f, side.s, side.o, side.q = m, d_yf, d_ys, d_yo, dQ
-            return None, None, None, None, d_pred, None, d_masks, None, None, None, None, None
-        return d_yf, d_ys, d_yo, dQ, d_pred, None, d_masks, None, None, None, None, None
+            return None, None, None, None, d_pred, None, d_masks, None, None, None, None, None, None
+        return d_yf, d_ys, d_yo, dQ, d_pred, None, d_masks, None, None, None, None, None, None
 
 
-def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side=None):
+def level_rate(yf, ys, yo, Q, pred, loc, masks, grows, x_means, use_clamp, K, side=None, out=None):
     """[bits_feat, bits_scaling, bits_offsets (mask-weighted)] summed over the chosen rows `loc` of a level.
     side: the RateSide given to the noise_quant call that produced yf/ys/yo/Q (their rate gradients then travel
     through it instead of through autograd)."""
-    return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K), side)
+    return _LevelRate.apply(yf, ys, yo, Q, pred, loc, masks, grows, x_means, bool(use_clamp), int(K), side, out)
+
+
+class _RateFinish(torch.autograd.Function):
+    """(bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param) [4] + the raw numbers of the
+    per-level report, from the per-level bit sums and the hyper bit sum: scene/gaussian_model.py:1687-1705 in ONE
+    launch each way (cgs_rate_finish_*).  The level rows must be consecutive rows of one [L,3] table."""
+
+    @staticmethod
+    def forward(ctx, hsum, cfg, *rows):
+        rate, n_f, n_s, n_o, dead = cfg
+        L = len(rows)
+        base = rows[0]
+        for j, r in enumerate(rows):
+            if r.data_ptr() != base.data_ptr() + 12 * j:
+                raise ValueError("rate_finish: level sums must be consecutive rows of one table")
+        out = torch.empty(4, dtype=_f32, device=base.device)
+        raw = torch.empty(2 + L, dtype=_f32, device=base.device)
+        _lib.check(_lib.lib().cgs_rate_finish_fwd(_lib.ptr(base), L, _lib.ptr(_c(hsum)), float(rate), float(n_f), float(n_s),
+                                                  float(n_o), float(dead), _lib.ptr(out), _lib.ptr(raw),
+                                                  _lib.current_stream()), "cgs_rate_finish_fwd")
+        ctx.cfg, ctx.L = cfg, L
+        ctx.mark_non_differentiable(raw)
+        return out, raw
+
+    @staticmethod
+    def backward(ctx, g, _g_raw):
+        rate, n_f, n_s, n_o, _dead = ctx.cfg
+        dS = torch.empty(ctx.L, 3, dtype=_f32, device=g.device)
+        dh = torch.empty(1, dtype=_f32, device=g.device)
+        _lib.check(_lib.lib().cgs_rate_finish_bwd(_lib.ptr(_c(g)), ctx.L, float(rate), float(n_f), float(n_s), float(n_o),
+                                                  _lib.ptr(dS), _lib.ptr(dh), _lib.current_stream()), "cgs_rate_finish_bwd")
+        return (dh, None, *dS.unbind(0))
+
+
+def rate_finish(level_sums, hsum, rate, n_feat, n_scaling, n_offsets, dead_frac):
+    """level_sums: list of [3] tensors (consecutive rows of one table, see level_rate(out=)); hsum: [1] hyper bit sum.
+    Returns (out [4], raw [2+L])."""
+    return _RateFinish.apply(hsum, (float(rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead_frac)), *level_sums)
 
 
 class _CtxAssemble(torch.autograd.Function):
@@ -361,3 +432,39 @@ def means3(a, b, c, exp_b=False):
     _lib.check(L.cgs_means3(_lib.ptr(a), a.numel(), _lib.ptr(b), b.numel(), int(bool(exp_b)), _lib.ptr(c), c.numel(),
                             _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.current_stream()), "cgs_means3")
     return out
+
+
+def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
+    """The rate subset of one training step in coding order (csrc/ctx_plan.hip): two launches and ONE host read.
+
+    perm: int64 [n] coding-order permutation (None = identity); mask / given / mask_ref: bool [n] or None; anchor /
+    anchor_ref: float32 [n,3] or None (plan-validity check); bounds: python list of the level boundaries in coding
+    order.  Returns (stale, live_count, per-level counts, nz, rows, loc) — nz / rows / loc hold, for every chosen row
+    in coding order, its coding-order position, original anchor index and level-local position; `stale` says the
+    anchors / mask no longer equal the reference copies (the caller rebuilds its plan and calls again)."""
+    L = _lib.lib()
+    dev = (perm if perm is not None else anchor if anchor is not None else mask).device
+    as_u8 = lambda t: None if t is None else (t if t.dtype == torch.uint8 else t.view(torch.uint8)).contiguous()
+    mask_u8, given_u8, mref_u8 = as_u8(mask), as_u8(given), as_u8(mask_ref)
+    nlev = len(bounds) - 1
+    nblk = int(L.cgs_ctx_choose_blocks(n))
+    flags = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    counts = torch.empty(max(nblk, 1), dtype=torch.int32, device=dev)
+    meta = torch.empty(2 + nlev, dtype=torch.int32, device=dev)
+    b_host = (C.c_int64 * (nlev + 1))(*[int(b) for b in bounds])
+    _lib.check(L.cgs_ctx_choose_flags(_lib.ptr(perm), n, _lib.ptr(mask_u8), _lib.ptr(given_u8), int(seed), float(thresh),
+                                      _lib.ptr(None if anchor is None else _c(anchor)),
+                                      _lib.ptr(None if anchor_ref is None else _c(anchor_ref)), _lib.ptr(mref_u8), b_host,
+                                      nlev, _lib.ptr(flags), _lib.ptr(counts), _lib.ptr(meta), _lib.current_stream()),
+               "cgs_ctx_choose_flags")
+    host = meta.tolist()                                   # the step's one synchronisation of the context model
+    stale, live, per_level = bool(host[0]), int(host[1]), [int(v) for v in host[2:]]
+    total = sum(per_level)
+    nz = torch.empty(total, dtype=torch.int64, device=dev)
+    rows = torch.empty(total, dtype=torch.int64, device=dev)
+    loc = torch.empty(total, dtype=torch.int64, device=dev)
+    if total > 0 and not stale:
+        _lib.check(L.cgs_ctx_choose_compact(_lib.ptr(flags), _lib.ptr(counts), _lib.ptr(perm), n, b_host, nlev,
+                                            _lib.ptr(nz), _lib.ptr(rows), _lib.ptr(loc), _lib.current_stream()),
+                   "cgs_ctx_choose_compact")
+    return stale, live, per_level, nz, rows, loc

@@ -71,6 +71,74 @@ class _FusedLikelihood(torch.autograd.Function):
         return g_v, g_p
 
 
+class _HyperNoiseGather(torch.autograd.Function):
+    """x [N,C] -> (x + U(-1/2,1/2))[perm] in ONE launch (cgs_hyper_noise_gather): the training quantisation of the
+    bottleneck, delivered in the context model's coding order.  The noise is the build's counter-based generator
+    keyed by (seed, ORIGINAL row, channel) — the reference draws torch's uniform_; same distribution."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm, seed):
+        from . import _lib
+        x = x.contiguous()
+        _lib.require_device(x)
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_hyper_noise_gather(_lib.ptr(x), _lib.ptr(perm), x.shape[0], x.shape[1], int(seed),
+                                                     _lib.ptr(out), _lib.current_stream()), "cgs_hyper_noise_gather")
+        ctx.inv_perm = inv_perm
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.inv_perm is None else g.index_select(0, ctx.inv_perm)), None, None, None
+
+
+_bits_ws = {}
+
+
+class _FusedBitsSum(torch.autograd.Function):
+    """sum over rows `rows` (coding-order positions) and channels of -log2(likelihood(v)) as a [1] tensor, one launch
+    each way (cgs_eb_bits_*): what the rate model reads of the hyper prior (scene/gaussian_model.py:1662, 1689)."""
+
+    @staticmethod
+    def forward(ctx, v, rows, packed):
+        from . import _lib
+        L = _lib.lib()
+        v, packed = v.contiguous(), packed.contiguous()
+        ws = _bits_ws.get(v.device)
+        if ws is None:
+            ws = _bits_ws[v.device] = torch.zeros(int(L.cgs_eb_bits_scratch_bytes()), dtype=torch.uint8, device=v.device)
+        out = torch.empty(1, dtype=torch.float32, device=v.device)
+        n = int(rows.shape[0]) if rows is not None else int(v.shape[0])
+        _lib.check(L.cgs_eb_bits_fwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), n, v.shape[1], _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(out), _lib.current_stream()), "cgs_eb_bits_fwd")
+        ctx.save_for_backward(v, rows, packed)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        v, rows, packed = ctx.saved_tensors
+        n, C = ctx.n, v.shape[1]
+        g = g.contiguous()
+        g_sub = torch.empty(n, C, dtype=torch.float32, device=v.device)
+        g_p = torch.zeros_like(packed)
+        _lib.check(_lib.lib().cgs_eb_bits_bwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), _lib.ptr(g), n, C,
+                                              _lib.ptr(g_sub), _lib.ptr(g_p), _lib.current_stream()), "cgs_eb_bits_bwd")
+        if rows is None:
+            return g_sub, None, g_p
+        g_v = torch.zeros_like(v)
+        g_v.index_copy_(0, rows, g_sub)
+        return g_v, None, g_p
+
+
+class HyperBitSum:
+    """What the fused training path hands the rate model instead of a likelihood tensor: the summed bits + their count."""
+
+    def __init__(self, total, numel):
+        self.total, self.numel = total, int(numel)
+
+
 class _RowsOf(torch.autograd.Function):
     """x[rows] for distinct rows; backward = row scatter into zeros (no sort, unlike index_put_ accumulate)."""
 
@@ -204,6 +272,15 @@ class EntropyBottleneck(nn.Module):
         lik = _LowerBound.apply(self._likelihood(out), self.likelihood_bound)
         back = lambda t: t.reshape(self.channels, -1).t()
         return back(out), back(lik)
+
+    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int):
+        """Training-step entry (extension): (noisy latents in coding order [N,C], HyperBitSum over the coding-order
+        positions rows_pos) — forward(x, training=True) restricted to what scene/gaussian_model.py:1556-1707 consumes,
+        in two launches.  perm / inv_perm: the coding-order permutation and its inverse (None: identity)."""
+        assert x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 2 and x.shape[1] == self.channels
+        v_p = _HyperNoiseGather.apply(x, perm, inv_perm, seed)
+        n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
+        return v_p, HyperBitSum(_FusedBitsSum.apply(v_p, rows_pos, self._packed_params()), n_rows * self.channels)
 
     def _packed_params(self) -> torch.Tensor:
         """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat)."""

@@ -272,11 +272,62 @@ int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
  * side_map (may be NULL; needs rows): int32 [n], side_map[r] = s >= 0 says row r is in the rate
  * subset and its rate gradients are row s of the COMPACT arrays side_f [n_sub,D], side_s [n_sub,S],
  * side_o [n_sub,O], side_Q [n_sub,3] (cgs_level_rate_bwd with compact != 0); they are added to
- * dy* / dQ_ext on the fly, so no N-row buffer is filled, scattered into and added. */
+ * dy* / dQ_ext on the fly, so no N-row buffer is filled, scattered into and added.
+ * sums3 (forward, may be NULL): double [cgs_means_accum_doubles()] on the device, zero before the
+ * first use (slotted accumulator: same-address atomics serialise), += the sums of the SOURCE values
+ * read from xf / xs / xo.  Over the levels of one step these are the numerators of the rate model's three
+ * clamp centres (_anchor_feat.mean(), get_scaling.mean(), _offset.mean(); scene/gaussian_model.py:
+ * 1664-1668); cgs_means_finalize turns them into float [3] means and zeroes the accumulator. */
 int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo,
                         const float *qadj, const int64_t *rows, int64_t n, int D,
                         int S, int O, uint64_t seed, float q0f, float q0s, float q0o,
-                        float *yf, float *ys, float *yo, float *Q, void *stream);
+                        float *yf, float *ys, float *yo, float *Q, double *sums3,
+                        void *stream);
+/* Training-step forms of the hyper prior (csrc/eb.hip; scene/gaussian_model.py:1556, 1662, 1689).
+ * hyper_noise_gather: out[r,:] = hyper[a,:] + U(-1/2,1/2) with a = perm[r] (NULL: r), the noise being the
+ * counter-based u(seed, tensor 3, a*C + c) — EntropyBottleneck's training quantisation, delivered in coding
+ * order.  eb_bits: out[0] = sum over rows[0..n) (NULL: 0..n) and channels of -log2(max(likelihood, 1e-9))
+ * of v [.,C] under the packed prior raw [C,58]; deterministic (block partials added in block order).
+ * scratch: cgs_eb_bits_scratch_bytes(), its last 256 bytes zero before the first use.  eb_bits_bwd: for the
+ * upstream gradient *g_sum (device scalar) g_v_sub [n,C] (row r <-> rows[r]) and g_raw [C,58] += . */
+int cgs_hyper_noise_gather(const float *hyper, const int64_t *perm, int64_t n, int C,
+                           uint64_t seed, float *out, void *stream);
+size_t cgs_eb_bits_scratch_bytes(void);
+int cgs_eb_bits_fwd(const float *v, const int64_t *rows, const float *raw, int64_t n, int C,
+                    void *scratch, size_t scratch_bytes, float *out, void *stream);
+int cgs_eb_bits_bwd(const float *v, const int64_t *rows, const float *raw, const float *g_sum,
+                    int64_t n, int C, float *g_v_sub, float *g_raw, void *stream);
+/* End of the rate model (scene/gaussian_model.py:1687-1705) in one launch each way.  S [L,3] = per level the
+ * summed bits of (features, scaling, offsets) of the rate subset, hsum [1] the hyper bits, rate = live
+ * fraction of the anchors, n_* the element counts of the three sums.  out4 = (bit_per_param,
+ * bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param); raw [2+L] = (dead_frac, rate*hsum,
+ * per-level bit sums) for the per-level report.  bwd: dS [L,3], dh [1] from g4. */
+int cgs_rate_finish_fwd(const float *S, int L, const float *hsum, float rate, double n_feat,
+                        double n_scaling, double n_offsets, float dead_frac, float *out4,
+                        float *raw, void *stream);
+int cgs_rate_finish_bwd(const float *g4, int L, float rate, double n_feat, double n_scaling,
+                        double n_offsets, float *dS, float *dh, void *stream);
+/* Per-step bookkeeping of the training context model (csrc/ctx_plan.hip; scene/gaussian_model.py:1658-1661
+ * `choose_mask`, restricted per level).  choose_flags: for coding-order position r (anchor a = perm[r], or r
+ * when perm is NULL) flag[r] = (u(seed, a) <= thresh, or given[a] when given != NULL) && mask[a]; writes
+ * block counts (cgs_ctx_choose_blocks(n) uint32) and meta = int32 [2 + nlevels] (zeroed by the call):
+ * [0] != 0 <=> anchor [N,3] / mask differ from anchor_ref / mask_ref (either may be NULL: not checked),
+ * [1] = live anchors, [2 + l] = chosen rows of level l.  bounds_host: int64 [nlevels + 1] level boundaries in
+ * coding order, on the HOST.  choose_compact: coding-order position (nz), original index (rows) and
+ * level-local position (loc) of every chosen row, in coding order. */
+size_t cgs_ctx_choose_blocks(int64_t n);
+int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask,
+                         const uint8_t *given, uint64_t seed, float thresh,
+                         const float *anchor, const float *anchor_ref,
+                         const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels,
+                         uint8_t *flags, uint32_t *block_counts, int32_t *meta, void *stream);
+int cgs_ctx_choose_compact(const uint8_t *flags, const uint32_t *block_counts,
+                           const int64_t *perm, int64_t n, const int64_t *bounds_host,
+                           int nlevels, int64_t *nz, int64_t *rows, int64_t *loc,
+                           void *stream);
+size_t cgs_means_accum_doubles(void);
+int cgs_means_finalize(double *sums3, int64_t na, int64_t nb, int64_t nc, float *out3,
+                       void *stream);
 int cgs_noise_quant_bwd(const float *dyf, const float *dys, const float *dyo,
                         const float *dQ_ext, const float *qadj, int64_t n, int D,
                         int S, int O, uint64_t seed, float q0f, float q0s, float q0o,

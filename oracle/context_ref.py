@@ -256,19 +256,28 @@ def bottleneck_likelihood(v, W):
     return lik.reshape(v.shape[1], -1).T
 
 
+def _mix32(x):
+    """lowbias32 integer mixer on uint32 arrays (wrap-around multiplication)."""
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7feb352d)
+        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x846ca68b)
+        x = x ^ (x >> np.uint32(16))
+    return x
+
+
 def ctx_noise(seed, tensor, count):
     """u in [-0.5, 0.5) for element 0..count-1 of tensor `tensor` (0 feat, 1 scaling, 2 offsets, 3 hyper) of the
-    counter-based training noise stream `seed`: splitmix64 of seed + golden * (4 e + tensor + 1), top 24 bits.
+    counter-based training noise stream `seed`:  key = mix32(seed_lo ^ golden32 * (tensor + 1)) ^ seed_hi,
+    u = (mix32(e_lo + key + e_hi * c) >> 8) / 2^24 - 1/2.
     NOT a reference function (the reference draws torch.uniform_, scene/gaussian_model.py:1610-1616): this restates
     the build's own generator (csrc/ctx.hip ctx_noise) so that fixtures can feed the SAME noise to the reference."""
-    M = np.uint64(0xFFFFFFFFFFFFFFFF)
-    e = np.arange(count, dtype=np.uint64)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     with np.errstate(over="ignore"):
-        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (e * np.uint64(4) + np.uint64(tensor + 1))
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return ((z >> np.uint64(40)).astype(np.uint32).astype(f32) * f32(1.0 / 16777216.0) - f32(0.5)).astype(f32)
+        key = _mix32(np.array([(seed & 0xFFFFFFFF) ^ ((0x9E3779B9 * (tensor + 1)) & 0xFFFFFFFF)], np.uint32))[0] ^ np.uint32(seed >> 32)
+        e = np.arange(count, dtype=np.uint64)
+        lo, hi = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
+        h = _mix32(lo + key + hi * np.uint32(0x632BE5AB))
+    return ((h >> np.uint32(8)).astype(f32) * f32(1.0 / 16777216.0) - f32(0.5)).astype(f32)
 
 
 # ---- scene/gaussian_model.py:1541-1707 ------------------------------------------------------------

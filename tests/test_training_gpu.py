@@ -102,65 +102,6 @@ def test_baseline_scale_anchor_counts_run(N):
     torch.cuda.empty_cache()
 
 
-def test_fused_context_training_path_equals_torch_composition(monkeypatch):
-    """The fused HIP stages of the level loop (ctx_ops: rowcat, noise_quant, level_rate, joined outputs) against
-    the torch composition of the same step (scene/gaussian_model.py:1594-1669), with IDENTICAL noise: the
-    fused path draws counter-based noise from per-level seeds, so the seeds are pinned and the torch path's
-    uniform_ calls are fed the very same numbers."""
-    from contextgs_amd import context_model as cm
-    from contextgs_amd import ctx_ops
-    from contextgs_amd.renderer import prefilter_voxel, render
-    pc, cams, pipe, bg = _setup(N=20000)
-    vis = prefilter_voxel(cams[1], pc, pipe, bg)
-    params = [p for p in pc.parameters() if p.requires_grad]
-    seeds = [11, 22, 33, 44, 55, 66]
-
-    def run(fused):
-        for p in params:
-            p.grad = None
-        torch.manual_seed(5)
-        it = iter(seeds)
-        monkeypatch.setattr(ctx_ops, "next_seed", lambda: next(it))
-        monkeypatch.setattr(cm, "FUSED_TRAINING", fused)
-        pkg = render(cams[1], pc, pipe, bg, visible_mask=vis, step=20000)
-        loss = (1.0 - pkg["render"]).abs().mean() + 0.05 * pkg["bit_per_param"]
-        loss.backward()
-        return pkg, [None if p.grad is None else p.grad.clone() for p in params]
-
-    pkg_f, g_f = run(True)
-
-    # the noise the fused kernels used, level by level (sizes from the cached plan), via Q == 1, x == 0
-    sizes = [s for s in pc._level_cache["sizes"] if s > 0]
-    queue = []
-    for s_, n_l in zip(seeds, sizes):
-        z = lambda w: torch.zeros(n_l, w, device="cuda")
-        uf, us, uo, _ = ctx_ops.noise_quant(z(pc.feat_dim), z(6), z(3 * pc.n_offsets), z(3), (1.0, 1.0, 1.0), seed=s_)
-        queue += [uf, us, uo.view(n_l, pc.n_offsets, 3)]
-    real_uniform = torch.Tensor.uniform_
-
-    def fake_uniform(self, a=0.0, b=1.0, **kw):
-        if queue and (a, b) == (-0.5, 0.5) and self.shape == queue[0].shape:
-            return self.copy_(queue.pop(0))
-        return real_uniform(self, a, b, **kw)
-
-    monkeypatch.setattr(torch.Tensor, "uniform_", fake_uniform)
-    pkg_t, g_t = run(False)
-    assert not queue, "the torch path did not consume every level's noise"
-    monkeypatch.setattr(torch.Tensor, "uniform_", real_uniform)
-
-    torch.testing.assert_close(pkg_f["render"], pkg_t["render"], rtol=1e-4, atol=2e-5)
-    for k in ("bit_per_param", "bit_per_feat_param", "bit_per_scaling_param", "bit_per_offsets_param"):
-        torch.testing.assert_close(pkg_f[k], pkg_t[k], rtol=1e-4, atol=1e-5)
-    names = [n for n, p in pc.named_parameters() if p.requires_grad]
-    for n, a, b in zip(names, g_f, g_t):
-        assert (a is None) == (b is None), n
-        if a is None:
-            continue
-        scale = float(b.abs().max()) + 1e-12
-        err = float((a - b).abs().max()) / scale
-        assert err < 2e-3, (n, err)
-
-
 @pytest.mark.parametrize("loss_kind", ["render+rate", "rate_only", "render_only"])
 def test_row_source_and_rate_side_equal_the_autograd_formulation(monkeypatch, loss_kind):
     """The two backward short-cuts of the fused level loop — parameter rows read / gradients scattered through the

