@@ -109,10 +109,37 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
         }
 }
 
-template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES>
+// Input row assembled on the fly (ROWS variant): [ feat_src[src_row[r], 0:50] | (a - cam)/|a - cam| | |a - cam| ] with a =
+// anchor[r] — gaussian_renderer/__init__.py:106-110 fused into the MLP's operand load, so the [n,54] input is written
+// once (for the weight-gradient kernel) instead of written by a gather kernel and read back here.
+struct M3Rows {
+    const float *feat_src;      // [*, 50] (the context model's output in coding order)
+    const int64_t *src_row;     // [n]
+    const float *anchor;        // [n, 3] visible anchors
+    const float *cam;           // [3] on the device
+    float *X_out;               // [n, 54] side output
+    float *d_feat_src;          // backward: rows src_row[r] of this [*, 50] buffer receive dX[:, 0:50]
+    float *d_anchor;            // backward: [n, 3]
+};
+
+__device__ __forceinline__ f32x4 m3_load_x_rows(const M3Rows &R, int64_t row, int q, int g, bool valid) {
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!valid) return v;
+    const float *fr = R.feat_src + R.src_row[row] * M3_HID;          // 50 features per row
+    const int col0 = 16 * q + 4 * g;
+    if (col0 + 3 < M3_HID) return *(const f32x4_a4 *)(fr + col0);
+    if (col0 >= M3_IN) return v;
+    const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1], uz = R.anchor[3 * row + 2] - R.cam[2];
+    const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
+    if (col0 == 48) { v[0] = fr[48]; v[1] = fr[49]; v[2] = ux / dist; v[3] = uy / dist; }
+    else { v[0] = uz / dist; v[1] = dist; }                          // col0 == 52
+    return v;
+}
+
+template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES, bool ROWS>
 __global__ void __launch_bounds__(WAVES * 64)
     mlp3_fwd_kernel(const float *__restrict__ X, int64_t ldx, M3Head h0, M3Head h1, M3Head h2,
-                    float *__restrict__ Hcat, int64_t n) {
+                    float *__restrict__ Hcat, int64_t n, M3Rows R) {
     __shared__ float lds[M3FwdLds<O0>::FLOATS + M3FwdLds<O1>::FLOATS + M3FwdLds<O2>::FLOATS];
     float *l0 = lds, *l1 = l0 + M3FwdLds<O0>::FLOATS, *l2 = l1 + M3FwdLds<O1>::FLOATS;
     const int tid = threadIdx.x, nthr = WAVES * 64;
@@ -131,7 +158,8 @@ __global__ void __launch_bounds__(WAVES * 64)
         const int64_t row = tile0 * 16 * RT + rt * 16 + c;
         valid[rt] = tile0 < ntiles && row < n;
 #pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
+        for (int q = 0; q < M3_NTI; ++q)
+            xb[rt][q] = ROWS ? m3_load_x_rows(R, row, q, g, valid[rt]) : frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
     }
     for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16 * RT;
@@ -141,7 +169,15 @@ __global__ void __launch_bounds__(WAVES * 64)
             const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c;
             validn[rt] = row < n;
 #pragma unroll
-            for (int q = 0; q < M3_NTI; ++q) xn[rt][q] = frag_load4<M3_IN>(X + row * ldx, q, g, validn[rt]);
+            for (int q = 0; q < M3_NTI; ++q)
+                xn[rt][q] = ROWS ? m3_load_x_rows(R, row, q, g, validn[rt]) : frag_load4<M3_IN>(X + row * ldx, q, g, validn[rt]);
+        }
+        if (ROWS && R.X_out) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < M3_NTI; ++q)
+                    frag_store4<M3_IN>(R.X_out + (row0 + rt * 16 + c) * M3_IN, q, g, valid[rt], xb[rt][q]);
         }
         m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
         m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
@@ -249,10 +285,10 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
         }
 }
 
-template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES>
+template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES, bool ROWS>
 __global__ void __launch_bounds__(WAVES * 64)
     mlp3_bwd_kernel(M3Head h0, M3Head h1, M3Head h2, const float *__restrict__ Hcat, float *__restrict__ dZ1cat,
-                    float *__restrict__ dX, int64_t lddx, int64_t n) {
+                    float *__restrict__ dX, int64_t lddx, int64_t n, M3Rows R) {
     __shared__ float lds[M3BwdLds<O0>::FLOATS + M3BwdLds<O1>::FLOATS + M3BwdLds<O2>::FLOATS];
     float *l0 = lds, *l1 = l0 + M3BwdLds<O0>::FLOATS, *l2 = l1 + M3BwdLds<O1>::FLOATS;
     const int tid = threadIdx.x, nthr = WAVES * 64;
@@ -276,7 +312,34 @@ __global__ void __launch_bounds__(WAVES * 64)
         m3_head_bwd<O0, A0, RT>(l0, h0, 0, valid, row0, g, c, Hcat, dZ1cat, adx);
         m3_head_bwd<O1, A1, RT>(l1, h1, 1, valid, row0, g, c, Hcat, dZ1cat, adx);
         m3_head_bwd<O2, A2, RT>(l2, h2, 2, valid, row0, g, c, Hcat, dZ1cat, adx);
-        if (dX) {
+        if (ROWS) {
+            // dX[:, 0:50] goes straight to the rows of the source's gradient (distinct rows: plain stores), the four view
+            // columns are pulled back to the anchor: u = a - cam, v = u/|u|:  da = (dv - v (v.dv)) / |u| + v d|u|
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int64_t row = row0 + rt * 16 + c;
+                const int64_t srow = valid[rt] ? R.src_row[row] : 0;
+                float *dst = R.d_feat_src + srow * M3_HID;
+#pragma unroll
+                for (int v = 0; v < 3; ++v)
+                    if (valid[rt]) *(f32x4_a4 *)(dst + 16 * v + 4 * g) = adx[v][rt];
+                // columns 48..55 sit in the q = 3 fragments of lanes g = 0 (48..51) and g = 1 (52..55) of this row
+                const float z52 = __shfl(adx[3][rt][0], 16 + c, 64), z53 = __shfl(adx[3][rt][1], 16 + c, 64);
+                if (g == 0 && valid[rt]) {
+                    dst[48] = adx[3][rt][0];
+                    dst[49] = adx[3][rt][1];
+                    const float dvx = adx[3][rt][2], dvy = adx[3][rt][3], dvz = z52, dd = z53;
+                    const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1],
+                                uz = R.anchor[3 * row + 2] - R.cam[2];
+                    const float dist = sqrtf(ux * ux + uy * uy + uz * uz), inv = 1.f / dist;
+                    const float vx = ux * inv, vy = uy * inv, vz = uz * inv;
+                    const float dot = vx * dvx + vy * dvy + vz * dvz;
+                    R.d_anchor[3 * row] = (dvx - vx * dot) * inv + vx * dd;
+                    R.d_anchor[3 * row + 1] = (dvy - vy * dot) * inv + vy * dd;
+                    R.d_anchor[3 * row + 2] = (dvz - vz * dot) * inv + vz * dd;
+                }
+            }
+        } else if (dX) {
 #pragma unroll
             for (int v = 0; v < M3_NTI; ++v)
 #pragma unroll
@@ -314,8 +377,36 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
     const int64_t want = (tiles + WAVES - 1) / WAVES;
     const int grid = (int)(want < m3_cus() ? want : m3_cus());
     CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
-                       X, ldx, h[0], h[1], h[2], Hcat, n);
+    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                       X, ldx, h[0], h[1], h[2], Hcat, n, M3Rows{});
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// The same with the input row assembled on the fly: X[r] = [feat_src[src_row[r], 0:50] | view direction (3) | distance (1)]
+// of anchor_vis[r] as seen from cam3 (device float[3]); X_out [n,54] receives the assembled rows (the weight-gradient
+// pass of the backward reads them).
+extern "C" int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                            const float *cam3, float *X_out, const float *const *W1,
+                                            const float *const *b1, const float *const *W2, const float *const *b2,
+                                            float *Y_op, float *Y_color, float *Y_cov, float *Hcat, int64_t n, void *stream) {
+    if (n < 0) { cgs_set_error("anchor_mlp3_forward_rows: n < 0"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!feat_src || !src_row || !anchor_vis || !cam3 || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) {
+        cgs_set_error("anchor_mlp3_forward_rows: NULL");
+        return CGS_ERR_ARG;
+    }
+    constexpr int RT = 2, WAVES = 8;
+    M3Head h[3];
+    float *ys[3] = {Y_op, Y_color, Y_cov};
+    for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
+    const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
+    const int64_t want = (tiles + WAVES - 1) / WAVES;
+    const int grid = (int)(want < m3_cus() ? want : m3_cus());
+    M3Rows R{feat_src, src_row, anchor_vis, cam3, X_out, nullptr, nullptr};
+    CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                       nullptr, 0, h[0], h[1], h[2], Hcat, n, R);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -323,12 +414,44 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
 // dY_* are the gradients of the three outputs; Y_op / Y_color the saved forward outputs (activation derivatives).
 // Scratch: dZ1cat [n,150], dZ2_op [n,10], dZ2_color [n,30].  dX [n, lddx] may be NULL.  Weight / bias gradients are
 // ACCUMULATED (atomics): dW1cat [150,54], db1cat [150], dW2[i] [OUT_i,50], db2[i] [OUT_i].
+static int m3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2, const float *Y_op,
+                       const float *Y_color, const float *dY_op, const float *dY_color, const float *dY_cov,
+                       const float *Hcat, float *dX, int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color,
+                       float *dW1cat, float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
+                       size_t scratch_bytes, const M3Rows *rows, void *stream_);
+
 extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2,
                                         const float *Y_op, const float *Y_color, const float *dY_op,
                                         const float *dY_color, const float *dY_cov, const float *Hcat, float *dX,
                                         int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color, float *dW1cat,
                                         float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
                                         size_t scratch_bytes, void *stream_) {
+    return m3_backward(X, ldx, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat, dX, lddx, dZ1cat, dZ2_op, dZ2_color,
+                       dW1cat, db1cat, dW2, db2, n, scratch, scratch_bytes, nullptr, stream_);
+}
+
+// Backward of cgs_anchor_mlp3_forward_rows: X is the [n,54] side output of the forward; instead of a dense dX the
+// feature columns are stored into rows src_row[r] of d_feat_src [*,50] (distinct rows; rows no visible anchor reads
+// are the caller's to zero) and the view columns are pulled back to d_anchor_vis [n,3].
+extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_row, const float *anchor_vis,
+                                             const float *cam3, const float *const *W1, const float *const *W2,
+                                             const float *Y_op, const float *Y_color, const float *dY_op,
+                                             const float *dY_color, const float *dY_cov, const float *Hcat,
+                                             float *d_feat_src, float *d_anchor_vis, float *dZ1cat, float *dZ2_op,
+                                             float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
+                                             float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
+                                             void *stream_) {
+    if (!src_row || !anchor_vis || !cam3 || !d_feat_src || !d_anchor_vis) { cgs_set_error("anchor_mlp3_backward_rows: NULL"); return CGS_ERR_ARG; }
+    M3Rows R{nullptr, src_row, anchor_vis, cam3, nullptr, d_feat_src, d_anchor_vis};
+    return m3_backward(X, M3_IN, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat, nullptr, 0, dZ1cat, dZ2_op, dZ2_color,
+                       dW1cat, db1cat, dW2, db2, n, scratch, scratch_bytes, &R, stream_);
+}
+
+static int m3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2, const float *Y_op,
+                       const float *Y_color, const float *dY_op, const float *dY_color, const float *dY_cov,
+                       const float *Hcat, float *dX, int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color,
+                       float *dW1cat, float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
+                       size_t scratch_bytes, const M3Rows *rows, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("anchor_mlp3_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
@@ -347,8 +470,12 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
     const int grid = (int)(want < m3_cus() ? want : m3_cus());
     {
         CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
-        hipLaunchKernelGGL((mlp3_bwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, stream, h[0],
-                           h[1], h[2], Hcat, dZ1cat, dX, lddx, n);
+        if (rows)
+            hipLaunchKernelGGL((mlp3_bwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, stream,
+                               h[0], h[1], h[2], Hcat, dZ1cat, nullptr, 0, n, *rows);
+        else
+            hipLaunchKernelGGL((mlp3_bwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, stream,
+                               h[0], h[1], h[2], Hcat, dZ1cat, dX, lddx, n, M3Rows{});
         CGS_CHECK_HIP(hipGetLastError());
     }
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);

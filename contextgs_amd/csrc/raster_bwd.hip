@@ -20,7 +20,13 @@ __global__ void __launch_bounds__(PB_THREADS)
                           float *__restrict__ dL_dscales, float *__restrict__ dL_drotations) {
     const int64_t i = (int64_t)blockIdx.x * PB_THREADS + threadIdx.x;
     if (i >= P) return;
-    if (radii[i] <= 0) return;   // culled in forward: all gradients stay zero
+    if (radii[i] <= 0) {         // culled in forward: all gradients are zero (the arrays arrive uninitialised)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = 0.f; dL_dmeans2D[3 * i + k] = 0.f; dL_dscales[3 * i + k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dL_drotations[4 * i + k] = 0.f;
+        return;
+    }
 
     float V[16], Pm[16];
 #pragma unroll

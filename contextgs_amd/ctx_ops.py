@@ -63,7 +63,9 @@ class _RowCat(torch.autograd.Function):
                 grads.append(torch.empty(rows, w, dtype=_f32, device=g.device))      # every row written
                 modes.append(1)
             else:
-                grads.append(torch.zeros(rows, w, dtype=_f32, device=g.device))
+                # distinct rows that number as many as the source has: every row is written, no zero fill
+                full = distinct and ctx.n == rows
+                grads.append((torch.empty if full else torch.zeros)(rows, w, dtype=_f32, device=g.device))
                 modes.append(1 if distinct else 2)
         if any(modes) and ctx.n > 0:
             _lib.check(_lib.lib().cgs_rowcat_bwd(len(grads), _ptrs(grads), _ptrs([sp[0] for sp in ctx.spec]),
@@ -77,6 +79,17 @@ def rowcat(parts):
     distinct says the rows of idx do not repeat (plain scatter backward instead of atomics)."""
     spec = tuple((idx, bool(distinct)) for (_s, idx, distinct) in parts)
     return _RowCat.apply(spec, *[s for (s, _i, _d) in parts])
+
+
+def gather_rows_nograd(x, idx):
+    """x[idx] (rows) through the rowcat kernel, no autograd: for use inside backward passes."""
+    x = _c(x)
+    n, w = int(idx.shape[0]), int(x[0].numel())
+    out = torch.empty((n,) + tuple(x.shape[1:]), dtype=_f32, device=x.device)
+    if n > 0:
+        _lib.check(_lib.lib().cgs_rowcat_fwd(1, _ptrs([x]), _ptrs([idx]), _ints([w]), _ints([w]), n, _lib.ptr(out),
+                                             _lib.current_stream()), "cgs_rowcat_fwd")
+    return out
 
 
 _seed_counter = itertools.count(1)

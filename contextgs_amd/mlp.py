@@ -182,6 +182,78 @@ class _AnchorMLP3(torch.autograd.Function):
         return tuple(grads)
 
 
+class _AnchorMLP3Rows(torch.autograd.Function):
+    """The three anchor MLPs on rows assembled inside the kernel: [feat_src[src_row] | view direction | distance]
+    (gaussian_renderer/__init__.py:106-127); backward scatters the feature gradient into the source rows and pulls the
+    view gradient back to the anchors — no [n,54] gather / scatter kernels around the MLP."""
+
+    @staticmethod
+    def forward(ctx, feat_src, src_row, anchor_vis, cam, *params):
+        L = _lib.lib()
+        f32c = lambda t: t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+        feat_src, anchor_vis, cam = f32c(feat_src.detach()), f32c(anchor_vis.detach()), f32c(cam.detach()).reshape(-1)
+        _lib.require_device(feat_src, anchor_vis, cam, src_row)
+        assert feat_src.dim() == 2 and feat_src.shape[1] == 50 and cam.numel() == 3 and src_row.dtype == torch.int64
+        p = [t.detach().contiguous() for t in params]
+        W1, b1, W2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
+        n = int(src_row.shape[0])
+        dev = feat_src.device
+        need_grad = any(ctx.needs_input_grad)
+        y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
+        y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
+        y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
+        hcat = torch.empty(n, 150, dtype=torch.float32, device=dev) if need_grad else None
+        x = torch.empty(n, 54, dtype=torch.float32, device=dev) if need_grad else None
+        _lib.check(L.cgs_anchor_mlp3_forward_rows(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
+                                                  _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
+                                                  _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n,
+                                                  _lib.current_stream()), "cgs_anchor_mlp3_forward_rows")
+        if need_grad:
+            ctx.save_for_backward(x, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
+            ctx.n_src = int(feat_src.shape[0])
+        return y_op, y_color, y_cov
+
+    @staticmethod
+    def backward(ctx, g_op, g_color, g_cov):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        x, src_row, anchor_vis, cam, y_op, y_color, hcat = saved[:7]
+        W1, W2 = list(saved[7:10]), list(saved[10:13])
+        n = x.shape[0]
+        dev = x.device
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else (
+            t.contiguous() if t.dtype == torch.float32 else t.float().contiguous())
+        g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
+        # rows of the source no visible anchor reads keep a zero gradient; when every row is read: no fill
+        d_src = (torch.empty if n == ctx.n_src else torch.zeros)(ctx.n_src, 50, dtype=torch.float32, device=dev)
+        d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        dz1 = torch.empty(n, 150, dtype=torch.float32, device=dev)
+        dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
+        dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
+        views = _zeros_views(dev, (150, 54), (150,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
+        ws = _wgrad_workspace(dev)
+        _lib.check(L.cgs_anchor_mlp3_backward_rows(
+            _lib.ptr(x), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam), _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op),
+            _lib.ptr(y_color), _lib.ptr(g_op), _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(d_src),
+            _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), _lib.ptr(dW1cat), _lib.ptr(db1cat),
+            _ptr_array(dW2), _ptr_array(db2), n, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+            "cgs_anchor_mlp3_backward_rows")
+        grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None]
+        for i in range(3):
+            grads += [dW1cat[50 * i:50 * (i + 1)], db1cat[50 * i:50 * (i + 1)], dW2[i], db2[i]]
+        return tuple(grads)
+
+
+def anchor_mlp3_rows(feat_src, src_row, anchor_vis, cam_center, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):
+    """(mlp_opacity(x), mlp_color(x), mlp_cov(x)) with x[r] = [feat_src[src_row[r]] | unit view vector | distance] of
+    anchor_vis[r] seen from cam_center, assembled inside the fused launch."""
+    params = []
+    for s in (mo, mc, mv):
+        params += [s[0].weight, s[0].bias, s[2].weight, s[2].bias]
+    return _AnchorMLP3Rows.apply(feat_src, src_row, anchor_vis, cam_center, *params)
+
+
 def anchor_mlp3(x, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):
     """(mlp_opacity(x), mlp_color(x), mlp_cov(x)) in one fused launch each way."""
     params = []

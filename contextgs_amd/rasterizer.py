@@ -114,11 +114,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         P = means3D.shape[0]
         dev = means3D.device
         g = _f32c(grad_color)
-        # one zero fill for the six gradient arrays (they are atomically accumulated into)
-        flat = torch.zeros(P * (3 + 3 + 3 + 1 + 3 + 4), dtype=torch.float32, device=dev)
-        parts = torch.split(flat, [3 * P, 3 * P, 3 * P, P, 3 * P, 4 * P])
-        d_means3D, d_means2D, d_colors = parts[0].view(P, 3), parts[1].view(P, 3), parts[2].view(P, 3)
-        d_opac, d_scales, d_rots = parts[3].view(opac.shape), parts[4].view(P, 3), parts[5].view(P, 4)
+        # colour / opacity gradients are accumulated atomically by the blend backward: one zero fill for both; the other
+        # four arrays are written for EVERY Gaussian by the preprocess backward (zeros for culled ones)
+        acc = torch.zeros(P * 4, dtype=torch.float32, device=dev)
+        d_colors, d_opac = acc[:3 * P].view(P, 3), acc[3 * P:].view(opac.shape)
+        rest = torch.empty(P * (3 + 3 + 3 + 4), dtype=torch.float32, device=dev)
+        parts = torch.split(rest, [3 * P, 3 * P, 3 * P, 4 * P])
+        d_means3D, d_means2D = parts[0].view(P, 3), parts[1].view(P, 3)
+        d_scales, d_rots = parts[2].view(P, 3), parts[3].view(P, 4)
         scratch = _workspace(L.cgs_raster_bwd_scratch_bytes(P), dev)
         _lib.check(L.cgs_raster_backward(
             cfg.ref, P, ctx.num_rendered, _lib.ptr(means3D), _lib.ptr(colors), _lib.ptr(opac), _lib.ptr(scales),

@@ -90,8 +90,10 @@ class _ExpandGaussians(torch.autograd.Function):
         d_op, d_mask = e(op_raw), e(masks)
         if src_row is None:
             d_gs, d_off = e(gscaling), e(offsets)
-        else:       # rows of the larger arrays that no visible anchor reads get a zero gradient (one fill for both)
-            flat = torch.zeros(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
+        else:       # rows of the larger arrays that no visible anchor reads get a zero gradient (one fill for both);
+            # when every anchor is visible (src_row is a permutation of all rows) every row is written: no fill
+            alloc = torch.empty if n == gscaling.shape[0] else torch.zeros
+            flat = alloc(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
             d_gs, d_off = flat[:gscaling.numel()].view_as(gscaling), flat[gscaling.numel():].view_as(offsets)
         d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
         d_cov = e(cov_in)
@@ -141,7 +143,10 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
     anchor = sel(full_anchor)
     if not use_context:
-        feat = sel(pc._anchor_feat)
+        # raw features of the visible anchors: left as (source, rows) when nothing is added to them, so that the
+        # anchor-MLP kernel gathers them itself
+        plain = not (is_training and 3000 < step <= 10000)
+        feat = LazyRows(pc._anchor_feat, vis_idx) if (plain and pc._anchor_feat.is_cuda) else sel(pc._anchor_feat)
         grid_offsets = sel(pc._offset)
         grid_scaling = sel(pc.get_scaling)
         binary_grid_masks = sel(pc.get_mask)
@@ -167,17 +172,25 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
             bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
         binary_grid_masks = sel(binary_all)
 
-    ob_view = anchor - viewpoint_camera.camera_center                                   # :106-110
-    ob_dist = ob_view.norm(dim=1, keepdim=True)
-    ob_view = ob_view / ob_dist
-    if isinstance(feat, LazyRows):
-        # the visibility gather of the context model's output and this concatenation are one launch (and one
-        # scatter on the way back) instead of a gather + a cat
-        cat_local_view = feat.cat_with(ob_view, ob_dist)
+    mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    if (isinstance(feat, LazyRows) and feat.src.dim() == 2 and feat.src.shape[1] == 50 and feat.src.is_cuda
+            and mlp.anchor_mlp3_supported(mo, mc, mv)):
+        # :106-127 in one launch: the visibility gather of the context model's output, the view direction / distance
+        # and the [feat, view, dist] concatenation happen inside the fused three-MLP kernel's operand load (and its
+        # backward scatters straight into the source rows): no [n,54] gather / scatter / norm / div launches
+        op_raw, color_in, cov_in = mlp.anchor_mlp3_rows(feat.src, feat.idx, anchor, viewpoint_camera.camera_center,
+                                                        mo, mc, mv)
     else:
-        cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
-
-    op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                          # :112-127
+        ob_view = anchor - viewpoint_camera.camera_center                               # :106-110
+        ob_dist = ob_view.norm(dim=1, keepdim=True)
+        ob_view = ob_view / ob_dist
+        if isinstance(feat, LazyRows):
+            # the visibility gather of the context model's output and this concatenation are one launch (and one
+            # scatter on the way back) instead of a gather + a cat
+            cat_local_view = feat.cat_with(ob_view, ob_dist)
+        else:
+            cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
+        op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                      # :112-127
     K = pc.n_offsets
     src_row = None
     if isinstance(grid_scaling, LazyRows) and isinstance(grid_offsets, LazyRows) and grid_scaling.idx is grid_offsets.idx:

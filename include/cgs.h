@@ -106,9 +106,10 @@ int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P,
                       void *bin_ws, size_t bin_bytes, void *img_ws,
                       size_t img_bytes, float *out_color, void *stream);
 
-/* Backward of the two stages above.  dL_dout is [3,H,W].  All gradient
- * buffers must be zero-initialised by the caller (the blend pass
- * accumulates).  dL_dmeans2D is [P,3] (x,y in the NDC-scaled convention the
+/* Backward of the two stages above.  dL_dout is [3,H,W].  dL_dcolors and
+ * dL_dopacities must be zero-initialised by the caller (the blend pass
+ * accumulates into them); the other four are written for every Gaussian
+ * (zeros for culled ones) and may arrive uninitialised.  dL_dmeans2D is [P,3] (x,y in the NDC-scaled convention the
  * densification threshold assumes; z = 0), the others match their inputs. */
 int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P,
                         int64_t num_rendered, const float *means3D,
@@ -383,6 +384,25 @@ int cgs_anchor_mlp3_backward(const float *X, int64_t ldx,
                              float *dZ2_color, float *dW1cat, float *db1cat,
                              float *const *dW2, float *const *db2, int64_t n,
                              void *scratch, size_t scratch_bytes, void *stream);
+/* The same pair with the MLP input assembled on the fly (gaussian_renderer/__init__.py:106-110 fused into the
+ * operand load): X[r] = [feat_src[src_row[r], 0:50] | (a - cam)/|a - cam| | |a - cam|], a = anchor_vis[r],
+ * cam3 = camera centre (device float[3]).  X_out [n,54] receives the assembled rows (read by the weight-
+ * gradient pass).  The backward stores dX[:, 0:50] into rows src_row[r] of d_feat_src [*,50] (distinct rows;
+ * rows that no visible anchor reads are the caller's to zero) and pulls the four view columns back to
+ * d_anchor_vis [n,3]; everything else as cgs_anchor_mlp3_backward (X = the forward's X_out). */
+int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t *src_row,
+                                 const float *anchor_vis, const float *cam3, float *X_out,
+                                 const float *const *W1, const float *const *b1,
+                                 const float *const *W2, const float *const *b2, float *Y_op,
+                                 float *Y_color, float *Y_cov, float *Hcat, int64_t n, void *stream);
+int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_row, const float *anchor_vis,
+                                  const float *cam3, const float *const *W1, const float *const *W2,
+                                  const float *Y_op, const float *Y_color, const float *dY_op,
+                                  const float *dY_color, const float *dY_cov, const float *Hcat,
+                                  float *d_feat_src, float *d_anchor_vis, float *dZ1cat, float *dZ2_op,
+                                  float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
+                                  float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
+                                  void *stream);
 
 /* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
  * scene/gaussian_model.py:1556; compressai is not in the mount, the density is

@@ -107,3 +107,45 @@ def test_anchor_mlp3_matches_three_torch_mlps(n):
     for i, (a, b) in enumerate(zip(got, ref)):
         tol = (2e-5 if i == 0 else 2e-4) * max(1e-6, float(b.abs().max()))
         assert (a - b).abs().max() <= tol, (i, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_anchor_mlp3_rows_equals_the_materialised_input():
+    """cgs_anchor_mlp3_{forward,backward}_rows (input row = [feat_src[src_row] | view direction | distance] assembled in
+    the kernel, gradient scattered into the source rows / pulled back to the anchors) against the same three MLPs on the
+    torch-assembled [n,54] input (gaussian_renderer/__init__.py:106-110)."""
+    import torch.nn as nn
+    from contextgs_amd import mlp
+    torch.manual_seed(3)
+    dev = "cuda"
+    mk = lambda out, act: nn.Sequential(nn.Linear(54, 50), nn.ReLU(True), nn.Linear(50, out), *([act()] if act else [])).to(dev)
+    mo, mc, mv = mk(10, nn.Tanh), mk(30, nn.Sigmoid), mk(70, None)
+    n_src, n = 5000, 3777
+    feat_src = torch.randn(n_src, 50, device=dev, requires_grad=True)
+    src_row = torch.randperm(n_src, device=dev)[:n].contiguous()
+    anchor = (torch.randn(n, 3, device=dev) * 2).requires_grad_(True)
+    cam = torch.tensor([0.3, -3.0, 0.5], device=dev)
+    ws = [torch.randn(n, k, device=dev) for k in (10, 30, 70)]
+
+    def loss(outs):
+        return sum((o * w).sum() for o, w in zip(outs, ws))
+
+    params = [p for m in (mo, mc, mv) for p in m.parameters()]
+    loss(mlp.anchor_mlp3_rows(feat_src, src_row, anchor, cam, mo, mc, mv)).backward()
+    got = [feat_src.grad.clone(), anchor.grad.clone()] + [p.grad.clone() for p in params]
+    outs_rows = [o.detach() for o in mlp.anchor_mlp3_rows(feat_src, src_row, anchor, cam, mo, mc, mv)]
+    for t in [feat_src, anchor] + params:
+        t.grad = None
+    u = anchor - cam
+    d = u.norm(dim=1, keepdim=True)
+    x = torch.cat([feat_src[src_row], u / d, d], dim=1)
+    outs_ref = mlp.anchor_mlp3(x, mo, mc, mv)
+    loss(outs_ref).backward()
+    ref = [feat_src.grad, anchor.grad] + [p.grad for p in params]
+    for a, b in zip(outs_rows, outs_ref):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max() <= 2e-5 * max(1e-6, float(b.abs().max())), float((a - b).abs().max())
+    # rows of the source that no anchor reads get exactly zero
+    unread = torch.ones(n_src, dtype=torch.bool, device=dev)
+    unread[src_row] = False
+    assert float(got[0][unread].abs().sum()) == 0.0

@@ -11,11 +11,11 @@ cams = [c.to_torch("cuda") for c in orbit_cameras(8, 1920, 1080)]
 w = torch.randn(3, 1080, 1920, device="cuda") / (1080 * 1920)
 params = [p for p in pc.parameters() if p.requires_grad]
 for i in range(3):
-    bench.one_step(pc, cams[i], pipe, bg, w, 20000, params, False)
+    bench.one_step(pc, cams[i], pipe, bg, w, 20000, params, None)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for i in range(4):
-        bench.one_step(pc, cams[i], pipe, bg, w, 20000, params, False)
+        bench.one_step(pc, cams[i], pipe, bg, w, 20000, params, None)
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
