@@ -225,14 +225,43 @@ def _as_mask(cm):
 choose_mask_provider = None      # test hook: callable(anchor, mask_anchor_bool) -> bool [N], replaces the random draw of the rate subset
 
 
-def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False):
+def _choose_args(cache, anchor, mask_anchor_bool, check):
+    sizes = cache["sizes"]
+    bounds = [0]
+    for s_ in sizes:
+        bounds.append(bounds[-1] + s_)
+    return dict(perm=None if cache.get("identity") else cache["perm"], n=int(anchor.shape[0]), mask=mask_anchor_bool,
+                anchor=anchor if check else None, anchor_ref=cache["anchor"] if check else None,
+                mask_ref=cache["mask"] if (check and mask_anchor_bool is not None) else None, bounds=bounds)
+
+
+def begin_step(pc, anchor, mask_anchor_bool, predict_bpp):
+    """Enqueue the step's bookkeeping kernel (rate subset + plan check + counts) on the cached plan WITHOUT reading
+    its result: the renderer calls this before the read-back of the visible-anchor count it needs anyway, so the
+    context model adds no synchronisation point of its own and the GPU does not idle behind it.  The handle is picked
+    up by _plan_and_chosen of the same step; anything unexpected (no plan yet, another shape) just returns None."""
+    if not (predict_bpp and anchor.is_cuda):
+        return None
+    cache = getattr(pc, "_level_cache", None)
+    if cache is None or pc.level_scale is None or cache["key"] != _plan_key(pc, anchor, mask_anchor_bool) or not cache["covers_all"]:
+        return None
+    given = choose_mask_provider(anchor, mask_anchor_bool) if choose_mask_provider is not None else None
+    seed = _ctx.next_seed() if given is None else 0
+    a = _choose_args(cache, anchor, mask_anchor_bool, True)
+    h = _ctx.choose_rows_begin(a["perm"], a["n"], a["mask"], given, seed, 0.15, a["anchor"], a["anchor_ref"], a["mask_ref"],
+                               a["bounds"])
+    return dict(handle=h, cache=cache, seed=seed, given=given, anchor=anchor, mask=mask_anchor_bool)
+
+
+def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begun=None):
     """(_cached_plan(...), per-level row lists of the rate subset, all chosen rows) with ONE host read.
 
     The cache check ("are anchor and mask what the plan was built from?"), the draw of the subset (when `draw`: the
     15 % of :1658-1659 from the counter-based generator, keyed by the anchor index) and the sizes of the per-level
     subsets are one launch + one read-back; a second launch compacts the chosen rows in coding order
     (ctx_ops.choose_rows).  Per level this equals nonzero(choose_mask[orig]) (:1658-1669 restricted to the level).
-    Also leaves the number of live anchors in cache['live_count'] (the mask_anchor_rate of :1661 without a reduction)."""
+    Also leaves the number of live anchors in cache['live_count'] (the mask_anchor_rate of :1661 without a reduction).
+    begun: the handle of begin_step() of this step (the first launch is already in flight)."""
     cache = getattr(pc, "_level_cache", None)
     if cache is not None:
         cache.pop("live_count", None)
@@ -245,22 +274,22 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False):
         cache = _cached_plan(pc, anchor, mask_anchor_bool)               # builds (device sorts + host reads)
     if not cache["covers_all"]:
         return cache, None, None
-    seed = _ctx.next_seed() if draw else 0
-    n = int(anchor.shape[0])
+    use_begun = (begun is not None and not fresh and begun["cache"] is cache and begun["anchor"] is anchor
+                 and begun["mask"] is mask_anchor_bool)
+    seed = begun["seed"] if use_begun else (_ctx.next_seed() if draw else 0)
     for attempt in range(2):
-        perm, sizes = cache["perm"], cache["sizes"]
-        bounds = [0]
-        for s_ in sizes:
-            bounds.append(bounds[-1] + s_)
-        check = not fresh and attempt == 0
-        stale, live, per_level, nz, rows, loc = _ctx.choose_rows(
-            None if cache.get("identity") else perm, n, mask_anchor_bool, choose_mask, seed, 0.15,
-            anchor if check else None, cache["anchor"] if check else None,
-            cache["mask"] if (check and mask_anchor_bool is not None) else None, bounds)
+        if use_begun and attempt == 0:
+            stale, live, per_level, nz, rows, loc = _ctx.choose_rows_end(begun["handle"])
+        else:
+            a = _choose_args(cache, anchor, mask_anchor_bool, not fresh and attempt == 0)
+            stale, live, per_level, nz, rows, loc = _ctx.choose_rows(
+                a["perm"], a["n"], a["mask"], choose_mask, seed, 0.15, a["anchor"], a["anchor_ref"], a["mask_ref"], a["bounds"])
         if not stale:
             break
         cache = _cached_plan(pc, anchor, mask_anchor_bool)               # rebuilds (rare: anchors / anchor mask changed)
         fresh = True
+    n = int(anchor.shape[0])
+    sizes = cache["sizes"]
     cache["live_count"] = live if mask_anchor_bool is not None else n
     cache["_nz"] = nz                       # coding-order positions of the chosen rows (this step)
     cum = [0]
@@ -415,7 +444,7 @@ def gather_rows(x, idx):
 
 
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
-                               keep_stats, choose_mask=None, draw_choose=False):
+                               keep_stats, choose_mask=None, draw_choose=False, begun=None):
     """The level loop of multi_scale_generating (:1556-1652) in coding order.
 
     Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
@@ -428,7 +457,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     # level plan (cached) + the rate subset's rows per level, with one host read for both
     c, locs, chosen_rows = _plan_and_chosen(pc, anchor, mask_anchor_bool,
                                             choose_mask if (keep_stats and anchor.is_cuda) else None,
-                                            draw=draw_choose and keep_stats and choose_mask is None)
+                                            draw=draw_choose and keep_stats and choose_mask is None, begun=begun)
     if draw_choose and keep_stats and choose_mask is None:
         # the kernels drew the subset: keep a bool mask around for the (rare) level that does not take the fused path
         if chosen_rows is None:            # anchors the plan does not cover: the torch draw
@@ -826,7 +855,7 @@ class LazyRows:
 
 
 def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
-                                   mask_anchor_bool, vis_idx, training, predict_bpp, defer_feat=False):
+                                   mask_anchor_bool, vis_idx, training, predict_bpp, defer_feat=False, begun=None):
     """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
     two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]].  defer_feat: return the
     feature rows as a LazyRows (source + row index) so that the caller can fuse the gather into its own kernel."""
@@ -834,7 +863,9 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     # build's counter-based generator instead of torch's Philox stream), by torch otherwise
     choose_mask, draw = None, False
     if predict_bpp:
-        if choose_mask_provider is not None:
+        if begun is not None and begun["given"] is not None:
+            choose_mask = begun["given"]
+        elif choose_mask_provider is not None:
             choose_mask = choose_mask_provider(anchor, mask_anchor_bool)
         elif anchor.is_cuda:
             draw = True
@@ -842,7 +873,7 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
             choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False)
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
-        choose_mask=choose_mask, draw_choose=draw)
+        choose_mask=choose_mask, draw_choose=draw, begun=begun)
     if draw:
         choose_mask = c.get("_choose_mask")
     if c["covers_all"]:

@@ -447,14 +447,9 @@ def means3(a, b, c, exp_b=False):
     return out
 
 
-def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
-    """The rate subset of one training step in coding order (csrc/ctx_plan.hip): two launches and ONE host read.
-
-    perm: int64 [n] coding-order permutation (None = identity); mask / given / mask_ref: bool [n] or None; anchor /
-    anchor_ref: float32 [n,3] or None (plan-validity check); bounds: python list of the level boundaries in coding
-    order.  Returns (stale, live_count, per-level counts, nz, rows, loc) — nz / rows / loc hold, for every chosen row
-    in coding order, its coding-order position, original anchor index and level-local position; `stale` says the
-    anchors / mask no longer equal the reference copies (the caller rebuilds its plan and calls again)."""
+def choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
+    """First half of choose_rows: launches the flag / count kernel and returns a handle WITHOUT waiting for it, so that
+    the caller can enqueue more work (or reach a synchronisation it has to make anyway) before the counts are read."""
     L = _lib.lib()
     dev = (perm if perm is not None else anchor if anchor is not None else mask).device
     as_u8 = lambda t: None if t is None else (t if t.dtype == torch.uint8 else t.view(torch.uint8)).contiguous()
@@ -470,14 +465,33 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
                                       _lib.ptr(None if anchor_ref is None else _c(anchor_ref)), _lib.ptr(mref_u8), b_host,
                                       nlev, _lib.ptr(flags), _lib.ptr(counts), _lib.ptr(meta), _lib.current_stream()),
                "cgs_ctx_choose_flags")
-    host = meta.tolist()                                   # the step's one synchronisation of the context model
+    return dict(perm=perm, n=n, nlev=nlev, flags=flags, counts=counts, meta=meta, b_host=b_host, dev=dev,
+                keep=(mask_u8, given_u8, mref_u8))
+
+
+def choose_rows_end(h):
+    """Second half: read the counts (the step's synchronisation of the context model), compact the chosen rows."""
+    L = _lib.lib()
+    host = h["meta"].tolist()
     stale, live, per_level = bool(host[0]), int(host[1]), [int(v) for v in host[2:]]
     total = sum(per_level)
+    dev = h["dev"]
     nz = torch.empty(total, dtype=torch.int64, device=dev)
     rows = torch.empty(total, dtype=torch.int64, device=dev)
     loc = torch.empty(total, dtype=torch.int64, device=dev)
     if total > 0 and not stale:
-        _lib.check(L.cgs_ctx_choose_compact(_lib.ptr(flags), _lib.ptr(counts), _lib.ptr(perm), n, b_host, nlev,
-                                            _lib.ptr(nz), _lib.ptr(rows), _lib.ptr(loc), _lib.current_stream()),
-                   "cgs_ctx_choose_compact")
+        _lib.check(L.cgs_ctx_choose_compact(_lib.ptr(h["flags"]), _lib.ptr(h["counts"]), _lib.ptr(h["perm"]), h["n"],
+                                            h["b_host"], h["nlev"], _lib.ptr(nz), _lib.ptr(rows), _lib.ptr(loc),
+                                            _lib.current_stream()), "cgs_ctx_choose_compact")
     return stale, live, per_level, nz, rows, loc
+
+
+def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
+    """The rate subset of one training step in coding order (csrc/ctx_plan.hip): two launches and ONE host read.
+
+    perm: int64 [n] coding-order permutation (None = identity); mask / given / mask_ref: bool [n] or None; anchor /
+    anchor_ref: float32 [n,3] or None (plan-validity check); bounds: python list of the level boundaries in coding
+    order.  Returns (stale, live_count, per-level counts, nz, rows, loc) — nz / rows / loc hold, for every chosen row
+    in coding order, its coding-order position, original anchor index and level-local position; `stale` says the
+    anchors / mask no longer equal the reference copies (the caller rebuilds its plan and calls again)."""
+    return choose_rows_end(choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds))

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, mlp
-from .context_model import LazyRows, gather_unique, multi_scale_generating, multi_scale_generating_visible
+from .context_model import LazyRows, begin_step, gather_unique, multi_scale_generating, multi_scale_generating_visible
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 Q_FEAT, Q_SCALING, Q_OFFSETS = 1, 0.001, 0.2      # :40-42
@@ -135,12 +135,23 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     bit_per_param = bit_per_anchor_param = bit_per_feat_param = None
     bit_per_scaling_param = bit_per_offsets_param = bpp_per_level = None
 
+    full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
+    use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
+    begun = binary_all = mask_anchor_bool = None
+    if use_context:
+        # everything of the context model that does not depend on the visible set is enqueued BEFORE the read-back of
+        # the visible count below (the accessors, the step's bookkeeping kernel): the GPU works through it while the
+        # host waits, and the context model's own count read-back finds its data already there
+        if hasattr(pc, "get_mask_pair"):
+            binary_all, mask_anchor_bool = pc.get_mask_pair()
+        else:                                   # the reference's own GaussianModel
+            binary_all = pc.get_mask
+            mask_anchor_bool = binary_all.detach().sum(dim=1)[:, 0] > 0
+        begun = begin_step(pc, full_anchor, mask_anchor_bool, is_training)
     # visible rows are distinct anchors: gather by index with a sort-free scatter backward (the reference's
     # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
     vis_idx = torch.nonzero(visible_mask)[:, 0]
     sel = lambda t: gather_unique(t, vis_idx)
-    full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
-    use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
     anchor = sel(full_anchor)
     if not use_context:
         # raw features of the visible anchors: left as (source, rows) when nothing is added to them, so that the
@@ -157,16 +168,12 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if is_training and step == 10000:                                                   # :60-61
         pc.update_anchor_bound()
     if use_context:                                                                     # :63-81 (train) / :83-101 (eval)
-        # get_mask_anchor (scene/gaussian_model.py:302-310) is "any offset alive" of the SAME mask values: take both
-        # from one evaluation instead of running the sigmoid / threshold / STE chain twice
-        if hasattr(pc, "get_mask_pair"):
-            binary_all, mask_anchor_bool = pc.get_mask_pair()
-        else:                                   # the reference's own GaussianModel
-            binary_all = pc.get_mask
-            mask_anchor_bool = binary_all.detach().sum(dim=1)[:, 0] > 0
+        # (get_mask_anchor, scene/gaussian_model.py:302-310, is "any offset alive" of the SAME mask values: both came
+        # from one evaluation above instead of running the sigmoid / threshold / STE chain twice)
         res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
                                              pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
-                                             training=is_training, predict_bpp=is_training, defer_feat=True)
+                                             training=is_training, predict_bpp=is_training, defer_feat=True,
+                                             begun=begun)
         feat, grid_scaling, grid_offsets = res[:3]
         if is_training:
             bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
