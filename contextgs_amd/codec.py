@@ -268,11 +268,16 @@ def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens,
     assert lens.shape[0] == S
     in_off_h = np.zeros(S + 1, dtype=np.int64)
     np.cumsum(lens, out=in_off_h[1:])
-    buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
-    assert buf.size == int(in_off_h[-1]), "stream lengths do not add up to the blob"
-    in_d = torch.empty(buf.size + 16, dtype=torch.uint8, device=dev)
-    if buf.size:
-        in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
+    if isinstance(blob, torch.Tensor) and blob.is_cuda:
+        # already on the device (StagedFiles): a uint8 slice followed by >= 16 readable bytes of its storage
+        assert blob.dtype == torch.uint8 and blob.numel() == int(in_off_h[-1]), "stream lengths do not add up to the blob"
+        in_d = blob
+    else:
+        buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        assert buf.size == int(in_off_h[-1]), "stream lengths do not add up to the blob"
+        in_d = torch.empty(buf.size + 16, dtype=torch.uint8, device=dev)
+        if buf.size:
+            in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
     in_off = torch.from_numpy(in_off_h).to(dev)
     mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
     mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
@@ -289,6 +294,70 @@ def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q
                                   [len(b) for b in streams], q_div)
 
 
+def _join_device_slices(parts):
+    """cat of uint8 device tensors; free when they are consecutive slices of one storage (StagedFiles hands them out so)."""
+    parts = [p_ for p_ in parts if p_.numel() > 0] or parts[:1]
+    first = parts[0]
+    end = first.data_ptr() + first.numel()
+    for p_ in parts[1:]:
+        if p_.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or p_.data_ptr() != end:
+            return torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device=first.device)])[:-16]
+        end += p_.numel()
+    total = sum(int(p_.numel()) for p_ in parts)
+    return torch.empty(0, dtype=torch.uint8, device=first.device).set_(first.untyped_storage(), first.storage_offset(), (total,), (1,))
+
+
+_PINNED = {}
+
+
+class StagedFiles:
+    """The bitstream files of a container, read into ONE pinned host buffer and copied to ONE device buffer by a host
+    thread on a side stream while the caller does something else (conduct_decoding: the hyper prior's rANS strings and the
+    first levels).  get(name) waits for the copy and returns that file's bytes as a device uint8 slice; consecutive
+    names are consecutive slices, so the streams of one coder launch need no concatenation.  Replaces, per file,
+    np.fromfile + np.concatenate + a pageable host-to-device copy (three passes over ~120 MB at 1 M anchors)."""
+
+    def __init__(self, paths, device):
+        import os
+        self.names = list(paths)
+        sizes = [os.path.getsize(p_) for p_ in self.names]
+        self.off = {}
+        pos = 0
+        for p_, n in zip(self.names, sizes):
+            self.off[p_] = (pos, n)
+            pos += n
+        self.total = pos
+        self.device = device
+        self.dev_buf = torch.empty(pos + 64, dtype=torch.uint8, device=device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.event = torch.cuda.Event()
+        self._job = host_pool().submit(self._run)
+
+    def _run(self):
+        key = (self.device.index if isinstance(self.device, torch.device) else 0)
+        pinned = _PINNED.get(key)
+        if pinned is None or pinned.numel() < self.total + 64:
+            pinned = _PINNED[key] = torch.empty(max(self.total + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        view = pinned.numpy()
+        for p_ in self.names:
+            pos, n = self.off[p_]
+            if n:
+                with open(p_, "rb", buffering=0) as f:
+                    got = f.readinto(memoryview(view[pos:pos + n]))
+                    assert got == n, (p_, got, n)
+        with torch.cuda.stream(self.stream):
+            self.dev_buf[: self.total].copy_(pinned[: self.total], non_blocking=True)
+            self.event.record(self.stream)
+        self.event.synchronize()          # the pinned buffer is reused by the next container: keep it until the copy is done
+        return True
+
+    def get(self, name):
+        self._job.result()
+        torch.cuda.current_stream().wait_event(self.event)
+        pos, n = self.off[name]
+        return self.dev_buf[pos:pos + n]
+
+
 def gaussian_decode_groups(groups):
     """groups = [(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div), ...] -> [flat float32 values, ...];
     one coder launch for all streams of all groups."""
@@ -300,12 +369,16 @@ def gaussian_decode_groups(groups):
         ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1)); qs.append(_expand_q(Q, q_div))
         edges.append(off[1:] + base)
         mns.append(np.asarray(mn, dtype=np.int32).reshape(-1)); mxs.append(np.asarray(mx, dtype=np.int32).reshape(-1))
-        blobs.append(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        blobs.append(blob if isinstance(blob, (np.ndarray, torch.Tensor)) else np.frombuffer(blob, dtype=np.uint8))
         lns.append(np.asarray(lens, dtype=np.int64).reshape(-1))
         sizes.append(int(ms[-1].numel()))
         base += sizes[-1]
     M, Sc, Qe, E = torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges)
-    mn, mx, blob, lens = np.concatenate(mns), np.concatenate(mxs), np.concatenate(blobs), np.concatenate(lns)
+    mn, mx, lens = np.concatenate(mns), np.concatenate(mxs), np.concatenate(lns)
+    if all(isinstance(b_, torch.Tensor) for b_ in blobs):
+        blob = _join_device_slices(blobs)
+    else:
+        blob = np.concatenate([b_.cpu().numpy() if isinstance(b_, torch.Tensor) else b_ for b_ in blobs])
     from . import dist as D
     if D.world() > 1:
         # multi-GPU: rank r decodes a contiguous block of the streams, then ONE all-gather hands every rank all

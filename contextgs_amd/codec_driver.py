@@ -226,6 +226,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     load_mlp_checkpoints(pc, path("mlp.pt"))
     pc.latent_codec.update(force=True)
     dev = pc.x_bound_min.device
+    # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
+    # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
+    n_lv = len(N_levels_list)
+    order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
+            [f"offsets{l}.b" for l in reversed(range(n_lv))]
+    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
 
     with open(path("hyper.b"), "rb") as f:
         hyper_stream = f.read()
@@ -252,12 +258,33 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     content_pre_gathered = None
 
     def chunk_lens(name, level, bit_list):
-        blob = np.fromfile(path(f"{name}{level}.b"), dtype=np.uint8)
+        blob = staged.get(path(f"{name}{level}.b"))                                      # device bytes
         lens = np.asarray(bit_list, dtype=np.int64) // 8
-        assert int(lens.sum()) == blob.size                                              # :1479-1481
+        assert int(lens.sum()) == int(blob.numel())                                      # :1479-1481
         return blob, lens
 
-    pending_offsets = []
+    # Coder launches last as long as their LONGEST stream (a 1000-anchor feature chunk: 50 000 serial symbols) however
+    # many streams they hold, so the fewer the better: one per level for features + scaling — the offsets of a level
+    # need nothing but that level's prediction and the masks, so ALL of them ride along with the last level's launch
+    # (the host thread decoding the mask stream has had the earlier launches to finish): 3 launches for 3 levels.
+    pending_offsets, masks_decoded = [], None
+
+    def offset_groups():
+        groups, fills = [], []
+        for (level_, orig_, n_, rows_, mean_o, scale_o, Qo_) in pending_offsets:
+            m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
+            cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
+            cnt[1:] = torch.cumsum(m30.sum(1), 0)
+            off_edges = cnt[rows_.to(dev)].cpu()
+            mflat = m30.reshape(-1)
+            Qo30 = Qo_.unsqueeze(1).expand(n_, 3 * K).reshape(-1)
+            groups.append((mean_o.reshape(-1)[mflat], scale_o.reshape(-1)[mflat], Qo30[mflat], off_edges,
+                           min_offsets_d[level_], max_offsets_d[level_],
+                           *chunk_lens("offsets", level_, bit_offsets_d[level_]), 1))
+            fills.append((orig_, n_, mflat))
+        return groups, fills
+
+    last_level = plan[-1][0] if plan else None
     for (level, to_code, orig, hybrid_anchor) in plan:
         n_l = int(orig.shape[0])
         assert n_l == N_levels_list[level]
@@ -268,12 +295,22 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
-        feat_dec, scal_dec = codec.gaussian_decode_groups([
-            (mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
-             *chunk_lens("feat", level, bit_feat_d[level]), D),
-            (mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level], max_scaling_d[level],
-             *chunk_lens("scaling", level, bit_scaling_d[level]), 6)])
         pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
+        groups = [(mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
+                   *chunk_lens("feat", level, bit_feat_d[level]), D),
+                  (mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level], max_scaling_d[level],
+                   *chunk_lens("scaling", level, bit_scaling_d[level]), 6)]
+        fills = []
+        if level == last_level:
+            masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
+            og, fills = offset_groups()
+            groups += og
+        decoded = codec.gaussian_decode_groups(groups)
+        feat_dec, scal_dec = decoded[0], decoded[1]
+        for (orig_, n_, mflat), off_vals in zip(fills, decoded[2:]):
+            off_dec = torch.zeros(n_ * 3 * K, device=dev)
+            off_dec[mflat] = off_vals
+            grid_offset_after_Q[orig_] = off_dec.view(n_, K, 3)
 
         feat_after_Q[orig] = feat_dec.view(n_l, D)
         grid_scaling_after_Q[orig] = scal_dec.view(n_l, 6)
@@ -281,23 +318,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             already_coded[orig] = True
             content_pre_gathered = extract_context_feat(anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
                                                         inverse_indices_list, mapping_list, level)
-
-    masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
-    groups, fills = [], []
-    for (level, orig, n_l, rows, mean_offsets, scale_offsets, Qo) in pending_offsets:
-        m30 = masks_decoded[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)
-        cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=dev)
-        cnt[1:] = torch.cumsum(m30.sum(1), 0)
-        off_edges = cnt[rows.to(dev)].cpu()
-        mflat = m30.reshape(-1)
-        Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
-        groups.append((mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat], Qo30[mflat], off_edges,
-                       min_offsets_d[level], max_offsets_d[level], *chunk_lens("offsets", level, bit_offsets_d[level]), 1))
-        fills.append((orig, n_l, mflat))
-    for (orig, n_l, mflat), off_vals in zip(fills, codec.gaussian_decode_groups(groups)):
-        off_dec = torch.zeros(n_l * 3 * K, device=dev)
-        off_dec[mflat] = off_vals
-        grid_offset_after_Q[orig] = off_dec.view(n_l, K, 3)
+    if masks_decoded is None:                    # no level at all (empty model)
+        masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
     torch.cuda.synchronize(); t2 = time.time()
     print("decoding time:", t2 - t1)
 
