@@ -98,7 +98,7 @@ SIGNATURES = {
     "cgs_ctx_choose_flags": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, C.c_uint64, c_float, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_ctx_choose_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                       c_void_p]),
+                                       c_void_p, c_void_p, c_void_p]),
     "cgs_means_accum_doubles": (c_size_t, []),
     "cgs_means_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "cgs_noise_quant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,

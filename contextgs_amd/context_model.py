@@ -267,6 +267,7 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begu
         cache.pop("live_count", None)
         cache.pop("_choose_mask", None)
         cache.pop("_nz", None)
+        cache.pop("_sub_map", None)
     if (choose_mask is None and not draw) or not anchor.is_cuda:
         return _cached_plan(pc, anchor, mask_anchor_bool), None, None
     fresh = cache is None or cache["key"] != _plan_key(pc, anchor, mask_anchor_bool)
@@ -279,10 +280,10 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begu
     seed = begun["seed"] if use_begun else (_ctx.next_seed() if draw else 0)
     for attempt in range(2):
         if use_begun and attempt == 0:
-            stale, live, per_level, nz, rows, loc = _ctx.choose_rows_end(begun["handle"])
+            stale, live, per_level, nz, rows, loc, sub_map = _ctx.choose_rows_end(begun["handle"])
         else:
             a = _choose_args(cache, anchor, mask_anchor_bool, not fresh and attempt == 0)
-            stale, live, per_level, nz, rows, loc = _ctx.choose_rows(
+            stale, live, per_level, nz, rows, loc, sub_map = _ctx.choose_rows(
                 a["perm"], a["n"], a["mask"], choose_mask, seed, 0.15, a["anchor"], a["anchor_ref"], a["mask_ref"], a["bounds"])
         if not stale:
             break
@@ -292,6 +293,7 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begu
     sizes = cache["sizes"]
     cache["live_count"] = live if mask_anchor_bool is not None else n
     cache["_nz"] = nz                       # coding-order positions of the chosen rows (this step)
+    cache["_sub_map"] = sub_map             # per level: row -> index in the level's chosen list, -1 if not chosen
     cum = [0]
     for v in per_level:
         cum.append(cum[-1] + v)
@@ -383,33 +385,6 @@ def _rowcat_ok(x):
     # 1 M rows of 12 floats): those go through the one-source rowcat kernel.
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] > 0 and x[0].numel() > 0
             and (x[0].numel() * 4) % 16 == 0)
-
-
-class _SplitUse(torch.autograd.Function):
-    """x -> (x, x[loc]) for a tensor with exactly two consumers: one takes every row, one the DISTINCT rows `loc`.
-    The backward adds the second consumer's row gradients into the first one's buffer in place (index_add_ on the
-    chosen rows only) instead of scattering them into an N-row zero buffer that autograd then adds in full."""
-
-    @staticmethod
-    def forward(ctx, x, loc):
-        ctx.save_for_backward(loc)
-        ctx.shape = x.shape
-        return x.view_as(x), x.index_select(0, loc)
-
-    @staticmethod
-    def backward(ctx, g_all, g_sub):
-        (loc,) = ctx.saved_tensors
-        if g_all is None:
-            g_all = torch.zeros(ctx.shape, dtype=g_sub.dtype, device=g_sub.device)
-        elif not g_all.is_contiguous():
-            g_all = g_all.contiguous()
-        if g_sub is not None:
-            g_all.index_add_(0, loc, g_sub)
-        return g_all, None
-
-
-def split_use(x, loc):
-    return _SplitUse.apply(x, loc)
 
 
 def gather_unique(x, idx, complete=False):
@@ -542,16 +517,18 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             # reference evaluates all 175 outputs for all rows and throws 85-100 % of them away; here the
             # second layer runs with its 3 step-size rows on every anchor and with all rows on the chosen
             # anchors only (identical values: the same fp32 fma chains).
-            feat_sub = None
-            if use_fused and keep_stats and feat_in.requires_grad:
-                # feat_in has two consumers, the step-size MLP on every row and the 172-output MLP on the chosen rows:
-                # one node hands both their inputs and merges the two gradients row-wise (no N-row buffer + add)
-                feat_in, feat_sub = split_use(feat_in, loc)
+            feat_sub = pred_sub = None
             if subset_mode:
                 seq = pc.get_grid_mlp[i]
                 D_ = pc.feat_dim
                 n_stat = 2 * (D_ + 6 + 3 * K)
-                qadj = _mlp.mlp2_weights(feat_in, seq[0].weight, seq[0].bias, seq[2].weight[n_stat:], seq[2].bias[n_stat:])
+                if use_fused and keep_stats:
+                    # mlp_grid has two consumers, the step sizes on every row and all outputs on the chosen rows: ONE
+                    # autograd node serves both (weight gradients of the module filled once, the subset's input
+                    # gradient merged row-wise into the full one)
+                    qadj, pred_sub = _mlp.level_mlp(feat_in, loc, seq, n_stat)
+                else:
+                    qadj = _mlp.mlp2_weights(feat_in, seq[0].weight, seq[0].bias, seq[2].weight[n_stat:], seq[2].bias[n_stat:])
             if use_fused:
                 # step sizes + noise (:1603-1616) in one launch; the rate of the chosen rows is one more (rate_model)
                 sl = slice(row_off, row_off + n_l)
@@ -571,9 +548,12 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                     if chosen_rows is not None:
                         lo_ = sum(int(l_.shape[0]) for l_ in locs[:j])
                         span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
+                    sm = c.get("_sub_map")
+                    lvl0 = sum(sizes[:j])
                     levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
                                        yo=ho, Q=Q_all, chosen=span, side=side, side_src=row_src,
-                                       pred=grid_mlp(pc, i, feat_sub if feat_sub is not None else gather_unique(feat_in, loc))))
+                                       sub_map=sm[lvl0:lvl0 + n_l] if (sm is not None and span is not None) else None,
+                                       pred=pred_sub))
                 feat_q.append(hf)
                 scal_q.append(hs)
                 off_q.append(ho)
@@ -686,6 +666,30 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
             x_means_fused = _ctx.means3(pc._anchor_feat, pc._scaling, pc._offset, exp_b=not pc.decoded_version)
     else:
         xm_feat, xm_scaling, xm_offsets = pc._anchor_feat.mean(), pc.get_scaling.mean(), pc._offset.mean()
+    if (all_fused and not return_sum_bits and all(L.get("chosen") is not None for L in levels)
+            and (mask_anchor_bool is None or live_count is not None)):
+        # every level on the fused rate kernel, the subset listed level after level, the live fraction a host number:
+        # the whole of :1658-1705 is ONE autograd node (a launch per level + one for the scalar tail, each way)
+        chosen_all = levels[0]["chosen"][0]
+        masks_chosen = gather_unique(binary_grid_masks.reshape(n, K), chosen_all)
+        tensors, spans, sides, maps, level_rows = [], [], [], [], []
+        n_feat = n_scaling = n_offsets = 0
+        for L in levels:
+            n_sub = int(L["loc"].shape[0])
+            tensors += [L["yf"], L["ys"], L["yo"], L["Q"], L["pred"], L["loc"]]
+            spans.append((L["chosen"][1], L["chosen"][2]))
+            sides.append(L.get("side"))
+            maps.append(L.get("sub_map"))
+            n_feat, n_scaling, n_offsets = n_feat + n_sub * pc.feat_dim, n_scaling + n_sub * 6, n_offsets + n_sub * 3 * K
+            level_rows.append(n_sub)
+        dead = 0.0 if mask_anchor_bool is None else 1.0 - live_count / mask_anchor_bool.numel()
+        meta = dict(use_clamp=_enc.use_clamp, K=K, spans=spans, sides=sides, maps=maps,
+                    finish=(float(mask_anchor_rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead)))
+        out4, raw = _ctx.rate_all(hyper_sum, masks_chosen, x_means_fused, meta, tensors)
+        feat_dim = pc.feat_dim + 6 + 3 * K
+        divisors = [1.0, float(max(1, n_hyper))] + [float(max(1, r) * feat_dim) for r in level_rows]
+        each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
+        return out4[0], out4[1], out4[2], out4[3], each_level_bpp
     masks30 = None                              # [N, 3K] mask weights, only the unfused levels read it
     zero = torch.zeros((), device=dev)
     s_feat, s_scaling, s_offsets = zero, zero, zero

@@ -11,7 +11,8 @@
 //                   flag (anchor / mask still equal to the copies the plan was built from) into `meta`.
 //   choose_compact  ordered compaction of the flagged rows: coding-order position, original index and level-local
 //                   position of every chosen anchor (the block bases are the prefix of the block counts, summed
-//                   by the block itself: at most N / 4096 values).
+//                   by the block itself: at most N / 4096 values); optionally the inverse, for every row of a level its
+//                   index in the level's chosen list or -1 (what the rate backward scatters through).
 // The host reads `meta` (ONE synchronisation, the sizes of the level subsets) between the two.
 #include "cgs_internal.h"
 
@@ -108,8 +109,9 @@ __global__ void __launch_bounds__(CP_THREADS)
 
 __global__ void __launch_bounds__(CP_THREADS)
     ctx_choose_compact_kernel(const uint8_t *__restrict__ flags, const uint32_t *__restrict__ block_counts,
-                              const int64_t *__restrict__ perm, int64_t n, CpBounds B, int64_t *__restrict__ nz,
-                              int64_t *__restrict__ rows, int64_t *__restrict__ loc) {
+                              const int64_t *__restrict__ perm, int64_t n, CpBounds B, CpBounds CB,
+                              int64_t *__restrict__ nz, int64_t *__restrict__ rows, int64_t *__restrict__ loc,
+                              int32_t *__restrict__ sub_map) {
     __shared__ uint32_t part[CP_THREADS];
     __shared__ uint32_t wave_cnt[CP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,9 +144,13 @@ __global__ void __launch_bounds__(CP_THREADS)
         }
         if (f) {
             const uint32_t p = running + before;
+            const int lvl = cp_level(B, r);
             nz[p] = r;
             rows[p] = perm ? perm[r] : r;
-            loc[p] = r - B.b[cp_level(B, r)];
+            loc[p] = r - B.b[lvl];
+            if (sub_map) sub_map[r] = (int32_t)((int64_t)p - CB.b[lvl]);
+        } else if (sub_map && r < n) {
+            sub_map[r] = -1;
         }
         running += total;
         __syncthreads();
@@ -178,21 +184,26 @@ extern "C" int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_
     return CGS_OK;
 }
 
-// nz / rows / loc: int64 [>= number of chosen rows]; entries appear in coding order.
+// nz / rows / loc: int64 [>= number of chosen rows]; entries appear in coding order.  sub_map (may be NULL): int32 [n],
+// row r of level l -> its index in level l's part of the chosen list, -1 when not chosen; needs chosen_counts_host
+// (int64 [nlevels], the per-level counts read back from `meta` of cgs_ctx_choose_flags).
 extern "C" int cgs_ctx_choose_compact(const uint8_t *flags, const uint32_t *block_counts, const int64_t *perm, int64_t n,
                                       const int64_t *bounds_host, int nlevels, int64_t *nz, int64_t *rows, int64_t *loc,
-                                      void *stream) {
+                                      int32_t *sub_map, const int64_t *chosen_counts_host, void *stream) {
     if (n < 0 || nlevels < 1 || nlevels > CP_MAX_LEVELS || !bounds_host || !flags || !block_counts || !nz || !rows || !loc) {
         cgs_set_error("ctx_choose_compact: bad args");
         return CGS_ERR_ARG;
     }
+    if (sub_map && !chosen_counts_host) { cgs_set_error("ctx_choose_compact: sub_map needs the per-level chosen counts"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
-    CpBounds B;
-    B.n = nlevels;
+    CpBounds B, CB;
+    B.n = CB.n = nlevels;
     for (int l = 0; l <= nlevels; ++l) B.b[l] = bounds_host[l];
+    CB.b[0] = 0;
+    for (int l = 0; l < nlevels; ++l) CB.b[l + 1] = CB.b[l] + (chosen_counts_host ? chosen_counts_host[l] : 0);
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(ctx_choose_compact_kernel, dim3((unsigned)cgs_ctx_choose_blocks(n)), dim3(CP_THREADS), 0,
-                       (hipStream_t)stream, flags, block_counts, perm, n, B, nz, rows, loc);
+                       (hipStream_t)stream, flags, block_counts, perm, n, B, CB, nz, rows, loc, sub_map);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

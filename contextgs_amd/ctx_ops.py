@@ -348,6 +348,98 @@ def rate_finish(level_sums, hsum, rate, n_feat, n_scaling, n_offsets, dead_frac)
     return _RateFinish.apply(hsum, (float(rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead_frac)), *level_sums)
 
 
+class _RateAll(torch.autograd.Function):
+    """The rate of ALL levels plus the scalar tail as one autograd node (scene/gaussian_model.py:1658-1705 on the
+    fused path): per level one cgs_level_rate_* launch, then cgs_rate_finish_*.  Compared with one node per level +
+    one for the tail: one zero fill for the [levels,3] sum table (forward) and one for the mask-weight gradient of all
+    chosen rows (backward), no per-level slice nodes, and the level-row -> chosen-index maps come from the step's
+    bookkeeping kernel (ctx_plan.hip) instead of a fill + arange + scatter per level.
+
+    meta: dict(use_clamp, K, finish=(rate, n_f, n_s, n_o, dead), spans=[(lo, hi) rows of `masks` per level],
+               sides=[RateSide | None per level], maps=[int32 [n_level] | None per level]);
+    masks [T, K]: the mask weights of the chosen rows of all levels, level after level; lv: per level
+    (yf, ys, yo, Q, pred, loc).  Returns (out [4], raw [2 + L])."""
+
+    @staticmethod
+    def forward(ctx, hsum, masks, x_means, meta, *lv):
+        Lc = _lib.lib()
+        nl = len(lv) // 6
+        K, use_clamp = int(meta["K"]), int(bool(meta["use_clamp"]))
+        masks, x_means, hsum = _c(masks), _c(x_means), _c(hsum)
+        lv = [t.contiguous() if k % 6 == 5 else _c(t) for k, t in enumerate(lv)]     # every 6th is loc (int64)
+        _lib.require_device(masks, x_means, lv[0], lv[4])
+        dev = masks.device
+        S = torch.zeros(nl, 3, dtype=_f32, device=dev)
+        stream = _lib.current_stream()
+        for j in range(nl):
+            yf, ys, yo, Q, pred, loc = lv[6 * j:6 * j + 6]
+            lo, hi = meta["spans"][j]
+            n_sub = int(pred.shape[0])
+            assert hi - lo == n_sub and int(loc.shape[0]) == n_sub
+            _lib.check(Lc.cgs_level_rate_fwd(
+                _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred),
+                masks.data_ptr() + 4 * K * lo, None, _lib.ptr(x_means), use_clamp, n_sub, yf.shape[1], K, pred.shape[1],
+                S.data_ptr() + 12 * j, stream), "cgs_level_rate_fwd")
+        rate, n_f, n_s, n_o, dead = meta["finish"]
+        out = torch.empty(4, dtype=_f32, device=dev)
+        raw = torch.empty(2 + nl, dtype=_f32, device=dev)
+        _lib.check(Lc.cgs_rate_finish_fwd(_lib.ptr(S), nl, _lib.ptr(hsum), float(rate), float(n_f), float(n_s), float(n_o),
+                                          float(dead), _lib.ptr(out), _lib.ptr(raw), stream), "cgs_rate_finish_fwd")
+        ctx.save_for_backward(masks, x_means, *lv)
+        ctx.meta = meta
+        ctx.mark_non_differentiable(raw)
+        return out, raw
+
+    @staticmethod
+    def backward(ctx, g, _g_raw):
+        Lc = _lib.lib()
+        masks, x_means = ctx.saved_tensors[:2]
+        lv = ctx.saved_tensors[2:]
+        meta = ctx.meta
+        nl = len(lv) // 6
+        K, use_clamp = int(meta["K"]), int(bool(meta["use_clamp"]))
+        rate, n_f, n_s, n_o, _dead = meta["finish"]
+        dev = masks.device
+        stream = _lib.current_stream()
+        dS = torch.empty(nl, 3, dtype=_f32, device=dev)
+        dh = torch.empty(1, dtype=_f32, device=dev)
+        _lib.check(Lc.cgs_rate_finish_bwd(_lib.ptr(_c(g)), nl, float(rate), float(n_f), float(n_s), float(n_o),
+                                          _lib.ptr(dS), _lib.ptr(dh), stream), "cgs_rate_finish_bwd")
+        d_masks = torch.zeros_like(masks) if ctx.needs_input_grad[1] else None      # the kernels add into it
+        grads = []
+        for j in range(nl):
+            yf, ys, yo, Q, pred, loc = lv[6 * j:6 * j + 6]
+            lo, _hi = meta["spans"][j]
+            n_sub, n_l, D = int(pred.shape[0]), int(yf.shape[0]), int(yf.shape[1])
+            side = meta["sides"][j]
+            n_o_rows = n_sub if side is not None else n_l
+            flat = (torch.empty if side is not None else torch.zeros)(n_o_rows * (D + 6 + 3 * K + 3), dtype=_f32, device=dev)
+            d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_o_rows * D, n_o_rows * 6, n_o_rows * 3 * K, n_o_rows * 3])
+            d_yf, d_ys, d_yo, dQ = d_yf.view(n_o_rows, D), d_ys.view(n_o_rows, 6), d_yo.view(n_o_rows, 3 * K), dQ.view(n_o_rows, 3)
+            d_pred = torch.empty_like(pred)
+            _lib.check(Lc.cgs_level_rate_bwd(
+                _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(loc), _lib.ptr(pred),
+                masks.data_ptr() + 4 * K * lo, None, _lib.ptr(x_means), use_clamp, n_sub, D, K, pred.shape[1],
+                dS.data_ptr() + 12 * j, _lib.ptr(d_pred), _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ),
+                None if d_masks is None else d_masks.data_ptr() + 4 * K * lo, int(side is not None), stream),
+                "cgs_level_rate_bwd")
+            if side is not None:
+                m = meta["maps"][j]
+                if m is None:
+                    m = torch.full((n_l,), -1, dtype=torch.int32, device=dev)
+                    m[loc] = torch.arange(n_sub, dtype=torch.int32, device=dev)
+                side.map, side.f, side.s, side.o, side.q = m, d_yf, d_ys, d_yo, dQ
+                grads += [None, None, None, None, d_pred, None]
+            else:
+                grads += [d_yf, d_ys, d_yo, dQ, d_pred, None]
+        return (dh, d_masks, None, None, *grads)
+
+
+def rate_all(hsum, masks, x_means, meta, level_tensors):
+    """See _RateAll.  level_tensors: flat list (yf, ys, yo, Q, pred, loc) per level."""
+    return _RateAll.apply(hsum, masks, x_means, meta, *level_tensors)
+
+
 class _CtxAssemble(torch.autograd.Function):
     """[anchor[idx] | base_f[pos] | base_s[pos] | own] with the atomics-free CSR backward (cgs_ctx_gather_bwd)."""
 
@@ -479,11 +571,14 @@ def choose_rows_end(h):
     nz = torch.empty(total, dtype=torch.int64, device=dev)
     rows = torch.empty(total, dtype=torch.int64, device=dev)
     loc = torch.empty(total, dtype=torch.int64, device=dev)
+    sub_map = None
     if total > 0 and not stale:
+        sub_map = torch.empty(max(h["n"], 1), dtype=torch.int32, device=dev)
+        c_host = (C.c_int64 * h["nlev"])(*per_level)
         _lib.check(L.cgs_ctx_choose_compact(_lib.ptr(h["flags"]), _lib.ptr(h["counts"]), _lib.ptr(h["perm"]), h["n"],
                                             h["b_host"], h["nlev"], _lib.ptr(nz), _lib.ptr(rows), _lib.ptr(loc),
-                                            _lib.current_stream()), "cgs_ctx_choose_compact")
-    return stale, live, per_level, nz, rows, loc
+                                            _lib.ptr(sub_map), c_host, _lib.current_stream()), "cgs_ctx_choose_compact")
+    return stale, live, per_level, nz, rows, loc, sub_map
 
 
 def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
@@ -491,7 +586,9 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
 
     perm: int64 [n] coding-order permutation (None = identity); mask / given / mask_ref: bool [n] or None; anchor /
     anchor_ref: float32 [n,3] or None (plan-validity check); bounds: python list of the level boundaries in coding
-    order.  Returns (stale, live_count, per-level counts, nz, rows, loc) — nz / rows / loc hold, for every chosen row
-    in coding order, its coding-order position, original anchor index and level-local position; `stale` says the
+    order.  Returns (stale, live_count, per-level counts, nz, rows, loc, sub_map) — nz / rows / loc hold, for every
+    chosen row in coding order, its coding-order position, original anchor index and level-local position; sub_map
+    (int32 [n], coding order) is the inverse per level: a row's index in its level's part of the chosen list or -1
+    (None when nothing was compacted); `stale` says the
     anchors / mask no longer equal the reference copies (the caller rebuilds its plan and calls again)."""
     return choose_rows_end(choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds))

@@ -187,15 +187,46 @@ def interval_likelihood(matrices, biases, factors, x, half_width, stop_gradient:
     return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
 
 
+_unpack_index = {}
+
+
+class _PackDensity(torch.autograd.Function):
+    """cat of the 14 small parameter tensors into the [C, 58] image csrc/eb.hip reads.  As plain torch ops the backward is
+    14 column slices, each cloned again when it reaches its (contiguous) parameter; here it is ONE gather that lays the
+    14 gradients out back to back, handed to the parameters as views."""
+
+    @staticmethod
+    def forward(ctx, channels, *parts):
+        ctx.shapes = [tuple(p.shape) for p in parts]
+        ctx.channels = channels
+        return torch.cat([p.reshape(channels, -1) for p in parts], dim=1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        C = ctx.channels
+        widths = [int(torch.Size(s).numel()) // C for s in ctx.shapes]
+        key = (C, tuple(widths), g.device)
+        idx = _unpack_index.get(key)
+        if idx is None:
+            total, cols, a = sum(widths), [], 0
+            for w in widths:
+                cols.append((torch.arange(C).unsqueeze(1) * total + a + torch.arange(w).unsqueeze(0)).reshape(-1))
+                a += w
+            idx = _unpack_index[key] = torch.cat(cols).to(g.device)
+        flat = g.contiguous().reshape(-1).index_select(0, idx)
+        out = [t.view(s) for t, s in zip(torch.split(flat, [C * w for w in widths]), ctx.shapes)]
+        return (None, *out)
+
+
 def pack_density_params(matrices, biases, factors, channels):
-    """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat); filters (3,3,3,3) only."""
+    """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable); filters (3,3,3,3) only."""
     parts = []
     for i in range(5):
-        parts.append(matrices[i].reshape(channels, -1))
-        parts.append(biases[i].reshape(channels, -1))
+        parts.append(matrices[i])
+        parts.append(biases[i])
         if i < 4:
-            parts.append(factors[i].reshape(channels, -1))
-    return torch.cat(parts, dim=1).contiguous()
+            parts.append(factors[i])
+    return _PackDensity.apply(int(channels), *parts)
 
 
 def fused_likelihood(v, packed):

@@ -96,6 +96,87 @@ class _MLP2(torch.autograd.Function):
         return dx, dW1, db1, dW2, db2, None
 
 
+class _LevelMLP(torch.autograd.Function):
+    """mlp_grid[level] (scene/gaussian_model.py:1600) with BOTH of its training consumers in one autograd node:
+    the last `out - n_stat` outputs (the quantisation-step adjustments) on every row of x, all outputs on the rows
+    `loc` (the rate subset, :1658-1669).  One node instead of two MLP nodes over weight slices: the backward fills
+    the weight gradients of the whole module once (no slice zero-fill / copy / add per consumer) and merges the
+    subset's input gradient into the full one row-wise."""
+
+    @staticmethod
+    def forward(ctx, x, loc, W1, b1, W2, b2, n_stat):
+        from . import ctx_ops
+        L = _lib.lib()
+        _lib.require_device(x, W1, W2, loc)
+        x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
+        W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
+        n, in_f = x.shape
+        hid, out = W1c.shape[0], W2c.shape[0]
+        nq, m = out - n_stat, int(loc.shape[0])
+        need_grad = any(ctx.needs_input_grad)
+        stream = _lib.current_stream()
+        qadj = torch.empty(n, nq, dtype=torch.float32, device=x.device)
+        # rows n_stat.. of the second layer are a contiguous block of W2 / b2: plain pointer offsets, no slice op
+        _lib.check(L.cgs_mlp2_forward(in_f, hid, nq, 0, _lib.ptr(x), in_f, _lib.ptr(W1c), _lib.ptr(b1c),
+                                      W2c.data_ptr() + 4 * n_stat * hid, b2c.data_ptr() + 4 * n_stat, _lib.ptr(qadj), nq,
+                                      None, n, stream), "cgs_mlp2_forward")
+        x_sub = ctx_ops.gather_rows_nograd(x, loc)
+        pred = torch.empty(m, out, dtype=torch.float32, device=x.device)
+        h_sub = torch.empty(m, hid, dtype=torch.float32, device=x.device) if need_grad else None
+        _lib.check(L.cgs_mlp2_forward(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1c), _lib.ptr(b1c), _lib.ptr(W2c),
+                                      _lib.ptr(b2c), _lib.ptr(pred), out, _lib.ptr(h_sub), m, stream), "cgs_mlp2_forward")
+        if need_grad:
+            ctx.save_for_backward(x, x_sub, loc, W1c, b1c, W2c, h_sub)
+        ctx.n_stat = n_stat
+        return qadj, pred
+
+    @staticmethod
+    def backward(ctx, d_q, d_pred):
+        L = _lib.lib()
+        x, x_sub, loc, W1, b1, W2, h_sub = ctx.saved_tensors
+        n_stat = ctx.n_stat
+        n, in_f = x.shape
+        hid, out = W1.shape[0], W2.shape[0]
+        nq, m = out - n_stat, int(loc.shape[0])
+        dev = x.device
+        f32c = lambda t: t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        stream = _lib.current_stream()
+        dW1, db1, dW2, db2 = _zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))   # one fill for the module
+        ws = _wgrad_workspace(dev)
+        dx = None
+        if d_q is not None:
+            dx = torch.empty(n, in_f, dtype=torch.float32, device=dev) if need_dx else None
+            dz1 = torch.empty(n, hid, dtype=torch.float32, device=dev)
+            d_q = f32c(d_q)
+            _lib.check(L.cgs_mlp2_backward(in_f, hid, nq, 0, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(b1),
+                                           W2.data_ptr() + 4 * n_stat * hid, None, _lib.ptr(d_q), nq, None, _lib.ptr(dx), in_f, 0,
+                                           _lib.ptr(dz1), None, _lib.ptr(dW1), _lib.ptr(db1), dW2.data_ptr() + 4 * n_stat * hid,
+                                           db2.data_ptr() + 4 * n_stat, n, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward")
+        if d_pred is not None and m > 0:
+            d_pred = f32c(d_pred)
+            dx_sub = torch.empty(m, in_f, dtype=torch.float32, device=dev) if need_dx else None
+            dz1s = torch.empty(m, hid, dtype=torch.float32, device=dev)
+            _lib.check(L.cgs_mlp2_backward(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1), None, _lib.ptr(W2), None,
+                                           _lib.ptr(d_pred), out, _lib.ptr(h_sub), _lib.ptr(dx_sub), in_f, 0, _lib.ptr(dz1s), None,
+                                           _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(),
+                                           stream), "cgs_mlp2_backward")
+            if need_dx:
+                if dx is None:
+                    dx = torch.zeros(n, in_f, dtype=torch.float32, device=dev)
+                dx.index_add_(0, loc, dx_sub)            # loc rows are unique
+        return dx, None, dW1, db1, dW2, db2, None
+
+
+def level_mlp(x: torch.Tensor, loc: torch.Tensor, seq: nn.Sequential, n_stat: int):
+    """(seq(x)[:, n_stat:], seq(x[loc])) for a supported Sequential(Linear, ReLU, Linear), one autograd node."""
+    l1, l2, act = _describe(seq)
+    in_f, hid, out = l1.in_features, l1.out_features, l2.out_features
+    if act != 0 or (in_f, hid, out, 0) not in _SUPPORTED or (in_f, hid, out - n_stat, 0) not in _SUPPORTED:
+        raise NotImplementedError(f"no fused MLP kernels for {(in_f, hid, out)} split at {n_stat}")
+    return _LevelMLP.apply(x, loc, l1.weight, l1.bias, l2.weight, l2.bias, int(n_stat))
+
+
 def mlp2_weights(x: torch.Tensor, W1, b1, W2, b2, act: int = 0) -> torch.Tensor:
     """Same kernels on explicit weight tensors (e.g. a row slice of the second layer)."""
     key = (W1.shape[1], W1.shape[0], W2.shape[0], act)

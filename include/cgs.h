@@ -325,7 +325,7 @@ int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask,
 int cgs_ctx_choose_compact(const uint8_t *flags, const uint32_t *block_counts,
                            const int64_t *perm, int64_t n, const int64_t *bounds_host,
                            int nlevels, int64_t *nz, int64_t *rows, int64_t *loc,
-                           void *stream);
+                           int32_t *sub_map, const int64_t *chosen_counts_host, void *stream);
 size_t cgs_means_accum_doubles(void);
 int cgs_means_finalize(double *sums3, int64_t na, int64_t nb, int64_t nc, float *out3,
                        void *stream);

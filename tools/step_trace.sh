@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rm -rf /tmp/prof_trace
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -o g -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-codec --no-image-loss --no-raster-only "$@" > gpurun_out/step_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_trace -o g -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-codec --no-image-loss --no-raster-only --no-heavy --no-eval-fps "$@" > gpurun_out/step_trace.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/prof_trace/**/*kernel_trace.csv", recursive=True)[0]

@@ -18,11 +18,11 @@ cams = [c.to_torch("cuda") for c in orbit_cameras(8, 1920, 1080)]
 w = torch.randn(3, 1080, 1920, device="cuda") / (1080 * 1920)
 params = [p for p in pc.parameters() if p.requires_grad]
 for i in range(3):
-    bench.one_step(pc, cams[i], pipe, bg, w, a.step, params, False)
+    bench.one_step(pc, cams[i], pipe, bg, w, a.step, params, None)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=a.stacks) as prof:
     for i in range(4):
-        bench.one_step(pc, cams[i], pipe, bg, w, a.step, params, False)
+        bench.one_step(pc, cams[i], pipe, bg, w, a.step, params, None)
     torch.cuda.synchronize()
 os.makedirs("gpurun_out", exist_ok=True)
 with open("gpurun_out/torch_prof.txt", "w") as f:
