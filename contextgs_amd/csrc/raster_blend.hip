@@ -362,8 +362,9 @@ int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
-    if (blend_rows_enabled() && !getenv("CGS_BWD_ABLATE"))
+    if (blend_rows_enabled() && !getenv("CGS_BWD_ABLATE")) {
         return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
+    }
     static int ablate = -1;     // CGS_BWD_ABLATE=1..3: timing experiments only (wrong results)
     if (ablate < 0) { const char *e = getenv("CGS_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }
 #define BWD_LAUNCH(A)                                                                                               \

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
 }
 
+template <int ABL>      // ABL != 0: timing ablations (WRONG results), see cgs_launch_blend_bwd_rows
 __global__ void __launch_bounds__(RB_THREADS)
     blend_bwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                           const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
@@ -228,36 +229,44 @@ __global__ void __launch_bounds__(RB_THREADS)
                 const uint32_t position = base_pos + (uint32_t)e + 1u;   // 1-based
                 const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
                 const float blue = srec[e * 3 + 2].x;
+                if (ABL == 4) { if (has && r0.x == 12345.f) atomicAdd(&sacc[e][0], r1.x + blue); continue; }
                 const RbEval ev = rb_eval(r0, r1, pxf, pyf);
                 const bool act = has && (position <= my_last) && ev.hit;
                 if (__ballot(act) == 0ull) continue;
+                if (ABL == 3) { if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue); continue; }
+                // Branch-free: a lane whose pixel takes no contribution runs the same updates on alpha = 0, G = 0, for which
+                // every one of them is an exact no-op (T / 1 = T, w = 0, the colour recurrence with alpha = 0 hands on
+                // the value the next contributing step would have computed) — two selects instead of a divergent block,
+                // nine zero-initialisations and the moves that merge its results (the kernel is VALU-issue bound).
+                const float alpha = act ? ev.alpha : 0.f, Gm = act ? ev.g : 0.f;
+                const float om = 1.f - alpha;
+                // 1/(1 - alpha), alpha <= 0.99: v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp) instead of the
+                // IEEE division sequence (10)
+                float inv_om = __builtin_amdgcn_rcpf(om);
+                inv_om = inv_om * fmaf(-om, inv_om, 2.f);
+                T = T * inv_om;
+                const float w = alpha * T;
+                acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);
+                last_cdot = fmaf(r1.z, gr, fmaf(r1.w, gg, blue * gb));
+                float dL_dalpha = (last_cdot - acc_dot) * T;
+                last_alpha = alpha;
+                dL_dalpha = fmaf(neg_bg_T, inv_om, dL_dalpha);
+                const float gG = Gm * dL_dalpha;
+                const float gx = gG * ev.dx, gy = gG * ev.dy;
                 float v[RB_NGRAD];
-#pragma unroll
-                for (int k = 0; k < RB_NGRAD; ++k) v[k] = 0.f;
-                if (act) {
-                    const float om = 1.f - ev.alpha;
-                    // 1/(1 - alpha), alpha <= 0.99: v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp) instead of the
-                    // IEEE division sequence (10): the kernel is VALU-issue bound (profiles/r02_pmc_blend_valu.txt)
-                    float inv_om = __builtin_amdgcn_rcpf(om);
-                    inv_om = inv_om * fmaf(-om, inv_om, 2.f);
-                    T = T * inv_om;
-                    const float w = ev.alpha * T;
-                    acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);
-                    last_cdot = fmaf(r1.z, gr, fmaf(r1.w, gg, blue * gb));
-                    float dL_dalpha = (last_cdot - acc_dot) * T;
-                    last_alpha = ev.alpha;
-                    dL_dalpha = fmaf(neg_bg_T, inv_om, dL_dalpha);
-                    const float gG = ev.g * dL_dalpha;
-                    const float gx = gG * ev.dx, gy = gG * ev.dy;
-                    v[0] = gx;
-                    v[1] = gy;
-                    v[2] = gx * ev.dx;
-                    v[3] = gx * ev.dy;
-                    v[4] = gy * ev.dy;
-                    v[5] = gG;
-                    v[6] = w * gr;
-                    v[7] = w * gg;
-                    v[8] = w * gb;
+                v[0] = gx;
+                v[1] = gy;
+                v[2] = gx * ev.dx;
+                v[3] = gx * ev.dy;
+                v[4] = gy * ev.dy;
+                v[5] = gG;
+                v[6] = w * gr;
+                v[7] = w * gg;
+                v[8] = w * gb;
+                if (ABL == 2) {
+                    const float sm = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
+                    if (sm == 12345.f) atomicAdd(&sacc[e][0], sm);
+                    continue;
                 }
                 // transposing reduction inside each 16-lane row (identical to raster_blend.hip); every row then adds
                 // into the accumulator of ITS OWN Gaussian
@@ -280,10 +289,14 @@ __global__ void __launch_bounds__(RB_THREADS)
                 b2[1] += rb_dpp<0x124>(b2[1]); b2[1] += rb_dpp<0x128>(b2[1]);
                 c8 += rb_dpp<0x124>(c8); c8 += rb_dpp<0x128>(c8);
                 const int sub = lane & 15;
-                if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8));
+                const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
+                if (ABL == 1) { if (has && red == 12345.f) atomicAdd(&sacc[e][sub], red); continue; }
+                if (ABL == 6) { if (has && sub < RB_NGRAD) sacc[e][sub] = red; continue; }
+                if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], red);
             }
         }
         __syncthreads();
+        if (ABL == 5 && tlast != 0x7fffffffu) continue;
         if (pos < tlast) {
             const uint32_t g = sgid[tid];
             const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
@@ -321,10 +334,24 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
                               float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
-    hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
-                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
-                       (const float4 *)g.rec, cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib,
-                       (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
+    static int abl = -1;        // CGS_ROWS_ABL=1..4: timing experiments only (wrong gradients)
+    if (abl < 0) { const char *e = getenv("CGS_ROWS_ABL"); abl = e ? atoi(e) : 0; }
+#define RB_BWD(A)                                                                                                     \
+    hipLaunchKernelGGL(blend_bwd_rows_kernel<A>, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream,              \
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,                             \
+                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, (const float *)im.final_T,      \
+                       (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px,         \
+                       dL_dconic, dL_dopacity, dL_dcolors)
+    switch (abl) {
+        case 1: RB_BWD(1); break;
+        case 2: RB_BWD(2); break;
+        case 3: RB_BWD(3); break;
+        case 4: RB_BWD(4); break;
+        case 5: RB_BWD(5); break;
+        case 6: RB_BWD(6); break;
+        default: RB_BWD(0);
+    }
+#undef RB_BWD
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 }
