@@ -276,9 +276,11 @@ def main():
                         "traffic": traffic.get(dom), "alg_bytes_per_launch": kernels[dom]["alg_bytes"],
                         "avg_launch_us": kernels[dom]["avg_us"],
                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not this run)",
-                        # the kernel's real bound: fraction of the kernel's duration its SIMDs' VALU is issuing
-                        # (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x duration), profiles/r02_pmc_blend_valu.txt)
-                        "valu_frac": valu.get(dom), "valu_frac_source": "profiles/pmc_valu.json (not this run)"}
+                        # what the kernel is actually limited by: VALU instructions x a NOMINAL 4 cycles / (SIMDs x
+                        # duration).  The classes issue at ~2.7 / ~4.7 / ~8.3 cycles, the loop's mix prices at 83 % of
+                        # the SIMD time, LDS float atomics take another ~17 % (profiles/r02_blend_bwd_experiments.txt)
+                        "valu_nominal_frac": valu.get(dom),
+                        "valu_nominal_frac_source": "profiles/pmc_valu.json (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles, not this run)"}
         elif dom and "TFLOPs" in kernels[dom]:
             roofline = {"kernel": dom + " (fused fp32-MFMA MLP family, all launches of a step)", "bound": "mfma",
                         "achieved": kernels[dom]["TFLOPs"], "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -287,7 +289,7 @@ def main():
         # the north star's kernel, always reported
         blend = {n_: {"achieved_GBps": kernels[n_]["GBps"], "frac_of_hbm_peak": round(kernels[n_]["GBps"] / HBM_PEAK_GBS, 4),
                       "alg_bytes": kernels[n_]["alg_bytes"], "avg_us": kernels[n_]["avg_us"],
-                      "pmc_hbm_bytes": traffic.get(n_), "valu_frac": valu.get(n_)}
+                      "pmc_hbm_bytes": traffic.get(n_), "valu_nominal_frac": valu.get(n_)}
                  for n_ in ("blend_fwd", "blend_bwd") if n_ in kernels}
         lib_ms = sum(k["total_ms"] for k in kernels.values()) / max(1, args.steps)
 

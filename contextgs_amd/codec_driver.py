@@ -23,6 +23,7 @@ than 10 000 anchors are valid (:1322-1331); this one decodes any size.
 from __future__ import annotations
 
 import os
+import re
 import time
 
 import numpy as np
@@ -54,10 +55,35 @@ def load_mlp_checkpoints(pc, path):                            # :939-950
     pc.mlp_cov.load_state_dict(ck["cov_mlp"])
     pc.mlp_color.load_state_dict(ck["color_mlp"])
     pc.latent_codec.update()
-    pc.latent_codec.load_state_dict(ck["latent_codec"], strict=False)
+    _load_latent_codec(pc.latent_codec, ck["latent_codec"])
     pc.mlp_grid.load_state_dict(ck["grid_mlp"])
     pc.x_bound_min, pc.x_bound_max = ck["bound"]
     pc.level_scale = ck["level_scale"]
+
+
+_LEGACY_EB_KEY = re.compile(r"^_?(matrix|bias|factor)(\d+)$")
+
+
+def _load_latent_codec(codec, state):
+    """load_state_dict for the hyper prior that refuses a checkpoint without its density parameters.
+
+    strict=False stays (the reference loads that way, :946: buffers such as the quantised CDF tables are rebuilt by
+    update()), but a checkpoint whose density parameters do not land — e.g. one written by a compressai release that
+    names them `_matrix0` / `_bias0` / `_factor0` instead of `matrices.0` ... — would leave the prior at its random
+    initialisation and decode garbage without a word.  Legacy names are remapped; anything still missing raises."""
+    own = set(codec.state_dict().keys())
+    remapped = {}
+    for k, v in state.items():
+        m = _LEGACY_EB_KEY.match(k)
+        if m and k not in own:
+            k = {"matrix": "matrices", "bias": "biases", "factor": "factors"}[m.group(1)] + "." + m.group(2)
+        remapped[k] = v
+    res = codec.load_state_dict(remapped, strict=False)
+    density = [k for k in res.missing_keys if k.split(".")[0] in ("matrices", "biases", "factors", "quantiles")]
+    if density:
+        raise RuntimeError("latent_codec checkpoint lacks the density parameters " + ", ".join(density) +
+                           (f" (unexpected keys: {', '.join(res.unexpected_keys)})" if res.unexpected_keys else ""))
+    return res
 
 
 @torch.no_grad()

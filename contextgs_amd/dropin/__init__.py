@@ -66,8 +66,25 @@ def install(patch_reference_python: bool = True) -> list[str]:
         pass
     rebind("gaussian_renderer", renderer, ["render", "prefilter_voxel", "generate_neural_gaussians"])
     rebind("gaussian_renderer", context_model, ["multi_scale_generating"])
-    rebind("train", renderer, ["render", "prefilter_voxel"])
     # image loss: train.py does `from utils.loss_utils import l1_loss, ssim` (train.py:37)
     rebind("utils.loss_utils", loss_utils, ["l1_loss", "ssim"])
-    rebind("train", loss_utils, ["l1_loss", "ssim"])
+
+    # train.py binds `render`, `prefilter_voxel`, `l1_loss`, `ssim` by name at import time (train.py:36-37).  It is never
+    # imported from here — when it is the running script that would execute its top level a second time as a separate
+    # module and patch only the copy.  Modules that ALREADY hold those names are re-pointed instead: `train` if some
+    # caller imported it, and `__main__` when it is the script.  Called before the script's own imports, install()
+    # needs neither: the names then resolve to the patched modules above.
+
+    def rebind_loaded(modname, src, names):
+        mod = sys.modules.get(modname)
+        if mod is None:
+            return
+        for n in names:
+            if hasattr(src, n) and hasattr(mod, n):
+                setattr(mod, n, getattr(src, n))
+                patched.append(f"{modname}.{n}")
+
+    for script in ("train", "__main__"):
+        rebind_loaded(script, renderer, ["render", "prefilter_voxel"])
+        rebind_loaded(script, loss_utils, ["l1_loss", "ssim"])
     return patched

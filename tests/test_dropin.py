@@ -52,3 +52,52 @@ def test_reference_python_imports_on_top_of_the_shims():
         sys.path.remove("/root/reference")
         for k in [k for k in sys.modules if k.split(".")[0] in ("scene", "utils", "gaussian_renderer", "arguments")]:
             del sys.modules[k]
+
+
+def test_install_repoints_a_loaded_script_without_importing_train():
+    """train.py binds render / l1_loss / ssim by name (train.py:36-37): install() re-points modules that already hold
+    them (`train`, `__main__`) and never imports `train` itself (that would run the script's top level twice)."""
+    import types
+    import contextgs_amd.dropin as dropin
+    from contextgs_amd import loss_utils, renderer
+    sys.modules.pop("train", None)
+    dropin.install()
+    assert "train" not in sys.modules                      # not imported as a side effect
+    fake = types.ModuleType("train")
+    fake.render = fake.prefilter_voxel = fake.l1_loss = fake.ssim = object()
+    fake.unrelated = 1
+    sys.modules["train"] = fake
+    try:
+        patched = dropin.install()
+        assert fake.render is renderer.render and fake.prefilter_voxel is renderer.prefilter_voxel
+        assert fake.l1_loss is loss_utils.l1_loss and fake.ssim is loss_utils.ssim and fake.unrelated == 1
+        assert "train.render" in patched and "train.ssim" in patched
+    finally:
+        del sys.modules["train"]
+        for k in [k for k in sys.modules if k.split(".")[0] in ("scene", "utils", "gaussian_renderer", "arguments")]:
+            del sys.modules[k]
+
+
+def test_latent_codec_checkpoint_must_carry_the_density_parameters():
+    import torch
+    from contextgs_amd.codec_driver import _load_latent_codec
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    src = EntropyBottleneck(12)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    sd = src.state_dict()
+    dst = EntropyBottleneck(12)
+    _load_latent_codec(dst, sd)
+    assert all(torch.equal(a, b) for a, b in zip(src.parameters(), dst.parameters()))
+    # names of older compressai releases are remapped
+    legacy = {}
+    for k, v in sd.items():
+        head, _, idx = k.partition(".")
+        legacy["_" + {"matrices": "matrix", "biases": "bias", "factors": "factor"}[head] + idx if head in ("matrices", "biases", "factors") else k] = v
+    dst = EntropyBottleneck(12)
+    _load_latent_codec(dst, legacy)
+    assert all(torch.equal(a, b) for a, b in zip(src.parameters(), dst.parameters()))
+    # a checkpoint without them is an error, not a silently random prior
+    with pytest.raises(RuntimeError, match="density parameters"):
+        _load_latent_codec(EntropyBottleneck(12), {k: v for k, v in sd.items() if not k.startswith("factors")})
