@@ -187,6 +187,20 @@ def interval_likelihood(matrices, biases, factors, x, half_width, stop_gradient:
     return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
 
 
+# The density's torch statement (cumulative_logits / interval_likelihood) is HOST code by design: update() evaluates it
+# on a few hundred points per channel to build the integer CDF tables of the host rANS coder (what compressai does), and
+# the CPU tests pin it against the reference's own outputs.  It is NOT a fallback of the hot path: a likelihood call on a
+# CPU tensor raises unless a caller (the tests) opts in explicitly.
+ALLOW_HOST_FORWARD = False
+
+
+def _require_device_or_host_opt_in(x, what):
+    if not x.is_cuda and not ALLOW_HOST_FORWARD:
+        raise RuntimeError(f"{what}: the hot path runs on device tensors through libcgs_hip.so; there is no CPU fallback "
+                           "(set contextgs_amd.entropy_bottleneck.ALLOW_HOST_FORWARD to evaluate the host statement of "
+                           "the density on purpose, as the golden tests do)")
+
+
 _unpack_index = {}
 
 
@@ -303,6 +317,7 @@ class EntropyBottleneck(nn.Module):
             return out, _FusedLikelihood.apply(sub, self._packed_params())
         if rows is not None:
             raise NotImplementedError("rows= is only implemented for the fused device path")
+        _require_device_or_host_opt_in(x, "EntropyBottleneck.forward")
         v = x.t().reshape(self.channels, 1, -1)                      # [C,1,N]
         out = self.quantize(v, "noise" if training else "dequantize", self._get_medians())
         lik = _LowerBound.apply(self._likelihood(out), self.likelihood_bound)

@@ -140,6 +140,7 @@ class Entropy_factorized(nn.Module):                         # :67-138
         if x.is_cuda and self.filters == (3, 3, 3, 3) and unit_q:
             lik = eb.fused_likelihood(_c(x), eb.pack_density_params(self._matrices, self._bias, self._factor, self.channel))
         else:
+            eb._require_device_or_host_opt_in(x, "Entropy_factorized.forward")
             half = 0.5 / Q if not isinstance(Q, torch.Tensor) else (0.5 / Q.expand(x.shape)).t().reshape(self.channel, 1, -1)
             v = x.t().reshape(self.channel, 1, -1)
             lik = eb.interval_likelihood(self._matrices, self._bias, self._factor, v, half).reshape(self.channel, -1).t()

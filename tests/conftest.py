@@ -24,3 +24,13 @@ def oracle64():
     from oracle.raster_oracle import RasterOracle
     import numpy as np
     return RasterOracle(np.float64)
+
+
+@pytest.fixture
+def host_density():
+    """Opt in to the HOST statement of the factorised density on CPU tensors (table-building code that the CPU tests pin
+    against the reference's outputs); without it a likelihood call on a CPU tensor raises (no CPU fallback)."""
+    from contextgs_amd import entropy_bottleneck as eb
+    eb.ALLOW_HOST_FORWARD = True
+    yield
+    eb.ALLOW_HOST_FORWARD = False

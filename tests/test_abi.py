@@ -58,3 +58,16 @@ def test_operators_refuse_cpu_tensors():
         Quantize_anchor.apply(x, torch.zeros(1, 3), torch.ones(1, 3))
     with pytest.raises(RuntimeError):
         Entropy_gaussian()(x, x, x.abs() + 1, torch.ones(4, 1), torch.tensor(0.0))
+
+
+def test_hyper_prior_likelihood_refuses_cpu_tensors():
+    """EntropyBottleneck / Entropy_factorized on a CPU tensor: no silent torch fallback of the hot path."""
+    import pytest
+    import torch
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    from contextgs_amd.entropy_models import Entropy_factorized
+    x = torch.zeros(5, 12)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        EntropyBottleneck(12)(x, training=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Entropy_factorized(channel=12, filters=(3, 3, 3, 3))(x)

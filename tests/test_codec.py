@@ -102,7 +102,7 @@ def test_rans_matches_oracle_and_roundtrips_with_escapes():
     assert np.array_equal(back, sym)
 
 
-def test_entropy_bottleneck_density_and_codec():
+def test_entropy_bottleneck_density_and_codec(host_density):
     from contextgs_amd.entropy_bottleneck import EntropyBottleneck, pmf_to_quantized_cdf
     torch.manual_seed(3)
     eb = EntropyBottleneck(12)

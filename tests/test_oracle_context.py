@@ -238,7 +238,7 @@ def test_entropy_api_goldens():
         assert np.abs(-np.log2(np.maximum(lik, 1e-6)) - g[f"fz{seed}_bits"]).max() <= 1e-3
 
 
-def test_host_density_classes_match_reference():
+def test_host_density_classes_match_reference(host_density):
     """The torch statement of the factorised density (entropy_bottleneck.cumulative_logits, shared by
     EntropyBottleneck and utils.entropy_models.Entropy_factorized) against the reference's `_logits_cumulative`
     outputs and autograd gradients — on CPU tensors: this is host code, no kernel involved."""

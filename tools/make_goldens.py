@@ -34,7 +34,9 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 # ---------------------------------------------------------------- harness -----
 def install_stubs():
+    from contextgs_amd import entropy_bottleneck as _eb
     from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    _eb.ALLOW_HOST_FORWARD = True       # the reference runs on CPU here: the host statement of the density, on purpose
 
     def mod(name, **attrs):
         m = types.ModuleType(name)
