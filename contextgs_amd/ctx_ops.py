@@ -476,7 +476,7 @@ class _CtxAssemble(torch.autograd.Function):
                                                          _lib.ptr(prow), _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s),
                                                          wa, DF, DS, _lib.current_stream()), "cgs_ctx_gather_bwd")
             if need[3]:
-                d_own = g[:, wa + DF + DS:].contiguous()
+                d_own = g[:, wa + DF + DS:]          # a column slice: its consumer (the split's cat) takes strided rows
         else:
             d_f = None if d_f is None else d_f.zero_()
             d_s = None if d_s is None else d_s.zero_()

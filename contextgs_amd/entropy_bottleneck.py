@@ -71,70 +71,62 @@ class _FusedLikelihood(torch.autograd.Function):
         return g_v, g_p
 
 
-class _HyperNoiseGather(torch.autograd.Function):
-    """x [N,C] -> (x + U(-1/2,1/2))[perm] in ONE launch (cgs_hyper_noise_gather): the training quantisation of the
-    bottleneck, delivered in the context model's coding order.  The noise is the build's counter-based generator
-    keyed by (seed, ORIGINAL row, channel) — the reference draws torch's uniform_; same distribution."""
-
-    @staticmethod
-    def forward(ctx, x, perm, inv_perm, seed):
-        from . import _lib
-        x = x.contiguous()
-        _lib.require_device(x)
-        out = torch.empty_like(x)
-        _lib.check(_lib.lib().cgs_hyper_noise_gather(_lib.ptr(x), _lib.ptr(perm), x.shape[0], x.shape[1], int(seed),
-                                                     _lib.ptr(out), _lib.current_stream()), "cgs_hyper_noise_gather")
-        ctx.inv_perm = inv_perm
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        if ctx.inv_perm is None:
-            return g, None, None, None
-        # rows of 48 bytes: torch's index_select takes its slow "vectorized gather" path for 16-byte-multiple rows
-        # (210 us for [1 M, 12] on gfx950); the one-source rowcat kernel does the same gather in ~35 us
-        from . import ctx_ops
-        return ctx_ops.gather_rows_nograd(g, ctx.inv_perm), None, None, None
-
-
 _bits_ws = {}
 
 
-class _FusedBitsSum(torch.autograd.Function):
-    """sum over rows `rows` (coding-order positions) and channels of -log2(likelihood(v)) as a [1] tensor, one launch
-    each way (cgs_eb_bits_*): what the rate model reads of the hyper prior (scene/gaussian_model.py:1662, 1689)."""
+class _HyperStep(torch.autograd.Function):
+    """The hyper prior of one training step as ONE node: x [N,C] -> (noisy latents in coding order [N,C], summed bits
+    of the rows `rows_pos` [1]) — cgs_hyper_noise_gather (x + U(-1/2,1/2) from the build's counter-based generator keyed by (seed, ORIGINAL row,
+    channel), delivered in coding order) followed by cgs_eb_bits_* (scene/gaussian_model.py:1662, 1689), with the two gradient paths of the
+    noisy latents (dense from the level inputs, ~15 % of the rows from the bit sum) merged here: the subset's rows are
+    added into the dense gradient in place (index_add_ on distinct rows) instead of being scattered into an [N,C] zero
+    buffer that autograd then adds in full."""
 
     @staticmethod
-    def forward(ctx, v, rows, packed):
+    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed):
         from . import _lib
         L = _lib.lib()
-        v, packed = v.contiguous(), packed.contiguous()
-        ws = _bits_ws.get(v.device)
+        x, packed = x.contiguous(), packed.contiguous()
+        _lib.require_device(x, packed)
+        N, C = x.shape
+        stream = _lib.current_stream()
+        v = torch.empty_like(x)
+        _lib.check(L.cgs_hyper_noise_gather(_lib.ptr(x), _lib.ptr(perm), N, C, int(seed), _lib.ptr(v), stream),
+                   "cgs_hyper_noise_gather")
+        ws = _bits_ws.get(x.device)
         if ws is None:
-            ws = _bits_ws[v.device] = torch.zeros(int(L.cgs_eb_bits_scratch_bytes()), dtype=torch.uint8, device=v.device)
-        out = torch.empty(1, dtype=torch.float32, device=v.device)
-        n = int(rows.shape[0]) if rows is not None else int(v.shape[0])
-        _lib.check(L.cgs_eb_bits_fwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), n, v.shape[1], _lib.ptr(ws), ws.numel(),
-                                     _lib.ptr(out), _lib.current_stream()), "cgs_eb_bits_fwd")
-        ctx.save_for_backward(v, rows, packed)
+            ws = _bits_ws[x.device] = torch.zeros(int(L.cgs_eb_bits_scratch_bytes()), dtype=torch.uint8, device=x.device)
+        bits = torch.empty(1, dtype=torch.float32, device=x.device)
+        n = int(rows_pos.shape[0]) if rows_pos is not None else N
+        _lib.check(L.cgs_eb_bits_fwd(_lib.ptr(v), _lib.ptr(rows_pos), _lib.ptr(packed), n, C, _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(bits), stream), "cgs_eb_bits_fwd")
+        ctx.save_for_backward(v, rows_pos, packed, inv_perm)
         ctx.n = n
-        return out
+        return v, bits
 
     @staticmethod
-    def backward(ctx, g):
-        from . import _lib
-        v, rows, packed = ctx.saved_tensors
+    def backward(ctx, g_v, g_bits):
+        from . import _lib, ctx_ops
+        v, rows, packed, inv_perm = ctx.saved_tensors
         n, C = ctx.n, v.shape[1]
-        g = g.contiguous()
-        g_sub = torch.empty(n, C, dtype=torch.float32, device=v.device)
-        g_p = torch.zeros_like(packed)
-        _lib.check(_lib.lib().cgs_eb_bits_bwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), _lib.ptr(g), n, C,
-                                              _lib.ptr(g_sub), _lib.ptr(g_p), _lib.current_stream()), "cgs_eb_bits_bwd")
-        if rows is None:
-            return g_sub, None, g_p
-        g_v = torch.zeros_like(v)
-        g_v.index_copy_(0, rows, g_sub)
-        return g_v, None, g_p
+        g_p = None
+        if g_bits is not None:
+            g_sub = torch.empty(n, C, dtype=torch.float32, device=v.device)
+            g_p = torch.zeros_like(packed)
+            _lib.check(_lib.lib().cgs_eb_bits_bwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), _lib.ptr(g_bits.contiguous()),
+                                                  n, C, _lib.ptr(g_sub), _lib.ptr(g_p), _lib.current_stream()),
+                       "cgs_eb_bits_bwd")
+            if rows is None:
+                g_v = g_sub if g_v is None else g_v + g_sub
+            else:
+                g_v = torch.zeros_like(v) if g_v is None else (g_v if g_v.is_contiguous() else g_v.contiguous())
+                g_v.index_add_(0, rows, g_sub)
+        if g_v is None:
+            return None, None, None, None, g_p, None
+        # rows of 48 bytes: torch's index_select takes its slow "vectorized gather" path for 16-byte-multiple rows
+        # (210 us for [1 M, 12] on gfx950); the one-source rowcat kernel does the same gather in ~35 us
+        g_x = g_v if inv_perm is None else ctx_ops.gather_rows_nograd(g_v, inv_perm)
+        return g_x, None, None, None, g_p, None
 
 
 class HyperBitSum:
@@ -329,9 +321,9 @@ class EntropyBottleneck(nn.Module):
         positions rows_pos) — forward(x, training=True) restricted to what scene/gaussian_model.py:1556-1707 consumes,
         in two launches.  perm / inv_perm: the coding-order permutation and its inverse (None: identity)."""
         assert x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 2 and x.shape[1] == self.channels
-        v_p = _HyperNoiseGather.apply(x, perm, inv_perm, seed)
+        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params(), seed)
         n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
-        return v_p, HyperBitSum(_FusedBitsSum.apply(v_p, rows_pos, self._packed_params()), n_rows * self.channels)
+        return v_p, HyperBitSum(bits, n_rows * self.channels)
 
     def _packed_params(self) -> torch.Tensor:
         """[C, 58] raw parameters in the order csrc/eb.hip expects (differentiable cat)."""

@@ -259,11 +259,13 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
 def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):   # :232-287
     """Anchor-level frustum/size cull: bool[N]."""
     rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier))
-    means3D = pc.get_anchor
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
     with torch.no_grad():
-        radii_pure = rasterizer.visible_filter(means3D=means3D, scales=scales[:, :3],
-                                               rotations=rotations[[0], :].repeat(means3D.shape[0], 1),
-                                               cov3D_precomp=None)
+        means3D = pc.get_anchor
+        # The reference evaluates get_scaling / get_rotation on all N rows and then reads three scale columns and
+        # rotation row 0 (:262-266, :283: `rotations[[0], :].repeat(N, 1)`).  Both activations are row / element-wise,
+        # so applying them to exactly what is read gives the same values: exp of 3 columns, normalisation of one row.
+        scales3 = pc._scaling[:, :3] if pc.decoded_version else torch.exp(pc._scaling[:, :3])
+        rot0 = pc.rotation_activation(pc._rotation[:1])
+        radii_pure = rasterizer.visible_filter(means3D=means3D, scales=scales3,
+                                               rotations=rot0.repeat(means3D.shape[0], 1), cov3D_precomp=None)
     return radii_pure > 0
