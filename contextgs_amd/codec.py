@@ -149,7 +149,18 @@ def _f(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
-def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1):
+_STAGE = None
+
+
+def _pinned_staging(nbytes: int) -> torch.Tensor:
+    """A grow-only pinned host buffer for bitstream downloads (allocating pinned memory costs milliseconds per call)."""
+    global _STAGE
+    if _STAGE is None or _STAGE.numel() < nbytes:
+        _STAGE = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+    return _STAGE
+
+
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
     (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
     blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
@@ -192,8 +203,17 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1):
     packed = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device=dev)
     _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
                                      _lib.ptr(packed), stream), "cgs_streams_compact")
-    blob = packed.cpu().numpy()[: int(lens.sum())]
-    mnmx_h = mnmx.cpu().numpy()
+    nbytes = int(lens.sum())
+    if staging and nbytes > 0:
+        # pinned, reused staging buffer: ~25 GB/s instead of a pageable copy (~5 GB/s, 25 ms for a 1 M-anchor model).
+        # The returned blob ALIASES it: valid until the next staging call (the container driver writes the files first).
+        stage = _pinned_staging(nbytes)
+        stage[:nbytes].copy_(packed[:nbytes], non_blocking=True)
+        mnmx_h = mnmx.cpu().numpy()                   # synchronises the stream: the staged bytes are complete too
+        blob = stage.numpy()[:nbytes]
+    else:
+        blob = packed.cpu().numpy()[:nbytes]
+        mnmx_h = mnmx.cpu().numpy()
     return blob, lens, mnmx_h[0], mnmx_h[1]
 
 
@@ -210,8 +230,9 @@ def _expand_q(Q, q_div):
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
 
 
-def gaussian_encode_groups(groups):
+def gaussian_encode_groups(groups, staging=False):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
+    staging: download through the module's reused pinned buffer; the blobs then alias it until the next staging call.
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
     lasts as long as its longest stream however many streams it holds."""
     groups = list(groups)
@@ -243,7 +264,7 @@ def gaussian_encode_groups(groups):
             return None
         blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
     else:
-        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1)
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging)
     out, s0, b0 = [], 0, 0
     for c in counts:
         nb = int(lens[s0:s0 + c].sum())

@@ -137,8 +137,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
         mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
         # hyper: 10 000-anchor rANS chunks (:1082-1098), also on host threads
-        hyper_bytes = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10)
-        bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
+        hyper_jobs = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10, lazy=True)
 
     # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
     hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
@@ -149,10 +148,10 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
+    writes = []                       # file writes run on host threads while the device predicts / codes
     if root:
-        np.save(path("anchor.npy"), quantized_anchor.cpu().numpy().astype(np.uint16))      # :1100-1101
-        with open(path("hyper.b"), "wb") as f:
-            f.write(b"".join(hyper_bytes))
+        anchor_u16 = quantized_anchor.cpu().numpy().astype(np.uint16)                       # :1100-1101
+        writes.append(codec.host_pool().submit(np.save, path("anchor.npy"), anchor_u16))
 
     N_levels_list, groups, tags = [], [], []
     content_pre_gathered = None
@@ -191,7 +190,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
                                                         inverse_indices_list, mapping_list, level)
 
     torch.cuda.synchronize(); t0 = time.time()
-    coded = codec.gaussian_encode_groups(groups)
+    coded = codec.gaussian_encode_groups(groups, staging=True)        # blobs alias a pinned buffer: written below
     torch.cuda.synchronize(); t_codec = time.time() - t0
     if not root:
         return mgpu.broadcast_object(None)            # the summary string of rank 0
@@ -200,11 +199,15 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     min_d = {"feat": {}, "scaling": {}, "offsets": {}}
     max_d = {"feat": {}, "scaling": {}, "offsets": {}}
     for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
-        blob.tofile(path(f"{name}{level}.b"))                                            # :1235-1238
+        writes.append(codec.host_pool().submit(blob.tofile, path(f"{name}{level}.b")))   # :1235-1238
         bit_d[name][level] = (lens * 8).tolist()
         min_d[name][level] = mn.astype(np.int64).tolist()
         max_d[name][level] = mx.astype(np.int64).tolist()
 
+    hyper_bytes = [j.result() for j in hyper_jobs]                                       # :1082-1098
+    bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
+    with open(path("hyper.b"), "wb") as f:
+        f.write(b"".join(hyper_bytes))
     bit_anchor = _anchor.numel() * 16
     bit_hyper = sum(bit_hyper_list)
     bit_feat = sum(sum(v) for v in bit_d["feat"].values())
@@ -215,6 +218,8 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     with open(path("masks.b"), "wb") as f:
         f.write(mask_bytes)
     bit_masks = len(mask_bytes) * 8
+    for w in writes:
+        w.result()                    # every file is on disk before the encoder reports (and raises here if one failed)
 
     torch.cuda.synchronize(); t2 = time.time()
     print("encoding time:", t2 - t1)

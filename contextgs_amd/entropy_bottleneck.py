@@ -390,8 +390,9 @@ class EntropyBottleneck(nn.Module):
     # so the chunk forms below quantise / dequantise ONCE on the device and run the strings concurrently on host
     # threads (the ctypes calls into libcgs release the GIL).  Byte-identical to a loop of compress()/decompress().
     @torch.no_grad()
-    def compress_chunks(self, x: torch.Tensor, chunk: int) -> list[bytes]:
-        """x [C, N] -> [compress(x[None, :, s:s+chunk])[0] for s in range(0, N, chunk)]."""
+    def compress_chunks(self, x: torch.Tensor, chunk: int, lazy: bool = False) -> list[bytes]:
+        """x [C, N] -> [compress(x[None, :, s:s+chunk])[0] for s in range(0, N, chunk)].
+        lazy: return the host-thread futures instead of waiting for them (the caller keeps the device busy meanwhile)."""
         from . import codec
         assert x.dim() == 2 and x.shape[0] == self.channels
         if self._offset.numel() == 0:
@@ -400,7 +401,7 @@ class EntropyBottleneck(nn.Module):
         tabs = (self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy())
         jobs = [codec.host_pool().submit(codec.rans_encode_channels, sym[:, s:s + chunk], *tabs, self.precision)
                 for s in range(0, sym.shape[1], chunk)]
-        return [j.result() for j in jobs]
+        return jobs if lazy else [j.result() for j in jobs]
 
     @torch.no_grad()
     def decompress_chunks(self, strings: list[bytes], sizes: list[int]) -> torch.Tensor:
