@@ -134,6 +134,8 @@ SIGNATURES = {
                                      c_size_t, C.POINTER(c_size_t)]),
     "cgs_rans_decode_host": (c_int, [c_void_p, c_size_t, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p]),
+    "cgs_rans_decode_rows_host": (c_int, [c_void_p, c_size_t, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_int64]),
     "cgs_prof_enable": (c_int, [c_int]),
     "cgs_prof_count": (c_int, []),
     "cgs_prof_name": (C.c_char_p, [c_int]),

@@ -351,30 +351,49 @@ class StagedFiles:
         self.device = device
         self.dev_buf = torch.empty(pos + 64, dtype=torch.uint8, device=device)
         self.stream = torch.cuda.Stream(device=device)
-        self.event = torch.cuda.Event()
+        import threading
+        self.ready = {p_: threading.Event() for p_ in self.names}     # host side: the file's copy has been enqueued
+        self.events = {}                                              # device side: the file's bytes have arrived
+        self.error = None
         self._job = host_pool().submit(self._run)
 
     def _run(self):
-        key = (self.device.index if isinstance(self.device, torch.device) else 0)
-        pinned = _PINNED.get(key)
-        if pinned is None or pinned.numel() < self.total + 64:
-            pinned = _PINNED[key] = torch.empty(max(self.total + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        view = pinned.numpy()
-        for p_ in self.names:
-            pos, n = self.off[p_]
-            if n:
-                with open(p_, "rb", buffering=0) as f:
-                    got = f.readinto(memoryview(view[pos:pos + n]))
-                    assert got == n, (p_, got, n)
-        with torch.cuda.stream(self.stream):
-            self.dev_buf[: self.total].copy_(pinned[: self.total], non_blocking=True)
-            self.event.record(self.stream)
-        self.event.synchronize()          # the pinned buffer is reused by the next container: keep it until the copy is done
+        try:
+            key = (self.device.index if isinstance(self.device, torch.device) else 0)
+            pinned = _PINNED.get(key)
+            if pinned is None or pinned.numel() < self.total + 64:
+                pinned = _PINNED[key] = torch.empty(max(self.total + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            view = pinned.numpy()
+            last = None
+            # file by file, in the order the coder launches consume them: the small coarse-level files are on the device
+            # after a millisecond, the 100 MB of the finest level arrive while the first launches run
+            for p_ in self.names:
+                pos, n = self.off[p_]
+                if n:
+                    with open(p_, "rb", buffering=0) as f:
+                        got = f.readinto(memoryview(view[pos:pos + n]))
+                        assert got == n, (p_, got, n)
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(self.stream):
+                    if n:
+                        self.dev_buf[pos:pos + n].copy_(pinned[pos:pos + n], non_blocking=True)
+                    ev.record(self.stream)
+                self.events[p_] = last = ev
+                self.ready[p_].set()
+            if last is not None:
+                last.synchronize()    # the pinned buffer is reused by the next container: keep it until the copies are done
+        except BaseException as e:    # wake the waiters, get() re-raises
+            self.error = e
+            for r in self.ready.values():
+                r.set()
+            raise
         return True
 
     def get(self, name):
-        self._job.result()
-        torch.cuda.current_stream().wait_event(self.event)
+        self.ready[name].wait()
+        if self.error is not None:
+            raise self.error
+        torch.cuda.current_stream().wait_event(self.events[name])
         pos, n = self.off[name]
         return self.dev_buf[pos:pos + n]
 

@@ -113,9 +113,25 @@ def _predict(pc, level, feat_in):
             Qo.reshape(-1).contiguous())
 
 
+def _tracer(name):
+    """CGS_CODEC_TRACE=1: wall-clock milestones of the container driver on stderr (host time, no extra synchronisation)."""
+    if not os.environ.get("CGS_CODEC_TRACE"):
+        return lambda label: None
+    import sys
+    sync = os.environ.get("CGS_CODEC_TRACE") == "2"       # 2: drain the device at every milestone (attributes device time)
+    t0 = time.perf_counter()
+
+    def mark(label):
+        if sync:
+            torch.cuda.synchronize()
+        print(f"[{name} +{(time.perf_counter() - t0) * 1e3:7.1f} ms] {label}", file=sys.stderr)
+    return mark
+
+
 @torch.no_grad()
 def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     torch.cuda.synchronize(); t1 = time.time()
+    tr = _tracer("encode")
     print("Start encoding ...")
     root = mgpu.rank() == 0          # multi-GPU: every rank predicts/quantises, codes its block of streams; rank 0 writes
     os.makedirs(pre_path_name, exist_ok=True)
@@ -123,6 +139,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     K, D = pc.n_offsets, pc.feat_dim
     path = lambda name: os.path.join(pre_path_name, name)
 
+    tr("tables updated")
     mask_anchor = pc.get_mask_anchor
     _anchor, quantized_anchor = Quantize_anchor.apply(pc._anchor[mask_anchor], pc.x_bound_min, pc.x_bound_max)
     _feat = pc._anchor_feat[mask_anchor]
@@ -131,13 +148,17 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     _mask = pc.get_mask[mask_anchor]
     _hyper_latent = pc._hyper_latent[mask_anchor]
 
+    tr("valid anchors gathered")
     # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream: start it on a host thread now
     prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
     if root:
         mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+        tr("mask symbols on the host")
         mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
-        # hyper: 10 000-anchor rANS chunks (:1082-1098), also on host threads
-        hyper_jobs = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10, lazy=True)
+        # hyper: 10 000-anchor rANS chunks (:1082-1098), on host threads too — but submitted only AFTER the level loop
+        # has been enqueued: ~100 short jobs finishing on the pool make the main thread queue for the GIL, which
+        # stretched the 7 ms of launch code below to 38 ms when they ran beside it
+        hyper_jobs = None
 
     # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
     hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
@@ -145,6 +166,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         pc.level_scale = find_divide_scale(pc, _anchor, pc.target_ratio, pc.level_num)
     plan, inverse_indices_list, mapping_list = level_plan(pc, _anchor, None)
 
+    tr("level plan built")
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
@@ -164,23 +186,28 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
             feat_in = torch.cat([content_pre_gathered, hyper_feat[orig].float()], dim=1)
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
+        tr(f"level {level}: predicted (enqueued)")
         rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
 
+        tr(f"level {level}: chunk rows")
         feat_q = STE_multistep.apply(_feat[orig], Qf.unsqueeze(1))
         scal_q = STE_multistep.apply(_scaling[orig], Qs.unsqueeze(1))
         off_q = STE_multistep.apply(_grid_offsets[orig].reshape(n_l, 3 * K), Qo.unsqueeze(1))
+        tr(f"level {level}: quantised")
         m30 = _mask[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)              # :1222-1223
         cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=m30.device)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         off_edges = cnt[rows.to(cnt.device)].cpu()
-        mflat = m30.reshape(-1)
-        Qo30 = Qo.unsqueeze(1).expand(n_l, 3 * K).reshape(-1)
+        tr(f"level {level}: offset stream edges on the host")
+        live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the four operands
+        pick = lambda t: t.reshape(-1).index_select(0, live)
 
         groups += [(feat_q, mean_feat, scale_feat, Qf, rows * D, D),
                    (scal_q, mean_scaling, scale_scaling, Qs, rows * 6, 6),
-                   (off_q.reshape(-1)[mflat], mean_offsets.reshape(-1)[mflat], scale_offsets.reshape(-1)[mflat],
-                    Qo30[mflat], off_edges, 1)]
+                   (pick(off_q), pick(mean_offsets), pick(scale_offsets), Qo.index_select(0, live // (3 * K)),
+                    off_edges, 1)]
         tags += [("feat", level), ("scaling", level), ("offsets", level)]
+        tr(f"level {level}: groups built")
 
         feat_after_Q[orig] = feat_q                                                      # :1240-1242
         grid_scaling_after_Q[orig] = scal_q
@@ -188,10 +215,17 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         if level != 0:
             content_pre_gathered = extract_context_feat(_anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
                                                         inverse_indices_list, mapping_list, level)
+            tr(f"level {level}: context of the next level gathered")
 
+    tr("levels enqueued")
+    if root:
+        hyper_jobs = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10, lazy=True)
+        tr("hyper symbols on the host, rANS jobs submitted")
     torch.cuda.synchronize(); t0 = time.time()
+    tr("levels done on the device")
     coded = codec.gaussian_encode_groups(groups, staging=True)        # blobs alias a pinned buffer: written below
     torch.cuda.synchronize(); t_codec = time.time() - t0
+    tr("coder launch done, bitstream on the host")
     if not root:
         return mgpu.broadcast_object(None)            # the summary string of rank 0
 
@@ -204,7 +238,9 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         min_d[name][level] = mn.astype(np.int64).tolist()
         max_d[name][level] = mx.astype(np.int64).tolist()
 
+    tr("file writes submitted")
     hyper_bytes = [j.result() for j in hyper_jobs]                                       # :1082-1098
+    tr("hyper rANS jobs done")
     bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
     with open(path("hyper.b"), "wb") as f:
         f.write(b"".join(hyper_bytes))
@@ -215,11 +251,13 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     bit_offsets = sum(sum(v) for v in bit_d["offsets"].values())
 
     mask_bytes = mask_job.result()
+    tr("mask stream done")
     with open(path("masks.b"), "wb") as f:
         f.write(mask_bytes)
     bit_masks = len(mask_bytes) * 8
     for w in writes:
         w.result()                    # every file is on disk before the encoder reports (and raises here if one failed)
+    tr("files written")
 
     torch.cuda.synchronize(); t2 = time.time()
     print("encoding time:", t2 - t1)
@@ -243,19 +281,24 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
 @torch.no_grad()
 def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     torch.cuda.synchronize(); t1 = time.time()
+    tr = _tracer("decode")
     print("Start decoding ...")
     path = lambda name: os.path.join(pre_path_name, name)
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
      bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(path("meta.b"),
                                                                                           weights_only=False)
+    tr("meta.b loaded")
     K, D, H = pc.n_offsets, pc.feat_dim, pc.feat_dim // pc.hyper_divisor
     N_levels_list = list(reversed(N_levels_list))
     N_valid = sum(N_levels_list)
     # the mask stream (:1348-1353) is serial and only the offsets need it: decode it on a host thread meanwhile
     mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
                                         N_valid * K, float(prob_masks))
+    tr("mask job submitted")
     load_mlp_checkpoints(pc, path("mlp.pt"))
+    tr("mlp.pt loaded")
     pc.latent_codec.update(force=True)
+    tr("prior tables rebuilt")
     dev = pc.x_bound_min.device
     # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
     # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
@@ -264,6 +307,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             [f"offsets{l}.b" for l in reversed(range(n_lv))]
     staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
 
+    tr("file staging started")
     with open(path("hyper.b"), "rb") as f:
         hyper_stream = f.read()
     pos, strings, sizes = 0, [], []
@@ -272,15 +316,22 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         strings.append(hyper_stream[pos:pos + nb])
         sizes.append(min(max_batch * 10, N_valid - s0))
         pos += nb
-    hyper_decoded = pc.latent_codec.decompress_chunks(strings, sizes).t().contiguous()   # [N_valid, H]
+    tr("meta / tables / staging started")
+    # the hyper strings are decoded by host threads (straight into a pinned [N_valid, H] buffer) while this thread
+    # loads the anchors and builds the level plan, which need nothing but anchor.npy
+    hyper_job = pc.latent_codec.decompress_chunks_rows(strings, sizes)
 
     q = torch.from_numpy(np.load(path("anchor.npy")).astype(np.int32)).to(dev)           # :1340-1342
     interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
     anchor_decoded = q * interval + pc.x_bound_min
 
+    tr("anchors on the device")
     if pc.level_scale is None:
         pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
     plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
+    tr("level plan built")
+    hyper_decoded = hyper_job()                                                          # [N_valid, H]
+    tr("hyper latents decoded (host rANS) and on the device")
 
     feat_after_Q = torch.zeros(N_valid, D, device=dev)
     grid_scaling_after_Q = torch.zeros(N_valid, 6, device=dev)
@@ -294,11 +345,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         assert int(lens.sum()) == int(blob.numel())                                      # :1479-1481
         return blob, lens
 
-    # Coder launches last as long as their LONGEST stream (a 1000-anchor feature chunk: 50 000 serial symbols) however
+    # Coder launches last as long as their LONGEST stream (a 10 000-anchor feature chunk: 500 000 serial symbols) however
     # many streams they hold, so the fewer the better: one per level for features + scaling — the offsets of a level
-    # need nothing but that level's prediction and the masks, so ALL of them ride along with the last level's launch
-    # (the host thread decoding the mask stream has had the earlier launches to finish): 3 launches for 3 levels.
+    # need nothing but that level's prediction and the masks, so ALL of them go into ONE more launch, beside the last
+    # level's (see below): 3 serial launches for 3 levels.
     pending_offsets, masks_decoded = [], None
+    side_stream = torch.cuda.Stream(device=dev)
 
     def offset_groups():
         groups, fills = [], []
@@ -307,12 +359,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
             cnt[1:] = torch.cumsum(m30.sum(1), 0)
             off_edges = cnt[rows_.to(dev)].cpu()
-            mflat = m30.reshape(-1)
-            Qo30 = Qo_.unsqueeze(1).expand(n_, 3 * K).reshape(-1)
-            groups.append((mean_o.reshape(-1)[mflat], scale_o.reshape(-1)[mflat], Qo30[mflat], off_edges,
+            live = torch.nonzero(m30.reshape(-1))[:, 0]          # ONE compaction index for the three operands and the fill
+            groups.append((mean_o.reshape(-1).index_select(0, live), scale_o.reshape(-1).index_select(0, live),
+                           Qo_.index_select(0, live // (3 * K)), off_edges,
                            min_offsets_d[level_], max_offsets_d[level_],
                            *chunk_lens("offsets", level_, bit_offsets_d[level_]), 1))
-            fills.append((orig_, n_, mflat))
+            fills.append((orig_, n_, live))
         return groups, fills
 
     last_level = plan[-1][0] if plan else None
@@ -325,23 +377,36 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             feat_in = torch.cat([content_pre_gathered, hyper_decoded[orig]], dim=1)
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
+        tr(f"level {level}: predicted (enqueued)")
         rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
         pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
         groups = [(mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
                    *chunk_lens("feat", level, bit_feat_d[level]), D),
                   (mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level], max_scaling_d[level],
                    *chunk_lens("scaling", level, bit_scaling_d[level]), 6)]
-        fills = []
         if level == last_level:
-            masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
-            og, fills = offset_groups()
-            groups += og
+            fork = torch.cuda.current_stream().record_event()       # everything the offsets need exists before this point
         decoded = codec.gaussian_decode_groups(groups)
+        tr(f"level {level}: coder launch enqueued")
         feat_dec, scal_dec = decoded[0], decoded[1]
-        for (orig_, n_, mflat), off_vals in zip(fills, decoded[2:]):
-            off_dec = torch.zeros(n_ * 3 * K, device=dev)
-            off_dec[mflat] = off_vals
-            grid_offset_after_Q[orig_] = off_dec.view(n_, K, 3)
+        if level == last_level:
+            # The offsets of ALL levels as their own launch on a side stream, forked BEFORE the last feature launch:
+            # they need the mask stream (a serial host job of ~70 ms that ends about now), the features do not, and a
+            # coder launch keeps few SIMDs busy (one wave per stream), so the two launches run side by side instead of
+            # the last one waiting for the masks.
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(side_stream):
+                side_stream.wait_event(fork)
+                tr("waiting for the mask stream")
+                masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
+                tr("mask stream decoded")
+                og, fills = offset_groups()
+                for (orig_, n_, live), off_vals in zip(fills, codec.gaussian_decode_groups(og)):
+                    off_dec = torch.zeros(n_ * 3 * K, device=dev)
+                    off_dec.index_copy_(0, live, off_vals)
+                    grid_offset_after_Q[orig_] = off_dec.view(n_, K, 3)
+                tr("offsets launch enqueued")
+            main.wait_stream(side_stream)
 
         feat_after_Q[orig] = feat_dec.view(n_l, D)
         grid_scaling_after_Q[orig] = scal_dec.view(n_l, 6)
@@ -351,7 +416,9 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
                                                         inverse_indices_list, mapping_list, level)
     if masks_decoded is None:                    # no level at all (empty model)
         masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
+    tr("levels enqueued")
     torch.cuda.synchronize(); t2 = time.time()
+    tr("device done")
     print("decoding time:", t2 - t1)
 
     z = lambda *s: torch.zeros(*s, device=dev)                                            # :1503-1533

@@ -284,9 +284,102 @@ extern "C" int cgs_ac_decode_table_host(const uint16_t *cdf, int Lp, int64_t n_s
 
 // Constant-CDF stream (the Bernoulli mask stream, utils/encodings.py:147-180): every symbol
 // shares one row, so no [n,3] table is materialised.
+// Two-symbol constant row, encoder side: the mask stream is ONE serial stream of N*K symbols (10 M at 1 M anchors) and
+// the longest single job of conduct_encoding AND conduct_decoding (76 / 69 ms at 1 M anchors when this was written), so
+// both directions get their own loops, written for the latency of the serial chain low/high -> span -> product ->
+// renormalisation:
+//   * one multiplication per symbol (symbol 1 keeps `high`, symbol 0 keeps `low`: c_high = 2^16 gives back the old high);
+//   * no data-dependent branch on the output side: the settled bits, preceded by the pending run when there is one, are
+//     assembled as ONE word of <= 56 bits with selects and appended to a 64-bit accumulator that is stored (8 bytes,
+//     unconditionally) and advanced by whole bytes — whether a symbol settles bits is a coin flip the branch predictor
+//     loses;
+//   * symbols are validated in a vectorisable pre-pass.
+// Same bits as the generic loop below (tests/test_codec.py pins both against the bit-list oracle).
+struct HostBitSink {
+    uint8_t *p, *end;
+    uint64_t acc;         // the low nacc bits are not stored yet (nacc < 8 between calls)
+    int nacc;
+    bool overflow;
+    void init(uint8_t *buf, size_t cap) { p = buf; end = buf + cap; acc = 0; nacc = 0; overflow = false; }
+    inline void put(uint64_t v, int n) {             // n <= 56, v < 2^n
+        acc = (acc << n) | v;
+        nacc += n;
+        const uint64_t w = __builtin_bswap64((acc << (63 - nacc)) << 1);    // pending bits left-aligned (nacc = 0: unused)
+        if (p + 8 <= end) memcpy(p, &w, 8);
+        else { for (int t = 0; t < (nacc >> 3); ++t) { if (p + t < end) p[t] = (uint8_t)(w >> (8 * t)); else overflow = true; } }
+        p += nacc >> 3;
+        nacc &= 7;
+    }
+    inline void put_run(int bit, uint64_t count) {   // `count` copies of `bit`
+        while (count > 0) {
+            const int n = count > 32 ? 32 : (int)count;
+            put(bit ? ((1ull << n) - 1ull) : 0ull, n);
+            count -= (uint64_t)n;
+        }
+    }
+    size_t finish(uint8_t *base) {                   // zero-pad to a byte boundary
+        if (nacc) put(0, 8 - nacc);
+        if (p > end) overflow = true;
+        return (size_t)(p - base);
+    }
+};
+
+static int ac_encode_binary_host(const uint16_t *row, const int16_t *sym, int64_t n_sym, uint8_t *out, size_t out_cap,
+                                 size_t *out_len) {
+    int bad = 0;
+    for (int64_t i = 0; i < n_sym; ++i) bad |= (sym[i] & ~1);
+    if (bad) { cgs_set_error("ac_encode_const: symbol out of range"); return CGS_ERR_BOUNDS; }
+    HostBitSink sink;
+    sink.init(out, out_cap);
+    const uint64_t c1 = row[1];
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint64_t pending = 0;
+    for (int64_t i = 0; i < n_sym; ++i) {
+        const uint64_t span = (uint64_t)(high - low) + 1;
+        const uint32_t t = (uint32_t)((span * c1) >> AC_PRECISION);
+        const bool one = sym[i] != 0;
+        const uint32_t nh = (low - 1) + t, nl = low + t;
+        high = one ? high : nh;
+        low = one ? nl : low;
+        const uint32_t settled = low;
+        const AcRenorm r = ac_renorm(low, high);
+        const int k = r.k;
+        if (__builtin_expect(pending > 24, 0)) {     // a long underflow run: the plain path
+            if (k) {
+                const uint32_t bits = (uint32_t)(((uint64_t)settled << k) >> 32);
+                const int b = (int)((bits >> (k - 1)) & 1u);
+                sink.put((uint64_t)b, 1);
+                sink.put_run(!b, pending);
+                if (k > 1) sink.put(bits & ((1u << (k - 1)) - 1u), k - 1);
+                pending = 0;
+            }
+            pending += (uint64_t)r.u;
+            continue;
+        }
+        const bool has = k != 0;
+        const int km1 = has ? k - 1 : 0;
+        const uint64_t bits = ((uint64_t)settled << k) >> 32;                 // top k bits of settled (0 if k = 0)
+        const uint64_t b = (bits >> km1) & 1ull;
+        const int P = (int)pending;
+        const uint64_t run = b ? 0ull : ((1ull << P) - 1ull);                 // the pending bits are the complement of b
+        const uint64_t word = (b << (P + km1)) | (run << km1) | (bits & ((1ull << km1) - 1ull));
+        sink.put(has ? word : 0ull, has ? k + P : 0);
+        pending = (has ? 0ull : pending) + (uint64_t)r.u;
+    }
+    // the closing bits of AcEncoderT::finish_bits
+    ++pending;
+    const int b = low < 0x40000000u ? 0 : 1;
+    sink.put((uint64_t)b, 1);
+    sink.put_run(!b, pending);
+    *out_len = sink.finish(out);
+    if (sink.overflow) { cgs_set_error("ac_encode_const: output buffer too small"); return CGS_ERR_WORKSPACE; }
+    return CGS_OK;
+}
+
 extern "C" int cgs_ac_encode_const_host(const uint16_t *row, int Lp, const int16_t *sym, int64_t n_sym, uint8_t *out,
                                         size_t out_cap, size_t *out_len) {
     if (!row || !sym || !out || !out_len || Lp < 2) { cgs_set_error("ac_encode_const: bad args"); return CGS_ERR_ARG; }
+    if (Lp == 3 && row[0] == 0) return ac_encode_binary_host(row, sym, n_sym, out, out_cap, out_len);
     AcEncoder enc;
     enc.init(out, out_cap);
     const int max_sym = Lp - 2;
@@ -338,27 +431,33 @@ static int ac_decode_binary_host(const uint16_t *row, int64_t n_sym, const uint8
     HostBitSource src;
     src.init(in, in_len);
     uint32_t low = 0, high = 0xFFFFFFFFu, value = src.get_bits(32);
-    const uint32_t c0 = row[0], c1 = row[1];
+    const uint32_t c1 = row[1];
     for (int64_t i = 0; i < n_sym; ++i) {
-        const uint32_t span_m1 = high - low;
+        const uint64_t span = (uint64_t)(high - low) + 1;
         const uint64_t num = (((uint64_t)value - (uint64_t)low + 1) << AC_PRECISION) - 1;
-        const bool one = (uint64_t)c1 * span_m1 + c1 <= num;
+        const uint64_t prod = (uint64_t)c1 * span;               // the one product both the test and the update need
+        const bool one = prod <= num;
         sym_out[i] = (int16_t)one;
         if (i == n_sym - 1) break;
-        const uint64_t span = (uint64_t)span_m1 + 1;
-        const uint32_t c_low = one ? c1 : c0, c_high = one ? AC_TOP : c1;
-        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
-        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        // symbol 1 = [c1, 2^16): high stays (span * 2^16 >> 16 = span), low moves up; symbol 0 = [0, c1): low stays.
+        // Selected with masks, and the bit refill below takes n = 0 in its stride: which symbol it was and whether it
+        // settles bits are coin flips, so nothing on this path may be a branch.
+        const uint32_t t = (uint32_t)(prod >> AC_PRECISION);
+        const uint32_t m1 = 0u - (uint32_t)one;
+        high = (high & m1) | (((low - 1) + t) & ~m1);
+        low = low + (t & m1);
         const AcRenorm r = ac_renorm(low, high);
         const int n = r.k + r.u;
-        if (n == 0) continue;
-        if (n <= 32) {
-            value = (uint32_t)(((uint64_t)value << n) | (uint64_t)src.get_bits(n));
-            if (r.u > 0) value ^= 0x80000000u;
-        } else {
+        if (__builtin_expect(n > 32, 0)) {
             value = r.k >= 32 ? src.get_bits(32) : ((value << r.k) | src.get_bits(r.k));
             value = ((value << r.u) ^ 0x80000000u) | src.get_bits(r.u);
+            continue;
         }
+        if (src.nb < n) src.refill();
+        const uint32_t fresh = (uint32_t)((src.bb >> 1) >> (63 - n));        // the next n bits (n = 0: none)
+        src.bb <<= n;
+        src.nb -= n;
+        value = (uint32_t)(((uint64_t)value << n) | (uint64_t)fresh) ^ ((uint32_t)(r.u != 0) << 31);
     }
     return CGS_OK;
 }
@@ -366,7 +465,7 @@ static int ac_decode_binary_host(const uint16_t *row, int64_t n_sym, const uint8
 extern "C" int cgs_ac_decode_const_host(const uint16_t *row, int Lp, int64_t n_sym, const uint8_t *in, size_t in_len,
                                         int16_t *sym_out) {
     if (!row || !sym_out || Lp < 2) { cgs_set_error("ac_decode_const: bad args"); return CGS_ERR_ARG; }
-    if (Lp == 3) return ac_decode_binary_host(row, n_sym, in, in_len, sym_out);
+    if (Lp == 3 && row[0] == 0) return ac_decode_binary_host(row, n_sym, in, in_len, sym_out);
     AcDecoder dec;
     dec.init(in, in_len);
     const int max_sym = Lp - 2;
@@ -823,9 +922,14 @@ extern "C" int cgs_rans_encode_host(const int32_t *symbols, int C_, int64_t n, c
     return CGS_OK;
 }
 
-extern "C" int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C_, int64_t n, const int32_t *cdf, int max_len,
-                                    const int32_t *cdf_len, const int32_t *offset, int prec, int32_t *symbols) {
-    if (!in || in_len < 4 || !cdf || !cdf_len || !offset || !symbols) { cgs_set_error("rans_decode: bad args"); return CGS_ERR_ARG; }
+// One hyper-prior chunk string -> symbols.  Two output forms: int32 symbols[C, n] (channel-major, the layout
+// compressai's decompress returns), or — out_rows != NULL — the DEQUANTISED latents, row-major by anchor:
+// out_rows[i * ld_rows + c] = (float)symbol + medians[c], which is what the container decoder feeds the context model
+// (scene/gaussian_model.py:1326-1338): every chunk job writes its rows of one pinned [N, C] buffer, no concatenation,
+// transpose or integer-to-float pass afterwards.
+static int rans_decode_impl(const uint8_t *in, size_t in_len, int C_, int64_t n, const int32_t *cdf, int max_len,
+                            const int32_t *cdf_len, const int32_t *offset, int prec, int32_t *symbols,
+                            const float *medians, float *out_rows, int64_t ld_rows) {
     RansDec dec;
     dec.init(in, in_len);
     for (int64_t i = 0; i < n; ++i)
@@ -845,7 +949,24 @@ extern "C" int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C_, in
                 for (int k = 0; k < nz; ++k) m = (m << 1) | dec.get_bit();
                 value = sign ? -(int)m : (int)m + max_value - 1;
             }
-            symbols[(size_t)c * n + i] = value + offset[c];
+            if (out_rows) out_rows[(size_t)i * ld_rows + c] = (float)(value + offset[c]) + medians[c];
+            else symbols[(size_t)c * n + i] = value + offset[c];
         }
     return CGS_OK;
+}
+
+extern "C" int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C_, int64_t n, const int32_t *cdf, int max_len,
+                                    const int32_t *cdf_len, const int32_t *offset, int prec, int32_t *symbols) {
+    if (!in || in_len < 4 || !cdf || !cdf_len || !offset || !symbols) { cgs_set_error("rans_decode: bad args"); return CGS_ERR_ARG; }
+    return rans_decode_impl(in, in_len, C_, n, cdf, max_len, cdf_len, offset, prec, symbols, nullptr, nullptr, 0);
+}
+
+extern "C" int cgs_rans_decode_rows_host(const uint8_t *in, size_t in_len, int C_, int64_t n, const int32_t *cdf,
+                                         int max_len, const int32_t *cdf_len, const int32_t *offset, int prec,
+                                         const float *medians, float *out_rows, int64_t ld_rows) {
+    if (!in || in_len < 4 || !cdf || !cdf_len || !offset || !medians || !out_rows || ld_rows < C_) {
+        cgs_set_error("rans_decode_rows: bad args");
+        return CGS_ERR_ARG;
+    }
+    return rans_decode_impl(in, in_len, C_, n, cdf, max_len, cdf_len, offset, prec, nullptr, medians, out_rows, ld_rows);
 }

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -404,6 +406,48 @@ class EntropyBottleneck(nn.Module):
         return jobs if lazy else [j.result() for j in jobs]
 
     @torch.no_grad()
+    def decompress_chunks_rows(self, strings: list[bytes], sizes: list[int], tasks: int = 0):
+        """decompress_chunks(...).t() as a job: the chunk strings are decoded by `tasks` host-thread tasks (a contiguous
+        run of chunks each: few, long tasks keep the pool off the GIL the launching thread needs) straight into the
+        rows of one pinned [N, C] float buffer, already dequantised (symbol + median, the same fp32 sum).  Returns a
+        callable that waits for the tasks and returns the [N, C] tensor on the module's device (one H2D copy)."""
+        from . import _lib, codec
+        import ctypes as C_
+        if self._offset.numel() == 0:
+            self.update()
+        dev = self.quantiles.device
+        Cn, N = self.channels, int(sum(sizes))
+        if not strings:
+            return lambda: torch.zeros(0, Cn, dtype=self.quantiles.dtype, device=dev)
+        cdf = np.ascontiguousarray(self._quantized_cdf.cpu().numpy(), dtype=np.int32)
+        cl = np.ascontiguousarray(self._cdf_length.cpu().numpy(), dtype=np.int32)
+        of = np.ascontiguousarray(self._offset.cpu().numpy(), dtype=np.int32)
+        med = np.ascontiguousarray(self._get_medians()[:, 0, 0].float().cpu().numpy(), dtype=np.float32)
+        stage = _rows_staging(N * Cn)
+        base = stage.data_ptr()
+        L = _lib.lib()
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ptr = lambda a: a.ctypes.data_as(C_.c_void_p)
+
+        def run(lo, hi):
+            for k in range(lo, hi):
+                buf = np.frombuffer(strings[k], dtype=np.uint8)
+                _lib.check(L.cgs_rans_decode_rows_host(ptr(buf), buf.size, Cn, int(sizes[k]), ptr(cdf), cdf.shape[1], ptr(cl),
+                                                       ptr(of), self.precision, ptr(med), base + 4 * Cn * int(starts[k]), Cn),
+                           "cgs_rans_decode_rows_host")
+
+        n_chunks = len(strings)
+        tasks = tasks or int(os.environ.get("CGS_HYPER_TASKS", "32"))
+        per = -(-n_chunks // max(1, min(tasks, n_chunks)))
+        jobs = [codec.host_pool().submit(run, lo, min(n_chunks, lo + per)) for lo in range(0, n_chunks, per)]
+
+        def finish():
+            for j in jobs:
+                j.result()
+            return stage[:N * Cn].view(N, Cn).to(dev, non_blocking=True).to(self.quantiles.dtype)
+        return finish
+
+    @torch.no_grad()
     def decompress_chunks(self, strings: list[bytes], sizes: list[int]) -> torch.Tensor:
         """inverse of compress_chunks -> [C, sum(sizes)] dequantised, on the module's device."""
         from . import codec
@@ -417,6 +461,17 @@ class EntropyBottleneck(nn.Module):
                 for b, n in zip(strings, sizes)]
         sym = np.concatenate([j.result() for j in jobs], axis=1)
         return torch.from_numpy(sym).to(dev).to(self.quantiles.dtype) + self._get_medians()[:, 0]
+
+
+_ROWS_STAGE = None
+
+
+def _rows_staging(n_floats: int) -> torch.Tensor:
+    """Grow-only pinned float buffer the hyper chunk jobs decode into (one H2D copy afterwards)."""
+    global _ROWS_STAGE
+    if _ROWS_STAGE is None or _ROWS_STAGE.numel() < n_floats:
+        _ROWS_STAGE = torch.empty(int(n_floats * 1.25) + 1024, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+    return _ROWS_STAGE
 
 
 def pmf_to_quantized_cdf(pmf: np.ndarray, precision: int = 16) -> np.ndarray:

@@ -496,6 +496,13 @@ int cgs_rans_decode_host(const uint8_t *in, size_t in_len, int C, int64_t n,
                          const int32_t *cdf, int max_len,
                          const int32_t *cdf_len, const int32_t *offset,
                          int prec, int32_t *symbols);
+/* The same decode delivering the DEQUANTISED latents row-major by anchor: out_rows[i * ld_rows + c] =
+ * (float)symbol + medians[c] (scene/gaussian_model.py:1326-1338 feeds exactly this to the context model); chunk jobs
+ * write disjoint row ranges of one [N, C] host buffer. */
+int cgs_rans_decode_rows_host(const uint8_t *in, size_t in_len, int C, int64_t n,
+                              const int32_t *cdf, int max_len, const int32_t *cdf_len,
+                              const int32_t *offset, int prec, const float *medians,
+                              float *out_rows, int64_t ld_rows);
 
 /* ------------------------------------------------------------------ */
 /* Anchor -> Gaussian expansion (gaussian_renderer/__init__.py:112-145)   */

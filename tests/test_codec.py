@@ -164,3 +164,22 @@ def test_binary_mask_decoder_equals_generic_table_decoder(p1, n, seed):
         fast = codec.bernoulli_decode_host(data[:cut], n, p1)
         generic = codec.decode_float_cdf(table, data[:cut]).numpy()
         assert np.array_equal(fast, generic)
+
+
+def test_hyper_chunks_decode_straight_into_rows():
+    """decompress_chunks_rows (chunk jobs writing dequantised rows of one [N, C] buffer) == decompress_chunks(...).t()."""
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    torch.manual_seed(3)
+    eb = EntropyBottleneck(12)
+    with torch.no_grad():
+        eb.quantiles[:, 0, 1] += torch.randn(12) * 0.3            # non-integer medians: the dequantisation matters
+    eb.update(force=True)
+    x = torch.randn(4321, 12) * 5
+    x[17, 3], x[4000, 0] = 80.0, -75.0                            # escapes
+    sizes = [1000, 1000, 1000, 1000, 321]
+    strings = eb.compress_chunks(x.t(), 1000)
+    want = eb.decompress_chunks(strings, sizes).t().contiguous()
+    for tasks in (1, 3, 16):
+        got = eb.decompress_chunks_rows(strings, sizes, tasks=tasks)()
+        assert got.shape == want.shape and torch.equal(got, want)
+    assert eb.decompress_chunks_rows([], [])().shape == (0, 12)
