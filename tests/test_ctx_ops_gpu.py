@@ -239,3 +239,49 @@ def test_means3_equals_torch_means():
     assert torch.equal(means3(a, b, c, exp_b=True), got)                      # deterministic
     got2 = means3(a[:1], b[:0], c, exp_b=False)
     assert torch.allclose(got2[0], a[:1].mean()) and float(got2[1]) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,with_perm,with_mask", [(1, False, False), (4097, True, True), (100_003, True, False), (50_000, False, True)])
+def test_choose_rows_matches_the_torch_composition(n, with_perm, with_mask):
+    """ctx_plan.hip (cgs_ctx_choose_flags / _compact): chosen rows in coding order, their original indices, level-local
+    positions, per-level counts, live count, the inverse map per level and the plan-validity flag, against the torch
+    statement of scene/gaussian_model.py:1658-1661 restricted to the levels."""
+    from contextgs_amd import ctx_ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(n)
+    perm = torch.randperm(n, generator=g).to(dev) if with_perm else None
+    mask = (torch.rand(n, generator=g) < 0.8).to(dev) if with_mask else None
+    given = (torch.rand(n, generator=g) < 0.15).to(dev)
+    cuts = sorted(set([0, n // 7, n // 3, n]))
+    anchor = torch.randn(n, 3, generator=g).to(dev)
+    stale, live, per_level, nz, rows, loc, sub_map = ctx_ops.choose_rows(perm, n, mask, given, 0, 0.15, anchor, anchor.clone(),
+                                                                          None if mask is None else mask.clone(), cuts)
+    order = perm if perm is not None else torch.arange(n, device=dev)
+    flag = given[order] & (mask[order] if mask is not None else torch.ones(n, dtype=torch.bool, device=dev))
+    want_nz = torch.nonzero(flag)[:, 0]
+    assert not stale and live == (int(mask.sum()) if mask is not None else n)
+    assert torch.equal(nz, want_nz) and torch.equal(rows, order[want_nz])
+    lvl = torch.bucketize(want_nz, torch.tensor(cuts[1:-1], device=dev), right=True) if len(cuts) > 2 else torch.zeros_like(want_nz)
+    starts = torch.tensor(cuts[:-1], device=dev)
+    assert torch.equal(loc, want_nz - starts[lvl])
+    assert per_level == [int((lvl == l).sum()) for l in range(len(cuts) - 1)]
+    # inverse map: row r of level l -> index in l's part of the chosen list
+    want_map = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    cum = [0]
+    for c in per_level:
+        cum.append(cum[-1] + c)
+    for l in range(len(cuts) - 1):
+        sel = want_nz[cum[l]:cum[l + 1]]
+        want_map[sel] = torch.arange(sel.numel(), dtype=torch.int32, device=dev)
+    if sum(per_level):
+        assert torch.equal(sub_map[:n], want_map)
+    # the counter-based draw is used when no mask is given: ~15 % of the live rows, reproducible by seed
+    _s, _l, pl1, nz1, _r, _lo, _m = ctx_ops.choose_rows(perm, n, mask, None, 1234, 0.15, anchor, None, None, cuts)
+    _s, _l, pl2, nz2, _r, _lo, _m = ctx_ops.choose_rows(perm, n, mask, None, 1234, 0.15, anchor, None, None, cuts)
+    assert pl1 == pl2 and torch.equal(nz1, nz2)
+    if n > 10_000:
+        assert abs(sum(pl1) / max(1, live) - 0.15) < 0.01
+    # a moved anchor / flipped mask bit is reported
+    moved = anchor.clone(); moved[n // 2, 1] += 1.0
+    assert ctx_ops.choose_rows(perm, n, mask, given, 0, 0.15, moved, anchor, None if mask is None else mask.clone(), cuts)[0]
