@@ -345,7 +345,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         assert int(lens.sum()) == int(blob.numel())                                      # :1479-1481
         return blob, lens
 
-    # Coder launches last as long as their LONGEST stream (a 10 000-anchor feature chunk: 500 000 serial symbols) however
+    # Coder launches last as long as their LONGEST stream (a 1000-anchor feature chunk: 50 000 serial symbols at ~0.4 us each) however
     # many streams they hold, so the fewer the better: one per level for features + scaling — the offsets of a level
     # need nothing but that level's prediction and the masks, so ALL of them go into ONE more launch, beside the last
     # level's (see below): 3 serial launches for 3 levels.
