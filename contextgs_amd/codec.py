@@ -149,15 +149,27 @@ def _f(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
-_STAGE = None
+_STAGE = {}
 
 
-def _pinned_staging(nbytes: int) -> torch.Tensor:
-    """A grow-only pinned host buffer for bitstream downloads (allocating pinned memory costs milliseconds per call)."""
-    global _STAGE
-    if _STAGE is None or _STAGE.numel() < nbytes:
-        _STAGE = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
-    return _STAGE
+def _pinned_staging(nbytes: int, key: str = "bitstream") -> torch.Tensor:
+    """Grow-only pinned host buffers, one per purpose (allocating pinned memory costs milliseconds per call, and a buffer a
+    host thread is still reading must not be reused for something else)."""
+    buf = _STAGE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _STAGE[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+    return buf
+
+
+def to_host_pinned(t: torch.Tensor, key: str) -> np.ndarray:
+    """Device tensor -> numpy array backed by the reused pinned buffer `key` (valid until the next call with that key):
+    a pinned download runs at PCIe rate, a pageable `.cpu()` at a fifth of it and on a runtime staging thread."""
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    stage = _pinned_staging(nbytes, key)[:nbytes].view(t.dtype).view(t.shape)
+    stage.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return stage.numpy()
 
 
 def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False):

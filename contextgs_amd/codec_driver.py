@@ -152,7 +152,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream: start it on a host thread now
     prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
     if root:
-        mask_sym = torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16).cpu().numpy()
+        mask_sym = codec.to_host_pinned(torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16), "mask symbols")
         tr("mask symbols on the host")
         mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
         # hyper: 10 000-anchor rANS chunks (:1082-1098), on host threads too — but submitted only AFTER the level loop

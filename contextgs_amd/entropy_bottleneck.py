@@ -399,7 +399,8 @@ class EntropyBottleneck(nn.Module):
         assert x.dim() == 2 and x.shape[0] == self.channels
         if self._offset.numel() == 0:
             self.update()
-        sym = self.quantize(x, "symbols", self._get_medians()[:, 0]).cpu().numpy()            # [C, N] int32
+        sym_d = self.quantize(x, "symbols", self._get_medians()[:, 0])                        # [C, N] int32
+        sym = codec.to_host_pinned(sym_d, "hyper symbols") if (lazy and sym_d.is_cuda) else sym_d.cpu().numpy()
         tabs = (self._quantized_cdf.cpu().numpy(), self._cdf_length.cpu().numpy(), self._offset.cpu().numpy())
         jobs = [codec.host_pool().submit(codec.rans_encode_channels, sym[:, s:s + chunk], *tabs, self.precision)
                 for s in range(0, sym.shape[1], chunk)]
