@@ -550,7 +550,10 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                         span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
                     sm = c.get("_sub_map")
                     lvl0 = sum(sizes[:j])
-                    levels.append(dict(level=i, orig=orig, rows=orig[loc], loc=loc, n_level=n_l, fused=True, yf=hf, ys=hs,
+                    # `rows` (original indices of the chosen anchors) is only read when the subset is not listed level by
+                    # level (span None): otherwise the mask rows come from ONE gather over all levels' chosen anchors
+                    levels.append(dict(level=i, orig=orig, rows=orig[loc] if span is None else None, loc=loc, n_level=n_l,
+                                       fused=True, yf=hf, ys=hs,
                                        yo=ho, Q=Q_all, chosen=span, side=side, side_src=row_src,
                                        sub_map=sm[lvl0:lvl0 + n_l] if (sm is not None and span is not None) else None,
                                        pred=pred_sub))

@@ -125,19 +125,19 @@ __global__ void __launch_bounds__(RB_THREADS)
                     const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
                     const float blue = srec[e * 3 + 2].x;
                     const RbEval ev = rb_eval(r0, r1, pxf, pyf);
-                    if (has && !done && ev.hit) {
-                        const float test_T = T * (1.f - ev.alpha);
-                        if (test_T < RB_T_EPS) {
-                            done = true;
-                        } else {
-                            const float w = ev.alpha * T;
-                            cr = fmaf(r1.z, w, cr);
-                            cg = fmaf(r1.w, w, cg);
-                            cb = fmaf(blue, w, cb);
-                            T = test_T;
-                            last = base_pos + (uint32_t)e + 1u;
-                        }
-                    }
+                    // branch-free (as in the backward): a lane that takes no contribution blends weight 0, an exact no-op
+                    const bool act = has && !done && ev.hit;
+                    const float alpha = act ? ev.alpha : 0.f;
+                    const float test_T = T * (1.f - alpha);
+                    const bool stop = act && test_T < RB_T_EPS;
+                    const bool upd = act && !stop;
+                    const float w = upd ? alpha * T : 0.f;
+                    cr = fmaf(r1.z, w, cr);
+                    cg = fmaf(r1.w, w, cg);
+                    cb = fmaf(blue, w, cb);
+                    T = upd ? test_T : T;
+                    last = upd ? base_pos + (uint32_t)e + 1u : last;
+                    done = done || stop;
                 }
                 if (__all(done)) break;
             }
