@@ -313,6 +313,9 @@ __global__ void __launch_bounds__(RB_THREADS)
                 b2[0] += rb_dpp<0x124>(b2[0]); b2[0] += rb_dpp<0x128>(b2[0]);
                 b2[1] += rb_dpp<0x124>(b2[1]); b2[1] += rb_dpp<0x128>(b2[1]);
                 c8 += rb_dpp<0x124>(c8); c8 += rb_dpp<0x128>(c8);
+                // keep the last three DPP additions in front of the predicated store: sunk into its exec-masked block
+                // they split into a full-exec v_mov_dpp plus an add each (and a zero for the mov's `old` operand)
+                asm volatile("" : "+v"(b2[0]), "+v"(b2[1]), "+v"(c8));
                 const int sub = lane & 15;
                 const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
                 if (ABL == 1) { if (has && red == 12345.f) atomicAdd(&sacc[e][sub], red); continue; }
