@@ -201,6 +201,11 @@ __global__ void __launch_bounds__(RB_THREADS)
 
     const float T_final = inside ? final_T[pix] : 0.f;
     const uint32_t my_last = inside ? n_contrib[pix] : 0u;
+    uint32_t blk_last = my_last;       // maximum over the 16 lanes (pixels) of the row
+    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0xB1, 0xF, 0xF, false));
+    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x4E, 0xF, 0xF, false));
+    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x124, 0xF, 0xF, false));
+    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x128, 0xF, 0xF, false));
     float T = T_final;
     float gr = 0.f, gg = 0.f, gb = 0.f;
     if (inside) { gr = dL_dout[pix]; gg = dL_dout[hw + pix]; gb = dL_dout[2 * hw + pix]; }
@@ -245,7 +250,12 @@ __global__ void __launch_bounds__(RB_THREADS)
         __syncthreads();
 
         for (int s = 7; s >= 0; --s) {
+            // entries behind the LAST contribution of every pixel of this 4x4 block (n_contrib: where the forward stopped)
+            // cannot contribute to it: the row drops them from its list (the tile-wide bound `tlast` is the maximum over
+            // 256 pixels, a block's own bound over 16)
+            const int lim = (int)blk_last - (int)base_pos - s * 32 - 1;       // highest admissible bit of this segment
             uint32_t m = bmask[L.blk][s];
+            m = lim < 0 ? 0u : (lim >= 31 ? m : (m & ((2u << lim) - 1u)));
             while (__ballot(m != 0u) != 0ull) {
                 const bool has = m != 0u;
                 const int j = 31 - __builtin_clz(m | 1u);            // m == 0: j = 0, has = false
@@ -257,7 +267,7 @@ __global__ void __launch_bounds__(RB_THREADS)
                 if (ABL == 4) { if (has && r0.x == 12345.f) atomicAdd(&sacc[e][0], r1.x + blue); continue; }
                 const RbEval ev = rb_eval(r0, r1, pxf, pyf);
                 const bool act = has && (position <= my_last) && ev.hit;
-                if (__ballot(act) == 0ull) continue;
+                if ((ABL != 7) && __ballot(act) == 0ull) continue;
                 if (ABL == 3) { if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue); continue; }
                 // Branch-free: a lane whose pixel takes no contribution runs the same updates on alpha = 0, G = 0, for which
                 // every one of them is an exact no-op (T / 1 = T, w = 0, the colour recurrence with alpha = 0 hands on
@@ -377,6 +387,7 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
         case 4: RB_BWD(4); break;
         case 5: RB_BWD(5); break;
         case 6: RB_BWD(6); break;
+        case 7: RB_BWD(7); break;
         default: RB_BWD(0);
     }
 #undef RB_BWD
