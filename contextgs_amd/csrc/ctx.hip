@@ -447,10 +447,28 @@ __global__ void __launch_bounds__(256)
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_parents; p += (int64_t)gridDim.x * 4) {
         const int64_t b = offs[p], e = offs[p + 1];
         float acc0 = 0.f, acc1 = 0.f;                     // columns lane and lane + 64
-        for (int64_t k = b; k < e; ++k) {
-            const float *row = dout + order[k] * ldo;
-            if (lane < W) acc0 += row[lane];
-            if (lane + 64 < W) acc1 += row[lane + 64];
+        // The children's row indices come in with ONE coalesced load per 64 children and are broadcast from a register,
+        // and four row loads are in flight before the first is added: the plain loop (index load -> row load -> add,
+        // per child) exposed two dependent memory latencies per child with ~5 children per parent.  Same additions in
+        // the same order.
+        for (int64_t base = b; base < e; base += 64) {
+            const int m = (int)((e - base) < 64 ? (e - base) : 64);
+            const int64_t mine = lane < m ? order[base + lane] : 0;
+            for (int j = 0; j < m; j += 4) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t child = __shfl(mine, (j + u) & 63, 64);      // wave-uniform source lane
+                    const float *row = dout + child * ldo;
+                    const bool ok = j + u < m;
+                    v0[u] = (ok && lane < W) ? row[lane] : 0.f;
+                    v1[u] = (ok && lane + 64 < W) ? row[lane + 64] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j + u < m) { acc0 += v0[u]; acc1 += v1[u]; }
+                }
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
