@@ -24,15 +24,32 @@ struct RowcatArgs {
 
 __global__ void __launch_bounds__(256) rowcat_fwd_kernel(RowcatArgs a, int64_t n, float *__restrict__ out) {
     const int64_t total = n * a.W;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / a.W;
-        const int c = (int)(i - r * a.W);
-        int s = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // four elements per trip: their row-index loads, then their (dependent) source loads, are issued together
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        const float *p[4];
+        int64_t row[4];
+        bool ok[4];
 #pragma unroll
-        for (int k = 1; k < RC_MAX_SRC; ++k)
-            if (k < a.nsrc && c >= a.begin[k]) s = k;
-        const int64_t row = a.idx[s] ? a.idx[s][r] : r;
-        out[i] = a.src[s][row * a.ld[s] + (c - a.begin[s])];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            ok[u] = i < total;
+            const int64_t r = ok[u] ? i / a.W : 0;
+            const int c = ok[u] ? (int)(i - r * a.W) : 0;
+            int s = 0;
+#pragma unroll
+            for (int k = 1; k < RC_MAX_SRC; ++k)
+                if (k < a.nsrc && c >= a.begin[k]) s = k;
+            row[u] = (ok[u] && a.idx[s]) ? a.idx[s][r] : r;
+            p[u] = a.src[s] + (c - a.begin[s]);
+            row[u] *= a.ld[s];
+        }
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ok[u] ? p[u][row[u]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) out[i0 + u * stride] = v[u];
     }
 }
 
