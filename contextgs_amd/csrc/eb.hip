@@ -31,16 +31,24 @@ struct EbTrace {           // intermediates of one evaluation
     float out;
 };
 
+// Effective parameters of channel c: softplus of the matrices, tanh of the factors, biases as they are.  The 58 values are
+// the same for every thread of a workgroup (one channel per workgroup), so each is transformed ONCE, by thread i, and
+// shared through LDS: as a per-thread loop this was ~2500 instructions of tanhf / softplusf per thread before the first
+// element — a third of eb_bits_fwd's time at ~3 elements per lane.  Call from all threads of the workgroup.
+__device__ __forceinline__ float eb_transform(int i, float v) {
+    const bool is_f = (i >= OFF_F0 && i < OFF_F0 + 3) || (i >= OFF_F(1) && i < OFF_F(1) + 3) ||
+                      (i >= OFF_F(2) && i < OFF_F(2) + 3) || (i >= OFF_F(3) && i < OFF_F(3) + 3);
+    const bool is_b = (i >= OFF_B0 && i < OFF_B0 + 3) || (i >= OFF_B(1) && i < OFF_B(1) + 3) ||
+                      (i >= OFF_B(2) && i < OFF_B(2) + 3) || (i >= OFF_B(3) && i < OFF_B(3) + 3) || i == OFF_B4;
+    return is_b ? v : (is_f ? tanhf(v) : softplusf(v));
+}
+
 __device__ __forceinline__ void eb_load_params(const float *__restrict__ raw, int c, float p[EB_P]) {
+    __shared__ float sp[EB_P];
+    if (threadIdx.x < EB_P) sp[threadIdx.x] = eb_transform((int)threadIdx.x, raw[c * EB_P + threadIdx.x]);
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < EB_P; ++i) {
-        const float v = raw[c * EB_P + i];
-        const bool is_f = (i >= OFF_F0 && i < OFF_F0 + 3) || (i >= OFF_F(1) && i < OFF_F(1) + 3) ||
-                          (i >= OFF_F(2) && i < OFF_F(2) + 3) || (i >= OFF_F(3) && i < OFF_F(3) + 3);
-        const bool is_b = (i >= OFF_B0 && i < OFF_B0 + 3) || (i >= OFF_B(1) && i < OFF_B(1) + 3) ||
-                          (i >= OFF_B(2) && i < OFF_B(2) + 3) || (i >= OFF_B(3) && i < OFF_B(3) + 3) || i == OFF_B4;
-        p[i] = is_b ? v : (is_f ? tanhf(v) : softplusf(v));
-    }
+    for (int i = 0; i < EB_P; ++i) p[i] = sp[i];
 }
 
 __device__ __forceinline__ float eb_eval(const float p[EB_P], float u, EbTrace &tr) {
