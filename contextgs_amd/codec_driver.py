@@ -54,8 +54,8 @@ def load_mlp_checkpoints(pc, path):                            # :939-950
     pc.mlp_opacity.load_state_dict(ck["opacity_mlp"])
     pc.mlp_cov.load_state_dict(ck["cov_mlp"])
     pc.mlp_color.load_state_dict(ck["color_mlp"])
-    pc.latent_codec.update()
     _load_latent_codec(pc.latent_codec, ck["latent_codec"])
+    pc.latent_codec.update(force=True)
     pc.mlp_grid.load_state_dict(ck["grid_mlp"])
     pc.x_bound_min, pc.x_bound_max = ck["bound"]
     pc.level_scale = ck["level_scale"]
@@ -74,6 +74,8 @@ def _load_latent_codec(codec, state):
     own = set(codec.state_dict().keys())
     remapped = {}
     for k, v in state.items():
+        if k in ("_quantized_cdf", "_offset", "_cdf_length"):
+            continue      # derived tables with data-dependent shapes: rebuilt from the parameters by update(force=True)
         m = _LEGACY_EB_KEY.match(k)
         if m and k not in own:
             k = {"matrix": "matrices", "bias": "biases", "factor": "factors"}[m.group(1)] + "." + m.group(2)

@@ -183,6 +183,47 @@ class GaussianModel(nn.Module):
         self._opacity = nn.Parameter(torch.from_numpy(d["opacity"]).to(dev), requires_grad=True)
         return self
 
+    # ---- checkpoint tuple (scene/gaussian_model.py:222-286; train.py saves it with torch.save) --------------------
+    def capture(self):
+        """The reference's 19-entry checkpoint tuple, same order.  The optimizer entry is `self.optimizer.state_dict()`
+        when a training driver has attached one (the driver and its optimizer are the reference's own, SURVEY 2 rows
+        12-23) and None otherwise."""
+        self.latent_codec.update()
+        opt = getattr(self, "optimizer", None)
+        return (self._anchor, self._anchor_feat, self._hyper_latent, self._offset, self._mask, self._scaling,
+                self._rotation, self._opacity, getattr(self, "max_radii2D", None),
+                opt.state_dict() if opt is not None else None, getattr(self, "spatial_lr_scale", 0.0),
+                self.mlp_opacity.state_dict(), self.mlp_cov.state_dict(), self.mlp_color.state_dict(),
+                self.latent_codec.state_dict(), self.mlp_grid.state_dict(),
+                self.x_bound_min, self.x_bound_max, self.level_scale)
+
+    def restore(self, model_args, training_args=None):
+        """Inverse of capture().  `training_setup(training_args)` is called when the object has one (the reference's
+        class does, :252); the optimizer state is loaded when both a state and an optimizer exist."""
+        (anchor, feat, hyper, offset, mask, scaling, rotation, opacity, self.max_radii2D, opt_dict, self.spatial_lr_scale,
+         sd_opacity, sd_cov, sd_color, sd_codec, sd_grid, self.x_bound_min, self.x_bound_max, self.level_scale) = model_args
+        dev = self.x_bound_min.device
+        as_param = lambda t, like: nn.Parameter(t.detach().to(dev).float().contiguous(),
+                                                requires_grad=bool(getattr(t, "requires_grad", like)))
+        self._anchor, self._anchor_feat = as_param(anchor, True), as_param(feat, True)
+        self._hyper_latent, self._offset = as_param(hyper, True), as_param(offset, True)
+        self._mask, self._scaling = as_param(mask, True), as_param(scaling, True)
+        self._rotation, self._opacity = as_param(rotation, False), as_param(opacity, False)
+        self.latent_codec.update()
+        if training_args is not None and hasattr(self, "training_setup"):
+            self.training_setup(training_args)
+        if opt_dict is not None and getattr(self, "optimizer", None) is not None:
+            self.optimizer.load_state_dict(opt_dict)
+        self.mlp_opacity.load_state_dict(sd_opacity)
+        self.mlp_cov.load_state_dict(sd_cov)
+        self.mlp_color.load_state_dict(sd_color)
+        from .codec_driver import _load_latent_codec
+        _load_latent_codec(self.latent_codec, sd_codec)
+        self.latent_codec.update(force=True)
+        self.mlp_grid.load_state_dict(sd_grid)
+        self._level_cache = None
+        return self
+
     # the codec / rate-report methods live in codec_driver.py and are bound here so the
     # reference's call sites (train.py:301-314, test.py:168-177) work unchanged.
     def estimate_final_bits(self):

@@ -80,3 +80,33 @@ def test_plyfile_shim_runs_the_reference_style_calls(tmp_path):
     finally:
         sys.path.pop(0)
         sys.modules.pop("plyfile", None)
+
+
+def test_capture_restore_is_the_reference_checkpoint_tuple(tmp_path):
+    """capture() / restore() (scene/gaussian_model.py:222-286): the 19-entry tuple in the reference's order survives
+    torch.save / torch.load and rebuilds an identical model (tensors, MLPs, prior, bounds, level scale)."""
+    import torch
+    from contextgs_amd.model import GaussianModel
+    torch.manual_seed(0)
+    n, K, D = 40, 10, 50
+    a = GaussianModel(device="cpu")
+    a.set_state(torch.randn(n, 3), torch.randn(n, K, 3), torch.randn(n, K, 1), torch.randn(n, D), torch.randn(n, D // 4),
+                torch.randn(n, 6))
+    a.level_scale, a.spatial_lr_scale = 1.75, 3.0
+    a.x_bound_min, a.x_bound_max = torch.full((1, 3), -2.0), torch.full((1, 3), 2.5)
+    with torch.no_grad():
+        for p in a.latent_codec.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    tup = a.capture()
+    assert len(tup) == 19 and tup[9] is None               # slot 9 is the optimizer state (no driver attached here)
+    torch.save(tup, tmp_path / "chkpnt.pth")
+    b = GaussianModel(device="cpu").restore(torch.load(tmp_path / "chkpnt.pth", weights_only=False))
+    for name in ("_anchor", "_anchor_feat", "_hyper_latent", "_offset", "_mask", "_scaling", "_rotation", "_opacity"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert getattr(a, name).requires_grad == getattr(b, name).requires_grad, name
+    for ma, mb in ((a.mlp_opacity, b.mlp_opacity), (a.mlp_cov, b.mlp_cov), (a.mlp_color, b.mlp_color), (a.mlp_grid, b.mlp_grid),
+                   (a.latent_codec, b.latent_codec)):
+        for (ka, va), (kb, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
+    assert b.level_scale == 1.75 and b.spatial_lr_scale == 3.0
+    assert torch.equal(b.x_bound_min, a.x_bound_min) and torch.equal(b.x_bound_max, a.x_bound_max)
