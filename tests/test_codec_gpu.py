@@ -161,6 +161,12 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed):
                                      return_sum_bits=True)
     est_bits = sums[2] + sums[3] + sums[4]
     assert 0.65 * est_bits <= coded <= 1.08 * est_bits
+    # the mask stream of the container (scene/gaussian_model.py:1265-1269; coded by the branch-free host loop on a pool
+    # thread) is byte for byte the bit-list oracle's stream for the same symbols and probability
+    prob = float(meta[8])
+    sym = ((enc.get_mask[m].reshape(-1) > 0).to(torch.int64)).cpu().tolist()
+    row = ref.float_cdf_to_int([0.0, float(np.float32(1.0) - np.float32(prob)), 1.0])
+    assert open(os.path.join(d, "masks.b"), "rb").read() == ref.ac_encode([row] * len(sym), sym)
 
 
 def test_grouped_launch_is_byte_identical_to_per_group_launches():
