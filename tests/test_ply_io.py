@@ -110,3 +110,12 @@ def test_capture_restore_is_the_reference_checkpoint_tuple(tmp_path):
             assert ka == kb and torch.equal(va, vb), ka
     assert b.level_scale == 1.75 and b.spatial_lr_scale == 3.0
     assert torch.equal(b.x_bound_min, a.x_bound_min) and torch.equal(b.x_bound_max, a.x_bound_max)
+
+
+def test_attribute_names_equal_the_reference_list():
+    """tests/golden/ply_names.json: the reference's construct_list_of_attributes() for the default shapes
+    (generated by tools/make_goldens.py from the reference's own method)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ply_names.json")))
+    assert ply_io.model_attribute_names(g["n_offsets"], g["feat_dim"], g["hyper_dim"]) == g["names"]

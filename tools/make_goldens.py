@@ -385,6 +385,18 @@ def golden_entropy_api():
     np.savez_compressed(os.path.join(OUT, "entropy_api.npz"), **out)
 
 
+def golden_ply_names():
+    """The reference's own attribute list of the model ply (scene/gaussian_model.py:561-576, a pure-Python method) for the
+    default shapes: the header our writer must produce.  (plyfile itself is absent, so no reference-written file exists.)"""
+    import json
+    from scene.gaussian_model import GaussianModel
+    shapes = types.SimpleNamespace(_offset=torch.zeros(1, 10, 3), _mask=torch.zeros(1, 10, 1), _anchor_feat=torch.zeros(1, 50),
+                                   _hyper_latent=torch.zeros(1, 12), _scaling=torch.zeros(1, 6), _rotation=torch.zeros(1, 4))
+    names = GaussianModel.construct_list_of_attributes(shapes)
+    with open(os.path.join(OUT, "ply_names.json"), "w") as f:
+        json.dump({"n_offsets": 10, "feat_dim": 50, "hyper_dim": 12, "names": names}, f)
+
+
 def main():
     assert os.path.isdir(REF), "the reference mount is required"
     os.makedirs(OUT, exist_ok=True)
@@ -395,6 +407,7 @@ def main():
     with CudaToCpu():
         golden_elementwise()
         golden_entropy_api()
+        golden_ply_names()
         golden_model(64, 1, "n64")
         golden_model(3000, 2, "n3000")
         golden_model(10000, 4, "n10000", 5)
