@@ -144,6 +144,10 @@ SIGNATURES = {
     "cgs_l1_ssim_partials": (c_size_t, [c_int, c_int, c_int]),
     "cgs_l1_ssim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_l1_ssim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cgs_anchor_gen_count": (c_int, [c_void_p] * 14 + [c_int64, c_int, C.POINTER(c_int64), c_void_p]),
+    "cgs_anchor_gen_write": (c_int, [c_void_p] * 20 + [c_int64, c_int, c_void_p]),
+    "cgs_anchor_gen_bwd_scratch_bytes": (c_size_t, [c_int64, c_int]),
+    "cgs_anchor_gen_backward": (c_int, [c_void_p] * 32 + [c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "cgs_expand_scratch_bytes": (c_size_t, [c_int64, c_int]),
     "cgs_expand_count": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, C.POINTER(c_int64), c_void_p]),

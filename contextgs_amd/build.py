@@ -28,6 +28,9 @@ ARCH = "gfx950"
 # encoder/decoder see bit-identical CDFs.
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
             "-Wall", "-Wno-unused-function", f"-I{INCLUDE}"]
+# tools/ only: extra defines for timing experiments (e.g. CGS_EXTRA_FLAGS="-DCGS_EXPERIMENTS -DAG_ABL=1"); the flags are
+# part of the build stamp, so an experiment build never masquerades as the product library
+CXXFLAGS += os.environ.get("CGS_EXTRA_FLAGS", "").split()
 
 
 def hipcc() -> str:

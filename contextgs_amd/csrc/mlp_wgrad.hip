@@ -439,3 +439,22 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// Sum `blocks` per-workgroup images laid out [dW | db] per product (the layout of WgmProducts) into the products'
+// gradient buffers: the reduction half of the two-pass scheme, for kernels that build the images themselves
+// (anchor_gen.hip).
+int cgs_launch_wgrad_reduce(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, hipStream_t s) {
+    if (nprod <= 0 || nprod > WGM_MAX_PROD || blocks <= 0) { cgs_set_error("wgrad_reduce: bad args"); return CGS_ERR_ARG; }
+    WgmProducts pr;
+    int E = 0;
+    for (int k = 0; k < nprod; ++k) {
+        pr.dW[k] = prods[k].dW; pr.db[k] = prods[k].db; pr.off[k] = E; pr.dadb[k] = prods[k].DA * prods[k].DB;
+        E += prods[k].DA * prods[k].DB + prods[k].DA;
+    }
+    for (int k = nprod; k < WGM_MAX_PROD; ++k) { pr.dW[k] = nullptr; pr.db[k] = nullptr; pr.off[k] = E; pr.dadb[k] = 0; }
+    pr.off[WGM_MAX_PROD] = E;
+    pr.nprod = nprod;
+    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, partial, blocks, E, pr);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -17,7 +17,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _lib, mlp
+from . import _lib, anchor_gen, mlp
 from .context_model import LazyRows, begin_step, gather_unique, multi_scale_generating, multi_scale_generating_visible
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
@@ -127,6 +127,57 @@ def _anchor_mlps(pc, x):
     return op_raw, color, cov
 
 
+def _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K):
+    """:106-145 as one autograd node over the fused kernel family (anchor_gen.py): MLP input assembly, the three anchor
+    MLPs, mask, compaction and the per-Gaussian tail.  None when the shapes are not the ones the kernels are built for."""
+    mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    fs, fr = (feat.src, feat.idx) if isinstance(feat, LazyRows) else (feat, None)
+    lazy_s, lazy_o = isinstance(grid_scaling, LazyRows), isinstance(grid_offsets, LazyRows)
+    if lazy_s and lazy_o and grid_scaling.idx is grid_offsets.idx:
+        gsrc, osrc, grow = grid_scaling.src, grid_offsets.src, grid_scaling.idx
+    elif not lazy_s and not lazy_o:
+        gsrc, osrc, grow = grid_scaling, grid_offsets, None
+    else:
+        return None
+    if not (fs.dim() == 2 and fs.shape[1] == 50 and gsrc.dim() == 2 and gsrc.shape[1] == 6
+            and anchor_gen.supported(mo, mc, mv, K, fs, fr, anchor, gsrc, osrc, grow, binary_grid_masks)):
+        return None
+    return anchor_gen.anchor_gen(fs, fr, anchor, viewpoint_camera.camera_center, gsrc, osrc, grow,
+                                 binary_grid_masks.reshape(-1, K), mo, mc, mv)
+
+
+def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K):
+    """The same stage as separate launches: fused three-MLP kernel (or torch) + the expansion kernels."""
+    mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+    if (isinstance(feat, LazyRows) and feat.src.dim() == 2 and feat.src.shape[1] == 50 and feat.src.is_cuda
+            and mlp.anchor_mlp3_supported(mo, mc, mv)):
+        # :106-127 in one launch: the visibility gather of the context model's output, the view direction / distance
+        # and the [feat, view, dist] concatenation happen inside the fused three-MLP kernel's operand load (and its
+        # backward scatters straight into the source rows): no [n,54] gather / scatter / norm / div launches
+        op_raw, color_in, cov_in = mlp.anchor_mlp3_rows(feat.src, feat.idx, anchor, viewpoint_camera.camera_center,
+                                                        mo, mc, mv)
+    else:
+        ob_view = anchor - viewpoint_camera.camera_center                               # :106-110
+        ob_dist = ob_view.norm(dim=1, keepdim=True)
+        ob_view = ob_view / ob_dist
+        if isinstance(feat, LazyRows):
+            # the visibility gather of the context model's output and this concatenation are one launch (and one
+            # scatter on the way back) instead of a gather + a cat
+            cat_local_view = feat.cat_with(ob_view, ob_dist)
+        else:
+            cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
+        op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                      # :112-127
+    src_row = None
+    if isinstance(grid_scaling, LazyRows) and isinstance(grid_offsets, LazyRows) and grid_scaling.idx is grid_offsets.idx:
+        # the expansion kernels read the context model's coding-order outputs through the row index themselves
+        src_row, grid_scaling, grid_offsets = grid_scaling.idx, grid_scaling.src, grid_offsets.src
+    else:
+        grid_scaling = grid_scaling.materialize() if isinstance(grid_scaling, LazyRows) else grid_scaling
+        grid_offsets = grid_offsets.materialize() if isinstance(grid_offsets, LazyRows) else grid_offsets
+    return _ExpandGaussians.apply(
+        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K, src_row)
+
+
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0):   # :25-150
     time_sub = 0
     if visible_mask is None:
@@ -179,35 +230,11 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
             bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
         binary_grid_masks = sel(binary_all)
 
-    mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
-    if (isinstance(feat, LazyRows) and feat.src.dim() == 2 and feat.src.shape[1] == 50 and feat.src.is_cuda
-            and mlp.anchor_mlp3_supported(mo, mc, mv)):
-        # :106-127 in one launch: the visibility gather of the context model's output, the view direction / distance
-        # and the [feat, view, dist] concatenation happen inside the fused three-MLP kernel's operand load (and its
-        # backward scatters straight into the source rows): no [n,54] gather / scatter / norm / div launches
-        op_raw, color_in, cov_in = mlp.anchor_mlp3_rows(feat.src, feat.idx, anchor, viewpoint_camera.camera_center,
-                                                        mo, mc, mv)
-    else:
-        ob_view = anchor - viewpoint_camera.camera_center                               # :106-110
-        ob_dist = ob_view.norm(dim=1, keepdim=True)
-        ob_view = ob_view / ob_dist
-        if isinstance(feat, LazyRows):
-            # the visibility gather of the context model's output and this concatenation are one launch (and one
-            # scatter on the way back) instead of a gather + a cat
-            cat_local_view = feat.cat_with(ob_view, ob_dist)
-        else:
-            cat_local_view = torch.cat([feat, ob_view, ob_dist], dim=1)
-        op_raw, color_in, cov_in = _anchor_mlps(pc, cat_local_view)                      # :112-127
     K = pc.n_offsets
-    src_row = None
-    if isinstance(grid_scaling, LazyRows) and isinstance(grid_offsets, LazyRows) and grid_scaling.idx is grid_offsets.idx:
-        # the expansion kernels read the context model's coding-order outputs through the row index themselves
-        src_row, grid_scaling, grid_offsets = grid_scaling.idx, grid_scaling.src, grid_offsets.src
-    else:
-        grid_scaling = grid_scaling.materialize() if isinstance(grid_scaling, LazyRows) else grid_scaling
-        grid_offsets = grid_offsets.materialize() if isinstance(grid_offsets, LazyRows) else grid_offsets
-    xyz, color, opacity, scaling, rot, neural_opacity, mask = _ExpandGaussians.apply(
-        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K, src_row)
+    out = _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
+    if out is None:
+        out = _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
+    xyz, color, opacity, scaling, rot, neural_opacity, mask = out
 
     if is_training:                                                                      # :147-150
         return (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, 16, bit_per_feat_param,

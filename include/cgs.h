@@ -24,8 +24,14 @@
  *   cgs_entropy_gaussian_*     utils/entropy_models.py:30-50,141-156
  *   cgs_ste_multistep,
  *   cgs_quantize_anchor        utils/encodings.py:203-231
- *   cgs_level_*                utils/multi_level.py:3-31,
+ *   cgs_sort_pairs_u32         the three stable key sorts behind
+ *                              utils/multi_level.py:3-31 (torch.unique(dim=0)
+ *                              with indices; the run-head bookkeeping around
+ *                              them is torch code in contextgs_amd/multi_level.py),
  *                              scene/gaussian_model.py:1751-1765
+ *   cgs_anchor_gen_*           generate_neural_gaussians' anchor MLPs + mask +
+ *                              compaction + per-Gaussian tail as one fused
+ *                              kernel family (gaussian_renderer/__init__.py:106-145)
  *   cgs_ac_*                   torchac.encode_float_cdf / decode_float_cdf as
  *                              called from utils/encodings.py:108,138,157,178
  *   cgs_gaussian_codec_*       encoder_gaussian / decoder_gaussian
@@ -503,6 +509,65 @@ int cgs_rans_decode_rows_host(const uint8_t *in, size_t in_len, int C, int64_t n
                               const int32_t *cdf, int max_len, const int32_t *cdf_len,
                               const int32_t *offset, int prec, const float *medians,
                               float *out_rows, int64_t ld_rows);
+
+/* ------------------------------------------------------------------ */
+/* Fused anchor MLPs + expansion (gaussian_renderer/__init__.py:106-145)  */
+/* ------------------------------------------------------------------ */
+/* The cgs_anchor_mlp3_*_rows + cgs_expand_* pipeline as one kernel family in
+ * which the 110 MLP outputs per anchor, the 150-float hidden layer, the
+ * [n,54] MLP input and all their gradients stay in registers / LDS (K must be
+ * 10, the shape of the three heads).  Visible anchor r reads its feature row
+ * feat_src[feat_row[r]] ([*,50]) and its geometry rows gs_src[geo_row[r]]
+ * ([*,6]) / off_src[geo_row[r]] ([*,K*3]); either index may be NULL
+ * (identity).  mask [n,K] = get_mask of the visible anchors.
+ *   cgs_anchor_gen_count: opacity head + mask (:112-116,129-130) ->
+ *     neural_opacity [n*K], y_op [n,K] (tanh output; NULL for inference),
+ *     mask_out [n*K] bool bytes (may be NULL), bits [n] (bit k = slot k
+ *     survives), base16 [ceil(n/16)+1] exclusive prefix of the survivor
+ *     counts per 16 anchors (total last); *count_host = survivors P (the
+ *     one stream synchronisation of boolean indexing, :137).
+ *   cgs_anchor_gen_write: colour / covariance heads (W1..b2: HOST arrays of
+ *     two device pointers: colour, covariance) + the compacted Gaussians
+ *     xyz/color/scaling [P,3], opacity [P], rot [P,4], siginv [P,4] (saved
+ *     for the backward; NULL for inference).
+ *   cgs_anchor_gen_backward: gradients of everything above.  g_* [P,.];
+ *     g_neural_opacity [n*K] or NULL.  W1/b1/W2 and dW2/db2: HOST arrays of
+ *     three device pointers (opacity, colour, covariance).  Written:
+ *     d_feat_src rows feat_row[r], d_gs / d_off rows geo_row[r] (other rows
+ *     are the caller's to zero), d_anchor [n,3], d_mask [n,K]; weight / bias
+ *     gradients are ACCUMULATED into dW1cat [150,54], db1cat [150], dW2[i],
+ *     db2[i].  fused != 0: the weight gradients are formed inside the same
+ *     kernel (hidden layer recomputed, nothing but per-workgroup partial sums
+ *     leaves the chip); 0: operands written to scratch for a separate launch. */
+int cgs_anchor_gen_count(const float *feat_src, const int64_t *feat_row,
+                         const float *anchor_vis, const float *cam3, const float *mask,
+                         const float *W1, const float *b1, const float *W2, const float *b2,
+                         float *y_op, float *neural_opacity, uint8_t *mask_out,
+                         uint32_t *bits, uint32_t *base16, int64_t n, int K,
+                         int64_t *count_host, void *stream);
+int cgs_anchor_gen_write(const float *feat_src, const int64_t *feat_row,
+                         const float *anchor_vis, const float *cam3, const float *gs_src,
+                         const float *off_src, const int64_t *geo_row,
+                         const float *neural_opacity, const uint32_t *bits,
+                         const uint32_t *base16, const float *const *W1,
+                         const float *const *b1, const float *const *W2,
+                         const float *const *b2, float *xyz, float *color, float *opacity,
+                         float *scaling, float *rot, float *siginv, int64_t n, int K,
+                         void *stream);
+size_t cgs_anchor_gen_bwd_scratch_bytes(int64_t n, int fused);
+int cgs_anchor_gen_backward(const float *feat_src, const int64_t *feat_row,
+                            const float *anchor_vis, const float *cam3, const float *gs_src,
+                            const float *off_src, const int64_t *geo_row, const float *mask,
+                            const float *y_op, const uint32_t *bits, const uint32_t *base16,
+                            const float *color, const float *rot, const float *siginv,
+                            const float *g_xyz, const float *g_color, const float *g_opacity,
+                            const float *g_scaling, const float *g_rot,
+                            const float *g_neural_opacity, const float *const *W1,
+                            const float *const *b1, const float *const *W2, float *d_feat_src,
+                            float *d_anchor, float *d_gs, float *d_off, float *d_mask,
+                            float *dW1cat, float *db1cat, float *const *dW2,
+                            float *const *db2, int64_t n, int K, int fused, void *scratch,
+                            size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* Anchor -> Gaussian expansion (gaussian_renderer/__init__.py:112-145)   */
