@@ -55,6 +55,7 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+#ifdef CGS_EXPERIMENTS   // round 1's quadrant-mapped kernels: experiment builds only (tools/)
 __global__ void __launch_bounds__(BLEND_THREADS)
     blend_fwd_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
@@ -144,18 +145,26 @@ __global__ void __launch_bounds__(BLEND_THREADS)
     if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
 }
 
-// CGS_BLEND_ROWS=0 selects the quadrant-mapped kernels of this file, anything else (default) the row-mapped ones of
-// raster_blend_rows.hip (A/B knob; both give the same image and gradients)
+#endif  // CGS_EXPERIMENTS
+// The product library has ONE blend path: the row-mapped kernels of raster_blend_rows.hip.  The quadrant-mapped kernels
+// of this file (round 1's mapping) and every timing ablation exist only in -DCGS_EXPERIMENTS builds (tools/), where
+// CGS_BLEND_ROWS=0 selects them.
+#ifdef CGS_EXPERIMENTS
 static bool blend_rows_enabled() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("CGS_BLEND_ROWS"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
+#endif
 
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_FWD, stream);
+#ifndef CGS_EXPERIMENTS
+    (void)tx; (void)ty;
+    return cgs_launch_blend_fwd_rows(cfg, g, b, im, out_color, stream);
+#else
     if (blend_rows_enabled()) return cgs_launch_blend_fwd_rows(cfg, g, b, im, out_color, stream);
     hipLaunchKernelGGL(blend_fwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
@@ -163,11 +172,13 @@ int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
                        im.n_contrib, im.tile_last);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
+#endif
 }
 
 // ---------------------------------------------------------------------------
 // Backward
 // ---------------------------------------------------------------------------
+#ifdef CGS_EXPERIMENTS
 // Full-wave sum on the DPP network (no LDS crossbar): after the 6 steps lane 63
 // holds the total of all 64 lanes.
 template <int CTRL, int ROW_MASK>
@@ -357,11 +368,17 @@ __global__ void __launch_bounds__(BLEND_THREADS)
     }
 }
 
+#endif  // CGS_EXPERIMENTS
+
 int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
                          float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
+#ifndef CGS_EXPERIMENTS
+    (void)tx; (void)ty;
+    return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
+#else
     if (blend_rows_enabled() && !getenv("CGS_BWD_ABLATE")) {
         return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
     }
@@ -377,6 +394,7 @@ int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
 #undef BWD_LAUNCH
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
+#endif
 }
 
 // R_eff / non-empty tile statistics for the roofline accounting.

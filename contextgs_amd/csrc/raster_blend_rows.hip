@@ -372,14 +372,17 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
                               float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
-    static int abl = -1;        // CGS_ROWS_ABL=1..4: timing experiments only (wrong gradients)
-    if (abl < 0) { const char *e = getenv("CGS_ROWS_ABL"); abl = e ? atoi(e) : 0; }
 #define RB_BWD(A)                                                                                                     \
     hipLaunchKernelGGL(blend_bwd_rows_kernel<A>, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream,              \
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,                             \
                        (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, (const float *)im.final_T,      \
                        (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px,         \
                        dL_dconic, dL_dopacity, dL_dcolors)
+#ifndef CGS_EXPERIMENTS
+    RB_BWD(0);
+#else
+    static int abl = -1;        // CGS_ROWS_ABL=1..7: timing experiments only (wrong gradients), tools/rows_ablate.sh
+    if (abl < 0) { const char *e = getenv("CGS_ROWS_ABL"); abl = e ? atoi(e) : 0; }
     switch (abl) {
         case 1: RB_BWD(1); break;
         case 2: RB_BWD(2); break;
@@ -390,6 +393,7 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
         case 7: RB_BWD(7); break;
         default: RB_BWD(0);
     }
+#endif
 #undef RB_BWD
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;

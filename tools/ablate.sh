@@ -1,3 +1,7 @@
+# needs the experiment build of the library: CGS_EXTRA_FLAGS="-DCGS_EXPERIMENTS" python -m contextgs_amd.build (and the
+# same CGS_EXTRA_FLAGS exported for the runs, it is part of the build stamp); rebuild without it afterwards
+export CGS_EXTRA_FLAGS="-DCGS_EXPERIMENTS"
+python -m contextgs_amd.build > /dev/null || exit 1
 python -m pytest tests/test_raster_gpu.py -x -q 2>&1 | tail -3
 for a in 0 2 3; do
   CGS_BWD_ABLATE=$a python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-raster-only --step-semantics 1000 2>/dev/null | python -c "
