@@ -361,8 +361,12 @@ class StagedFiles:
             pos += n
         self.total = pos
         self.device = device
-        self.dev_buf = torch.empty(pos + 64, dtype=torch.uint8, device=device)
         self.stream = torch.cuda.Stream(device=device)
+        # allocated UNDER the side stream (the caching allocator then never hands out a block that kernels queued on
+        # the caller's stream may still be reading); consumers on other streams are registered in get()
+        self.stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(self.stream):
+            self.dev_buf = torch.empty(pos + 64, dtype=torch.uint8, device=device)
         import threading
         self.ready = {p_: threading.Event() for p_ in self.names}     # host side: the file's copy has been enqueued
         self.events = {}                                              # device side: the file's bytes have arrived
@@ -405,7 +409,9 @@ class StagedFiles:
         self.ready[name].wait()
         if self.error is not None:
             raise self.error
-        torch.cuda.current_stream().wait_event(self.events[name])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.events[name])
+        self.dev_buf.record_stream(cur)       # the buffer belongs to the side stream's pool: keep it alive for this consumer
         pos, n = self.off[name]
         return self.dev_buf[pos:pos + n]
 

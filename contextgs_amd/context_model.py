@@ -662,8 +662,10 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         xm_feat = xm_scaling = xm_offsets = None
         src0 = next((L["side_src"] for L in levels if L.get("side_src") is not None), None)
         # (valid when the level kernels read exactly pc's parameters: multi_scale_generating is also callable on other tensors)
+        s_is_pc = src0 is not None and ((pc.decoded_version and src0.s_orig is pc._scaling)
+                                        or getattr(src0.s_orig, "_cgs_exp_of", None) is pc._scaling)
         if (src0 is not None and src0.rows_read == n and src0.f.data_ptr() == pc._anchor_feat.data_ptr()
-                and src0.o.data_ptr() == pc._offset.data_ptr() and src0.s.shape == pc._scaling.shape):
+                and src0.o.data_ptr() == pc._offset.data_ptr() and s_is_pc):
             x_means_fused = src0.means()        # accumulated by the level kernels while they read the rows
         else:
             x_means_fused = _ctx.means3(pc._anchor_feat, pc._scaling, pc._offset, exp_b=not pc.decoded_version)

@@ -101,9 +101,6 @@ def next_seed() -> int:
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
 
 
-_sums_ws = {}
-
-
 class RowSource:
     """The three per-anchor parameter tensors (features [N,D], scaling [N,S], offsets [N,K,3]) read THROUGH a row
     index by the level kernels, instead of being gathered into coding order first.
@@ -117,6 +114,7 @@ class RowSource:
     def __init__(self, feat, scal, off, complete: bool):
         self.shapes = (feat.shape, scal.shape, off.shape)
         self.f, self.s = _c(feat.detach()), _c(scal.detach())
+        self.s_orig = scal                      # the tensor the caller passed (rate_model checks WHOSE scaling it is)
         self.o = _c(off.detach()).reshape(off.shape[0], -1)
         _lib.require_device(self.f, self.s, self.o)
         self.complete = bool(complete)          # the levels' rows cover every row: no zero fill needed
@@ -126,16 +124,10 @@ class RowSource:
         self.token = _RowSourceFn.apply(self, feat, scal, off)
 
     def sums_buffer(self):
-        """The accumulator the level kernels add the sums of their source rows to (zeroed by means())."""
+        """The accumulator the level kernels add the sums of their source rows to: private to this RowSource (two sources
+        alive at once — interleaved forwards, a second stream — never share partial sums), zeroed at creation."""
         if self.sums is None:
-            dev = self.f.device
-            ws = _sums_ws.get(dev)
-            if ws is None:
-                ws = _sums_ws[dev] = [torch.zeros(int(_lib.lib().cgs_means_accum_doubles()), dtype=torch.float64, device=dev), False]
-            if ws[1]:                   # a previous step accumulated but never finalised (it raised): start clean
-                ws[0].zero_()
-            ws[1] = True
-            self.sums = ws[0]
+            self.sums = torch.zeros(int(_lib.lib().cgs_means_accum_doubles()), dtype=torch.float64, device=self.f.device)
         return self.sums
 
     def means(self):
@@ -147,7 +139,6 @@ class RowSource:
         out = torch.empty(3, dtype=_f32, device=self.f.device)
         _lib.check(_lib.lib().cgs_means_finalize(_lib.ptr(self.sums), self.f.numel(), self.s.numel(), self.o.numel(),
                                                  _lib.ptr(out), _lib.current_stream()), "cgs_means_finalize")
-        _sums_ws[self.f.device][1] = False
         return out
 
     def grad_buffers(self):

@@ -80,6 +80,10 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
     dev = params[0].device
     avg_in_collective = average and dist.get_backend() == "nccl"       # RCCL averages inside the collective
     op = dist.ReduceOp.AVG if avg_in_collective else dist.ReduceOp.SUM
+    # a parameter NO rank produced a gradient for keeps .grad = None (the optimiser skips it, as on one GPU: mlp_grid /
+    # latent_codec / _hyper_latent before iteration 10 000); zeros are filled in only where SOME rank has a gradient
+    has = _any_rank_has_grad(params, dev)
+    params = [p for p, h in zip(params, has) if h]
     pending = []
     for p in params:
         if p.numel() >= BIG_TENSOR:
@@ -112,6 +116,15 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = Tr
     return int(sum(p.numel() for p in params))
 
 
+def _any_rank_has_grad(params, dev) -> list:
+    """[some rank has .grad for p  for p in params]: ONE small MAX all-reduce (host tensor on gloo)."""
+    local = [0 if p.grad is None else 1 for p in params]
+    on_dev = dist.get_backend() == "nccl"
+    m = torch.tensor(local, dtype=torch.int32, device=dev if on_dev else "cpu")
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return [bool(v) for v in m.tolist()]
+
+
 class GradientSync:
     """Gradient all-reduce that starts DURING the backward (SURVEY 8e "overlap with the tail of backward").
 
@@ -142,6 +155,11 @@ class GradientSync:
         self._pos = {id(p): k for k, p in enumerate(self.big)}
         self._ready, self._seen, self._next, self._pending = set(), [], 0, []
         self._order_synced = False
+        # big tensors expected to receive a gradient on some rank this step = those that did last step (agreed on by all
+        # ranks through finish()'s mask all-reduce); only these are issued from the hooks, so a tensor nobody differentiates
+        # (e.g. _hyper_latent before iteration 10 000) costs no zero all-reduce and keeps .grad = None
+        self._active = set(range(len(self.big)))
+        self._filled = set()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.big]
         self.bytes_reduced = 0
 
@@ -158,6 +176,7 @@ class GradientSync:
     def _issue(self, p):
         if p.grad is None:
             p.grad = torch.zeros_like(p)
+            self._filled.add(id(p))
         elif not p.grad.is_contiguous():
             p.grad = p.grad.contiguous()
         op, in_coll = self._op()
@@ -184,8 +203,14 @@ class GradientSync:
         return idx, compact, dist.all_reduce(compact, op=op, async_op=True)
 
     def _drain_ready(self):
-        while self._next < len(self.order) and self.order[self._next] in self._ready:
-            self._issue(self.big[self.order[self._next]])
+        while self._next < len(self.order):
+            k = self.order[self._next]
+            if k not in self._active:                      # issued (if at all) from finish(), after the mask
+                self._next += 1
+                continue
+            if k not in self._ready:
+                break
+            self._issue(self.big[k])
             self._next += 1
 
     def _on_grad(self, p):
@@ -198,23 +223,40 @@ class GradientSync:
 
     # -- API ----------------------------------------------------------------------------------------------------------
     def finish(self) -> int:
-        """Call after loss.backward(): issues whatever is left (parameters without a gradient contribute zeros), reduces
-        the small-tensor bucket, waits for everything.  Returns the number of bytes that went through collectives."""
+        """Call after loss.backward(): issues whatever is left (a parameter without a gradient on this rank contributes
+        zeros IF some other rank has one; a parameter no rank differentiated keeps .grad = None, so Adam skips it exactly
+        as on one GPU), reduces the small-tensor bucket, waits for everything.  Returns the bytes that went through
+        collectives."""
         w = world()
         self.bytes_reduced = self.bytes_reduced if w > 1 else 0
         if w == 1:
             self._reset()
             return 0
         while self._next < len(self.order):                  # gradient-less (on this rank) or out-of-order leftovers
-            self._issue(self.big[self.order[self._next]])
+            k = self.order[self._next]
+            if k in self._active:
+                self._issue(self.big[k])
             self._next += 1
+        # which parameters have a gradient on SOME rank (one small MAX all-reduce, at the same point of every rank's
+        # collective sequence: after the predicted-active big tensors)
+        every = self.big + self.small
+        local = [0 if (p.grad is None or id(p) in self._filled) else 1 for p in every]
+        on_dev = dist.get_backend() == "nccl"
+        m = torch.tensor(local, dtype=torch.int32, device=every[0].device if on_dev else "cpu")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        has = [bool(v) for v in m.tolist()]
+        has_big, has_small = has[:len(self.big)], has[len(self.big):]
+        for k in range(len(self.big)):                       # mispredicted inactive: reduce now (same order on every rank)
+            if has_big[k] and k not in self._active:
+                self._issue(self.big[k])
         op, in_coll = self._op()
         flat = None
-        if self.small:
-            sizes = [p.numel() for p in self.small]
-            flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.small[0].device)
+        small = [p for p, h in zip(self.small, has_small) if h]
+        if small:
+            sizes = [p.numel() for p in small]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=small[0].device)
             off = 0
-            for p, n in zip(self.small, sizes):
+            for p, n in zip(small, sizes):
                 if p.grad is not None:
                     flat[off:off + n].copy_(p.grad.reshape(-1))
                 else:
@@ -223,7 +265,7 @@ class GradientSync:
             work = dist.all_reduce(flat, op=op, async_op=True)
             self.bytes_reduced += flat.numel() * 4
             off = 0
-            for p, n in zip(self.small, sizes):
+            for p, n in zip(small, sizes):
                 p.grad = flat[off:off + n].view_as(p)
                 off += n
             self._pending.append(("dense", None, flat, work))
@@ -240,6 +282,10 @@ class GradientSync:
                     t /= w
                 if idx is not None:                           # rows outside the union are zero on every rank already
                     p.grad.index_copy_(0, idx, t)
+        for k, p in enumerate(self.big):                      # predicted active, but no rank had a gradient: the zeros
+            if k in self._active and not has_big[k]:           # that kept the collective sequence aligned are dropped
+                p.grad = None
+        self._active = {k for k in range(len(self.big)) if has_big[k]}
         if not self._order_synced:                            # adopt rank 0's completion order from now on
             seen = self._seen + [k for k in range(len(self.big)) if k not in self._seen]
             self.order = broadcast_object(seen, src=0)
@@ -250,6 +296,7 @@ class GradientSync:
 
     def _reset(self):
         self._ready, self._seen, self._next, self._pending, self.bytes_reduced = set(), [], 0, [], 0
+        self._filled = set()
 
 
 _shared_rng_counter = [0]

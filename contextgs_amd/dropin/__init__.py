@@ -80,7 +80,11 @@ def install(patch_reference_python: bool = True) -> list[str]:
         if mod is None:
             return
         for n in names:
-            if hasattr(src, n) and hasattr(mod, n):
+            cur = getattr(mod, n, None)
+            # only names that ARE the reference's functions (defined in gaussian_renderer / utils.loss_utils): an unrelated
+            # script that happens to have its own `render` or `ssim` is left alone
+            owner = getattr(cur, "__module__", "") or ""
+            if hasattr(src, n) and cur is not None and owner.split(".")[0] in ("gaussian_renderer", "utils"):
                 setattr(mod, n, getattr(src, n))
                 patched.append(f"{modname}.{n}")
 

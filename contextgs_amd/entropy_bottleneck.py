@@ -121,7 +121,9 @@ class _HyperStep(torch.autograd.Function):
             if rows is None:
                 g_v = g_sub if g_v is None else g_v + g_sub
             else:
-                g_v = torch.zeros_like(v) if g_v is None else (g_v if g_v.is_contiguous() else g_v.contiguous())
+                # never accumulate into the INCOMING gradient buffer: autograd may hand the same tensor to another
+                # consumer (retain_graph, a second use of v); one [n, C] copy, the rows are added on top
+                g_v = torch.zeros_like(v) if g_v is None else g_v.clone(memory_format=torch.contiguous_format)
                 g_v.index_add_(0, rows, g_sub)
         if g_v is None:
             return None, None, None, None, g_p, None

@@ -73,7 +73,9 @@ class GaussianModel(nn.Module):
     def get_scaling(self):
         if self.decoded_version:
             return self._scaling
-        return torch.exp(self._scaling)          # the reference's `1.0 *` (:291) is an exact no-op: not launched
+        out = torch.exp(self._scaling)           # the reference's `1.0 *` (:291) is an exact no-op: not launched
+        out._cgs_exp_of = self._scaling          # lets the rate model recognise "this is get_scaling of that parameter"
+        return out
 
     def get_mask_pair(self):
         """(get_mask, get_mask_anchor) from ONE evaluation (:295-310): the training step needs both."""

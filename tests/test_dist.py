@@ -183,3 +183,73 @@ def test_gradient_sync_hooks_sparse_rows_and_shared_rng():
     dense_total = (40 * 3 + 40 * 2 + 40 * 1) * 4 + (6 + 2) * 4
     assert res[0][1][0][2] < dense_total
     assert res[0][2] == res[1][2] and res[0][3] != res[1][3]
+
+
+def _nograd_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        cd.BIG_TENSOR = 8
+        torch.manual_seed(0)
+        a = torch.nn.Parameter(torch.randn(20, 2))            # big, always differentiated
+        late = torch.nn.Parameter(torch.randn(20, 1))         # big, no gradient anywhere before step 2 (then rank 1 only):
+        never = torch.nn.Parameter(torch.randn(3))            # the schedule of _hyper_latent / mlp_grid before iteration 10000
+        params = [a, late, never]
+        opt = torch.optim.Adam(params, lr=0.1)
+        sync = cd.GradientSync(params, average=True)
+        trace = []
+        for step in range(4):
+            opt.zero_grad(set_to_none=True)
+            loss = (a * float(rank + 1)).sum()
+            if step >= 2 and rank == 1:
+                loss = loss + (late * 3.0).sum()
+            loss.backward()
+            nbytes = sync.finish()
+            trace.append((late.grad is None, never.grad is None, nbytes,
+                          None if late.grad is None else late.grad.flatten().tolist()))
+            opt.step()
+        sync.close()
+        # the non-hook variant applies the same rule
+        for p in params:
+            p.grad = None
+        (a * 1.0).sum().backward()
+        cd.allreduce_gradients(params)
+        plain = (late.grad is None, never.grad is None, a.grad.flatten().tolist())
+        st = lambda p: int(opt.state[p]["step"]) if p in opt.state and "step" in opt.state[p] else 0
+        q.put((rank, trace, (st(a), st(late), st(never)), late.detach().flatten().tolist(), plain))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameters_without_a_gradient_on_any_rank_stay_without_one():
+    """under world > 1 a parameter no rank differentiated must keep .grad = None, so that Adam's step counter
+    (bias correction) matches single-GPU training; zeros are contributed only where some other rank has a gradient."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nograd_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        trace, steps, late, plain = res[r][1], res[r][2], res[r][3], res[r][4]
+        assert [t[0] for t in trace] == [True, True, False, False] and all(t[1] for t in trace)
+        assert trace[2][3] == [1.5] * 20                        # rank 1's 3.0 averaged with rank 0's zeros
+        assert trace[1][2] < trace[2][2]                         # no zero all-reduce of `late` while nobody has a gradient
+        assert steps == (4, 2, 0)                                # Adam stepped `late` twice, `never` not at all
+        assert plain[0] and plain[1] and plain[2] == [1.0] * 40
+    assert res[0][3] == res[1][3]                                # replicas identical
+    # world-1 reference of the same schedule: two Adam steps on a constant gradient 1.5 move every entry by 2 * lr
+    torch.manual_seed(0)
+    torch.randn(20, 2)
+    late0 = torch.randn(20, 1).flatten()
+    assert torch.allclose(torch.tensor(res[0][3]), late0 - 0.2, atol=1e-5)

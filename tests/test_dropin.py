@@ -64,15 +64,27 @@ def test_install_repoints_a_loaded_script_without_importing_train():
     dropin.install()
     assert "train" not in sys.modules                      # not imported as a side effect
     fake = types.ModuleType("train")
-    fake.render = fake.prefilter_voxel = fake.l1_loss = fake.ssim = object()
+    def ref_fn(module):                                    # stands for a function the reference's module defined
+        f = lambda *a, **k: None
+        f.__module__ = module
+        return f
+    fake.render, fake.prefilter_voxel = ref_fn("gaussian_renderer"), ref_fn("gaussian_renderer")
+    fake.l1_loss, fake.ssim = ref_fn("utils.loss_utils"), ref_fn("utils.loss_utils")
     fake.unrelated = 1
+    own_render = ref_fn("my_viewer")                       # an unrelated script's own `render` must survive install()
+    other = types.ModuleType("__main__")
+    other.render = own_render
+    real_main = sys.modules["__main__"]
+    sys.modules["__main__"] = other
     sys.modules["train"] = fake
     try:
         patched = dropin.install()
         assert fake.render is renderer.render and fake.prefilter_voxel is renderer.prefilter_voxel
         assert fake.l1_loss is loss_utils.l1_loss and fake.ssim is loss_utils.ssim and fake.unrelated == 1
         assert "train.render" in patched and "train.ssim" in patched
+        assert other.render is own_render and "__main__.render" not in patched
     finally:
+        sys.modules["__main__"] = real_main
         del sys.modules["train"]
         for k in [k for k in sys.modules if k.split(".")[0] in ("scene", "utils", "gaussian_renderer", "arguments")]:
             del sys.modules[k]
