@@ -50,3 +50,61 @@ extern "C" int cgs_densify_stats(int64_t n_vis, int K, const int64_t *vis_idx, c
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ---- anchor pruning / growing surgery (scene/gaussian_model.py:673-760, `cat_tensors_to_optimizer`,
+// `_prune_anchor_optimizer`): dst_t[r] = src_t[idx[r]] for r < n_keep, for up to CGS_COMPACT_MAX row-major fp32 tensors
+// (the eight per-anchor parameters with their two Adam moments, the four statistics buffers) in ONE launch — the
+// reference indexes each of them with the same boolean mask, i.e. 24+ (mask scan + gather) launch pairs.
+// clamp_col0 >= 0 (per tensor): columns >= clamp_col0 are clamped to <= clamp_max on the way (the log-scale cap that
+// `_prune_anchor_optimizer` applies to `scaling[:, 3:]`, :741-745).
+#define CGS_COMPACT_MAX 32
+struct CompactArgs {
+    const float *src[CGS_COMPACT_MAX];
+    float *dst[CGS_COMPACT_MAX];
+    int width[CGS_COMPACT_MAX];
+    int clamp_col0[CGS_COMPACT_MAX];
+    int nt;
+    float clamp_max;
+};
+
+__global__ void __launch_bounds__(256) compact_rows_kernel(CompactArgs a, const int64_t *__restrict__ idx, int64_t n_keep) {
+    // a workgroup walks a block of 64 destination rows through every tensor: the index loads are shared, and the
+    // elements of one tensor's row block are contiguous in the destination (coalesced stores)
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)min((int64_t)64, n_keep - r0);
+    __shared__ int64_t sidx[64];
+    if (threadIdx.x < rows) sidx[threadIdx.x] = idx[r0 + threadIdx.x];
+    __syncthreads();
+    for (int t = 0; t < a.nt; ++t) {
+        const float *src = nullptr; float *dst = nullptr; int w = 0, c0 = -1;
+#pragma unroll
+        for (int k = 0; k < CGS_COMPACT_MAX; ++k)
+            if (k == t) { src = a.src[k]; dst = a.dst[k]; w = a.width[k]; c0 = a.clamp_col0[k]; }
+        const int total = rows * w;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int r = e / w, c = e - r * w;
+            float v = src[sidx[r] * w + c];
+            if (c0 >= 0 && c >= c0) v = fminf(v, a.clamp_max);
+            dst[(r0 + r) * w + c] = v;
+        }
+    }
+}
+
+extern "C" int cgs_compact_rows(int nt, const float *const *src, float *const *dst, const int *width,
+                                const int *clamp_col0, float clamp_max, const int64_t *idx, int64_t n_keep, void *stream) {
+    if (nt < 0 || nt > CGS_COMPACT_MAX || n_keep < 0) { cgs_set_error("compact_rows: bad args"); return CGS_ERR_ARG; }
+    if (nt == 0 || n_keep == 0) return CGS_OK;
+    if (!src || !dst || !width || !idx) { cgs_set_error("compact_rows: NULL"); return CGS_ERR_ARG; }
+    CompactArgs a;
+    for (int t = 0; t < CGS_COMPACT_MAX; ++t) {
+        const bool on = t < nt;
+        if (on && (!src[t] || !dst[t] || width[t] < 1)) { cgs_set_error("compact_rows: NULL tensor or width < 1"); return CGS_ERR_ARG; }
+        a.src[t] = on ? src[t] : nullptr; a.dst[t] = on ? dst[t] : nullptr; a.width[t] = on ? width[t] : 0;
+        a.clamp_col0[t] = (on && clamp_col0) ? clamp_col0[t] : -1;
+    }
+    a.nt = nt;
+    a.clamp_max = clamp_max;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n_keep + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a, idx, n_keep);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -4,10 +4,11 @@ Carries exactly the state tensors, accessors and MLP definitions the
 render-and-compress path reads (SURVEY §8a rows a6/a7 and the state-tensor
 table): same attribute and property names, same shapes, same activations, so
 `render()` / `multi_scale_generating()` / the codec accept either this class
-or the reference's own GaussianModel.  The optimiser stays in the reference
-(out of scope); the SURVEY §8(f) widenings live next to this class:
-densification (densify.py), anchor initialisation (knn.py, `create_from_pcd`)
-and the ply files (ply_io.py, `save_ply` / `load_ply_sparse_gaussian`).
+or the reference's own GaussianModel.  The SURVEY §8(f) widenings live next to
+this class: the optimizer set-up and densification (`training_setup`,
+`update_learning_rate`, `training_statis`, `adjust_anchor`, `prune_anchor`,
+`cat_tensors_to_optimizer` -> densify.py), anchor initialisation (knn.py,
+`create_from_pcd`) and the ply files (ply_io.py).
 
 Cited lines are scene/gaussian_model.py unless stated otherwise.
 """
@@ -19,6 +20,23 @@ import torch.nn as nn
 from .encodings import Quantize_anchor
 from .entropy_bottleneck import EntropyBottleneck
 from .entropy_models import Entropy_gaussian
+
+
+def expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000, step_sub=0):
+    """Learning-rate schedule of utils/general_utils.py:49-82: log-linear interpolation from lr_init (step = step_sub)
+    to lr_final (step = max_steps), optionally eased in over lr_delay_steps; 0 for a negative step or a disabled group."""
+    import math
+
+    def at(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        delay = 1.0
+        if lr_delay_steps > 0:
+            delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max((step - step_sub) / (max_steps - step_sub), 0.0), 1.0)
+        return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+    return at
 
 
 class GaussianModel(nn.Module):
@@ -168,6 +186,73 @@ class GaussianModel(nn.Module):
         self._opacity = nn.Parameter(opacity, requires_grad=False)
         self.max_radii2D = torch.zeros(anchor.shape[0], device=dev)
         return self
+
+    # ---- optimizer + densification (:426-559, :656-910) ---------------------------------------------
+    update_depth, update_init_factor, update_hierachy_factor, ste_binary = 3, 100, 4, True     # ctor defaults (:65-72)
+
+    def training_setup(self, training_args):                             # :426-525
+        dev = self._anchor.device
+        N, K = self._anchor.shape[0], self.n_offsets
+        self.percent_dense = training_args.percent_dense
+        self.opacity_accum = torch.zeros(N, 1, device=dev)
+        self.offset_gradient_accum = torch.zeros(N * K, 1, device=dev)
+        self.offset_denom = torch.zeros(N * K, 1, device=dev)
+        self.anchor_demon = torch.zeros(N, 1, device=dev)
+        a, s = training_args, getattr(self, "spatial_lr_scale", 0.0)
+        groups = [
+            {"params": [self._anchor], "lr": a.position_lr_init * s, "name": "anchor"},
+            {"params": [self._offset], "lr": a.offset_lr_init * s, "name": "offset"},
+            {"params": [self._mask], "lr": a.mask_lr_init * s, "name": "mask"},
+            {"params": [self._anchor_feat], "lr": a.feature_lr, "name": "anchor_feat"},
+            {"params": [self._hyper_latent], "lr": a.hyper_latent_lr, "name": "hyper_latent"},
+            {"params": [self._opacity], "lr": a.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": a.scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": a.rotation_lr, "name": "rotation"},
+            {"params": self.mlp_opacity.parameters(), "lr": a.mlp_opacity_lr_init, "name": "mlp_opacity"},
+            {"params": self.mlp_cov.parameters(), "lr": a.mlp_cov_lr_init, "name": "mlp_cov"},
+            {"params": self.mlp_color.parameters(), "lr": a.mlp_color_lr_init, "name": "mlp_color"},
+            {"params": self.latent_codec.parameters(), "lr": a.latent_codec_lr_init, "name": "latent_codec"},
+            {"params": self.mlp_grid.parameters(), "lr": a.mlp_grid_lr_init, "name": "mlp_grid"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        late = 0 if self.ste_binary else 10000
+        sched = lambda pre, scale=1.0, step_sub=0: expon_lr_func(
+            getattr(a, pre + "_lr_init") * scale, getattr(a, pre + "_lr_final") * scale,
+            lr_delay_mult=getattr(a, pre + "_lr_delay_mult"), max_steps=getattr(a, pre + "_lr_max_steps"), step_sub=step_sub)
+        self._schedulers = {"anchor": sched("position", s), "offset": sched("offset", s), "mask": sched("mask", s),
+                            "mlp_opacity": sched("mlp_opacity"), "mlp_cov": sched("mlp_cov"), "mlp_color": sched("mlp_color"),
+                            "latent_codec": sched("latent_codec", step_sub=late), "mlp_grid": sched("mlp_grid", step_sub=late)}
+
+    def update_learning_rate(self, iteration):                           # :527-559
+        for group in self.optimizer.param_groups:
+            f = self._schedulers.get(group["name"])
+            if f is not None:
+                group["lr"] = f(iteration)
+
+    def cat_tensors_to_optimizer(self, tensors_dict):                    # :673-694
+        from . import densify
+        return densify.cat_tensors_to_optimizer(self, tensors_dict)
+
+    def replace_tensor_to_optimizer(self, tensor, name):                 # :656-670
+        from . import densify
+        return densify.replace_tensor_to_optimizer(self, tensor, name)
+
+    def training_statis(self, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
+        from . import densify                                            # :696-713
+        densify.training_statis(self, viewspace_point_tensor, opacity, update_filter, offset_selection_mask, anchor_visible_mask)
+
+    def anchor_growing(self, grads, threshold, offset_mask, rand_fn=None):   # :762-855
+        from . import densify
+        densify.anchor_growing(self, grads, threshold, offset_mask, rand_fn)
+
+    def prune_anchor(self, mask):                                        # :747-760
+        from . import densify
+        densify.prune_anchor(self, mask)
+
+    def adjust_anchor(self, check_interval=100, success_threshold=0.8, grad_threshold=0.0002, min_opacity=0.005,
+                      rand_fn=None, reduce_stats=True):                  # :856-910
+        from . import densify
+        densify.adjust_anchor(self, check_interval, success_threshold, grad_threshold, min_opacity, rand_fn, reduce_stats)
 
     def save_ply(self, path):                                           # :579-598
         import os

@@ -648,6 +648,16 @@ int cgs_densify_stats(int64_t n_vis, int K, const int64_t *vis_idx,
                       float *offset_gradient_accum, float *offset_denom,
                       void *stream);
 
+/* ---- anchor pruning surgery (scene/gaussian_model.py:715-760, `_prune_anchor_optimizer` / `prune_anchor`, and the
+ * statistics compaction of `adjust_anchor` :883-903) ----
+ * dst[t][r, :] = src[t][idx[r], :] for r < n_keep, for nt <= 32 row-major fp32 tensors of widths width[t] in ONE
+ * launch (the eight per-anchor parameters, their Adam moments, the statistics buffers; the reference boolean-indexes
+ * each separately).  src / dst / width / clamp_col0 are HOST arrays.  clamp_col0[t] >= 0: columns >= clamp_col0[t] of
+ * tensor t are capped at clamp_max on the way (the `scaling[:, 3:] > 0.05 -> 0.05` of :741-745); NULL = no clamps. */
+int cgs_compact_rows(int nt, const float *const *src, float *const *dst, const int *width,
+                     const int *clamp_col0, float clamp_max, const int64_t *idx, int64_t n_keep,
+                     void *stream);
+
 /* ---- image loss of the training iteration ----
  * train.py:199-204 with utils/loss_utils.py:17-63: L1 = mean|img - gt| and SSIM (11x11 Gaussian
  * window, sigma 1.5, zero padding, per channel) of two [C,H,W] fp32 images, fused.

@@ -3,11 +3,15 @@ the checker for contextgs_amd/densify.py and csrc/densify.hip.  Imported only by
 
 Follows scene/gaussian_model.py of the reference:
   training_statis  :696-713
+  adjust_anchor    :856-910   (statistics bookkeeping around anchor_growing, prune mask, row compaction of the eight
+                               per-anchor tensors, their Adam moments and the four statistics buffers incl. the
+                               `scaling[:, 3:] > 0.05 -> 0.05` cap of _prune_anchor_optimizer, :741-745)
   anchor_growing   :762-855   (candidate selection, voxel de-duplication against the existing anchors,
                                per-voxel feature max, new-anchor attributes; including the quirk that rounds
                                i > 0 are skipped while no anchor has been added, :774-777)
   Quantize_anchor  utils/encodings.py:219-231 (get_anchor)
-Pinned by tests/golden/densify.npz (outputs of the reference's own methods, tools/make_densify_golden.py).
+Pinned by tests/golden/densify.npz and tests/golden/adjust_anchor.npz (outputs of the reference's own methods,
+tools/make_densify_golden.py, tools/make_adjust_golden.py).
 """
 import numpy as np
 
@@ -84,3 +88,56 @@ def anchor_growing(anchor, offset, scaling, feat, hyper, lo, hi, grads, threshol
         feat = np.concatenate([feat, new_feat])
         hyper = np.concatenate([hyper, new_hyper])
     return rounds
+
+
+def adjust_anchor(params, moments, stats, lo, hi, rands, voxel_size, K, check_interval=100, success_threshold=0.8,
+                  grad_threshold=0.0002, min_opacity=0.005):
+    """One densification round.  params: {group name: array} of the eight per-anchor tensors; moments: {name: (exp_avg,
+    exp_avg_sq)} for the groups that have Adam state; stats: {offset_denom, offset_gradient_accum, opacity_accum,
+    anchor_demon}.  Returns (params, moments, stats) after growing and pruning (inputs are not modified)."""
+    params = {k: v.copy() for k, v in params.items()}
+    moments = {k: (m.copy(), v.copy()) for k, (m, v) in moments.items()}
+    od, oga = stats["offset_denom"].copy(), stats["offset_gradient_accum"].copy()
+    oa, ad = stats["opacity_accum"].copy(), stats["anchor_demon"].copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        grads = oga / od
+    grads[np.isnan(grads)] = 0
+    grads_norm = np.abs(grads[:, 0])                                   # norm over a length-1 axis
+    offset_mask = od[:, 0] > f32(check_interval * success_threshold * 0.5)
+    rounds = anchor_growing(params["anchor"], params["offset"], params["scaling"], params["anchor_feat"],
+                            params["hyper_latent"], lo, hi, grads_norm, grad_threshold, offset_mask, rands, voxel_size, K)
+    for r in rounds:                                                    # cat_tensors_to_optimizer (:673-694)
+        M = r["anchor"].shape[0]
+        rot = np.zeros((M, 4), f32)
+        rot[:, 0] = 1
+        ext = dict(anchor=r["anchor"], scaling=r["scaling"], anchor_feat=r["anchor_feat"], hyper_latent=r["hyper_latent"],
+                   offset=np.zeros((M, K, 3), f32), mask=np.ones((M, K, 1), f32), rotation=rot,
+                   opacity=np.full((M, 1), np.log(f32(0.1) / f32(0.9)), f32))
+        for k in params:
+            params[k] = np.concatenate([params[k], ext[k].astype(f32)])
+            if k in moments:
+                z = np.zeros_like(ext[k], dtype=f32)
+                moments[k] = (np.concatenate([moments[k][0], z]), np.concatenate([moments[k][1], z]))
+        ad = np.concatenate([ad, np.zeros((M, 1), f32)])
+        oa = np.concatenate([oa, np.zeros((M, 1), f32)])
+    od[offset_mask] = 0
+    oga[offset_mask] = 0
+    pad = params["anchor"].shape[0] * K - od.shape[0]
+    od = np.concatenate([od, np.zeros((pad, 1), f32)])
+    oga = np.concatenate([oga, np.zeros((pad, 1), f32)])
+    prune = (oa < f32(min_opacity) * ad)[:, 0]
+    seen = ad[:, 0] > f32(check_interval * success_threshold)
+    prune &= seen
+    keep = ~prune
+    od = od.reshape(-1, K)[keep].reshape(-1, 1)
+    oga = oga.reshape(-1, K)[keep].reshape(-1, 1)
+    oa[seen] = 0
+    ad[seen] = 0
+    oa, ad = oa[keep], ad[keep]
+    for k in params:
+        params[k] = params[k][keep]
+        if k in moments:
+            moments[k] = (moments[k][0][keep], moments[k][1][keep])
+    sc = params["scaling"]
+    sc[:, 3:] = np.minimum(sc[:, 3:], f32(0.05))
+    return params, moments, dict(offset_denom=od, offset_gradient_accum=oga, opacity_accum=oa, anchor_demon=ad)

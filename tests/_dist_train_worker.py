@@ -35,19 +35,28 @@ def main():
     K = pc.n_offsets
     cams = [c.to_torch("cuda") for c in orbit_cameras(8, 320, 180)]
     pipe, bg = SynthPipe(), torch.zeros(3, device="cuda")
-    per_anchor = [pc._anchor, pc._offset, pc._mask, pc._anchor_feat, pc._hyper_latent, pc._scaling]
-    params = [p for p in pc.parameters() if p.requires_grad]
+    import types
+    # the model's own optimizer set-up (scene/gaussian_model.py:426-525) with the reference's default learning rates
+    pc.spatial_lr_scale = 1.0
+    pc.training_setup(types.SimpleNamespace(
+        percent_dense=0.01, position_lr_init=0.0, position_lr_final=0.0, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+        offset_lr_init=0.01, offset_lr_final=0.0001, offset_lr_delay_mult=0.01, offset_lr_max_steps=30000,
+        mask_lr_init=0.01, mask_lr_final=0.0001, mask_lr_delay_mult=0.01, mask_lr_max_steps=30000,
+        feature_lr=0.0075, hyper_latent_lr=0.0075, opacity_lr=0.02, scaling_lr=0.007, rotation_lr=0.002,
+        mlp_opacity_lr_init=0.002, mlp_opacity_lr_final=0.00002, mlp_opacity_lr_delay_mult=0.01, mlp_opacity_lr_max_steps=30000,
+        mlp_cov_lr_init=0.004, mlp_cov_lr_final=0.004, mlp_cov_lr_delay_mult=0.01, mlp_cov_lr_max_steps=30000,
+        mlp_color_lr_init=0.008, mlp_color_lr_final=0.00005, mlp_color_lr_delay_mult=0.01, mlp_color_lr_max_steps=30000,
+        latent_codec_lr_init=0.005, latent_codec_lr_final=0.00001, latent_codec_lr_delay_mult=0.33, latent_codec_lr_max_steps=30000,
+        mlp_grid_lr_init=0.005, mlp_grid_lr_final=0.00001, mlp_grid_lr_delay_mult=0.01, mlp_grid_lr_max_steps=30000))
+    opt = pc.optimizer
+    all_params = lambda: [p for g in opt.param_groups for p in g["params"] if p.requires_grad]
+    params = all_params()
     mgpu.BIG_TENSOR = N                                       # per-anchor tensors in place, MLPs in the bucket
-    opt = torch.optim.Adam([{"params": per_anchor[1:], "lr": 1e-3}, {"params": [pc._anchor], "lr": 0.0},
-                            {"params": [p for p in params if all(p is not q for q in per_anchor)], "lr": 1e-3}])
     sync = mgpu.GradientSync(params, average=True)
-    pc.opacity_accum = torch.zeros(N, 1, device="cuda")
-    pc.anchor_demon = torch.zeros(N, 1, device="cuda")
-    pc.offset_gradient_accum = torch.zeros(N * K, 1, device="cuda")
-    pc.offset_denom = torch.zeros(N * K, 1, device="cuda")
     torch.manual_seed(1000 + rank)                            # the ranks' RNG streams differ from here on (as in training)
     for it, step_sem in enumerate((2000, 5000, 20000, 20000)):
         cam = cams[mgpu.view_for(it, len(cams))]
+        pc.update_learning_rate(step_sem)
         opt.zero_grad(set_to_none=True)
         vis = prefilter_voxel(cam, pc, pipe, bg)
         pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=step_sem)
@@ -57,8 +66,7 @@ def main():
         loss.backward()
         sync.finish()
         opt.step()
-        densify.training_statis(pc, pkg["viewspace_points"], pkg["neural_opacity"], pkg["visibility_filter"],
-                                pkg["selection_mask"], vis)
+        pc.training_statis(pkg["viewspace_points"], pkg["neural_opacity"], pkg["visibility_filter"], pkg["selection_mask"], vis)
         mine = digest(params)
         every = mgpu.gather_objects(mine, dst=0)
         if rank == 0:
@@ -78,9 +86,39 @@ def main():
     if rank == 0:
         assert len(set(every)) == 1, f"replicas grew different anchors: {every}"
         assert every[0][0] > 0, "the test scene must actually grow anchors"
+    # ---- the model's own adjust_anchor (grow + prune + optimizer surgery) on the summed statistics: replicas must end
+    # up with the same anchors, parameters and Adam moments; thresholds scaled to the 4 x 2 views these statistics hold
+    sync.close()
+    ratio = (pc.opacity_accum / pc.anchor_demon.clamp(min=1)).squeeze(1)
+    seen = pc.anchor_demon.squeeze(1) > 2
+    min_op = float(torch.quantile(ratio[seen], 0.2)) if bool(seen.any()) else 0.0
+    n0 = int(pc._anchor.shape[0])
+    pc.update_init_factor = 16
+    pc.adjust_anchor(check_interval=4, success_threshold=0.5, grad_threshold=thr, min_opacity=min_op, reduce_stats=False)
+    n1 = int(pc._anchor.shape[0])
+    moments = [v for p in all_params() for k, v in sorted(opt.state.get(p, {}).items()) if k != "step"]
+    stats = [pc.offset_gradient_accum, pc.offset_denom, pc.opacity_accum, pc.anchor_demon]
+    every = mgpu.gather_objects((n1, digest(all_params()), digest(moments), digest(stats)), dst=0)
+    if rank == 0:
+        assert len(set(every)) == 1, f"replicas differ after adjust_anchor: {every}"
+        assert n1 != n0 and pc.offset_denom.shape[0] == n1 * K and pc.opacity_accum.shape[0] == n1
+    # ... and keep training on the new anchor set (fresh hooks on the new Parameter objects, level plan rebuilt)
+    params = all_params()
+    sync = mgpu.GradientSync(params, average=True)
+    cam = cams[mgpu.view_for(4, len(cams))]
+    opt.zero_grad(set_to_none=True)
+    vis = prefilter_voxel(cam, pc, pipe, bg)
+    pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=20000)
+    ((1.0 - pkg["render"]).abs().mean() + 0.001 * pkg["bit_per_param"]).backward()
+    sync.finish()
+    opt.step()
+    every = mgpu.gather_objects(digest(params), dst=0)
+    if rank == 0:
+        assert len(set(every)) == 1, "replicas diverged in the step after adjust_anchor"
     sync.close()
     dist.barrier()
-    print(f"rank {rank}: replicas identical after 4 optimiser steps; grew {grown} anchors identically", flush=True)
+    print(f"rank {rank}: replicas identical after 4 optimiser steps; grew {grown} anchors identically; "
+          f"adjust_anchor {n0} -> {n1} anchors identically", flush=True)
     dist.destroy_process_group()
 
 

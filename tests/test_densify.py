@@ -88,3 +88,94 @@ def test_anchor_growing_matches_reference_and_scales():
     for s in range(0, grid.shape[0], 4096):
         slow |= (cand.unsqueeze(1) == grid[s:s + 4096]).all(-1).any(-1)
     assert torch.equal(fast, slow)
+
+
+# ---- optimizer set-up + one full densification round against the reference's own training_setup / adjust_anchor ----
+ADJ = os.path.join(os.path.dirname(__file__), "golden", "adjust_anchor.npz")
+GROUPS = ("anchor", "offset", "mask", "anchor_feat", "hyper_latent", "opacity", "scaling", "rotation")
+
+
+def _args(z):
+    import types
+    return types.SimpleNamespace(**{str(k): float(v) for k, v in zip(z["args_names"], z["args_values"])})
+
+
+def test_oracle_adjust_anchor_matches_reference():
+    from oracle.densify_ref import adjust_anchor
+    z = np.load(ADJ)
+    params = {g: z[f"pre_{g}"] for g in GROUPS}
+    moments = {g: (z[f"pre_m_{g}"], z[f"pre_v_{g}"]) for g in GROUPS if bool(z[f"pre_has_state_{g}"])}
+    stats = {k: z[f"pre_{k}"] for k in ("offset_denom", "offset_gradient_accum", "opacity_accum", "anchor_demon")}
+    rands = [z[f"rand{i}"].reshape(-1) for i in range(int(z["draws"]))]
+    p, m, s = adjust_anchor(params, moments, stats, z["bound_min"], z["bound_max"], rands, 0.01, K)
+    assert p["anchor"].shape[0] == int(z["n_after"]) != int(z["n_before"])
+    for g in GROUPS:
+        assert np.array_equal(p[g], z[f"post_{g}"]), g
+        assert (g in m) == bool(z[f"post_has_state_{g}"]), g
+        if g in m:
+            assert np.array_equal(m[g][0], z[f"post_m_{g}"]) and np.array_equal(m[g][1], z[f"post_v_{g}"]), g
+    for k, v in s.items():
+        assert np.array_equal(v, z[f"post_{k}"].astype(np.float32)), k
+
+
+def test_training_setup_groups_and_learning_rate_schedule_match_reference():
+    """Host logic, no kernels: the param groups, their initial learning rates and the per-iteration schedule of
+    `update_learning_rate` against the reference's (OptimizationParams defaults, spatial_lr_scale 1.7)."""
+    import torch
+    from contextgs_amd.model import GaussianModel
+    z = np.load(ADJ)
+    pc = GaussianModel(device="cpu")
+    n = 7
+    pc.set_state(torch.zeros(n, 3), torch.zeros(n, K, 3), torch.zeros(n, K, 1), torch.zeros(n, 50), torch.zeros(n, 12),
+                 torch.zeros(n, 6))
+    pc.spatial_lr_scale = 1.7
+    pc.training_setup(_args(z))
+    assert [g["name"] for g in pc.optimizer.param_groups] == [str(s) for s in z["lr_groups"]]
+    assert np.allclose([g["lr"] for g in pc.optimizer.param_groups], z["lr_initial"], rtol=1e-12, atol=0)
+    assert pc.optimizer.defaults["eps"] == 1e-15
+    for it, row in zip(z["lr_iterations"], z["lr_schedule"]):
+        pc.update_learning_rate(int(it))
+        assert np.allclose([g["lr"] for g in pc.optimizer.param_groups], row, rtol=1e-12, atol=0), int(it)
+    assert pc.opacity_accum.shape == (n, 1) and pc.offset_denom.shape == (n * K, 1)
+
+
+@pytest.mark.gpu
+def test_adjust_anchor_matches_reference_including_the_optimizer_state():
+    import torch
+    from contextgs_amd.model import GaussianModel
+    z = np.load(ADJ)
+    T = lambda k: torch.tensor(z[k], device="cuda")
+    pc = GaussianModel()
+    pc.set_state(T("pre_anchor"), T("pre_offset"), T("pre_mask"), T("pre_anchor_feat"), T("pre_hyper_latent"), T("pre_scaling"))
+    pc.x_bound_min, pc.x_bound_max = T("bound_min"), T("bound_max")
+    pc.spatial_lr_scale = 1.7
+    pc.training_setup(_args(z))
+    for g in pc.optimizer.param_groups:                      # the moments the reference's two Adam steps left behind
+        if g["name"] in GROUPS and bool(z[f"pre_has_state_{g['name']}"]):
+            pc.optimizer.state[g["params"][0]] = {"step": torch.tensor(float(z[f"pre_step_{g['name']}"])),
+                                                  "exp_avg": T(f"pre_m_{g['name']}"), "exp_avg_sq": T(f"pre_v_{g['name']}")}
+    pc.offset_denom, pc.offset_gradient_accum = T("pre_offset_denom"), T("pre_offset_gradient_accum")
+    pc.opacity_accum, pc.anchor_demon = T("pre_opacity_accum"), T("pre_anchor_demon")
+    rands = [T(f"rand{i}").reshape(-1) for i in range(int(z["draws"]))]
+    pc.adjust_anchor(check_interval=100, success_threshold=0.8, grad_threshold=2e-4, min_opacity=0.005,
+                     rand_fn=lambda i, like: rands[i])
+    assert pc._anchor.shape[0] == int(z["n_after"])
+    attr = {"anchor": "_anchor", "offset": "_offset", "mask": "_mask", "anchor_feat": "_anchor_feat",
+            "hyper_latent": "_hyper_latent", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
+    for g in pc.optimizer.param_groups:
+        name = g["name"]
+        if name not in GROUPS:
+            continue
+        p = g["params"][0]
+        assert p is getattr(pc, attr[name]) and p.requires_grad == bool(z[f"post_requires_grad_{name}"]), name
+        assert torch.equal(p.detach(), T(f"post_{name}")), name
+        st = pc.optimizer.state.get(p, None)
+        assert bool(st) == bool(z[f"post_has_state_{name}"]), name
+        if st:
+            assert torch.equal(st["exp_avg"], T(f"post_m_{name}")) and torch.equal(st["exp_avg_sq"], T(f"post_v_{name}")), name
+            assert float(st["step"]) == float(z[f"post_step_{name}"])
+    for k in ("offset_denom", "offset_gradient_accum", "opacity_accum", "anchor_demon", "max_radii2D"):
+        assert torch.equal(getattr(pc, k), T(f"post_{k}").float()), k
+    # the model keeps training after the surgery: one optimizer step on the new parameters
+    (pc._anchor_feat.sum() + pc._offset.sum()).backward()
+    pc.optimizer.step()

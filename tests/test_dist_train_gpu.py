@@ -26,7 +26,7 @@ def test_two_replicas_stay_identical_through_optimiser_steps_and_anchor_growing(
            "--master-port", str(_free_port()), worker, "30000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("replicas identical after 4 optimiser steps") == 2
+    assert r.stdout.count("replicas identical after 4 optimiser steps") == 2 and r.stdout.count("adjust_anchor") == 2
 
 
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
@@ -47,3 +47,14 @@ def test_bench_two_ranks_prints_one_json_line(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["config"]["views_per_step"] == 2
     assert d["value"] > 0 and d["cpu_baseline"] is None and d["codec"]["decoded_anchor_and_masks_bit_exact"]
+
+
+def test_rccl_backend_initialises_and_runs_our_collectives_on_one_rank():
+    """RCCL itself (backend "nccl") at world size 1: init + the collective flavours dist.py issues."""
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rccl_world1_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), worker]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rccl world-1 ok" in r.stdout
