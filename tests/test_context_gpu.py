@@ -215,3 +215,27 @@ def test_generate_neural_gaussians(tag, N, seed):
             a = _sub(g, a)
         assert a.shape == ref.shape, key
         assert np.abs(a - ref).max() <= 2e-4 * max(1e-6, np.abs(ref).max()), (key, np.abs(a - ref).max(), np.abs(ref).max())
+
+
+def test_extract_context_feat_matches_reference_directly():
+    """Row b3 on its own (scene/gaussian_model.py:1711-1724): the reference's extract_context_feat called on the n3000
+    model's level division with two `already_coded` patterns per level (tests/golden/context_feat.npz) — same rows in the
+    same order (quirk Q1: ascending original index), bit-equal values."""
+    from contextgs_amd import context_model as cm
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "context_feat.npz"))
+    pc, _st = _model(3000, 2)
+    pc.level_scale = [float(v) for v in z["level_scale"]]
+    T = lambda k: torch.tensor(z[k], device="cuda")
+    anchor, feat, scal = T("anchor_q"), T("feat"), T("scaling")
+    assert torch.equal(pc.get_anchor.detach(), anchor)
+    _, inverses, mappings, _ = cm.divide_levels(pc, anchor, torch.ones(3000, dtype=torch.bool, device="cuda"))
+    n_cases = 0
+    for key in z.files:
+        if not key.startswith("ctx_l"):
+            continue
+        level = int(key[5])
+        coded = T("coded" + key[3:])
+        got = cm.extract_context_feat(anchor, feat, scal, coded, inverses, mappings, level)
+        assert got.shape == z[key].shape and torch.equal(got, T(key)), key
+        n_cases += 1
+    assert n_cases == 4

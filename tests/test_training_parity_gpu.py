@@ -141,30 +141,45 @@ def test_training_step_outputs_and_every_gradient_match_reference(tag, N, seed, 
     loss = loss + float(RW[0]) * bpp + float(RW[1]) * bf + float(RW[2]) * bs + float(RW[3]) * bo
     loss.backward()
     assert abs(loss.item() - float(g["tr_loss"])) <= 1e-4 * abs(float(g["tr_loss"])) + 1e-3
-    # per-anchor parameters: within 1e-3 of the tensor's largest gradient entry (fp32 accumulation order of the MLP
-    # backward; measured: <= 7e-5 except for a handful of entries).  The rate gradient carries 1/likelihood, and where
-    # the likelihood is tiny the fp32 cancellation of its two CDFs dominates (tests/test_context_gpu.py allows 15 % on
-    # exactly those entries of Entropy_gaussian's own gradient): at most 1e-4 of the entries may sit outside, each
-    # within 2 % of the maximum.  The fixture's level MLPs predict trained-like positive sigmas
-    # (golden_inputs.mlp_weights(positive_scales=True)); with raw random weights most symbols sit on the 1e-6
-    # likelihood floor and the fp32 gradient of BOTH implementations is rounding noise there
+    # ---- gradients: judged against the FP64 run of the reference (tests/golden/train64_*.npz, tools/make_goldens64.py) ----
+    # The reference's OWN fp32 gradients sit up to 1.5e-2 of the tensor maximum away from its fp64 gradients on the
+    # entries that carry 1 / likelihood (the difference of two fp32 normal CDFs cancels there): g_scaling 1.5e-2,
+    # g_offset 7e-3, g_hyper 4e-3, mlp_grid weights up to 4.5e-3 — which is why a plain "HIP vs reference fp32" comparison
+    # needed an outlier allowance in round 2.  The criterion now: on every tensor the HIP path must be AS CLOSE TO THE FP64
+    # TRUTH AS THE REFERENCE'S FP32 RUN IS (within a factor 2 in the max norm, floor 2e-5 of the tensor maximum for
+    # tensors where both are at round-off), and no more entries may sit outside the round-2 tolerance of the fp64 value
+    # than the reference itself leaves there (+2).
+    g64 = np.load(os.path.join(GOLD, f"train64_{tag}.npz"))
+    assert np.array_equal(g64["tr_mask"], g["tr_mask"])
+    stride = int(g["stride"])
+
+    def judge(key, got, ref32, ref64):
+        big = max(float(np.abs(ref64).max()), 1e-12)
+        e_hip, e_ref = np.abs(got - ref64), np.abs(ref32 - ref64)
+        tol = 1e-3 * np.abs(ref64) + 1e-3 * big
+        n_hip, n_ref = int((e_hip > tol).sum()), int((e_ref > tol).sum())
+        print(f"{key:32s} max|ref64| {big:9.3g}  HIP-vs-fp64 {e_hip.max() / big:8.2e}  ref32-vs-fp64 {e_ref.max() / big:8.2e}"
+              f"  outside 1e-3: HIP {n_hip} ref {n_ref} of {e_hip.size}")
+        assert e_hip.max() <= max(2.0 * e_ref.max(), 2e-5 * big), (key, float(e_hip.max()), float(e_ref.max()), big)
+        assert n_hip <= n_ref + 2, (key, n_hip, n_ref)
+
     for key, p in (("g_anchor", pc._anchor), ("g_offset", pc._offset), ("g_mask", pc._mask), ("g_feat", pc._anchor_feat),
                    ("g_hyper", pc._hyper_latent), ("g_scaling", pc._scaling)):
         assert p.grad is not None, key
-        _cmp(g, key, p.grad.reshape(N, -1), 1e-3, 1e-3, outliers=1e-4)
+        a = p.grad.reshape(N, -1).detach().cpu().numpy()
+        sub = a[::stride].reshape(g[key].shape) if stride > 1 else a.reshape(g[key].shape)
+        judge(key, sub, g[key], g64[key])
+        if stride > 1:      # all rows through their fp64 column sums (reference fp32 run)
+            cs, ab = a.astype(np.float64).sum(0), g[key + "__abssum"]
+            assert np.all(np.abs(cs - g[key + "__colsum"]) <= 2e-2 * (ab + 1e-30) + 1e-12), key
     checked = 0
     for name, p in pc.named_parameters():
         k = "gw_" + name
         if k not in g.files:
             continue
-        ref = g[k]
         assert p.grad is not None, name
         a = p.grad.cpu().numpy()
-        assert a.shape == ref.shape, name
-        err, big = float(np.abs(a - ref).max()), float(np.abs(ref).max())
-        print(f"{name:32s} max|ref| {big:10.4g}  max err {err:9.3g}  rel {err / max(big, 1e-12):8.2e}")
-        # level MLPs: sums over rows of rate gradients (1 / likelihood inside): 2e-3 of the largest entry; everything
-        # else (anchor MLPs, hyper prior) is plain fp32 accumulation order: 5e-5
-        assert err <= (2e-3 if name.startswith("mlp_grid") else 5e-5) * max(big, 1e-6), (name, err, big)
+        assert a.shape == g[k].shape, name
+        judge(name, a, g[k], g64[k])
         checked += 1
     assert checked >= 3 * 4 + 3 * 4 + 14, checked       # anchor MLPs, level MLPs, hyper-prior matrices/biases/factors

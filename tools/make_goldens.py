@@ -223,8 +223,12 @@ def pack(out, name, arr, stride):
         out[name + "__abssum"] = np.abs(flat).sum(0)
 
 
-def golden_training(N, seed, tag, stride):
-    """The TRAINING variant of the context / rate path (scene/gaussian_model.py:1594-1707 with training=True,
+def golden_training(N, seed, tag, stride, double=False):
+    """double=True: the same run with every parameter, activation and accumulation in fp64 (same fp32 noise and inputs):
+    the yardstick for WHICH fp32 implementation — the reference's or the HIP path — is closer on the gradient entries
+    where they disagree; only the loss, the rate terms and the gradients are stored (tests/golden/train64_*.npz).
+
+    The TRAINING variant of the context / rate path (scene/gaussian_model.py:1594-1707 with training=True,
     predict_bpp=True) as gaussian_renderer/__init__.py:63-81 calls it at step > 10000, then the expansion, with
     FIXED noise: every torch uniform_ / rand_like the reference draws is replaced by the arrays of
     oracle.context_ref.ctx_noise(seed, tensor, .) (the build's counter-based generator), so the HIP path can be
@@ -234,6 +238,13 @@ def golden_training(N, seed, tag, stride):
     from scene import gaussian_model as gm
     from oracle.context_ref import ctx_noise
     pc = build_reference_model(N, seed, positive_scales=True)      # trained-like sigmas: see golden_inputs.mlp_weights
+    if double:
+        torch.set_default_dtype(torch.float64)
+        pc.double()
+        for a in ("_anchor", "_offset", "_mask", "_anchor_feat", "_hyper_latent", "_scaling", "_rotation", "_opacity"):
+            old = getattr(pc, a)
+            setattr(pc, a, torch.nn.Parameter(old.detach().double(), requires_grad=old.requires_grad))
+        pc.x_bound_min, pc.x_bound_max = pc.x_bound_min.double(), pc.x_bound_max.double()
     pc.train()
     out = {"_meta": np.array(f"training variant, step=20000, N={N} seed={seed} stride={stride}; noise = "
                              f"oracle.context_ref.ctx_noise; EntropyBottleneck stub = contextgs_amd.entropy_bottleneck"),
@@ -274,6 +285,8 @@ def golden_training(N, seed, tag, stride):
     hooks = [pc.mlp_grid[i].register_forward_hook(lambda m, a, o, i=i: preds.__setitem__(i, o.detach().clone()))
              for i in range(pc.level_num)]
     cam = types.SimpleNamespace(camera_center=torch.from_numpy(gi.camera_center(seed)))
+    if double:
+        cam.camera_center = cam.camera_center.double()
     vis = torch.from_numpy(np.random.default_rng(seed + 3).random(N) < 0.8)
     out["visible_mask"] = npy(vis)
     torch.Tensor.uniform_, torch.rand_like = fake_uniform_, fake_rand_like
@@ -304,7 +317,7 @@ def golden_training(N, seed, tag, stride):
     for i in range(pc.level_num):
         pack(out, f"pred_level{i}", preds[i], max(stride, 4))
     rng = np.random.default_rng(seed + 11)
-    ws = [torch.from_numpy(rng.normal(size=tuple(t.shape)).astype(np.float32)) for t in (xyz, color, opacity, scaling, rot)]
+    ws = [torch.from_numpy(rng.normal(size=tuple(t.shape)).astype(np.float32)).to(t.dtype) for t in (xyz, color, opacity, scaling, rot)]
     RW = (50.0, 30.0, 20.0, 10.0)        # weights of the four rate terms in the test loss
     loss = sum((t * w).sum() for t, w in zip((xyz, color, opacity, scaling, rot), ws))
     loss = loss + RW[0] * bit_per_param + RW[1] * bit_per_feat_param + RW[2] * bit_per_scaling_param + RW[3] * bit_per_offsets_param
@@ -322,6 +335,13 @@ def golden_training(N, seed, tag, stride):
     for name, p in pc.named_parameters():
         if name.split(".")[0] in ("mlp_opacity", "mlp_cov", "mlp_color", "mlp_grid", "latent_codec") and p.grad is not None:
             out["gw_" + name] = npy(p.grad)
+    if double:
+        torch.set_default_dtype(torch.float32)
+        keep = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and k.startswith(("g_", "gw_")) and "__" not in k else v)
+                for k, v in out.items() if k.startswith(("g_", "gw_", "tr_loss", "bits", "stride", "tr_mask", "_meta"))}
+        keep["_meta"] = np.array(str(keep["_meta"]) + "; EVERYTHING IN FP64 (parameters .double(), default dtype float64), gradients stored rounded to fp32")
+        np.savez_compressed(os.path.join(OUT, f"train64_{tag}.npz"), **keep)
+        return
     np.savez_compressed(os.path.join(OUT, f"train_{tag}.npz"), **out)
 
 
