@@ -183,12 +183,17 @@ def main():
     value = views / dt
     ms_per_step = dt / args.steps * 1e3
 
-    value_raster = None
+    value_raster = value_mid = None
     if not args.no_raster_only:
         for i in range(max(1, args.warmup // 2)):
             raster(i)
         dt_r = timed(raster, args.steps, dist_on)
         value_raster = views / dt_r
+        # the middle phase (3000 < step <= 10000, gaussian_renderer/__init__.py:54-58): quantisation noise, no context model
+        mid = lambda i: one_step(pc, cam_of(i), pipe, bg, w, 5000, params, sync)
+        for i in range(max(1, args.warmup // 2)):
+            mid(i)
+        value_mid = views / timed(mid, args.steps, dist_on)
     # the same step with the training image loss of train.py:199-209 (fused L1 + SSIM) instead
     # of the metric's fixed linear loss
     value_img_loss = None
@@ -323,6 +328,7 @@ def main():
                        "anchors": N, "image": [W, H], "views_per_step": world, "visible_anchors": n_vis,
                        "gaussians_per_view": P, "tile_pairs_per_view": R, "R_eff": R_eff, "parallelism": f"dp{world}"},
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
+            "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
             "roofline": roofline, "blend_roofline": blend, "kernels": kernels,
             "hip_kernel_ms_per_step": round(lib_ms, 3),

@@ -16,6 +16,15 @@
 #define M3_NT1 4             // ceil(50/16)
 #define M3_HP 64
 #define M3_HCAT 150
+// wave-tile shapes (rows per wave tile = 16 RT, waves per workgroup); overridable for tools/mlp_tiling.sh
+#ifndef M3_FWD_RT
+#define M3_FWD_RT 1
+#define M3_FWD_WAVES 16
+#endif
+#ifndef M3_BWD_RT
+#define M3_BWD_RT 2
+#define M3_BWD_WAVES 8
+#endif
 
 struct M3Head {
     const float *W1, *b1, *W2, *b2;
@@ -369,7 +378,9 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
     if (n < 0) { cgs_set_error("anchor_mlp3_forward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) { cgs_set_error("anchor_mlp3_forward: NULL"); return CGS_ERR_ARG; }
-    constexpr int RT = 2, WAVES = 8;
+    // 16-row wave tiles, 16 waves per workgroup (4 per SIMD, 111-118 VGPRs): 548 -> 510 us at 1 M anchors against the
+    // 32-row / 8-wave shape (tools/mlp_tiling.sh); the backward measured the same either way and keeps 32 / 8
+    constexpr int RT = M3_FWD_RT, WAVES = M3_FWD_WAVES;
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
@@ -396,7 +407,9 @@ extern "C" int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t
         cgs_set_error("anchor_mlp3_forward_rows: NULL");
         return CGS_ERR_ARG;
     }
-    constexpr int RT = 2, WAVES = 8;
+    // 16-row wave tiles, 16 waves per workgroup (4 per SIMD, 111-118 VGPRs): 548 -> 510 us at 1 M anchors against the
+    // 32-row / 8-wave shape (tools/mlp_tiling.sh); the backward measured the same either way and keeps 32 / 8
+    constexpr int RT = M3_FWD_RT, WAVES = M3_FWD_WAVES;
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
@@ -460,7 +473,7 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
         cgs_set_error("anchor_mlp3_backward: NULL");
         return CGS_ERR_ARG;
     }
-    constexpr int RT = 2, WAVES = 8;
+    constexpr int RT = M3_BWD_RT, WAVES = M3_BWD_WAVES;
     M3Head h[3];
     h[0] = M3Head{W1[0], nullptr, W2[0], nullptr, const_cast<float *>(Y_op), dY_op, dZ2_op};
     h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};

@@ -9,7 +9,9 @@
 #define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
 #define SORT_THREADS 256
+#ifndef SORT_ITEMS
 #define SORT_ITEMS 16
+#endif
 #define SORT_TILE (SORT_THREADS * SORT_ITEMS)
 #define SORT_WAVES (SORT_THREADS / CGS_WAVE)
 #define RADIX_BITS 8

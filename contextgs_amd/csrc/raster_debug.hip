@@ -94,3 +94,91 @@ extern "C" int cgs_debug_blend_occupancy(const cgs_raster_cfg *cfg, int64_t P, i
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ---- splat-parallel backward mapping, counted instead of timed ----
+// Mapping under study: lane = Gaussian of a bucket of 64 consecutive list entries, the wave walks the tile's pixels and
+// carries each pixel's transmittance / colour recurrence across the bucket with DPP scans; a lane's nine gradient sums
+// stay in its registers (no 16-lane reduction, no LDS atomics).  Its cost is the number of (pixel, bucket) visits times
+// a wave-instruction count per visit, and its efficiency the fraction of the 64 lanes whose Gaussian actually touches
+// the pixel.  out[0] = (pixel, bucket) pairs up to the pixel's own last contributor, out[1] = those with >= 1 lane hit,
+// out[2] = lane hits (alpha >= 1/255) in them, out[3] = (4x4 block, bucket) pairs with >= 1 hit (a wave could skip whole
+// blocks with one ballot), out[4] = buckets.
+__global__ void __launch_bounds__(256)
+    blend_splat_occupancy_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                                 const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                                 const uint32_t *__restrict__ tile_last, const uint32_t *__restrict__ n_contrib,
+                                 unsigned long long *__restrict__ out) {
+    __shared__ float4 s0[64], s1[64];
+    __shared__ unsigned int blk_any[16];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t tlast = tile_last[tile];
+    const uint2 range = ranges[tile];
+    const int px = tx * 16 + (tid & 15), py = ty * 16 + (tid >> 4);
+    const int blk = (tid >> 6) * 4 + ((tid & 15) >> 2);
+    const uint32_t my_last = (px < W && py < H) ? n_contrib[(size_t)py * W + px] : 0u;
+    unsigned long long pairs = 0, visits = 0, hits = 0, blk_visits = 0, buckets = 0;
+    for (uint32_t base = 0; base < tlast; base += 64) {
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t pos = base + tid;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (pos < tlast) {
+                const uint32_t g = gid_sorted[range.x + pos];
+                a = rec[3 * (size_t)g];
+                b = rec[3 * (size_t)g + 1];
+            } else {
+                b.y = 0.f;      // opacity 0: never hits
+            }
+            s0[tid] = a; s1[tid] = b;
+        }
+        if (tid < 16) blk_any[tid] = 0;
+        __syncthreads();
+        unsigned int h = 0;
+        if (base < my_last) {
+            const uint32_t n = min(64u, my_last - base);
+            for (uint32_t j = 0; j < n; ++j) {
+                const float4 r0 = s0[j], r1 = s1[j];
+                const float dx = r0.x - (float)px, dy = r0.y - (float)py;
+                const float p2 = fmaf(r0.z * dx, dx, fmaf(r1.x * dy, dy, (r0.w * dx) * dy));
+                const float alpha = fminf(0.99f, r1.y * __builtin_amdgcn_exp2f(p2));
+                h += (p2 <= 0.f && alpha >= (1.0f / 255.0f)) ? 1u : 0u;
+            }
+            pairs += 1;
+            visits += h ? 1 : 0;
+            hits += h;
+            if (h) atomicOr(&blk_any[blk], 1u);
+        }
+        __syncthreads();
+        if (tid < 16) blk_visits += blk_any[tid];
+        if (tid == 0) buckets += 1;
+    }
+    // block-level sums
+    __shared__ unsigned long long red[5];
+    if (tid < 5) red[tid] = 0;
+    __syncthreads();
+    atomicAdd(&red[0], pairs); atomicAdd(&red[1], visits); atomicAdd(&red[2], hits); atomicAdd(&red[3], blk_visits); atomicAdd(&red[4], buckets);
+    __syncthreads();
+    if (tid < 5) atomicAdd(&out[tid], red[tid]);
+}
+
+extern "C" int cgs_debug_blend_splat_occupancy(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws, size_t geom_bytes,
+                                               void *bin_ws, size_t bin_bytes, void *img_ws, size_t img_bytes, int64_t *out5,
+                                               void *stream) {
+    CgsGeom g;
+    CgsBin b;
+    CgsImg im;
+    if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width) || !cgs_geom_carve(&g, geom_ws, geom_bytes, P) ||
+        !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R)) {
+        cgs_set_error("debug_blend_splat_occupancy: workspace");
+        return CGS_ERR_WORKSPACE;
+    }
+    CGS_CHECK_HIP(hipMemsetAsync(out5, 0, 5 * sizeof(int64_t), (hipStream_t)stream));
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_splat_occupancy_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, (hipStream_t)stream,
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
+                       (const float4 *)g.rec, (const uint32_t *)im.tile_last, (const uint32_t *)im.n_contrib,
+                       (unsigned long long *)out5);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -213,9 +213,21 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         grid_scaling = sel(pc.get_scaling)
         binary_grid_masks = sel(pc.get_mask)
         if is_training and 3000 < step <= 10000:                                        # :54-58
-            feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q_FEAT
-            grid_scaling = grid_scaling + torch.empty_like(grid_scaling).uniform_(-0.5, 0.5) * Q_SCALING
-            grid_offsets = grid_offsets + torch.empty_like(grid_offsets).uniform_(-0.5, 0.5) * Q_OFFSETS
+            if feat.is_cuda and grid_offsets.dim() == 3:
+                # x + U(-1/2, 1/2) Q for the three tensors in ONE launch (the level kernel of the context model with a
+                # zero step-size adjustment: Q = q0 (1 + tanh 0) = q0) instead of three uniform_ / mul / add chains over
+                # [n,50], [n,6], [n,30]; the build's counter-based generator instead of torch's Philox stream (same
+                # distribution), backward = identity
+                from . import ctx_ops as _ctx
+                n_vis = feat.shape[0]
+                zero_adj = torch.zeros(n_vis, 3, dtype=torch.float32, device=feat.device)
+                feat, grid_scaling, off2, _q = _ctx.noise_quant(feat, grid_scaling, grid_offsets.reshape(n_vis, -1), zero_adj,
+                                                                (Q_FEAT, Q_SCALING, Q_OFFSETS))
+                grid_offsets = off2.view(grid_offsets.shape)
+            else:
+                feat = feat + torch.empty_like(feat).uniform_(-0.5, 0.5) * Q_FEAT
+                grid_scaling = grid_scaling + torch.empty_like(grid_scaling).uniform_(-0.5, 0.5) * Q_SCALING
+                grid_offsets = grid_offsets + torch.empty_like(grid_offsets).uniform_(-0.5, 0.5) * Q_OFFSETS
     if is_training and step == 10000:                                                   # :60-61
         pc.update_anchor_bound()
     if use_context:                                                                     # :63-81 (train) / :83-101 (eval)

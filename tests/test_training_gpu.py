@@ -201,3 +201,33 @@ def test_bench_scene_full_size_properties(tmp_path):
     sizes = {f: (tmp_path / "bits" / f).stat().st_size for f in ("feat0.b", "scaling0.b", "offsets0.b", "masks.b")}
     assert all(v > 0 for v in sizes.values())
     assert dec._anchor_feat.shape == (1_000_000, 50) and torch.isfinite(dec._anchor_feat).all()
+
+
+def test_mid_phase_noise_is_one_launch_with_the_reference_distribution(monkeypatch):
+    """3000 < step <= 10000 (gaussian_renderer/__init__.py:54-58): feat / scaling / offsets of the visible anchors get
+    U(-1/2, 1/2) * (1, 0.001, 0.2) added — by one fused launch; the values that reach the anchor MLPs / the expansion
+    differ from the parameters by exactly such noise, and the gradients pass through unchanged."""
+    from contextgs_amd import ctx_ops, renderer
+    pc, cams, pipe, bg = _setup(N=30000)
+    seen = {}
+    real = ctx_ops.noise_quant
+
+    def spy(xf, xs, xo, qadj, q0, **kw):
+        out = real(xf, xs, xo, qadj, q0, **kw)
+        seen.update(x=(xf.detach().clone(), xs.detach().clone(), xo.detach().clone()), y=tuple(t.detach().clone() for t in out[:3]),
+                    q0=q0, calls=seen.get("calls", 0) + 1)
+        return out
+
+    monkeypatch.setattr(ctx_ops, "noise_quant", spy)
+    vis = renderer.prefilter_voxel(cams[0], pc, pipe, bg)
+    pkg = renderer.render(cams[0], pc, pipe, bg, visible_mask=vis, retain_grad=True, step=5000)
+    assert seen["calls"] == 1 and tuple(seen["q0"]) == (1, 0.001, 0.2)
+    for x, y, q in zip(seen["x"], seen["y"], seen["q0"]):
+        u = (y - x) / q
+        # x + u q in fp32: the quotient carries the rounding of the sum (|x| up to ~10 against q down to 1e-3)
+        assert float(u.abs().max()) <= 0.5 + 1e-2 and abs(float(u.mean())) < 5e-3
+        assert abs(float(u.var()) - 1.0 / 12.0) < 5e-3
+    pkg["render"].sum().backward()
+    for name in ("_anchor_feat", "_scaling", "_offset"):
+        g = getattr(pc, name).grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name

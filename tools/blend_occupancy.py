@@ -26,3 +26,20 @@ q, b, v, e, o, ph = out.tolist()
 print(f"rc={rc} P={lc['P']} R={lc['num_rendered']}: quadrant iterations {q}, block-mapped iterations {b} ({q / max(1, b):.2f}x fewer), 4x4 block visits {v} ({v / max(1, q):.2f} per quadrant visit)")
 print(f"4x4 block visits: box test {v}, octagon test {o} ({o / max(1, v):.3f}), exact (some pixel has alpha >= 1/255) {e} ({e / max(1, v):.3f})")
 print(f"(pixel, Gaussian) pairs with alpha >= 1/255 up to the tile's last contributor: {ph} = {ph / max(1, v * 16):.3f} of the 16 pixels of a visited block; {ph / max(1, lc['P']):.1f} per Gaussian")
+
+# ---- splat-parallel backward mapping, counted (csrc/raster_debug.hip: blend_splat_occupancy_kernel) ----
+out5 = torch.zeros(5, dtype=torch.int64, device="cuda")
+f2 = L.cgs_debug_blend_splat_occupancy
+f2.restype = C.c_int
+f2.argtypes = f.argtypes
+rc = f2(C.addressof(lc["cfg"].c), lc["P"], lc["num_rendered"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
+        lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out5.data_ptr(), None)
+torch.cuda.synchronize()
+pairs, visits, hits, blkv, buckets = out5.tolist()
+print(f"splat-parallel mapping rc={rc}: {buckets} 64-entry buckets; (pixel, bucket) pairs below the pixel's last contributor {pairs}, "
+      f"with >= 1 hit {visits} ({visits / max(1, pairs):.3f}); lane hits {hits} = {hits / max(1, visits):.2f} of 64 lanes per visited pair "
+      f"({hits / max(1, 64 * visits):.3f} lane utilisation); (4x4 block, bucket) pairs with a hit {blkv}")
+ROW_INSTR, SPLAT_INSTR, SPLAT_SKIP = 84, 70, 16
+print(f"wave instructions per view: row mapping {b} iterations x {ROW_INSTR} = {b * ROW_INSTR / 1e6:.0f} M;  splat-parallel "
+      f"{visits} x {SPLAT_INSTR} + {pairs - visits} x {SPLAT_SKIP} = {(visits * SPLAT_INSTR + (pairs - visits) * SPLAT_SKIP) / 1e6:.0f} M "
+      f"({(visits * SPLAT_INSTR + (pairs - visits) * SPLAT_SKIP) / max(1, b * ROW_INSTR):.2f}x)")
