@@ -7,11 +7,13 @@ input row to its unique row, `indices` is the SMALLEST original index of each gr
 group sizes.
 
 Integer-valued voxel keys (the only inputs on the hot path: torch.round(anchor/voxel/
-scale), scene/gaussian_model.py:1760) take the HIP route: the three coordinates are
-biased and packed into one 63-bit key and sorted with libcgs_hip's stable LSD radix
-sort (prims.hip) — ascending packed key == ascending lexicographic row order, stability
-gives the first-occurrence index for free.  Anything else (non-integer rows, huge
-ranges, other dims) is not on the hot path and raises.
+scale), scene/gaussian_model.py:1760) run on the device (csrc/levels.hip, round 3): range /
+integrality reduction, the three coordinates biased and packed into one <= 62-bit key,
+libcgs_hip's stable LSD radix sort of (key, index) (one sort, or two for keys wider than 32
+bits), run heads, scan, and one kernel that writes inverse / first occurrence / unique rows —
+ascending packed key == ascending lexicographic row order, stability gives the first-
+occurrence index for free.  Anything else (non-integer rows, huge ranges, other dims) is not
+on the hot path and raises.
 """
 from __future__ import annotations
 
@@ -33,6 +35,7 @@ def _sort_pairs_u32(keys: torch.Tensor, vals: torch.Tensor, bits: int):
 
 def torch_unique_with_indices(tensor, dim=0):
     """Return (unique rows, inverse_indices, first-occurrence indices, counts)."""
+    import ctypes as C
     if dim != 0 or tensor.dim() != 2:
         raise NotImplementedError("hot path only needs dim=0 on [N,C] voxel keys")
     _lib.require_device(tensor)
@@ -42,34 +45,30 @@ def torch_unique_with_indices(tensor, dim=0):
         if n == 0:
             e = torch.zeros(0, dtype=torch.long, device=dev)
             return tensor.clone(), e, e.clone(), e.clone()
-        t = tensor + 0.0                               # -0.0 -> +0.0 so that equal rows get equal keys
-        # one host read for (min, max, integrality) — fp32 reductions, not int64 ones (those run ~10x slower)
-        not_int = (torch.round(t) != t).any().to(t.dtype).reshape(1)
-        host = torch.cat([t.amin(dim=0), t.amax(dim=0), not_int]).cpu().tolist()
-        if host[-1] != 0.0:
+        if c != 3 or tensor.dtype != torch.float32:
+            raise NotImplementedError("torch_unique_with_indices: [N,3] fp32 voxel keys only")
+        L = _lib.lib()
+        t = tensor.contiguous()
+        stream = _lib.current_stream()
+        # launch 1-3: per-column range + integrality; ONE host read decides the key widths
+        out7 = torch.empty(7, dtype=torch.float32, device=dev)
+        tmp8 = torch.empty(8, dtype=torch.int32, device=dev)
+        _lib.check(L.cgs_level_key_range(_lib.ptr(t), n, _lib.ptr(out7), _lib.ptr(tmp8), stream), "cgs_level_key_range")
+        host = out7.tolist()
+        if host[6] != 0.0:
             raise NotImplementedError("torch_unique_with_indices: rows must be integer-valued voxel keys")
-        lo_l = [int(v) for v in host[:c]]
-        span = [int(hi) - l + 1 for hi, l in zip(host[c:2 * c], lo_l)]
-        bits = [max(1, int(s_ - 1).bit_length()) for s_ in span]
+        lo_l = [int(v) for v in host[:3]]
+        bits = [max(1, int(int(hi) - l).bit_length()) for hi, l in zip(host[3:6], lo_l)]
         if sum(bits) > 62 or max(bits) > 31:
             raise NotImplementedError("voxel key range too large to pack")
-        lo = torch.tensor(lo_l, dtype=t.dtype, device=dev)
-        ti = (t - lo).to(torch.int32)
-        rel = ti
-        # LSD over columns, least significant (last column) first; each column in <=32-bit digits
-        order = torch.arange(n, dtype=torch.int32, device=dev)
-        for col in reversed(range(c)):
-            keys = rel[:, col][order.long()].contiguous()
-            _, order = _sort_pairs_u32(keys, order.contiguous(), bits[col])
-        order = order.long()
-        sorted_rows = rel[order]
-        new_group = torch.ones(n, dtype=torch.bool, device=dev)
-        new_group[1:] = (sorted_rows[1:] != sorted_rows[:-1]).any(dim=1)
-        gid_sorted = torch.cumsum(new_group.to(torch.int64), 0) - 1
-        starts = torch.nonzero(new_group)[:, 0]
         inverse = torch.empty(n, dtype=torch.long, device=dev)
-        inverse[order] = gid_sorted
-        indices = order[starts]                        # stable sort => first element of a group is its smallest index
-        counts = torch.diff(torch.cat([starts, torch.tensor([n], device=dev)]))
-        unique = t[indices]
-        return unique, inverse, indices, counts
+        first = torch.empty(n, dtype=torch.long, device=dev)
+        counts = torch.empty(n, dtype=torch.long, device=dev)
+        unique = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(L.cgs_level_unique_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        m = C.c_int64(0)
+        _lib.check(L.cgs_level_unique(_lib.ptr(t), n, (C.c_int32 * 3)(*lo_l), (C.c_int32 * 3)(*bits), _lib.ptr(inverse),
+                                      _lib.ptr(first), _lib.ptr(counts), _lib.ptr(unique), C.byref(m), _lib.ptr(scratch),
+                                      scratch.numel(), stream), "cgs_level_unique")
+        k = int(m.value)
+        return unique[:k], inverse, first[:k], counts[:k]

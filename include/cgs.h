@@ -24,11 +24,11 @@
  *   cgs_entropy_gaussian_*     utils/entropy_models.py:30-50,141-156
  *   cgs_ste_multistep,
  *   cgs_quantize_anchor        utils/encodings.py:203-231
- *   cgs_sort_pairs_u32         the three stable key sorts behind
- *                              utils/multi_level.py:3-31 (torch.unique(dim=0)
- *                              with indices; the run-head bookkeeping around
- *                              them is torch code in contextgs_amd/multi_level.py),
- *                              scene/gaussian_model.py:1751-1765
+ *   cgs_level_key_range,
+ *   cgs_level_unique           utils/multi_level.py:3-31 (torch.unique(dim=0) with
+ *                              indices on the voxel keys of
+ *                              scene/gaussian_model.py:1751-1765): packed keys,
+ *                              cgs_sort_pairs_u32, run heads, scan
  *   cgs_anchor_gen_*           generate_neural_gaussians' anchor MLPs + mask +
  *                              compaction + per-Gaussian tail as one fused
  *                              kernel family (gaussian_renderer/__init__.py:106-145)
@@ -657,6 +657,20 @@ int cgs_densify_stats(int64_t n_vis, int K, const int64_t *vis_idx,
 int cgs_compact_rows(int nt, const float *const *src, float *const *dst, const int *width,
                      const int *clamp_col0, float clamp_max, const int64_t *idx, int64_t n_keep,
                      void *stream);
+
+/* ---- level division of the context model: utils/multi_level.py:3-31
+ * `torch_unique_with_indices` on the integer voxel keys of scene/gaussian_model.py:1751-1765 ----
+ * cgs_level_key_range: out7 (device floats) = per-column min (3), max (3) of keys [n,3] and 1.0 if some value is not
+ *   an integer; scratch8: 8 device ints.  The caller reads out7 (one host read) to choose the key widths.
+ * cgs_level_unique: lo / bits = HOST arrays (3 each): column minima and key widths (each <= 31, sum <= 62).  Unique
+ *   rows in ascending lexicographic order (-0.0 merged with 0.0); inverse [n] = unique row of every input row;
+ *   first [n] = smallest input index of each group, counts [n], unique [n,3]: the first *n_unique_host entries are
+ *   valid (one stream synchronisation for that count, as torch.unique has). */
+int cgs_level_key_range(const float *keys, int64_t n, float *out7, void *scratch8, void *stream);
+size_t cgs_level_unique_scratch_bytes(int64_t n);
+int cgs_level_unique(const float *keys, int64_t n, const int32_t *lo, const int32_t *bits, int64_t *inverse,
+                     int64_t *first, int64_t *counts, float *unique, int64_t *n_unique_host, void *scratch,
+                     size_t scratch_bytes, void *stream);
 
 /* ---- image loss of the training iteration ----
  * train.py:199-204 with utils/loss_utils.py:17-63: L1 = mean|img - gt| and SSIM (11x11 Gaussian

@@ -239,3 +239,26 @@ def test_extract_context_feat_matches_reference_directly():
         assert got.shape == z[key].shape and torch.equal(got, T(key)), key
         n_cases += 1
     assert n_cases == 4
+
+
+@pytest.mark.parametrize("n,span", [(1, 3), (5000, 7), (200_003, 90), (60_000, 1 << 18), (40_000, 1 << 12)])
+def test_level_unique_kernels_equal_torch_unique(n, span):
+    """csrc/levels.hip (cgs_level_key_range + cgs_level_unique) against torch.unique(dim=0) on the host, which is what
+    utils/multi_level.py:3-31 calls: lexicographic row order, inverse, smallest original index per group, counts — for
+    narrow keys (one 32-bit sort) and wide ones (> 32 packed bits: two sorts), negative coordinates and -0.0."""
+    from contextgs_amd.multi_level import torch_unique_with_indices
+    g = torch.Generator().manual_seed(n + span)
+    keys = torch.randint(-span, span + 1, (n, 3), generator=g).float()
+    keys[::7, 1] = -0.0 * keys[::7, 1].abs().clamp(max=0)          # a few explicit -0.0
+    u, inv, first, cnt = torch_unique_with_indices(keys.cuda(), dim=0)
+    ru, rinv, rcnt = torch.unique(keys + 0.0, dim=0, return_inverse=True, return_counts=True)
+    rfirst = torch.full((ru.shape[0],), n, dtype=torch.long).scatter_reduce_(0, rinv, torch.arange(n), reduce="amin")
+    assert torch.equal(u.cpu(), ru) and torch.equal(inv.cpu(), rinv) and torch.equal(cnt.cpu(), rcnt)
+    assert torch.equal(first.cpu(), rfirst)
+    assert not torch.signbit(u).logical_and(u == 0).any()           # -0.0 merged into +0.0
+
+
+def test_level_unique_rejects_non_integer_rows():
+    from contextgs_amd.multi_level import torch_unique_with_indices
+    with pytest.raises(NotImplementedError):
+        torch_unique_with_indices(torch.tensor([[0.5, 1.0, 2.0]], device="cuda"), dim=0)
