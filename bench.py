@@ -301,6 +301,25 @@ def main():
                       "pmc_hbm_bytes": traffic.get(n_), "valu_nominal_frac": valu.get(n_)}
                  for n_ in ("blend_fwd", "blend_bwd") if n_ in kernels}
         lib_ms = sum(k["total_ms"] for k in kernels.values()) / max(1, args.steps)
+        # the fused fp32-MFMA MLP family as a whole (forward, data gradient and weight gradient have the same contraction
+        # sizes): the largest block of the step, bounded by the matrix cores in flops and by HBM in the intermediates the
+        # kernels hand each other (anchor MLPs: X 216 + Y 440 + Hcat 600 B per visible anchor forward, dY 440 + Y 160 + Hcat
+        # 600 read and dZ1 600 + dZ2 160 + dX 212 written backward, 1856 B read by the weight-gradient launch)
+        mlp_group = None
+        fam = [kernels[n_] for n_ in ("mlp_fwd", "mlp_bwd", "mlp_wgrad") if n_ in kernels]
+        if fam:
+            fam_ms = sum(k["total_ms"] for k in fam) / max(1, args.steps)
+            tf = 3.0 * mlp_flops / (fam_ms * 1e-3) / 1e12
+            anchor_alg = n_vis * (212 + 216 + 440 + 600 + 440 + 160 + 600 + 600 + 160 + 212 + 1856)
+            anchor_pmc = sum(traffic.get(k_, 0) for k_ in ("mlp3_fwd", "mlp3_bwd")) or None
+            mlp_group = {"kernels": "mlp2_* / mlp3_* / wgrad_multi (all launches of a step)", "bound": "mfma",
+                         "ms_per_step": round(fam_ms, 3), "share_of_hip_kernel_time": round(fam_ms / max(lib_ms, 1e-9), 3),
+                         "alg_flops_per_step": 3.0 * mlp_flops, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                         "anchor_mlp_alg_bytes_per_step": anchor_alg,
+                         "anchor_mlp_fwd_bwd_pmc_bytes": anchor_pmc,
+                         "note": "HBM-bound on hand-over intermediates, not on flops; fused alternatives measured in "
+                                 "profiles/r03_anchor_gen_experiments.txt"}
 
         # stdout carries exactly ONE line (the JSON below): the codec driver's progress prints (they mirror the
         # reference's) and anything the baseline prints go to stderr
@@ -330,7 +349,7 @@ def main():
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
             "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
-            "roofline": roofline, "blend_roofline": blend, "kernels": kernels,
+            "roofline": roofline, "blend_roofline": blend, "mlp_group_roofline": mlp_group, "kernels": kernels,
             "hip_kernel_ms_per_step": round(lib_ms, 3),
             "ms_per_step_profiled_pass": round(dt_prof / args.steps * 1e3, 3),
             "cpu_baseline": cpu,
