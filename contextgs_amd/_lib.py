@@ -156,6 +156,9 @@ SIGNATURES = {
     "cgs_expand_scratch_bytes": (c_size_t, [c_int64, c_int]),
     "cgs_expand_count": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, C.POINTER(c_int64), c_void_p]),
+    "cgs_expand_count_launch": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    "cgs_expand_count_wait": (c_int, [C.POINTER(c_int64)]),
     "cgs_expand_write": (c_int, [c_int64, c_int] + [c_void_p] * 15),
     "cgs_expand_backward": (c_int, [c_int64, c_int] + [c_void_p] * 22),
 }

@@ -250,7 +250,10 @@ def begin_step(pc, anchor, mask_anchor_bool, predict_bpp):
     a = _choose_args(cache, anchor, mask_anchor_bool, True)
     h = _ctx.choose_rows_begin(a["perm"], a["n"], a["mask"], given, seed, 0.15, a["anchor"], a["anchor_ref"], a["mask_ref"],
                                a["bounds"])
-    return dict(handle=h, cache=cache, seed=seed, given=given, anchor=anchor, mask=mask_anchor_bool)
+    packed = None
+    if isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3) and not pc.disable_hyper:
+        packed = pc.latent_codec._packed_params()      # a cat launch the step needs anyway: queued before the read-back
+    return dict(handle=h, cache=cache, seed=seed, given=given, anchor=anchor, mask=mask_anchor_bool, packed=packed)
 
 
 def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begun=None):
@@ -450,7 +453,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             and not pc.disable_hyper and c.get("_nz") is not None and c["covers_all"] and hyper.dtype == torch.float32):
         hyp_p, likelihood_hyper = pc.latent_codec.training_step_forms(
             hyper, None if c.get("identity") else perm, None if c.get("identity") else c["inv_perm"], c["_nz"],
-            _ctx.next_seed())
+            _ctx.next_seed(), packed=begun.get("packed") if begun is not None else None)
         hyper_feat = None
     elif FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine:
         rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(_as_mask(choose_mask))[:, 0]
@@ -864,7 +867,8 @@ class LazyRows:
 
 
 def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_scaling, binary_grid_masks,
-                                   mask_anchor_bool, vis_idx, training, predict_bpp, defer_feat=False, begun=None):
+                                   mask_anchor_bool, vis_idx, training, predict_bpp, defer_feat=False, begun=None,
+                                   defer_rate=False):
     """multi_scale_generating followed by `[visible_mask]` (gaussian_renderer/__init__.py:73-81, 93-101) with the
     two row gathers composed into one: out[k] = Q_coding_order[inv_perm[vis_idx[k]]].  defer_feat: return the
     feature rows as a LazyRows (source + row index) so that the caller can fuse the gather into its own kernel."""
@@ -898,5 +902,8 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
         outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:
         return outs
-    return outs + tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False,
-                                   choose_mask, live_count=c.get("live_count")))
+    rate = lambda: tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False,
+                                    choose_mask, live_count=c.get("live_count")))
+    if defer_rate:      # the caller enqueues the rate model where it fills a read-back bubble (renderer.py)
+        return outs + (rate,)
+    return outs + rate()

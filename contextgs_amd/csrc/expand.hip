@@ -157,15 +157,26 @@ extern "C" size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K) {
 }
 
 // Pass A + scan.  flags/pos are uint32 [n_anchor*K] kept by the caller for pass B
-// and the backward; *count_host receives the number of surviving Gaussians (one
-// stream synchronisation, the same one the reference's boolean indexing incurs).
-extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, const float *mask,
-                                float *neural_opacity, uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
-                                void *scratch, size_t scratch_bytes, int64_t *count_host, void *stream_) {
+// and the backward; the number of surviving Gaussians goes to the host through a pinned
+// slot + event: cgs_expand_count_launch enqueues everything and returns, cgs_expand_count_wait
+// blocks on THAT copy only (hipEventSynchronize), so work the caller enqueued in between keeps
+// the GPU busy while the host learns the count (the reference's boolean indexing, :137, drains
+// the whole stream at this point).  cgs_expand_count = launch + wait.
+struct ExpandCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
+static thread_local ExpandCountSlot g_expand_slot = {nullptr, nullptr, false};
+
+extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_raw, const float *mask,
+                                       float *neural_opacity, uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
+                                       void *scratch, size_t scratch_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    ExpandCountSlot &sl = g_expand_slot;
     if (n_anchor < 0 || K < 1 || K > EX_MAX_K) { cgs_set_error("expand_count: bad args"); return CGS_ERR_ARG; }
-    if (!count_host) { cgs_set_error("expand_count: NULL count_host"); return CGS_ERR_ARG; }
-    *count_host = 0;
+    if (!sl.pinned) {
+        CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
+        CGS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    sl.pending = false;
+    sl.pinned[0] = 0;
     const int64_t n = n_anchor * K;
     if (n == 0) return CGS_OK;
     if (n >= (1ll << 31)) { cgs_set_error("expand_count: too many slots"); return CGS_ERR_ARG; }
@@ -181,12 +192,34 @@ extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, co
     uint32_t *total = (uint32_t *)((char *)scratch + scratch_bytes - 256);
     int rc = cgs_scan_exclusive_u32_total(flags, pos, n, scratch, scratch_bytes - 256, total, stream);
     if (rc) return rc;
-    static thread_local uint32_t *pinned = nullptr;
-    if (!pinned) CGS_CHECK_HIP(hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
-    CGS_CHECK_HIP(hipMemcpyAsync(pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CGS_CHECK_HIP(hipStreamSynchronize(stream));
-    *count_host = pinned[0];
+    CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
+    sl.pending = true;
     return CGS_OK;
+}
+
+extern "C" int cgs_expand_count_wait(int64_t *count_host) {
+    ExpandCountSlot &sl = g_expand_slot;
+    if (!count_host) { cgs_set_error("expand_count_wait: NULL count_host"); return CGS_ERR_ARG; }
+    *count_host = 0;
+    if (!sl.pinned) { cgs_set_error("expand_count_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (sl.pending) {
+        CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    *count_host = sl.pinned[0];
+    return CGS_OK;
+}
+
+extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, const float *mask,
+                                float *neural_opacity, uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
+                                void *scratch, size_t scratch_bytes, int64_t *count_host, void *stream_) {
+    if (!count_host) { cgs_set_error("expand_count: NULL count_host"); return CGS_ERR_ARG; }
+    *count_host = 0;
+    int rc = cgs_expand_count_launch(n_anchor, K, op_raw, mask, neural_opacity, mask_out, flags, pos, scratch, scratch_bytes,
+                                     stream_);
+    if (rc) return rc;
+    return cgs_expand_count_wait(count_host);
 }
 
 extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags, const uint32_t *pos,

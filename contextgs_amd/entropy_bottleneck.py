@@ -320,12 +320,14 @@ class EntropyBottleneck(nn.Module):
         back = lambda t: t.reshape(self.channels, -1).t()
         return back(out), back(lik)
 
-    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int):
+    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int, packed=None):
         """Training-step entry (extension): (noisy latents in coding order [N,C], HyperBitSum over the coding-order
         positions rows_pos) — forward(x, training=True) restricted to what scene/gaussian_model.py:1556-1707 consumes,
         in two launches.  perm / inv_perm: the coding-order permutation and its inverse (None: identity)."""
         assert x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 2 and x.shape[1] == self.channels
-        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params(), seed)
+        # packed: self._packed_params() evaluated earlier by the caller (the renderer does it before a host read-back, so
+        # that the GPU has the launch queued while the host waits)
+        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed)
         n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
         return v_p, HyperBitSum(bits, n_rows * self.channels)
 

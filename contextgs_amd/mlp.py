@@ -277,6 +277,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         assert feat_src.dim() == 2 and feat_src.shape[1] == 50 and cam.numel() == 3 and src_row.dtype == torch.int64
         p = [t.detach().contiguous() for t in params]
         W1, b1, W2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
+        ctx.set_materialize_grads(False)
         n = int(src_row.shape[0])
         dev = feat_src.device
         need_grad = any(ctx.needs_input_grad)

@@ -85,8 +85,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         cfg = _Cfg(raster_settings)
         H, W = cfg.c.image_height, cfg.c.image_width
         stream = _lib.current_stream()
+        ctx.set_materialize_grads(False)        # no zero tensors for the gradient of `radii`
 
-        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)       # the preprocess kernel writes every entry (0 = culled)
         geom = _workspace(L.cgs_raster_geom_bytes(P), dev)
         img = _workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -113,6 +114,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         cfg = ctx.cfg
         P = means3D.shape[0]
         dev = means3D.device
+        if grad_color is None:
+            return (None,) * 7
         g = _f32c(grad_color)
         # colour / opacity gradients are accumulated atomically by the blend backward: one zero fill for both; the other
         # four arrays are written for EVERY Gaussian by the preprocess backward (zeros for culled ones)

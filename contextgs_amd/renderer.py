@@ -28,13 +28,46 @@ def _c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
+class ExpandCount:
+    """Pass A of the expansion (mask * opacity, survivor flags, their scan) enqueued WITHOUT reading the survivor count:
+    `launch` returns at once, the caller may enqueue independent work (the rate model of the step), `wait` then blocks
+    only until the count has arrived — the device does not drain at this read-back."""
+
+    def __init__(self, op_raw, masks, K):
+        L = _lib.lib()
+        op_raw, masks = _c(op_raw.detach()), _c(masks.detach())
+        _lib.require_device(op_raw, masks)
+        n = int(op_raw.shape[0])
+        dev = op_raw.device
+        slots = n * K
+        self.n, self.K = n, K
+        self.neural_opacity = torch.empty(slots, 1, dtype=torch.float32, device=dev)
+        self.mask_out = torch.empty(slots, dtype=torch.bool, device=dev)
+        self.flags = torch.empty(slots, dtype=torch.int32, device=dev)
+        self.pos = torch.empty(slots, dtype=torch.int32, device=dev)
+        self.scratch = torch.empty(L.cgs_expand_scratch_bytes(n, K), dtype=torch.uint8, device=dev)
+        self.P = None
+        _lib.check(L.cgs_expand_count_launch(n, K, _lib.ptr(op_raw), _lib.ptr(masks), _lib.ptr(self.neural_opacity),
+                                             _lib.ptr(self.mask_out), _lib.ptr(self.flags), _lib.ptr(self.pos),
+                                             _lib.ptr(self.scratch), self.scratch.numel(), _lib.current_stream()),
+                   "cgs_expand_count_launch")
+
+    def wait(self) -> int:
+        if self.P is None:
+            cnt = C.c_int64(0)
+            _lib.check(_lib.lib().cgs_expand_count_wait(C.byref(cnt)), "cgs_expand_count_wait")
+            self.P = int(cnt.value)
+        return self.P
+
+
 class _ExpandGaussians(torch.autograd.Function):
     """(anchor, grid_scaling, offsets, masks, mlp outputs) -> compacted Gaussians (:112-145)."""
 
     @staticmethod
-    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, K, src_row=None):
+    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, K, src_row=None, pre=None):
         # src_row: gscaling / offsets are the context model's full coding-order outputs and visible anchor n uses
         # their row src_row[n] (the visibility gather is done by the kernel)
+        # pre: an ExpandCount already launched for (op_raw, masks) by the caller
         L = _lib.lib()
         _lib.require_device(anchor, gscaling, offsets, masks, op_raw, color_in, cov_in)
         anchor, gscaling, offsets = _c(anchor), _c(gscaling), _c(offsets)
@@ -42,17 +75,12 @@ class _ExpandGaussians(torch.autograd.Function):
         n = anchor.shape[0]
         dev = anchor.device
         stream = _lib.current_stream()
-        slots = n * K
-        neural_opacity = torch.empty(slots, 1, dtype=torch.float32, device=dev)
-        mask_out = torch.empty(slots, dtype=torch.bool, device=dev)
-        flags = torch.empty(slots, dtype=torch.int32, device=dev)
-        pos = torch.empty(slots, dtype=torch.int32, device=dev)
-        scratch = torch.empty(L.cgs_expand_scratch_bytes(n, K), dtype=torch.uint8, device=dev)
-        cnt = C.c_int64(0)
-        _lib.check(L.cgs_expand_count(n, K, _lib.ptr(op_raw), _lib.ptr(masks), _lib.ptr(neural_opacity),
-                                      _lib.ptr(mask_out), _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(scratch),
-                                      scratch.numel(), C.byref(cnt), stream), "cgs_expand_count")
-        P = int(cnt.value)
+        if pre is None:
+            pre = ExpandCount(op_raw, masks, K)
+        assert pre.n == n and pre.K == K
+        ctx.set_materialize_grads(False)        # an unused output (neural_opacity in most losses) arrives as None, not as zeros
+        P = pre.wait()
+        neural_opacity, mask_out, flags, pos = pre.neural_opacity, pre.mask_out, pre.flags, pre.pos
         xyz = torch.empty(P, 3, dtype=torch.float32, device=dev)
         color = torch.empty(P, 3, dtype=torch.float32, device=dev)
         opacity = torch.empty(P, 1, dtype=torch.float32, device=dev)
@@ -103,7 +131,7 @@ class _ExpandGaussians(torch.autograd.Function):
             _lib.ptr(g_scaling), _lib.ptr(g_rot), _lib.ptr(g_no), _lib.ptr(d_anchor), _lib.ptr(d_gs),
             _lib.ptr(d_off), _lib.ptr(d_op), _lib.ptr(d_mask), _lib.ptr(d_color), _lib.ptr(d_cov),
             _lib.ptr(src_row), _lib.current_stream()), "cgs_expand_backward")
-        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None
+        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None, None
 
 
 def _anchor_mlps(pc, x):
@@ -146,8 +174,10 @@ def _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offse
                                  binary_grid_masks.reshape(-1, K), mo, mc, mv)
 
 
-def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K):
-    """The same stage as separate launches: fused three-MLP kernel (or torch) + the expansion kernels."""
+def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K, between=None):
+    """The same stage as separate launches: fused three-MLP kernel (or torch) + the expansion kernels.
+    between: called after the expansion's survivor count has been ENQUEUED and before it is read — work it launches
+    (the step's rate model) runs on the device while the host waits for the count."""
     mo, mc, mv = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
     if (isinstance(feat, LazyRows) and feat.src.dim() == 2 and feat.src.shape[1] == 50 and feat.src.is_cuda
             and mlp.anchor_mlp3_supported(mo, mc, mv)):
@@ -174,8 +204,13 @@ def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_off
     else:
         grid_scaling = grid_scaling.materialize() if isinstance(grid_scaling, LazyRows) else grid_scaling
         grid_offsets = grid_offsets.materialize() if isinstance(grid_offsets, LazyRows) else grid_offsets
-    return _ExpandGaussians.apply(
-        anchor, grid_scaling, grid_offsets, binary_grid_masks.reshape(-1, K), op_raw, color_in, cov_in, K, src_row)
+    masks2 = binary_grid_masks.reshape(-1, K)
+    pre = None
+    if op_raw.is_cuda and masks2.is_cuda:
+        pre = ExpandCount(op_raw, masks2, K)
+    if between is not None:
+        between()
+    return _ExpandGaussians.apply(anchor, grid_scaling, grid_offsets, masks2, op_raw, color_in, cov_in, K, src_row, pre)
 
 
 def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0):   # :25-150
@@ -188,7 +223,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
 
     full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
     use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
-    begun = binary_all = mask_anchor_bool = None
+    begun = binary_all = mask_anchor_bool = rate_thunk = None
     if use_context:
         # everything of the context model that does not depend on the visible set is enqueued BEFORE the read-back of
         # the visible count below (the accessors, the step's bookkeeping kernel): the GPU works through it while the
@@ -236,22 +271,62 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
                                              pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
                                              training=is_training, predict_bpp=is_training, defer_feat=True,
-                                             begun=begun)
+                                             begun=begun, defer_rate=True)
         feat, grid_scaling, grid_offsets = res[:3]
         if is_training:
-            bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = res[3:]
+            rate_thunk = res[3]         # the rate model (:1657-1707) is enqueued behind the expansion's count (see below)
         binary_grid_masks = sel(binary_all)
 
     K = pc.n_offsets
+    rate_out = []
+    run_rate = (lambda: rate_out.extend(rate_thunk())) if rate_thunk is not None else None
     out = _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
     if out is None:
-        out = _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
+        out = _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K,
+                                between=run_rate)
+    elif run_rate is not None:
+        run_rate()
+    if rate_out:
+        bit_per_param, bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level = rate_out
     xyz, color, opacity, scaling, rot, neural_opacity, mask = out
 
     if is_training:                                                                      # :147-150
         return (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, 16, bit_per_feat_param,
                 bit_per_scaling_param, bit_per_offsets_param, bpp_per_level)
     return xyz, color, opacity, scaling, rot, time_sub
+
+
+_ZERO_POOL = {}
+
+
+class _ZeroPoints(torch.autograd.Function):
+    """The reference's `screenspace_points` (gaussian_renderer/__init__.py:168: a zero [P,3] non-leaf tensor whose .grad
+    receives the 2-D position gradients) without its per-view fill + add: the values are never written by anyone (the
+    rasterizer only fills the GRADIENT), so every view gets a view of one per-device zero buffer, wrapped in an
+    autograd node so that it is a fresh non-leaf tensor that requires grad, as in the reference."""
+
+    @staticmethod
+    def forward(ctx, like, token):
+        P = int(like.shape[0])
+        dev = like.device
+        buf = _ZERO_POOL.get(dev)
+        if buf is None or buf.shape[0] < P:
+            buf = _ZERO_POOL[dev] = torch.zeros(max(P, 1) * 5 // 4, 3, dtype=torch.float32, device=dev)
+        return buf[:P]
+
+    @staticmethod
+    def backward(ctx, _g):
+        return None, None
+
+
+_GRAD_TOKEN = {}
+
+
+def _zero_points(xyz):
+    tok = _GRAD_TOKEN.get(xyz.device)
+    if tok is None:
+        tok = _GRAD_TOKEN[xyz.device] = torch.zeros(1, device=xyz.device, requires_grad=True)
+    return _ZeroPoints.apply(xyz.detach(), tok)
 
 
 def _raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier):
@@ -275,7 +350,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
         xyz, color, opacity, scaling, rot, time_sub = generate_neural_gaussians(
             viewpoint_camera, pc, visible_mask, is_training=False, step=step)
 
-    screenspace_points = torch.zeros_like(xyz, dtype=pc.get_anchor.dtype, requires_grad=True) + 0
+    screenspace_points = _zero_points(xyz)       # :168 `torch.zeros_like(xyz, requires_grad=True) + 0`
     if retain_grad:
         try:
             screenspace_points.retain_grad()

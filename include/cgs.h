@@ -590,6 +590,13 @@ int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw,
                      uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
                      void *scratch, size_t scratch_bytes, int64_t *count_host,
                      void *stream);
+/* cgs_expand_count in two halves: _launch enqueues pass A + scan + the 4-byte copy of the count and returns;
+ * _wait (same host thread) blocks on that copy alone, so kernels the caller enqueued in between keep the device busy. */
+int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_raw,
+                            const float *mask, float *neural_opacity,
+                            uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
+                            void *scratch, size_t scratch_bytes, void *stream);
+int cgs_expand_count_wait(int64_t *count_host);
 int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags,
                      const uint32_t *pos, const float *anchor,
                      const float *gscaling, const float *offsets,
