@@ -62,6 +62,12 @@ def install(patch_reference_python: bool = True) -> list[str]:
         gm.GaussianModel.training_statis = lambda self, *a, **k: densify.training_statis(self, *a, **k)
         gm.GaussianModel.anchor_growing = lambda self, *a, **k: densify.anchor_growing(self, *a, **k)
         patched += ["scene.gaussian_model.GaussianModel.training_statis", "scene.gaussian_model.GaussianModel.anchor_growing"]
+        # round 3: the optimizer surgery around them (one-launch row compaction of parameters + Adam moments + statistics)
+        gm.GaussianModel.adjust_anchor = lambda self, *a, **k: densify.adjust_anchor(self, *a, **k)
+        gm.GaussianModel.prune_anchor = lambda self, mask: densify.prune_anchor(self, mask)
+        gm.GaussianModel.cat_tensors_to_optimizer = lambda self, d: densify.cat_tensors_to_optimizer(self, d)
+        patched += ["scene.gaussian_model.GaussianModel.adjust_anchor", "scene.gaussian_model.GaussianModel.prune_anchor",
+                    "scene.gaussian_model.GaussianModel.cat_tensors_to_optimizer"]
     except Exception:
         pass
     rebind("gaussian_renderer", renderer, ["render", "prefilter_voxel", "generate_neural_gaussians"])
