@@ -231,3 +231,21 @@ def test_mid_phase_noise_is_one_launch_with_the_reference_distribution(monkeypat
     for name in ("_anchor_feat", "_scaling", "_offset"):
         g = getattr(pc, name).grad
         assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+
+
+def test_miniature_training_run_with_densification_encodes_and_decodes():
+    """tools/train_loop.py: the reference's train.py loop in miniature on contextgs_amd.model.GaussianModel alone —
+    training_setup, learning-rate schedule, three phases, training_statis, adjust_anchor (grow + prune + optimizer
+    surgery) several times, then conduct_encoding / conduct_decoding of the trained model."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_loop.py"), "180", "30000"], capture_output=True,
+                       text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "finite True" in r.stdout and r.stdout.count("adjust_anchor") >= 3
+    losses = [float(l.split("loss")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("it ")]
+    assert losses[-1] < 0.7 * losses[0], losses
+    dec = [l for l in r.stdout.splitlines() if l.startswith("decoded anchors")][0].split()
+    assert dec[2] == dec[4], dec
