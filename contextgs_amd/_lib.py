@@ -141,6 +141,9 @@ SIGNATURES = {
     "cgs_prof_name": (C.c_char_p, [c_int]),
     "cgs_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64)]),
     "cgs_densify_stats": (c_int, [c_int64, c_int] + [c_void_p] * 11),
+    "cgs_nonzero_scratch_bytes": (c_size_t, [c_int64]),
+    "cgs_nonzero_launch": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cgs_nonzero_wait": (c_int, [C.POINTER(c_int64)]),
     "cgs_level_key_range": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "cgs_level_unique_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_level_unique": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

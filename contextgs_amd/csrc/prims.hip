@@ -367,3 +367,74 @@ extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_
     }
     return CGS_OK;
 }
+
+// ----------------------------------------------------------------------------
+// Indices of the non-zero bytes of a mask, ascending (torch.nonzero of a bool [n] — the visible-anchor list of
+// gaussian_renderer/__init__.py:44-50), in two halves: _launch enqueues flags -> scan -> scatter and the 4-byte copy of
+// the count behind them, _wait blocks on that copy's event only.  torch.nonzero drains the stream to size its result;
+// here the kernels the caller enqueues between the halves (the context model's accessors, the step's bookkeeping) keep
+// the device busy while the host learns the count.  idx_out has room for n entries; the first *count are valid.
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nz_flags_kernel(const uint8_t *__restrict__ mask, int64_t n, uint32_t *__restrict__ f) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) f[i] = mask[i] ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+    nz_scatter_kernel(const uint32_t *__restrict__ f, const uint32_t *__restrict__ pos, int64_t n, int64_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && f[i]) idx[pos[i]] = i;
+}
+
+struct NzSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
+static thread_local NzSlot g_nz_slot = {nullptr, nullptr, false};
+
+extern "C" size_t cgs_nonzero_scratch_bytes(int64_t n) {
+    if (n < 1) n = 1;
+    return 2 * cgs_align_up((size_t)n * 4, 256) + cgs_scan_scratch_bytes(n) + 512;
+}
+
+extern "C" int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_out, void *scratch, size_t scratch_bytes,
+                                  void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NzSlot &sl = g_nz_slot;
+    if (n < 0 || n >= (1ll << 31)) { cgs_set_error("nonzero: bad n"); return CGS_ERR_ARG; }
+    if (!sl.pinned) {
+        CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
+        CGS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    sl.pending = false;
+    sl.pinned[0] = 0;
+    if (n == 0) return CGS_OK;
+    if (!mask || !idx_out || !scratch) { cgs_set_error("nonzero: NULL"); return CGS_ERR_ARG; }
+    if (scratch_bytes < cgs_nonzero_scratch_bytes(n)) { cgs_set_error("nonzero: scratch too small"); return CGS_ERR_WORKSPACE; }
+    CgsCarver cv(scratch, scratch_bytes);
+    uint32_t *f = cv.take<uint32_t>(n), *pos = cv.take<uint32_t>(n);
+    const size_t scan_bytes = cgs_scan_scratch_bytes(n);
+    char *scan_scratch = cv.take<char>(scan_bytes + 256);
+    uint32_t *total = (uint32_t *)(scan_scratch + scan_bytes);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(nz_flags_kernel, grid, block, 0, stream, mask, n, f);
+    CGS_CHECK_HIP(hipGetLastError());
+    int rc = cgs_scan_exclusive_u32_total(f, pos, n, scan_scratch, scan_bytes, total, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nz_scatter_kernel, grid, block, 0, stream, (const uint32_t *)f, (const uint32_t *)pos, n, idx_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
+    sl.pending = true;
+    return CGS_OK;
+}
+
+extern "C" int cgs_nonzero_wait(int64_t *count_host) {
+    NzSlot &sl = g_nz_slot;
+    if (!count_host) { cgs_set_error("nonzero_wait: NULL"); return CGS_ERR_ARG; }
+    *count_host = 0;
+    if (!sl.pinned) { cgs_set_error("nonzero_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (sl.pending) {
+        CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    *count_host = sl.pinned[0];
+    return CGS_OK;
+}

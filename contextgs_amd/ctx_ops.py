@@ -530,6 +530,18 @@ def means3(a, b, c, exp_b=False):
     return out
 
 
+_PINNED_FREE = []
+
+
+def _pinned_i32(k):
+    """A small pinned int32 buffer from a free list (allocating pinned memory per step would cost more than the read)."""
+    while _PINNED_FREE:
+        b = _PINNED_FREE.pop()
+        if b.numel() >= k:
+            return b
+    return torch.empty(max(k, 16), dtype=torch.int32, pin_memory=True)
+
+
 def choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds):
     """First half of choose_rows: launches the flag / count kernel and returns a handle WITHOUT waiting for it, so that
     the caller can enqueue more work (or reach a synchronisation it has to make anyway) before the counts are read."""
@@ -548,14 +560,22 @@ def choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, ma
                                       _lib.ptr(None if anchor_ref is None else _c(anchor_ref)), _lib.ptr(mref_u8), b_host,
                                       nlev, _lib.ptr(flags), _lib.ptr(counts), _lib.ptr(meta), _lib.current_stream()),
                "cgs_ctx_choose_flags")
+    # the counts travel to a pinned host buffer behind the kernel, with an event of their own: choose_rows_end waits for
+    # THAT copy (long finished by then) instead of draining whatever the caller has queued since
+    pinned = _pinned_i32(2 + nlev)
+    pinned[:2 + nlev].copy_(meta, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
     return dict(perm=perm, n=n, nlev=nlev, flags=flags, counts=counts, meta=meta, b_host=b_host, dev=dev,
-                keep=(mask_u8, given_u8, mref_u8))
+                keep=(mask_u8, given_u8, mref_u8), pinned=pinned, event=ev)
 
 
 def choose_rows_end(h):
     """Second half: read the counts (the step's synchronisation of the context model), compact the chosen rows."""
     L = _lib.lib()
-    host = h["meta"].tolist()
+    h["event"].synchronize()
+    host = h["pinned"][:2 + h["nlev"]].tolist()
+    _PINNED_FREE.append(h.pop("pinned"))
     stale, live, per_level = bool(host[0]), int(host[1]), [int(v) for v in host[2:]]
     total = sum(per_level)
     dev = h["dev"]

@@ -28,6 +28,26 @@ def _c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
+class VisibleList:
+    """torch.nonzero(mask)[:, 0] in two halves (cgs_nonzero_launch / _wait): the kernels are enqueued at construction,
+    `wait()` blocks only until the count has been copied back and returns the index tensor."""
+
+    def __init__(self, mask):
+        L = _lib.lib()
+        m = mask if mask.dtype == torch.uint8 else mask.view(torch.uint8)
+        self.mask = m = m.contiguous().reshape(-1)
+        n = int(m.numel())
+        self.idx = torch.empty(n, dtype=torch.int64, device=m.device)
+        self.scratch = torch.empty(int(L.cgs_nonzero_scratch_bytes(n)), dtype=torch.uint8, device=m.device)
+        _lib.check(L.cgs_nonzero_launch(_lib.ptr(m), n, _lib.ptr(self.idx), _lib.ptr(self.scratch), self.scratch.numel(),
+                                        _lib.current_stream()), "cgs_nonzero_launch")
+
+    def wait(self):
+        cnt = C.c_int64(0)
+        _lib.check(_lib.lib().cgs_nonzero_wait(C.byref(cnt)), "cgs_nonzero_wait")
+        return self.idx[:int(cnt.value)]
+
+
 class ExpandCount:
     """Pass A of the expansion (mask * opacity, survivor flags, their scan) enqueued WITHOUT reading the survivor count:
     `launch` returns at once, the caller may enqueue independent work (the rate model of the step), `wait` then blocks
@@ -221,6 +241,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     bit_per_param = bit_per_anchor_param = bit_per_feat_param = None
     bit_per_scaling_param = bit_per_offsets_param = bpp_per_level = None
 
+    # the visible-anchor list is ENQUEUED first and read after everything below that does not need it (:44-50)
+    vis_pending = VisibleList(visible_mask) if visible_mask.is_cuda else None
     full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
     use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
     begun = binary_all = mask_anchor_bool = rate_thunk = None
@@ -236,7 +258,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         begun = begin_step(pc, full_anchor, mask_anchor_bool, is_training)
     # visible rows are distinct anchors: gather by index with a sort-free scatter backward (the reference's
     # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
-    vis_idx = torch.nonzero(visible_mask)[:, 0]
+    vis_idx = vis_pending.wait() if vis_pending is not None else torch.nonzero(visible_mask)[:, 0]
     sel = lambda t: gather_unique(t, vis_idx)
     anchor = sel(full_anchor)
     if not use_context:

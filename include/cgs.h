@@ -665,6 +665,15 @@ int cgs_compact_rows(int nt, const float *const *src, float *const *dst, const i
                      const int *clamp_col0, float clamp_max, const int64_t *idx, int64_t n_keep,
                      void *stream);
 
+/* ---- visible-anchor list (gaussian_renderer/__init__.py:44-50: boolean-mask indexing = torch.nonzero) ----
+ * Ascending indices of the non-zero bytes of mask [n] into idx_out [n] (first *count_host valid), in two halves:
+ * _launch enqueues the kernels and the 4-byte copy of the count, _wait (same host thread) blocks on that copy alone,
+ * so work enqueued in between keeps the device busy (torch.nonzero drains the stream). */
+size_t cgs_nonzero_scratch_bytes(int64_t n);
+int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_out, void *scratch,
+                       size_t scratch_bytes, void *stream);
+int cgs_nonzero_wait(int64_t *count_host);
+
 /* ---- level division of the context model: utils/multi_level.py:3-31
  * `torch_unique_with_indices` on the integer voxel keys of scene/gaussian_model.py:1751-1765 ----
  * cgs_level_key_range: out7 (device floats) = per-column min (3), max (3) of keys [n,3] and 1.0 if some value is not

@@ -249,3 +249,14 @@ def test_miniature_training_run_with_densification_encodes_and_decodes():
     assert losses[-1] < 0.7 * losses[0], losses
     dec = [l for l in r.stdout.splitlines() if l.startswith("decoded anchors")][0].split()
     assert dec[2] == dec[4], dec
+
+
+@pytest.mark.parametrize("n,p", [(1, 1.0), (1000, 0.0), (4097, 0.5), (1_000_003, 0.995)])
+def test_visible_list_equals_torch_nonzero(n, p):
+    from contextgs_amd.renderer import VisibleList
+    g = torch.Generator(device="cuda").manual_seed(n)
+    mask = torch.rand(n, device="cuda", generator=g) < p
+    pending = VisibleList(mask)
+    filler = torch.ones(1000, device="cuda").cumsum(0)          # work enqueued between the two halves
+    got = pending.wait()
+    assert got.dtype == torch.int64 and torch.equal(got, torch.nonzero(mask)[:, 0]) and float(filler[-1]) == 1000.0
