@@ -44,14 +44,22 @@ __global__ void __launch_bounds__(256) level_range_kernel(const float *__restric
         }
         bad |= __shfl_xor(bad, d, 64);
     }
+    // one set of atomics per WORKGROUP (the four waves combine in LDS): same-address global atomics serialise
+    __shared__ float smn[4][3], smx[4][3];
+    __shared__ int sbad[4];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicMin(&o[c], lv_f2o(mn[c]));
-            atomicMax(&o[3 + c], lv_f2o(mx[c]));
-        }
-        if (bad) atomicOr(&o[6], 1);
+        for (int c = 0; c < 3; ++c) { smn[wave][c] = mn[c]; smx[wave][c] = mx[c]; }
+        sbad[wave] = bad;
     }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        atomicMin(&o[c], lv_f2o(fminf(fminf(smn[0][c], smn[1][c]), fminf(smn[2][c], smn[3][c]))));
+        atomicMax(&o[3 + c], lv_f2o(fmaxf(fmaxf(smx[0][c], smx[1][c]), fmaxf(smx[2][c], smx[3][c]))));
+    }
+    if (threadIdx.x == 3 && (sbad[0] | sbad[1] | sbad[2] | sbad[3])) atomicOr(&o[6], 1);
 }
 
 __global__ void level_range_finish_kernel(const int *__restrict__ o, float *__restrict__ out7) {
@@ -66,7 +74,7 @@ extern "C" int cgs_level_key_range(const float *keys, int64_t n, float *out7, vo
     int *o = (int *)scratch8;
     hipLaunchKernelGGL(level_range_init_kernel, dim3(1), dim3(64), 0, stream, o);
     const int64_t want = (n + 255) / 256;
-    hipLaunchKernelGGL(level_range_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, keys, n, o);
+    hipLaunchKernelGGL(level_range_kernel, dim3((unsigned)(want < 512 ? want : 512)), dim3(256), 0, stream, keys, n, o);
     hipLaunchKernelGGL(level_range_finish_kernel, dim3(1), dim3(64), 0, stream, (const int *)o, out7);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;

@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     mlp2_bwd_kernel(const float *__restrict__ dY, const float *__restrict__ Y, int64_t ldy,
                     const float *__restrict__ Hsave, const float *__restrict__ W1, const float *__restrict__ W2,
                     float *__restrict__ dX, int64_t lddx, int accumulate_dx, float *__restrict__ dZ2,
-                    float *__restrict__ dZ1, int64_t n) {
+                    float *__restrict__ dZ1, int64_t n, const int64_t *__restrict__ dx_rows) {
+    // dx_rows (may be NULL): row r of this call's input gradient goes to row dx_rows[r] of dX (distinct rows) — with
+    // accumulate_dx this is `dX.index_add_(0, dx_rows, dx)` folded into the store
     constexpr int NT2 = (OUT + 15) / 16, NT1 = (HID + 15) / 16, NTX = (IN + 15) / 16;
     constexpr int OP = NT2 * 16, HP = NT1 * 16, XP = NTX * 16;
     constexpr int SA = frag_pad4mod8(HP), SB = frag_pad4mod8(XP);
@@ -256,9 +258,10 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const int64_t row = row0 + rt * 16 + c;
+                    const int64_t drow = dx_rows ? (valid[rt] ? dx_rows[row] : 0) : row;
                     f32x4 d = adx[v][rt];
-                    if (accumulate_dx) d += frag_load4<IN>(dX + row * lddx, v, g, valid[rt]);
-                    frag_store4<IN>(dX + row * lddx, v, g, valid[rt], d);
+                    if (accumulate_dx) d += frag_load4<IN>(dX + drow * lddx, v, g, valid[rt]);
+                    frag_store4<IN>(dX + drow * lddx, v, g, valid[rt], d);
                 }
         }
     }
@@ -293,14 +296,15 @@ static int launch_fwd(const float *X, int64_t ldx, const float *W1, const float 
 
 template <int IN, int HID, int OUT, int ACT>
 static int launch_bwd(const float *dY, const float *Y, int64_t ldy, const float *H, const float *W1, const float *W2,
-                      float *dX, int64_t lddx, int acc, float *dZ2, float *dZ1, int64_t n, hipStream_t s) {
+                      float *dX, int64_t lddx, int acc, float *dZ2, float *dZ1, int64_t n, const int64_t *dx_rows,
+                      hipStream_t s) {
     // 16-row wave tiles, 16 waves per workgroup: 5-18 % faster than 32 rows / 8 waves on every shape (tools/mlp_tiling.sh)
     constexpr int RT = M2_RT, WAVES = M2_WAVES;
     const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
     const int64_t want = (tiles + WAVES - 1) / WAVES;
     const int grid = (int)(want < num_cus() ? want : num_cus());
     hipLaunchKernelGGL((mlp2_bwd_kernel<IN, HID, OUT, ACT, RT, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, dY, Y, ldy, H, W1,
-                       W2, dX, lddx, acc, dZ2, dZ1, n);
+                       W2, dX, lddx, acc, dZ2, dZ1, n, dx_rows);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -332,11 +336,39 @@ extern "C" int cgs_mlp2_forward(int in, int hid, int out, int act, const float *
 
 // dX [n,lddx] (NULL to skip; accumulate_dx adds into it), dZ1 [n,hid], dZ2 [n,out] (may be NULL when act == none:
 // then dZ2 == dY).  Weight/bias gradients are ACCUMULATED (atomics) into dW1/db1/dW2/db2: zero or pre-load them.
+static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,
+                              const float *b1, const float *W2, const float *Y, const float *dY, int64_t ldy, const float *H,
+                              float *dX, int64_t lddx, int accumulate_dx, const int64_t *dx_rows, float *dZ1, float *dZ2,
+                              float *dW1, float *db1, float *dW2, float *db2, int64_t n, void *scratch,
+                              size_t scratch_bytes, void *stream_);
+
 extern "C" int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,
                                  const float *b1, const float *W2, const float *Y, const float *dY, int64_t ldy, const float *H,
                                  float *dX, int64_t lddx, int accumulate_dx, float *dZ1, float *dZ2, float *dW1,
                                  float *db1, float *dW2, float *db2, int64_t n, void *scratch,
                                  size_t scratch_bytes, void *stream_) {
+    return mlp2_backward_impl(in, hid, out, act, X, ldx, W1, b1, W2, Y, dY, ldy, H, dX, lddx, accumulate_dx, nullptr, dZ1, dZ2,
+                              dW1, db1, dW2, db2, n, scratch, scratch_bytes, stream_);
+}
+
+// The same with the input gradient of row r stored to (accumulate_dx: added into) row dx_rows[r] of dX — the rows of a
+// SUBSET of a larger batch (distinct indices): `dX.index_add_(0, dx_rows, .)` without the temporary and the launch.
+// Needs the saved hidden layer (H != NULL).
+extern "C" int cgs_mlp2_backward_rows(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,
+                                      const float *b1, const float *W2, const float *Y, const float *dY, int64_t ldy,
+                                      const float *H, float *dX, int64_t lddx, int accumulate_dx, const int64_t *dx_rows,
+                                      float *dZ1, float *dZ2, float *dW1, float *db1, float *dW2, float *db2, int64_t n,
+                                      void *scratch, size_t scratch_bytes, void *stream_) {
+    if (dx_rows && !H) { cgs_set_error("mlp2_backward_rows: dx_rows needs the saved hidden layer"); return CGS_ERR_ARG; }
+    return mlp2_backward_impl(in, hid, out, act, X, ldx, W1, b1, W2, Y, dY, ldy, H, dX, lddx, accumulate_dx, dx_rows, dZ1, dZ2,
+                              dW1, db1, dW2, db2, n, scratch, scratch_bytes, stream_);
+}
+
+static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X, int64_t ldx, const float *W1,
+                              const float *b1, const float *W2, const float *Y, const float *dY, int64_t ldy, const float *H,
+                              float *dX, int64_t lddx, int accumulate_dx, const int64_t *dx_rows, float *dZ1, float *dZ2,
+                              float *dW1, float *db1, float *dW2, float *db2, int64_t n, void *scratch,
+                              size_t scratch_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("mlp2_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
@@ -365,7 +397,7 @@ extern "C" int cgs_mlp2_backward(int in, int hid, int out, int act, const float 
 #define X_(I, Hh, O, A)                                                                                              \
     if (!found && in == I && hid == Hh && out == O && act == A) {                                                     \
         found = true;                                                                                                 \
-        rc = launch_bwd<I, Hh, O, A>(dY, Y, ldy, H, W1, W2, dX, lddx, accumulate_dx, dZ2, dZ1, n, stream);            \
+        rc = launch_bwd<I, Hh, O, A>(dY, Y, ldy, H, W1, W2, dX, lddx, accumulate_dx, dZ2, dZ1, n, dx_rows, stream);   \
     }
         MLP_CONFIGS(X_)
 #undef X_

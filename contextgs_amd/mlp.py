@@ -155,16 +155,15 @@ class _LevelMLP(torch.autograd.Function):
                                            db2.data_ptr() + 4 * n_stat, n, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward")
         if d_pred is not None and m > 0:
             d_pred = f32c(d_pred)
-            dx_sub = torch.empty(m, in_f, dtype=torch.float32, device=dev) if need_dx else None
             dz1s = torch.empty(m, hid, dtype=torch.float32, device=dev)
-            _lib.check(L.cgs_mlp2_backward(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1), None, _lib.ptr(W2), None,
-                                           _lib.ptr(d_pred), out, _lib.ptr(h_sub), _lib.ptr(dx_sub), in_f, 0, _lib.ptr(dz1s), None,
-                                           _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(),
-                                           stream), "cgs_mlp2_backward")
-            if need_dx:
-                if dx is None:
-                    dx = torch.zeros(n, in_f, dtype=torch.float32, device=dev)
-                dx.index_add_(0, loc, dx_sub)            # loc rows are unique
+            if need_dx and dx is None:
+                dx = torch.zeros(n, in_f, dtype=torch.float32, device=dev)
+            # the subset's input gradient is ADDED into rows loc (unique) of dx by the kernel's own store
+            # (cgs_mlp2_backward_rows): no [m, in] temporary, no index_add_ launch
+            _lib.check(L.cgs_mlp2_backward_rows(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1), None, _lib.ptr(W2), None,
+                                                _lib.ptr(d_pred), out, _lib.ptr(h_sub), _lib.ptr(dx) if need_dx else None, in_f, 1,
+                                                _lib.ptr(loc), _lib.ptr(dz1s), None, _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2),
+                                                _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward_rows")
         return dx, None, dW1, db1, dW2, db2, None
 
 

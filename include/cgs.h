@@ -236,6 +236,15 @@ int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       int accumulate_dx, float *dZ1, float *dZ2, float *dW1,
                       float *db1, float *dW2, float *db2, int64_t n,
                       void *scratch, size_t scratch_bytes, void *stream);
+/* cgs_mlp2_backward with the input gradient of row r stored to (accumulate_dx != 0: added into) row dx_rows[r] of dX:
+ * the rows of a SUBSET of a larger batch (distinct indices; scene/gaussian_model.py:1658-1669 evaluates mlp_grid on
+ * the rate subset) — `dX.index_add_(0, dx_rows, .)` folded into the store.  Needs the saved hidden layer (H != NULL). */
+int cgs_mlp2_backward_rows(int in, int hid, int out, int act, const float *X, int64_t ldx,
+                           const float *W1, const float *b1, const float *W2, const float *Y,
+                           const float *dY, int64_t ldy, const float *H, float *dX, int64_t lddx,
+                           int accumulate_dx, const int64_t *dx_rows, float *dZ1, float *dZ2,
+                           float *dW1, float *db1, float *dW2, float *db2, int64_t n,
+                           void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- fused element-wise stages of the per-level context model (training path) ----
  * Reference: scene/gaussian_model.py:1556-1707 (multi_scale_generating).
