@@ -43,6 +43,7 @@ SIGNATURES = {
     "cgs_version": (c_int, []),
     "cgs_last_error": (C.c_char_p, []),
     "cgs_filter": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_filter_voxel": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_raster_geom_bytes": (c_size_t, [c_int64]),
     "cgs_raster_bin_bytes": (c_size_t, [c_int64, c_int64]),
     "cgs_raster_img_bytes": (c_size_t, [c_int32, c_int32]),

@@ -120,6 +120,20 @@ extern "C" int cgs_filter(const cgs_raster_cfg *cfg, int64_t N, const float *mea
                                  (hipStream_t)stream);
 }
 
+int cgs_launch_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const float *means3D, const float *scaling, int64_t ld,
+                            int scales_are_log, const float *rot1, uint8_t *visible, hipStream_t stream);
+
+// prefilter_voxel in one launch: scaling [N, ld] raw rows (columns 0..2 used; exp applied when scales_are_log), rot1 [4]
+// the normalised rotation shared by every anchor, visible [N] receives (radii > 0) as bool bytes.
+extern "C" int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const float *means3D, const float *scaling,
+                                int64_t ld, int scales_are_log, const float *rot1, uint8_t *visible, void *stream) {
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (N < 0 || ld < 3) { cgs_set_error("cgs_filter_voxel: bad N / ld"); return CGS_ERR_ARG; }
+    if (N > 0 && (!means3D || !scaling || !rot1 || !visible)) { cgs_set_error("cgs_filter_voxel: NULL input"); return CGS_ERR_ARG; }
+    return cgs_launch_filter_voxel(cfg, N, means3D, scaling, ld, scales_are_log, rot1, visible, (hipStream_t)stream);
+}
+
 // ---- forward stage 1 -----------------------------------------------------------------
 extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
                                      const float *colors, const float *opacities, const float *scales,

@@ -99,6 +99,51 @@ __global__ void __launch_bounds__(PRE_THREADS)
     }
 }
 
+// prefilter_voxel (gaussian_renderer/__init__.py:232-287) in one launch: the reference evaluates get_scaling /
+// get_rotation on all N rows and then reads three scale columns and rotation row 0 (:262-266, :283); here the kernel
+// reads the raw scaling rows (exp applied to the three columns it uses unless the model is decoded), takes the ONE
+// normalised rotation every anchor shares, and writes `radii_pure > 0` as a bool byte.  Same cgs_project as the
+// rasterizer's preprocess, so the same anchors are visible.
+__global__ void __launch_bounds__(PRE_THREADS)
+    filter_voxel_kernel(int64_t N, int W, int H, float tanfovx, float tanfovy, float scale_modifier,
+                        const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
+                        const float *__restrict__ means3D, const float *__restrict__ scaling, int64_t ld, int scales_are_log,
+                        const float *__restrict__ rot1, uint8_t *__restrict__ visible) {
+    const int64_t i = (int64_t)blockIdx.x * PRE_THREADS + threadIdx.x;
+    if (i >= N) return;
+    float V[16], Pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = viewmatrix[k]; Pm[k] = projmatrix[k]; }
+    const float3 p = make_float3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    float sx = scaling[i * ld], sy = scaling[i * ld + 1], sz = scaling[i * ld + 2];
+    if (scales_are_log) { sx = expf(sx); sy = expf(sy); sz = expf(sz); }
+    const float4 q = make_float4(rot1[0], rot1[1], rot1[2], rot1[3]);
+    CgsProj pr;
+    const bool ok = cgs_project<float>(p, make_float3(sx, sy, sz), q, V, Pm, W, H, tanfovx, tanfovy, scale_modifier, pr);
+    int32_t radius = 0;
+    if (ok) {
+        const int gx = (W + CGS_TILE - 1) / CGS_TILE, gy = (H + CGS_TILE - 1) / CGS_TILE;
+        const float r = pr.radius;
+        const int x0 = min(gx, max(0, (int)((pr.px - r) / (float)CGS_TILE)));
+        const int y0 = min(gy, max(0, (int)((pr.py - r) / (float)CGS_TILE)));
+        const int x1 = min(gx, max(0, (int)((pr.px + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
+        const int y1 = min(gy, max(0, (int)((pr.py + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
+        if ((x1 - x0) * (y1 - y0) > 0) radius = (int32_t)r;
+    }
+    visible[i] = radius > 0 ? 1 : 0;
+}
+
+int cgs_launch_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const float *means3D, const float *scaling, int64_t ld,
+                            int scales_are_log, const float *rot1, uint8_t *visible, hipStream_t stream) {
+    if (N == 0) return CGS_OK;
+    CgsProfScope prof(CGS_PROF_FILTER, stream);
+    hipLaunchKernelGGL(filter_voxel_kernel, dim3((unsigned)((N + PRE_THREADS - 1) / PRE_THREADS)), dim3(PRE_THREADS), 0, stream, N,
+                       cfg->image_width, cfg->image_height, cfg->tanfovx, cfg->tanfovy, cfg->scale_modifier, cfg->viewmatrix,
+                       cfg->projmatrix, means3D, scaling, ld, scales_are_log, rot1, visible);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
 int cgs_launch_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D, const float *colors,
                           const float *opacities, const float *scales, const float *rotations, CgsGeom &g,
                           int32_t *radii, bool filter_only, hipStream_t stream) {

@@ -394,14 +394,30 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
 
 def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):   # :232-287
     """Anchor-level frustum/size cull: bool[N]."""
-    rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier))
+    rs = _raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier)
     with torch.no_grad():
         means3D = pc.get_anchor
         # The reference evaluates get_scaling / get_rotation on all N rows and then reads three scale columns and
         # rotation row 0 (:262-266, :283: `rotations[[0], :].repeat(N, 1)`).  Both activations are row / element-wise,
         # so applying them to exactly what is read gives the same values: exp of 3 columns, normalisation of one row.
-        scales3 = pc._scaling[:, :3] if pc.decoded_version else torch.exp(pc._scaling[:, :3])
         rot0 = pc.rotation_activation(pc._rotation[:1])
+        sc = pc._scaling
+        if (means3D.is_cuda and sc.is_cuda and sc.dtype == torch.float32 and sc.dim() == 2 and sc.stride(1) == 1
+                and means3D.dtype == torch.float32):
+            # one launch (csrc/raster_geom.hip filter_voxel_kernel): exp of the three columns and the shared rotation are
+            # applied inside, the bool mask comes out directly — no exp / repeat / zero-fill / compare launches
+            from .rasterizer import _Cfg
+            cfg = _Cfg(rs)
+            N = int(means3D.shape[0])
+            m = means3D.contiguous()
+            r1 = rot0.reshape(-1).float().contiguous()
+            vis = torch.empty(N, dtype=torch.bool, device=m.device)
+            _lib.check(_lib.lib().cgs_filter_voxel(cfg.ref, N, _lib.ptr(m), sc.data_ptr(), int(sc.stride(0)),
+                                                   0 if pc.decoded_version else 1, _lib.ptr(r1), _lib.ptr(vis),
+                                                   _lib.current_stream()), "cgs_filter_voxel")
+            return vis
+        scales3 = sc[:, :3] if pc.decoded_version else torch.exp(sc[:, :3])
+        rasterizer = GaussianRasterizer(rs)
         radii_pure = rasterizer.visible_filter(means3D=means3D, scales=scales3,
                                                rotations=rot0.repeat(means3D.shape[0], 1), cov3D_precomp=None)
     return radii_pure > 0

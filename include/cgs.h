@@ -88,6 +88,12 @@ typedef struct cgs_raster_cfg {
 int cgs_filter(const cgs_raster_cfg *cfg, int64_t N, const float *means3D,
                const float *scales, const float *rotations, int32_t *radii,
                void *stream);
+/* prefilter_voxel (gaussian_renderer/__init__.py:232-287) in one launch: scaling [N, ld] = the model's RAW scaling rows
+ * (columns 0..2 are read; exp is applied when scales_are_log != 0, i.e. the model is not a decoded one), rot1 [4] the
+ * normalised rotation row every anchor shares (:283 repeats row 0), visible [N] receives `radii_pure > 0` as bool bytes. */
+int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const float *means3D,
+                     const float *scaling, int64_t ld, int scales_are_log, const float *rot1,
+                     uint8_t *visible, void *stream);
 
 /* Workspace sizes in bytes (host-side helpers, no device work). */
 size_t cgs_raster_geom_bytes(int64_t P);
