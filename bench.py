@@ -222,7 +222,10 @@ def main():
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tile_bits = max(1, (tiles - 1).bit_length())
         # algorithmic bytes per launch (SURVEY.md §8d / BASELINE.md §4; sort traffic is for OUR two-level
-        # sort: 4 passes over P (key+value, histogram read + scatter read/write) and ceil(bits/8) over R)
+        # sort: 4 passes over P (key+value, histogram read + scatter read/write); over R (csrc/tile_bin.hip, grids of
+        # <= 65536 tiles): a first pass that generates its pairs from 16 B per Gaussian (histogram + scatter) and writes
+        # 6-byte pairs ("emit_pairs"), a second pass that reads them and writes ids ("tile_sort"; the tile ranges come from
+        # atomics on its key runs + a prefix maximum over the tiles))
         alg = {
             "blend_fwd": 40 * R_eff + 20 * H * W,
             "blend_bwd": 76 * R_eff + 20 * H * W,
@@ -230,10 +233,10 @@ def main():
             "preprocess_bwd": (40 + 20 + 52) * P,
             "filter": 44 * N,
             "depth_sort": 4 * 20 * P + 4 * P,
-            "tile_sort": ((tile_bits + 7) // 8) * 20 * R,
-            "emit_pairs": 20 * P + 8 * R,
-            "offsets_scan": 20 * P,
-            "ranges": 4 * R + 8 * tiles,
+            "tile_sort": (12 * R if tile_bits > 8 else 0) if tile_bits <= 16 else ((tile_bits + 7) // 8) * 20 * R,
+            "emit_pairs": (2 * 16 * P + 6 * R) if tile_bits <= 16 else 20 * P + 8 * R,
+            "offsets_scan": 28 * P,
+            "ranges": (0 if tile_bits <= 16 else 4) * R + 16 * tiles,
             "expand_fwd": (396 - 200) * n_vis + 56 * P,
             "expand_bwd": 2 * (396 - 200) * n_vis + 56 * P,
         }

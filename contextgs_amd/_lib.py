@@ -11,7 +11,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgs_hip.so")
+# CGS_LIB_PATH: another build of the same library (tools/variant_lib.sh: one translation unit recompiled with timing-experiment
+# defines); the default is the in-tree product library
+LIB_PATH = os.environ.get("CGS_LIB_PATH") or os.path.join(_HERE, "libcgs_hip.so")
 
 _lib = None
 _lock = threading.Lock()

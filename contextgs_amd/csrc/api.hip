@@ -168,7 +168,8 @@ extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const
     }
     {
         CgsProfScope prof(CGS_PROF_OFFSETS_SCAN, stream);
-        if ((rc = cgs_launch_gather_tiles(P, g.order, g.tiles, g.sort_a, stream))) return rc;
+        // tile rectangles and tile counts in depth order (sort_b / sort_d / sort_a are free after the sort)
+        if ((rc = cgs_launch_gather_rects(P, g, stream))) return rc;
         if ((rc = cgs_scan_exclusive_u32_total(g.sort_a, g.offsets, P, g.scratch, g.scratch_bytes, g.total,
                                                stream)))
             return rc;
@@ -201,6 +202,7 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
     CgsImg im;
     memset(&g, 0, sizeof(g));
     memset(&b, 0, sizeof(b));
+    const bool bin16 = cgs_tile_bin16_ok(tile_bits(cfg));
     if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width)) {
         cgs_set_error("image workspace too small");
         return CGS_ERR_WORKSPACE;
@@ -214,15 +216,18 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
             cgs_set_error("binning workspace too small: %zu < %zu", bin_bytes, cgs_raster_bin_bytes(P, R));
             return CGS_ERR_WORKSPACE;
         }
-        if ((rc = cgs_launch_emit_pairs(cfg, P, g, b, stream))) return rc;
-        {
+        if (bin16) {
+            // csrc/tile_bin.hip: the first radix pass generates its pairs, 16-bit tile keys
+            if ((rc = cgs_launch_tile_bin16(cfg, P, R, tile_bits(cfg), g, b, im, stream))) return rc;
+        } else {
+            if ((rc = cgs_launch_emit_pairs(cfg, P, g, b, stream))) return rc;
             CgsProfScope prof(CGS_PROF_TILE_SORT, stream);
             if ((rc = cgs_sort_pairs_u32(b.tile_key_a, b.gid_a, b.tile_key_c, b.gid_sorted, b.tile_key_b, b.gid_b,
                                          R, 0, tile_bits(cfg), b.scratch, b.scratch_bytes, stream)))
                 return rc;
         }
     }
-    if ((rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
+    if (!(bin16 && R > 0) && (rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
     return cgs_launch_blend_fwd(cfg, g, b, im, out_color, stream);
 }
 

@@ -221,3 +221,16 @@ def test_prefilter_voxel_one_launch_equals_visible_filter(decoded):
             ref = GaussianRasterizer(_raster_settings(cam, pipe, bg, 1.0)).visible_filter(
                 means3D=pc.get_anchor, scales=sc, rotations=rot0.repeat(sc.shape[0], 1), cov3D_precomp=None) > 0
         assert got.dtype == torch.bool and torch.equal(got, ref) and 0 < int(got.sum()) < got.numel()
+
+
+def test_grid_above_65536_tiles_takes_the_32bit_key_path(oracle32):
+    """4112 x 4112 pixels = 257 x 257 tiles: one more than the 16-bit tile keys of csrc/tile_bin.hip hold, so the
+    rasterizer bins through emit_pairs + the 32-bit pair sort (csrc/api.hip); same image, same radii."""
+    W = H = 4112
+    cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
+    g = random_gaussians(400, seed=11, extent=1.0, scale_lo=0.003, scale_hi=0.05)
+    bg = (0.1, 0.25, 0.4)
+    ref = oracle32.render(cam.oracle_dict(bg=bg), **_kw(g))
+    out = _run_gpu(cam, g, bg)
+    assert (out["radii"] == ref["radii"]).all()
+    _check_image(out["color"], ref["color"])
