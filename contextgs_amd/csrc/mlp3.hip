@@ -26,6 +26,16 @@
 #define M3_BWD_WAVES 8
 #endif
 
+// M3_PIPE: explicit register double-buffering of the LDS weight fragments in the forward kernel
+#ifndef M3_PIPE
+#define M3_PIPE 0
+#endif
+#define M3_FENCE()                         \
+    do {                                   \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
 struct M3Head {
     const float *W1, *b1, *W2, *b2;
     float *Y;            // forward output [n, OUT] (backward: saved forward output, read-only use)
@@ -68,6 +78,36 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if M3_PIPE
+    // A fragments of k-group q + 1 are read from LDS before the 16 MFMAs of group q are issued (two register
+    // buffers): the compiler's own schedule reads two values, waits for them and issues two MFMAs, i.e. an exposed LDS
+    // round trip per pair (profiles/r03_mlp_pipeline.txt)
+    float a1[2][4][M3_NT1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) a1[0][j][t] = W1s[(4 * g + j) * L::S1 + 16 * t + c];
+#pragma unroll
+    for (int q = 0; q < M3_NTI; ++q) {
+        if (q + 1 < M3_NTI) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < M3_NT1; ++t)
+                    a1[(q + 1) & 1][j][t] = W1s[(16 * (q + 1) + 4 * g + j) * L::S1 + 16 * t + c];
+        }
+        M3_FENCE();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (16 * q + j >= M3_IN) continue;
+#pragma unroll
+            for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = frag_mfma(a1[q & 1][j][t], xb[rt][q][j], acc1[t][rt]);
+        }
+        M3_FENCE();
+    }
+#else
 #pragma unroll
     for (int q = 0; q < M3_NTI; ++q)
 #pragma unroll
@@ -80,6 +120,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
                 for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = frag_mfma(a, xb[rt][q][j], acc1[t][rt]);
             }
         }
+#endif
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
@@ -94,6 +135,34 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
     for (int u = 0; u < L::NT2; ++u)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if M3_PIPE
+    float a2[2][4][L::NT2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < L::NT2; ++u) a2[0][r][u] = W2s[(4 * g + r) * L::S2 + 16 * u + c];
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) {
+        if (t + 1 < M3_NT1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * (t + 1) + r >= M3_HID) continue;
+#pragma unroll
+                for (int u = 0; u < L::NT2; ++u) a2[(t + 1) & 1][r][u] = W2s[(16 * (t + 1) + 4 * g + r) * L::S2 + 16 * u + c];
+            }
+        }
+        M3_FENCE();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * t + r >= M3_HID) continue;
+#pragma unroll
+            for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = frag_mfma(a2[t & 1][r][u], acc1[t][rt][r], acc2[u][rt]);
+        }
+        M3_FENCE();
+    }
+#else
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
@@ -106,6 +175,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
                 for (int rt = 0; rt < RT; ++rt) acc2[u][rt] = frag_mfma(a, acc1[t][rt][r], acc2[u][rt]);
             }
         }
+#endif
 #pragma unroll
     for (int u = 0; u < L::NT2; ++u)
 #pragma unroll

@@ -292,25 +292,24 @@ __global__ void __launch_bounds__(1024)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < a.E; i += 1024) img[i] = 0.f;
-    __syncthreads();
     const int ti = wave % a.ntask, sub = wave / a.ntask;
-    if (sub < a.nsub) {
-        // scalar copies of the task (dynamic indexing of the by-value argument struct)
-        const float *P = nullptr, *Q = nullptr;
-        int ldp = 0, ldq = 0, DA = 0, DB = 0, ga = 0, gb = 0, img_off = 0;
+    // scalar copies of the task (dynamic indexing of the by-value argument struct)
+    const float *P = nullptr, *Q = nullptr;
+    int ldp = 0, ldq = 0, DA = 0, DB = 0, ga = 0, gb = 0, img_off = 0;
 #pragma unroll
-        for (int k = 0; k < WGM_MAX_TASKS; ++k)
-            if (k == ti) {
-                P = a.t[k].P; Q = a.t[k].Q; ldp = a.t[k].ldp; ldq = a.t[k].ldq; DA = a.t[k].DA; DB = a.t[k].DB;
-                ga = a.t[k].ga; gb = a.t[k].gb; img_off = a.t[k].img_off;
-            }
+    for (int k = 0; k < WGM_MAX_TASKS; ++k)
+        if (k == ti) {
+            P = a.t[k].P; Q = a.t[k].Q; ldp = a.t[k].ldp; ldq = a.t[k].ldq; DA = a.t[k].DA; DB = a.t[k].DB;
+            ga = a.t[k].ga; gb = a.t[k].gb; img_off = a.t[k].img_off;
+        }
+    f32x4 acc[4][4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (sub < a.nsub) {
         const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
         const int64_t r_end = min(n, r_begin + rows_per_block);
-        f32x4 acc[4][4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ja = 0; ja < 4; ++ja)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end);
         const WgStream sb = wg_stream(Q, ldq, DB, gb, c, r_begin, r_end);
         const int rows = (int)(r_end - r_begin), stride = a.nsub * 4 * UNR;
@@ -327,32 +326,40 @@ __global__ void __launch_bounds__(1024)
             wg_consume<UNR>(f1, sa, sb, acc, bsum);
             WG_FENCE();
         }
-        float *const outW = img + img_off;
-        float *const outb = outW + DA * DB;
-        const int acol0 = 64 * ga + 4 * c, bcol0 = 64 * gb + 4 * c;
+    }
+    __syncthreads();      // image zeroed
+    // Image update without LDS float atomics (ds_add_f32 retires ~0.6 lanes per clock on gfx950: 16 waves x 68 wave-wide
+    // atomics were a fixed ~40 us of every launch): tasks own disjoint parts of the image, and the nsub waves of one task
+    // take turns, separated by workgroup barriers, with plain read-add-write.
+    for (int s = 0; s < a.nsub; ++s) {
+        if (sub == s) {
+            float *const outW = img + img_off;
+            float *const outb = outW + DA * DB;
+            const int acol0 = 64 * ga + 4 * c, bcol0 = 64 * gb + 4 * c;
 #pragma unroll
-        for (int ja = 0; ja < 4; ++ja)
+            for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ar = 64 * ga + 4 * (4 * g + r) + ja;
-                if (ar >= DA) continue;
+                for (int r = 0; r < 4; ++r) {
+                    const int ar = 64 * ga + 4 * (4 * g + r) + ja;
+                    if (ar >= DA) continue;
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const int b = bcol0 + jb;
-                    if (b < DB) atomicAdd(&outW[ar * DB + b], acc[ja][jb][r]);
+                    for (int jb = 0; jb < 4; ++jb) {
+                        const int b = bcol0 + jb;
+                        if (b < DB) outW[ar * DB + b] += acc[ja][jb][r];
+                    }
+                }
+            if (gb == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = bsum[j];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (g == 0 && acol0 + j < DA) outb[acol0 + j] += v;
                 }
             }
-        if (gb == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = bsum[j];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (g == 0 && acol0 + j < DA) atomicAdd(&outb[acol0 + j], v);
-            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     float *dst = partial + (int64_t)blockIdx.x * a.E;
     for (int i = tid; i < a.E; i += 1024) dst[i] = img[i];
 }
