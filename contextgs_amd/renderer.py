@@ -261,6 +261,10 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     vis_idx = vis_pending.wait() if vis_pending is not None else torch.nonzero(visible_mask)[:, 0]
     sel = lambda t: gather_unique(t, vis_idx)
     anchor = sel(full_anchor)
+    if use_context:
+        # enqueued here, in front of the context model's count read-back: the host falls behind the device while it
+        # waits there, and a gather the device still has queued covers part of the catch-up
+        binary_grid_masks = sel(binary_all)
     if not use_context:
         # raw features of the visible anchors: left as (source, rows) when nothing is added to them, so that the
         # anchor-MLP kernel gathers them itself
@@ -297,7 +301,6 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         feat, grid_scaling, grid_offsets = res[:3]
         if is_training:
             rate_thunk = res[3]         # the rate model (:1657-1707) is enqueued behind the expansion's count (see below)
-        binary_grid_masks = sel(binary_all)
 
     K = pc.n_offsets
     rate_out = []
