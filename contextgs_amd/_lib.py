@@ -52,6 +52,11 @@ SIGNATURES = {
     "cgs_raster_bwd_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_raster_preprocess": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p, C.POINTER(c_int64), c_void_p]),
+    "cgs_raster_preprocess_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_raster_preprocess_wait": (c_int, [C.POINTER(c_int64)]),
+    "cgs_raster_render_spec": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
+                                       c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_render": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
                                   c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_backward": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -135,16 +135,27 @@ extern "C" int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const floa
 }
 
 // ---- forward stage 1 -----------------------------------------------------------------
-extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
-                                     const float *colors, const float *opacities, const float *scales,
-                                     const float *rotations, void *geom_ws, size_t geom_bytes, int32_t *radii,
-                                     int64_t *num_rendered_host, void *stream_) {
+// cgs_raster_preprocess_launch enqueues projection, the depth sort and the pair-offset scan, and the 4-byte copy of the
+// pair count behind them; cgs_raster_preprocess_wait blocks on THAT copy's event only.  What the caller enqueues in between
+// (cgs_raster_render_spec) keeps the device busy while the host learns the count.  cgs_raster_preprocess = both.
+struct RasterCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
+static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false};
+
+extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+                                            const float *colors, const float *opacities, const float *scales,
+                                            const float *rotations, void *geom_ws, size_t geom_bytes, int32_t *radii,
+                                            void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    RasterCountSlot &sl = g_raster_slot;
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (P < 0 || P >= (1ll << 31)) { cgs_set_error("P out of range"); return CGS_ERR_ARG; }
-    if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
-    *num_rendered_host = 0;
+    if (!sl.pinned) {
+        CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
+        CGS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    sl.pending = false;
+    sl.pinned[0] = 0;
     if (P == 0) return CGS_OK;
     if (!means3D || !colors || !opacities || !scales || !rotations || !radii || !geom_ws) {
         cgs_set_error("cgs_raster_preprocess: NULL input");
@@ -174,12 +185,35 @@ extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const
                                                stream)))
             return rc;
     }
-    static thread_local uint32_t *pinned = nullptr;
-    if (!pinned) CGS_CHECK_HIP(hipHostMalloc((void **)&pinned, 64, hipHostMallocDefault));
-    CGS_CHECK_HIP(hipMemcpyAsync(pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CGS_CHECK_HIP(hipStreamSynchronize(stream));
-    *num_rendered_host = (int64_t)pinned[0];
+    CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
+    sl.pending = true;
     return CGS_OK;
+}
+
+extern "C" int cgs_raster_preprocess_wait(int64_t *num_rendered_host) {
+    RasterCountSlot &sl = g_raster_slot;
+    if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
+    *num_rendered_host = 0;
+    if (!sl.pinned) { cgs_set_error("cgs_raster_preprocess_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (sl.pending) {
+        CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    *num_rendered_host = (int64_t)sl.pinned[0];
+    return CGS_OK;
+}
+
+extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+                                     const float *colors, const float *opacities, const float *scales,
+                                     const float *rotations, void *geom_ws, size_t geom_bytes, int32_t *radii,
+                                     int64_t *num_rendered_host, void *stream_) {
+    if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
+    *num_rendered_host = 0;
+    int rc = cgs_raster_preprocess_launch(cfg, P, means3D, colors, opacities, scales, rotations, geom_ws, geom_bytes, radii,
+                                          stream_);
+    if (rc) return rc;
+    return cgs_raster_preprocess_wait(num_rendered_host);
 }
 
 // ---- forward stage 2 -----------------------------------------------------------------
@@ -190,10 +224,9 @@ static int tile_bits(const cgs_raster_cfg *cfg) {
     return bits;
 }
 
-extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws,
-                                 size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
-                                 size_t img_bytes, float *out_color, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int raster_render_impl(const cgs_raster_cfg *cfg, int64_t P, int64_t R, bool spec, void *geom_ws,
+                              size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
+                              size_t img_bytes, float *out_color, hipStream_t stream) {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!cfg->bg || !out_color || !img_ws) { cgs_set_error("cgs_raster_render: NULL input"); return CGS_ERR_ARG; }
@@ -203,6 +236,10 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
     memset(&g, 0, sizeof(g));
     memset(&b, 0, sizeof(b));
     const bool bin16 = cgs_tile_bin16_ok(tile_bits(cfg));
+    if (spec && (!bin16 || P <= 0 || R <= 0)) {
+        cgs_set_error("cgs_raster_render_spec: needs a grid of <= 65536 tiles, P > 0 and a positive capacity");
+        return CGS_ERR_ARG;
+    }
     if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width)) {
         cgs_set_error("image workspace too small");
         return CGS_ERR_WORKSPACE;
@@ -218,7 +255,7 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
         }
         if (bin16) {
             // csrc/tile_bin.hip: the first radix pass generates its pairs, 16-bit tile keys
-            if ((rc = cgs_launch_tile_bin16(cfg, P, R, tile_bits(cfg), g, b, im, stream))) return rc;
+            if ((rc = cgs_launch_tile_bin16(cfg, P, R, tile_bits(cfg), g, b, im, stream, spec ? g.total : nullptr))) return rc;
         } else {
             if ((rc = cgs_launch_emit_pairs(cfg, P, g, b, stream))) return rc;
             CgsProfScope prof(CGS_PROF_TILE_SORT, stream);
@@ -229,6 +266,24 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
     }
     if (!(bin16 && R > 0) && (rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
     return cgs_launch_blend_fwd(cfg, g, b, im, out_color, stream);
+}
+
+extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws,
+                                 size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
+                                 size_t img_bytes, float *out_color, void *stream_) {
+    return raster_render_impl(cfg, P, R, false, geom_ws, geom_bytes, bin_ws, bin_bytes, img_ws, img_bytes, out_color,
+                              (hipStream_t)stream_);
+}
+
+// Speculative render between cgs_raster_preprocess_launch and _wait: R_cap is the capacity of the binning workspace
+// (cgs_raster_bin_bytes(P, R_cap)), the pair count itself stays on the device.  Valid when the count _wait returns is
+// <= R_cap (the per-tile lists are then exactly those of cgs_raster_render, and the backward takes R_cap as its R);
+// otherwise the caller renders again with cgs_raster_render and the true count.  Grids of more than 65536 tiles: CGS_ERR_ARG.
+extern "C" int cgs_raster_render_spec(const cgs_raster_cfg *cfg, int64_t P, int64_t R_cap, void *geom_ws,
+                                      size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
+                                      size_t img_bytes, float *out_color, void *stream_) {
+    return raster_render_impl(cfg, P, R_cap, true, geom_ws, geom_bytes, bin_ws, bin_bytes, img_ws, img_bytes, out_color,
+                              (hipStream_t)stream_);
 }
 
 // ---- backward -----------------------------------------------------------------------------

@@ -123,7 +123,7 @@ int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &i
 int cgs_launch_gather_rects(int64_t P, CgsGeom &g, hipStream_t stream);
 bool cgs_tile_bin16_ok(int tile_bits);
 int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int tile_bits, CgsGeom &g, CgsBin &b, CgsImg &im,
-                          hipStream_t stream);     // per-tile lists AND im.ranges
+                          hipStream_t stream, const uint32_t *R_dev = nullptr);     // per-tile lists AND im.ranges
 // raster_blend_rows.hip: row-mapped variants (four 4x4 blocks per wave), selected by cgs_blend_rows_enabled()
 int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                               hipStream_t stream);

@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256)
     if (i < n && a[i] != b[i]) atomicAdd(out, 1ull);
 }
 
-extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws, size_t geom_bytes,
+extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int64_t R_ws /* the count bin_ws was carved with */,
+                                     void *geom_ws, size_t geom_bytes,
                                      void *bin_ws, size_t bin_bytes, void *img_ws, size_t img_bytes, void *bin_ws2,
                                      size_t bin_bytes2, void *ranges2 /* [tiles] uint2 */, int64_t *out2, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -202,7 +203,7 @@ extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64
     CgsBin b, b2;
     CgsImg im, im2;
     if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width) || !cgs_geom_carve(&g, geom_ws, geom_bytes, P) ||
-        !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R) || !cgs_bin_carve(&b2, bin_ws2, bin_bytes2, P, R)) {
+        !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R_ws) || !cgs_bin_carve(&b2, bin_ws2, bin_bytes2, P, R)) {
         cgs_set_error("debug_bin_compare: workspace");
         return CGS_ERR_WORKSPACE;
     }

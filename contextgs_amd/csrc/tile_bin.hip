@@ -48,9 +48,10 @@ __global__ void __launch_bounds__(256)
 // ranges (the last pass accumulates into them).
 __global__ void __launch_bounds__(256)
     block_first_kernel(int64_t nb, int64_t P, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ bf, int nt,
-                       uint2 *__restrict__ ranges) {
+                       uint2 *__restrict__ ranges, const uint32_t *__restrict__ R_dev, uint32_t R_cap) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b < nt) ranges[b] = make_uint2(0u, 0u);
+    if (R_dev) nb = ((int64_t)min(*R_dev, R_cap) + TB_TILE - 1) / TB_TILE;      // speculative launch: the pair count is on the device
     if (b > nb) return;
     if (b == nb) { bf[b] = (uint32_t)(P - 1); return; }
     const uint32_t target = (uint32_t)(b * TB_TILE);
@@ -131,7 +132,8 @@ __global__ void __launch_bounds__(TB_THREADS)
     tb_hist_kernel(const uint16_t *__restrict__ keys, const uint32_t *__restrict__ offsets,
                    const uint32_t *__restrict__ rect_lo, const uint32_t *__restrict__ rect_hi,
                    const uint32_t *__restrict__ bf, int64_t P, uint32_t R, uint32_t tiles_x,
-                   uint32_t *__restrict__ hist /*[rows][nblocks]*/, int shift, int nbits) {
+                   uint32_t *__restrict__ hist /*[rows][nblocks]*/, int shift, int nbits, const uint32_t *__restrict__ R_dev) {
+    if (R_dev) R = min(*R_dev, R);         // speculative launch: R (argument) is the capacity, the count is on the device
     __shared__ uint32_t h[TB_MAXR];
     __shared__ uint32_t sidx[GEN ? TB_TILE : 1];
     __shared__ uint32_t swave[TB_WAVES];
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(TB_THREADS)
     h[tid] = 0;
     const uint32_t base = blockIdx.x * (uint32_t)TB_TILE;
     uint32_t i_lo = 0;
-    if (GEN) {
+    if (GEN && base < R) {                 // (base >= R: a block past the pairs of a speculative launch writes zeros)
         i_lo = bf[blockIdx.x];
         build_owner_index(sidx, swave, base, i_lo, bf[blockIdx.x + 1], P, R, offsets);
     } else {
@@ -167,7 +169,9 @@ __global__ void __launch_bounds__(TB_THREADS)
                       const uint32_t *__restrict__ rect_hi, const uint32_t *__restrict__ order,
                       const uint32_t *__restrict__ bf, int64_t P, uint32_t R, uint32_t tiles_x,
                       uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint2 *__restrict__ ranges,
-                      const uint32_t *__restrict__ hist_scanned, int shift) {
+                      const uint32_t *__restrict__ hist_scanned, int shift, const uint32_t *__restrict__ R_dev) {
+    if (R_dev) R = min(*R_dev, R);
+    if (blockIdx.x * (uint32_t)TB_TILE >= R) return;
     constexpr int nbits = NBITS;
     __shared__ uint32_t wcnt[TB_WAVES][TB_MAXR];
     __shared__ uint32_t lstart[TB_MAXR], gbase[TB_MAXR];
@@ -350,8 +354,11 @@ int cgs_launch_gather_rects(int64_t P, CgsGeom &g, hipStream_t stream) {
 bool cgs_tile_bin16_ok(int tile_bits) { return tile_bits <= 16; }
 
 // per-tile lists of Gaussian ids (b.gid_sorted) and their tile keys ((uint16_t *)b.tile_key_c), depth order inside a tile
+// R_dev != nullptr: speculative launch — R is a CAPACITY (the binning workspace holds R pairs), the pair count is read on
+// the device from *R_dev by every kernel; a count above the capacity leaves garbage inside the workspace and the caller
+// renders again (cgs_raster_render_spec).
 int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int tile_bits, CgsGeom &g, CgsBin &b, CgsImg &im,
-                          hipStream_t stream) {
+                          hipStream_t stream, const uint32_t *R_dev) {
     const int nt = cgs_tiles_x(cfg) * cgs_tiles_y(cfg);
     if (R == 0 || P == 0) {
         CGS_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)nt * sizeof(uint2), stream));
@@ -378,7 +385,7 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
 #define TB_SCATTER_N(GEN, FINAL, N, KIN, VIN, KOUT, VOUT, SHIFT)                                                          \
     hipLaunchKernelGGL((tb_scatter_kernel<GEN, FINAL, N>), dim3((unsigned)nb), dim3(TB_THREADS), 0, stream, KIN, VIN,     \
                        offsets, rlo, rhi, order, (const uint32_t *)bf, P, (uint32_t)R, tiles_x, KOUT, VOUT, im.ranges,    \
-                       (const uint32_t *)hist, SHIFT)
+                       (const uint32_t *)hist, SHIFT, R_dev)
 #define TB_SCATTER(GEN, FINAL, NB, KIN, VIN, KOUT, VOUT, SHIFT)                                                           \
     do { switch (NB) {                                                                                                    \
         case 1: TB_SCATTER_N(GEN, FINAL, 1, KIN, VIN, KOUT, VOUT, SHIFT); break;                                          \
@@ -395,10 +402,10 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
         CgsProfScope prof(CGS_PROF_EMIT_PAIRS, stream);
         const int64_t nthr = nb + 1 > nt ? nb + 1 : nt;
         hipLaunchKernelGGL(block_first_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, nb, P, offsets, bf,
-                           nt, im.ranges);
+                           nt, im.ranges, R_dev, (uint32_t)R);
         hipLaunchKernelGGL(tb_hist_kernel<true>, dim3((unsigned)nb), dim3(TB_THREADS), 0, stream,
                            (const uint16_t *)nullptr, offsets, rlo, rhi, (const uint32_t *)bf, P, (uint32_t)R, tiles_x,
-                           hist, 0, bits_a);
+                           hist, 0, bits_a, R_dev);
         CGS_CHECK_HIP(hipGetLastError());
         if ((rc = cgs_scan_exclusive_u32_total(hist, hist, (int64_t)(1 << bits_a) * nb, scan_scratch, scan_bytes, nullptr,
                                                stream)))
@@ -414,7 +421,7 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
         CgsProfScope prof(CGS_PROF_TILE_SORT, stream);
         hipLaunchKernelGGL(tb_hist_kernel<false>, dim3((unsigned)nb), dim3(TB_THREADS), 0, stream,
                            (const uint16_t *)key_a, offsets, rlo, rhi, (const uint32_t *)bf, P, (uint32_t)R, tiles_x, hist,
-                           bits_a, bits_b);
+                           bits_a, bits_b, R_dev);
         CGS_CHECK_HIP(hipGetLastError());
         if ((rc = cgs_scan_exclusive_u32_total(hist, hist, (int64_t)(1 << bits_b) * nb, scan_scratch, scan_bytes, nullptr,
                                                stream)))

@@ -15,6 +15,7 @@ gaussian_renderer/__init__.py:197-205, 280-285); the others raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -68,6 +69,13 @@ class _Cfg:
 
 last_call: dict = {}   # sizes / image workspace of the most recent forward (bench.py's byte accounting)
 
+# Pair-count speculation (cgs_raster_render_spec): the binning + blend of a view are enqueued before the host has read the
+# view's pair count, into a workspace sized from the largest count seen so far for that image size (x 1.25); the count is
+# read through an event while the device renders.  A view that needs more pairs than that is rendered again with its true
+# count (same buffers, same stream: nothing has consumed the first attempt).  CGS_RASTER_SPEC=0 turns it off.
+SPECULATE = os.environ.get("CGS_RASTER_SPEC", "1") != "0"
+_pair_capacity: dict = {}     # (H, W) -> largest pair count seen
+
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -92,17 +100,31 @@ class _RasterizeGaussians(torch.autograd.Function):
         img = _workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         R = C.c_int64(0)
-        _lib.check(L.cgs_raster_preprocess(cfg.ref, P, _lib.ptr(means3D_c), _lib.ptr(colors_c), _lib.ptr(opac_c),
-                                           _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
-                                           _lib.ptr(radii), C.byref(R), stream), "cgs_raster_preprocess")
+        _lib.check(L.cgs_raster_preprocess_launch(cfg.ref, P, _lib.ptr(means3D_c), _lib.ptr(colors_c), _lib.ptr(opac_c),
+                                                  _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
+                                                  _lib.ptr(radii), stream), "cgs_raster_preprocess_launch")
+        tiles = ((H + 15) // 16) * ((W + 15) // 16)
+        seen = _pair_capacity.get((H, W), 0)
+        cap = (seen + seen // 4 + 4096) if (SPECULATE and seen > 0 and P > 0 and tiles <= 65536) else 0
+        binws = None
+        if cap:
+            binws = _workspace(L.cgs_raster_bin_bytes(P, cap), dev)
+            _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
+                                                binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
+                       "cgs_raster_render_spec")
+        _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
         num_rendered = int(R.value)
-        binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
-        _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
-                                       binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
-                   "cgs_raster_render")
+        _pair_capacity[(H, W)] = max(seen, num_rendered)
+        bin_R = cap                              # the count the binning workspace was carved with (the backward's `R`)
+        if not cap or num_rendered > cap:
+            bin_R = num_rendered
+            binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
+            _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
+                                           binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
+                       "cgs_raster_render")
         ctx.cfg = cfg
-        ctx.num_rendered = num_rendered
-        last_call.update(P=P, num_rendered=num_rendered, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
+        ctx.num_rendered = bin_R
+        last_call.update(P=P, num_rendered=num_rendered, bin_R=bin_R, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
         ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii)
         return color, radii

@@ -7,7 +7,7 @@
  * caller owns every buffer; the library never allocates or frees device
  * memory and never synchronises the device, except for the single 4-byte
  * read-back of `num_rendered` in cgs_raster_preprocess (the reference
- * rasterizer has the same one).  Every function returns 0 on success and a
+ * rasterizer has the same one; cgs_raster_preprocess_launch / _wait + cgs_raster_render_spec hide it behind the render).  Every function returns 0 on success and a
  * non-zero code otherwise; cgs_last_error() gives the thread-local message.
  *
  * What each group replaces in the reference (wyf0912/ContextGS, paths
@@ -111,12 +111,32 @@ int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P,
                           size_t geom_bytes, int32_t *radii,
                           int64_t *num_rendered_host, void *stream);
 
-/* Forward, stage 2: pair emission, per-tile stable sort, ranges, alpha blend.
+/* The same in two halves: _launch enqueues everything of stage 1 plus the 4-byte copy of the pair count and returns;
+ * _wait blocks on THAT copy's event only (no stream drain) and returns the count.  Between the halves the caller may enqueue
+ * cgs_raster_render_spec (below), so that the device works on the binning and the blend while the host learns the count. */
+int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P,
+                                 const float *means3D, const float *colors,
+                                 const float *opacities, const float *scales,
+                                 const float *rotations, void *geom_ws,
+                                 size_t geom_bytes, int32_t *radii, void *stream);
+int cgs_raster_preprocess_wait(int64_t *num_rendered_host);
+
+/* Forward, stage 2: per-tile lists (stable by depth inside a tile), tile ranges, alpha blend.
  * out_color is [3, H, W]. */
 int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P,
                       int64_t num_rendered, void *geom_ws, size_t geom_bytes,
                       void *bin_ws, size_t bin_bytes, void *img_ws,
                       size_t img_bytes, float *out_color, void *stream);
+
+/* Stage 2 enqueued BEFORE the pair count is known on the host: `capacity` pairs fit the binning workspace
+ * (cgs_raster_bin_bytes(P, capacity)), the kernels read the count on the device.  The result is the one of
+ * cgs_raster_render when the count cgs_raster_preprocess_wait returns is <= capacity (pass `capacity` as num_rendered to
+ * cgs_raster_backward then); otherwise it is garbage inside the buffers and the caller calls cgs_raster_render with the
+ * true count.  Grids of more than 65536 tiles, P == 0 or capacity <= 0: error, nothing enqueued. */
+int cgs_raster_render_spec(const cgs_raster_cfg *cfg, int64_t P,
+                           int64_t capacity, void *geom_ws, size_t geom_bytes,
+                           void *bin_ws, size_t bin_bytes, void *img_ws,
+                           size_t img_bytes, float *out_color, void *stream);
 
 /* Backward of the two stages above.  dL_dout is [3,H,W].  dL_dcolors and
  * dL_dopacities must be zero-initialised by the caller (the blend pass

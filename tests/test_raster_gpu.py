@@ -236,33 +236,54 @@ def test_grid_above_65536_tiles_takes_the_32bit_key_path(oracle32):
     _check_image(out["color"], ref["color"])
 
 
+def _bin_compare():
+    """[differing list entries, differing range words] between the lists of the last forward and the round-1 binning"""
+    import ctypes as C
+    from contextgs_amd import _lib
+    from contextgs_amd.rasterizer import last_call
+    L = _lib.lib()
+    R, R_ws, Pn = int(last_call["num_rendered"]), int(last_call["bin_R"]), int(last_call["P"])
+    assert R > 0
+    cfg = last_call["cfg"]
+    dev = last_call["bin_ws"].device
+    bin2 = torch.empty(int(L.cgs_raster_bin_bytes(Pn, R)), dtype=torch.uint8, device=dev)
+    tiles = ((cfg.c.image_width + 15) // 16) * ((cfg.c.image_height + 15) // 16)
+    ranges2 = torch.zeros(tiles * 2, dtype=torch.int32, device=dev)
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    f = L.cgs_debug_bin_compare
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib.check(f(cfg.ref, Pn, R, R_ws, _lib.ptr(last_call["geom_ws"]), last_call["geom_ws"].numel(),
+                 _lib.ptr(last_call["bin_ws"]), last_call["bin_ws"].numel(), _lib.ptr(last_call["img_ws"]),
+                 last_call["img_ws"].numel(), _lib.ptr(bin2), bin2.numel(), _lib.ptr(ranges2), _lib.ptr(out),
+                 _lib.current_stream()), "cgs_debug_bin_compare")
+    return out.tolist(), R, R_ws
+
+
 @pytest.mark.parametrize("P,W,H,scale_hi", [(4000, 256, 256, 0.05), (30000, 800, 800, 0.02), (20000, 1920, 1080, 0.08),
                                              (300, 97, 61, 0.4)])
 def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
     """csrc/tile_bin.hip (pair-generating first radix pass, 16-bit tile keys, ranges from the last pass) leaves the same
     per-tile lists, entry for entry, and the same tile ranges as the round-1 binning (emit_pairs + stable 32-bit pair sort,
     the path the oracle comparisons of rounds 1-2 ran on): one pass (256 tiles), 6+6 and 7+6 bit passes, a 28-tile grid
-    with splats that cover all of it."""
-    import ctypes as C
-    from contextgs_amd import _lib
-    from contextgs_amd.rasterizer import last_call
-    L = _lib.lib()
+    with splats that cover all of it.  Three renders of each scene: with the pair count known on the host, speculative
+    (count read on the device, capacity 1.25 x the first render's), and speculative with a capacity that is too small
+    (the view is rendered again with the true count)."""
+    from contextgs_amd import rasterizer as rz
     cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
     g = random_gaussians(P, seed=P, extent=1.0, scale_lo=0.003, scale_hi=scale_hi)
-    _run_gpu(cam, g, (0.0, 0.0, 0.0))
-    R, Pn = int(last_call["num_rendered"]), int(last_call["P"])
-    assert R > 0
-    cfg = last_call["cfg"]
-    dev = last_call["bin_ws"].device
-    bin2 = torch.empty_like(last_call["bin_ws"])
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    ranges2 = torch.zeros(tiles * 2, dtype=torch.int32, device=dev)
-    out = torch.zeros(2, dtype=torch.int64, device=dev)
-    f = L.cgs_debug_bin_compare
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
-    _lib.check(f(cfg.ref, Pn, R, _lib.ptr(last_call["geom_ws"]), last_call["geom_ws"].numel(), _lib.ptr(last_call["bin_ws"]),
-                 last_call["bin_ws"].numel(), _lib.ptr(last_call["img_ws"]), last_call["img_ws"].numel(), _lib.ptr(bin2),
-                 bin2.numel(), _lib.ptr(ranges2), _lib.ptr(out), _lib.current_stream()), "cgs_debug_bin_compare")
-    assert out.tolist() == [0, 0], (out.tolist(), R)
+    rz._pair_capacity.pop((H, W), None)
+    first = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]
+    diff, R, R_ws = _bin_compare()
+    assert diff == [0, 0] and R_ws == R, (diff, R, R_ws)
+    again = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]              # speculative: the capacity comes from the first render
+    diff, R2, R_ws = _bin_compare()
+    assert diff == [0, 0] and R2 == R and R_ws == R + R // 4 + 4096, (diff, R2, R_ws)
+    assert (again == first).all()
+    rz._pair_capacity[(H, W)] = 1                                    # capacity 4097 pairs: all but the 28-tile case need more
+    third = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]
+    diff, R3, R_ws = _bin_compare()
+    assert diff == [0, 0] and R3 == R and R_ws == (R if R > 4097 else 4097), (diff, R3, R_ws)
+    assert R > 4097 or P == 300
+    assert (third == first).all()

@@ -19,7 +19,7 @@ f = L.cgs_debug_blend_occupancy
 f.restype = C.c_int
 f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
 lc = last_call
-rc = f(C.addressof(lc["cfg"].c), lc["P"], lc["num_rendered"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
+rc = f(C.addressof(lc["cfg"].c), lc["P"], lc["bin_R"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
        lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out.data_ptr(), None)
 torch.cuda.synchronize()
 q, b, v, e, o, ph = out.tolist()
@@ -32,7 +32,7 @@ out5 = torch.zeros(5, dtype=torch.int64, device="cuda")
 f2 = L.cgs_debug_blend_splat_occupancy
 f2.restype = C.c_int
 f2.argtypes = f.argtypes
-rc = f2(C.addressof(lc["cfg"].c), lc["P"], lc["num_rendered"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
+rc = f2(C.addressof(lc["cfg"].c), lc["P"], lc["bin_R"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
         lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out5.data_ptr(), None)
 torch.cuda.synchronize()
 pairs, visits, hits, blkv, buckets = out5.tolist()
