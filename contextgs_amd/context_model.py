@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib
 from . import ctx_ops as _ctx
 from . import encodings as _enc
 from . import mlp as _mlp
@@ -356,11 +357,21 @@ class _GatherUnique(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.shape = x.shape
         ctx.complete = complete and idx.shape[0] == x.shape[0]
+        ctx.ascending = bool(getattr(idx, "_cgs_ascending", False))
         return x.index_select(0, idx)
 
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
+        n, N = int(idx.shape[0]), int(ctx.shape[0])
+        if (ctx.ascending and not ctx.complete and g.is_cuda and g.dtype == torch.float32 and N > 0 and 8 * n >= N
+                and idx.dtype == torch.int64):
+            # ascending rows (the visible-anchor list): zero fill and scatter in ONE pass (cgs_scatter_rows_sorted)
+            g = g.contiguous()
+            out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+            _lib.check(_lib.lib().cgs_scatter_rows_sorted(_lib.ptr(g), _lib.ptr(idx), n, N, int(out[0].numel()), _lib.ptr(out),
+                                                         _lib.current_stream()), "cgs_scatter_rows_sorted")
+            return out, None, None
         # `complete`: idx is a permutation of all rows, every row is written, no zero fill needed
         out = (torch.empty if ctx.complete else torch.zeros)(ctx.shape, dtype=g.dtype, device=g.device)
         out.index_copy_(0, idx, g.contiguous())
@@ -503,8 +514,9 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             use_fused = fused and subset_mode
             if ctx_src is None:                                                        # :1596-1600
                 if use_fused:
-                    a_src = anchor * mask_anchor_bool.unsqueeze(1) if (i >= 1 and mask_anchor_bool is not None) else anchor
-                    feat_in = _ctx.rowcat([(a_src, orig, True), (hyp_l[j], None, True)])
+                    # (masked anchors sit at the origin from level 1 up, :1758-1759: the product is folded into the gather)
+                    a_mask = mask_anchor_bool if (i >= 1 and mask_anchor_bool is not None) else None
+                    feat_in = _ctx.rowcat([(anchor, orig, True, a_mask), (hyp_l[j], None, True)])
                 else:
                     feat_in = torch.cat([level_anchors(anchor, mask_anchor_bool, i, orig), hyp_l[j].float()], dim=1)
             else:

@@ -18,6 +18,7 @@ struct RowcatArgs {
     const float *src[RC_MAX_SRC];
     float *dsrc[RC_MAX_SRC];
     const int64_t *idx[RC_MAX_SRC];
+    const uint8_t *rmask[RC_MAX_SRC];      // optional: source row r counts as src[r] * (rmask[r] != 0)
     int width[RC_MAX_SRC], ld[RC_MAX_SRC], mode[RC_MAX_SRC], begin[RC_MAX_SRC];
     int nsrc, W;
 };
@@ -28,7 +29,8 @@ __global__ void __launch_bounds__(256) rowcat_fwd_kernel(RowcatArgs a, int64_t n
     // four elements per trip: their row-index loads, then their (dependent) source loads, are issued together
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
         const float *p[4];
-        int64_t row[4];
+        const uint8_t *mk[4];
+        int64_t row[4], mrow[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -42,11 +44,16 @@ __global__ void __launch_bounds__(256) rowcat_fwd_kernel(RowcatArgs a, int64_t n
                 if (k < a.nsrc && c >= a.begin[k]) s = k;
             row[u] = (ok[u] && a.idx[s]) ? a.idx[s][r] : r;
             p[u] = a.src[s] + (c - a.begin[s]);
+            mk[u] = a.rmask[s];
+            mrow[u] = row[u];
             row[u] *= a.ld[s];
         }
         float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ok[u] ? p[u][row[u]] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+            v[u] = ok[u] ? p[u][row[u]] : 0.f;
+            if (ok[u] && mk[u]) v[u] *= mk[u][mrow[u]] ? 1.f : 0.f;       // a product, like the reference's anchor * mask (-0.0 stays -0.0)
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (ok[u]) out[i0 + u * stride] = v[u];
@@ -66,13 +73,15 @@ __global__ void __launch_bounds__(256) rowcat_bwd_kernel(RowcatArgs a, int64_t n
         if (a.mode[s] == 0) continue;
         const int64_t row = a.idx[s] ? a.idx[s][r] : r;
         float *p = a.dsrc[s] + row * a.ld[s] + (c - a.begin[s]);
-        if (a.mode[s] == 1) *p = dout[i];
-        else atomicAdd(p, dout[i]);
+        float gv = dout[i];
+        if (a.rmask[s]) gv *= a.rmask[s][row] ? 1.f : 0.f;
+        if (a.mode[s] == 1) *p = gv;
+        else atomicAdd(p, gv);
     }
 }
 
 static int rowcat_fill(RowcatArgs &a, int nsrc, const void *const *data, const int64_t *const *idx, const int *width,
-                       const int *ld, const int *mode, bool bwd) {
+                       const int *ld, const int *mode, bool bwd, const uint8_t *const *rmask = nullptr) {
     if (nsrc < 1 || nsrc > RC_MAX_SRC || !data || !width || !ld) { cgs_set_error("rowcat: bad source list"); return CGS_ERR_ARG; }
     a.nsrc = nsrc;
     int W = 0;
@@ -81,6 +90,7 @@ static int rowcat_fill(RowcatArgs &a, int nsrc, const void *const *data, const i
         a.src[s] = on && !bwd ? (const float *)data[s] : nullptr;
         a.dsrc[s] = on && bwd ? (float *)data[s] : nullptr;
         a.idx[s] = on && idx ? idx[s] : nullptr;
+        a.rmask[s] = on && rmask ? rmask[s] : nullptr;
         a.width[s] = on ? width[s] : 0;
         a.ld[s] = on ? ld[s] : 0;
         a.mode[s] = on && mode ? mode[s] : 0;
@@ -101,11 +111,18 @@ static unsigned stream_grid(int64_t total, int per_block) {
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+extern "C" int cgs_rowcat_fwd_masked(int nsrc, const void *const *data, const int64_t *const *idx, const uint8_t *const *rowmask,
+                                     const int *width, const int *ld, int64_t n, float *out, void *stream);
 extern "C" int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *const *idx, const int *width,
                               const int *ld, int64_t n, float *out, void *stream) {
+    return cgs_rowcat_fwd_masked(nsrc, data, idx, nullptr, width, ld, n, out, stream);
+}
+
+extern "C" int cgs_rowcat_fwd_masked(int nsrc, const void *const *data, const int64_t *const *idx, const uint8_t *const *rowmask,
+                                     const int *width, const int *ld, int64_t n, float *out, void *stream) {
     if (n < 0) { cgs_set_error("rowcat_fwd: n < 0"); return CGS_ERR_ARG; }
     RowcatArgs a;
-    int rc = rowcat_fill(a, nsrc, data, idx, width, ld, nullptr, false);
+    int rc = rowcat_fill(a, nsrc, data, idx, width, ld, nullptr, false, rowmask);
     if (rc) return rc;
     if (n == 0) return CGS_OK;
     if (!out) { cgs_set_error("rowcat_fwd: NULL out"); return CGS_ERR_ARG; }
@@ -115,16 +132,61 @@ extern "C" int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *
     return CGS_OK;
 }
 
+extern "C" int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t *const *idx, const uint8_t *const *rowmask,
+                                     const int *width, const int *ld, const int *mode, int64_t n, const float *dout, void *stream);
 extern "C" int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const *idx, const int *width, const int *ld,
                               const int *mode, int64_t n, const float *dout, void *stream) {
+    return cgs_rowcat_bwd_masked(nsrc, ddata, idx, nullptr, width, ld, mode, n, dout, stream);
+}
+
+extern "C" int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t *const *idx, const uint8_t *const *rowmask,
+                                     const int *width, const int *ld, const int *mode, int64_t n, const float *dout, void *stream) {
     if (n < 0 || !mode) { cgs_set_error("rowcat_bwd: bad args"); return CGS_ERR_ARG; }
     RowcatArgs a;
-    int rc = rowcat_fill(a, nsrc, (const void *const *)ddata, idx, width, ld, mode, true);
+    int rc = rowcat_fill(a, nsrc, (const void *const *)ddata, idx, width, ld, mode, true, rowmask);
     if (rc) return rc;
     if (n == 0) return CGS_OK;
     if (!dout) { cgs_set_error("rowcat_bwd: NULL dout"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(rowcat_bwd_kernel, dim3(stream_grid(n * a.W, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, n, dout);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// out[idx[i]] = g[i] for ASCENDING distinct row indices, every other row of out = 0, in one pass: the thread that writes
+// element c of row idx[i] also clears element c of the rows between idx[i-1] and idx[i] (and, for the last index, of the
+// rows behind it).  The backward of x[visible rows] (gaussian_renderer/__init__.py:44-50): a zero fill of [N, w] plus an
+// index_copy_ become one launch that writes every output line once.  Meant for dense index sets (the visible anchors are
+// ~all anchors); the caller falls back to fill + scatter when fewer than 1/8 of the rows are listed.
+__global__ void __launch_bounds__(256)
+    scatter_rows_sorted_kernel(const float *__restrict__ g, const int64_t *__restrict__ idx, int64_t n, int64_t N, int w,
+                               float *__restrict__ out) {
+    const int64_t total = n * w;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / w;
+        const int c = (int)(t - i * w);
+        const int64_t r = idx[i];
+        const int64_t prev = i > 0 ? idx[i - 1] : -1;
+        for (int64_t z = prev + 1; z < r; ++z) out[z * w + c] = 0.f;
+        out[r * w + c] = g[t];
+        if (i == n - 1)
+            for (int64_t z = r + 1; z < N; ++z) out[z * w + c] = 0.f;
+    }
+}
+
+extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w, float *out,
+                                       void *stream) {
+    if (n < 0 || N < n || w < 1) { cgs_set_error("scatter_rows_sorted: bad sizes"); return CGS_ERR_ARG; }
+    if (N == 0) return CGS_OK;
+    if (!out) { cgs_set_error("scatter_rows_sorted: NULL out"); return CGS_ERR_ARG; }
+    if (n == 0) {
+        CGS_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)N * w * sizeof(float), (hipStream_t)stream));
+        return CGS_OK;
+    }
+    if (!g || !idx) { cgs_set_error("scatter_rows_sorted: NULL input"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(stream_grid(n * w, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, idx,
+                       n, N, w, out);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -34,10 +34,12 @@ def _ints(v):
 class _RowCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, *srcs):
-        # spec[s] = (idx LongTensor | None, distinct: bool)
+        # spec[s] = (idx LongTensor | None, distinct: bool, rowmask uint8/bool [rows] | None)
         srcs = [_c(s) for s in srcs]
         _lib.require_device(*srcs)
         idxs = [sp[0] for sp in spec]
+        masks = ctx.masks = [None if sp[2] is None else (sp[2] if sp[2].dtype == torch.uint8 else sp[2].view(torch.uint8)).contiguous()
+                             for sp in spec]
         n = next((i.shape[0] for i in idxs if i is not None), srcs[0].shape[0])
         for s, i in zip(srcs, idxs):
             if i is None and s.shape[0] != n:
@@ -45,8 +47,9 @@ class _RowCat(torch.autograd.Function):
         widths = [int(s.shape[1]) for s in srcs]
         out = torch.empty(n, sum(widths), dtype=_f32, device=srcs[0].device)
         if n > 0:
-            _lib.check(_lib.lib().cgs_rowcat_fwd(len(srcs), _ptrs(srcs), _ptrs(idxs), _ints(widths), _ints(widths), n,
-                                                 _lib.ptr(out), _lib.current_stream()), "cgs_rowcat_fwd")
+            _lib.check(_lib.lib().cgs_rowcat_fwd_masked(len(srcs), _ptrs(srcs), _ptrs(idxs), _ptrs(masks), _ints(widths),
+                                                        _ints(widths), n, _lib.ptr(out), _lib.current_stream()),
+                       "cgs_rowcat_fwd")
         ctx.spec, ctx.widths, ctx.n = spec, widths, n
         ctx.rows = [int(s.shape[0]) for s in srcs]
         return out
@@ -55,7 +58,7 @@ class _RowCat(torch.autograd.Function):
     def backward(ctx, g):
         g = _c(g)
         grads, modes = [], []
-        for k, ((idx, distinct), w, rows) in enumerate(zip(ctx.spec, ctx.widths, ctx.rows)):
+        for k, ((idx, distinct, _m), w, rows) in enumerate(zip(ctx.spec, ctx.widths, ctx.rows)):
             if not ctx.needs_input_grad[1 + k]:
                 grads.append(None)
                 modes.append(0)
@@ -68,17 +71,18 @@ class _RowCat(torch.autograd.Function):
                 grads.append((torch.empty if full else torch.zeros)(rows, w, dtype=_f32, device=g.device))
                 modes.append(1 if distinct else 2)
         if any(modes) and ctx.n > 0:
-            _lib.check(_lib.lib().cgs_rowcat_bwd(len(grads), _ptrs(grads), _ptrs([sp[0] for sp in ctx.spec]),
-                                                 _ints(ctx.widths), _ints(ctx.widths), _ints(modes), ctx.n,
-                                                 _lib.ptr(g), _lib.current_stream()), "cgs_rowcat_bwd")
+            _lib.check(_lib.lib().cgs_rowcat_bwd_masked(len(grads), _ptrs(grads), _ptrs([sp[0] for sp in ctx.spec]),
+                                                        _ptrs(ctx.masks), _ints(ctx.widths), _ints(ctx.widths), _ints(modes),
+                                                        ctx.n, _lib.ptr(g), _lib.current_stream()), "cgs_rowcat_bwd")
         return (None, *grads)
 
 
 def rowcat(parts):
-    """cat([src[idx] for (src, idx, distinct) in parts], dim=1) in one launch; idx None = all rows in order;
-    distinct says the rows of idx do not repeat (plain scatter backward instead of atomics)."""
-    spec = tuple((idx, bool(distinct)) for (_s, idx, distinct) in parts)
-    return _RowCat.apply(spec, *[s for (s, _i, _d) in parts])
+    """cat([src[idx] for (src, idx, distinct[, rowmask]) in parts], dim=1) in one launch; idx None = all rows in order;
+    distinct says the rows of idx do not repeat (plain scatter backward instead of atomics); rowmask (bool / uint8 per
+    SOURCE row): the source counts as src * rowmask[:, None]."""
+    spec = tuple((p[1], bool(p[2]), p[3] if len(p) > 3 else None) for p in parts)
+    return _RowCat.apply(spec, *[p[0] for p in parts])
 
 
 def gather_rows_nograd(x, idx):

@@ -45,7 +45,9 @@ class VisibleList:
     def wait(self):
         cnt = C.c_int64(0)
         _lib.check(_lib.lib().cgs_nonzero_wait(C.byref(cnt)), "cgs_nonzero_wait")
-        return self.idx[:int(cnt.value)]
+        idx = self.idx[:int(cnt.value)]
+        idx._cgs_ascending = True        # row gathers by this list take the one-pass backward (cgs_scatter_rows_sorted)
+        return idx
 
 
 class ExpandCount:

@@ -288,6 +288,20 @@ int cgs_rowcat_fwd(int nsrc, const void *const *data, const int64_t *const *idx,
 int cgs_rowcat_bwd(int nsrc, void *const *ddata, const int64_t *const *idx,
                    const int *width, const int *ld, const int *mode, int64_t n,
                    const float *dout, void *stream);
+/* The same with an optional row mask per source (rowmask[s] == NULL: none): source row r counts as
+ * src_s[r] * (rowmask[s][r] != 0) — `anchor * mask_anchor.unsqueeze(1)` of scene/gaussian_model.py:1758-1759 (masked anchors
+ * move to the origin from level 1 up) folded into the gather; the backward multiplies the scattered gradient likewise. */
+int cgs_rowcat_fwd_masked(int nsrc, const void *const *data, const int64_t *const *idx,
+                          const uint8_t *const *rowmask, const int *width, const int *ld,
+                          int64_t n, float *out, void *stream);
+int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t *const *idx,
+                          const uint8_t *const *rowmask, const int *width, const int *ld,
+                          const int *mode, int64_t n, const float *dout, void *stream);
+
+/* out [N, w] = 0 everywhere except out[idx[i]] = g[i], for ASCENDING distinct idx [n]: the backward of a row gather by the
+ * visible-anchor list (gaussian_renderer/__init__.py:44-50) in one launch instead of a zero fill + a scatter. */
+int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w,
+                            float *out, void *stream);
 /* Atomics-free backward of a context assembly whose first three sources are gathered parent rows
  * (anchor position [N,wa] by original row, coded features [n_parents,DF] and scaling [n_parents,DS]
  * by position in the coded prefix): the children of parent p are order[offs[p] .. offs[p+1])
