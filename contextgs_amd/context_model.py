@@ -365,7 +365,7 @@ class _GatherUnique(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         n, N = int(idx.shape[0]), int(ctx.shape[0])
         if (ctx.ascending and not ctx.complete and g.is_cuda and g.dtype == torch.float32 and N > 0 and 8 * n >= N
-                and idx.dtype == torch.int64):
+                and idx.dtype == torch.int64 and 1 <= int(g[0].numel()) <= 256):
             # ascending rows (the visible-anchor list): zero fill and scatter in ONE pass (cgs_scatter_rows_sorted)
             g = g.contiguous()
             out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)

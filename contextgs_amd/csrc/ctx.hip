@@ -161,14 +161,15 @@ extern "C" int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t
 __global__ void __launch_bounds__(256)
     scatter_rows_sorted_kernel(const float *__restrict__ g, const int64_t *__restrict__ idx, int64_t n, int64_t N, int w,
                                float *__restrict__ out) {
-    const int64_t total = n * w;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int64_t i = t / w;
-        const int c = (int)(t - i * w);
+    // a workgroup takes 256 / w consecutive list entries per trip (32-bit index arithmetic; w <= 256)
+    const int rpb = 256 / w;
+    const int li = (int)threadIdx.x / w, c = (int)threadIdx.x - li * w;
+    if (li >= rpb) return;
+    for (int64_t i = (int64_t)blockIdx.x * rpb + li; i < n; i += (int64_t)gridDim.x * rpb) {
         const int64_t r = idx[i];
         const int64_t prev = i > 0 ? idx[i - 1] : -1;
         for (int64_t z = prev + 1; z < r; ++z) out[z * w + c] = 0.f;
-        out[r * w + c] = g[t];
+        out[r * w + c] = g[i * w + c];
         if (i == n - 1)
             for (int64_t z = r + 1; z < N; ++z) out[z * w + c] = 0.f;
     }
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256)
 
 extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w, float *out,
                                        void *stream) {
-    if (n < 0 || N < n || w < 1) { cgs_set_error("scatter_rows_sorted: bad sizes"); return CGS_ERR_ARG; }
+    if (n < 0 || N < n || w < 1 || w > 256) { cgs_set_error("scatter_rows_sorted: bad sizes (1 <= w <= 256)"); return CGS_ERR_ARG; }
     if (N == 0) return CGS_OK;
     if (!out) { cgs_set_error("scatter_rows_sorted: NULL out"); return CGS_ERR_ARG; }
     if (n == 0) {
@@ -185,7 +186,7 @@ extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64
     }
     if (!g || !idx) { cgs_set_error("scatter_rows_sorted: NULL input"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(stream_grid(n * w, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, idx,
+    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(stream_grid(n, (256 / w) * 4)), dim3(256), 0, (hipStream_t)stream, g, idx,
                        n, N, w, out);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
