@@ -394,7 +394,7 @@ def heavy_variant(args, L, pipe, bg, w, cams, steps=20):
     pc.train()
     params = [p for p in pc.parameters() if p.requires_grad]
     step = lambda i: one_step(pc, cams[i % len(cams)], pipe, bg, w, args.step_semantics, params, None)
-    for i in range(3):
+    for i in range(len(cams) + 1):      # every camera once: the rasterizer's pair capacity and the allocator have settled
         pkg = step(i)
     L.cgs_prof_enable(1)
     dt = timed(step, steps, False)

@@ -6,6 +6,7 @@
 // The reference's CUDA rasterizer is not in the mount; semantics follow the
 // public 3DGS algorithm as recorded in SURVEY.md Appendix A and the call-site
 // contract gaussian_renderer/__init__.py:179-205,250-285.
+#include <hip/hip_fp16.h>
 #include "cgs_internal.h"
 #include "raster_math.h"
 
@@ -57,11 +58,19 @@ __global__ void __launch_bounds__(PRE_THREADS)
                 // it are skipped by the blend loop anyway, so tiles (and 8x8 quadrants)
                 // outside it never need to see this Gaussian.
                 float hx = -1.f, hy = -1.f;
+                uint32_t diag = 0x7C007C00u;      // (+inf, +inf) as two halves: no diagonal cull
                 const float t255 = 255.f * op;
                 if (t255 >= 1.f) {
                     const float tau2 = 2.f * logf(t255);
                     hx = sqrtf(tau2 * pr.cov_a) * 1.002f + 0.02f;
                     hy = sqrtf(tau2 * pr.cov_c) * 1.002f + 0.02f;
+                    // half extents of the same ellipse along x + y and x - y (the blend kernels cull 4x4 blocks against the
+                    // octagon box /\ diagonals): sqrt(tau (1, +-1) cov (1, +-1)^T), padded like hx / hy and rounded UP to fp16
+                    const float su = fmaxf(pr.cov_a + pr.cov_c + 2.f * pr.cov_b, 0.f);
+                    const float sv = fmaxf(pr.cov_a + pr.cov_c - 2.f * pr.cov_b, 0.f);
+                    const float hu = sqrtf(tau2 * su) * 1.002f + 0.03f, hv = sqrtf(tau2 * sv) * 1.002f + 0.03f;
+                    diag = (uint32_t)__half_as_ushort(__float2half_ru(hu)) |
+                           ((uint32_t)__half_as_ushort(__float2half_ru(hv)) << 16);
                     // pixels are at integer coordinates; first/last pixel inside the box
                     const float fx0 = ceilf(pr.px - hx), fx1 = floorf(pr.px + hx);
                     const float fy0 = ceilf(pr.py - hy), fy1 = floorf(pr.py + hy);
@@ -87,7 +96,7 @@ __global__ void __launch_bounds__(PRE_THREADS)
                 const float k = 1.4426950408889634f;  // log2(e): blend uses exp2
                 rec[3 * i + 0] = make_float4(pr.px, pr.py, -0.5f * k * pr.con_a, -k * pr.con_b);
                 rec[3 * i + 1] = make_float4(-0.5f * k * pr.con_c, op, colors[3 * i], colors[3 * i + 1]);
-                rec[3 * i + 2] = make_float4(colors[3 * i + 2], hx, hy, 0.f);
+                rec[3 * i + 2] = make_float4(colors[3 * i + 2], hx, hy, __uint_as_float(diag));
             }
         }
     }
