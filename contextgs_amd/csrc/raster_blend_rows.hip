@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(RB_THREADS)
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ final_T,
                           uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ tile_last) {
     __shared__ float4 srec[RB_THREADS * 3];
-    __shared__ uint64_t bmask[16][4];     // [block][source wave]
+    __shared__ uint32_t bmask[16][8];     // [block][32-entry segment]: 32-bit masks keep the per-lane bit walk cheap
     __shared__ uint32_t wave_last[4];
 
     const int tile = blockIdx.x;
@@ -146,18 +146,18 @@ __global__ void __launch_bounds__(RB_THREADS)
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             const uint64_t bal = __ballot((m16 >> b) & 1u);
-            if (lane == 0) bmask[b][wave] = bal;
+            if (lane == 0) { bmask[b][2 * wave] = (uint32_t)bal; bmask[b][2 * wave + 1] = (uint32_t)(bal >> 32); }
         }
         __syncthreads();
         const uint32_t base_pos = start - range.x;
         if (!__all(done)) {
-            for (int s = 0; s < 4; ++s) {
-                uint64_t m = done ? 0ull : bmask[L.blk][s];
-                while (__ballot(m != 0ull) != 0ull) {
-                    const bool has = m != 0ull;
-                    const int j = has ? __builtin_ctzll(m) : 0;
-                    m &= m - 1ull;                                   // 0 stays 0
-                    const int e = s * 64 + j;
+            for (int s = 0; s < 8; ++s) {
+                uint32_t m = done ? 0u : bmask[L.blk][s];
+                while (__ballot(m != 0u) != 0ull) {
+                    const bool has = m != 0u;
+                    const int j = has ? __builtin_ctz(m) : 0;
+                    m &= m - 1u;                                     // 0 stays 0
+                    const int e = s * 32 + j;
                     const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
                     const float blue = srec[e * 3 + 2].x;
                     const RbEval ev = rb_eval(r0, r1, pxf, pyf);
