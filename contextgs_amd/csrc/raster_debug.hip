@@ -227,3 +227,114 @@ extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ---- analysis hook: wave iterations of the row mapping (four 4x4 blocks per wave) against an eight-group mapping (eight 4x2
+// half-blocks per wave, 8-lane groups), both with the octagon test of raster_blend_rows.hip and the backward's per-group bound
+// (entries behind the last contribution of the group's own pixels are dropped).  out4 = {iterations 4x4, iterations 4x2,
+// (group, Gaussian) visits 4x4, visits 4x2}.  tools/blend_occupancy.py; not part of include/cgs.h.
+#include <hip/hip_fp16.h>
+__device__ __forceinline__ bool dbg_oct_hits(float rx, float ry, float hx, float hy, float hu, float hv, float x0, float x1,
+                                             float y0, float y1) {
+    // pixel-centre ranges [x0, x1] x [y0, y1] (tile-relative) against box and diagonals
+    return (rx - hx <= x1) && (rx + hx >= x0) && (ry - hy <= y1) && (ry + hy >= y0) && (rx + ry - hu <= x1 + y1) &&
+           (rx + ry + hu >= x0 + y0) && (rx - ry - hv <= x1 - y0) && (rx - ry + hv >= x0 - y1);
+}
+
+__global__ void __launch_bounds__(256)
+    blend_group_occupancy_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
+                                 const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
+                                 const uint32_t *__restrict__ tile_last, const uint32_t *__restrict__ n_contrib,
+                                 unsigned long long *__restrict__ out) {
+    __shared__ uint32_t sm16[256], sm32[256], snc[256], last16[16], last32[32];
+    __shared__ unsigned long long red[4];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t tlast = tile_last[tile];
+    const uint2 range = ranges[tile];
+    {
+        const int px = tx * 16 + (tid & 15), py = ty * 16 + (tid >> 4);
+        snc[tid] = (px < W && py < H) ? n_contrib[(size_t)py * W + px] : 0u;
+    }
+    if (tid < 4) red[tid] = 0;
+    __syncthreads();
+    if (tid < 16) {       // 4x4 block (bx, by)
+        const int bx = tid & 3, by = tid >> 2;
+        uint32_t m = 0;
+        for (int y = 0; y < 4; ++y) for (int x = 0; x < 4; ++x) m = max(m, snc[(by * 4 + y) * 16 + bx * 4 + x]);
+        last16[tid] = m;
+    }
+    if (tid < 32) {       // 4x2 half-block (bx, hy)
+        const int bx = tid & 3, hy = tid >> 2;
+        uint32_t m = 0;
+        for (int y = 0; y < 2; ++y) for (int x = 0; x < 4; ++x) m = max(m, snc[(hy * 2 + y) * 16 + bx * 4 + x]);
+        last32[tid] = m;
+    }
+    unsigned long long it16 = 0, it32 = 0, v16 = 0, v32 = 0;
+    for (uint32_t base = 0; base < tlast; base += 256) {
+        __syncthreads();
+        uint32_t m16 = 0, m32 = 0;
+        const uint32_t pos = base + tid;
+        if (pos < tlast) {
+            const uint32_t g = gid_sorted[range.x + pos];
+            const float4 r0 = rec[3 * (size_t)g], r2 = rec[3 * (size_t)g + 2];
+            const uint32_t db = __float_as_uint(r2.w);
+            const float hu = __half2float(__ushort_as_half((unsigned short)(db & 0xFFFFu)));
+            const float hv = __half2float(__ushort_as_half((unsigned short)(db >> 16)));
+            const float rx = r0.x - (float)(tx * 16), ry = r0.y - (float)(ty * 16);
+            for (int k = 0; k < 16; ++k) {
+                const float x0 = (float)(4 * (k & 3)), y0 = (float)(4 * (k >> 2));
+                if (dbg_oct_hits(rx, ry, r2.y, r2.z, hu, hv, x0, x0 + 3.f, y0, y0 + 3.f)) m16 |= 1u << k;
+            }
+            for (int k = 0; k < 32; ++k) {
+                const float x0 = (float)(4 * (k & 3)), y0 = (float)(2 * (k >> 2));
+                if (dbg_oct_hits(rx, ry, r2.y, r2.z, hu, hv, x0, x0 + 3.f, y0, y0 + 1.f)) m32 |= 1u << k;
+            }
+        }
+        sm16[tid] = m16; sm32[tid] = m32;
+        __syncthreads();
+        if (tid < 32) {                   // (segment s, wave w): the wave's quadrant = blocks (2 qx + {0,1}, 2 qy + {0,1})
+            const int s = tid >> 2, w = tid & 3, qx = w & 1, qy = w >> 1;
+            uint32_t c16[4] = {0, 0, 0, 0}, c32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t position = base + (uint32_t)(s * 32 + j) + 1u;
+                const uint32_t a = sm16[s * 32 + j], b = sm32[s * 32 + j];
+                for (int k = 0; k < 4; ++k) {
+                    const int blk = (2 * qy + (k >> 1)) * 4 + 2 * qx + (k & 1);
+                    if (((a >> blk) & 1u) && position <= last16[blk]) ++c16[k];
+                }
+                for (int k = 0; k < 8; ++k) {
+                    const int hb = (4 * qy + (k >> 1)) * 4 + 2 * qx + (k & 1);
+                    if (((b >> hb) & 1u) && position <= last32[hb]) ++c32[k];
+                }
+            }
+            uint32_t mx16 = 0, mx32 = 0;
+            for (int k = 0; k < 4; ++k) { mx16 = max(mx16, c16[k]); v16 += c16[k]; }
+            for (int k = 0; k < 8; ++k) { mx32 = max(mx32, c32[k]); v32 += c32[k]; }
+            it16 += mx16; it32 += mx32;
+        }
+    }
+    atomicAdd(&red[0], it16); atomicAdd(&red[1], it32); atomicAdd(&red[2], v16); atomicAdd(&red[3], v32);
+    __syncthreads();
+    if (tid < 4) atomicAdd(&out[tid], red[tid]);
+}
+
+extern "C" int cgs_debug_blend_group_occupancy(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws, size_t geom_bytes,
+                                               void *bin_ws, size_t bin_bytes, void *img_ws, size_t img_bytes, int64_t *out4,
+                                               void *stream) {
+    CgsGeom g;
+    CgsBin b;
+    CgsImg im;
+    if (!cgs_img_carve(&im, img_ws, img_bytes, cfg->image_height, cfg->image_width) || !cgs_geom_carve(&g, geom_ws, geom_bytes, P) ||
+        !cgs_bin_carve(&b, bin_ws, bin_bytes, P, R)) {
+        cgs_set_error("debug_blend_group_occupancy: workspace");
+        return CGS_ERR_WORKSPACE;
+    }
+    CGS_CHECK_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), (hipStream_t)stream));
+    const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(blend_group_occupancy_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, (hipStream_t)stream,
+                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
+                       (const float4 *)g.rec, (const uint32_t *)im.tile_last, (const uint32_t *)im.n_contrib,
+                       (unsigned long long *)out4);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
