@@ -23,6 +23,24 @@
 #define RB_INV_LOG2E 0.6931471805599453f
 #define RB_NGRAD 9
 
+#if defined(CGS_EXPERIMENTS) && defined(RB_COUNT)
+__device__ unsigned long long g_rb_iters[4];      // [0] forward wave iterations, [1] backward, [2] backward past the `continue`
+extern "C" int cgs_debug_rb_iters(unsigned long long *out4_host, int reset) {
+    if (out4_host) hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_rb_iters), sizeof(g_rb_iters));
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rb_iters), z, sizeof(z)); }
+    return 0;
+}
+#define RB_COUNT_DECL unsigned int rb_n0 = 0, rb_n1 = 0
+#define RB_COUNT_INC0 ++rb_n0
+#define RB_COUNT_INC1 ++rb_n1
+#define RB_COUNT_FLUSH(A, B) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_rb_iters[A], (unsigned long long)rb_n0); atomicAdd(&g_rb_iters[B], (unsigned long long)rb_n1); } } while (0)
+#else
+#define RB_COUNT_DECL
+#define RB_COUNT_INC0
+#define RB_COUNT_INC1
+#define RB_COUNT_FLUSH(A, B)
+#endif
+
 namespace {
 
 struct RbEval { float dx, dy, g, alpha; bool hit; };
@@ -97,13 +115,58 @@ __device__ __forceinline__ RbLane rb_lane(int tx, int ty, int wave, int lane) {
 
 }  // namespace
 
+// Per-block entry lists of one staged batch.  Every staging thread owns one entry of the batch and publishes a 16-bit mask
+// of the 4x4 blocks its octagon reaches (smask).  After the staging barrier every ROW builds the list of ITS OWN block: lane
+// j of the row takes entries 16 j .. 16 j + 15 (two 16-byte LDS reads), extracts its block's bit from each mask, an
+// exclusive scan over the row's sixteen counts (four DPP steps) gives it the slot of its first entry, and it stores the
+// batch indices of its entries in ascending order.  The list is written and read by the same wave: no workgroup barrier, no
+// atomics.  A row then walks its list with its own cursor — no bit scan, and no waiting for the other rows of the wave at
+// 32-entry segment boundaries as the mask walk had (tools/rb_iters.py: 6.45 M -> 5.28 M backward wave iterations per view).
+struct RbLists {
+    uint8_t list[16][RB_THREADS];       // [block][k] = batch index of the block's k-th entry (ascending)
+    uint16_t smask[RB_THREADS];         // block mask of every entry of the batch
+};
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t rb_dpp_u(uint32_t v) {      // bound_ctrl: lanes shifted in from outside the row read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// returns the number of entries of the row's block; `lim` = highest admissible batch index for this block (>= 255: all)
+__device__ __forceinline__ uint32_t rb_list_build(RbLists &S, int blk, int lane, int lim) {
+    const int sub = lane & 15;
+    const uint4 w0 = ((const uint4 *)S.smask)[sub * 2], w1 = ((const uint4 *)S.smask)[sub * 2 + 1];
+    const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bits |= ((w[k >> 1] >> (blk + 16 * (k & 1))) & 1u) << k;
+    const int l = lim - 16 * sub;                                 // highest admissible k of this lane
+    bits = l < 0 ? 0u : (l >= 15 ? bits : (bits & ((2u << l) - 1u)));
+    const uint32_t cnt = (uint32_t)__builtin_popcount(bits);
+    uint32_t inc = cnt;
+    inc += rb_dpp_u<0x111>(inc);      // row_shr:1
+    inc += rb_dpp_u<0x112>(inc);      // row_shr:2
+    inc += rb_dpp_u<0x114>(inc);      // row_shr:4
+    inc += rb_dpp_u<0x118>(inc);      // row_shr:8
+    uint32_t slot = inc - cnt;
+    while (bits) {
+        const int k = __builtin_ctz(bits);
+        bits &= bits - 1u;
+        S.list[blk][slot++] = (uint8_t)(16 * sub + k);
+    }
+    const uint32_t total = (uint32_t)__shfl((int)inc, lane | 15, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the row's own stores are visible to its loads below
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
 __global__ void __launch_bounds__(RB_THREADS)
     blend_fwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                           const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ final_T,
                           uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ tile_last) {
     __shared__ float4 srec[RB_THREADS * 3];
-    __shared__ uint32_t bmask[16][8];     // [block][32-entry segment]: 32-bit masks keep the per-lane bit walk cheap
+    __shared__ RbLists S;
     __shared__ uint32_t wave_last[4];
 
     const int tile = blockIdx.x;
@@ -117,6 +180,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     uint32_t last = 0;
     bool done = !inside;
+    RB_COUNT_DECL;
 
     // The batch after the one being walked is fetched into registers BEFORE the walk starts (gid -> three dependent
     // 16-byte gathers, ~2 us of latency per batch) and handed to LDS at the top of the next round.
@@ -127,13 +191,17 @@ __global__ void __launch_bounds__(RB_THREADS)
         p0 = rec[3 * (size_t)g]; p1 = rec[3 * (size_t)g + 1]; p2 = rec[3 * (size_t)g + 2];
     }
     for (uint32_t start = range.x; start < range.y; start += RB_THREADS) {
-        if (__syncthreads_count(done) == RB_THREADS) break;
+        if (__syncthreads_count(done) == RB_THREADS) break;      // (also: the previous walk is over, LDS may be rewritten)
         uint32_t m16 = 0;
         if (pvalid) {
             srec[tid * 3] = p0;
             srec[tid * 3 + 1] = p1;
             srec[tid * 3 + 2] = p2;
             m16 = rb_block_mask(p0.x, p0.y, p2.y, p2.z, p2.w, tx * CGS_TILE, ty * CGS_TILE);
+        } else {
+            // a lane without an entry blends record `e` of a stale list slot with weight 0: the record must be finite
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            srec[tid * 3] = z; srec[tid * 3 + 1] = z; srec[tid * 3 + 2] = z;
         }
         {
             const uint32_t i = start + RB_THREADS + tid;
@@ -143,43 +211,45 @@ __global__ void __launch_bounds__(RB_THREADS)
                 p0 = rec[3 * (size_t)g]; p1 = rec[3 * (size_t)g + 1]; p2 = rec[3 * (size_t)g + 2];
             }
         }
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const uint64_t bal = __ballot((m16 >> b) & 1u);
-            if (lane == 0) { bmask[b][2 * wave] = (uint32_t)bal; bmask[b][2 * wave + 1] = (uint32_t)(bal >> 32); }
-        }
+        S.smask[tid] = (uint16_t)m16;
         __syncthreads();
         const uint32_t base_pos = start - range.x;
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL_NOWALK)
+        if (range.x == 0xFFFFFFFFu)
+#endif
         if (!__all(done)) {
-            for (int s = 0; s < 8; ++s) {
-                uint32_t m = done ? 0u : bmask[L.blk][s];
-                while (__ballot(m != 0u) != 0ull) {
-                    const bool has = m != 0u;
-                    const int j = has ? __builtin_ctz(m) : 0;
-                    m &= m - 1u;                                     // 0 stays 0
-                    const int e = s * 32 + j;
-                    const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
-                    const float blue = srec[e * 3 + 2].x;
-                    const RbEval ev = rb_eval(r0, r1, pxf, pyf);
-                    // branch-free (as in the backward): a lane that takes no contribution blends weight 0, an exact no-op
-                    const bool act = has && !done && ev.hit;
-                    const float alpha = act ? ev.alpha : 0.f;
-                    const float test_T = T * (1.f - alpha);
-                    const bool stop = act && test_T < RB_T_EPS;
-                    const bool upd = act && !stop;
-                    const float w = upd ? alpha * T : 0.f;
-                    cr = fmaf(r1.z, w, cr);
-                    cg = fmaf(r1.w, w, cg);
-                    cb = fmaf(blue, w, cb);
-                    T = upd ? test_T : T;
-                    last = upd ? base_pos + (uint32_t)e + 1u : last;
-                    done = done || stop;
-                }
-                if (__all(done)) break;
+            const uint32_t cnt = rb_list_build(S, L.blk, lane, RB_THREADS);
+            uint32_t i = 0;
+            uint32_t e_next = S.list[L.blk][0];
+            // every lane of a row advances i together (also the lanes whose pixel is finished); the wave leaves when no
+            // unfinished pixel has entries left
+            while (__ballot(!done && i < cnt) != 0ull) {
+                RB_COUNT_INC0;
+                const bool has = i < cnt;
+                const uint32_t e = e_next;
+                i += has ? 1u : 0u;
+                e_next = S.list[L.blk][i & (RB_THREADS - 1)];       // next entry's index: in flight during this iteration
+                const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
+                const float blue = srec[e * 3 + 2].x;
+                const RbEval ev = rb_eval(r0, r1, pxf, pyf);
+                // branch-free (as in the backward): a lane that takes no contribution blends weight 0, an exact no-op
+                const bool act = has && !done && ev.hit;
+                const float alpha = act ? ev.alpha : 0.f;
+                const float test_T = T * (1.f - alpha);
+                const bool stop = act && test_T < RB_T_EPS;
+                const bool upd = act && !stop;
+                const float w = upd ? alpha * T : 0.f;
+                cr = fmaf(r1.z, w, cr);
+                cg = fmaf(r1.w, w, cg);
+                cb = fmaf(blue, w, cb);
+                T = upd ? test_T : T;
+                last = upd ? base_pos + e + 1u : last;
+                done = done || stop;
             }
         }
     }
 
+    RB_COUNT_FLUSH(0, 3);
     if (inside) {
         const size_t pix = (size_t)L.py * W + L.px;
         const size_t hw = (size_t)H * W;
@@ -197,7 +267,6 @@ __global__ void __launch_bounds__(RB_THREADS)
     if (tid == 0) tile_last[tile] = max(max(wave_last[0], wave_last[1]), max(wave_last[2], wave_last[3]));
 }
 
-template <int ABL>      // ABL != 0: timing ablations (WRONG results), see cgs_launch_blend_bwd_rows
 __global__ void __launch_bounds__(RB_THREADS)
     blend_bwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                           const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
@@ -206,10 +275,13 @@ __global__ void __launch_bounds__(RB_THREADS)
                           const float *__restrict__ dL_dout, float *__restrict__ dL_dmean2D_px,
                           float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
                           float *__restrict__ dL_dcolors) {
-    __shared__ float4 srec[RB_THREADS * 3];
-    __shared__ uint32_t sgid[RB_THREADS];
+    // 22.6 KB of LDS per workgroup = seven workgroups per CU: two float4 per record plus its blue component (the third
+    // float4 only carries cull extents the staging thread has in registers), no copy of the Gaussian ids (the flush reads
+    // gid_sorted again)
+    __shared__ float4 srec[RB_THREADS * 2];
+    __shared__ float sblue[RB_THREADS];
     __shared__ float sacc[RB_THREADS][RB_NGRAD];
-    __shared__ uint32_t bmask[16][8];     // [block][32-entry segment]: 32-bit masks keep the per-lane bit walk cheap
+    __shared__ RbLists S;
 
     const int tile = blockIdx.x;
     const uint32_t tlast = tile_last[tile];
@@ -235,6 +307,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
     const float neg_bg_T = -T_final * bg_dot;
     float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;       // scalar colour recurrence (see raster_blend.hip)
+    RB_COUNT_DECL;
 
     const int nbatch = (int)((tlast + RB_THREADS - 1) / RB_THREADS);
     // the batch after the one being walked is fetched into registers before the walk starts (see the forward)
@@ -253,11 +326,13 @@ __global__ void __launch_bounds__(RB_THREADS)
         uint32_t m16 = 0;
         __syncthreads();   // previous batch fully flushed before LDS is reused
         if (pos < tlast) {
-            srec[tid * 3] = p0;
-            srec[tid * 3 + 1] = p1;
-            srec[tid * 3 + 2] = p2;
-            sgid[tid] = pg;
+            srec[tid * 2] = p0;
+            srec[tid * 2 + 1] = p1;
+            sblue[tid] = p2.x;
             m16 = rb_block_mask(p0.x, p0.y, p2.y, p2.z, p2.w, tx * CGS_TILE, ty * CGS_TILE);
+        } else {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            srec[tid * 2] = z; srec[tid * 2 + 1] = z; sblue[tid] = 0.f;
         }
         if (bi > 0) {      // every position of an earlier batch is < tlast
             pg = gid_sorted[range.x + pos - RB_THREADS];
@@ -265,33 +340,31 @@ __global__ void __launch_bounds__(RB_THREADS)
         }
 #pragma unroll
         for (int k = 0; k < RB_NGRAD; ++k) sacc[tid][k] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            const uint64_t bal = __ballot((m16 >> b) & 1u);
-            if (lane == 0) { bmask[b][2 * wave] = (uint32_t)bal; bmask[b][2 * wave + 1] = (uint32_t)(bal >> 32); }
-        }
+        S.smask[tid] = (uint16_t)m16;
         __syncthreads();
 
-        for (int s = 7; s >= 0; --s) {
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL_NOWALK)
+        if (range.x == 0xFFFFFFFFu)
+#endif
+        {
             // entries behind the LAST contribution of every pixel of this 4x4 block (n_contrib: where the forward stopped)
-            // cannot contribute to it: the row drops them from its list (the tile-wide bound `tlast` is the maximum over
+            // cannot contribute to it: they never enter the block's list (the tile-wide bound `tlast` is the maximum over
             // 256 pixels, a block's own bound over 16)
-            const int lim = (int)blk_last - (int)base_pos - s * 32 - 1;       // highest admissible bit of this segment
-            uint32_t m = bmask[L.blk][s];
-            m = lim < 0 ? 0u : (lim >= 31 ? m : (m & ((2u << lim) - 1u)));
-            while (__ballot(m != 0u) != 0ull) {
-                const bool has = m != 0u;
-                const int j = 31 - __builtin_clz(m | 1u);            // m == 0: j = 0, has = false
-                m &= ~(1u << j);
-                const int e = s * 32 + j;
-                const uint32_t position = base_pos + (uint32_t)e + 1u;   // 1-based
-                const float4 r0 = srec[e * 3], r1 = srec[e * 3 + 1];
-                const float blue = srec[e * 3 + 2].x;
-                if (ABL == 4) { if (has && r0.x == 12345.f) atomicAdd(&sacc[e][0], r1.x + blue); continue; }
+            int i = (int)rb_list_build(S, L.blk, lane, (int)blk_last - (int)base_pos - 1) - 1;
+            uint32_t e_next = S.list[L.blk][max(i, 0)];
+            while (__ballot(i >= 0) != 0ull) {
+                RB_COUNT_INC0;
+                const bool has = i >= 0;
+                const uint32_t e = e_next;
+                i -= has ? 1 : 0;
+                e_next = S.list[L.blk][max(i, 0)];                   // next entry's index: in flight during this iteration
+                const uint32_t position = base_pos + e + 1u;         // 1-based
+                const float4 r0 = srec[e * 2], r1 = srec[e * 2 + 1];
+                const float blue = sblue[e];
                 const RbEval ev = rb_eval(r0, r1, pxf, pyf);
                 const bool act = has && (position <= my_last) && ev.hit;
-                if ((ABL != 7) && __ballot(act) == 0ull) continue;
-                if (ABL == 3) { if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue); continue; }
+                if (__ballot(act) == 0ull) continue;
+                RB_COUNT_INC1;
                 // Branch-free: a lane whose pixel takes no contribution runs the same updates on alpha = 0, G = 0, for which
                 // every one of them is an exact no-op (T / 1 = T, w = 0, the colour recurrence with alpha = 0 hands on
                 // the value the next contributing step would have computed) — two selects instead of a divergent block,
@@ -321,11 +394,6 @@ __global__ void __launch_bounds__(RB_THREADS)
                 v[6] = w * gr;
                 v[7] = w * gg;
                 v[8] = w * gb;
-                if (ABL == 2) {
-                    const float sm = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
-                    if (sm == 12345.f) atomicAdd(&sacc[e][0], sm);
-                    continue;
-                }
                 // transposing reduction inside each 16-lane row (identical to raster_blend.hip); every row then adds
                 // into the accumulator of ITS OWN Gaussian
                 const bool b0 = lane & 1, b1 = lane & 2;
@@ -351,21 +419,18 @@ __global__ void __launch_bounds__(RB_THREADS)
                 asm volatile("" : "+v"(b2[0]), "+v"(b2[1]), "+v"(c8));
                 const int sub = lane & 15;
                 const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
-                if (ABL == 1) { if (has && red == 12345.f) atomicAdd(&sacc[e][sub], red); continue; }
-                if (ABL == 6) { if (has && sub < RB_NGRAD) sacc[e][sub] = red; continue; }
                 if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], red);
             }
         }
         __syncthreads();
-        if (ABL == 5 && tlast != 0x7fffffffu) continue;
         if (pos < tlast) {
-            const uint32_t g = sgid[tid];
             const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
                         a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],
                         a8 = sacc[tid][8];
             if (a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f || a4 != 0.f || a5 != 0.f || a6 != 0.f ||
                 a7 != 0.f || a8 != 0.f) {
-                const float4 q0 = srec[tid * 3], q1 = srec[tid * 3 + 1];
+                const uint32_t g = gid_sorted[range.x + pos];
+                const float4 q0 = srec[tid * 2], q1 = srec[tid * 2 + 1];
                 const float cC = q1.x, op = q1.y;
                 atomicAdd(&dL_dmean2D_px[2 * (size_t)g], op * fmaf(2.f * q0.z, a0, q0.w * a1) * RB_INV_LOG2E);
                 atomicAdd(&dL_dmean2D_px[2 * (size_t)g + 1], op * fmaf(2.f * cC, a1, q0.w * a0) * RB_INV_LOG2E);
@@ -379,6 +444,7 @@ __global__ void __launch_bounds__(RB_THREADS)
             }
         }
     }
+    RB_COUNT_FLUSH(1, 2);
 }
 
 int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
@@ -395,29 +461,10 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
                               float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
-#define RB_BWD(A)                                                                                                     \
-    hipLaunchKernelGGL(blend_bwd_rows_kernel<A>, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream,              \
-                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,                             \
-                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, (const float *)im.final_T,      \
-                       (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px,         \
-                       dL_dconic, dL_dopacity, dL_dcolors)
-#ifndef CGS_EXPERIMENTS
-    RB_BWD(0);
-#else
-    static int abl = -1;        // CGS_ROWS_ABL=1..7: timing experiments only (wrong gradients), tools/rows_ablate.sh
-    if (abl < 0) { const char *e = getenv("CGS_ROWS_ABL"); abl = e ? atoi(e) : 0; }
-    switch (abl) {
-        case 1: RB_BWD(1); break;
-        case 2: RB_BWD(2); break;
-        case 3: RB_BWD(3); break;
-        case 4: RB_BWD(4); break;
-        case 5: RB_BWD(5); break;
-        case 6: RB_BWD(6); break;
-        case 7: RB_BWD(7); break;
-        default: RB_BWD(0);
-    }
-#endif
-#undef RB_BWD
+    hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
+                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, (const float4 *)g.rec,
+                       cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last,
+                       dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 }

@@ -231,7 +231,7 @@ extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64
 // ---- analysis hook: wave iterations of the row mapping (four 4x4 blocks per wave) against an eight-group mapping (eight 4x2
 // half-blocks per wave, 8-lane groups), both with the octagon test of raster_blend_rows.hip and the backward's per-group bound
 // (entries behind the last contribution of the group's own pixels are dropped).  out4 = {iterations 4x4, iterations 4x2,
-// (group, Gaussian) visits 4x4, visits 4x2}.  tools/blend_occupancy.py; not part of include/cgs.h.
+// (group, Gaussian) visits 4x4, visits 4x2, iterations 4x4 with rows that do not wait for each other at the 32-entry segment boundaries}.  tools/blend_occupancy.py; not part of include/cgs.h.
 #include <hip/hip_fp16.h>
 __device__ __forceinline__ bool dbg_oct_hits(float rx, float ry, float hx, float hy, float hu, float hv, float x0, float x1,
                                              float y0, float y1) {
@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(256)
                                  const uint32_t *__restrict__ tile_last, const uint32_t *__restrict__ n_contrib,
                                  unsigned long long *__restrict__ out) {
     __shared__ uint32_t sm16[256], sm32[256], snc[256], last16[16], last32[32];
-    __shared__ unsigned long long red[4];
+    __shared__ uint32_t c16s[4][4][8];      // [wave][row][segment] visit counts of the current batch
+    __shared__ unsigned long long red[5];
     const int tile = blockIdx.x, tid = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t tlast = tile_last[tile];
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256)
         const int px = tx * 16 + (tid & 15), py = ty * 16 + (tid >> 4);
         snc[tid] = (px < W && py < H) ? n_contrib[(size_t)py * W + px] : 0u;
     }
-    if (tid < 4) red[tid] = 0;
+    if (tid < 5) red[tid] = 0;
     __syncthreads();
     if (tid < 16) {       // 4x4 block (bx, by)
         const int bx = tid & 3, by = tid >> 2;
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(256)
         for (int y = 0; y < 2; ++y) for (int x = 0; x < 4; ++x) m = max(m, snc[(hy * 2 + y) * 16 + bx * 4 + x]);
         last32[tid] = m;
     }
-    unsigned long long it16 = 0, it32 = 0, v16 = 0, v32 = 0;
+    unsigned long long it16 = 0, it32 = 0, v16 = 0, v32 = 0, it16_free = 0;
     for (uint32_t base = 0; base < tlast; base += 256) {
         __syncthreads();
         uint32_t m16 = 0, m32 = 0;
@@ -308,14 +309,25 @@ __global__ void __launch_bounds__(256)
                 }
             }
             uint32_t mx16 = 0, mx32 = 0;
-            for (int k = 0; k < 4; ++k) { mx16 = max(mx16, c16[k]); v16 += c16[k]; }
+            for (int k = 0; k < 4; ++k) { mx16 = max(mx16, c16[k]); v16 += c16[k]; c16s[w][k][s] = c16[k]; }
             for (int k = 0; k < 8; ++k) { mx32 = max(mx32, c32[k]); v32 += c32[k]; }
             it16 += mx16; it32 += mx32;
         }
+        __syncthreads();
+        if (tid < 4) {                    // rows that advance through the batch's segments independently: max over rows of the SUM
+            uint32_t mx = 0;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t t = 0;
+                for (int s = 0; s < 8; ++s) t += c16s[tid][k][s];
+                mx = max(mx, t);
+            }
+            it16_free += mx;
+        }
     }
+    atomicAdd(&red[4], it16_free);
     atomicAdd(&red[0], it16); atomicAdd(&red[1], it32); atomicAdd(&red[2], v16); atomicAdd(&red[3], v32);
     __syncthreads();
-    if (tid < 4) atomicAdd(&out[tid], red[tid]);
+    if (tid < 5) atomicAdd(&out[tid], red[tid]);
 }
 
 extern "C" int cgs_debug_blend_group_occupancy(const cgs_raster_cfg *cfg, int64_t P, int64_t R, void *geom_ws, size_t geom_bytes,
@@ -329,7 +341,7 @@ extern "C" int cgs_debug_blend_group_occupancy(const cgs_raster_cfg *cfg, int64_
         cgs_set_error("debug_blend_group_occupancy: workspace");
         return CGS_ERR_WORKSPACE;
     }
-    CGS_CHECK_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), (hipStream_t)stream));
+    CGS_CHECK_HIP(hipMemsetAsync(out4, 0, 5 * sizeof(int64_t), (hipStream_t)stream));
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     hipLaunchKernelGGL(blend_group_occupancy_kernel, dim3((unsigned)(tx * ty)), dim3(256), 0, (hipStream_t)stream,
                        cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,

@@ -45,13 +45,14 @@ print(f"wave instructions per view: row mapping {b} iterations x {ROW_INSTR} = {
       f"({(visits * SPLAT_INSTR + (pairs - visits) * SPLAT_SKIP) / max(1, b * ROW_INSTR):.2f}x)")
 
 # ---- four 4x4 blocks per wave (shipped) against eight 4x2 half-blocks per wave, both with the octagon test and the per-group bound ----
-out4 = torch.zeros(4, dtype=torch.int64, device="cuda")
+out4 = torch.zeros(5, dtype=torch.int64, device="cuda")
 f3 = L.cgs_debug_blend_group_occupancy
 f3.restype = C.c_int
 f3.argtypes = f.argtypes
 rc = f3(C.addressof(lc["cfg"].c), lc["P"], lc["bin_R"], lc["geom_ws"].data_ptr(), lc["geom_ws"].numel(),
         lc["bin_ws"].data_ptr(), lc["bin_ws"].numel(), lc["img_ws"].data_ptr(), lc["img_ws"].numel(), out4.data_ptr(), None)
 torch.cuda.synchronize()
-i16, i32, v16, v32 = out4.tolist()
+i16, i32, v16, v32, i16f = out4.tolist()
 print(f"group mapping rc={rc}: wave iterations with four 4x4 blocks per wave {i16} ({v16} block visits), with eight 4x2 half-blocks "
-      f"per wave {i32} ({v32} half-block visits): {i32 / max(1, i16):.3f}x the iterations")
+      f"per wave {i32} ({v32} half-block visits): {i32 / max(1, i16):.3f}x the iterations; four 4x4 blocks whose rows do not wait "
+      f"for each other at segment boundaries {i16f} ({i16f / max(1, i16):.3f}x)")
