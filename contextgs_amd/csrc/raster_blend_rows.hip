@@ -365,6 +365,10 @@ __global__ void __launch_bounds__(RB_THREADS)
                 const bool act = has && (position <= my_last) && ev.hit;
                 if (__ballot(act) == 0ull) continue;
                 RB_COUNT_INC1;
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 4      // timing only: walk + evaluation, nothing else
+                if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue);
+                continue;
+#endif
                 // Branch-free: a lane whose pixel takes no contribution runs the same updates on alpha = 0, G = 0, for which
                 // every one of them is an exact no-op (T / 1 = T, w = 0, the colour recurrence with alpha = 0 hands on
                 // the value the next contributing step would have computed) — two selects instead of a divergent block,
@@ -394,6 +398,13 @@ __global__ void __launch_bounds__(RB_THREADS)
                 v[6] = w * gr;
                 v[7] = w * gg;
                 v[8] = w * gb;
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 3      // timing only: no row reduction, no accumulation
+                {
+                    const float sm = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
+                    if (sm == 12345.f) atomicAdd(&sacc[e][0], sm);
+                    continue;
+                }
+#endif
                 // transposing reduction inside each 16-lane row (identical to raster_blend.hip); every row then adds
                 // into the accumulator of ITS OWN Gaussian
                 const bool b0 = lane & 1, b1 = lane & 2;
@@ -419,10 +430,17 @@ __global__ void __launch_bounds__(RB_THREADS)
                 asm volatile("" : "+v"(b2[0]), "+v"(b2[1]), "+v"(c8));
                 const int sub = lane & 15;
                 const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 1      // timing only: plain stores instead of LDS float atomics
+                if (has && sub < RB_NGRAD) sacc[e][sub] = red;
+#else
                 if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], red);
+#endif
             }
         }
         __syncthreads();
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 2      // timing only: no flush to global memory
+        if (tlast != 0x7fffffffu) continue;
+#endif
         if (pos < tlast) {
             const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
                         a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],

@@ -1,9 +1,8 @@
-# needs the experiment build of the library: CGS_EXTRA_FLAGS="-DCGS_EXPERIMENTS" python -m contextgs_amd.build (and the
-# same CGS_EXTRA_FLAGS exported for the runs, it is part of the build stamp); rebuild without it afterwards
-export CGS_EXTRA_FLAGS="-DCGS_EXPERIMENTS"
-python -m contextgs_amd.build > /dev/null || exit 1
-# blend_bwd_rows_kernel under the timing ablations CGS_ROWS_ABL=0..4 (same box, back to back); wrong gradients for != 0
+#!/bin/bash
+# Timing ablations of blend_bwd_rows_kernel (wrong gradients by construction).  Round 3's kernel (per-block entry lists):
+# -DRB_ABL=1 plain LDS stores instead of float atomics, =2 no flush to global memory, =3 no row reduction and no accumulation,
+# =4 walk + evaluation only.  Build the four variant libraries in the authoring container, then run this on the GPU box:
+#   for k in 1 2 3 4; do tools/variant_lib.sh rbabl$k raster_blend_rows.hip -DRB_ABL=$k; done
+# (Round 2's kernel and its CGS_ROWS_ABL=1..7 switch are in the history: profiles/r02_blend_bwd_experiments.txt.)
 cd $GRAFT_REPO_ROOT
-for a in 0 1 2 4 5 6 7 0; do
-  CGS_ROWS_ABL=$a timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-codec --no-heavy --no-eval-fps --no-image-loss --no-raster-only 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ABL=$a', 'blend_bwd us', d['kernels']['blend_bwd']['avg_us'], 'blend_fwd us', d['kernels']['blend_fwd']['avg_us'], 'step ms', d['ms_per_step'])"
-done
+bash tools/variants_prof.sh "blend_bwd" rbabl1 rbabl2 rbabl3 rbabl4
