@@ -93,6 +93,9 @@ __device__ __forceinline__ uint32_t rb_block_mask(float gx, float gy, float hx, 
     return m & um & vm;
 }
 
+// ballot of a bool (HIP's __ballot takes an int: a v_cndmask + v_cmp_ne pair per call)
+__device__ __forceinline__ uint64_t rb_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 template <int CTRL>
 __device__ __forceinline__ float rb_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
@@ -174,7 +177,8 @@ __global__ void __launch_bounds__(RB_THREADS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RbLane L = rb_lane(tx, ty, wave, lane);
     const bool inside = L.px < W && L.py < H;
-    const float pxf = (float)L.px, pyf = (float)L.py;
+    float pxf = (float)L.px, pyf = (float)L.py;
+    asm volatile("" : "+v"(pxf), "+v"(pyf));      // keep the converted coordinates in registers (the compiler re-converts per iteration)
     const uint2 range = ranges[tile];
 
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
@@ -217,13 +221,13 @@ __global__ void __launch_bounds__(RB_THREADS)
 #if defined(CGS_EXPERIMENTS) && defined(RB_ABL_NOWALK)
         if (range.x == 0xFFFFFFFFu)
 #endif
-        if (!__all(done)) {
+        if (rb_ballot(!done) != 0ull) {
             const uint32_t cnt = rb_list_build(S, L.blk, lane, RB_THREADS);
-            uint32_t i = 0;
+            uint32_t i = 0, lastb = 0;             // lastb: batch index + 1 of the pixel's last contribution in this batch
             uint32_t e_next = S.list[L.blk][0];
             // every lane of a row advances i together (also the lanes whose pixel is finished); the wave leaves when no
             // unfinished pixel has entries left
-            while (__ballot(!done && i < cnt) != 0ull) {
+            while (rb_ballot(!done && i < cnt) != 0ull) {
                 RB_COUNT_INC0;
                 const bool has = i < cnt;
                 const uint32_t e = e_next;
@@ -243,9 +247,10 @@ __global__ void __launch_bounds__(RB_THREADS)
                 cg = fmaf(r1.w, w, cg);
                 cb = fmaf(blue, w, cb);
                 T = upd ? test_T : T;
-                last = upd ? base_pos + e + 1u : last;
+                lastb = upd ? e + 1u : lastb;
                 done = done || stop;
             }
+            last = lastb ? base_pos + lastb : last;
         }
     }
 
@@ -352,7 +357,7 @@ __global__ void __launch_bounds__(RB_THREADS)
             // 256 pixels, a block's own bound over 16)
             int i = (int)rb_list_build(S, L.blk, lane, (int)blk_last - (int)base_pos - 1) - 1;
             uint32_t e_next = S.list[L.blk][max(i, 0)];
-            while (__ballot(i >= 0) != 0ull) {
+            while (rb_ballot(i >= 0) != 0ull) {
                 RB_COUNT_INC0;
                 const bool has = i >= 0;
                 const uint32_t e = e_next;
@@ -363,7 +368,7 @@ __global__ void __launch_bounds__(RB_THREADS)
                 const float blue = sblue[e];
                 const RbEval ev = rb_eval(r0, r1, pxf, pyf);
                 const bool act = has && (position <= my_last) && ev.hit;
-                if (__ballot(act) == 0ull) continue;
+                if (rb_ballot(act) == 0ull) continue;
                 RB_COUNT_INC1;
 #if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 4      // timing only: walk + evaluation, nothing else
                 if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue);
