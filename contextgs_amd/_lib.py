@@ -93,6 +93,7 @@ SIGNATURES = {
     "cgs_anchor_mlp3_backward_rows": (c_int, [c_void_p] * 21 + [c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_rowcat_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_rowcat_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cgs_anchor_mlp3_layout": (c_int, [c_void_p]),
     "cgs_scatter_rows_sorted": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_rowcat_fwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_rowcat_bwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,

@@ -197,6 +197,19 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
 import ctypes as _C
 
 
+_M3_LAYOUT = None
+
+
+def _m3_layout():
+    """(row stride of Hcat / dZ1cat, row stride of X_out, column pitch of a head) from the library (cgs_anchor_mlp3_layout)."""
+    global _M3_LAYOUT
+    if _M3_LAYOUT is None:
+        out = (_C.c_int * 3)()
+        _lib.check(_lib.lib().cgs_anchor_mlp3_layout(out), "cgs_anchor_mlp3_layout")
+        _M3_LAYOUT = (int(out[0]), int(out[1]), int(out[2]))
+    return _M3_LAYOUT
+
+
 def _ptr_array(tensors):
     return (_C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -224,7 +237,7 @@ class _AnchorMLP3(torch.autograd.Function):
         y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
-        hcat = torch.empty(n, 150, dtype=torch.float32, device=dev) if need_grad else None
+        hcat = torch.empty(n, _m3_layout()[0], dtype=torch.float32, device=dev) if need_grad else None
         _lib.check(L.cgs_anchor_mlp3_forward(_lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(b1), _ptr_array(W2),
                                              _ptr_array(b2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov),
                                              _lib.ptr(hcat), n, _lib.current_stream()), "cgs_anchor_mlp3_forward")
@@ -245,10 +258,11 @@ class _AnchorMLP3(torch.autograd.Function):
         g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(n, x.shape[1], dtype=torch.float32, device=dev) if need_dx else None
-        dz1 = torch.empty(n, 150, dtype=torch.float32, device=dev)
+        hld, _xld, hp = _m3_layout()
+        dz1 = torch.empty(n, hld, dtype=torch.float32, device=dev)
         dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
-        views = _zeros_views(dev, (150, 54), (150,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        views = _zeros_views(dev, (hld, 54), (hld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward(
@@ -258,7 +272,7 @@ class _AnchorMLP3(torch.autograd.Function):
             _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward")
         grads = [dx]
         for i in range(3):
-            grads += [dW1cat[50 * i:50 * (i + 1)], db1cat[50 * i:50 * (i + 1)], dW2[i], db2[i]]
+            grads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
         return tuple(grads)
 
 
@@ -283,8 +297,9 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
-        hcat = torch.empty(n, 150, dtype=torch.float32, device=dev) if need_grad else None
-        x = torch.empty(n, 54, dtype=torch.float32, device=dev) if need_grad else None
+        hld, xld, _hp = _m3_layout()
+        hcat = torch.empty(n, hld, dtype=torch.float32, device=dev) if need_grad else None
+        x = torch.empty(n, xld, dtype=torch.float32, device=dev) if need_grad else None
         _lib.check(L.cgs_anchor_mlp3_forward_rows(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
                                                   _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
                                                   _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n,
@@ -308,10 +323,11 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         # rows of the source no visible anchor reads keep a zero gradient; when every row is read: no fill
         d_src = (torch.empty if n == ctx.n_src else torch.zeros)(ctx.n_src, 50, dtype=torch.float32, device=dev)
         d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        dz1 = torch.empty(n, 150, dtype=torch.float32, device=dev)
+        hld, _xld, hp = _m3_layout()
+        dz1 = torch.empty(n, hld, dtype=torch.float32, device=dev)
         dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
-        views = _zeros_views(dev, (150, 54), (150,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        views = _zeros_views(dev, (hld, 54), (hld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward_rows(
@@ -322,7 +338,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
             "cgs_anchor_mlp3_backward_rows")
         grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None]
         for i in range(3):
-            grads += [dW1cat[50 * i:50 * (i + 1)], db1cat[50 * i:50 * (i + 1)], dW2[i], db2[i]]
+            grads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
         return tuple(grads)
 
 
