@@ -70,11 +70,18 @@ class _Cfg:
 last_call: dict = {}   # sizes / image workspace of the most recent forward (bench.py's byte accounting)
 
 # Pair-count speculation (cgs_raster_render_spec): the binning + blend of a view are enqueued before the host has read the
-# view's pair count, into a workspace sized from the largest count seen so far for that image size (x 1.25); the count is
+# view's pair count, into a workspace whose capacity is kept per image size (1.25 x the count that last exceeded it, rounded
+# up to a whole 2^20 pairs, so that the workspace keeps ONE size and the caching allocator keeps handing out the same block:
+# a capacity that crept up with every new maximum cost a fresh multi-GB hipMalloc each time); the count is
 # read through an event while the device renders.  A view that needs more pairs than that is rendered again with its true
 # count (same buffers, same stream: nothing has consumed the first attempt).  CGS_RASTER_SPEC=0 turns it off.
 SPECULATE = os.environ.get("CGS_RASTER_SPEC", "1") != "0"
-_pair_capacity: dict = {}     # (H, W) -> largest pair count seen
+_pair_capacity: dict = {}     # (H, W) -> capacity (pairs) of the speculative binning workspace
+
+
+def pair_capacity_for(num_rendered: int) -> int:
+    """The capacity a view with `num_rendered` pairs sets for the following views of its image size."""
+    return ((num_rendered + num_rendered // 4 + 4096 + (1 << 20) - 1) >> 20) << 20
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -104,8 +111,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                   _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
                                                   _lib.ptr(radii), stream), "cgs_raster_preprocess_launch")
         tiles = ((H + 15) // 16) * ((W + 15) // 16)
-        seen = _pair_capacity.get((H, W), 0)
-        cap = (seen + seen // 4 + 4096) if (SPECULATE and seen > 0 and P > 0 and tiles <= 65536) else 0
+        cap = _pair_capacity.get((H, W), 0) if (SPECULATE and P > 0 and tiles <= 65536) else 0
         binws = None
         if cap:
             binws = _workspace(L.cgs_raster_bin_bytes(P, cap), dev)
@@ -114,7 +120,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                        "cgs_raster_render_spec")
         _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
         num_rendered = int(R.value)
-        _pair_capacity[(H, W)] = max(seen, num_rendered)
+        if num_rendered > _pair_capacity.get((H, W), 0):
+            _pair_capacity[(H, W)] = pair_capacity_for(num_rendered)
         bin_R = cap                              # the count the binning workspace was carved with (the backward's `R`)
         if not cap or num_rendered > cap:
             bin_R = num_rendered

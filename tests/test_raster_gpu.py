@@ -268,7 +268,7 @@ def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
     per-tile lists, entry for entry, and the same tile ranges as the round-1 binning (emit_pairs + stable 32-bit pair sort,
     the path the oracle comparisons of rounds 1-2 ran on): one pass (256 tiles), 6+6 and 7+6 bit passes, a 28-tile grid
     with splats that cover all of it.  Three renders of each scene: with the pair count known on the host, speculative
-    (count read on the device, capacity 1.25 x the first render's), and speculative with a capacity that is too small
+    (count read on the device, capacity from the first render), and speculative with a capacity that is too small
     (the view is rendered again with the true count)."""
     from contextgs_amd import rasterizer as rz
     cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
@@ -279,11 +279,12 @@ def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
     assert diff == [0, 0] and R_ws == R, (diff, R, R_ws)
     again = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]              # speculative: the capacity comes from the first render
     diff, R2, R_ws = _bin_compare()
-    assert diff == [0, 0] and R2 == R and R_ws == R + R // 4 + 4096, (diff, R2, R_ws)
+    assert diff == [0, 0] and R2 == R and R_ws == rz.pair_capacity_for(R), (diff, R2, R_ws)
     assert (again == first).all()
-    rz._pair_capacity[(H, W)] = 1                                    # capacity 4097 pairs: all but the 28-tile case need more
+    rz._pair_capacity[(H, W)] = 4097                                 # too small for all but the 28-tile case
     third = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]
     diff, R3, R_ws = _bin_compare()
     assert diff == [0, 0] and R3 == R and R_ws == (R if R > 4097 else 4097), (diff, R3, R_ws)
     assert R > 4097 or P == 300
+    assert rz._pair_capacity[(H, W)] == (rz.pair_capacity_for(R) if R > 4097 else 4097)
     assert (third == first).all()
