@@ -16,13 +16,18 @@
 #define M3_NT1 4             // ceil(50/16)
 #define M3_HP 64
 #define M3_HCAT 150          // valid hidden columns of the three heads
-// Row layout of the hidden activations / their gradients in memory: [n][3][64] floats — every head's 50 columns start on a
-// 256-byte boundary and a row is 768 bytes, so the 64-byte chunk a wave instruction moves per row (16 features) is one
-// aligned 64-byte sector.  With the packed [n][150] layout of rounds 1-2 (600-byte rows) every chunk straddled two sectors:
-// twice the write requests, measured +46 % on a store-heavy MFMA kernel (tools/micro/bf16_split.hip, profiles/r03_row_alignment.txt).
-// The 14 pad columns of a head hold zeros (zero weights and bias in, zero gradient out).  X_out rows are 64 floats likewise.
-#define M3_HLD 192
-#define M3_XLD 64
+// Row layouts of what the forward and the backward hand over in memory.  A wave instruction moves a 64-byte chunk (16
+// features) per row, and a chunk that straddles two 64-byte sectors is two write requests (tools/micro/bf16_split.hip:
+// +46 % on a store-heavy MFMA kernel at EQUAL bytes).  Padding a row to whole sectors costs bytes, though, and the two were
+// measured against each other per buffer on one box (tools/ab_m3_layout.sh, profiles/r03_row_alignment.txt):
+//   Hcat   [n][150], X_out [n][54]  packed: the forward is bound by the bytes it stores (padded: +5 %)
+//   dZ1cat [n][3][64]               padded (a head's 50 columns on a 256-byte boundary, 768-byte rows, pad columns zero):
+//                                   the backward gains 6 % from it
+#define M3_HLD 150           // Hcat row stride, heads 50 columns apart
+#define M3_HPITCH 50
+#define M3_GLD 192           // dZ1cat row stride, heads 64 columns apart (dW1cat [192, 54] / db1cat [192] use the same rows)
+#define M3_GPITCH 64
+#define M3_XLD 54
 // wave-tile shapes (rows per wave tile = 16 RT, waves per workgroup); overridable for tools/mlp_tiling.sh
 #ifndef M3_FWD_RT
 #define M3_FWD_RT 1
@@ -135,7 +140,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             const int64_t row = row0 + rt * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc1[t][rt][r] = fmaxf(acc1[t][rt][r] + b1s[16 * t + 4 * g + r], 0.f);
-            if (Hcat) frag_store4<M3_HP>(Hcat + row * M3_HLD + M3_HP * head, t, g, valid[rt], acc1[t][rt]);
+            if (Hcat) frag_store4<M3_HID>(Hcat + row * M3_HLD + M3_HPITCH * head, t, g, valid[rt], acc1[t][rt]);
         }
     f32x4 acc2[L::NT2][RT];
 #pragma unroll
@@ -263,7 +268,7 @@ __global__ void __launch_bounds__(WAVES * 64)
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int q = 0; q < M3_NTI; ++q)
-                    frag_store4<M3_XLD>(R.X_out + (row0 + rt * 16 + c) * M3_XLD, q, g, valid[rt], xb[rt][q]);
+                    frag_store4<M3_IN>(R.X_out + (row0 + rt * 16 + c) * M3_XLD, q, g, valid[rt], xb[rt][q]);
         }
         m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
         m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
@@ -325,7 +330,7 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-            hv[t][rt] = frag_load4<M3_HP>(Hcat + (row0 + rt * 16 + c) * M3_HLD + M3_HP * head, t, g, valid[rt]);
+            hv[t][rt] = frag_load4<M3_HID>(Hcat + (row0 + rt * 16 + c) * M3_HLD + M3_HPITCH * head, t, g, valid[rt]);
     if (ACT != FRAG_ACT_NONE) {
 #pragma unroll
         for (int u = 0; u < L::NT2; ++u)
@@ -352,7 +357,7 @@ __device__ __forceinline__ void m3_head_bwd(const float *lds, const M3Head &h, i
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int64_t at = (row0 + rt * 16 + c) * M3_HLD + M3_HP * head;
+            const int64_t at = (row0 + rt * 16 + c) * M3_GLD + M3_GPITCH * head;
 #pragma unroll
             for (int r = 0; r < 4; ++r) adh[t][rt][r] = hv[t][rt][r] > 0.f ? adh[t][rt][r] : 0.f;
             frag_store4<M3_HP>(dZ1cat + at, t, g, valid[rt], adh[t][rt]);
@@ -447,12 +452,12 @@ static int m3_cus() {
     return cus;
 }
 
-// Row strides (floats) of the buffers the forward / backward hand to each other: out3 = {hidden (Hcat, dZ1cat: [n, 192],
-// head h in columns 64 h .. 64 h + 49; dW1cat [192, 54] and db1cat [192] use the same row numbering), X_out of the ROWS
-// variant ([n, 64]), valid hidden columns per head (50)}.
-extern "C" int cgs_anchor_mlp3_layout(int *out3) {
-    if (!out3) { cgs_set_error("cgs_anchor_mlp3_layout: NULL"); return CGS_ERR_ARG; }
-    out3[0] = M3_HLD; out3[1] = M3_XLD; out3[2] = M3_HP;
+// Row strides (floats) of the buffers the forward / backward hand to each other: out4 = {Hcat row stride (150: head h in
+// columns 50 h ..), X_out row stride of the ROWS variant (54), dZ1cat row stride (192), dZ1cat column pitch of a head (64:
+// head h in columns 64 h .. 64 h + 49; dW1cat [192, 54] and db1cat [192] use the same row numbering)}.
+extern "C" int cgs_anchor_mlp3_layout(int *out4) {
+    if (!out4) { cgs_set_error("cgs_anchor_mlp3_layout: NULL"); return CGS_ERR_ARG; }
+    out4[0] = M3_HLD; out4[1] = M3_XLD; out4[2] = M3_GLD; out4[3] = M3_GPITCH;
     return CGS_OK;
 }
 
@@ -581,9 +586,9 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     // the three first layers as one [150 x 54] product and the three second layers, all in ONE launch over the
     // same rows (7 wave tasks): an Hcat / dZ1cat row is pulled from HBM once
     const CgsWgProduct prods[4] = {
-        {dZ1cat, M3_HLD, M3_HLD, X, ldx, M3_IN, dW1cat, db1cat},       // dW1cat [192, 54]: head h = rows 64 h .. 64 h + 49
+        {dZ1cat, M3_GLD, M3_GLD, X, ldx, M3_IN, dW1cat, db1cat},       // dW1cat [192, 54]: head h = rows 64 h .. 64 h + 49
         {dZ2_op, 10, 10, Hcat, M3_HLD, M3_HID, dW2[0], db2[0]},
-        {dZ2_color, 30, 30, Hcat + M3_HP, M3_HLD, M3_HID, dW2[1], db2[1]},
-        {dY_cov, 70, 70, Hcat + 2 * M3_HP, M3_HLD, M3_HID, dW2[2], db2[2]}};
+        {dZ2_color, 30, 30, Hcat + M3_HPITCH, M3_HLD, M3_HID, dW2[1], db2[1]},
+        {dY_cov, 70, 70, Hcat + 2 * M3_HPITCH, M3_HLD, M3_HID, dW2[2], db2[2]}};
     return cgs_launch_wgrad_multi(prods, 4, n, m3_cus(), scratch, scratch_bytes, stream);
 }

@@ -201,12 +201,13 @@ _M3_LAYOUT = None
 
 
 def _m3_layout():
-    """(row stride of Hcat / dZ1cat, row stride of X_out, column pitch of a head) from the library (cgs_anchor_mlp3_layout)."""
+    """(row stride of Hcat, row stride of X_out, row stride of dZ1cat, column pitch of a head in dZ1cat / dW1cat / db1cat)
+    from the library (cgs_anchor_mlp3_layout)."""
     global _M3_LAYOUT
     if _M3_LAYOUT is None:
-        out = (_C.c_int * 3)()
+        out = (_C.c_int * 4)()
         _lib.check(_lib.lib().cgs_anchor_mlp3_layout(out), "cgs_anchor_mlp3_layout")
-        _M3_LAYOUT = (int(out[0]), int(out[1]), int(out[2]))
+        _M3_LAYOUT = tuple(int(v) for v in out)
     return _M3_LAYOUT
 
 
@@ -258,11 +259,11 @@ class _AnchorMLP3(torch.autograd.Function):
         g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(n, x.shape[1], dtype=torch.float32, device=dev) if need_dx else None
-        hld, _xld, hp = _m3_layout()
-        dz1 = torch.empty(n, hld, dtype=torch.float32, device=dev)
+        _hld, _xld, gld, hp = _m3_layout()
+        dz1 = torch.empty(n, gld, dtype=torch.float32, device=dev)
         dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
-        views = _zeros_views(dev, (hld, 54), (hld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward(
@@ -297,7 +298,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
-        hld, xld, _hp = _m3_layout()
+        hld, xld, _gld, _gp = _m3_layout()
         hcat = torch.empty(n, hld, dtype=torch.float32, device=dev) if need_grad else None
         x = torch.empty(n, xld, dtype=torch.float32, device=dev) if need_grad else None
         _lib.check(L.cgs_anchor_mlp3_forward_rows(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
@@ -323,11 +324,11 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         # rows of the source no visible anchor reads keep a zero gradient; when every row is read: no fill
         d_src = (torch.empty if n == ctx.n_src else torch.zeros)(ctx.n_src, 50, dtype=torch.float32, device=dev)
         d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        hld, _xld, hp = _m3_layout()
-        dz1 = torch.empty(n, hld, dtype=torch.float32, device=dev)
+        _hld, _xld, gld, hp = _m3_layout()
+        dz1 = torch.empty(n, gld, dtype=torch.float32, device=dev)
         dz2_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         dz2_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
-        views = _zeros_views(dev, (hld, 54), (hld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
+        views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
         _lib.check(L.cgs_anchor_mlp3_backward_rows(

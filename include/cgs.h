@@ -418,17 +418,18 @@ int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
                        int compact, void *stream);
 
 /* Row strides (floats) of the buffers the anchor-MLP forward and backward hand to each other, so that callers size them:
- * out3 = {row stride of Hcat and dZ1cat (192: head h occupies columns 64 h .. 64 h + 49, pad columns hold zeros; dW1cat is
- * [192, 54] and db1cat [192] with the same row numbering), row stride of X_out of the _rows variant (64), column pitch of a
- * head (64)}.  Every 16-feature chunk of a row is then one aligned 64-byte sector. */
-int cgs_anchor_mlp3_layout(int *out3);
+ * out4 = {row stride of Hcat (150: head h in columns 50 h .. 50 h + 49), row stride of X_out of the _rows variant (54),
+ * row stride of dZ1cat (192), column pitch of a head in dZ1cat (64: head h in columns 64 h .. 64 h + 49, pad columns hold
+ * zeros; dW1cat is [192, 54] and db1cat [192] with the same row numbering)}.  dZ1cat is padded so that every 16-feature chunk
+ * the backward stores per row is one aligned 64-byte sector; Hcat and X_out stay packed. */
+int cgs_anchor_mlp3_layout(int *out4);
 
 /* The three anchor MLPs (mlp_opacity 54->50->10 tanh, mlp_color 54->50->30
  * sigmoid, mlp_cov 54->50->70; gaussian_renderer/__init__.py:112,122,126) on
  * their shared input in ONE launch each way.  W1/b1/W2/b2 (and dW2/db2) are
  * HOST arrays of three device pointers in the order (opacity, color, cov).
- * Hcat [n,192] holds the three ReLU hidden layers, head h in columns 64 h .. 64 h + 49
- * (cgs_anchor_mlp3_layout); dZ1cat [n,192] likewise, dZ2_op [n,10], dZ2_color [n,30] are backward
+ * Hcat [n,150] holds the three ReLU hidden layers side by side; dZ1cat [n,192] their gradients, head h in
+ * columns 64 h .. 64 h + 49 (cgs_anchor_mlp3_layout); dZ2_op [n,10], dZ2_color [n,30] are backward
  * scratch.  dW1cat [192,54] / db1cat [192] hold the three first-layer gradients in rows 64 h .. 64 h + 49;
  * all weight / bias gradients are ACCUMULATED into (scratch as for cgs_mlp2_backward). */
 int cgs_anchor_mlp3_forward(const float *X, int64_t ldx,
@@ -447,8 +448,8 @@ int cgs_anchor_mlp3_backward(const float *X, int64_t ldx,
                              void *scratch, size_t scratch_bytes, void *stream);
 /* The same pair with the MLP input assembled on the fly (gaussian_renderer/__init__.py:106-110 fused into the
  * operand load): X[r] = [feat_src[src_row[r], 0:50] | (a - cam)/|a - cam| | |a - cam|], a = anchor_vis[r],
- * cam3 = camera centre (device float[3]).  X_out [n,64] (54 columns + zeros) receives the assembled rows (read by
- * the weight-gradient pass).  The backward stores dX[:, 0:50] into rows src_row[r] of d_feat_src [*,50] (distinct rows;
+ * cam3 = camera centre (device float[3]).  X_out [n,54] receives the assembled rows (read by the weight-
+ * gradient pass).  The backward stores dX[:, 0:50] into rows src_row[r] of d_feat_src [*,50] (distinct rows;
  * rows that no visible anchor reads are the caller's to zero) and pulls the four view columns back to
  * d_anchor_vis [n,3]; everything else as cgs_anchor_mlp3_backward (X = the forward's X_out). */
 int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t *src_row,
