@@ -10,6 +10,12 @@
 // happens inside a 16-lane row (two quad butterflies + two row rotations), and each row adds into the LDS
 // accumulator of ITS Gaussian (fewer same-address conflicts than four rows adding into one).
 //
+// Round 3: a row's Gaussians are a LIST of batch indices (rb_list_build: built by the row itself from the staging threads'
+// 16-bit block masks, one DPP scan, no atomics) that the row walks with its own cursor - rows no longer wait for each
+// other at 32-entry segment boundaries as with the bit masks of round 2 (-18..20 % wave iterations, tools/rb_iters.py);
+// blocks are culled against the octagon (box + diagonals) of the alpha >= 1/255 ellipse (rb_block_mask).
+// profiles/r03_blend_lists.txt has the measurements, including what the backward's time is made of now.
+//
 // Same arithmetic per (pixel, Gaussian) as raster_blend.hip (blend_eval is identical), same list order per pixel, so
 // results are bit-identical to the quadrant-mapped kernels for the forward and equal up to the summation order of
 // the per-Gaussian partial sums for the backward.
