@@ -262,17 +262,20 @@ def _bin_compare():
 
 
 @pytest.mark.parametrize("P,W,H,scale_hi", [(4000, 256, 256, 0.05), (30000, 800, 800, 0.02), (20000, 1920, 1080, 0.08),
-                                             (300, 97, 61, 0.4)])
+                                             (300, 97, 61, 0.4), (60000, 64, 64, 0.3)])
 def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
     """csrc/tile_bin.hip (pair-generating first radix pass, 16-bit tile keys, ranges from the last pass) leaves the same
     per-tile lists, entry for entry, and the same tile ranges as the round-1 binning (emit_pairs + stable 32-bit pair sort,
     the path the oracle comparisons of rounds 1-2 ran on): one pass (256 tiles), 6+6 and 7+6 bit passes, a 28-tile grid
-    with splats that cover all of it.  Three renders of each scene: with the pair count known on the host, speculative
+    with splats that cover all of it, and 16 tiles with ~40 000 entries each, half of them exact depth ties (pairs of Gaussians
+    at the same position: the ids decide).  Three renders of each scene: with the pair count known on the host, speculative
     (count read on the device, capacity from the first render), and speculative with a capacity that is too small
     (the view is rendered again with the true count)."""
     from contextgs_amd import rasterizer as rz
     cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
     g = random_gaussians(P, seed=P, extent=1.0, scale_lo=0.003, scale_hi=scale_hi)
+    if P == 60000:
+        g["means3D"][1::2] = g["means3D"][0::2]
     rz._pair_capacity.pop((H, W), None)
     first = _run_gpu(cam, g, (0.0, 0.0, 0.0))["color"]
     diff, R, R_ws = _bin_compare()
