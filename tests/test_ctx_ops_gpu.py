@@ -285,3 +285,45 @@ def test_choose_rows_matches_the_torch_composition(n, with_perm, with_mask):
     # a moved anchor / flipped mask bit is reported
     moved = anchor.clone(); moved[n // 2, 1] += 1.0
     assert ctx_ops.choose_rows(perm, n, mask, given, 0, 0.15, moved, anchor, None if mask is None else mask.clone(), cuts)[0]
+
+
+@pytest.mark.parametrize("n,rows", [(1, 5), (777, 1000), (20000, 20000)])
+def test_rowcat_row_mask_equals_the_product(n, rows):
+    """rowcat with a per-source-row mask == cat([(src * mask[:, None])[idx], other]) — `anchor * mask_anchor.unsqueeze(1)` of
+    scene/gaussian_model.py:1758-1759 folded into the level gather (cgs_rowcat_*_masked): values (incl. -0.0 for masked
+    negative entries, as the product gives) and both gradients."""
+    from contextgs_amd import ctx_ops
+    torch.manual_seed(n)
+    dev = "cuda"
+    a = torch.randn(rows, 3, device=dev, requires_grad=True)
+    b = torch.randn(n, 12, device=dev, requires_grad=True)
+    mask = torch.rand(rows, device=dev) < 0.7
+    idx = torch.randperm(rows, device=dev)[:n]
+    out = ctx_ops.rowcat([(a, idx, True, mask), (b, None, True)])
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = torch.cat([(a2 * mask.unsqueeze(1))[idx], b2], dim=1)
+    assert torch.equal(out, ref) and torch.equal(torch.signbit(out), torch.signbit(ref))
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+
+
+@pytest.mark.parametrize("N,frac,w", [(1000, 0.995, 3), (50000, 0.9, 10), (4096, 1.0, 30), (1000, 0.0, 7), (3000, 0.3, 256),
+                                       (10, 0.5, 1)])
+def test_scatter_rows_sorted_equals_zeros_index_copy(N, frac, w):
+    """cgs_scatter_rows_sorted (the one-pass backward of x[visible rows]) == zeros(N, w).index_copy_(0, idx, g) for ascending idx:
+    dense and sparse lists, an empty list, every row listed, the widest row the kernel takes."""
+    from contextgs_amd import _lib
+    torch.manual_seed(N + w)
+    dev = "cuda"
+    idx = torch.nonzero(torch.rand(N, device=dev) < frac)[:, 0] if 0.0 < frac < 1.0 else (
+        torch.arange(N, device=dev) if frac >= 1.0 else torch.zeros(0, dtype=torch.int64, device=dev))
+    n = int(idx.numel())
+    g = torch.randn(n, w, device=dev)
+    out = torch.full((N, w), float("nan"), device=dev)
+    _lib.check(_lib.lib().cgs_scatter_rows_sorted(_lib.ptr(g), _lib.ptr(idx), n, N, w, _lib.ptr(out), _lib.current_stream()),
+               "cgs_scatter_rows_sorted")
+    ref = torch.zeros(N, w, device=dev)
+    if n:
+        ref.index_copy_(0, idx, g)
+    assert torch.equal(out, ref)
