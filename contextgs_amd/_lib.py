@@ -84,6 +84,9 @@ SIGNATURES = {
                                        c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_mlp_wgrad_scratch_bytes": (c_size_t, []),
+    "cgs_mlp2_wgrad": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_anchor_mlp3_wgrad": (c_int, [c_void_p, c_int64] + [c_void_p] * 9 + [c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_anchor_mlp3_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_void_p]),
     "cgs_anchor_mlp3_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -372,8 +372,13 @@ static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X,
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("mlp2_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
-    if (!X || !W1 || !W2 || !dY || !dZ1 || !dW1 || !db1 || !dW2 || !db2 || (act != ACT_NONE && (!Y || !dZ2))) {
-        cgs_set_error("mlp2_backward: NULL");
+    // dW1 == NULL: data gradients only — the weight-gradient products are the caller's to launch later (cgs_mlp2_wgrad)
+    // (with H == NULL the recomputing kernel still accumulates the second layer: dW2 / db2 stay required there)
+    const bool data_only = !dW1;
+    const bool second_inside = data_only && !H;
+    bool wg_ok = data_only ? (!db1 && (second_inside ? (dW2 && db2) : (!dW2 && !db2))) : (db1 && dW2 && db2);
+    if (!X || !W1 || !W2 || !dY || !dZ1 || (act != ACT_NONE && (!Y || !dZ2)) || !wg_ok) {
+        cgs_set_error("mlp2_backward: NULL (or a partial set of weight-gradient pointers)");
         return CGS_ERR_ARG;
     }
     int rc = CGS_ERR_ARG;
@@ -386,7 +391,7 @@ static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X,
                                                db2, n, num_cus(), scratch, scratch_bytes, stream);
         }
         if (rc == -1) { cgs_set_error("mlp2_backward: no recompute instance for %d -> %d -> %d", in, hid, out); return CGS_ERR_ARG; }
-        if (rc) return rc;
+        if (rc || data_only) return rc;
         CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
         const CgsWgProduct prod = {dZ1, hid, hid, X, ldx, in, dW1, db1};
         return cgs_launch_wgrad_multi(&prod, 1, n, num_cus(), scratch, scratch_bytes, stream);
@@ -402,12 +407,31 @@ static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X,
         MLP_CONFIGS(X_)
 #undef X_
         if (!found) { cgs_set_error("mlp2_backward: no kernel instance for %d -> %d -> %d act %d", in, hid, out, act); return CGS_ERR_ARG; }
-        if (rc) return rc;
+        if (rc || data_only) return rc;
     }
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
     const float *P2 = (act == ACT_NONE || !dZ2) ? dY : dZ2;
     const int64_t ldp2 = (act == ACT_NONE || !dZ2) ? ldy : out;
     const CgsWgProduct prods[2] = {{P2, ldp2, out, H, hid, hid, dW2, db2}, {dZ1, hid, hid, X, ldx, in, dW1, db1}};
+    return cgs_launch_wgrad_multi(prods, 2, n, num_cus(), scratch, scratch_bytes, stream);
+}
+
+// The weight-gradient products of cgs_mlp2_backward as a call of their own (after a backward with dW1 == NULL):
+// dW1 += dZ1^T X, db1 += sum dZ1 and — when H != NULL — dW2 += dZ2^T H, db2 += sum dZ2 (dZ2 [n, lddz2]: the backward's dZ2, or
+// dY itself for act == 0).  H == NULL: the recomputing backward has accumulated the second layer already.
+extern "C" int cgs_mlp2_wgrad(int in, int hid, int out, const float *X, int64_t ldx, const float *H, const float *dZ2,
+                              int64_t lddz2, const float *dZ1, float *dW1, float *db1, float *dW2, float *db2, int64_t n,
+                              void *scratch, size_t scratch_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) { cgs_set_error("mlp2_wgrad: n < 0"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!X || !dZ1 || !dW1 || !db1 || (H && (!dZ2 || !dW2 || !db2))) { cgs_set_error("mlp2_wgrad: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+    if (!H) {
+        const CgsWgProduct prod = {dZ1, hid, hid, X, ldx, in, dW1, db1};
+        return cgs_launch_wgrad_multi(&prod, 1, n, num_cus(), scratch, scratch_bytes, stream);
+    }
+    const CgsWgProduct prods[2] = {{dZ2, lddz2, out, H, hid, hid, dW2, db2}, {dZ1, hid, hid, X, ldx, in, dW1, db1}};
     return cgs_launch_wgrad_multi(prods, 2, n, num_cus(), scratch, scratch_bytes, stream);
 }
 

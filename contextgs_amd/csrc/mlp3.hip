@@ -523,6 +523,10 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
                        const float *Hcat, float *dX, int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color,
                        float *dW1cat, float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
                        size_t scratch_bytes, const M3Rows *rows, void *stream_);
+extern "C" int cgs_anchor_mlp3_wgrad(const float *X, int64_t ldx, const float *Hcat, const float *dZ1cat,
+                                     const float *dZ2_op, const float *dZ2_color, const float *dY_cov, float *dW1cat,
+                                     float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
+                                     size_t scratch_bytes, void *stream_);
 
 extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2,
                                         const float *Y_op, const float *Y_color, const float *dY_op,
@@ -559,9 +563,11 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("anchor_mlp3_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
+    // dW1cat == NULL: data gradients only — the weight-gradient launch is the caller's to make later (cgs_anchor_mlp3_wgrad)
+    const bool data_only = !dW1cat;
     if (!X || !W1 || !W2 || !Y_op || !Y_color || !dY_op || !dY_color || !dY_cov || !Hcat || !dZ1cat || !dZ2_op ||
-        !dZ2_color || !dW1cat || !db1cat || !dW2 || !db2) {
-        cgs_set_error("anchor_mlp3_backward: NULL");
+        !dZ2_color || (data_only ? (db1cat || dW2 || db2) : (!db1cat || !dW2 || !db2))) {
+        cgs_set_error("anchor_mlp3_backward: NULL (or a partial set of weight-gradient pointers)");
         return CGS_ERR_ARG;
     }
     constexpr int RT = M3_BWD_RT, WAVES = M3_BWD_WAVES;
@@ -581,6 +587,25 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
             hipLaunchKernelGGL((mlp3_bwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, stream,
                                h[0], h[1], h[2], Hcat, dZ1cat, dX, lddx, n, M3Rows{});
         CGS_CHECK_HIP(hipGetLastError());
+    }
+    if (data_only) return CGS_OK;
+    return cgs_anchor_mlp3_wgrad(X, ldx, Hcat, dZ1cat, dZ2_op, dZ2_color, dY_cov, dW1cat, db1cat, dW2, db2, n, scratch,
+                                 scratch_bytes, stream_);
+}
+
+// The weight-gradient launch of cgs_anchor_mlp3_backward as a call of its own (after a backward with dW1cat == NULL):
+// X [n, ldx] (the forward's X_out for the _rows pair, ldx = cgs_anchor_mlp3_layout()[1]), dZ1cat / dZ2_op / dZ2_color as the
+// backward left them, dY_cov the incoming gradient of the covariance head (its second layer has no activation).
+extern "C" int cgs_anchor_mlp3_wgrad(const float *X, int64_t ldx, const float *Hcat, const float *dZ1cat,
+                                     const float *dZ2_op, const float *dZ2_color, const float *dY_cov, float *dW1cat,
+                                     float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
+                                     size_t scratch_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) { cgs_set_error("anchor_mlp3_wgrad: n < 0"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!X || !Hcat || !dZ1cat || !dZ2_op || !dZ2_color || !dY_cov || !dW1cat || !db1cat || !dW2 || !db2) {
+        cgs_set_error("anchor_mlp3_wgrad: NULL");
+        return CGS_ERR_ARG;
     }
     CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
     // the three first layers as one [150 x 54] product and the three second layers, all in ONE launch over the

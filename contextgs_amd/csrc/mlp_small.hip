@@ -116,7 +116,8 @@ __global__ void __launch_bounds__(WAVES * 64)
             }
         }
     }
-    // dW2 / db2: sum over the 16 row lanes, then over the waves (LDS), one partial image per workgroup
+    // dW2 / db2: sum over the 16 row lanes, then over the waves — the waves take turns with plain LDS read-modify-writes
+    // (a fixed order: the same bits every run, which LDS float atomics do not give) — one partial image per workgroup
 #pragma unroll
     for (int o = 0; o < OUT; ++o) {
 #pragma unroll
@@ -128,14 +129,27 @@ __global__ void __launch_bounds__(WAVES * 64)
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 1);
-                if (c == 0) atomicAdd(&red[o * HP + 16 * t + 4 * g + r], v);
+                accW2[o][t][r] = v;
             }
         float vb = accb[o];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) vb += __shfl_xor(vb, d);
-        if (lane == 0) atomicAdd(&red[OUT * HP + o], vb);
+        accb[o] = vb;
     }
-    __syncthreads();
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int o = 0; o < OUT; ++o) {
+#pragma unroll
+                for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c == 0) red[o * HP + 16 * t + 4 * g + r] += accW2[o][t][r];
+                if (lane == 0) red[OUT * HP + o] += accb[o];
+            }
+        }
+        __syncthreads();
+    }
     float *dst = partial + (int64_t)blockIdx.x * E;
     for (int i = tid; i < E; i += nthr) {
         const int o = i / HID, h = i % HID;

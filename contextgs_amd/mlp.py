@@ -31,6 +31,78 @@ def _wgrad_workspace(dev) -> torch.Tensor:
     return torch.empty(int(_lib.lib().cgs_mlp_wgrad_scratch_bytes()), dtype=torch.uint8, device=dev)
 
 
+# ---- weight gradients deferred to the end of the backward (data-parallel steps) ------------------------------------
+class _Deferred:
+    """Queue of weight-gradient launches that the backward nodes below leave for the END of the backward pass.
+
+    On one GPU a node launches its weight-gradient products right behind its data-gradient kernel.  In a data-parallel
+    step the per-anchor gradients (0.44 GB at 1 M anchors) become final in the last nodes of the graph, so their
+    all-reduce has nothing left to hide behind — unless the ≈ 1.1 ms of weight-gradient kernels, which nothing in
+    the backward depends on, run AFTER it has been issued.  With `defer_weight_gradients(True)` the nodes call the
+    data-only form of their C entry point, keep the operands alive in a closure, and an autograd-engine callback
+    (end of `backward()`) first runs the `before_flush` hooks (`dist.GradientSync` issues its remaining per-anchor
+    collectives there), then launches the queued products on the compute stream and accumulates the results into
+    the parameters' `.grad` exactly as autograd would have (same kernels, same order: bit-identical gradients)."""
+    on = os.environ.get("CGS_DEFER_WGRAD", "0") == "1"
+    queue: list = []
+    armed = False
+    before_flush: list = []
+    staged: dict = {}
+
+
+def defer_weight_gradients(on: bool = True) -> bool:
+    """Switch the deferral on / off; returns the previous setting."""
+    prev, _Deferred.on = _Deferred.on, bool(on)
+    return prev
+
+
+def add_before_flush_hook(fn):
+    _Deferred.before_flush.append(fn)
+    return fn
+
+
+def remove_before_flush_hook(fn):
+    if fn in _Deferred.before_flush:
+        _Deferred.before_flush.remove(fn)
+
+
+def _can_defer(params) -> bool:
+    # only leaf parameters: a gradient for anything else has to travel through autograd
+    return _Deferred.on and all(isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad for p in params)
+
+
+def _flush_deferred():
+    _Deferred.armed = False
+    jobs, _Deferred.queue = _Deferred.queue, []
+    for hook in list(_Deferred.before_flush):
+        hook()
+    for job in jobs:
+        job()
+    # like the engine's input buffer of an AccumulateGrad node: the contributions of THIS backward are summed first (in
+    # node order), then added to an existing .grad
+    staged, _Deferred.staged = _Deferred.staged, {}
+    with torch.no_grad():
+        for p, g in staged.values():
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+
+def _defer(job):
+    _Deferred.queue.append(job)
+    if not _Deferred.armed:
+        _Deferred.armed = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+
+
+def _accumulate(params, grads):
+    with torch.no_grad():
+        for p, g in zip(params, grads):
+            have = _Deferred.staged.get(id(p))
+            _Deferred.staged[id(p)] = (p, g if have is None else have[1].add_(g))
+
+
 _SUPPORTED = {(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0), (71, 100, 175, 0), (15, 100, 175, 0), (71, 100, 3, 0),
               (15, 100, 3, 0)}
 
@@ -69,6 +141,7 @@ class _MLP2(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x, W1c, W2c, y, h if h is not None else b1c)
         ctx.act, ctx.recompute = act, recompute
+        ctx.params = (W1, b1, W2, b2)
         return y
 
     @staticmethod
@@ -89,11 +162,25 @@ class _MLP2(torch.autograd.Function):
         dz2 = torch.empty(n, out, dtype=torch.float32, device=dev) if act != 0 else None
         dW1, db1, dW2, db2 = _zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))   # one fill for the four
         ws = _wgrad_workspace(dev)
+        defer = _can_defer(ctx.params) and n > 0
+        inside = defer and h is None          # the recomputing kernel accumulates the second layer itself
+        wg = lambda t, keep: _lib.ptr(t) if (not defer or keep) else None
         _lib.check(L.cgs_mlp2_backward(in_f, hid, out, act, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(y),
                                        _lib.ptr(dy), out, _lib.ptr(h), _lib.ptr(dx), in_f, 0, _lib.ptr(dz1), _lib.ptr(dz2),
-                                       _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n,
+                                       wg(dW1, False), wg(db1, False), wg(dW2, inside), wg(db2, inside), n,
                                        _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_mlp2_backward")
-        return dx, dW1, db1, dW2, db2, None
+        if not defer:
+            return dx, dW1, db1, dW2, db2, None
+        p2 = dz2 if dz2 is not None else dy
+        params = ctx.params
+
+        def job():
+            _lib.check(L.cgs_mlp2_wgrad(in_f, hid, out, _lib.ptr(x), in_f, _lib.ptr(h), _lib.ptr(p2), out, _lib.ptr(dz1),
+                                        _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), n, _lib.ptr(ws), ws.numel(),
+                                        _lib.current_stream()), "cgs_mlp2_wgrad")
+            _accumulate(params, (dW1, db1, dW2, db2))
+        _defer(job)
+        return dx, None, None, None, None, None
 
 
 class _LevelMLP(torch.autograd.Function):
@@ -128,6 +215,7 @@ class _LevelMLP(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x, x_sub, loc, W1c, b1c, W2c, h_sub)
         ctx.n_stat = n_stat
+        ctx.params = (W1, b1, W2, b2)
         return qadj, pred
 
     @staticmethod
@@ -145,14 +233,22 @@ class _LevelMLP(torch.autograd.Function):
         dW1, db1, dW2, db2 = _zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))   # one fill for the module
         ws = _wgrad_workspace(dev)
         dx = None
+        defer = _can_defer(ctx.params)
+        wg = lambda t: None if defer else _lib.ptr(t)
+        jobs = []
         if d_q is not None:
             dx = torch.empty(n, in_f, dtype=torch.float32, device=dev) if need_dx else None
             dz1 = torch.empty(n, hid, dtype=torch.float32, device=dev)
             d_q = f32c(d_q)
+            # (recomputing kernel: the step-size rows of the second layer are accumulated inside it, deferred or not)
             _lib.check(L.cgs_mlp2_backward(in_f, hid, nq, 0, _lib.ptr(x), in_f, _lib.ptr(W1), _lib.ptr(b1),
                                            W2.data_ptr() + 4 * n_stat * hid, None, _lib.ptr(d_q), nq, None, _lib.ptr(dx), in_f, 0,
-                                           _lib.ptr(dz1), None, _lib.ptr(dW1), _lib.ptr(db1), dW2.data_ptr() + 4 * n_stat * hid,
+                                           _lib.ptr(dz1), None, wg(dW1), wg(db1), dW2.data_ptr() + 4 * n_stat * hid,
                                            db2.data_ptr() + 4 * n_stat, n, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward")
+            if defer and n > 0:
+                jobs.append(lambda: _lib.check(L.cgs_mlp2_wgrad(
+                    in_f, hid, nq, _lib.ptr(x), in_f, None, None, 0, _lib.ptr(dz1), _lib.ptr(dW1), _lib.ptr(db1), None, None, n,
+                    _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_mlp2_wgrad"))
         if d_pred is not None and m > 0:
             d_pred = f32c(d_pred)
             dz1s = torch.empty(m, hid, dtype=torch.float32, device=dev)
@@ -162,9 +258,23 @@ class _LevelMLP(torch.autograd.Function):
             # (cgs_mlp2_backward_rows): no [m, in] temporary, no index_add_ launch
             _lib.check(L.cgs_mlp2_backward_rows(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1), None, _lib.ptr(W2), None,
                                                 _lib.ptr(d_pred), out, _lib.ptr(h_sub), _lib.ptr(dx) if need_dx else None, in_f, 1,
-                                                _lib.ptr(loc), _lib.ptr(dz1s), None, _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2),
-                                                _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward_rows")
-        return dx, None, dW1, db1, dW2, db2, None
+                                                _lib.ptr(loc), _lib.ptr(dz1s), None, wg(dW1), wg(db1), wg(dW2),
+                                                wg(db2), m, _lib.ptr(ws), ws.numel(), stream), "cgs_mlp2_backward_rows")
+            if defer:
+                jobs.append(lambda: _lib.check(L.cgs_mlp2_wgrad(
+                    in_f, hid, out, _lib.ptr(x_sub), in_f, _lib.ptr(h_sub), _lib.ptr(d_pred), out, _lib.ptr(dz1s), _lib.ptr(dW1),
+                    _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+                    "cgs_mlp2_wgrad"))
+        if not defer:
+            return dx, None, dW1, db1, dW2, db2, None
+        params = ctx.params
+
+        def job():
+            for j in jobs:
+                j()
+            _accumulate(params, (dW1, db1, dW2, db2))
+        _defer(job)
+        return dx, None, None, None, None, None, None
 
 
 def level_mlp(x: torch.Tensor, loc: torch.Tensor, seq: nn.Sequential, n_stat: int):
@@ -223,6 +333,17 @@ def anchor_mlp3_supported(mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequentia
     return keys == [(54, 50, 10, 1), (54, 50, 30, 2), (54, 50, 70, 0)]
 
 
+def _m3_wgrad_job(x, ldx, hcat, dz1, dz2_op, dz2_color, g_cov, dW1cat, db1cat, dW2, db2, n, ws, params, wgrads):
+    """The deferred weight-gradient launch of an anchor-MLP backward node (operands kept alive by the closure)."""
+    def job():
+        _lib.check(_lib.lib().cgs_anchor_mlp3_wgrad(
+            _lib.ptr(x), ldx, _lib.ptr(hcat), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), _lib.ptr(g_cov),
+            _lib.ptr(dW1cat), _lib.ptr(db1cat), _ptr_array(dW2), _ptr_array(db2), n, _lib.ptr(ws), ws.numel(),
+            _lib.current_stream()), "cgs_anchor_mlp3_wgrad")
+        _accumulate(params, wgrads)
+    return job
+
+
 class _AnchorMLP3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *params):
@@ -244,6 +365,7 @@ class _AnchorMLP3(torch.autograd.Function):
                                              _lib.ptr(hcat), n, _lib.current_stream()), "cgs_anchor_mlp3_forward")
         if need_grad:
             ctx.save_for_backward(x, y_op, y_color, hcat, *W1, *W2)
+        ctx.params = params
         return y_op, y_color, y_cov
 
     @staticmethod
@@ -266,15 +388,21 @@ class _AnchorMLP3(torch.autograd.Function):
         views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
+        defer = _can_defer(ctx.params) and n > 0
         _lib.check(L.cgs_anchor_mlp3_backward(
             _lib.ptr(x), x.shape[1], _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(g_op),
             _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(dx), x.shape[1], _lib.ptr(dz1), _lib.ptr(dz2_op),
-            _lib.ptr(dz2_color), _lib.ptr(dW1cat), _lib.ptr(db1cat), _ptr_array(dW2), _ptr_array(db2), n,
+            _lib.ptr(dz2_color), None if defer else _lib.ptr(dW1cat), None if defer else _lib.ptr(db1cat),
+            None if defer else _ptr_array(dW2), None if defer else _ptr_array(db2), n,
             _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward")
-        grads = [dx]
+        wgrads = []
         for i in range(3):
-            grads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
-        return tuple(grads)
+            wgrads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
+        if not defer:
+            return (dx, *wgrads)
+        _defer(_m3_wgrad_job(x, x.shape[1], hcat, dz1, dz2_op, dz2_color, g_cov, dW1cat, db1cat, dW2, db2, n, ws, ctx.params,
+                             wgrads))
+        return (dx,) + (None,) * 12
 
 
 class _AnchorMLP3Rows(torch.autograd.Function):
@@ -308,6 +436,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(x, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
             ctx.n_src = int(feat_src.shape[0])
+        ctx.params = params
         return y_op, y_color, y_cov
 
     @staticmethod
@@ -331,16 +460,22 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
+        defer = _can_defer(ctx.params) and n > 0
         _lib.check(L.cgs_anchor_mlp3_backward_rows(
             _lib.ptr(x), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam), _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op),
             _lib.ptr(y_color), _lib.ptr(g_op), _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(d_src),
-            _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), _lib.ptr(dW1cat), _lib.ptr(db1cat),
-            _ptr_array(dW2), _ptr_array(db2), n, _lib.ptr(ws), ws.numel(), _lib.current_stream()),
-            "cgs_anchor_mlp3_backward_rows")
+            _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), None if defer else _lib.ptr(dW1cat),
+            None if defer else _lib.ptr(db1cat), None if defer else _ptr_array(dW2), None if defer else _ptr_array(db2), n,
+            _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward_rows")
         grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None]
+        wgrads = []
         for i in range(3):
-            grads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
-        return tuple(grads)
+            wgrads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
+        if not defer:
+            return tuple(grads + wgrads)
+        _defer(_m3_wgrad_job(x, x.shape[1], hcat, dz1, dz2_op, dz2_color, g_cov, dW1cat, db1cat, dW2, db2, n, ws, ctx.params,
+                             wgrads))
+        return tuple(grads) + (None,) * 12
 
 
 def anchor_mlp3_rows(feat_src, src_row, anchor_vis, cam_center, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):

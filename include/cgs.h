@@ -253,7 +253,10 @@ int cgs_mlp2_forward(int in, int hid, int out, int act, const float *X,
  * H == NULL (forward called with H == NULL; instances for {71,15} -> 100 -> 3, act 0): the
  * hidden layer is recomputed from X, W1, b1 instead of being stored and re-read, and the
  * second layer's weight gradient is accumulated inside the same kernel; needs scratch.
- * b1 is only read in that mode. */
+ * b1 is only read in that mode.
+ * dW1 == NULL (then db1 == NULL too, and dW2 == db2 == NULL unless H == NULL): data gradients only — the
+ * weight-gradient products are left to a later cgs_mlp2_wgrad on the dZ1 / dZ2 this call wrote (a data-parallel
+ * step launches them behind the per-anchor gradient all-reduces, contextgs_amd/mlp.py defer_weight_gradients). */
 size_t cgs_mlp_wgrad_scratch_bytes(void);
 int cgs_mlp2_backward(int in, int hid, int out, int act, const float *X,
                       int64_t ldx, const float *W1, const float *b1, const float *W2,
@@ -271,6 +274,13 @@ int cgs_mlp2_backward_rows(int in, int hid, int out, int act, const float *X, in
                            int accumulate_dx, const int64_t *dx_rows, float *dZ1, float *dZ2,
                            float *dW1, float *db1, float *dW2, float *db2, int64_t n,
                            void *scratch, size_t scratch_bytes, void *stream);
+/* The weight-gradient products of cgs_mlp2_backward on their own: dW1 += dZ1^T X, db1 += sum_rows dZ1 and, when
+ * H != NULL, dW2 += dZ2^T H, db2 += sum_rows dZ2 (dZ2 [n, lddz2] = the backward's dZ2, or dY itself for act == 0).
+ * H == NULL: the recomputing backward has accumulated the second layer already.  scratch as above. */
+int cgs_mlp2_wgrad(int in, int hid, int out, const float *X, int64_t ldx, const float *H,
+                   const float *dZ2, int64_t lddz2, const float *dZ1, float *dW1, float *db1,
+                   float *dW2, float *db2, int64_t n, void *scratch, size_t scratch_bytes,
+                   void *stream);
 
 /* ---- fused element-wise stages of the per-level context model (training path) ----
  * Reference: scene/gaussian_model.py:1556-1707 (multi_scale_generating).
@@ -465,6 +475,14 @@ int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_row, const 
                                   float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
                                   float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
                                   void *stream);
+/* cgs_anchor_mlp3_backward / _backward_rows with dW1cat == db1cat == dW2 == db2 == NULL write the data gradients
+ * only; this is the weight-gradient launch they leave out, on the buffers they wrote (X: the backward's X, ldx = 54 —
+ * or the forward's X_out with ldx = cgs_anchor_mlp3_layout()[1] for the _rows pair; dY_cov: the covariance head's
+ * incoming gradient).  All gradients are ACCUMULATED into. */
+int cgs_anchor_mlp3_wgrad(const float *X, int64_t ldx, const float *Hcat, const float *dZ1cat,
+                          const float *dZ2_op, const float *dZ2_color, const float *dY_cov,
+                          float *dW1cat, float *db1cat, float *const *dW2, float *const *db2,
+                          int64_t n, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
  * scene/gaussian_model.py:1556; compressai is not in the mount, the density is

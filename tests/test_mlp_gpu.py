@@ -149,3 +149,80 @@ def test_anchor_mlp3_rows_equals_the_materialised_input():
     unread = torch.ones(n_src, dtype=torch.bool, device=dev)
     unread[src_row] = False
     assert float(got[0][unread].abs().sum()) == 0.0
+
+
+def _mlp_zoo_grads(defer, twice=False):
+    """Every MLP node of the path in one graph (plain, recomputing, level node, fused anchor MLPs both ways); returns the
+    gradients of all parameters and inputs with the weight gradients launched inline or at the end of the backward."""
+    from contextgs_amd import mlp
+    torch.manual_seed(11)
+    dev = "cuda"
+    grid = _seq(71, 100, 175, None)
+    small = _seq(15, 100, 3, None)
+    mo, mc, mv = _seq(54, 50, 10, nn.Tanh), _seq(54, 50, 30, nn.Sigmoid), _seq(54, 50, 70, None)
+    n = 4099
+    x71 = torch.randn(n, 71, device=dev, requires_grad=True)
+    x15 = torch.randn(n, 15, device=dev, requires_grad=True)
+    x54 = torch.randn(n, 54, device=dev, requires_grad=True)
+    loc = torch.randperm(n, device=dev)[:700].sort().values
+    feat_src = torch.randn(n + 50, 50, device=dev, requires_grad=True)
+    src_row = torch.randperm(n + 50, device=dev)[:n].contiguous()
+    anchor = (torch.randn(n, 3, device=dev) * 2).requires_grad_(True)
+    cam = torch.tensor([0.3, -3.0, 0.5], device=dev)
+    prev = mlp.defer_weight_gradients(defer)
+    try:
+        for _ in range(2 if twice else 1):       # the second pass ACCUMULATES into .grad
+            qadj, pred = mlp.level_mlp(x71, loc, grid, 172)
+            outs = [qadj, pred, mlp.mlp2(x15, small), mlp.mlp2(x71, grid), *mlp.anchor_mlp3(x54, mo, mc, mv),
+                    *mlp.anchor_mlp3_rows(feat_src, src_row, anchor, cam, mo, mc, mv)]
+            g = torch.Generator(device=dev).manual_seed(5)
+            sum((o * torch.randn(o.shape, device=dev, generator=g)).sum() for o in outs).backward()
+            assert not mlp._Deferred.queue and not mlp._Deferred.armed
+    finally:
+        mlp.defer_weight_gradients(prev)
+    params = [p for s in (grid, small, mo, mc, mv) for p in s.parameters()]
+    return [t.grad for t in params + [x71, x15, x54, feat_src, anchor]]
+
+
+@pytest.mark.parametrize("twice", [False, True])
+def test_deferred_weight_gradients_are_the_inline_ones(twice):
+    """mlp.defer_weight_gradients (what dist.GradientSync switches on for world > 1): the data-only backward entry points +
+    cgs_mlp2_wgrad / cgs_anchor_mlp3_wgrad from the autograd engine's end-of-backward callback leave bit-identical .grad on
+    every parameter and input, including a second backward that accumulates."""
+    a, b = _mlp_zoo_grads(False, twice), _mlp_zoo_grads(True, twice)
+    assert len(a) == len(b) and all(t is not None for t in a + b)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
+
+
+def test_deferral_leaves_non_leaf_weights_to_autograd_and_runs_the_hooks():
+    from contextgs_amd import mlp
+    torch.manual_seed(2)
+    seq = _seq(71, 100, 175, None)
+    x = torch.randn(300, 71, device="cuda")
+    scale = torch.ones((), device="cuda", requires_grad=True)
+    calls = []
+    hook = mlp.add_before_flush_hook(lambda: calls.append(1))
+    prev = mlp.defer_weight_gradients(True)
+    try:
+        # weights that are functions of another leaf: their gradient must travel through autograd, not into .grad
+        y = mlp.mlp2_weights(x, seq[0].weight * scale, seq[0].bias, seq[2].weight, seq[2].bias, 0)
+        y.sum().backward()
+        assert scale.grad is not None and seq[2].weight.grad is not None and calls == []
+        seq.zero_grad()
+        mlp.mlp2(x, seq).sum().backward()                     # leaf weights: deferred, the hook runs before the launches
+        assert calls == [1] and all(p.grad is not None for p in seq.parameters())
+    finally:
+        mlp.defer_weight_gradients(prev)
+        mlp.remove_before_flush_hook(hook)
+
+
+def test_data_only_backward_rejects_a_partial_pointer_set():
+    from contextgs_amd import _lib
+    L = _lib.lib()
+    n = 64
+    t = lambda *s: torch.zeros(*s, device="cuda")
+    x, W1, W2, dy, h, dz1, dW2 = t(n, 71), t(100, 71), t(175, 100), t(n, 175), t(n, 100), t(n, 100), t(175, 100)
+    rc = L.cgs_mlp2_backward(71, 100, 175, 0, _lib.ptr(x), 71, _lib.ptr(W1), None, _lib.ptr(W2), None, _lib.ptr(dy), 175, _lib.ptr(h),
+                             None, 71, 0, _lib.ptr(dz1), None, None, None, _lib.ptr(dW2), None, n, None, 0, _lib.current_stream())
+    assert rc != 0
