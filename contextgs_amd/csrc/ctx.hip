@@ -9,6 +9,7 @@
 //   level_rate    sum of the discretised-Gaussian bits of the chosen rows (:1658-1669 + utils/entropy_models.py:30-50)
 //
 // All three are pure streaming kernels: their roofline is HBM bytes (rows x widths x 4 B).
+#include <initializer_list>
 #include "cgs_internal.h"
 #include "rate_math.h"
 
@@ -217,6 +218,9 @@ __device__ __forceinline__ float ctx_noise(uint64_t seed, uint32_t tensor, uint6
 
 __device__ __forceinline__ float ctx_step(float q0, float qadj) { return fmaxf(q0 * (1.f + tanhf(qadj)), 1e-9f); }
 
+#ifndef NQ_VEC2
+#define NQ_VEC2 1         // float2 forms of the noise_quant kernels (tools/variant_lib.sh ... -DNQ_VEC2=0 for the A/B)
+#endif
 #define CTX_SUM_SLOTS 64
 #define CTX_SUM_STRIDE 16        // doubles: one 128-byte line per slot
 
@@ -249,6 +253,50 @@ __global__ void __launch_bounds__(256)
         for (int c = l; c < O; c += 16) { const float v = xo[sr * O + c]; po += v; yo[r * O + c] = v + ctx_noise_k(ko, (uint64_t)r * O + c) * qo; }
     }
     if (sums) {        // one atomic per block and quantity, spread over CTX_SUM_SLOTS cache lines (same-address atomics serialise)
+        __shared__ double part[4][3];
+        const double a = ctx_wave_sum((double)pf), b = ctx_wave_sum((double)ps), c = ctx_wave_sum((double)po);
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int k = threadIdx.x;
+            atomicAdd(&sums[(blockIdx.x % CTX_SUM_SLOTS) * CTX_SUM_STRIDE + k], part[0][k] + part[1][k] + part[2][k] + part[3][k]);
+        }
+    }
+}
+
+// The same with 8-byte accesses (even D, S, O with D <= 64, S <= 32, O <= 32 — the reference's 50 / 6 / 30 — and 8-byte
+// aligned bases): a lane moves float2 pairs, 4 loads + 4 stores per row pass instead of 7 + 7, all loads issued before the
+// first store.  Same element -> noise mapping, so the same bits as the scalar kernel.
+__global__ void __launch_bounds__(256)
+    noise_quant_fwd2_kernel(const float *__restrict__ xf, const float *__restrict__ xs, const float *__restrict__ xo,
+                            const float *__restrict__ qadj, const int64_t *__restrict__ rows, int64_t n, int D, int S,
+                            int O, uint64_t seed, float q0f, float q0s, float q0o, float *__restrict__ yf,
+                            float *__restrict__ ys, float *__restrict__ yo, float *__restrict__ Q,
+                            double *__restrict__ sums) {
+    const int l = threadIdx.x & 15;
+    const int D2 = D >> 1, S2 = S >> 1, O2 = O >> 1;
+    const uint32_t kf = ctx_noise_key(seed, 0), ks = ctx_noise_key(seed, 1), ko = ctx_noise_key(seed, 2);
+    float pf = 0.f, ps = 0.f, po = 0.f;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
+        const int64_t sr = rows ? rows[r] : r;        // source row: the level's slice of the coding-order permutation
+        const float2 *sf = (const float2 *)(xf + sr * D), *ss = (const float2 *)(xs + sr * S), *so = (const float2 *)(xo + sr * O);
+        const bool f1 = l + 16 < D2, hs = l < S2, ho = l < O2;
+        const float2 z = make_float2(0.f, 0.f);
+        const float2 a0 = l < D2 ? sf[l] : z, a1 = f1 ? sf[l + 16] : z, b = hs ? ss[l] : z, c = ho ? so[l] : z;
+        const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
+                    qo = ctx_step(q0o, qadj[r * 3 + 2]);
+        if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);
+        pf += (a0.x + a0.y) + (a1.x + a1.y);
+        ps += b.x + b.y;
+        po += c.x + c.y;
+        const uint64_t ef = (uint64_t)r * D + 2 * l, es = (uint64_t)r * S + 2 * l, eo = (uint64_t)r * O + 2 * l;
+        float2 *df = (float2 *)(yf + r * D), *ds = (float2 *)(ys + r * S), *dd = (float2 *)(yo + r * O);
+        if (l < D2) df[l] = make_float2(a0.x + ctx_noise_k(kf, ef) * qf, a0.y + ctx_noise_k(kf, ef + 1) * qf);
+        if (f1) df[l + 16] = make_float2(a1.x + ctx_noise_k(kf, ef + 32) * qf, a1.y + ctx_noise_k(kf, ef + 33) * qf);
+        if (hs) ds[l] = make_float2(b.x + ctx_noise_k(ks, es) * qs, b.y + ctx_noise_k(ks, es + 1) * qs);
+        if (ho) dd[l] = make_float2(c.x + ctx_noise_k(ko, eo) * qo, c.y + ctx_noise_k(ko, eo + 1) * qo);
+    }
+    if (sums) {
         __shared__ double part[4][3];
         const double a = ctx_wave_sum((double)pf), b = ctx_wave_sum((double)ps), c = ctx_wave_sum((double)po);
         if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
@@ -362,6 +410,13 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+static bool nq_vec2_ok(int D, int S, int O, std::initializer_list<const void *> ptrs) {
+    if ((D | S | O) & 1 || D > 64 || S > 32 || O > 32) return false;
+    for (const void *p : ptrs)
+        if ((uintptr_t)p & 7) return false;
+    return true;
+}
+
 extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo, const float *qadj,
                                    const int64_t *rows, int64_t n, int D, int S, int O, uint64_t seed, float q0f,
                                    float q0s, float q0o, float *yf, float *ys, float *yo, float *Q, double *sums3,
@@ -370,8 +425,12 @@ extern "C" int cgs_noise_quant_fwd(const float *xf, const float *xs, const float
     if (n == 0) return CGS_OK;
     if (!xf || !xs || !xo || !qadj || !yf || !ys || !yo || !Q) { cgs_set_error("noise_quant_fwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(noise_quant_fwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
-                       xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q, sums3);
+    if (NQ_VEC2 && nq_vec2_ok(D, S, O, {xf, xs, xo, yf, ys, yo}))
+        hipLaunchKernelGGL(noise_quant_fwd2_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
+                           xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q, sums3);
+    else
+        hipLaunchKernelGGL(noise_quant_fwd_kernel, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, xf, xs,
+                           xo, qadj, rows, n, D, S, O, seed, q0f, q0s, q0o, yf, ys, yo, Q, sums3);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -387,6 +446,7 @@ extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const flo
     if (rows && (!dxf || !dxs || !dxo)) { cgs_set_error("noise_quant_bwd: rows without dxf/dxs/dxo"); return CGS_ERR_ARG; }
     if (side_map && (!rows || !side_f || !side_s || !side_o || !side_Q)) { cgs_set_error("noise_quant_bwd: side_map needs rows and the four side arrays"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    // (a float2 form of this kernel, like noise_quant_fwd2_kernel, measured 7 % SLOWER: 96 -> 104 us per launch)
     if (D <= 64 && S <= 16 && O <= 32)
         hipLaunchKernelGGL(noise_quant_bwd_kernel<true>, dim3(stream_grid(n * 16, 256 * 4)), dim3(256), 0, (hipStream_t)stream, dyf,
                            dys, dyo, dQ_ext, qadj, n, D, S, O, seed, q0f, q0s, q0o, dqadj, rows, dxf, dxs, dxo, side_map, side_f, side_s, side_o, side_Q);
