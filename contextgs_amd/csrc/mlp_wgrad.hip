@@ -28,25 +28,31 @@ struct WgStream {
     int col4;           // this lane's first column, in bytes
     bool m[4];          // column col0 + j < dim  (a 16-byte access that crosses the row end picks up the next row)
     bool partial;       // wave-uniform: this 64-feature group crosses the row end
+    bool narrow;        // wave-uniform: the group holds <= 16 features — lane c carries feature 64 group + c alone (ONE tile)
 };
 
 __device__ __forceinline__ WgStream wg_stream(const float *base, int64_t ld, int dim, int group, int c, int64_t r_begin,
-                                              int64_t r_end) {
+                                              int64_t r_end, bool narrow = false) {
     WgStream st;
+    st.narrow = narrow;
     const float *p = base + r_begin * ld;
     const int64_t rows = r_end - r_begin;
     const uint32_t bytes = rows > 0 ? (uint32_t)(((rows - 1) * ld + dim) * 4) : 0u;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
     st.ld4 = (int)ld * 4;
-    const int col0 = 64 * group + 4 * c;
+    const int col0 = narrow ? 64 * group + c : 64 * group + 4 * c;
     st.col4 = col0 * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st.m[j] = col0 + j < dim;
-    st.partial = 64 * group + 63 >= dim;
+    for (int j = 0; j < 4; ++j) st.m[j] = (!narrow || j == 0) && col0 + j < dim;
+    st.partial = narrow || 64 * group + 63 >= dim;
     return st;
 }
 
 __device__ __forceinline__ f32x4 wg_load4(const WgStream &st, int rel_row) {
+    if (st.narrow) {      // one feature per lane: a 4-byte access (components 1..3 are masked off at consume time)
+        const int raw = __builtin_amdgcn_raw_buffer_load_b32(st.rsrc, rel_row * st.ld4 + st.col4, 0, 0);
+        return (f32x4){__builtin_bit_cast(float, raw), 0.f, 0.f, 0.f};
+    }
     const i32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(st.rsrc, rel_row * st.ld4 + st.col4, 0, 0);
     return __builtin_bit_cast(f32x4, raw);
 }
@@ -80,10 +86,16 @@ __device__ __forceinline__ void wg_consume(const WgFrag<UNR> &f, const WgStream 
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
         const f32x4 a = wg_mask(sa, f.a[q]), b = wg_mask(sb, f.b[q]);
+        // a narrow operand fills tile index 0 only: 4 (or 1) MFMAs instead of 16 for a <= 16-feature group
 #pragma unroll
-        for (int ja = 0; ja < 4; ++ja)
+        for (int ja = 0; ja < 4; ++ja) {
+            if (ja > 0 && sa.narrow) break;
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = frag_mfma(a[ja], b[jb], acc[ja][jb]);
+            for (int jb = 0; jb < 4; ++jb) {
+                if (jb > 0 && sb.narrow) break;
+                acc[ja][jb] = frag_mfma(a[ja], b[jb], acc[ja][jb]);
+            }
+        }
         bsum += a;
     }
 }
@@ -268,12 +280,16 @@ int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64
 // group of Q) pair of every product is a task for one wave, all waves of a workgroup walk the same row range, so a
 // row's cache lines (e.g. the three 200-byte slices of an Hcat row) are pulled from HBM once, and 2-4 launches +
 // reductions become one of each.  Same inner loop and LDS-image / two-pass reduction as wgrad4_kernel.
+#ifndef WGM_NARROW
+#define WGM_NARROW 1         // one-tile tasks for <= 16-feature groups (tools/variant_lib.sh ... -DWGM_NARROW=0 for the A/B)
+#endif
 #define WGM_MAX_TASKS 16
 #define WGM_MAX_PROD 4
 #define WGM_MAX_E 25000      // floats of LDS image: 175x100+175 + 100x71+100 (both layers of mlp_grid) = 24875
 struct WgmTask {
     const float *P, *Q;
     int ldp, ldq, DA, DB, ga, gb, img_off;
+    int narrow;          // bit 0: the P group holds <= 16 features, bit 1: the Q group does
 };
 struct WgmArgs {
     WgmTask t[WGM_MAX_TASKS];
@@ -292,27 +308,33 @@ __global__ void __launch_bounds__(1024)
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < a.E; i += 1024) img[i] = 0.f;
+    // wave -> (task, sub-range): wave % ntask, so that a SIMD (waves go to the four SIMDs round-robin) hosts the sub-waves
+    // of few tasks — task k in waves k*nsub .. k*nsub + nsub - 1 measured 2-20 % slower.  Every task has the same number of
+    // waves: all waves of the workgroup move through the row range at the same pace, which is what lets the tasks that
+    // read the same rows share them through the caches.  (Scalar copies: dynamic indexing of the by-value argument
+    // struct would go through scratch.)
     const int ti = wave % a.ntask, sub = wave / a.ntask;
-    // scalar copies of the task (dynamic indexing of the by-value argument struct)
+    const int nsub = sub < a.nsub ? a.nsub : 0;
     const float *P = nullptr, *Q = nullptr;
-    int ldp = 0, ldq = 0, DA = 0, DB = 0, ga = 0, gb = 0, img_off = 0;
+    int ldp = 0, ldq = 0, DA = 0, DB = 0, ga = 0, gb = 0, img_off = 0, narrow = 0;
 #pragma unroll
     for (int k = 0; k < WGM_MAX_TASKS; ++k)
         if (k == ti) {
             P = a.t[k].P; Q = a.t[k].Q; ldp = a.t[k].ldp; ldq = a.t[k].ldq; DA = a.t[k].DA; DB = a.t[k].DB;
-            ga = a.t[k].ga; gb = a.t[k].gb; img_off = a.t[k].img_off;
+            ga = a.t[k].ga; gb = a.t[k].gb; img_off = a.t[k].img_off; narrow = a.t[k].narrow;
         }
+    const bool nA = narrow & 1, nB = narrow & 2;
     f32x4 acc[4][4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (sub < a.nsub) {
+    if (nsub > 0) {
         const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
         const int64_t r_end = min(n, r_begin + rows_per_block);
-        const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end);
-        const WgStream sb = wg_stream(Q, ldq, DB, gb, c, r_begin, r_end);
-        const int rows = (int)(r_end - r_begin), stride = a.nsub * 4 * UNR;
+        const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end, nA);
+        const WgStream sb = wg_stream(Q, ldq, DB, gb, c, r_begin, r_end, nB);
+        const int rows = (int)(r_end - r_begin), stride = nsub * 4 * UNR;
         int row0 = sub * 4 * UNR;
         WgFrag<UNR> f0, f1;
         wg_fetch<UNR>(f0, sa, sb, row0, g);
@@ -331,30 +353,36 @@ __global__ void __launch_bounds__(1024)
     // Image update without LDS float atomics (ds_add_f32 retires ~0.6 lanes per clock on gfx950: 16 waves x 68 wave-wide
     // atomics were a fixed ~40 us of every launch): tasks own disjoint parts of the image, and the nsub waves of one task
     // take turns, separated by workgroup barriers, with plain read-add-write.
-    for (int s = 0; s < a.nsub; ++s) {
-        if (sub == s) {
+    for (int s = 0; s < a.nsub; ++s) {            // a.nsub = the largest wave count of a task
+        if (nsub > 0 && sub == s) {
             float *const outW = img + img_off;
             float *const outb = outW + DA * DB;
-            const int acol0 = 64 * ga + 4 * c, bcol0 = 64 * gb + 4 * c;
+            // D layout of tile (ja, jb): reg r of lane (g, c) <-> P feature 64 ga + 4 (4g + r) + ja (narrow: 64 ga + 4g + r,
+            // ja = 0 only), Q feature 64 gb + 4c + jb (narrow: 64 gb + c, jb = 0 only)
 #pragma unroll
-            for (int ja = 0; ja < 4; ++ja)
+            for (int ja = 0; ja < 4; ++ja) {
+                if (ja > 0 && nA) break;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ar = 64 * ga + 4 * (4 * g + r) + ja;
+                    const int ar = nA ? 64 * ga + 4 * g + r : 64 * ga + 4 * (4 * g + r) + ja;
                     if (ar >= DA) continue;
 #pragma unroll
                     for (int jb = 0; jb < 4; ++jb) {
-                        const int b = bcol0 + jb;
+                        if (jb > 0 && nB) break;
+                        const int b = nB ? 64 * gb + c : 64 * gb + 4 * c + jb;
                         if (b < DB) outW[ar * DB + b] += acc[ja][jb][r];
                     }
                 }
+            }
             if (gb == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (j > 0 && nA) break;
                     float v = bsum[j];
                     v += __shfl_xor(v, 16);
                     v += __shfl_xor(v, 32);
-                    if (g == 0 && acol0 + j < DA) outb[acol0 + j] += v;
+                    const int ac = nA ? 64 * ga + c : 64 * ga + 4 * c + j;
+                    if (g == 0 && ac < DA) outb[ac] += v;
                 }
             }
         }
@@ -420,7 +448,8 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
         for (int ga = 0; ga < GA && fits; ++ga)
             for (int gb = 0; gb < GB; ++gb) {
                 if (ntask >= WGM_MAX_TASKS) { fits = false; break; }
-                a.t[ntask++] = WgmTask{p.P, p.Q, (int)p.ldp, (int)p.ldq, p.DA, p.DB, ga, gb, E};
+                const int narrow = (WGM_NARROW && p.DA - 64 * ga <= 16 ? 1 : 0) | (WGM_NARROW && p.DB - 64 * gb <= 16 ? 2 : 0);
+                a.t[ntask++] = WgmTask{p.P, p.Q, (int)p.ldp, (int)p.ldq, p.DA, p.DB, ga, gb, E, narrow};
             }
         E += p.DA * p.DB + p.DA;
     }
@@ -434,13 +463,23 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
         }
         return CGS_OK;
     }
-    for (int k = ntask; k < WGM_MAX_TASKS; ++k) a.t[k] = WgmTask{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = ntask; k < WGM_MAX_TASKS; ++k) a.t[k] = WgmTask{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+    // One-tile (narrow) tasks only when EVERY task of the launch is narrow in the same way: the tasks of a workgroup share
+    // their rows through the caches because all waves move through the row range at the same pace; tasks of unequal
+    // weight lose that (measured: a narrow minority racing ahead, or wave counts in proportion to the work, made the
+    // mixed launches 10-40 % SLOWER), while a launch of equal narrow tasks (mlp_grid[0]'s 100 x 15 product) halves.
+    {
+        bool uniform = ntask > 0;
+        for (int k = 1; k < ntask; ++k) uniform = uniform && a.t[k].narrow == a.t[0].narrow;
+        for (int k = 0; k < ntask; ++k)
+            if (!uniform) a.t[k].narrow = 0;
+        a.nsub = 16 / ntask;
+    }
     for (int k = nprod; k < WGM_MAX_PROD; ++k) { pr.dW[k] = nullptr; pr.db[k] = nullptr; pr.off[k] = E; pr.dadb[k] = 0; }
     pr.off[WGM_MAX_PROD] = E;
     pr.nprod = nprod;
     constexpr int UNR = 2;
     a.ntask = ntask;
-    a.nsub = 16 / ntask;
     a.E = E;
     int64_t blocks = (n + 255) / 256;
     int64_t cap = num_cus;

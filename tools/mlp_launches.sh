@@ -8,7 +8,7 @@ python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/prof_mlp/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", ""))) for r in csv.DictReader(open(f))))
-starts = [i for i, r in enumerate(rows) if "preprocess_kernel<true>" in r[2]]
+starts = [i for i, r in enumerate(rows) if "filter_voxel_kernel" in r[2]]
 a, b = starts[-2], starts[-1]
 with open("gpurun_out/mlp_launches.txt", "w") as o:
     for s, e, n, g, w in rows[a:b]:
