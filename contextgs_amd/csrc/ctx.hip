@@ -525,6 +525,9 @@ extern "C" int cgs_noise_quant_bwd(const float *dyf, const float *dys, const flo
 //   e <  D + 6    scaling  x = ys[r,e-D]      mean = pred[s, 2D + .]        scale = pred[s, 2D + 6 + .]     q = Q[r,1]
 //   else          offsets  x = yo[r,.]        mean = pred[s, 2D + 12 + .]   scale = pred[s, 2D + 12 + 3K + .] q = Q[r,2]
 //                 weighted by masks[grows[s], ./3]   (binary_grid_masks.repeat(1,1,3), :1664)
+#ifndef RATE_LANES
+#define RATE_LANES 32        // lanes per chosen row in level_rate_* (64 = round 2's wave per row; -DRATE_LANES=64 for the A/B)
+#endif
 struct RateElem { float x, mean, scale, q, w, xm; int kind, mcol, scol; int64_t xoff, moff; };
 
 __device__ __forceinline__ RateElem rate_elem(int e, int64_t s, int64_t r, int64_t grow, int D, int K, int64_t ldp,
@@ -565,9 +568,13 @@ __global__ void __launch_bounds__(256)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = D + 6 + 3 * K;
     float acc[3] = {0.f, 0.f, 0.f};
-    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
+    // HALF a wave per row: the reference's 86 elements are three passes of 32 lanes (90 % of the lanes busy) where a
+    // whole wave needed two passes of 64 (67 %) — the kernel is bound by the erf / log arithmetic, not by its loads
+    const int l = lane & (RATE_LANES - 1);
+    for (int64_t s = ((int64_t)blockIdx.x * 4 + wave) * (64 / RATE_LANES) + lane / RATE_LANES; s < n_sub;
+         s += (int64_t)gridDim.x * 4 * (64 / RATE_LANES)) {
         const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : s;
-        for (int e = lane; e < E; e += 64) {
+        for (int e = l; e < E; e += RATE_LANES) {
             const RateElem t = rate_elem(e, s, r, grow, D, K, ldp, yf, ys, yo, Q, pred, masks, x_means);
             const float b = rate_bits(rate_terms(t.x, t.mean, t.scale, t.q, t.xm, use_clamp)) * t.w;
             acc[0] += t.kind == 0 ? b : 0.f;
@@ -598,12 +605,14 @@ __global__ void __launch_bounds__(256)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = D + 6 + 3 * K, P = 2 * E;
     const float g0 = g_sums[0], g1 = g_sums[1], g2 = g_sums[2];
-    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n_sub; s += (int64_t)gridDim.x * 4) {
+    const int l = lane & (RATE_LANES - 1);          // half a wave per row, as in the forward
+    for (int64_t s = ((int64_t)blockIdx.x * 4 + wave) * (64 / RATE_LANES) + lane / RATE_LANES; s < n_sub;
+         s += (int64_t)gridDim.x * 4 * (64 / RATE_LANES)) {
         const int64_t r = loc ? loc[s] : s, grow = grows ? grows[s] : s;
         const int64_t ro = compact ? s : r;         // output row of d_yf / d_ys / d_yo / dQ
         float gq[3] = {0.f, 0.f, 0.f};
-        if (lane < ldp - P) d_pred[s * ldp + P + lane] = 0.f;   // outputs beyond the mean/scale block (the step sizes)
-        for (int e = lane; e < E; e += 64) {
+        for (int c = l; c < ldp - P; c += RATE_LANES) d_pred[s * ldp + P + c] = 0.f;   // outputs beyond the mean/scale block (the step sizes)
+        for (int e = l; e < E; e += RATE_LANES) {
             const RateElem t = rate_elem(e, s, r, grow, D, K, ldp, yf, ys, yo, Q, pred, masks, x_means);
             const RateTerms rt = rate_terms(t.x, t.mean, t.scale, t.q, t.xm, use_clamp);
             const float gb = (t.kind == 0 ? g0 : (t.kind == 1 ? g1 : g2)) * t.w;
@@ -620,8 +629,10 @@ __global__ void __launch_bounds__(256)
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float v = wave_sum(gq[k]);
-            if (lane == 0) dQ[ro * 3 + k] = v;
+            float v = gq[k];
+#pragma unroll
+            for (int o = RATE_LANES / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (l == 0) dQ[ro * 3 + k] = v;
         }
     }
 }
