@@ -68,13 +68,16 @@ __global__ void __launch_bounds__(CP_THREADS)
         else f = (float)(cp_mix32((uint32_t)a + key + (uint32_t)((uint64_t)a >> 32) * 0x632BE5ABu) >> 8) * (1.0f / 16777216.0f) <= thresh;
         f = f && live;
         flags[r] = f ? 1 : 0;
+        // the staleness test and the live count are sums over ALL anchors: taken over anchor r instead of perm[r], so
+        // that the two [n,3] tensors and the reference mask stream in order instead of being gathered through perm
         bool stale = false;
         if (anchor_ref)
-            stale = anchor[3 * a] != anchor_ref[3 * a] || anchor[3 * a + 1] != anchor_ref[3 * a + 1] ||
-                    anchor[3 * a + 2] != anchor_ref[3 * a + 2];
-        if (mask_ref) stale = stale || ((mask[a] != 0) != (mask_ref[a] != 0));
+            stale = anchor[3 * r] != anchor_ref[3 * r] || anchor[3 * r + 1] != anchor_ref[3 * r + 1] ||
+                    anchor[3 * r + 2] != anchor_ref[3 * r + 2];
+        const bool live_r = mask ? mask[r] != 0 : true;
+        if (mask_ref) stale = stale || (live_r != (mask_ref[r] != 0));
         mine += f ? 1u : 0u;
-        live_n += live ? 1u : 0u;
+        live_n += live_r ? 1u : 0u;
         stale_n += stale ? 1u : 0u;
         const int lvl = cp_level(B, r);
 #pragma unroll

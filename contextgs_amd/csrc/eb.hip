@@ -262,6 +262,28 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// the same with 16-byte accesses (C a multiple of 4, 16-byte aligned bases, n * C / 4 < 2^32)
+__global__ void __launch_bounds__(256)
+    hyper_noise_gather4_kernel(const float *__restrict__ hyper, const int64_t *__restrict__ perm, int64_t n, int C,
+                               uint32_t key, float *__restrict__ out) {
+    const uint32_t C4 = (uint32_t)C >> 2, total = (uint32_t)(n * C4);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const uint32_t r = i / C4, c4 = i - r * C4;
+        const uint64_t e = (uint64_t)(perm ? perm[r] : (int64_t)r) * (uint64_t)C + 4 * c4;
+        float4 v = *(const float4 *)(hyper + e);
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t ek = e + k;
+            uint32_t h = (uint32_t)ek + key + (uint32_t)(ek >> 32) * 0x632BE5ABu;
+            h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+            u[k] = (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+        }
+        v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
+        ((float4 *)out)[i] = v;
+    }
+}
+
 static uint32_t eb_noise_key(uint64_t seed, uint32_t tensor) {     // == ctx_noise_key of csrc/ctx.hip
     uint32_t x = (uint32_t)seed ^ (0x9E3779B9u * (tensor + 1u));
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -276,8 +298,12 @@ extern "C" int cgs_hyper_noise_gather(const float *hyper, const int64_t *perm, i
     int64_t blocks = (n * C + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(hyper_noise_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hyper, perm, n, C,
-                       eb_noise_key(seed, 3), out);
+    if (!(C & 3) && !(((uintptr_t)hyper | (uintptr_t)out) & 15) && n * (C / 4) < (int64_t)0xFFFF0000)
+        hipLaunchKernelGGL(hyper_noise_gather4_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, hyper,
+                           perm, n, C, eb_noise_key(seed, 3), out);
+    else
+        hipLaunchKernelGGL(hyper_noise_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hyper, perm, n, C,
+                           eb_noise_key(seed, 3), out);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
