@@ -254,7 +254,15 @@ def begin_step(pc, anchor, mask_anchor_bool, predict_bpp):
     packed = None
     if isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3) and not pc.disable_hyper:
         packed = pc.latent_codec._packed_params()      # a cat launch the step needs anyway: queued before the read-back
-    return dict(handle=h, cache=cache, seed=seed, given=given, anchor=anchor, mask=mask_anchor_bool, packed=packed)
+    hyper_pre = None
+    hl = getattr(pc, "_hyper_latent", None)
+    if (packed is not None and FUSED_TRAINING and hl is not None and hl.is_cuda and hl.dtype == torch.float32 and hl.dim() == 2
+            and hl.is_contiguous() and hl.shape[0] == a["n"]):
+        # the noisy hyper latents in coding order depend on the plan only, not on the rate subset: launched here, in front
+        # of the read-back, instead of behind it where the GPU would wait for the host to issue them (a 30 us gap)
+        hyper_pre = pc.latent_codec.noisy_latents_launch(hl, None if cache.get("identity") else cache["perm"], _ctx.next_seed())
+    return dict(handle=h, cache=cache, seed=seed, given=given, anchor=anchor, mask=mask_anchor_bool, packed=packed,
+                hyper_pre=hyper_pre)
 
 
 def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begun=None):
@@ -462,9 +470,13 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     eb_mine = isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3)
     if (FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine
             and not pc.disable_hyper and c.get("_nz") is not None and c["covers_all"] and hyper.dtype == torch.float32):
+        pre = begun.get("hyper_pre") if (begun is not None and begun.get("cache") is c) else None
+        if pre is not None and pre[0] is not hyper:
+            pre = None
         hyp_p, likelihood_hyper = pc.latent_codec.training_step_forms(
             hyper, None if c.get("identity") else perm, None if c.get("identity") else c["inv_perm"], c["_nz"],
-            _ctx.next_seed(), packed=begun.get("packed") if begun is not None else None)
+            pre[2] if pre is not None else _ctx.next_seed(), packed=begun.get("packed") if begun is not None else None,
+            noisy=pre[1] if pre is not None else None)
         hyper_feat = None
     elif FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine:
         rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(_as_mask(choose_mask))[:, 0]

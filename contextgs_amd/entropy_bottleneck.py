@@ -85,16 +85,20 @@ class _HyperStep(torch.autograd.Function):
     buffer that autograd then adds in full."""
 
     @staticmethod
-    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed):
+    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed, noisy=None):
         from . import _lib
         L = _lib.lib()
         x, packed = x.contiguous(), packed.contiguous()
         _lib.require_device(x, packed)
         N, C = x.shape
         stream = _lib.current_stream()
-        v = torch.empty_like(x)
-        _lib.check(L.cgs_hyper_noise_gather(_lib.ptr(x), _lib.ptr(perm), N, C, int(seed), _lib.ptr(v), stream),
-                   "cgs_hyper_noise_gather")
+        if noisy is not None:                 # launched earlier by noisy_latents_launch(x, perm, seed): same values
+            v = noisy
+            assert v.shape == x.shape and v.is_contiguous()
+        else:
+            v = torch.empty_like(x)
+            _lib.check(L.cgs_hyper_noise_gather(_lib.ptr(x), _lib.ptr(perm), N, C, int(seed), _lib.ptr(v), stream),
+                       "cgs_hyper_noise_gather")
         ws = _bits_ws.get(x.device)
         if ws is None:
             ws = _bits_ws[x.device] = torch.zeros(int(L.cgs_eb_bits_scratch_bytes()), dtype=torch.uint8, device=x.device)
@@ -126,11 +130,11 @@ class _HyperStep(torch.autograd.Function):
                 g_v = torch.zeros_like(v) if g_v is None else g_v.clone(memory_format=torch.contiguous_format)
                 g_v.index_add_(0, rows, g_sub)
         if g_v is None:
-            return None, None, None, None, g_p, None
+            return None, None, None, None, g_p, None, None
         # rows of 48 bytes: torch's index_select takes its slow "vectorized gather" path for 16-byte-multiple rows
         # (210 us for [1 M, 12] on gfx950); the one-source rowcat kernel does the same gather in ~35 us
         g_x = g_v if inv_perm is None else ctx_ops.gather_rows_nograd(g_v, inv_perm)
-        return g_x, None, None, None, g_p, None
+        return g_x, None, None, None, g_p, None, None
 
 
 class HyperBitSum:
@@ -320,14 +324,25 @@ class EntropyBottleneck(nn.Module):
         back = lambda t: t.reshape(self.channels, -1).t()
         return back(out), back(lik)
 
-    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int, packed=None):
+    def noisy_latents_launch(self, x: torch.Tensor, perm, seed: int):
+        """Enqueue x + U(-1/2, 1/2) in coding order (the first launch of training_step_forms) ahead of time; returns
+        (x, noisy, seed) to hand to training_step_forms(..., seed, noisy=noisy) of the same step."""
+        from . import _lib
+        assert x.is_cuda and x.dim() == 2 and x.shape[1] == self.channels and x.is_contiguous() and x.dtype == torch.float32
+        v = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_hyper_noise_gather(_lib.ptr(x.detach()), _lib.ptr(perm), x.shape[0], x.shape[1], int(seed),
+                                                     _lib.ptr(v), _lib.current_stream()), "cgs_hyper_noise_gather")
+        return x, v, int(seed)
+
+    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int, packed=None, noisy=None):
         """Training-step entry (extension): (noisy latents in coding order [N,C], HyperBitSum over the coding-order
         positions rows_pos) — forward(x, training=True) restricted to what scene/gaussian_model.py:1556-1707 consumes,
         in two launches.  perm / inv_perm: the coding-order permutation and its inverse (None: identity)."""
         assert x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 2 and x.shape[1] == self.channels
         # packed: self._packed_params() evaluated earlier by the caller (the renderer does it before a host read-back, so
         # that the GPU has the launch queued while the host waits)
-        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed)
+        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed,
+                                     noisy)
         n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
         return v_p, HyperBitSum(bits, n_rows * self.channels)
 
