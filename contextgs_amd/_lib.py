@@ -63,6 +63,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
+    "cgs_raster_preprocess_expand_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_int] + [c_void_p] * 9 + [c_int64, c_void_p,
+                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_stats": (c_int, [C.POINTER(RasterCfg), c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_scan_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_scan_exclusive_u32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

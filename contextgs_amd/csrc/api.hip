@@ -140,6 +140,7 @@ extern "C" int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const floa
 // (cgs_raster_render_spec) keeps the device busy while the host learns the count.  cgs_raster_preprocess = both.
 struct RasterCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
 static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false};
+static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream);
 
 extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
                                             const float *colors, const float *opacities, const float *scales,
@@ -169,6 +170,12 @@ extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P
     if ((rc = cgs_launch_preprocess(cfg, P, means3D, colors, opacities, scales, rotations, g, radii, false,
                                     stream)))
         return rc;
+    return raster_count_tail(P, g, sl, stream);
+}
+
+// depth sort, tile rectangles in depth order, pair-offset scan and the copy of the pair count behind a preprocess launch
+static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream) {
+    int rc;
     // depth order (stable: ties keep ascending Gaussian id)
     {
         CgsProfScope prof(CGS_PROF_DEPTH_SORT, stream);
@@ -189,6 +196,48 @@ extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P
     CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
     sl.pending = true;
     return CGS_OK;
+}
+
+// cgs_raster_preprocess_launch with the Gaussians taken straight from the anchor expansion (csrc/expand_raster.hip): slot i
+// of the n_anchor * K slots with flags[i] != 0 is Gaussian pos[i] (flags / pos / neural_opacity from cgs_expand_count_launch,
+// P = the count it returned); scaling_out [P,3] receives the Gaussians' scales (the one per-Gaussian tensor the training
+// loss reads), xyz_out [P,3] / rot_out [P,4] (both or neither) the positions and rotations for a later cgs_raster_backward.
+// Everything downstream (cgs_raster_render*, _wait, cgs_raster_backward + cgs_expand_backward) is unchanged.
+extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anchor, int K, const uint32_t *flags,
+                                                   const uint32_t *pos, const float *anchor, const float *gscaling,
+                                                   const float *offsets, const float *neural_opacity, const float *color_in,
+                                                   const float *cov_in, const int64_t *src_row, int64_t P, float *scaling_out,
+                                                   float *xyz_out, float *rot_out, void *geom_ws, size_t geom_bytes,
+                                                   int32_t *radii, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    RasterCountSlot &sl = g_raster_slot;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (P < 0 || P >= (1ll << 31) || n_anchor < 0 || K < 1 || n_anchor * (int64_t)K >= (1ll << 31) || P > n_anchor * (int64_t)K) {
+        cgs_set_error("cgs_raster_preprocess_expand: sizes out of range");
+        return CGS_ERR_ARG;
+    }
+    if (!sl.pinned) {
+        CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
+        CGS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    }
+    sl.pending = false;
+    sl.pinned[0] = 0;
+    if (P == 0) return CGS_OK;
+    if (!flags || !pos || !anchor || !gscaling || !offsets || !neural_opacity || !color_in || !cov_in || !scaling_out || !radii ||
+        !geom_ws) {
+        cgs_set_error("cgs_raster_preprocess_expand: NULL input");
+        return CGS_ERR_ARG;
+    }
+    CgsGeom g;
+    if (!cgs_geom_carve(&g, geom_ws, geom_bytes, P)) {
+        cgs_set_error("geometry workspace too small: %zu < %zu", geom_bytes, cgs_raster_geom_bytes(P));
+        return CGS_ERR_WORKSPACE;
+    }
+    const CgsExpandSrc x{n_anchor, K, flags, pos, anchor, gscaling, offsets, neural_opacity, color_in, cov_in, src_row};
+    if ((xyz_out == nullptr) != (rot_out == nullptr)) { cgs_set_error("cgs_raster_preprocess_expand: xyz_out and rot_out go together"); return CGS_ERR_ARG; }
+    if ((rc = cgs_launch_expand_preprocess(cfg, x, scaling_out, xyz_out, rot_out, g, radii, stream))) return rc;
+    return raster_count_tail(P, g, sl, stream);
 }
 
 extern "C" int cgs_raster_preprocess_wait(int64_t *num_rendered_host) {

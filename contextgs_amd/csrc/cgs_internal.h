@@ -141,6 +141,17 @@ int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float 
                               const float *dL_dconic, float *dL_dmeans3D, float *dL_dmeans2D,
                               float *dL_dscales, float *dL_drotations, hipStream_t stream);
 
+// expand_raster.hip: the anchor expansion fused with the rasterizer's preprocess stage
+struct CgsExpandSrc {
+    int64_t n_anchor;
+    int K;
+    const uint32_t *flags, *pos;
+    const float *anchor, *gscaling, *offsets, *neural_opacity, *color_in, *cov_in;
+    const int64_t *src_row;
+};
+int cgs_launch_expand_preprocess(const cgs_raster_cfg *cfg, const CgsExpandSrc &x, float *scaling_out, float *xyz_out,
+                                 float *rot_out, CgsGeom &g, int32_t *radii, hipStream_t stream);
+
 static inline int cgs_tiles_x(const cgs_raster_cfg *c) { return (c->image_width + CGS_TILE - 1) / CGS_TILE; }
 static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height + CGS_TILE - 1) / CGS_TILE; }
 

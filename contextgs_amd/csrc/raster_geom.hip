@@ -9,6 +9,7 @@
 #include <hip/hip_fp16.h>
 #include "cgs_internal.h"
 #include "raster_math.h"
+#include "raster_pre.h"
 
 #define PRE_THREADS 256
 
@@ -33,79 +34,9 @@ __global__ void __launch_bounds__(PRE_THREADS)
     const float4 q = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2],
                                  rotations[4 * i + 3]);
 
-    CgsProj pr;
-    const bool ok = cgs_project<float>(p, s, q, V, Pm, W, H, tanfovx, tanfovy, scale_modifier, pr);
-
-    int32_t radius = 0;
-    uint32_t ntiles = 0;
-    uint2 packed = make_uint2(0u, 0u);
-    uint32_t dkey = 0xFFFFFFFFu;
-    if (ok) {
-        const int gx = (W + CGS_TILE - 1) / CGS_TILE, gy = (H + CGS_TILE - 1) / CGS_TILE;
-        // reference tile rect: centre +- 3 sigma radius
-        const float r = pr.radius;
-        int x0 = min(gx, max(0, (int)((pr.px - r) / (float)CGS_TILE)));
-        int y0 = min(gy, max(0, (int)((pr.py - r) / (float)CGS_TILE)));
-        int x1 = min(gx, max(0, (int)((pr.px + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
-        int y1 = min(gy, max(0, (int)((pr.py + r + (float)(CGS_TILE - 1)) / (float)CGS_TILE)));
-        if ((x1 - x0) * (y1 - y0) > 0) {
-            radius = (int32_t)r;
-            if (!FILTER_ONLY) {
-                const float op = opacities[i];
-                // Output-invariant tightening: alpha >= 1/255 needs
-                // 0.5 d^T conic d <= tau = ln(255 op); that ellipse's bounding box has
-                // half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy).  Pixels outside
-                // it are skipped by the blend loop anyway, so tiles (and 8x8 quadrants)
-                // outside it never need to see this Gaussian.
-                float hx = -1.f, hy = -1.f;
-                uint32_t diag = 0x7C007C00u;      // (+inf, +inf) as two halves: no diagonal cull
-                const float t255 = 255.f * op;
-                if (t255 >= 1.f) {
-                    const float tau2 = 2.f * logf(t255);
-                    hx = sqrtf(tau2 * pr.cov_a) * 1.002f + 0.02f;
-                    hy = sqrtf(tau2 * pr.cov_c) * 1.002f + 0.02f;
-                    // half extents of the same ellipse along x + y and x - y (the blend kernels cull 4x4 blocks against the
-                    // octagon box /\ diagonals): sqrt(tau (1, +-1) cov (1, +-1)^T), padded like hx / hy and rounded UP to fp16
-                    const float su = fmaxf(pr.cov_a + pr.cov_c + 2.f * pr.cov_b, 0.f);
-                    const float sv = fmaxf(pr.cov_a + pr.cov_c - 2.f * pr.cov_b, 0.f);
-                    const float hu = sqrtf(tau2 * su) * 1.002f + 0.03f, hv = sqrtf(tau2 * sv) * 1.002f + 0.03f;
-                    diag = (uint32_t)__half_as_ushort(__float2half_ru(hu)) |
-                           ((uint32_t)__half_as_ushort(__float2half_ru(hv)) << 16);
-                    // pixels are at integer coordinates; first/last pixel inside the box
-                    const float fx0 = ceilf(pr.px - hx), fx1 = floorf(pr.px + hx);
-                    const float fy0 = ceilf(pr.py - hy), fy1 = floorf(pr.py + hy);
-                    if (fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.f && fy1 >= 0.f && fx0 <= (float)(W - 1) &&
-                        fy0 <= (float)(H - 1)) {
-                        const int tx0 = max(0, (int)fx0) / CGS_TILE;
-                        const int ty0 = max(0, (int)fy0) / CGS_TILE;
-                        const int tx1 = min(W - 1, (int)fx1) / CGS_TILE + 1;
-                        const int ty1 = min(H - 1, (int)fy1) / CGS_TILE + 1;
-                        x0 = max(x0, tx0); y0 = max(y0, ty0);
-                        x1 = min(x1, tx1); y1 = min(y1, ty1);
-                    } else {
-                        x1 = x0; y1 = y0;
-                    }
-                } else {
-                    x1 = x0; y1 = y0;
-                }
-                if (x1 > x0 && y1 > y0) {
-                    ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-                    packed = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
-                    dkey = __float_as_uint(pr.depth);
-                }
-                const float k = 1.4426950408889634f;  // log2(e): blend uses exp2
-                rec[3 * i + 0] = make_float4(pr.px, pr.py, -0.5f * k * pr.con_a, -k * pr.con_b);
-                rec[3 * i + 1] = make_float4(-0.5f * k * pr.con_c, op, colors[3 * i], colors[3 * i + 1]);
-                rec[3 * i + 2] = make_float4(colors[3 * i + 2], hx, hy, __uint_as_float(diag));
-            }
-        }
-    }
-    radii[i] = radius;
-    if (!FILTER_ONLY) {
-        tiles[i] = ntiles;
-        rect[i] = packed;
-        depth_key[i] = dkey;
-    }
+    cgs_pre_fwd_one<FILTER_ONLY>(i, p, s, q, FILTER_ONLY ? 0.f : opacities[i], FILTER_ONLY ? 0.f : colors[3 * i],
+                                 FILTER_ONLY ? 0.f : colors[3 * i + 1], FILTER_ONLY ? 0.f : colors[3 * i + 2], V, Pm, W, H, tanfovx,
+                                 tanfovy, scale_modifier, rec, depth_key, tiles, rect, radii);
 }
 
 // prefilter_voxel (gaussian_renderer/__init__.py:232-287) in one launch: the reference evaluates get_scaling /

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -156,6 +157,126 @@ class _ExpandGaussians(torch.autograd.Function):
         return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None, None
 
 
+FUSE_VIEW = os.environ.get("CGS_FUSE_VIEW", "1") != "0"    # tuning / A-B knob: expansion fused with the rasterizer's preprocess
+
+
+class ViewFusion:
+    """What render() hands to generate_neural_gaussians when the expansion may run fused with the rasterizer: the view's
+    raster settings in, the rendered view out (`done`: (image, radii, screenspace_points))."""
+
+    def __init__(self, raster_settings, retain_grad):
+        self.raster_settings, self.retain_grad, self.done = raster_settings, retain_grad, None
+
+
+class _ExpandRasterize(torch.autograd.Function):
+    """_ExpandGaussians followed by the rasterizer (rasterizer._RasterizeGaussians) as ONE node whose forward goes from the
+    expansion's slots to the rasterizer's records in one kernel (csrc/expand_raster.hip): colour and opacity never exist as
+    per-Gaussian tensors and nothing the expansion writes is read back by the preprocess stage.  The backward is the two
+    nodes' backward launches (cgs_raster_backward, cgs_expand_backward) with their hand-over buffers kept inside the node.
+    Same device functions on the same values as the two nodes: bit-identical image, radii and scaling
+    (tests/test_fused_view_gpu.py).  means2D: the view's screenspace_points (its gradient is the only thing it
+    carries), created by the caller once the survivor count P is known."""
+
+    @staticmethod
+    def forward(ctx, anchor, gscaling, offsets, masks, op_raw, color_in, cov_in, means2D, K, src_row, pre, raster_settings):
+        from . import rasterizer as rz
+        L = _lib.lib()
+        _lib.require_device(anchor, gscaling, offsets, masks, op_raw, color_in, cov_in)
+        anchor, gscaling, offsets = _c(anchor), _c(gscaling), _c(offsets)
+        masks, op_raw, color_in, cov_in = _c(masks), _c(op_raw), _c(color_in), _c(cov_in)
+        n = anchor.shape[0]
+        dev = anchor.device
+        stream = _lib.current_stream()
+        assert pre.n == n and pre.K == K
+        ctx.set_materialize_grads(False)
+        P = pre.wait()
+        assert means2D.shape[0] == P
+        neural_opacity, mask_out, flags, pos = pre.neural_opacity, pre.mask_out, pre.flags, pre.pos
+        cfg = rz._Cfg(raster_settings)
+        H, W = cfg.c.image_height, cfg.c.image_width
+        flat = torch.empty(P * 10, dtype=torch.float32, device=dev)          # scaling | xyz | rot (kept for the backward)
+        scaling, xyz, rot = flat[:3 * P].view(P, 3), flat[3 * P:6 * P].view(P, 3), flat[6 * P:].view(P, 4)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        geom = rz._workspace(L.cgs_raster_geom_bytes(P), dev)
+        img = rz._workspace(L.cgs_raster_img_bytes(H, W), dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        R = C.c_int64(0)
+        _lib.check(L.cgs_raster_preprocess_expand_launch(
+            cfg.ref, n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(anchor), _lib.ptr(gscaling), _lib.ptr(offsets),
+            _lib.ptr(neural_opacity), _lib.ptr(color_in), _lib.ptr(cov_in), _lib.ptr(src_row), P, _lib.ptr(scaling),
+            _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(geom), geom.numel(), _lib.ptr(radii), stream),
+            "cgs_raster_preprocess_expand_launch")
+        # from here on: rasterizer._RasterizeGaussians.forward (speculative binning + blend, then the pair count)
+        tiles = ((H + 15) // 16) * ((W + 15) // 16)
+        cap = rz._pair_capacity.get((H, W), 0) if (rz.SPECULATE and P > 0 and tiles <= 65536) else 0
+        binws = None
+        if cap:
+            binws = rz._workspace(L.cgs_raster_bin_bytes(P, cap), dev)
+            _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
+                                                _lib.ptr(img), img.numel(), _lib.ptr(color), stream), "cgs_raster_render_spec")
+        _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
+        num_rendered = int(R.value)
+        if num_rendered > rz._pair_capacity.get((H, W), 0):
+            rz._pair_capacity[(H, W)] = rz.pair_capacity_for(num_rendered)
+        bin_R = cap
+        if not cap or num_rendered > cap:
+            bin_R = num_rendered
+            binws = rz._workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
+            _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
+                                           _lib.ptr(img), img.numel(), _lib.ptr(color), stream), "cgs_raster_render")
+        rz.last_call.update(P=P, num_rendered=num_rendered, bin_R=bin_R, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
+        ctx.cfg, ctx.num_rendered, ctx.K, ctx.n, ctx.src_row, ctx.P = cfg, bin_R, K, n, src_row, P
+        ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in, xyz, scaling, rot, radii, geom, binws, img)
+        ctx.mark_non_differentiable(radii, mask_out)
+        return color, radii, scaling, neural_opacity, mask_out
+
+    @staticmethod
+    def backward(ctx, g_img, _g_radii, g_scaling, g_no, _g_mask):
+        from . import rasterizer as rz
+        L = _lib.lib()
+        (flags, pos, gscaling, offsets, op_raw, masks, cov_in, xyz, scaling, rot, radii, geom, binws, img) = ctx.saved_tensors
+        cfg, K, n, src_row, P = ctx.cfg, ctx.K, ctx.n, ctx.src_row, ctx.P
+        dev = gscaling.device
+        stream = _lib.current_stream()
+        # ---- the rasterizer's backward (as _RasterizeGaussians.backward) into buffers that stay inside this node
+        acc = torch.zeros(max(P, 1) * 4, dtype=torch.float32, device=dev)      # atomically accumulated: dL/d colour | opacity
+        d_colors, d_opac = acc[:3 * P].view(P, 3), acc[3 * P:4 * P].view(P, 1)
+        rest = torch.empty(max(P, 1) * 13, dtype=torch.float32, device=dev)
+        d_means3D, d_means2D = rest[:3 * P].view(P, 3), rest[3 * P:6 * P].view(P, 3)
+        d_scales, d_rots = rest[6 * P:9 * P].view(P, 3), rest[9 * P:13 * P].view(P, 4)
+        if g_img is not None and P > 0:
+            scratch = rz._workspace(L.cgs_raster_bwd_scratch_bytes(P), dev)
+            _lib.check(L.cgs_raster_backward(
+                cfg.ref, P, ctx.num_rendered, _lib.ptr(xyz), None, None, _lib.ptr(scaling), _lib.ptr(rot), _lib.ptr(radii),
+                _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel() if binws is not None else 0, _lib.ptr(img),
+                img.numel(), _lib.ptr(rz._f32c(g_img)), _lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_colors),
+                _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rots), _lib.ptr(scratch), scratch.numel(), stream),
+                "cgs_raster_backward")
+        else:
+            rest.zero_()
+        if g_scaling is not None:            # the loss reads `scaling` too (train.py:204): what autograd would have summed
+            d_scales = d_scales + _c(g_scaling)
+        # ---- the expansion's backward (as _ExpandGaussians.backward)
+        g_no = _c(g_no) if g_no is not None else None
+        e = lambda t: torch.empty_like(t)
+        d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        d_op, d_mask = e(op_raw), e(masks)
+        if src_row is None:
+            d_gs, d_off = e(gscaling), e(offsets)
+        else:       # rows of the larger arrays that no visible anchor reads get zeros; every row written -> no fill
+            alloc = torch.empty if n == gscaling.shape[0] else torch.zeros
+            flat = alloc(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
+            d_gs, d_off = flat[:gscaling.numel()].view_as(gscaling), flat[gscaling.numel():].view_as(offsets)
+        d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
+        d_cov = e(cov_in)
+        _lib.check(L.cgs_expand_backward(
+            n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(gscaling), _lib.ptr(offsets), _lib.ptr(op_raw), _lib.ptr(masks),
+            _lib.ptr(cov_in), _lib.ptr(d_means3D), _lib.ptr(d_colors), _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rots),
+            _lib.ptr(g_no), _lib.ptr(d_anchor), _lib.ptr(d_gs), _lib.ptr(d_off), _lib.ptr(d_op), _lib.ptr(d_mask),
+            _lib.ptr(d_color), _lib.ptr(d_cov), _lib.ptr(src_row), stream), "cgs_expand_backward")
+        return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, d_means2D, None, None, None, None
+
+
 def _anchor_mlps(pc, x):
     """mlp_opacity / mlp_color / mlp_cov on the shared [N,54] input (:112,122,126).
     The three first layers are one GEMM; outputs are identical dot products."""
@@ -196,7 +317,8 @@ def _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offse
                                  binary_grid_masks.reshape(-1, K), mo, mc, mv)
 
 
-def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K, between=None):
+def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K, between=None,
+                      view=None):
     """The same stage as separate launches: fused three-MLP kernel (or torch) + the expansion kernels.
     between: called after the expansion's survivor count has been ENQUEUED and before it is read — work it launches
     (the step's rate model) runs on the device while the host waits for the count."""
@@ -232,10 +354,26 @@ def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_off
         pre = ExpandCount(op_raw, masks2, K)
     if between is not None:
         between()
+    if (view is not None and FUSE_VIEW and pre is not None and anchor.is_cuda and grid_scaling.is_cuda
+            and grid_offsets.is_cuda and torch.is_grad_enabled()):
+        # the expansion and the rasterizer as one node (csrc/expand_raster.hip); the survivor count is read here, after
+        # `between` has put the rate model in the queue, so that screenspace_points can be an INPUT of the node
+        P = pre.wait()
+        screenspace_points = _zero_points(torch.empty(P, 0, device=anchor.device))
+        if view.retain_grad:
+            try:
+                screenspace_points.retain_grad()
+            except Exception:
+                pass
+        image, radii, scaling, neural_opacity, mask = _ExpandRasterize.apply(
+            anchor, grid_scaling, grid_offsets, masks2, op_raw, color_in, cov_in, screenspace_points, K, src_row, pre,
+            view.raster_settings)
+        view.done = (image, radii, screenspace_points)
+        return None, None, None, scaling, None, neural_opacity, mask
     return _ExpandGaussians.apply(anchor, grid_scaling, grid_offsets, masks2, op_raw, color_in, cov_in, K, src_row, pre)
 
 
-def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0):   # :25-150
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0, _view=None):   # :25-150
     time_sub = 0
     if visible_mask is None:
         visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
@@ -310,7 +448,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     out = _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
     if out is None:
         out = _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K,
-                                between=run_rate)
+                                between=run_rate, view=_view if is_training else None)
     elif run_rate is not None:
         run_rate()
     if rate_out:
@@ -369,10 +507,21 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, visible_m
            step=0):                                                                      # :155-229
     """Render the scene.  Background tensor (bg_color) must be on the GPU."""
     is_training = pc.get_color_mlp.training
+    view = None
     if is_training:
+        # the expansion may run fused with the rasterizer's per-Gaussian stages (then `view.done` holds the rendered view
+        # and xyz / color / opacity / rot are None: they never existed as tensors)
+        view = ViewFusion(_raster_settings(viewpoint_camera, pipe, bg_color, scaling_modifier), retain_grad)
         (xyz, color, opacity, scaling, rot, neural_opacity, mask, bit_per_param, bit_per_anchor_param,
          bit_per_feat_param, bit_per_scaling_param, bit_per_offsets_param, bpp_per_level) = \
-            generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=True, step=step)
+            generate_neural_gaussians(viewpoint_camera, pc, visible_mask, is_training=True, step=step, _view=view)
+        if view.done is not None:
+            rendered_image, radii, screenspace_points = view.done
+            return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                    "radii": radii, "selection_mask": mask, "neural_opacity": neural_opacity, "scaling": scaling,
+                    "bit_per_param": bit_per_param, "bit_per_anchor_param": bit_per_anchor_param,
+                    "bit_per_feat_param": bit_per_feat_param, "bit_per_scaling_param": bit_per_scaling_param,
+                    "bit_per_offsets_param": bit_per_offsets_param, "bpp_per_level": bpp_per_level}
     else:
         xyz, color, opacity, scaling, rot, time_sub = generate_neural_gaussians(
             viewpoint_camera, pc, visible_mask, is_training=False, step=step)

@@ -154,6 +154,24 @@ int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P,
                         float *dL_dcolors, float *dL_dopacities,
                         float *dL_dscales, float *dL_drotations,
                         void *scratch, size_t scratch_bytes, void *stream);
+
+/* ---- the anchor expansion fused with the rasterizer's preprocess stage (csrc/expand_raster.hip) ----
+ * Training path of render(): gaussian_renderer/__init__.py:130-145 (generate_neural_gaussians' tail) feeding :179-205.
+ * cgs_raster_preprocess_expand_launch = cgs_raster_preprocess_launch whose Gaussians are the surviving slots of
+ * cgs_expand_count_launch (flags / pos / neural_opacity [n_anchor*K], P = its count): slot i with flags[i] != 0 is Gaussian
+ * pos[i], computed from anchor [n_anchor,3], gscaling [*,6] / offsets [*,K,3] (row src_row[n] of anchor n when src_row != NULL,
+ * else row n), color_in [n_anchor*K,3], cov_in [n_anchor*K,7] exactly as cgs_expand_write would, and handed to the preprocess
+ * stage in registers.  scaling_out [P,3] receives the scales; xyz_out [P,3] and rot_out [P,4] (both or neither) the positions
+ * and normalised rotations — what cgs_raster_backward needs besides the workspaces; colours and opacities are not stored.
+ * cgs_raster_preprocess_wait / cgs_raster_render* / cgs_raster_backward / cgs_expand_backward follow as usual.  Records, radii
+ * and scales are bit-identical to cgs_expand_write + cgs_raster_preprocess_launch (same device functions, same values). */
+int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anchor, int K,
+                                        const uint32_t *flags, const uint32_t *pos, const float *anchor,
+                                        const float *gscaling, const float *offsets,
+                                        const float *neural_opacity, const float *color_in,
+                                        const float *cov_in, const int64_t *src_row, int64_t P,
+                                        float *scaling_out, float *xyz_out, float *rot_out, void *geom_ws,
+                                        size_t geom_bytes, int32_t *radii, void *stream);
 size_t cgs_raster_bwd_scratch_bytes(int64_t P);
 
 /* Statistics of the last render held in img_ws (device reads; async):
