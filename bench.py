@@ -240,6 +240,14 @@ def main():
             "expand_fwd": (396 - 200) * n_vis + 56 * P,
             "expand_bwd": 2 * (396 - 200) * n_vis + 56 * P,
         }
+        from contextgs_amd import renderer as _rd
+        if _rd.FUSE_VIEW:
+            # training views go from the expansion's slots to the rasterizer's records in ONE kernel (csrc/expand_raster.hip,
+            # timed under "preprocess"; no "expand_fwd" launch): flags + pos of every slot, 36 B per anchor, 56 B of slot
+            # inputs per surviving Gaussian in; record 48 + depth 4 + tiles 4 + rect 8 + radius 4 + scaling 12 + xyz 12 + rot 16 out
+            K_ = int(pc.n_offsets)
+            alg["preprocess"] = 8 * n_vis * K_ + 36 * n_vis + (56 + 108) * P
+            alg.pop("expand_fwd")
         # fused-MLP kernel families are MFMA-bound: algorithmic flops of ALL their launches in one step
         # (three anchor MLPs on n_vis rows + one context MLP per level on that level's rows)
         mlp_flops = 0.0
