@@ -253,3 +253,110 @@ def test_parameters_without_a_gradient_on_any_rank_stay_without_one():
     torch.randn(20, 2)
     late0 = torch.randn(20, 1).flatten()
     assert torch.allclose(torch.tensor(res[0][3]), late0 - 0.2, atol=1e-5)
+
+
+class _DeferringLinear(torch.autograd.Function):
+    """Stand-in for the MLP nodes of contextgs_amd/mlp.py on CPU: y = x W^T with the data gradient returned at once and
+    the weight gradient left to mlp's end-of-backward queue when deferral is on."""
+
+    @staticmethod
+    def forward(ctx, x, W, log):
+        ctx.save_for_backward(x, W.detach())
+        ctx.W, ctx.log = W, log
+        return x @ W.detach().t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from contextgs_amd import mlp
+        x, Wd = ctx.saved_tensors
+        dx = g @ Wd
+        if not mlp._can_defer((ctx.W,)):
+            return dx, g.t() @ x, None
+        W, log = ctx.W, ctx.log
+
+        def job():
+            log.append("wgrad")
+            mlp._accumulate((W,), (g.t() @ x,))
+        mlp._defer(job)
+        return dx, None, None
+
+
+def _defer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        from contextgs_amd import mlp
+        torch.manual_seed(0)
+        W = torch.nn.Parameter(torch.randn(3, 4))             # "MLP weight": small bucket, gradient deferred
+        big = torch.nn.Parameter(torch.randn(16, 4))          # "per-anchor" tensors: reduced in place from the hooks
+        big2 = torch.nn.Parameter(torch.randn(16, 4))
+        cd.BIG_TENSOR = 32
+        assert not mlp._Deferred.on
+        sync = cd.GradientSync([W, big, big2], average=True)
+        assert mlp._Deferred.on                               # world > 1: GradientSync switched the deferral on
+        log = []
+        orig_issue = sync._issue
+        sync._issue = lambda p: (log.append("issue"), orig_issue(p))[1]
+        results = []
+        for step in range(2):                                 # second step: W is used by TWO nodes and .grad accumulates
+            x = big * float(rank + 1) + (big2 if step else 0.0)
+            y = _DeferringLinear.apply(x, W, log)
+            if step:
+                y = y + _DeferringLinear.apply(big2 * 2.0, W, log)
+            y.sum().backward()
+            assert not mlp._Deferred.queue and not mlp._Deferred.armed and not mlp._Deferred.staged
+            sync.finish()
+            results.append([t.grad.clone() for t in (W, big, big2) if t.grad is not None])
+            if step == 0:
+                for t in (big, big2):
+                    t.grad = None                              # W.grad is kept: the next backward must ADD to it
+        sync.close()
+        assert not mlp._Deferred.on and not mlp._Deferred.before_flush
+        q.put((rank, log, results))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_deferred_weight_gradients_follow_the_per_anchor_collectives():
+    """dist.GradientSync + mlp.defer_weight_gradients on two gloo ranks with a CPU stand-in for the MLP nodes: every
+    per-anchor collective is issued BEFORE the first deferred weight-gradient job runs, a parameter used by two nodes gets
+    the sum of both, an existing .grad is added to, and the reduced values are what an inline backward + all-reduce gives."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_defer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, log, results in out:
+        # step 0: both per-anchor tensors are predicted active (big2 without a gradient anywhere: zeros, dropped again in
+        # finish()) and are issued BEFORE the deferred weight gradient runs; step 1: big is issued first, then the two queued
+        # weight gradients, and big2 — predicted inactive after step 0 — only after finish()'s has-grad mask
+        assert log == ["issue", "issue", "wgrad", "issue", "wgrad", "wgrad", "issue"], log
+    # reference: the same two steps in one process per "rank", inline gradients, averaged by hand
+    torch.manual_seed(0)
+    W = torch.randn(3, 4); big = torch.randn(16, 4); big2 = torch.randn(16, 4)
+    ref = []
+    for step in range(2):
+        gW, gb, gb2 = [], [], []
+        for rank in range(world):
+            Wp, bp, b2p = (t.clone().requires_grad_(True) for t in (W, big, big2))
+            x = bp * float(rank + 1) + (b2p if step else 0.0)
+            y = x @ Wp.t()
+            if step:
+                y = y + (b2p * 2.0) @ Wp.t()
+            y.sum().backward()
+            gW.append(Wp.grad); gb.append(bp.grad); gb2.append(b2p.grad if b2p.grad is not None else torch.zeros_like(b2p))
+        ref.append((sum(gW) / world, sum(gb) / world, sum(gb2) / world))
+    for rank, log, results in out:
+        w0, b0 = results[0][0], results[0][1]
+        torch.testing.assert_close(w0, ref[0][0]); torch.testing.assert_close(b0, ref[0][1])
+        # step 1: W.grad carried over from step 0 (already averaged) + this step's average
+        torch.testing.assert_close(results[1][0], ref[0][0] + ref[1][0])
+        torch.testing.assert_close(results[1][1], ref[1][1]); torch.testing.assert_close(results[1][2], ref[1][2])
