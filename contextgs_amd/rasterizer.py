@@ -88,6 +88,37 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def bin_and_blend(cfg, P, geom, img, color, stream):
+    """Everything of a view's forward behind a cgs_raster_preprocess*_launch on `geom`: the speculative binning + blend with
+    the image size's pair capacity, the read of the pair count, and the re-render with the true count when the capacity did
+    not hold.  Returns (binning workspace, the pair count it was carved with = the backward's `R`, the view's pair count)."""
+    L = _lib.lib()
+    dev = geom.device
+    H, W = cfg.c.image_height, cfg.c.image_width
+    R = C.c_int64(0)
+    tiles = ((H + 15) // 16) * ((W + 15) // 16)
+    cap = _pair_capacity.get((H, W), 0) if (SPECULATE and P > 0 and tiles <= 65536) else 0
+    binws = None
+    if cap:
+        binws = _workspace(L.cgs_raster_bin_bytes(P, cap), dev)
+        _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
+                                            binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
+                   "cgs_raster_render_spec")
+    _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
+    num_rendered = int(R.value)
+    if num_rendered > _pair_capacity.get((H, W), 0):
+        _pair_capacity[(H, W)] = pair_capacity_for(num_rendered)
+    bin_R = cap                              # the count the binning workspace was carved with (the backward's `R`)
+    if not cap or num_rendered > cap:
+        bin_R = num_rendered
+        binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
+        _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
+                                       binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
+                   "cgs_raster_render")
+    last_call.update(P=P, num_rendered=num_rendered, bin_R=bin_R, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
+    return binws, bin_R, num_rendered
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, colors, opacities, scales, rotations, raster_settings):
@@ -106,32 +137,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom = _workspace(L.cgs_raster_geom_bytes(P), dev)
         img = _workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        R = C.c_int64(0)
         _lib.check(L.cgs_raster_preprocess_launch(cfg.ref, P, _lib.ptr(means3D_c), _lib.ptr(colors_c), _lib.ptr(opac_c),
                                                   _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
                                                   _lib.ptr(radii), stream), "cgs_raster_preprocess_launch")
-        tiles = ((H + 15) // 16) * ((W + 15) // 16)
-        cap = _pair_capacity.get((H, W), 0) if (SPECULATE and P > 0 and tiles <= 65536) else 0
-        binws = None
-        if cap:
-            binws = _workspace(L.cgs_raster_bin_bytes(P, cap), dev)
-            _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
-                                                binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
-                       "cgs_raster_render_spec")
-        _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
-        num_rendered = int(R.value)
-        if num_rendered > _pair_capacity.get((H, W), 0):
-            _pair_capacity[(H, W)] = pair_capacity_for(num_rendered)
-        bin_R = cap                              # the count the binning workspace was carved with (the backward's `R`)
-        if not cap or num_rendered > cap:
-            bin_R = num_rendered
-            binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
-            _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
-                                           binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
-                       "cgs_raster_render")
+        binws, bin_R, _num_rendered = bin_and_blend(cfg, P, geom, img, color, stream)
         ctx.cfg = cfg
         ctx.num_rendered = bin_R
-        last_call.update(P=P, num_rendered=num_rendered, bin_R=bin_R, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
         ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii)
         return color, radii

@@ -200,31 +200,12 @@ class _ExpandRasterize(torch.autograd.Function):
         geom = rz._workspace(L.cgs_raster_geom_bytes(P), dev)
         img = rz._workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        R = C.c_int64(0)
         _lib.check(L.cgs_raster_preprocess_expand_launch(
             cfg.ref, n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(anchor), _lib.ptr(gscaling), _lib.ptr(offsets),
             _lib.ptr(neural_opacity), _lib.ptr(color_in), _lib.ptr(cov_in), _lib.ptr(src_row), P, _lib.ptr(scaling),
             _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(geom), geom.numel(), _lib.ptr(radii), stream),
             "cgs_raster_preprocess_expand_launch")
-        # from here on: rasterizer._RasterizeGaussians.forward (speculative binning + blend, then the pair count)
-        tiles = ((H + 15) // 16) * ((W + 15) // 16)
-        cap = rz._pair_capacity.get((H, W), 0) if (rz.SPECULATE and P > 0 and tiles <= 65536) else 0
-        binws = None
-        if cap:
-            binws = rz._workspace(L.cgs_raster_bin_bytes(P, cap), dev)
-            _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
-                                                _lib.ptr(img), img.numel(), _lib.ptr(color), stream), "cgs_raster_render_spec")
-        _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
-        num_rendered = int(R.value)
-        if num_rendered > rz._pair_capacity.get((H, W), 0):
-            rz._pair_capacity[(H, W)] = rz.pair_capacity_for(num_rendered)
-        bin_R = cap
-        if not cap or num_rendered > cap:
-            bin_R = num_rendered
-            binws = rz._workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
-            _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
-                                           _lib.ptr(img), img.numel(), _lib.ptr(color), stream), "cgs_raster_render")
-        rz.last_call.update(P=P, num_rendered=num_rendered, bin_R=bin_R, img_ws=img, geom_ws=geom, bin_ws=binws, cfg=cfg)
+        binws, bin_R, _num_rendered = rz.bin_and_blend(cfg, P, geom, img, color, stream)
         ctx.cfg, ctx.num_rendered, ctx.K, ctx.n, ctx.src_row, ctx.P = cfg, bin_R, K, n, src_row, P
         ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in, xyz, scaling, rot, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii, mask_out)
