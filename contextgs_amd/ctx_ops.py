@@ -158,6 +158,7 @@ class _RowSourceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, feat, scal, off):
         ctx.src = src
+        ctx.set_materialize_grads(False)     # the token's gradient carries nothing: no zeros(1) for it
         return feat.new_zeros(1)
 
     @staticmethod
@@ -199,6 +200,7 @@ class _NoiseQuant(torch.autograd.Function):
             xf, xs, xo = _c(xf), _c(xs), _c(xo)
             n = xf.shape[0]
         _lib.require_device(xf, xs, xo, qadj)
+        ctx.set_materialize_grads(False)     # an output nobody differentiates (Q outside the rate subset) arrives as None, not zeros
         D, S, O = xf.shape[1], xs.shape[1], xo.shape[1]
         if outs is None:
             mk = lambda w: torch.empty(n, w, dtype=_f32, device=qadj.device)
@@ -235,7 +237,9 @@ class _NoiseQuant(torch.autograd.Function):
             side.map = side.f = side.s = side.o = side.q = None
         if src is not None:
             src.rows_written += n
-            return None, None, None, dq, None, None, None, None, None, qadj.new_zeros(1), None
+            # (no gradient VALUE for the token: it only ties _RowSourceFn into the graph, whose backward hands out the
+            #  buffers this kernel filled — a zeros(1) per level cost a fill and an add launch each)
+            return None, None, None, dq, None, None, None, None, None, None, None
         return gf, gs, go, dq, None, None, None, None, None, None, None
 
 
