@@ -549,6 +549,7 @@ extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_
                                              float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
                                              float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
                                              void *stream_) {
+    if (n == 0) return CGS_OK;           // no visible anchor: nothing to do (empty tensors arrive as NULL pointers)
     if (!src_row || !anchor_vis || !cam3 || !d_feat_src || !d_anchor_vis) { cgs_set_error("anchor_mlp3_backward_rows: NULL"); return CGS_ERR_ARG; }
     M3Rows R{nullptr, src_row, anchor_vis, cam3, nullptr, d_feat_src, d_anchor_vis};
     return m3_backward(X, M3_XLD, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat, nullptr, 0, dZ1cat, dZ2_op, dZ2_color,

@@ -84,3 +84,53 @@ def test_render_takes_the_fused_node_in_training_only():
         assert seen == [1]
     finally:
         renderer._ExpandRasterize.apply = orig
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("step_sem", [1000, 20000])
+@pytest.mark.parametrize("case", ["all_masked", "nothing_visible", "one_anchor"])
+def test_degenerate_training_views(fuse, case, step_sem):
+    """Edge cases of the training view, both node layouts: every offset masked out (P = 0 Gaussians from n > 0 visible
+    anchors), a camera that sees no anchor (n = 0), a single visible anchor.  The image is the background, the backward
+    runs, every parameter gets a (finite) gradient or none."""
+    from contextgs_amd import renderer
+    from contextgs_amd.renderer import prefilter_voxel, render
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    torch.manual_seed(3)
+    pc = make_scene(2000, seed=3)
+    pc.train()
+    cam = orbit_cameras(2, 96, 64)[0].to_torch("cuda")
+    pipe, bg = SynthPipe(), torch.tensor([0.3, 0.2, 0.1], device="cuda")
+    prev, renderer.FUSE_VIEW = renderer.FUSE_VIEW, fuse
+    try:
+        vis = prefilter_voxel(cam, pc, pipe, bg)
+        if case == "all_masked":
+            with torch.no_grad():
+                pc._mask.fill_(-20.0)                    # sigmoid < 0.01 -> every offset masked (scene/gaussian_model.py:295-300)
+        elif case == "nothing_visible":
+            vis = torch.zeros_like(vis)
+        else:
+            keep = torch.nonzero(vis)[:1, 0]
+            vis = torch.zeros_like(vis)
+            vis[keep] = True
+        if case == "all_masked" and step_sem > 10000:
+            # no live anchor at all: the level division bisects on `kept cells / anchors` = 0 / 0, as the reference's
+            # find_divide_scale does (scene/gaussian_model.py:1726-1749) — same exception, nothing to render
+            with pytest.raises(ZeroDivisionError):
+                render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=step_sem)
+            return
+        pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=step_sem)
+        img = pkg["render"]
+        assert img.shape == (3, 64, 96) and bool(torch.isfinite(img).all())
+        if case != "one_anchor":
+            assert pkg["radii"].numel() == 0 and pkg["scaling"].shape == (0, 3)
+            assert torch.equal(img, bg.view(3, 1, 1).expand(3, 64, 96))
+        loss = img.sum() + pkg["scaling"].sum()
+        if pkg["bit_per_param"] is not None:
+            assert bool(torch.isfinite(pkg["bit_per_param"]))
+            loss = loss + 0.001 * pkg["bit_per_param"]
+        loss.backward()
+        for name, p in pc.named_parameters():
+            assert p.grad is None or bool(torch.isfinite(p.grad).all()), name
+    finally:
+        renderer.FUSE_VIEW = prev
