@@ -621,7 +621,10 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                                    mf=mean_feat, sf=scale_feat, qf=Q_feat, ms=mean_scaling, ss=scale_scaling,
                                    qs=Q_scaling, mo=mean_offsets, so=scale_offsets, qo=Q_offsets))
         else:
-            hf, hs, ho = feat_l[j], scal_l[j], off_l[j].reshape(-1, 3 * K)
+            if feat_l is not None:
+                hf, hs, ho = feat_l[j], scal_l[j], off_l[j].reshape(-1, 3 * K)
+            else:       # an EMPTY level on the row-source path (tiny scenes): the per-level slices were never materialised
+                hf, hs, ho = (anchor.new_zeros(0, w, dtype=torch.float32) for w in (pc.feat_dim, 6, 3 * K))
             joined = joined and n_l == 0
         feat_q.append(hf)
         scal_q.append(hs)

@@ -227,7 +227,10 @@ class _NoiseQuant(torch.autograd.Function):
         dq = torch.empty(n, 3, dtype=_f32, device=qadj.device) if (ctx.needs_input_grad[3] or src is not None) else None
         dx = src.grad_buffers() if src is not None else (None, None, None)
         side = ctx.side if (ctx.side is not None and ctx.side.map is not None and src is not None) else None
-        sd = (side.map, side.f, side.s, side.o, side.q) if side is not None else (None,) * 5
+        # (a level without a single chosen row has an all -1 map and EMPTY side arrays: nothing to add, and empty tensors
+        #  would reach the C entry point as NULL pointers)
+        use_side = side is not None and side.f is not None and side.f.numel() > 0
+        sd = (side.map, side.f, side.s, side.o, side.q) if use_side else (None,) * 5
         if dq is not None:
             _lib.check(_lib.lib().cgs_noise_quant_bwd(
                 _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), _lib.ptr(qadj), n, D, S, O, ctx.seed, ctx.q0[0],

@@ -403,7 +403,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
                 from . import ctx_ops as _ctx
                 n_vis = feat.shape[0]
                 zero_adj = torch.zeros(n_vis, 3, dtype=torch.float32, device=feat.device)
-                feat, grid_scaling, off2, _q = _ctx.noise_quant(feat, grid_scaling, grid_offsets.reshape(n_vis, -1), zero_adj,
+                off_flat = grid_offsets.reshape(n_vis, grid_offsets.shape[1] * grid_offsets.shape[2])    # (explicit: n_vis may be 0)
+                feat, grid_scaling, off2, _q = _ctx.noise_quant(feat, grid_scaling, off_flat, zero_adj,
                                                                 (Q_FEAT, Q_SCALING, Q_OFFSETS))
                 grid_offsets = off2.view(grid_offsets.shape)
             else:
