@@ -78,3 +78,28 @@ def test_container_round_trip_of_tiny_scenes(N, tmp_path):
     for name in ("_anchor_feat", "_scaling", "_offset", "_mask"):
         t = getattr(dec, name)
         assert t.shape[0] == n_valid and bool(torch.isfinite(t).all()), name
+
+
+@pytest.mark.parametrize("feat_dim,n_offsets", [(32, 10), (50, 5), (32, 4), (64, 12), (50, 20)])
+def test_model_shapes_without_fused_mlp_instances_still_train_and_code(feat_dim, n_offsets, tmp_path):
+    """The fused MLP kernels are instantiated for the reference's default widths (feat_dim 50, n_offsets 10); other
+    configurations (arguments/__init__.py: feat_dim, n_offsets are options) must take the generic paths: train through
+    every phase, evaluate, encode and decode."""
+    import copy
+    from contextgs_amd.renderer import prefilter_voxel
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    pc = make_scene(1500, seed=6, feat_dim=feat_dim, n_offsets=n_offsets)
+    cam = orbit_cameras(2, 96, 64)[0].to_torch("cuda")
+    pipe, bg = SynthPipe(), torch.zeros(3, device="cuda")
+    vis = prefilter_voxel(cam, pc, pipe, bg)
+    for step in (1000, 5000, 20000):
+        pc.zero_grad()
+        _view(pc, cam, pipe, bg, vis, step, True)
+    _view(pc, cam, pipe, bg, vis, 20000, False)
+    pc.eval()
+    ref = copy.deepcopy(pc)
+    with torch.no_grad():
+        pc.conduct_encoding(str(tmp_path))
+        ref.conduct_decoding(str(tmp_path))
+        ref.eval()
+        _view(ref, cam, pipe, bg, prefilter_voxel(cam, ref, pipe, bg), 20000, False)
