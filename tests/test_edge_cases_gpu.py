@@ -41,7 +41,7 @@ def test_views_that_see_almost_nothing(train, step, n_visible):
     vis[:n_visible] = True
     pkg = _view(pc, cam, pipe, bg, vis, step, train)
     if n_visible == 0:
-        assert pkg["radii"].numel() == 0 and float(pkg["render"].abs().max()) == 0.0
+        assert pkg["radii"].numel() == 0 and float(pkg["render"].detach().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 17, 33, 100, 257])
@@ -103,3 +103,71 @@ def test_model_shapes_without_fused_mlp_instances_still_train_and_code(feat_dim,
         ref.conduct_decoding(str(tmp_path))
         ref.eval()
         _view(ref, cam, pipe, bg, prefilter_voxel(cam, ref, pipe, bg), 20000, False)
+
+
+# ---- densification on degenerate statistics (scene/gaussian_model.py:856-910 through contextgs_amd.densify) ----------
+import types
+
+ARGS = types.SimpleNamespace(
+    percent_dense=0.01, position_lr_init=0.0, position_lr_final=0.0, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+    offset_lr_init=0.01, offset_lr_final=0.0001, offset_lr_delay_mult=0.01, offset_lr_max_steps=30000,
+    mask_lr_init=0.01, mask_lr_final=0.0001, mask_lr_delay_mult=0.01, mask_lr_max_steps=30000,
+    feature_lr=0.0075, hyper_latent_lr=0.0075, opacity_lr=0.02, scaling_lr=0.007, rotation_lr=0.002,
+    mlp_opacity_lr_init=0.002, mlp_opacity_lr_final=0.00002, mlp_opacity_lr_delay_mult=0.01, mlp_opacity_lr_max_steps=30000,
+    mlp_cov_lr_init=0.004, mlp_cov_lr_final=0.004, mlp_cov_lr_delay_mult=0.01, mlp_cov_lr_max_steps=30000,
+    mlp_color_lr_init=0.008, mlp_color_lr_final=0.00005, mlp_color_lr_delay_mult=0.01, mlp_color_lr_max_steps=30000,
+    latent_codec_lr_init=0.005, latent_codec_lr_final=0.00001, latent_codec_lr_delay_mult=0.33, latent_codec_lr_max_steps=30000,
+    mlp_grid_lr_init=0.005, mlp_grid_lr_final=0.00001, mlp_grid_lr_delay_mult=0.01, mlp_grid_lr_max_steps=30000)
+
+
+def _cams():
+    from contextgs_amd.synth import orbit_cameras
+    return [c.to_torch("cuda") for c in orbit_cameras(4, 96, 64)]
+
+
+def _adjust_flow(N, views, adjust_kw, empty_view=False, steps=(1000,)):
+    from contextgs_amd.renderer import prefilter_voxel, render
+    from contextgs_amd.synth import make_scene
+    pc = make_scene(N, seed=3); pc.train(); pc.spatial_lr_scale = 1.0
+    pc.training_setup(ARGS)
+    for it in range(views):
+        cam = _cams()[it % 4]
+        pc.optimizer.zero_grad(set_to_none=True)
+        vis = prefilter_voxel(cam, pc, _PIPE(), _BG())
+        if empty_view: vis = torch.zeros_like(vis)
+        pkg = render(cam, pc, _PIPE(), _BG(), visible_mask=vis, retain_grad=True, step=steps[it % len(steps)])
+        loss = (1.0 - pkg["render"]).abs().mean() + 0.01 * pkg["scaling"].prod(dim=1).mean()
+        if pkg["bit_per_param"] is not None: loss = loss + 0.001 * pkg["bit_per_param"]
+        loss.backward()
+        pc.optimizer.step()
+        pc.training_statis(pkg["viewspace_points"], pkg["neural_opacity"], pkg["visibility_filter"], pkg["selection_mask"], vis)
+    n0 = pc._anchor.shape[0]
+    pc.adjust_anchor(**adjust_kw)
+    n1 = pc._anchor.shape[0]
+    # and keep training on the adjusted set
+    cam = _cams()[0]; pc.optimizer.zero_grad(set_to_none=True)
+    vis = prefilter_voxel(cam, pc, _PIPE(), _BG())
+    pkg = render(cam, pc, _PIPE(), _BG(), visible_mask=vis, retain_grad=True, step=20000)
+    (pkg["render"].sum() + (pkg["bit_per_param"] if pkg["bit_per_param"] is not None else 0)).backward()
+    pc.optimizer.step()
+    return n0, n1
+
+
+def _PIPE():
+    from contextgs_amd.synth import SynthPipe
+    return SynthPipe()
+
+
+def _BG():
+    return torch.zeros(3, device="cuda")
+
+
+@pytest.mark.parametrize("name,N,views,kw,empty", [
+    ("no statistics at all", 500, 0, dict(check_interval=100, success_threshold=0.8, grad_threshold=0.0002, min_opacity=0.005), False),
+    ("empty views only", 500, 3, dict(check_interval=1, success_threshold=0.0, grad_threshold=0.0, min_opacity=0.005), True),
+    ("everything is a candidate", 300, 4, dict(check_interval=1, success_threshold=0.0, grad_threshold=0.0, min_opacity=-1.0), False),
+    ("five anchors", 5, 4, dict(check_interval=1, success_threshold=0.0, grad_threshold=0.0, min_opacity=0.005), False),
+    ("one anchor", 1, 4, dict(check_interval=1, success_threshold=0.0, grad_threshold=0.0, min_opacity=0.005), False)])
+def test_adjust_anchor_on_degenerate_statistics_then_trains_on(name, N, views, kw, empty):
+    n0, n1 = _adjust_flow(N, views, kw, empty_view=empty)
+    assert n0 == N and n1 >= 1
