@@ -54,11 +54,15 @@ def main():
     mgpu.BIG_TENSOR = N                                       # per-anchor tensors in place, MLPs in the bucket
     sync = mgpu.GradientSync(params, average=True)
     torch.manual_seed(1000 + rank)                            # the ranks' RNG streams differ from here on (as in training)
-    for it, step_sem in enumerate((2000, 5000, 20000, 20000)):
+    # (the fifth step: rank 1's camera sees NO anchor — its backward produces no per-anchor gradient at all, the collective
+    #  sequence must stay aligned and the replicas identical; the sixth: back to normal)
+    for it, step_sem in enumerate((2000, 5000, 20000, 20000, 20000, 20000)):
         cam = cams[mgpu.view_for(it, len(cams))]
         pc.update_learning_rate(step_sem)
         opt.zero_grad(set_to_none=True)
         vis = prefilter_voxel(cam, pc, pipe, bg)
+        if it == 4 and rank == 1:
+            vis = torch.zeros_like(vis)
         pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=step_sem)
         loss = (1.0 - pkg["render"]).abs().mean() + 0.01 * pkg["scaling"].prod(dim=1).mean()
         if pkg["bit_per_param"] is not None:
@@ -117,7 +121,7 @@ def main():
         assert len(set(every)) == 1, "replicas diverged in the step after adjust_anchor"
     sync.close()
     dist.barrier()
-    print(f"rank {rank}: replicas identical after 4 optimiser steps; grew {grown} anchors identically; "
+    print(f"rank {rank}: replicas identical after 6 optimiser steps (one of them with an empty view on rank 1); grew {grown} anchors identically; "
           f"adjust_anchor {n0} -> {n1} anchors identically", flush=True)
     dist.destroy_process_group()
 
