@@ -1,0 +1,57 @@
+"""Degenerate inputs of the entropy-model / quantiser / codec / kNN entry points (utils/entropy_models.py, utils/encodings.py,
+simple_knn.distCUDA2 as the reference calls them): empty tensors, vanishing and huge scales, far-out values, one symbol,
+a stream one symbol longer than a chunk, a million symbols over a wide range, fewer points than neighbours."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n,scale,xval,Q", [(0, 1.0, 0.0, 1.0), (5, 0.0, 0.0, 1.0), (5, 1e-30, 0.0, 1.0), (5, 1.0, 1e6, 1.0),
+                                           (5, 1e6, 0.0, 1.0), (5, 1.0, 0.0, 1e-9)])
+def test_entropy_gaussian_stays_finite(n, scale, xval, Q):
+    from contextgs_amd import entropy_models as em
+    m = em.Entropy_gaussian(Q=1)
+    x = torch.full((n, 4), xval, device=DEV, requires_grad=True)
+    mean = torch.zeros(n, 4, device=DEV, requires_grad=True)
+    sc = torch.full((n, 4), scale, device=DEV, requires_grad=True)
+    bits = m(x, mean, sc, Q)
+    assert bits.shape == (n, 4) and bool(torch.isfinite(bits).all()) and bool((bits >= 0).all())
+    bits.sum().backward()
+    assert all(bool(torch.isfinite(t.grad).all()) for t in (x, mean, sc))
+
+
+def test_quantisers_on_empty_tensors():
+    from contextgs_amd import encodings as enc
+    assert enc.STE_multistep.apply(torch.zeros(0, 3, device=DEV), torch.ones(0, 1, device=DEV)).shape == (0, 3)
+    assert enc.STE_binary.apply(torch.zeros(0, device=DEV)).shape == (0,)
+    assert enc.Quantize_anchor.apply(torch.zeros(0, 3, device=DEV), torch.zeros(3, device=DEV), torch.ones(3, device=DEV))[0].shape == (0, 3)
+
+
+@pytest.mark.parametrize("n,scale,Q,spread", [(0, 1.0, 1.0, 1.0), (1, 1.0, 1.0, 1.0), (5000, 1e-9, 1.0, 3.0), (5000, 1e3, 1.0, 3.0),
+                                              (5000, 1.0, 1e-3, 0.01), (50001, 1.0, 1.0, 3.0), (1_000_000, 20.0, 1.0, 50.0),
+                                              (4096, 1e-9, 1.0, 0.0)])
+def test_gaussian_codec_round_trips_on_extreme_parameters(n, scale, Q, spread, tmp_path):
+    from contextgs_amd import encodings as enc
+    g = torch.Generator(device=DEV).manual_seed(n + 1)
+    mean = torch.randn(n, device=DEV, generator=g) * spread
+    sc = torch.full((n,), scale, device=DEV)
+    q = torch.full((n,), Q, device=DEV)
+    x = torch.round((mean + torch.randn(n, device=DEV, generator=g) * min(max(scale, 1e-3), 30.0)) / Q) * Q
+    f = os.path.join(str(tmp_path), "s.b")
+    _bytes, _nbits, mn, mx = enc.encoder_gaussian(x, mean, sc, q, file_name=f)
+    y = enc.decoder_gaussian(mean, sc, q, file_name=f, min_value=mn, max_value=mx)
+    assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 64])
+def test_knn_with_fewer_points_than_neighbours(n):
+    from contextgs_amd import knn
+    d = knn.distCUDA2(torch.randn(n, 3, device=DEV))
+    assert d.shape == (n,) and not bool(torch.isnan(d).any())
+    # the mean over three neighbours needs three neighbours: a missing one counts as FLT_MAX (so does the public simple_knn)
+    assert bool((d < 1e30).all()) == (n >= 4)
+    assert float(knn.distCUDA2(torch.zeros(10, 3, device=DEV)).abs().max()) == 0.0
