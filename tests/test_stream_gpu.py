@@ -20,3 +20,36 @@ def test_current_stream_follows_torch():
         side.synchronize()
         assert int(out[-1]) == x.numel() - 1
     assert _lib.current_stream() == torch.cuda.current_stream().cuda_stream
+
+
+def test_training_step_on_a_side_stream_equals_the_default_stream():
+    """Everything a step enqueues (kernels, the count copies and their events, torch's allocations) follows torch's current
+    stream: the same step inside torch.cuda.stream(side) gives the same image and, up to the blend backward's atomic order,
+    the same gradients."""
+    import itertools
+    from contextgs_amd import ctx_ops
+    from contextgs_amd.renderer import prefilter_voxel, render
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    pipe, bg = SynthPipe(), torch.zeros(3, device="cuda")
+    cam = orbit_cameras(2, 160, 96)[0].to_torch("cuda")
+    pc = make_scene(5000, seed=1)
+    pc.train()
+
+    def step():
+        torch.manual_seed(0)
+        ctx_ops._seed_counter = itertools.count(1)
+        pc.zero_grad()
+        vis = prefilter_voxel(cam, pc, pipe, bg)
+        pkg = render(cam, pc, pipe, bg, visible_mask=vis, step=20000)
+        (pkg["render"].sum() + pkg["bit_per_param"]).backward()
+        return pkg["render"].detach().clone(), {k: p.grad.clone() for k, p in pc.named_parameters() if p.grad is not None}
+
+    img0, g0 = step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        img1, g1 = step()
+    side.synchronize()
+    assert torch.equal(img0, img1) and set(g0) == set(g1)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-12, k
