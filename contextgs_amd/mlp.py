@@ -89,6 +89,16 @@ def _flush_deferred():
                 p.grad.add_(g)
 
 
+def _drop_stale_deferred():
+    """Called by the MLP nodes' FORWARD: a queue that is still armed then belongs to a backward that died before the engine
+    ran its callbacks (an exception in some node) — its jobs hold that step's buffers and must neither run nor keep the next
+    backward from arming a callback of its own."""
+    if _Deferred.armed or _Deferred.queue or _Deferred.staged:
+        _Deferred.armed = False
+        _Deferred.queue = []
+        _Deferred.staged = {}
+
+
 def _defer(job):
     _Deferred.queue.append(job)
     if not _Deferred.armed:
@@ -125,6 +135,7 @@ class _MLP2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, act):
         L = _lib.lib()
+        _drop_stale_deferred()
         _lib.require_device(x, W1, W2)
         x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
         W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
@@ -194,6 +205,7 @@ class _LevelMLP(torch.autograd.Function):
     def forward(ctx, x, loc, W1, b1, W2, b2, n_stat):
         from . import ctx_ops
         L = _lib.lib()
+        _drop_stale_deferred()
         _lib.require_device(x, W1, W2, loc)
         x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
         W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
@@ -349,6 +361,7 @@ class _AnchorMLP3(torch.autograd.Function):
     def forward(ctx, x, *params):
         # params: (W1, b1, W2, b2) x (opacity, color, cov)
         L = _lib.lib()
+        _drop_stale_deferred()
         _lib.require_device(x)
         x = x.contiguous() if x.dtype == torch.float32 else x.float().contiguous()
         p = [t.detach().contiguous() for t in params]
@@ -413,6 +426,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_src, src_row, anchor_vis, cam, *params):
         L = _lib.lib()
+        _drop_stale_deferred()
         f32c = lambda t: t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
         feat_src, anchor_vis, cam = f32c(feat_src.detach()), f32c(anchor_vis.detach()), f32c(cam.detach()).reshape(-1)
         _lib.require_device(feat_src, anchor_vis, cam, src_row)

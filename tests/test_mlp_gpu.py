@@ -226,3 +226,38 @@ def test_data_only_backward_rejects_a_partial_pointer_set():
     rc = L.cgs_mlp2_backward(71, 100, 175, 0, _lib.ptr(x), 71, _lib.ptr(W1), None, _lib.ptr(W2), None, _lib.ptr(dy), 175, _lib.ptr(h),
                              None, 71, 0, _lib.ptr(dz1), None, None, None, _lib.ptr(dW2), None, n, None, 0, _lib.current_stream())
     assert rc != 0
+
+
+def test_a_backward_that_dies_leaves_no_stale_deferred_jobs():
+    """Deferred mode: if a backward raises after an MLP node has queued its weight-gradient job, the engine never runs the
+    end-of-backward callback; the next step must neither execute that stale job nor lose its own weight gradients."""
+    from contextgs_amd import mlp
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(4)
+    seq = _seq(71, 100, 175, None)
+    x = torch.randn(500, 71, device="cuda")
+    prev = mlp.defer_weight_gradients(True)
+    try:
+        x_bad = torch.randn(300, 71, device="cuda", requires_grad=True)
+        y = mlp.mlp2(Boom.apply(x_bad), seq)                 # backward order: mlp node (queues its job), then Boom raises
+        with pytest.raises(RuntimeError, match="boom"):
+            y.sum().backward()
+        assert mlp._Deferred.armed and len(mlp._Deferred.queue) == 1 and all(p.grad is None for p in seq.parameters())
+        mlp.mlp2(x, seq).sum().backward()                     # a clean step afterwards
+        assert not mlp._Deferred.armed and not mlp._Deferred.queue and not mlp._Deferred.staged
+        got = [p.grad.clone() for p in seq.parameters()]
+    finally:
+        mlp.defer_weight_gradients(prev)
+    seq.zero_grad()
+    mlp.mlp2(x, seq).sum().backward()                         # the same step with inline weight gradients
+    for a, p in zip(got, seq.parameters()):
+        assert torch.equal(a, p.grad)
