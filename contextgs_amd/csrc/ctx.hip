@@ -113,6 +113,19 @@ __global__ void __launch_bounds__(256) rowcat_fwd_lds_kernel(RowcatArgs a, int64
     }
 }
 
+// One source, rows of whole float4s (e.g. the [N,12] hyper latents' gradient back through the coding permutation): out[r] =
+// src[idx[r]] with 16-byte accesses.
+__global__ void __launch_bounds__(256) rowgather4_kernel(const float4 *__restrict__ src, const int64_t *__restrict__ idx, int64_t n,
+                                                         int w4, int ld4, float4 *__restrict__ out) {
+    const int64_t total = n * w4;
+    const bool small = total < (1ll << 32);                      // 32-bit division (an emulated 64-bit one is ~5x the instructions)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = small ? (int64_t)((uint32_t)i / (uint32_t)w4) : i / w4;
+        const int c4 = (int)(i - r * w4);
+        out[i] = src[idx[r] * ld4 + c4];
+    }
+}
+
 // mode 0: no gradient; 1: store (rows of this source are distinct, or identity); 2: atomic add (rows repeat)
 __global__ void __launch_bounds__(256) rowcat_bwd_kernel(RowcatArgs a, int64_t n, const float *__restrict__ dout) {
     const int64_t total = n * a.W;
@@ -180,6 +193,13 @@ extern "C" int cgs_rowcat_fwd_masked(int nsrc, const void *const *data, const in
     if (n == 0) return CGS_OK;
     if (!out) { cgs_set_error("rowcat_fwd: NULL out"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    if (nsrc == 1 && a.idx[0] && !a.rmask[0] && !(a.W & 3) && !(a.ld[0] & 3) && !(((uintptr_t)a.src[0] | (uintptr_t)out) & 15) &&
+        n * (a.W / 4) < (1ll << 40)) {
+        hipLaunchKernelGGL(rowgather4_kernel, dim3(stream_grid(n * (a.W / 4), 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)a.src[0], a.idx[0], n, a.W / 4, a.ld[0] / 4, (float4 *)out);
+        CGS_CHECK_HIP(hipGetLastError());
+        return CGS_OK;
+    }
     // wide rows of several sources (the context rows of a level): staged through LDS; single narrow gathers: element-wise
     if (RC_LDS && nsrc >= 2 && a.W >= 16 && a.W <= 256 && n >= 4 * RC_ROWS && !((uintptr_t)out & 15)) {
         unsigned pair_mask = 0;

@@ -327,3 +327,13 @@ def test_scatter_rows_sorted_equals_zeros_index_copy(N, frac, w):
     if n:
         ref.index_copy_(0, idx, g)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("n,rows,w", [(1, 3, 4), (1000, 5000, 12), (70001, 70001, 8), (33, 40, 64)])
+def test_single_source_row_gather_with_whole_float4_rows(n, rows, w):
+    """gather_rows_nograd on rows of whole float4s takes the 16-byte kernel (rowgather4_kernel): == x[idx]."""
+    from contextgs_amd import ctx_ops
+    torch.manual_seed(n)
+    x = torch.randn(rows, w, device="cuda")
+    idx = torch.randint(0, rows, (n,), device="cuda")
+    assert torch.equal(ctx_ops.gather_rows_nograd(x, idx), x[idx])
