@@ -23,8 +23,6 @@
 struct XrSlot {
     float3 p, s;
     float4 q;
-    float sig[3];            // sigmoid of the three scale logits
-    float nrm, inv;          // |q_raw|, 1 / max(|q_raw|, 1e-12)   (used by the removed backward; free here)
 };
 
 // the per-slot arithmetic of expand_write_kernel (csrc/expand.hip), same operation order
@@ -34,16 +32,14 @@ __device__ __forceinline__ XrSlot xr_slot(const float *__restrict__ anchor3, con
     float pv[3], sv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        t.sig[c] = 1.f / (1.f + __expf(-sr[c]));
-        sv[c] = gs[3 + c] * t.sig[c];
+        sv[c] = gs[3 + c] * (1.f / (1.f + __expf(-sr[c])));
         pv[c] = anchor3[c] + off3[c] * gs[c];
     }
     t.p = make_float3(pv[0], pv[1], pv[2]);
     t.s = make_float3(sv[0], sv[1], sv[2]);
     const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
-    t.nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-    t.inv = 1.f / fmaxf(t.nrm, 1e-12f);   // F.normalize eps
-    t.q = make_float4(q0 * t.inv, q1 * t.inv, q2 * t.inv, q3 * t.inv);
+    const float inv = 1.f / fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);   // F.normalize eps
+    t.q = make_float4(q0 * inv, q1 * inv, q2 * inv, q3 * inv);
     return t;
 }
 
