@@ -188,7 +188,7 @@ def _cached_plan(pc, anchor, mask_anchor_bool):
                  mask=None if mask_anchor_bool is None else mask_anchor_bool.clone(), plan=plan,
                  inverse=inverse_indices_list, mapping=mapping_list, perm=perm, inv_perm=inv_perm, sizes=sizes,
                  ctx_idx=ctx_idx, ctx_pos=ctx_pos, ctx_csr=ctx_csr, covers_all=bool(perm.shape[0] == n),
-                 # anchors already stored in coding order (layout.reorder_anchors_to_coding_order): no permutation gathers
+                 # anchors already stored in coding order (e.g. a decoded model): no permutation gathers
                  identity=bool(perm.shape[0] == n and n > 0 and bool((perm == torch.arange(n, device=dev)).all())))
     try:
         pc._level_cache = cache
