@@ -70,6 +70,7 @@ def test_render_takes_the_fused_node_in_training_only():
     seen = []
     orig = renderer._ExpandRasterize.apply
     renderer._ExpandRasterize.apply = staticmethod(lambda *a: (seen.append(1), orig(*a))[1])
+    prev, renderer.FUSE_VIEW = renderer.FUSE_VIEW, True          # (the default; CGS_FUSE_VIEW=0 in the environment turns it off)
     try:
         pc = make_scene(3000, seed=1)
         cam = orbit_cameras(2, 96, 64)[0].to_torch("cuda")
@@ -84,6 +85,7 @@ def test_render_takes_the_fused_node_in_training_only():
         assert seen == [1]
     finally:
         renderer._ExpandRasterize.apply = orig
+        renderer.FUSE_VIEW = prev
 
 
 @pytest.mark.parametrize("fuse", [False, True])
