@@ -38,6 +38,7 @@ Q_FEAT0, Q_SCALING0, Q_OFFSETS0 = 1, 0.001, 0.2      # :1564-1566
 import os as _os
 LAZY_MODE = int(_os.environ.get("CGS_LAZY_MODE", "2"))   # tuning knob: 0 gather all, 1 defer feat, 2 defer feat+scaling+offsets
 FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip it to compare with the torch composition)
+HYPER_BLOCKS = _os.environ.get("CGS_HYPER_BLOCKS", "1") != "0"   # the noisy hyper latents leave their node one block per level
 ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = gather into coding order first
 RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
 
@@ -476,7 +477,8 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         hyp_p, likelihood_hyper = pc.latent_codec.training_step_forms(
             hyper, None if c.get("identity") else perm, None if c.get("identity") else c["inv_perm"], c["_nz"],
             pre[2] if pre is not None else _ctx.next_seed(), packed=begun.get("packed") if begun is not None else None,
-            noisy=pre[1] if pre is not None else None)
+            noisy=pre[1] if pre is not None else None, sizes=sizes if (HYPER_BLOCKS and len(sizes) <= 4) else None,
+            rows_orig=chosen_rows)
         hyper_feat = None
     elif FUSED_TRAINING and training and keep_stats and choose_mask is not None and hyper.is_cuda and eb_mine:
         rows_h = chosen_rows if chosen_rows is not None else torch.nonzero(_as_mask(choose_mask))[:, 0]
@@ -506,7 +508,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         feat_l = torch.split(in_order(feat), sizes)
         scal_l = torch.split(in_order(grid_scaling), sizes)
         off_l = torch.split(in_order(grid_offsets), sizes)
-    hyp_l = torch.split(hyp_p if hyp_p is not None else in_order(hyper_feat), sizes)
+    hyp_l = hyp_p if isinstance(hyp_p, tuple) else torch.split(hyp_p if hyp_p is not None else in_order(hyper_feat), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level

@@ -126,6 +126,59 @@ __global__ void __launch_bounds__(256) rowgather4_kernel(const float4 *__restric
     }
 }
 
+static unsigned stream_grid(int64_t total, int per_block);
+
+// out[a, 0:w] = row idx[a] (NULL: a) of the VIRTUAL concatenation of up to RC_MAX_SRC row blocks: block k holds rows
+// begin[k] .. begin[k+1] - 1 as src[k] + (r - begin[k]) * ld[k] (ld in floats; src[k] == NULL: zeros).  The gradient of the
+// hyper latents arrives as one block per level — two of them strided column slices of the levels' input-row gradients — and
+// leaves through the inverse coding permutation: one pass instead of cat + copy + gather.
+struct SegGatherArgs {
+    const float *src[RC_MAX_SRC];
+    int64_t ld[RC_MAX_SRC], begin[RC_MAX_SRC + 1];
+    int nseg;
+};
+
+__global__ void __launch_bounds__(256) gather_rows_segmented_kernel(SegGatherArgs a, const int64_t *__restrict__ idx, int64_t n, int w,
+                                                                    float *__restrict__ out) {
+    const int64_t total = n * w;
+    const bool small = total < (1ll << 32);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = small ? (int64_t)((uint32_t)i / (uint32_t)w) : i / w;
+        const int c = (int)(i - row * w);
+        const int64_t r = idx ? idx[row] : row;
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < RC_MAX_SRC; ++q)
+            if (q < a.nseg && r >= a.begin[q]) k = q;
+        const float *base = nullptr;
+        int64_t ld = 0, b0 = 0;
+#pragma unroll
+        for (int q = 0; q < RC_MAX_SRC; ++q)
+            if (q == k) { base = a.src[q]; ld = a.ld[q]; b0 = a.begin[q]; }
+        out[i] = base ? base[(r - b0) * ld + c] : 0.f;
+    }
+}
+
+extern "C" int cgs_gather_rows_segmented(int nseg, const float *const *src, const int64_t *ld, const int64_t *begin,
+                                         const int64_t *idx, int64_t n, int w, float *out, void *stream) {
+    if (nseg < 1 || nseg > RC_MAX_SRC || !src || !ld || !begin || n < 0 || w < 1) { cgs_set_error("gather_rows_segmented: bad args"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!out) { cgs_set_error("gather_rows_segmented: NULL out"); return CGS_ERR_ARG; }
+    SegGatherArgs a;
+    a.nseg = nseg;
+    for (int k = 0; k < RC_MAX_SRC; ++k) {
+        a.src[k] = k < nseg ? src[k] : nullptr;
+        a.ld[k] = k < nseg ? ld[k] : 0;
+        a.begin[k] = k < nseg ? begin[k] : begin[nseg];
+        if (k < nseg && (begin[k + 1] < begin[k] || (src[k] && ld[k] < w))) { cgs_set_error("gather_rows_segmented: bad block %d", k); return CGS_ERR_ARG; }
+    }
+    a.begin[RC_MAX_SRC] = begin[nseg];
+    CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(gather_rows_segmented_kernel, dim3(stream_grid(n * w, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, idx, n, w, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
 // mode 0: no gradient; 1: store (rows of this source are distinct, or identity); 2: atomic add (rows repeat)
 __global__ void __launch_bounds__(256) rowcat_bwd_kernel(RowcatArgs a, int64_t n, const float *__restrict__ dout) {
     const int64_t total = n * a.W;

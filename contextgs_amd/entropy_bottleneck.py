@@ -85,7 +85,7 @@ class _HyperStep(torch.autograd.Function):
     buffer that autograd then adds in full."""
 
     @staticmethod
-    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed, noisy=None):
+    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed, noisy=None, sizes=None, rows_orig=None):
         from . import _lib
         L = _lib.lib()
         x, packed = x.contiguous(), packed.contiguous()
@@ -106,13 +106,61 @@ class _HyperStep(torch.autograd.Function):
         n = int(rows_pos.shape[0]) if rows_pos is not None else N
         _lib.check(L.cgs_eb_bits_fwd(_lib.ptr(v), _lib.ptr(rows_pos), _lib.ptr(packed), n, C, _lib.ptr(ws), ws.numel(),
                                      _lib.ptr(bits), stream), "cgs_eb_bits_fwd")
-        ctx.save_for_backward(v, rows_pos, packed, inv_perm)
         ctx.n = n
+        ctx.sizes = None
+        if sizes is not None and rows_pos is not None and (rows_orig is not None or perm is None) and len(sizes) <= 4:
+            # sizes: the noisy latents leave as one row block per level (views of v) — their gradients then come back
+            # block by block and go through the inverse permutation in ONE pass (cgs_gather_rows_segmented) instead of
+            # autograd's cat of the split + a copy + a gather.  rows_orig = perm[rows_pos] (the subset's anchor rows).
+            ctx.sizes = tuple(int(t) for t in sizes)
+            assert sum(ctx.sizes) == N
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(v, rows_pos, packed, inv_perm, rows_orig if rows_orig is not None else rows_pos)
+            return (*torch.split(v, ctx.sizes), bits)
+        ctx.save_for_backward(v, rows_pos, packed, inv_perm)
         return v, bits
 
     @staticmethod
-    def backward(ctx, g_v, g_bits):
+    def _backward_blocks(ctx, *gs):
+        from . import _lib
+        import ctypes as C_
+        L = _lib.lib()
+        v, rows, packed, inv_perm, rows_orig = ctx.saved_tensors
+        n, (N, C) = ctx.n, v.shape
+        g_blocks, g_bits = gs[:-1], gs[-1]
+        dev = v.device
+        stream = _lib.current_stream()
+        g_p = g_sub = None
+        if g_bits is not None:
+            g_sub = torch.empty(n, C, dtype=torch.float32, device=dev)
+            g_p = torch.zeros_like(packed)
+            _lib.check(L.cgs_eb_bits_bwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), _lib.ptr(g_bits.contiguous()), n, C,
+                                         _lib.ptr(g_sub), _lib.ptr(g_p), stream), "cgs_eb_bits_bwd")
+        if all(g is None for g in g_blocks) and g_sub is None:
+            return (None,) * 9
+        srcs, lds, begin = [], [], [0]
+        for g, sz in zip(g_blocks, ctx.sizes):
+            if g is not None and (g.dtype != torch.float32 or g.stride(1) != 1 or (sz > 1 and g.stride(0) < C)):
+                g = g.float().contiguous()
+            srcs.append(g)
+            lds.append(int(g.stride(0)) if (g is not None and sz > 0) else C)
+            begin.append(begin[-1] + sz)
+        k = len(srcs)
+        g_x = torch.empty(N, C, dtype=torch.float32, device=dev)
+        _lib.check(L.cgs_gather_rows_segmented(
+            k, (C_.c_void_p * k)(*[None if (t is None or t.numel() == 0) else t.data_ptr() for t in srcs]),
+            (C_.c_int64 * k)(*lds), (C_.c_int64 * (k + 1))(*begin), _lib.ptr(inv_perm), N, C, _lib.ptr(g_x), stream),
+            "cgs_gather_rows_segmented")
+        if g_sub is not None:
+            g_x.index_add_(0, rows_orig, g_sub)          # the rate subset's rows (distinct), in parameter order
+        return g_x, None, None, None, g_p, None, None, None, None
+
+    @staticmethod
+    def backward(ctx, *gs):
         from . import _lib, ctx_ops
+        if ctx.sizes is not None:
+            return _HyperStep._backward_blocks(ctx, *gs)
+        g_v, g_bits = gs
         v, rows, packed, inv_perm = ctx.saved_tensors
         n, C = ctx.n, v.shape[1]
         g_p = None
@@ -130,11 +178,11 @@ class _HyperStep(torch.autograd.Function):
                 g_v = torch.zeros_like(v) if g_v is None else g_v.clone(memory_format=torch.contiguous_format)
                 g_v.index_add_(0, rows, g_sub)
         if g_v is None:
-            return None, None, None, None, g_p, None, None
+            return None, None, None, None, g_p, None, None, None, None
         # rows of 48 bytes: torch's index_select takes its slow "vectorized gather" path for 16-byte-multiple rows
         # (210 us for [1 M, 12] on gfx950); the one-source rowcat kernel does the same gather in ~35 us
         g_x = g_v if inv_perm is None else ctx_ops.gather_rows_nograd(g_v, inv_perm)
-        return g_x, None, None, None, g_p, None, None
+        return g_x, None, None, None, g_p, None, None, None, None
 
 
 class HyperBitSum:
@@ -334,15 +382,18 @@ class EntropyBottleneck(nn.Module):
                                                      _lib.ptr(v), _lib.current_stream()), "cgs_hyper_noise_gather")
         return x, v, int(seed)
 
-    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int, packed=None, noisy=None):
+    def training_step_forms(self, x: torch.Tensor, perm, inv_perm, rows_pos, seed: int, packed=None, noisy=None, sizes=None,
+                            rows_orig=None):
         """Training-step entry (extension): (noisy latents in coding order [N,C], HyperBitSum over the coding-order
         positions rows_pos) — forward(x, training=True) restricted to what scene/gaussian_model.py:1556-1707 consumes,
         in two launches.  perm / inv_perm: the coding-order permutation and its inverse (None: identity)."""
         assert x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 2 and x.shape[1] == self.channels
         # packed: self._packed_params() evaluated earlier by the caller (the renderer does it before a host read-back, so
         # that the GPU has the launch queued while the host waits)
-        v_p, bits = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed,
-                                     noisy)
+        # sizes (optional): return the noisy latents as one row block per level (a tuple) — see _HyperStep.forward
+        out = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed, noisy,
+                               sizes, rows_orig)
+        v_p, bits = (out[0], out[1]) if len(out) == 2 else (tuple(out[:-1]), out[-1])
         n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
         return v_p, HyperBitSum(bits, n_rows * self.channels)
 

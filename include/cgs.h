@@ -502,6 +502,15 @@ int cgs_anchor_mlp3_wgrad(const float *X, int64_t ldx, const float *Hcat, const 
                           float *dW1cat, float *db1cat, float *const *dW2, float *const *db2,
                           int64_t n, void *scratch, size_t scratch_bytes, void *stream);
 
+/* out[a, 0:w] = row idx[a] (idx == NULL: row a) of the virtual concatenation of nseg (<= 4) row blocks: block k = rows
+ * begin[k] .. begin[k+1]-1, row r at src[k] + (r - begin[k]) * ld[k] floats (src[k] == NULL: zeros).  src / ld / begin are
+ * HOST arrays (begin has nseg + 1 entries).  The backward of the hyper latents' per-level slices
+ * (scene/gaussian_model.py:1594-1600, :1650-1651 consume them level by level): the levels' gradients, two of them strided
+ * column slices, leave through the inverse coding permutation in one pass. */
+int cgs_gather_rows_segmented(int nseg, const float *const *src, const int64_t *ld,
+                              const int64_t *begin, const int64_t *idx, int64_t n, int w,
+                              float *out, void *stream);
+
 /* Factorised-prior likelihood of the hyper latents (EntropyBottleneck.forward,
  * scene/gaussian_model.py:1556; compressai is not in the mount, the density is
  * the one of utils/entropy_models.py:103-138 with filters (3,3,3,3)).  v, lik,

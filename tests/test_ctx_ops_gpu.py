@@ -337,3 +337,31 @@ def test_single_source_row_gather_with_whole_float4_rows(n, rows, w):
     x = torch.randn(rows, w, device="cuda")
     idx = torch.randint(0, rows, (n,), device="cuda")
     assert torch.equal(ctx_ops.gather_rows_nograd(x, idx), x[idx])
+
+
+@pytest.mark.parametrize("with_idx", [True, False])
+def test_gather_rows_segmented_equals_cat_then_gather(with_idx):
+    """cgs_gather_rows_segmented: rows of the virtual concatenation of row blocks (one contiguous, one a strided column slice,
+    one missing = zeros, one empty) through an index — == cat(blocks)[idx]."""
+    import ctypes as C
+    from contextgs_amd import _lib
+    torch.manual_seed(0)
+    w = 12
+    a = torch.randn(37, w, device="cuda")
+    big = torch.randn(1000, 71, device="cuda")
+    b = big[:, 59:71]                                         # strided block: row stride 71 floats
+    sizes = [37, 1000, 50, 0]
+    blocks = [a, b, None, torch.zeros(0, w, device="cuda")]
+    ref_cat = torch.cat([a, b, torch.zeros(50, w, device="cuda")])
+    N = sum(sizes)
+    idx = torch.randperm(N, device="cuda") if with_idx else None
+    begin = [0]
+    for s_ in sizes:
+        begin.append(begin[-1] + s_)
+    out = torch.full((N, w), float("nan"), device="cuda")
+    k = len(blocks)
+    _lib.check(_lib.lib().cgs_gather_rows_segmented(
+        k, (C.c_void_p * k)(*[None if (t is None or t.numel() == 0) else t.data_ptr() for t in blocks]),
+        (C.c_int64 * k)(*[w if (t is None or t.numel() == 0) else int(t.stride(0)) for t in blocks]),
+        (C.c_int64 * (k + 1))(*begin), _lib.ptr(idx), N, w, _lib.ptr(out), _lib.current_stream()), "cgs_gather_rows_segmented")
+    assert torch.equal(out, ref_cat[idx] if with_idx else ref_cat)
