@@ -506,11 +506,14 @@ class _MaskSTE(torch.autograd.Function):
                    "cgs_mask_ste_fwd")
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(alive)
+        ctx.set_materialize_grads(False)       # no zeros [N] for the gradient of the (bool) `alive` output
         return mask, alive
 
     @staticmethod
     def backward(ctx, g, _g_alive):
         (x,) = ctx.saved_tensors
+        if g is None:
+            return None
         d = torch.empty_like(x)
         _lib.check(_lib.lib().cgs_mask_ste_bwd(_lib.ptr(x), _lib.ptr(_c(g)), x.numel(), _lib.ptr(d), _lib.current_stream()),
                    "cgs_mask_ste_bwd")

@@ -77,6 +77,7 @@ class Quantize_anchor(torch.autograd.Function):             # :219-231
                                                   anchor_round_digits, _lib.ptr(aq), _lib.ptr(qv),
                                                   _lib.current_stream()), "cgs_quantize_anchor")
         ctx.mark_non_differentiable(qv)
+        ctx.set_materialize_grads(False)       # no zeros [N,3] for the gradient of the non-differentiable second output
         return aq, qv
 
     @staticmethod
