@@ -159,7 +159,7 @@ class _RowSourceFn(torch.autograd.Function):
     def forward(ctx, src, feat, scal, off):
         ctx.src = src
         ctx.set_materialize_grads(False)     # the token's gradient carries nothing: no zeros(1) for it
-        return feat.new_zeros(1)
+        return feat.new_empty(1)             # (its VALUE is never read either: no fill launch)
 
     @staticmethod
     def backward(ctx, _g):
