@@ -289,8 +289,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
      bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(path("meta.b"), map_location="cpu",
                                                                                           weights_only=False)
-    # (map_location: the nine scalar tensors of the header are only ever read as Python numbers; restoring them on the device
-    #  cost an allocation + copy each and a stream drain per .item() — ~10 ms in front of BOTH critical chains of the decoder)
+    # (map_location: whatever tensors a header holds — the reference stores its minima / maxima as device tensors — are only
+    #  ever read as Python numbers here: restoring them on the device would cost a copy each and a stream drain per .item())
     tr("meta.b loaded")
     K, D, H = pc.n_offsets, pc.feat_dim, pc.feat_dim // pc.hyper_divisor
     N_levels_list = list(reversed(N_levels_list))
