@@ -343,6 +343,9 @@ def _join_device_slices(parts):
 _PINNED = {}
 
 
+_STAGE_STREAMS = {}
+
+
 class StagedFiles:
     """The bitstream files of a container, read into ONE pinned host buffer and copied to ONE device buffer by a host
     thread on a side stream while the caller does something else (conduct_decoding: the hyper prior's rANS strings and the
@@ -361,7 +364,12 @@ class StagedFiles:
             pos += n
         self.total = pos
         self.device = device
-        self.stream = torch.cuda.Stream(device=device)
+        # ONE staging stream per device for the life of the process: the caching allocator keeps a pool per stream, so a fresh
+        # stream per container meant a fresh ~120 MB hipMalloc for dev_buf in front of every decode (~5 ms on its critical path)
+        skey = str(device)
+        self.stream = _STAGE_STREAMS.get(skey)
+        if self.stream is None:
+            self.stream = _STAGE_STREAMS[skey] = torch.cuda.Stream(device=device)
         # allocated UNDER the side stream (the caching allocator then never hands out a block that kernels queued on
         # the caller's stream may still be reading); consumers on other streams are registered in get()
         self.stream.wait_stream(torch.cuda.current_stream(device))

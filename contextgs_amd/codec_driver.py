@@ -286,6 +286,9 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     tr = _tracer("decode")
     print("Start decoding ...")
     path = lambda name: os.path.join(pre_path_name, name)
+    # anchor.npy (12 MB at 1 M anchors) is read and converted on a host thread while this one loads the header, the MLPs and
+    # the prior tables: the level plan — the first thing the device chain waits for — needs nothing else from the files
+    anchor_job = codec.host_pool().submit(lambda: np.load(path("anchor.npy")).astype(np.int32))
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
      bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(path("meta.b"), map_location="cpu",
                                                                                           weights_only=False)
@@ -304,14 +307,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     pc.latent_codec.update(force=True)
     tr("prior tables rebuilt")
     dev = pc.x_bound_min.device
-    # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
-    # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
-    n_lv = len(N_levels_list)
-    order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
-            [f"offsets{l}.b" for l in reversed(range(n_lv))]
-    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
-
-    tr("file staging started")
+    # the hyper strings are decoded by host threads (straight into a pinned [N_valid, H] buffer) while this thread stages the
+    # files, loads the anchors and builds the level plan; submitted FIRST: the first level's prediction waits for them
     with open(path("hyper.b"), "rb") as f:
         hyper_stream = f.read()
     pos, strings, sizes = 0, [], []
@@ -320,12 +317,18 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         strings.append(hyper_stream[pos:pos + nb])
         sizes.append(min(max_batch * 10, N_valid - s0))
         pos += nb
-    tr("meta / tables / staging started")
-    # the hyper strings are decoded by host threads (straight into a pinned [N_valid, H] buffer) while this thread
-    # loads the anchors and builds the level plan, which need nothing but anchor.npy
     hyper_job = pc.latent_codec.decompress_chunks_rows(strings, sizes)
+    tr("hyper rANS jobs submitted")
+    # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
+    # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
+    n_lv = len(N_levels_list)
+    order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
+            [f"offsets{l}.b" for l in reversed(range(n_lv))]
+    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
 
-    q = torch.from_numpy(np.load(path("anchor.npy")).astype(np.int32)).to(dev)           # :1340-1342
+    tr("file staging started")
+
+    q = torch.from_numpy(anchor_job.result()).to(dev)                                    # :1340-1342
     interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
     anchor_decoded = q * interval + pc.x_bound_min
 
