@@ -932,14 +932,37 @@ static int rans_decode_impl(const uint8_t *in, size_t in_len, int C_, int64_t n,
                             const float *medians, float *out_rows, int64_t ld_rows) {
     RansDec dec;
     dec.init(in, in_len);
+    // Symbol search: the largest v in [0, max_value] with tab[v] <= t.  A 256-slot table per channel over the top 8 bits of
+    // t gives the answer for the slot's first value, a short forward scan the rest (0-1 steps for the ~60-entry tables of
+    // the hyper prior) — a binary search is six unpredictable branches per symbol, and the 12 M hyper symbols of a 1 M-anchor
+    // container sit on the decoder's critical path.  Same symbols (the scan stops at exactly the searched v).
+    const bool use_lut = prec >= 8 && prec <= 24 && C_ <= 64 && n * C_ >= 4096;
+    uint16_t lut[64 * 256];
+    if (use_lut)
+        for (int c = 0; c < C_; ++c) {
+            const int32_t *tab = cdf + (size_t)c * max_len;
+            const int max_value = cdf_len[c] - 2;
+            int v = 0;
+            for (int sl = 0; sl < 256; ++sl) {
+                const uint32_t t0 = (uint32_t)sl << (prec - 8);
+                while (v < max_value && (uint32_t)tab[v + 1] <= t0) ++v;
+                lut[c * 256 + sl] = (uint16_t)v;
+            }
+        }
     for (int64_t i = 0; i < n; ++i)
         for (int c = 0; c < C_; ++c) {
             const int32_t *tab = cdf + (size_t)c * max_len;
             const int max_value = cdf_len[c] - 2;
             const uint32_t t = dec.peek(prec);
-            int lo = 0, hi = max_value + 1;                // largest v with tab[v] <= t
-            while (lo + 1 < hi) { const int m = (lo + hi) >> 1; if ((uint32_t)tab[m] <= t) lo = m; else hi = m; }
-            int value = lo;
+            int value;
+            if (use_lut) {
+                value = lut[c * 256 + (t >> (prec - 8))];
+                while (value < max_value && (uint32_t)tab[value + 1] <= t) ++value;
+            } else {
+                int lo = 0, hi = max_value + 1;            // largest v with tab[v] <= t
+                while (lo + 1 < hi) { const int m = (lo + hi) >> 1; if ((uint32_t)tab[m] <= t) lo = m; else hi = m; }
+                value = lo;
+            }
             dec.advance((uint32_t)tab[value], (uint32_t)(tab[value + 1] - tab[value]), prec);
             if (value == max_value) {
                 const int sign = (int)dec.get_bit();
