@@ -197,6 +197,10 @@ def lib() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # torch FIRST: it ships its own libamdhip64, and whichever HIP runtime is loaded first is the one the process uses.
+        # With libcgs_hip.so loaded before torch (e.g. __graft_entry__.build() followed by smoke() in one process) the two
+        # ended up with a runtime each and this library's saw "no ROCm-capable device".
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found. Build it with `python -m contextgs_amd.build` "
