@@ -53,3 +53,20 @@ def test_training_step_on_a_side_stream_equals_the_default_stream():
     assert torch.equal(img0, img1) and set(g0) == set(g1)
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-12, k
+
+
+def test_library_loaded_before_torch_shares_torch_s_hip_runtime():
+    """A process that touches the library before it imports torch (the driver's build() then smoke()) must end up with ONE
+    HIP runtime: _lib.lib() imports torch first.  Run in a fresh interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import __graft_entry__ as g\n"
+            "g.build()\n"
+            "assert 'torch' in sys.modules\n"
+            "g.smoke()\n"
+            "print('both ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "both ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
