@@ -137,21 +137,13 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     print("Start encoding ...")
     root = mgpu.rank() == 0          # multi-GPU: every rank predicts/quantises, codes its block of streams; rank 0 writes
     os.makedirs(pre_path_name, exist_ok=True)
-    pc.latent_codec.update(force=True)
     K, D = pc.n_offsets, pc.feat_dim
     path = lambda name: os.path.join(pre_path_name, name)
 
-    tr("tables updated")
+    # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream and the longest chain of the encoder (10 M symbols on
+    # a host thread): it is started FIRST, before the prior tables and the other per-anchor gathers
     mask_anchor = pc.get_mask_anchor
-    _anchor, quantized_anchor = Quantize_anchor.apply(pc._anchor[mask_anchor], pc.x_bound_min, pc.x_bound_max)
-    _feat = pc._anchor_feat[mask_anchor]
-    _grid_offsets = pc._offset[mask_anchor]
-    _scaling = pc.get_scaling[mask_anchor]
     _mask = pc.get_mask[mask_anchor]
-    _hyper_latent = pc._hyper_latent[mask_anchor]
-
-    tr("valid anchors gathered")
-    # the mask stream (:1265-1269) is ONE serial arithmetic-coded stream: start it on a host thread now
     prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
     if root:
         mask_sym = codec.to_host_pinned(torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16), "mask symbols")
@@ -161,6 +153,14 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         # has been enqueued: ~100 short jobs finishing on the pool make the main thread queue for the GIL, which
         # stretched the 7 ms of launch code below to 38 ms when they ran beside it
         hyper_jobs = None
+    pc.latent_codec.update(force=True)
+    tr("tables updated")
+    _anchor, quantized_anchor = Quantize_anchor.apply(pc._anchor[mask_anchor], pc.x_bound_min, pc.x_bound_max)
+    _feat = pc._anchor_feat[mask_anchor]
+    _grid_offsets = pc._offset[mask_anchor]
+    _scaling = pc.get_scaling[mask_anchor]
+    _hyper_latent = pc._hyper_latent[mask_anchor]
+    tr("valid anchors gathered")
 
     # Q3: the encoder feeds integer SYMBOLS to the context MLP (:1040,1164)
     hyper_feat = pc.latent_codec.quantize(_hyper_latent, "symbols", means=pc.latent_codec._get_medians().permute(1, 2, 0)[0])
