@@ -66,8 +66,10 @@ __global__ void __launch_bounds__(EX_THREADS)
 #define EX_APB 32          // anchors per workgroup in the backward
 
 // One thread per slot (coalesced reads/writes of every per-slot array); the nine per-anchor sums
-// (d_anchor 3, d_gscaling 6) are reduced over the anchor's K slots with LDS float atomics.
-// Workgroup = EX_APB anchors x K slots.
+// (d_anchor 3, d_gscaling 6) are reduced over the anchor's K slots through LDS: every slot stores its nine terms
+// (part[c][thread], conflict-free), then one thread per (anchor, sum) adds the K terms in slot order — deterministic,
+// and no LDS float atomics (ten slots of an anchor hit the same address; ds_add_f32 retires < 1 lane per clock).
+// Workgroup = EX_APB anchors x K slots; dynamic LDS = 9 * blockDim floats.
 __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
     expand_bwd_kernel(int64_t n_anchor, int K, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
                       const float *__restrict__ gscaling, const float *__restrict__ offsets,
@@ -79,11 +81,11 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
                       float *__restrict__ d_anchor, float *__restrict__ d_gscaling, float *__restrict__ d_offsets,
                       float *__restrict__ d_op_raw, float *__restrict__ d_mask, float *__restrict__ d_color_in,
                       float *__restrict__ d_cov_in, const int64_t *__restrict__ src_row) {
-    __shared__ float acc[EX_APB][9];
+    extern __shared__ float part[];            // [9][blockDim.x]
     __shared__ float sgs[EX_APB][6];
     const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
     const int64_t a0 = (int64_t)blockIdx.x * EX_APB;
-    for (int t = tid; t < EX_APB * 9; t += blockDim.x) acc[t / 9][t % 9] = 0.f;
     for (int t = tid; t < EX_APB * 6; t += blockDim.x) {
         const int64_t n = a0 + t / 6;
         sgs[t / 6][t % 6] = n < n_anchor ? gscaling[6 * (src_row ? src_row[n] : n) + t % 6] : 0.f;
@@ -97,6 +99,7 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
         const int64_t si = src_row ? src_row[n] * K + (tid - la * K) : i;
         float g_no = g_neural_opacity ? g_neural_opacity[i] : 0.f;
         float dcol[3] = {0.f, 0.f, 0.f}, doff[3] = {0.f, 0.f, 0.f}, dsr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float term[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (flags[i]) {
             const size_t j = pos[i];
             g_no += g_opacity[j];
@@ -109,9 +112,9 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
                 const float sig = 1.f / (1.f + __expf(-sr[c]));
                 const float gsc = g_scaling[3 * j + c];
                 dsr[c] = gsc * gs[3 + c] * sig * (1.f - sig);
-                atomicAdd(&acc[la][c], gx);
-                atomicAdd(&acc[la][3 + c], gx * offsets[3 * si + c]);
-                atomicAdd(&acc[la][6 + c], gsc * sig);
+                term[c] = gx;
+                term[3 + c] = gx * offsets[3 * si + c];
+                term[6 + c] = gsc * sig;
             }
             const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
             const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
@@ -137,14 +140,19 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
         }
 #pragma unroll
         for (int c = 0; c < 7; ++c) d_cov_in[7 * i + c] = dsr[c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) part[c * nthr + tid] = term[c];
     }
     __syncthreads();
-    for (int t = tid; t < EX_APB * 9; t += blockDim.x) {
-        const int64_t nn = a0 + t / 9;
-        const int c = t % 9;
+    for (int t = tid; t < EX_APB * 9; t += nthr) {
+        const int c = t / EX_APB, a = t - c * EX_APB;       // neighbours differ in the anchor: LDS stride K
+        const int64_t nn = a0 + a;
         if (nn < n_anchor) {
-            if (c < 3) d_anchor[3 * nn + c] = acc[t / 9][c];
-            else d_gscaling[6 * (src_row ? src_row[nn] : nn) + (c - 3)] = acc[t / 9][c];
+            const float *q = part + c * nthr + a * K;
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) sum += q[k];
+            if (c < 3) d_anchor[3 * nn + c] = sum;
+            else d_gscaling[6 * (src_row ? src_row[nn] : nn) + (c - 3)] = sum;
         }
     }
 }
@@ -249,7 +257,7 @@ extern "C" int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flag
     if (n_anchor == 0) return CGS_OK;
     CgsProfScope prof(CGS_PROF_EXPAND_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((n_anchor + EX_APB - 1) / EX_APB)),
-                       dim3(EX_APB * K), 0, (hipStream_t)stream, n_anchor, K, flags, pos, gscaling, offsets, op_raw,
+                       dim3(EX_APB * K), (size_t)9 * EX_APB * K * sizeof(float), (hipStream_t)stream, n_anchor, K, flags, pos, gscaling, offsets, op_raw,
                        mask, cov_in, g_xyz, g_color, g_opacity, g_scaling, g_rot, g_neural_opacity, d_anchor,
                        d_gscaling, d_offsets, d_op_raw, d_mask, d_color_in, d_cov_in, src_row);
     CGS_CHECK_HIP(hipGetLastError());

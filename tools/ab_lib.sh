@@ -9,6 +9,6 @@ for rep in $(seq 1 $reps); do
     CGS_LIB_PATH=$L python bench.py $F 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.readlines()[-1]); k=j['kernels']
-print('lib=${L:-product} rep=$rep', j['value'], 'views/s', j['ms_per_step'], 'ms |', ' '.join('%s %.0fx%d' % (n, k[n]['avg_us'], k[n]['launches']//j['steps']) for n in ('ctx_fwd','ctx_bwd','expand_fwd','rate_fwd','rate_bwd')))"
+print('lib=${L:-product} rep=$rep', j['value'], 'views/s', j['ms_per_step'], 'ms |', ' '.join('%s %.0fx%d' % (n, k[n]['avg_us'], k[n]['launches']//j['steps']) for n in ('ctx_fwd','ctx_bwd','expand_bwd','rate_fwd','rate_bwd')))"
   done
 done | tee gpurun_out/ab_lib.txt
