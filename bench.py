@@ -68,10 +68,10 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
         if pkg["bit_per_param"] is not None:
             loss = loss + 0.001 * pkg["bit_per_param"]          # lambda * rate term (train.py:206-209)
     else:
-        from contextgs_amd.loss_utils import training_image_loss
-        loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * pkg["scaling"].prod(dim=1).mean()
+        from contextgs_amd.loss_utils import training_image_loss, scaling_reg, mask_reg
+        loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * scaling_reg(pkg["scaling"])     # train.py:203-204
         if pkg["bit_per_param"] is not None:
-            loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
+            loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * mask_reg(pc._mask)                    # train.py:207-209
     loss.backward()
     if sync is not None:
         sync.finish()        # RCCL over xGMI: per-anchor tensors in place (started from gradient hooks), MLPs as one bucket

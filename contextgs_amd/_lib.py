@@ -174,6 +174,11 @@ SIGNATURES = {
     "cgs_l1_ssim_partials": (c_size_t, [c_int, c_int, c_int]),
     "cgs_l1_ssim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_l1_ssim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cgs_reg_partials": (c_size_t, [c_int64]),
+    "cgs_scaling_reg_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "cgs_scaling_reg_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "cgs_sigmoid_mean_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "cgs_sigmoid_mean_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_anchor_gen_count": (c_int, [c_void_p] * 14 + [c_int64, c_int, C.POINTER(c_int64), c_void_p]),
     "cgs_anchor_gen_write": (c_int, [c_void_p] * 20 + [c_int64, c_int, c_void_p]),
     "cgs_anchor_gen_bwd_scratch_bytes": (c_size_t, [c_int64, c_int]),

@@ -181,3 +181,130 @@ extern "C" int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *m
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// The two regularisers of the training loss next to the image terms (train.py:203,209):
+//     scaling_reg = scaling.prod(dim=1).mean()                 scaling [P,3], the visible Gaussians' scales
+//     mask_reg    = torch.mean(torch.sigmoid(gaussians._mask))
+// As torch operators the first is a strided product reduction, a mean and — in the backward — an `input == 0` count that
+// is read back on the HOST (prod's zero-safe gradient) followed by grad * result / input: a stream drain in the middle
+// of every backward plus ~8 passes over P x 3 floats; the second is ~5 passes over the 10 M mask logits.  Here: one
+// streaming launch each way, per-workgroup partial sums (summed by the caller, deterministic), gradients written
+// directly: d scaling[i][c] = g / P * (product of the other two), d x = g / n * s (1 - s).
+#define RG_THREADS 256
+#define RG_MAX_BLOCKS 2048
+
+__global__ void __launch_bounds__(RG_THREADS)
+    scaling_reg_fwd_kernel(const float *__restrict__ s, int64_t P, float *__restrict__ partials) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const int64_t quads = P / 4;       // four rows = three float4 (the caller checked the 16-byte alignment)
+    for (int64_t q = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x; q < quads; q += (int64_t)gridDim.x * RG_THREADS) {
+        const float4 a = ((const float4 *)s)[3 * q], b = ((const float4 *)s)[3 * q + 1], c = ((const float4 *)s)[3 * q + 2];
+        acc += (a.x * a.y * a.z + a.w * b.x * b.y) + (b.z * b.w * c.x + c.y * c.z * c.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(P - 4 * quads)) {
+        const float *r = s + 3 * (4 * quads + threadIdx.x);
+        acc += r[0] * r[1] * r[2];
+    }
+    const float tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(RG_THREADS)
+    scaling_reg_bwd_kernel(const float *__restrict__ s, const float *__restrict__ g, int64_t P, float *__restrict__ d) {
+    const float c0 = g[0] / (float)P;
+    const int64_t quads = P / 4;
+    for (int64_t q = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x; q < quads; q += (int64_t)gridDim.x * RG_THREADS) {
+        const float4 a = ((const float4 *)s)[3 * q], b = ((const float4 *)s)[3 * q + 1], c = ((const float4 *)s)[3 * q + 2];
+        float4 o0, o1, o2;
+        o0.x = c0 * (a.y * a.z); o0.y = c0 * (a.x * a.z); o0.z = c0 * (a.x * a.y);
+        o0.w = c0 * (b.x * b.y); o1.x = c0 * (a.w * b.y); o1.y = c0 * (a.w * b.x);
+        o1.z = c0 * (b.w * c.x); o1.w = c0 * (b.z * c.x); o2.x = c0 * (b.z * b.w);
+        o2.y = c0 * (c.z * c.w); o2.z = c0 * (c.y * c.w); o2.w = c0 * (c.y * c.z);
+        ((float4 *)d)[3 * q] = o0; ((float4 *)d)[3 * q + 1] = o1; ((float4 *)d)[3 * q + 2] = o2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(P - 4 * quads)) {
+        const int64_t i = 3 * (4 * quads + threadIdx.x);
+        d[i] = c0 * (s[i + 1] * s[i + 2]); d[i + 1] = c0 * (s[i] * s[i + 2]); d[i + 2] = c0 * (s[i] * s[i + 1]);
+    }
+}
+
+__device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void __launch_bounds__(RG_THREADS)
+    sigmoid_mean_fwd_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ partials) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    const int64_t quads = n / 4;
+    for (int64_t q = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x; q < quads; q += (int64_t)gridDim.x * RG_THREADS) {
+        const float4 a = ((const float4 *)x)[q];
+        acc += (rg_sigmoid(a.x) + rg_sigmoid(a.y)) + (rg_sigmoid(a.z) + rg_sigmoid(a.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * quads)) acc += rg_sigmoid(x[4 * quads + threadIdx.x]);
+    const float tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(RG_THREADS)
+    sigmoid_mean_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, int64_t n, float *__restrict__ d) {
+    const float c0 = g[0] / (float)n;
+    const int64_t quads = n / 4;
+    for (int64_t q = (int64_t)blockIdx.x * RG_THREADS + threadIdx.x; q < quads; q += (int64_t)gridDim.x * RG_THREADS) {
+        const float4 a = ((const float4 *)x)[q];
+        const float s0 = rg_sigmoid(a.x), s1 = rg_sigmoid(a.y), s2 = rg_sigmoid(a.z), s3 = rg_sigmoid(a.w);
+        ((float4 *)d)[q] = make_float4(c0 * s0 * (1.f - s0), c0 * s1 * (1.f - s1), c0 * s2 * (1.f - s2), c0 * s3 * (1.f - s3));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * quads)) {
+        const float s0 = rg_sigmoid(x[4 * quads + threadIdx.x]);
+        d[4 * quads + threadIdx.x] = c0 * s0 * (1.f - s0);
+    }
+}
+
+static unsigned rg_grid(int64_t quads) {
+    const int64_t b = (quads + RG_THREADS - 1) / RG_THREADS;
+    return (unsigned)(b < 1 ? 1 : (b > RG_MAX_BLOCKS ? RG_MAX_BLOCKS : b));
+}
+
+extern "C" size_t cgs_reg_partials(int64_t n) { return n < 0 ? 0 : (size_t)rg_grid(n / 4); }
+
+static int rg_check(const char *who, const void *x, const void *out, int64_t n) {
+    if (n < 1) { cgs_set_error("%s: n < 1", who); return CGS_ERR_ARG; }
+    if (!x || !out) { cgs_set_error("%s: NULL", who); return CGS_ERR_ARG; }
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 3)) { cgs_set_error("%s: the input must be 16-byte aligned", who); return CGS_ERR_ARG; }
+    return CGS_OK;
+}
+
+extern "C" int cgs_scaling_reg_fwd(const float *scaling, int64_t P, float *partials, void *stream) {
+    if (int rc = rg_check("scaling_reg_fwd", scaling, partials, P)) return rc;
+    CgsProfScope prof(CGS_PROF_LOSS_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(scaling_reg_fwd_kernel, dim3(rg_grid(P / 4)), dim3(RG_THREADS), 0, (hipStream_t)stream, scaling, P, partials);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_scaling_reg_bwd(const float *scaling, const float *g, int64_t P, float *d_scaling, void *stream) {
+    if (int rc = rg_check("scaling_reg_bwd", scaling, d_scaling, P)) return rc;
+    if (!g || ((uintptr_t)d_scaling & 15)) { cgs_set_error("scaling_reg_bwd: g NULL or d_scaling not 16-byte aligned"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(scaling_reg_bwd_kernel, dim3(rg_grid(P / 4)), dim3(RG_THREADS), 0, (hipStream_t)stream, scaling, g, P, d_scaling);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_sigmoid_mean_fwd(const float *x, int64_t n, float *partials, void *stream) {
+    if (int rc = rg_check("sigmoid_mean_fwd", x, partials, n)) return rc;
+    CgsProfScope prof(CGS_PROF_LOSS_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(sigmoid_mean_fwd_kernel, dim3(rg_grid(n / 4)), dim3(RG_THREADS), 0, (hipStream_t)stream, x, n, partials);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_sigmoid_mean_bwd(const float *x, const float *g, int64_t n, float *dx, void *stream) {
+    if (int rc = rg_check("sigmoid_mean_bwd", x, dx, n)) return rc;
+    if (!g || ((uintptr_t)dx & 15)) { cgs_set_error("sigmoid_mean_bwd: g NULL or dx not 16-byte aligned"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(sigmoid_mean_bwd_kernel, dim3(rg_grid(n / 4)), dim3(RG_THREADS), 0, (hipStream_t)stream, x, g, n, dx);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

@@ -3,7 +3,9 @@
 `ssim` (11x11 Gaussian window, sigma 1.5, zero padding, per channel, mean; utils/loss_utils.py:33-63) and
 `l1_loss` run as ONE fused HIP launch forward and one backward (csrc/loss.hip, `cgs_l1_ssim_{fwd,bwd}`) instead
 of five grouped conv2d + ~15 element-wise passes each way.  `l1_ssim(image, gt)` returns both means from a
-single launch; `ssim` / `l1_loss` keep the reference's signatures.  Device tensors only: there is no CPU path.
+single launch; `ssim` / `l1_loss` keep the reference's signatures.  `scaling_reg` and `mask_reg` are the two
+regularisers train.py:203,209 adds to the image terms, one launch each way (torch's `prod` backward reads a zero
+count back on the host in the middle of every backward).  Device tensors only: there is no CPU path.
 """
 from __future__ import annotations
 
@@ -71,3 +73,46 @@ def training_image_loss(image, gt, lambda_dssim: float = 0.2):
     """(1 - lambda) L1 + lambda (1 - SSIM) of train.py:199-204, both terms from the same launch."""
     l1, s = l1_ssim(image, gt)
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s), l1, s
+
+
+class _MeanReg(torch.autograd.Function):
+    """mean over rows of prod(dim=1) ([P,3], kind 0) or mean of sigmoid (any shape, kind 1): csrc/loss.hip."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        _lib.require_device(x)
+        x = x if (x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0) else x.float().contiguous().clone()
+        L = _lib.lib()
+        n = x.shape[0] if kind == 0 else x.numel()
+        fwd = L.cgs_scaling_reg_fwd if kind == 0 else L.cgs_sigmoid_mean_fwd
+        partials = torch.empty(int(L.cgs_reg_partials(n)), dtype=torch.float32, device=x.device)
+        _lib.check(fwd(_lib.ptr(x), n, _lib.ptr(partials), _lib.current_stream()), "cgs_reg_fwd")
+        ctx.kind, ctx.n = kind, n
+        ctx.save_for_backward(x)
+        return partials.sum() / float(n)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        L = _lib.lib()
+        bwd = L.cgs_scaling_reg_bwd if ctx.kind == 0 else L.cgs_sigmoid_mean_bwd
+        d = torch.empty_like(x)
+        _lib.check(bwd(_lib.ptr(x), _lib.ptr(g.float().reshape(1).contiguous()), ctx.n, _lib.ptr(d), _lib.current_stream()),
+                   "cgs_reg_bwd")
+        return d, None
+
+
+def scaling_reg(scaling: torch.Tensor):
+    """`scaling.prod(dim=1).mean()` of train.py:203 for the rendered Gaussians' scales [P,3] (render()'s "scaling")."""
+    if scaling.dim() != 2 or scaling.shape[1] != 3:
+        raise ValueError("scaling_reg expects [P,3]")
+    if scaling.shape[0] == 0:
+        return scaling.prod(dim=1).mean()           # nan, as the reference's expression on an empty view
+    return _MeanReg.apply(scaling, 0)
+
+
+def mask_reg(mask: torch.Tensor):
+    """`torch.mean(torch.sigmoid(gaussians._mask))` of train.py:209."""
+    if mask.numel() == 0:
+        return torch.mean(torch.sigmoid(mask))
+    return _MeanReg.apply(mask, 1)

@@ -804,6 +804,20 @@ int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *maps,
                     const float *g, int C, int H, int W, float *dimg,
                     void *stream);
 
+/* ---- the regularisers next to the image loss (train.py:203,209) ----
+ * scaling_reg = scaling.prod(dim=1).mean() over the visible Gaussians' scales [P,3], and
+ * torch.mean(torch.sigmoid(gaussians._mask)) over the n mask logits.  One streaming launch each way:
+ * the forward writes cgs_reg_partials(n) per-workgroup partial SUMS (n = P or the element count;
+ * the caller adds them up and divides by P / n), the backward takes the upstream gradient of the MEAN
+ * as one float on the device (no host read; torch's prod backward reads an `input == 0` count back
+ * on the host) and writes d scaling[i][c] = g / P * (product of the other two) / dx = g / n * s (1 - s).
+ * Inputs and gradient outputs must be 16-byte aligned. */
+size_t cgs_reg_partials(int64_t n);
+int cgs_scaling_reg_fwd(const float *scaling, int64_t P, float *partials, void *stream);
+int cgs_scaling_reg_bwd(const float *scaling, const float *g, int64_t P, float *d_scaling, void *stream);
+int cgs_sigmoid_mean_fwd(const float *x, int64_t n, float *partials, void *stream);
+int cgs_sigmoid_mean_bwd(const float *x, const float *g, int64_t n, float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

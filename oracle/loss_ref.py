@@ -8,6 +8,9 @@ Follows utils/loss_utils.py of the reference:
                     ssim_map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)); mean
 Pinned by tests/golden/loss.npz (values and gradients produced by the reference's own functions,
 tools/make_loss_golden.py).  The gradient below is the analytic adjoint of the same expressions.
+
+`scaling_reg` / `mask_reg` restate the two regularisers train.py:203,209 adds to the image terms (they are inline torch
+expressions there, not functions): pinned in tests/test_loss.py against torch's CPU autograd of the same expressions.
 """
 from math import exp
 
@@ -54,3 +57,18 @@ def l1_ssim(img, gt, dtype=np.float32):
     g_ssim = (_filt(dm_dmu1, w) + 2 * x * _filt(dm_ds1, w) + y * _filt(dm_ds12, w)) / dtype(n)
     g_l1 = np.sign(x - y) / dtype(n)
     return float(np.abs(x - y).mean(dtype=np.float64)), float(m.mean(dtype=np.float64)), g_l1, g_ssim
+
+
+def scaling_reg(scaling):
+    """train.py:203 `scaling.prod(dim=1).mean()` for [P,3]: (value, d value / d scaling) in float64."""
+    s = np.asarray(scaling, dtype=np.float64)
+    P = s.shape[0]
+    d = np.stack([s[:, 1] * s[:, 2], s[:, 0] * s[:, 2], s[:, 0] * s[:, 1]], axis=1) / P
+    return float((s[:, 0] * s[:, 1] * s[:, 2]).mean()), d
+
+
+def mask_reg(mask):
+    """train.py:209 `torch.mean(torch.sigmoid(gaussians._mask))`: (value, d value / d mask) in float64."""
+    x = np.asarray(mask, dtype=np.float64)
+    sg = 1.0 / (1.0 + np.exp(-x))
+    return float(sg.mean()), sg * (1.0 - sg) / x.size

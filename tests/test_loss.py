@@ -68,3 +68,81 @@ def test_hip_full_hd_properties_and_torch_reference():
     (ga,) = torch.autograd.grad(0.8 * l1 + 0.2 * (1 - s), [img])
     (gb,) = torch.autograd.grad(0.8 * ref_l1 + 0.2 * (1 - ref_s), [img])
     assert float((ga - gb).abs().max()) < 2e-4 * float(gb.abs().max())
+
+
+# ---- the two regularisers train.py:203,209 adds to the image terms ----------------------------------------------------
+
+def _reg_inputs(P, seed):
+    r = np.random.default_rng(seed)
+    scaling = np.exp(r.normal(-3.0, 1.0, size=(P, 3))).astype(np.float32)
+    if P > 2:
+        scaling[1, 1] = 0.0           # torch's prod backward has a separate zero-safe path: d/d(that entry) = product of the others
+    mask = r.normal(0.5, 2.0, size=(P, 10, 1)).astype(np.float32)
+    return scaling, mask
+
+
+@pytest.mark.parametrize("P", [1, 3, 4, 5, 1001])
+def test_reg_oracle_matches_the_reference_expressions(P):
+    """oracle/loss_ref.py against torch's CPU autograd of the literal expressions of train.py:203,209 (fp64)."""
+    import torch
+    from oracle.loss_ref import scaling_reg, mask_reg
+    scaling, mask = _reg_inputs(P, 7 + P)
+    s = torch.tensor(scaling, dtype=torch.float64, requires_grad=True)
+    m = torch.tensor(mask, dtype=torch.float64, requires_grad=True)
+    a, b = s.prod(dim=1).mean(), torch.mean(torch.sigmoid(m))
+    ga, gb = torch.autograd.grad(a, s)[0], torch.autograd.grad(b, m)[0]
+    va, da = scaling_reg(scaling)
+    vb, db = mask_reg(mask)
+    assert abs(va - float(a)) <= 1e-14 * abs(float(a)) + 1e-300 and np.allclose(da, ga.numpy(), rtol=1e-13, atol=0)
+    assert abs(vb - float(b)) <= 1e-14 and np.allclose(db, gb.numpy(), rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 3, 4, 5, 1001, 1_000_003])
+def test_hip_regularisers_match_oracle(P):
+    import torch
+    from contextgs_amd.loss_utils import scaling_reg, mask_reg
+    from oracle import loss_ref
+    scaling, mask = _reg_inputs(P, 7 + P)
+    for x_np, op, ref in ((scaling, scaling_reg, loss_ref.scaling_reg), (mask, mask_reg, loss_ref.mask_reg)):
+        v_ref, d_ref = ref(x_np)
+        for misaligned in (False, True):
+            if misaligned:        # a view that does not start on 16 bytes goes through an aligned copy
+                buf = torch.zeros(x_np.size + 1, device="cuda")
+                buf[1:] = torch.tensor(x_np.reshape(-1), device="cuda")
+                x = buf[1:].view(x_np.shape).requires_grad_()
+            else:
+                x = torch.tensor(x_np, device="cuda", requires_grad=True)
+            v = op(x)
+            (d,) = torch.autograd.grad(3.0 * v, [x])
+            assert abs(float(v) - v_ref) <= 2e-6 * abs(v_ref) + 1e-12, (float(v), v_ref)       # fp32 sums of P terms
+            d = d.cpu().numpy().astype(np.float64) / 3.0
+            # s (1 - s) in fp32 loses relative accuracy where s -> 1 (the reference's sigmoid backward forms it the same way):
+            # absolute tolerance of a few fp32 roundings of the largest entry for the mask term
+            atol = (1e-12 if op is scaling_reg else 5e-7) * np.abs(d_ref).max()
+            assert np.allclose(d, d_ref, rtol=3e-6, atol=atol)
+        # the reference's own expression in fp32 on the device
+        t = torch.tensor(x_np, device="cuda", requires_grad=True)
+        e = t.prod(dim=1).mean() if op is scaling_reg else torch.mean(torch.sigmoid(t))
+        (g,) = torch.autograd.grad(e, [t])
+        assert abs(float(op(t)) - float(e)) <= 3e-6 * abs(float(e)) + 1e-12
+        assert np.allclose(g.cpu().numpy(), d_ref, rtol=2e-5, atol=(1e-10 if op is scaling_reg else 5e-7) * np.abs(d_ref).max())
+
+
+@pytest.mark.gpu
+def test_hip_regularisers_reject_bad_arguments():
+    import torch
+    from contextgs_amd import _lib
+    from contextgs_amd.loss_utils import scaling_reg, mask_reg
+    with pytest.raises(ValueError):
+        scaling_reg(torch.ones(4, 2, device="cuda"))
+    with pytest.raises(Exception):
+        scaling_reg(torch.ones(4, 3))                      # host tensor: no CPU path
+    L = _lib.lib()
+    x = torch.ones(8, 3, device="cuda")
+    out = torch.empty(int(L.cgs_reg_partials(8)), device="cuda")
+    assert L.cgs_scaling_reg_fwd(_lib.ptr(x), 0, _lib.ptr(out), _lib.current_stream()) != 0
+    assert L.cgs_scaling_reg_fwd(None, 8, _lib.ptr(out), _lib.current_stream()) != 0
+    assert L.cgs_sigmoid_mean_fwd(x.data_ptr() + 4, 8, _lib.ptr(out), _lib.current_stream()) != 0      # misaligned
+    assert torch.isnan(scaling_reg(torch.ones(0, 3, device="cuda")))     # empty view: nan, like the reference's expression
+    assert torch.isnan(mask_reg(torch.ones(0, 10, 1, device="cuda")))

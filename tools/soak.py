@@ -3,7 +3,7 @@ trend, the peak memory and checks for NaNs / allocator growth."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from contextgs_amd.loss_utils import training_image_loss
+from contextgs_amd.loss_utils import training_image_loss, scaling_reg
 from contextgs_amd.renderer import prefilter_voxel, render
 from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -24,7 +24,7 @@ for it in range(steps):
     c, gt = cams[it % 8], gts[it % 8]
     vis = prefilter_voxel(c, pc, pipe, bg)
     pkg = render(c, pc, pipe, bg, visible_mask=vis, step=20000)
-    loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * pkg["scaling"].prod(dim=1).mean() + 0.001 * pkg["bit_per_param"]
+    loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * scaling_reg(pkg["scaling"]) + 0.001 * pkg["bit_per_param"]
     opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
     if it % 50 == 0 or it == steps - 1:
         hist.append((it, float(loss.detach()), float(pkg["bit_per_param"].detach()), torch.cuda.memory_allocated() / 2**20))

@@ -6,7 +6,7 @@ usage: python tools/train_loop.py [iterations=360] [anchors=100000]"""
 import os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from contextgs_amd.loss_utils import training_image_loss
+from contextgs_amd.loss_utils import training_image_loss, scaling_reg, mask_reg
 from contextgs_amd.renderer import prefilter_voxel, render
 from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
 
@@ -44,9 +44,9 @@ for it in range(1, iters + 1):
     pc.update_learning_rate(step)
     vis = prefilter_voxel(c, pc, pipe, bg)
     pkg = render(c, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=step)
-    loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * pkg["scaling"].prod(dim=1).mean()
+    loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * scaling_reg(pkg["scaling"])
     if pkg["bit_per_param"] is not None:
-        loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * torch.mean(torch.sigmoid(pc._mask))
+        loss = loss + 0.001 * pkg["bit_per_param"] + 5e-4 * mask_reg(pc._mask)
     pc.optimizer.zero_grad(set_to_none=True)
     loss.backward()
     with torch.no_grad():
