@@ -10,6 +10,7 @@
 //
 // All three are pure streaming kernels: their roofline is HBM bytes (rows x widths x 4 B).
 #include <initializer_list>
+#include <type_traits>
 #include "cgs_internal.h"
 #include "rate_math.h"
 
@@ -311,6 +312,50 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The same pass with wider lanes (the one-float-per-lane form spends its time on index loads and 64-bit address
+// arithmetic, two index loads per float): V = 2 moves float2 pairs of even-width rows (8-byte aligned: w even), ROW = a lane
+// owns a whole row of w <= 4 floats.
+template <int V>
+__global__ void __launch_bounds__(256)
+    scatter_rows_sorted_vec_kernel(const float *__restrict__ g, const int64_t *__restrict__ idx, int64_t n, int64_t N, int wv,
+                                   float *__restrict__ out) {
+    typedef typename std::conditional<V == 2, float2, float4>::type T;
+    const int rpb = 256 / wv;
+    const int li = (int)threadIdx.x / wv, c = (int)threadIdx.x - li * wv;
+    if (li >= rpb) return;
+    const T zero = {};
+    for (int64_t i = (int64_t)blockIdx.x * rpb + li; i < n; i += (int64_t)gridDim.x * rpb) {
+        const int64_t r = idx[i];
+        const int64_t prev = i > 0 ? idx[i - 1] : -1;
+        for (int64_t z = prev + 1; z < r; ++z) ((T *)out)[z * wv + c] = zero;
+        ((T *)out)[r * wv + c] = ((const T *)g)[i * wv + c];
+        if (i == n - 1)
+            for (int64_t z = r + 1; z < N; ++z) ((T *)out)[z * wv + c] = zero;
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(256)
+    scatter_rows_sorted_row_kernel(const float *__restrict__ g, const int64_t *__restrict__ idx, int64_t n, int64_t N,
+                                   float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx[i];
+        const int64_t prev = i > 0 ? idx[i - 1] : -1;
+        float v[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] = g[i * W + c];
+        for (int64_t z = prev + 1; z < r; ++z)
+#pragma unroll
+            for (int c = 0; c < W; ++c) out[z * W + c] = 0.f;
+#pragma unroll
+        for (int c = 0; c < W; ++c) out[r * W + c] = v[c];
+        if (i == n - 1)
+            for (int64_t z = r + 1; z < N; ++z)
+#pragma unroll
+                for (int c = 0; c < W; ++c) out[z * W + c] = 0.f;
+    }
+}
+
 extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w, float *out,
                                        void *stream) {
     if (n < 0 || N < n || w < 1 || w > 256) { cgs_set_error("scatter_rows_sorted: bad sizes (1 <= w <= 256)"); return CGS_ERR_ARG; }
@@ -322,8 +367,22 @@ extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64
     }
     if (!g || !idx) { cgs_set_error("scatter_rows_sorted: NULL input"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(stream_grid(n, (256 / w) * 4)), dim3(256), 0, (hipStream_t)stream, g, idx,
-                       n, N, w, out);
+    const bool al8 = (((uintptr_t)g | (uintptr_t)out) & 7) == 0, al16 = (((uintptr_t)g | (uintptr_t)out) & 15) == 0;
+    if (w == 3)
+        hipLaunchKernelGGL(scatter_rows_sorted_row_kernel<3>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                           idx, n, N, out);
+    else if (w == 1)
+        hipLaunchKernelGGL(scatter_rows_sorted_row_kernel<1>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g,
+                           idx, n, N, out);
+    else if (w % 4 == 0 && al16)
+        hipLaunchKernelGGL(scatter_rows_sorted_vec_kernel<4>, dim3(stream_grid(n, (256 / (w / 4)) * 2)), dim3(256), 0,
+                           (hipStream_t)stream, g, idx, n, N, w / 4, out);
+    else if (w % 2 == 0 && al8)
+        hipLaunchKernelGGL(scatter_rows_sorted_vec_kernel<2>, dim3(stream_grid(n, (256 / (w / 2)) * 2)), dim3(256), 0,
+                           (hipStream_t)stream, g, idx, n, N, w / 2, out);
+    else
+        hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(stream_grid(n, (256 / w) * 4)), dim3(256), 0, (hipStream_t)stream, g,
+                           idx, n, N, w, out);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

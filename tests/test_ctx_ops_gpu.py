@@ -309,7 +309,8 @@ def test_rowcat_row_mask_equals_the_product(n, rows):
 
 
 @pytest.mark.parametrize("N,frac,w", [(1000, 0.995, 3), (50000, 0.9, 10), (4096, 1.0, 30), (1000, 0.0, 7), (3000, 0.3, 256),
-                                       (10, 0.5, 1)])
+                                       (10, 0.5, 1), (100003, 0.995, 3), (100003, 0.97, 10), (5000, 0.8, 12), (5000, 0.6, 4),
+                                       (5000, 0.9, 5), (777, 0.5, 2), (1_000_000, 0.995, 10), (1_000_000, 0.995, 3)])
 def test_scatter_rows_sorted_equals_zeros_index_copy(N, frac, w):
     """cgs_scatter_rows_sorted (the one-pass backward of x[visible rows]) == zeros(N, w).index_copy_(0, idx, g) for ascending idx:
     dense and sparse lists, an empty list, every row listed, the widest row the kernel takes."""
