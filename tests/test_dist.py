@@ -8,6 +8,25 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+
+def _by_value(obj):
+    """tensors -> numpy arrays (pickled by value) before a result goes into the mp queue: a torch tensor travels as a
+    file descriptor that the parent fetches from the CHILD, which fails when the child has already exited."""
+    if isinstance(obj, torch.Tensor):
+        return ("__tensor__", obj.detach().cpu().numpy().copy())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_by_value(o) for o in obj)
+    return obj
+
+
+def _from_value(obj):
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+        return torch.from_numpy(obj[1])
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_from_value(o) for o in obj)
+    return obj
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -49,8 +68,8 @@ def _worker(rank, world, port, q):
         word = cd.broadcast_object("from0" if rank == 0 else None)
         with cd.local_only():
             alone = (cd.world(), cd.rank(), cd.all_gather_rows(torch.ones(2), [2]).tolist())
-        q.put((rank, views, n, lin.weight.grad.clone(), extra.grad.clone(), stats[0].clone(), int(stats[1]),
-               p2.data.clone(), merged, rows, objs, word, alone, big1.grad.clone()))
+        q.put(_by_value((rank, views, n, lin.weight.grad.clone(), extra.grad.clone(), stats[0].clone(), int(stats[1]),
+                         p2.data.clone(), merged, rows, objs, word, alone, big1.grad.clone())))
     finally:
         dist.destroy_process_group()
 
@@ -65,7 +84,7 @@ def test_world_size_2_gradient_sync_and_sharding():
         p.start()
     res = {}
     for _ in range(world):
-        r = q.get(timeout=120)
+        r = _from_value(q.get(timeout=120))
         res[r[0]] = r
     for p in procs:
         p.join(timeout=60)
@@ -151,7 +170,7 @@ def _sync_worker(rank, world, port, q):
         shared = cd.shared_rand_like(torch.empty(5))
         own = torch.rand(5)
         sync.close()
-        q.put((rank, out, shared.tolist(), own.tolist()))             # plain lists: no tensor fd passing at exit
+        q.put(_by_value((rank, out, shared.tolist(), own.tolist())))  # by value: no tensor fd passing at exit
     finally:
         dist.destroy_process_group()
 
@@ -166,7 +185,7 @@ def test_gradient_sync_hooks_sparse_rows_and_shared_rng():
         p.start()
     res = {}
     for _ in range(world):
-        r = q.get(timeout=120)
+        r = _from_value(q.get(timeout=120))
         res[r[0]] = r
     for p in procs:
         p.join(timeout=60)
@@ -218,7 +237,7 @@ def _nograd_worker(rank, world, port, q):
         cd.allreduce_gradients(params)
         plain = (late.grad is None, never.grad is None, a.grad.flatten().tolist())
         st = lambda p: int(opt.state[p]["step"]) if p in opt.state and "step" in opt.state[p] else 0
-        q.put((rank, trace, (st(a), st(late), st(never)), late.detach().flatten().tolist(), plain))
+        q.put(_by_value((rank, trace, (st(a), st(late), st(never)), late.detach().flatten().tolist(), plain)))
     finally:
         dist.destroy_process_group()
 
@@ -235,7 +254,7 @@ def test_parameters_without_a_gradient_on_any_rank_stay_without_one():
         p.start()
     res = {}
     for _ in range(world):
-        r = q.get(timeout=120)
+        r = _from_value(q.get(timeout=120))
         res[r[0]] = r
     for p in procs:
         p.join(timeout=60)
@@ -314,7 +333,7 @@ def _defer_worker(rank, world, port, q):
                     t.grad = None                              # W.grad is kept: the next backward must ADD to it
         sync.close()
         assert not mlp._Deferred.on and not mlp._Deferred.before_flush
-        q.put((rank, log, results))
+        q.put(_by_value((rank, log, results)))
     finally:
         dist.destroy_process_group()
 
@@ -330,7 +349,7 @@ def test_deferred_weight_gradients_follow_the_per_anchor_collectives():
     procs = [ctx.Process(target=_defer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    out = sorted((_from_value(q.get(timeout=120)) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
