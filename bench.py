@@ -434,40 +434,58 @@ def codec_bench(pc, cams=None, pipe=None, bg=None):
     import tempfile
     import torch
     from contextgs_amd.synth import make_scene
-    d = tempfile.mkdtemp(prefix="cgs_bits_")
+    from contextgs_amd.codec_driver import conduct_encoding
+
+    def round_trip(version, with_fps):
+        d = tempfile.mkdtemp(prefix="cgs_bits_")
+        try:
+            n_valid = int(pc.get_mask_anchor.sum())
+            conduct_encoding(pc, d, container_version=version)   # untimed warm-up (first-touch allocations, CDF tables of the prior)
+            enc_s = []
+            for _ in range(3):                                   # median of three: the host side of the container varies run to run
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                conduct_encoding(pc, d, container_version=version)
+                torch.cuda.synchronize(); enc_s.append(time.perf_counter() - t0)
+            size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+            warm = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
+            warm.eval()
+            warm.conduct_decoding(d)                # untimed warm-up, like the encoder's (first-touch allocations, tables)
+            del warm
+            dec_s = []
+            for _ in range(3):
+                dec = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
+                dec.eval()
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                dec.conduct_decoding(d)
+                torch.cuda.synchronize(); dec_s.append(time.perf_counter() - t2)
+            with torch.no_grad():
+                m = pc.get_mask_anchor
+                exact = bool(torch.equal(dec._anchor[:n_valid], pc.get_anchor[m])) and \
+                    bool(torch.equal(dec._mask[:n_valid], pc.get_mask[m]))
+            fps = None
+            if with_fps and cams is not None:   # eval-path throughput: decoded model (parameters ARE the values) vs non-decoded
+                fps = {"decoded_views_per_s": round(eval_fps(dec, cams, pipe, bg), 2),       # (context model per view, Q7)
+                       "not_decoded_views_per_s": round(eval_fps(pc, cams, pipe, bg), 2)}
+            te, td = sorted(enc_s)[1], sorted(dec_s)[1]
+            return {"container_version": version, "test_fps": fps, "encode_Manchors_per_s": round(n_valid / te / 1e6, 4),
+                    "decode_Manchors_per_s": round(n_valid / td / 1e6, 4), "encode_s": round(te, 4), "decode_s": round(td, 4),
+                    "encode_s_runs": [round(x, 4) for x in enc_s], "decode_s_runs": [round(x, 4) for x in dec_s],
+                    "valid_anchors": n_valid, "bitstream_MB": round(size / 2**20, 3),
+                    "decoded_anchor_and_masks_bit_exact": exact}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    was = pc.get_color_mlp.training
+    pc.eval()
     try:
-        was = pc.get_color_mlp.training
-        pc.eval()
-        n_valid = int(pc.get_mask_anchor.sum())
-        pc.conduct_encoding(d)                      # untimed warm-up (first-touch allocations, CDF tables of the prior)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        pc.conduct_encoding(d)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
-        warm = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
-        warm.eval()
-        warm.conduct_decoding(d)                    # untimed warm-up, like the encoder's (first-touch allocations, tables)
-        del warm
-        dec = make_scene(pc._anchor.shape[0], seed=0, requires_grad=False)
-        dec.eval()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        dec.conduct_decoding(d)
-        torch.cuda.synchronize(); t3 = time.perf_counter()
-        with torch.no_grad():
-            m = pc.get_mask_anchor
-            exact = bool(torch.equal(dec._anchor[:n_valid], pc.get_anchor[m])) and \
-                bool(torch.equal(dec._mask[:n_valid], pc.get_mask[m]))
-        fps = None
-        if cams is not None:        # eval-path throughput: decoded model (parameters ARE the values) vs non-decoded
-            fps = {"decoded_views_per_s": round(eval_fps(dec, cams, pipe, bg), 2),       # (context model per view, Q7)
-                   "not_decoded_views_per_s": round(eval_fps(pc, cams, pipe, bg), 2)}
+        out = round_trip(1, True)            # the reference's container: one serial mask stream, 1000-anchor chunks
+        v2 = round_trip(2, False)            # same symbols re-cut for the device (codec_driver.CONTAINER_VERSION notes)
+        v2.pop("test_fps")
+        out["container_v2"] = v2
+        return out
+    finally:
         if was:
             pc.train()
-        return {"test_fps": fps, "encode_Manchors_per_s": round(n_valid / (t1 - t0) / 1e6, 4), "decode_Manchors_per_s": round(n_valid / (t3 - t2) / 1e6, 4),
-                "encode_s": round(t1 - t0, 3), "decode_s": round(t3 - t2, 3), "valid_anchors": n_valid,
-                "bitstream_MB": round(size / 2**20, 3), "decoded_anchor_and_masks_bit_exact": exact}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(pc, cam, pipe, bg, w, pkg, ctx_sample=200_000):

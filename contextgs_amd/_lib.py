@@ -12,7 +12,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGS_LIB_PATH: another build of the same library (tools/variant_lib.sh: one translation unit recompiled with timing-experiment
-# defines); the default is the in-tree product library
+# defines, kept under tools/variants/); the default is the in-tree product library.  A CGS_LIB_PATH library is only accepted
+# when it was built from the sources next to this file (cgs_build_info() carries their digest) — a stale A/B library must be
+# asked for explicitly with CGS_LIB_ALLOW_STALE=1 (tools/ab_lib.sh does) — and its use is announced on stderr.
 LIB_PATH = os.environ.get("CGS_LIB_PATH") or os.path.join(_HERE, "libcgs_hip.so")
 
 _lib = None
@@ -66,6 +68,9 @@ SIGNATURES = {
     "cgs_raster_preprocess_expand_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_int] + [c_void_p] * 9 + [c_int64, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_stats": (c_int, [C.POINTER(RasterCfg), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_debug_bin_compare": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
+                                      c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "cgs_build_info": (C.c_char_p, []),
     "cgs_scan_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_scan_exclusive_u32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_sort_scratch_bytes": (c_size_t, [c_int64]),
@@ -142,6 +147,8 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_gaussian_ac_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_bernoulli_ac_encode": (c_int, [c_void_p, C.c_uint32, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_bernoulli_ac_decode": (c_int, [C.c_uint32, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_means3_scratch_bytes": (c_size_t, []),
     "cgs_means3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
                            c_void_p]),
@@ -215,6 +222,15 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)   # AttributeError => ABI mismatch, fail loudly
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("CGS_LIB_PATH"):
+            import sys
+            from . import build as _build
+            info = (handle.cgs_build_info() or b"").decode()
+            want = _build.source_digest()
+            if info.split("|")[0] != want and not os.environ.get("CGS_LIB_ALLOW_STALE"):
+                raise RuntimeError(f"CGS_LIB_PATH={LIB_PATH} was built from other sources ({info.split('|')[0][:12]}... vs "
+                                   f"{want[:12]}...): rebuild it (tools/variant_lib.sh) or set CGS_LIB_ALLOW_STALE=1")
+            print(f"[contextgs_amd] variant library {LIB_PATH} ({info[:12]}...|{info.split('|')[-1]})", file=sys.stderr)
         _lib = handle
     return _lib
 

@@ -44,22 +44,31 @@ def sources() -> list[str]:
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def _digest(paths: list[str]) -> str:
+def _headers() -> list[str]:
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+           [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+
+
+def source_digest() -> str:
+    """sha256 over the library's sources and headers (names relative to the package, so the digest is the same in the
+    authoring container and on the GPU box); cgs_build_info() carries it."""
     h = hashlib.sha256()
-    for p in sorted(paths):
+    for p in sorted(sources() + _headers(), key=os.path.basename):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())
             h.update(f.read())
-    h.update(" ".join(CXXFLAGS).encode())
     return h.hexdigest()
+
+
+def _digest(paths: list[str]) -> str:
+    return hashlib.sha256((source_digest() + " ".join(CXXFLAGS)).encode()).hexdigest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     srcs = sources()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
     stamp = os.path.join(OBJ_DIR, "stamp")
-    digest = _digest(srcs + headers)
+    digest = _digest(srcs)
+    src_digest = source_digest()
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == digest:
         return OUT
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -68,6 +77,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         cmd = [cc, *CXXFLAGS, "-c", src, "-o", obj]
+        if os.path.basename(src) == "api.hip":      # cgs_build_info()
+            flags = " ".join(f for f in CXXFLAGS if f.startswith(("-O", "-D", "-ffp")))
+            cmd += [f'-DCGS_SOURCE_DIGEST="{src_digest}"', f'-DCGS_BUILD_FLAGS="{flags}"']
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

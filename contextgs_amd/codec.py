@@ -98,6 +98,34 @@ def host_pool():
     return _POOL
 
 
+def write_file(path: str, blob, piece: int = 8 << 20):
+    """Write a uint8 ndarray / bytes to `path` on the pool: files above `piece` bytes are written as concurrent os.pwrite
+    slices (one thread copies ~9 GB/s into the page cache; the finest level's feature file is ~80 MB at 1 M anchors and
+    sat on the encoder's tail for 10 ms).  Returns the futures to wait on."""
+    import os
+    mv = memoryview(blob).cast("B") if not isinstance(blob, (bytes, bytearray)) else memoryview(blob)
+    n = len(mv)
+    if n <= piece:
+        def small():
+            with open(path, "wb") as f:
+                f.write(mv)
+        return [host_pool().submit(small)]
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.ftruncate(fd, n)
+
+    def part(lo):
+        hi = min(n, lo + piece)
+        while lo < hi:
+            lo += os.pwrite(fd, mv[lo:hi], lo)
+    jobs = [host_pool().submit(part, lo) for lo in range(0, n, piece)]
+
+    def close():
+        for j in jobs:
+            j.result()
+        os.close(fd)
+    return [host_pool().submit(close)]
+
+
 def bernoulli_encode_host(sym: np.ndarray, p0: float) -> bytes:
     """sym int16 [n] in {0,1}, P(1) = p0 -> the single arithmetic-coded stream of utils/encodings.py:147-163."""
     L = _lib.lib()
@@ -142,6 +170,98 @@ def decoder(p, file_name):
         data = f.read()
     out = bernoulli_decode_host(data, pf.numel(), float(pf[0].item()) if pf.numel() else 0.5)
     return (torch.from_numpy(out).to(torch.float32) * 2 - 1).to(dvc)
+
+
+# ---- Bernoulli chunk streams on the device (container version 2) -------------------------------------
+def bernoulli_c1(p0: float) -> int:
+    """The one interior entry of the mask stream's integer CDF row [0, c1, 2^16] (P(1) = p0), through the same float ->
+    uint16 conversion the host coder uses (utils/encodings.py:151-157)."""
+    return int(_bernoulli_row(np.float32(p0))[1])
+
+
+class BernoulliEncodeJob:
+    """Mask chunk streams coded by ONE device launch (one wave per stream) on a side stream; result() downloads
+    (packed bytes, per-stream byte lengths).  Stream s holds exactly bernoulli_encode_host(sym[off[s]:off[s+1]], p0)."""
+
+    def __init__(self, sym01: torch.Tensor, p0: float, stream_off, side_stream=None):
+        L = _lib.lib()
+        _lib.require_device(sym01)
+        self.dev = dev = sym01.device
+        self.sym = sym = _f(sym01).reshape(-1)
+        off_h = torch.as_tensor(stream_off, dtype=torch.int64).cpu()
+        self.S = S = int(off_h.numel()) - 1
+        self.stream = side_stream or torch.cuda.current_stream(dev)
+        if S <= 0:
+            return
+        assert int(off_h[-1]) == sym.numel() and int(off_h[0]) == 0
+        caps = ((off_h[1:] - off_h[:-1]) * 2 + 16 + 7) // 8 * 8
+        out_off_h = torch.zeros(S + 1, dtype=torch.int64)
+        out_off_h[1:] = torch.cumsum(caps, 0)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            off_d, out_off = off_h.to(dev, non_blocking=True), out_off_h.to(dev, non_blocking=True)
+            out = torch.empty(int(out_off_h[-1]) + 16, dtype=torch.uint8, device=dev)
+            self.st_len = st_len = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+            raw = self.stream.cuda_stream
+            _lib.check(L.cgs_bernoulli_ac_encode(_lib.ptr(sym), bernoulli_c1(p0), _lib.ptr(off_d), S, _lib.ptr(out),
+                                                 _lib.ptr(out_off), _lib.ptr(st_len[1:]), _lib.ptr(st_len[:1]), raw),
+                       "cgs_bernoulli_ac_encode")
+            dst_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(st_len[1:], 0, out=dst_off[1:])
+            # an upper bound sizes the packed buffer, so nothing is read back before the compaction is enqueued
+            self.packed = packed = torch.empty(int(out_off_h[-1]) + 16, dtype=torch.uint8, device=dev)
+            _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(st_len[1:]), _lib.ptr(dst_off), S,
+                                             _lib.ptr(packed), raw), "cgs_streams_compact")
+            for t in (sym, off_d, out_off, out, st_len, dst_off, packed):
+                t.record_stream(self.stream)
+
+    def result(self):
+        if self.S <= 0:
+            return np.zeros(0, np.uint8), np.zeros(0, np.int64)
+        with torch.cuda.stream(self.stream):
+            st_len_h = self.st_len.cpu().numpy()
+            if int(st_len_h[0]) != 0:
+                raise RuntimeError("bernoulli codec: " + ("symbol outside {0, 1}" if int(st_len_h[0]) == 1
+                                                          else "stream overflowed its buffer"))
+            lens = st_len_h[1:].astype(np.int64)
+            nbytes = int(lens.sum())
+            blob = self.packed[:nbytes].cpu().numpy()
+        return blob, lens
+
+
+def bernoulli_encode_packed(sym01, p0, stream_off):
+    """sym01 flat float {0,1} device tensor -> (blob uint8 ndarray of the S streams back to back, lens int64 [S])."""
+    return BernoulliEncodeJob(sym01, p0, stream_off).result()
+
+
+def bernoulli_decode_packed(p0, stream_off, blob, lens, device=None):
+    """Inverse of bernoulli_encode_packed -> flat float32 {0,1} device tensor.  blob: bytes / uint8 ndarray / uint8 device
+    tensor (followed by >= 16 readable bytes of its storage, as StagedFiles hands them out)."""
+    L = _lib.lib()
+    off_h = torch.as_tensor(stream_off, dtype=torch.int64).cpu()
+    S = int(off_h.numel()) - 1
+    if isinstance(blob, torch.Tensor) and blob.is_cuda:
+        dev, in_d = blob.device, blob
+    else:
+        dev = torch.device(device if device is not None else "cuda")
+        buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        in_d = torch.zeros(buf.size + 16, dtype=torch.uint8, device=dev)
+        if buf.size:
+            in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
+    n = int(off_h[-1]) if S >= 0 and off_h.numel() else 0
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    if S <= 0:
+        return out
+    lens = np.asarray(lens, dtype=np.int64)
+    assert lens.shape[0] == S
+    in_off_h = np.zeros(S + 1, dtype=np.int64)
+    np.cumsum(lens, out=in_off_h[1:])
+    assert int(in_off_h[-1]) <= int(in_d.numel()), "stream lengths exceed the blob"
+    in_off = torch.from_numpy(in_off_h).to(dev)
+    off_d = off_h.to(dev)
+    _lib.check(L.cgs_bernoulli_ac_decode(bernoulli_c1(p0), _lib.ptr(off_d), S, _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(out),
+                                         _lib.current_stream()), "cgs_bernoulli_ac_decode")
+    return out
 
 
 # ---- batched device Gaussian codec ---------------------------------------------------------------

@@ -39,6 +39,19 @@ from .encodings import Q_anchor, Quantize_anchor, STE_multistep, decoder, encode
 bit2MB_scale = 8 * 1024 * 1024
 MAX_BATCH = 1_000                                              # :1071
 
+# Container versions.  1 = the reference's container (default): one serial arithmetic-coded mask stream, 10 000-anchor hyper
+# strings, 1000-anchor chunk streams for every Gaussian-coded attribute, a 14-item meta list.  2 = the same files, symbols,
+# order and coder, re-cut for a device: the masks are chunk streams coded by the device coder (codec.BernoulliEncodeJob; no
+# serial host stream is left on either critical chain), and the chunk length is per attribute (a coder launch lasts as long
+# as its LONGEST stream — 50 000 serial symbols for a 1000-anchor feature chunk —, so version 2 cuts streams of ~10 000
+# symbols).  meta.b gets a 15th item {"version": 2, "chunk": {...}, "bit_masks": [...]}; a 14-item list is version 1.
+CONTAINER_VERSION = 1
+V2_CHUNK = {"feat": 200, "scaling": 1000, "offsets": 400, "masks": 1000}       # anchors per chunk stream
+
+
+def default_container_version():
+    return int(os.environ.get("CGS_CONTAINER_VERSION", CONTAINER_VERSION))
+
 
 def save_mlp_checkpoints(pc, path):                            # :912-936
     pc.latent_codec.update()
@@ -101,8 +114,8 @@ def estimate_final_bits(pc):                                   # :980-1004
             f"masks {r(mk)}, MLPs {r(mlp)}, Total {r(a + f + s + o + h + mk + mlp)}")
 
 
-def _chunk_rows(n):
-    edges = list(range(0, n, MAX_BATCH)) + [n]
+def _chunk_rows(n, batch=MAX_BATCH):
+    edges = list(range(0, n, batch)) + [n]
     return edges if n > 0 else [0]
 
 
@@ -113,6 +126,18 @@ def _predict(pc, level, feat_in):
     return (mean_feat.contiguous(), c(scale_feat), mean_scaling.contiguous(), c(scale_scaling),
             mean_offsets.contiguous(), c(scale_offsets), Qf.reshape(-1).contiguous(), Qs.reshape(-1).contiguous(),
             Qo.reshape(-1).contiguous())
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """One side stream per device for the life of the process (a fresh stream per container costs the caching allocator a
+    fresh pool, see codec.StagedFiles)."""
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def _tracer(name):
@@ -131,7 +156,11 @@ def _tracer(name):
 
 
 @torch.no_grad()
-def conduct_encoding(pc, pre_path_name):                       # :1007-1295
+def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
+    version = default_container_version() if container_version is None else int(container_version)
+    if version not in (1, 2):
+        raise ValueError(f"container version {version}: 1 (the reference's container) or 2")
+    chunk = dict(V2_CHUNK) if version == 2 else {k: MAX_BATCH for k in V2_CHUNK}
     torch.cuda.synchronize(); t1 = time.time()
     tr = _tracer("encode")
     print("Start encoding ...")
@@ -145,7 +174,13 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     mask_anchor = pc.get_mask_anchor
     _mask = pc.get_mask[mask_anchor]
     prob_masks = (_mask.sum() / _mask.numel()).item() if _mask.numel() else 0.5
-    if root:
+    if root and version == 2:
+        # version 2: the same symbols as 1000-anchor chunk streams, one device launch on a side stream beside everything below
+        mask_edges = torch.tensor(_chunk_rows(int(_mask.shape[0]), chunk["masks"]), dtype=torch.int64) * K
+        mask_job = codec.BernoulliEncodeJob(torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2), prob_masks, mask_edges,
+                                            _side_stream(_mask.device))
+        tr("mask chunk streams enqueued (device)")
+    elif root:
         mask_sym = codec.to_host_pinned(torch.floor(((_mask * 2 - 1).view(-1) + 1) / 2).to(torch.int16), "mask symbols")
         tr("mask symbols on the host")
         mask_job = codec.host_pool().submit(codec.bernoulli_encode_host, mask_sym, prob_masks)
@@ -189,7 +224,8 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
-        rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
+        rows_f, rows_s, rows_o = (torch.tensor(_chunk_rows(n_l, chunk[a]), dtype=torch.int64)
+                                  for a in ("feat", "scaling", "offsets"))
 
         tr(f"level {level}: chunk rows")
         feat_q = STE_multistep.apply(_feat[orig], Qf.unsqueeze(1))
@@ -199,13 +235,13 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
         m30 = _mask[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)              # :1222-1223
         cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=m30.device)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
-        off_edges = cnt[rows.to(cnt.device)].cpu()
+        off_edges = cnt[rows_o.to(cnt.device)].cpu()
         tr(f"level {level}: offset stream edges on the host")
         live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the four operands
         pick = lambda t: t.reshape(-1).index_select(0, live)
 
-        groups += [(feat_q, mean_feat, scale_feat, Qf, rows * D, D),
-                   (scal_q, mean_scaling, scale_scaling, Qs, rows * 6, 6),
+        groups += [(feat_q, mean_feat, scale_feat, Qf, rows_f * D, D),
+                   (scal_q, mean_scaling, scale_scaling, Qs, rows_s * 6, 6),
                    (pick(off_q), pick(mean_offsets), pick(scale_offsets), Qo.index_select(0, live // (3 * K)),
                     off_edges, 1)]
         tags += [("feat", level), ("scaling", level), ("offsets", level)]
@@ -235,7 +271,7 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     min_d = {"feat": {}, "scaling": {}, "offsets": {}}
     max_d = {"feat": {}, "scaling": {}, "offsets": {}}
     for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
-        writes.append(codec.host_pool().submit(blob.tofile, path(f"{name}{level}.b")))   # :1235-1238
+        writes += codec.write_file(path(f"{name}{level}.b"), blob)                        # :1235-1238
         bit_d[name][level] = (lens * 8).tolist()
         min_d[name][level] = mn.astype(np.int64).tolist()
         max_d[name][level] = mx.astype(np.int64).tolist()
@@ -252,7 +288,11 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     bit_scaling = sum(sum(v) for v in bit_d["scaling"].values())
     bit_offsets = sum(sum(v) for v in bit_d["offsets"].values())
 
-    mask_bytes = mask_job.result()
+    if version == 2:
+        mask_blob, mask_lens = mask_job.result()
+        mask_bytes = mask_blob.tobytes()
+    else:
+        mask_bytes = mask_job.result()
     tr("mask stream done")
     with open(path("masks.b"), "wb") as f:
         f.write(mask_bytes)
@@ -266,9 +306,12 @@ def conduct_encoding(pc, pre_path_name):                       # :1007-1295
     print("codec time:", t_codec)
 
     meta_path = path("meta.b")                                                            # :1276-1277
-    torch.save([pc._anchor.shape[0], MAX_BATCH, min_d["feat"], max_d["feat"], min_d["scaling"], max_d["scaling"],
-                min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
-                bit_d["offsets"], N_levels_list], meta_path)
+    meta = [pc._anchor.shape[0], MAX_BATCH, min_d["feat"], max_d["feat"], min_d["scaling"], max_d["scaling"],
+            min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
+            bit_d["offsets"], N_levels_list]
+    if version == 2:
+        meta.append({"version": 2, "chunk": chunk, "bit_masks": (mask_lens * 8).tolist()})
+    torch.save(meta, meta_path)
     save_mlp_checkpoints(pc, path("mlp.pt"))
     bit_meta = os.path.getsize(meta_path) * 8
     mlp = pc.get_mlp_size()[0]
@@ -289,9 +332,14 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # anchor.npy (12 MB at 1 M anchors) is read and converted on a host thread while this one loads the header, the MLPs and
     # the prior tables: the level plan — the first thing the device chain waits for — needs nothing else from the files
     anchor_job = codec.host_pool().submit(lambda: np.load(path("anchor.npy")).astype(np.int32))
+    meta = torch.load(path("meta.b"), map_location="cpu", weights_only=False)
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
-     bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = torch.load(path("meta.b"), map_location="cpu",
-                                                                                          weights_only=False)
+     bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = meta[:14]
+    extra = meta[14] if len(meta) > 14 else {"version": 1}
+    version = int(extra.get("version", 1))
+    if version not in (1, 2):
+        raise RuntimeError(f"meta.b: container version {version} is newer than this decoder (1, 2)")
+    chunk = extra["chunk"] if version == 2 else {k: max_batch for k in V2_CHUNK}
     # (map_location: whatever tensors a header holds — the reference stores its minima / maxima as device tensors — are only
     #  ever read as Python numbers here: restoring them on the device would cost a copy each and a stream drain per .item())
     tr("meta.b loaded")
@@ -299,9 +347,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     N_levels_list = list(reversed(N_levels_list))
     N_valid = sum(N_levels_list)
     # the mask stream (:1348-1353) is serial and only the offsets need it: decode it on a host thread meanwhile
-    mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
-                                        N_valid * K, float(prob_masks))
-    tr("mask job submitted")
+    # (version 2: chunk streams, decoded by one device launch as soon as masks.b is staged — see below)
+    mask_job = None
+    if version == 1:
+        mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
+                                            N_valid * K, float(prob_masks))
+        tr("mask job submitted")
     load_mlp_checkpoints(pc, path("mlp.pt"))
     tr("mlp.pt loaded")
     pc.latent_codec.update(force=True)
@@ -322,11 +373,25 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
     # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
     n_lv = len(N_levels_list)
-    order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
-            [f"offsets{l}.b" for l in reversed(range(n_lv))]
+    if version == 2:       # masks first (their launch runs beside the prologue), then level by level incl. the offsets
+        order = ["masks.b"] + [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling", "offsets")]
+    else:
+        order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
+                [f"offsets{l}.b" for l in reversed(range(n_lv))]
     staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
 
     tr("file staging started")
+    side_stream = _side_stream(dev)
+    masks_decoded, masks_ready = None, None
+    if version == 2:
+        with torch.cuda.stream(side_stream):
+            mask_edges = torch.tensor(_chunk_rows(N_valid, chunk["masks"]), dtype=torch.int64) * K
+            mask_lens = np.asarray(extra["bit_masks"], dtype=np.int64) // 8
+            blob = staged.get(path("masks.b"))
+            assert int(mask_lens.sum()) == int(blob.numel())
+            masks_decoded = codec.bernoulli_decode_packed(float(prob_masks), mask_edges, blob, mask_lens).view(-1, K, 1)
+            masks_ready = side_stream.record_event()
+        tr("mask chunk streams: device launch enqueued")
 
     q = torch.from_numpy(anchor_job.result()).to(dev)                                    # :1340-1342
     interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
@@ -356,17 +421,40 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # many streams they hold, so the fewer the better: one per level for features + scaling — the offsets of a level
     # need nothing but that level's prediction and the masks, so ALL of them go into ONE more launch, beside the last
     # level's (see below): 3 serial launches for 3 levels.
-    pending_offsets, masks_decoded = [], None
-    side_stream = torch.cuda.Stream(device=dev)
+    pending_offsets = []
 
-    def offset_groups():
+    def live_slots(orig_, n_, rows_):
+        m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
+        cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
+        cnt[1:] = torch.cumsum(m30.sum(1), 0)
+        live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the three operands and the fill
+        return cnt[rows_.to(dev)], live
+
+    live_pre = {}
+    if version == 2:
+        # the offsets' stream edges of EVERY level in one host read, before the first coder launch is queued (a read inside
+        # the level loop would drain the previous level's launch and leave the device idle while the next one is built)
+        torch.cuda.current_stream().wait_event(masks_ready)
+        masks_decoded.record_stream(torch.cuda.current_stream())
+        for (level_, _tc, orig_, _h) in plan:
+            n_ = int(orig_.shape[0])
+            live_pre[level_] = live_slots(orig_, n_, torch.tensor(_chunk_rows(n_, chunk["offsets"]), dtype=torch.int64))
+        if live_pre:
+            edges_h = torch.cat([e for (e, _l) in live_pre.values()]).cpu()
+            pos = 0
+            for level_, (e, l) in list(live_pre.items()):
+                live_pre[level_] = (edges_h[pos:pos + e.numel()], l)
+                pos += e.numel()
+        tr("offset stream edges of all levels on the host")
+
+    def offset_groups(pending):
         groups, fills = [], []
-        for (level_, orig_, n_, rows_, mean_o, scale_o, Qo_) in pending_offsets:
-            m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
-            cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
-            cnt[1:] = torch.cumsum(m30.sum(1), 0)
-            off_edges = cnt[rows_.to(dev)].cpu()
-            live = torch.nonzero(m30.reshape(-1))[:, 0]          # ONE compaction index for the three operands and the fill
+        for (level_, orig_, n_, rows_, mean_o, scale_o, Qo_) in pending:
+            if level_ in live_pre:
+                off_edges, live = live_pre[level_]
+            else:
+                off_edges, live = live_slots(orig_, n_, rows_)
+                off_edges = off_edges.cpu()
             groups.append((mean_o.reshape(-1).index_select(0, live), scale_o.reshape(-1).index_select(0, live),
                            Qo_.index_select(0, live // (3 * K)), off_edges,
                            min_offsets_d[level_], max_offsets_d[level_],
@@ -385,18 +473,29 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
-        rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
-        pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
-        groups = [(mean_feat, scale_feat, Qf, rows * D, min_feat_d[level], max_feat_d[level],
+        rows_f, rows_s, rows_o = (torch.tensor(_chunk_rows(n_l, chunk[a]), dtype=torch.int64)
+                                  for a in ("feat", "scaling", "offsets"))
+        pending_offsets.append((level, orig, n_l, rows_o, mean_offsets, scale_offsets, Qo))
+        groups = [(mean_feat, scale_feat, Qf, rows_f * D, min_feat_d[level], max_feat_d[level],
                    *chunk_lens("feat", level, bit_feat_d[level]), D),
-                  (mean_scaling, scale_scaling, Qs, rows * 6, min_scaling_d[level], max_scaling_d[level],
+                  (mean_scaling, scale_scaling, Qs, rows_s * 6, min_scaling_d[level], max_scaling_d[level],
                    *chunk_lens("scaling", level, bit_scaling_d[level]), 6)]
-        if level == last_level:
+        fills = []
+        if version == 2:
+            # version 2: the masks are on the device long before the first level is predicted, so a level's offsets ride in
+            # that level's launch (their streams are not longer than the feature streams beside them)
+            og, fills = offset_groups(pending_offsets[-1:])
+            groups += og
+        elif level == last_level:
             fork = torch.cuda.current_stream().record_event()       # everything the offsets need exists before this point
         decoded = codec.gaussian_decode_groups(groups)
         tr(f"level {level}: coder launch enqueued")
         feat_dec, scal_dec = decoded[0], decoded[1]
-        if level == last_level:
+        for (orig_, n_, live), off_vals in zip(fills, decoded[2:]):
+            off_dec = torch.zeros(n_ * 3 * K, device=dev)
+            off_dec.index_copy_(0, live, off_vals)
+            grid_offset_after_Q[orig_] = off_dec.view(n_, K, 3)
+        if version == 1 and level == last_level:
             # The offsets of ALL levels as their own launch on a side stream, forked BEFORE the last feature launch:
             # they need the mask stream (a serial host job of ~70 ms that ends about now), the features do not, and a
             # coder launch keeps few SIMDs busy (one wave per stream), so the two launches run side by side instead of
@@ -407,7 +506,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
                 tr("waiting for the mask stream")
                 masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
                 tr("mask stream decoded")
-                og, fills = offset_groups()
+                og, fills = offset_groups(pending_offsets)
                 for (orig_, n_, live), off_vals in zip(fills, codec.gaussian_decode_groups(og)):
                     off_dec = torch.zeros(n_ * 3 * K, device=dev)
                     off_dec.index_copy_(0, live, off_vals)
@@ -423,6 +522,9 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
                                                         inverse_indices_list, mapping_list, level)
     if masks_decoded is None:                    # no level at all (empty model)
         masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
+    if masks_ready is not None:
+        torch.cuda.current_stream().wait_event(masks_ready)
+        masks_decoded.record_stream(torch.cuda.current_stream())
     tr("levels enqueued")
     torch.cuda.synchronize(); t2 = time.time()
     tr("device done")

@@ -15,6 +15,13 @@ void cgs_set_error(const char *fmt, ...) {
 
 extern "C" const char *cgs_last_error(void) { return g_err; }
 extern "C" int cgs_version(void) { return CGS_VERSION; }
+#ifndef CGS_SOURCE_DIGEST
+#define CGS_SOURCE_DIGEST "unknown"
+#endif
+#ifndef CGS_BUILD_FLAGS
+#define CGS_BUILD_FLAGS ""
+#endif
+extern "C" const char *cgs_build_info(void) { return CGS_SOURCE_DIGEST "|" CGS_BUILD_FLAGS; }
 
 int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
                                  size_t scratch_bytes, uint32_t *grand_total, hipStream_t stream);

@@ -834,6 +834,92 @@ extern "C" int cgs_gaussian_cdf_table(const float *mean, const float *scale, con
 }
 
 // ---------------------------------------------------------------------------------
+// Bernoulli chunk streams on the device (container version 2, masks.b)
+// ---------------------------------------------------------------------------------
+// The reference codes the N*K offset masks as ONE arithmetic-coded stream with a constant two-symbol CDF
+// (scene/gaussian_model.py:1265-1269,1348-1353; utils/encodings.py:147-180): a serial chain of 10 M symbols at
+// 1 M anchors that no device can parallelise and that the version-1 container therefore codes on a host thread.
+// Version 2 of the container cuts the SAME symbol sequence into chunk streams (as the reference itself does for every
+// other attribute) and codes each with the same coder core: one wave per stream, the 64 symbols of a step fetched by
+// one coalesced load + ballot, the wave-uniform coder walking the ballot's bits on the scalar unit.  Stream s holds
+// exactly the bytes cgs_ac_encode_const_host produces for its symbols (tests/test_codec_gpu.py).
+__global__ void __launch_bounds__(64)
+    bernoulli_encode_kernel(const float *__restrict__ sym01, uint32_t c1, const int64_t *__restrict__ stream_off,
+                            int n_streams, uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
+                            uint32_t *__restrict__ out_len, int32_t *__restrict__ status) {
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (s >= n_streams) return;
+    const int64_t b = stream_off[s], e = stream_off[s + 1];
+    uint8_t *base = out + out_off[s];
+    AcEncoderT<WaveBitWriter> enc;
+    enc.init(base, (size_t)(out_off[s + 1] - out_off[s]));
+    bool bad = false;
+    for (int64_t i0 = b; i0 < e; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const float v = i < e ? sym01[i] : 0.f;
+        if (__ballot(v != 0.f && v != 1.f) != 0ull) { bad = true; break; }
+        const uint64_t ones = __ballot(v != 0.f);
+        const int cnt = (int)min((int64_t)64, e - i0);
+        for (int j = 0; j < cnt; ++j) {
+            const bool one = (ones >> j) & 1ull;
+            enc.encode(one ? c1 : 0u, one ? AC_TOP : c1);
+        }
+    }
+    const uint32_t len = (uint32_t)enc.finish(base);
+    if (lane == 0) {
+        out_len[s] = len;
+        if (bad) atomicMax(status, 1);
+        if (enc.out.overflow) atomicMax(status, 2);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+    bernoulli_decode_kernel(uint32_t c1, const int64_t *__restrict__ stream_off, int n_streams,
+                            const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off,
+                            float *__restrict__ sym_out) {
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (s >= n_streams) return;
+    const int64_t b = stream_off[s], e = stream_off[s + 1];
+    WaveAcDecoder dec;
+    dec.init(in + in_off[s], (size_t)(in_off[s + 1] - in_off[s]));
+    for (int64_t i0 = b; i0 < e; i0 += 64) {
+        const int cnt = (int)min((int64_t)64, e - i0);
+        const int last_j = (int)min((int64_t)64, e - 1 - i0);   // the stream's final symbol is not consumed
+        uint64_t ones = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const bool one = cdf_le_target(c1, dec.span_m1(), dec.num());
+            ones |= (uint64_t)one << j;
+            if (j != last_j) dec.consume(one ? c1 : 0u, one ? AC_TOP : c1);
+        }
+        const int64_t i = i0 + lane;
+        if (i < e) sym_out[i] = (ones >> lane) & 1ull ? 1.f : 0.f;
+    }
+}
+
+extern "C" int cgs_bernoulli_ac_encode(const float *sym01, uint32_t c1, const int64_t *stream_off, int n_streams,
+                                       uint8_t *out, const int64_t *out_off, uint32_t *out_len, int32_t *status,
+                                       void *stream) {
+    if (n_streams < 0 || c1 == 0 || c1 >= AC_TOP) { cgs_set_error("bernoulli_ac_encode: bad args"); return CGS_ERR_ARG; }
+    if (n_streams == 0) return CGS_OK;
+    hipLaunchKernelGGL(bernoulli_encode_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, sym01, c1, stream_off,
+                       n_streams, out, out_off, out_len, status);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_bernoulli_ac_decode(uint32_t c1, const int64_t *stream_off, int n_streams, const uint8_t *in,
+                                       const int64_t *in_off, float *sym_out, void *stream) {
+    if (n_streams < 0 || c1 == 0 || c1 >= AC_TOP) { cgs_set_error("bernoulli_ac_decode: bad args"); return CGS_ERR_ARG; }
+    if (n_streams == 0) return CGS_OK;
+    hipLaunchKernelGGL(bernoulli_decode_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, c1, stream_off,
+                       n_streams, in, in_off, sym_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // range-ANS for the hyper-prior symbols (host)
 // ---------------------------------------------------------------------------------
 // 32-bit state, 16-bit renormalisation words, frequency precision `prec` (16).

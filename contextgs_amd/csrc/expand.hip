@@ -2,8 +2,10 @@
 // elementwise / compaction chain of generate_neural_gaussians
 // (gaussian_renderer/__init__.py:112-145) as two streaming passes plus one
 // backward pass, instead of ~25 torch kernels and ten [N_vis*K, 22]
-// temporaries.  The three anchor MLPs stay on rocBLAS (north_star); this file
-// consumes their raw outputs.
+// temporaries.  The three anchor MLPs are the fused fp32-MFMA kernels of
+// csrc/mlp3.hip (rocBLAS, as the north star first suggested, was the round-1 v0
+// path: three skinny GEMMs per head and a 75 ms step); this file consumes
+// their raw outputs.
 //
 //   pass A  neural_opacity = mlp_opacity_out * mask;  flag = neural_opacity > 0
 //           (then an exclusive scan of flag gives every surviving slot its

@@ -1,9 +1,10 @@
-// Analysis hook (not part of include/cgs.h): how many wave iterations the blend kernels need with the current
+// Analysis hooks (experiment builds only, not part of include/cgs.h) and one test hook.  First: how many wave iterations the blend kernels need with the current
 // mapping (one 8x8 quadrant per wave, one Gaussian per iteration) versus a mapping where the four 16-lane rows of
 // a wave own one 4x4 pixel block each and walk their own Gaussian lists (four Gaussians per iteration).
 // Uses only the bounding boxes of the alpha >= 1/255 ellipses, like the blend kernels' own quadrant masks.
 #include "cgs_internal.h"
 
+#ifdef CGS_EXPERIMENTS   // counting kernels behind tools/blend_occupancy.py: experiment builds only
 __global__ void __launch_bounds__(256)
     blend_occupancy_kernel(int tiles_x, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ gid_sorted,
                            const float4 *__restrict__ rec, const uint32_t *__restrict__ tile_last,
@@ -182,11 +183,12 @@ extern "C" int cgs_debug_blend_splat_occupancy(const cgs_raster_cfg *cfg, int64_
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+#endif  // CGS_EXPERIMENTS
 
 // ---- test hook: the per-tile lists of csrc/tile_bin.hip against the round-1 binning (emit_pairs + 32-bit pair sort) ----
 // Re-bins the geometry of the last forward into a SECOND binning workspace with the round-1 path and counts the entries
 // of gid_sorted and of the tile ranges that differ from what the forward left in bin_ws / img_ws (out2[0], out2[1]).
-// tests/test_raster_gpu.py::test_tile_lists_equal_the_pair_sort; not part of include/cgs.h.
+// tests/test_raster_gpu.py::test_tile_lists_equal_the_pair_sort; declared in include/cgs.h as a test hook.
 __global__ void __launch_bounds__(256)
     dbg_count_diff_kernel(int64_t n, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
                           unsigned long long *__restrict__ out) {
@@ -228,6 +230,7 @@ extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64
     return CGS_OK;
 }
 
+#ifdef CGS_EXPERIMENTS
 // ---- analysis hook: wave iterations of the row mapping (four 4x4 blocks per wave) against an eight-group mapping (eight 4x2
 // half-blocks per wave, 8-lane groups), both with the octagon test of raster_blend_rows.hip and the backward's per-group bound
 // (entries behind the last contribution of the group's own pixels are dropped).  out4 = {iterations 4x4, iterations 4x2,
@@ -350,3 +353,4 @@ extern "C" int cgs_debug_blend_group_occupancy(const cgs_raster_cfg *cfg, int64_
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+#endif  // CGS_EXPERIMENTS

@@ -289,15 +289,41 @@ def prune_anchor(pc, mask):
     _assign(pc, params)
 
 
+_STATS = ("offset_gradient_accum", "offset_denom", "opacity_accum", "anchor_demon")
+
+
+@torch.no_grad()
+def reduce_statistics(pc):
+    """Multi-GPU: make the four densification buffers hold the GLOBAL statistics on every rank — the sum over
+    ranks of what each rank accumulated SINCE THE LAST CALL, on top of the carry-over the ranks already share.
+
+    A plain in-place all-reduce is only right once: entries that stay below adjust_anchor's reset thresholds
+    (offset_denom <= 40, anchor_demon <= 80) carry their — by then global — counts into the next round, and a second SUM
+    would count that carry once per rank.  So the model remembers the buffers as they were when the replicas
+    last agreed (`_stats_base`: set here and at the end of adjust_anchor, after its resets / compaction / padding) and only
+    the difference to it is reduced.  Idempotent; a no-op without a process group."""
+    if _dist.world() == 1:
+        return
+    bufs = [getattr(pc, n) for n in _STATS]
+    base = getattr(pc, "_stats_base", None)
+    if base is None or any(b.shape != t.shape for b, t in zip(base, bufs)):
+        base = [torch.zeros_like(t) for t in bufs]
+    deltas = [t - b for t, b in zip(bufs, base)]
+    _dist.allreduce_stats(deltas)
+    for t, b, d in zip(bufs, base, deltas):
+        t.copy_(b + d)
+    pc._stats_base = [t.clone() for t in bufs]
+
+
 @torch.no_grad()
 def adjust_anchor(pc, check_interval=100, success_threshold=0.8, grad_threshold=0.0002, min_opacity=0.005, rand_fn=None,
                   reduce_stats=True):
-    """:856-910.  With a process group the four statistics buffers are summed over the ranks first, so that every replica
-    grows and prunes the same anchors (the growing draw is shared, `dist.shared_rand_like`); reduce_stats=False
-    when the caller already summed them."""
+    """:856-910.  With a process group the four statistics buffers are summed over the ranks first (reduce_statistics), so
+    that every replica grows and prunes the same anchors (SURVEY 8e; the growing draw is shared, `dist.shared_rand_like`);
+    reduce_stats=False when the caller already called reduce_statistics(pc)."""
     K = int(pc.n_offsets)
     if reduce_stats:
-        _dist.allreduce_stats([pc.offset_gradient_accum, pc.offset_denom, pc.opacity_accum, pc.anchor_demon])
+        reduce_statistics(pc)
     # ---- adding anchors (:858-876) ----
     grads = pc.offset_gradient_accum / pc.offset_denom
     grads[grads.isnan()] = 0.0
@@ -327,3 +353,5 @@ def adjust_anchor(pc, check_interval=100, success_threshold=0.8, grad_threshold=
         pc.offset_denom, pc.offset_gradient_accum = od.view(-1, 1), oga.view(-1, 1)
         pc.opacity_accum, pc.anchor_demon = oa, ad
     pc.max_radii2D = torch.zeros(pc.get_anchor.shape[0], device=dev)
+    if _dist.world() > 1:      # what the replicas agree on from here; the next reduce_statistics sums the ranks' additions to it
+        pc._stats_base = [getattr(pc, n).clone() for n in _STATS]

@@ -249,6 +249,11 @@ class GaussianModel(nn.Module):
         from . import densify
         densify.prune_anchor(self, mask)
 
+    def reduce_statistics(self):
+        """Multi-GPU extension: global densification statistics on every rank (densify.reduce_statistics)."""
+        from . import densify
+        densify.reduce_statistics(self)
+
     def adjust_anchor(self, check_interval=100, success_threshold=0.8, grad_threshold=0.0002, min_opacity=0.005,
                       rand_fn=None, reduce_stats=True):                  # :856-910
         from . import densify

@@ -34,9 +34,13 @@
  *                              kernel family (gaussian_renderer/__init__.py:106-145)
  *   cgs_ac_*                   torchac.encode_float_cdf / decode_float_cdf as
  *                              called from utils/encodings.py:108,138,157,178
- *   cgs_gaussian_codec_*       encoder_gaussian / decoder_gaussian
+ *   cgs_gaussian_ac_*,
+ *   cgs_gaussian_stream_minmax encoder_gaussian / decoder_gaussian
  *                              (utils/encodings.py:83-144) without the
  *                              [n_sym, L] float table
+ *   cgs_bernoulli_ac_*         encoder / decoder of the offset masks
+ *                              (utils/encodings.py:147-180) as chunk streams
+ *                              on the device (container version 2)
  */
 #ifndef CGS_H
 #define CGS_H
@@ -180,6 +184,20 @@ size_t cgs_raster_bwd_scratch_bytes(int64_t P);
  * tiles. int64 x 2 on the device. */
 int cgs_raster_stats(const cgs_raster_cfg *cfg, void *img_ws, size_t img_bytes,
                      int64_t *stats_out, void *stream);
+/* test hook (tests/test_raster_gpu.py::test_tile_lists_equal_the_pair_sort): re-bins
+ * the geometry of the last forward into a second binning workspace with the
+ * classic (tile, depth)-pair sort and counts the entries of the per-tile lists
+ * (out2[0]) and of the tile ranges (out2[1]) that differ from what the forward
+ * left in bin_ws / img_ws.  R_ws = the pair count bin_ws was carved with. */
+int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64_t R,
+                          int64_t R_ws, void *geom_ws, size_t geom_bytes,
+                          void *bin_ws, size_t bin_bytes, void *img_ws,
+                          size_t img_bytes, void *bin_ws2, size_t bin_bytes2,
+                          void *ranges2, int64_t *out2, void *stream);
+/* "<sha256 of the sources the library was built from>|<compiler flags>"
+ * (contextgs_amd/build.py); the loader refuses a CGS_LIB_PATH library whose
+ * digest is not that of the sources next to it. */
+const char *cgs_build_info(void);
 
 /* ------------------------------------------------------------------ */
 /* Generic device primitives used by the path (exposed for tests)      */
@@ -584,6 +602,22 @@ int cgs_gaussian_ac_decode(const float *mean, const float *scale,
 int cgs_streams_compact(const uint8_t *src, const int64_t *src_off,
                         const uint32_t *len, const int64_t *dst_off,
                         int n_streams, uint8_t *dst, void *stream);
+/* Container version 2: the offset-mask symbols (scene/gaussian_model.py:1265-1269,
+ * 1348-1353; utils/encodings.py:147-180 code them as ONE serial stream) cut into
+ * chunk streams and coded by the same arithmetic coder, one wave per stream.
+ * sym01 flat float {0,1} (device); c1 = the interior entry of the integer CDF row
+ * [0, c1, 2^16] (cgs_cdf_float_to_u16_host of [0, 1-p, 1]); stream s covers
+ * [stream_off[s], stream_off[s+1]) and holds exactly the bytes
+ * cgs_ac_encode_const_host produces for those symbols.  Buffers / status as in
+ * cgs_gaussian_ac_encode. */
+int cgs_bernoulli_ac_encode(const float *sym01, uint32_t c1,
+                            const int64_t *stream_off, int n_streams,
+                            uint8_t *out, const int64_t *out_off,
+                            uint32_t *out_len, int32_t *status, void *stream);
+int cgs_bernoulli_ac_decode(uint32_t c1, const int64_t *stream_off,
+                            int n_streams, const uint8_t *in,
+                            const int64_t *in_off, float *sym_out,
+                            void *stream);
 /* test hook: the integer CDF table [n, max_v-min_v+2] of one stream */
 int cgs_gaussian_cdf_table(const float *mean, const float *scale,
                            const float *Q, int64_t q_div, int64_t n, int min_v,

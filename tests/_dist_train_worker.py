@@ -76,8 +76,7 @@ def main():
         if rank == 0:
             assert len(set(every)) == 1, f"replicas diverged after step {it}"
     # densification: statistics summed over ranks, then the same candidates everywhere (shared random draw)
-    stats = [pc.offset_gradient_accum, pc.offset_denom, pc.opacity_accum, pc.anchor_demon]
-    mgpu.allreduce_stats(stats)
+    pc.reduce_statistics()
     grads = (pc.offset_gradient_accum / pc.offset_denom.clamp(min=1)).squeeze(1)
     offset_mask = (pc.offset_denom > 0).squeeze(1)
     thr = float(torch.quantile(grads[offset_mask], 0.7)) if bool(offset_mask.any()) else 0.0

@@ -99,11 +99,37 @@ def test_row_broadcast_Q_and_reference_signatures(tmp_path):
     assert torch.equal(decoder_gaussian(mf, sf, 0.5, bstream=b, min_value=int(mn.item()), max_value=int(mx.item())), xs)
 
 
-@pytest.mark.parametrize("N,seed", [(3000, 2), (12000, 5)])
-def test_container_encode_decode_roundtrip(tmp_path, N, seed):
+@pytest.mark.parametrize("p0", [0.03, 0.31, 0.5, 0.97])
+def test_bernoulli_chunk_streams_equal_the_host_coder(p0):
+    """Container version 2's mask streams (cgs_bernoulli_ac_encode / _decode, one wave per chunk stream): every stream is
+    byte for byte the host coder's stream for its symbols (which tests/test_codec.py pins against the bit-list oracle),
+    incl. empty, 1-symbol, 63/64/65-symbol and ragged streams; decode is the inverse; non-binary input is refused."""
+    from contextgs_amd import codec
+    rng = np.random.default_rng(int(p0 * 1000))
+    lens = [0, 1, 63, 64, 65, 1000, 0, 10_000, 4097, 2]
+    edges = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    sym = (rng.random(int(edges[-1])) < p0).astype(np.float32)
+    sym_d = torch.from_numpy(sym).cuda()
+    blob, blens = codec.bernoulli_encode_packed(sym_d, p0, edges)
+    want = [codec.bernoulli_encode_host(sym[a:b].astype(np.int16), p0) for a, b in zip(edges[:-1], edges[1:])]
+    assert blens.tolist() == [len(w) for w in want]
+    assert blob.tobytes() == b"".join(want)
+    out = codec.bernoulli_decode_packed(p0, edges, blob, blens)
+    assert torch.equal(out, sym_d)
+    # a side-stream job gives the same bytes
+    job = codec.BernoulliEncodeJob(sym_d, p0, edges, torch.cuda.Stream())
+    blob2, blens2 = job.result()
+    assert blob2.tobytes() == blob.tobytes() and np.array_equal(blens, blens2)
+    bad = sym_d.clone(); bad[5000] = 0.5
+    with pytest.raises(RuntimeError, match="outside"):
+        codec.bernoulli_encode_packed(bad, p0, edges)
+
+
+@pytest.mark.parametrize("N,seed,version", [(3000, 2, 1), (12000, 5, 1), (3000, 2, 2), (12000, 5, 2)])
+def test_container_encode_decode_roundtrip(tmp_path, N, seed, version):
     """conduct_encoding -> files -> conduct_decoding on a second model object: every decoded
     attribute equals the encoder-side quantised value bit for bit; rendering the decoded model
-    equals rendering the encoder's quantised model."""
+    equals rendering the encoder's quantised model.  Both container versions (codec_driver.CONTAINER_VERSION)."""
     import golden_inputs as gi
     from contextgs_amd import context_model as cm
     from contextgs_amd.model import GaussianModel
@@ -122,7 +148,8 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed):
     enc = build()
     enc.eval()
     d = str(tmp_path / "bitstreams")
-    info = enc.conduct_encoding(d)
+    from contextgs_amd.codec_driver import conduct_encoding
+    info = conduct_encoding(enc, d, container_version=version)
     assert "EncTime" in info and "Total" in info
     for f in ["anchor.npy", "hyper.b", "masks.b", "meta.b", "mlp.pt"] + [f"{a}{l}.b" for a in ("feat", "scaling", "offsets") for l in range(3)]:
         assert os.path.exists(os.path.join(d, f)), f
@@ -166,7 +193,37 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed):
     prob = float(meta[8])
     sym = ((enc.get_mask[m].reshape(-1) > 0).to(torch.int64)).cpu().tolist()
     row = ref.float_cdf_to_int([0.0, float(np.float32(1.0) - np.float32(prob)), 1.0])
-    assert open(os.path.join(d, "masks.b"), "rb").read() == ref.ac_encode([row] * len(sym), sym)
+    masks_b = open(os.path.join(d, "masks.b"), "rb").read()
+    if version == 1:
+        assert len(meta) == 14
+        assert masks_b == ref.ac_encode([row] * len(sym), sym)
+    else:
+        # version 2: the same symbols cut into 1000-anchor chunk streams, each the oracle's stream for its symbols
+        assert len(meta) == 15 and meta[14]["version"] == 2
+        ck, K = meta[14]["chunk"], enc.n_offsets
+        want = b"".join(ref.ac_encode([row] * len(sym[a:a + ck["masks"] * K]), sym[a:a + ck["masks"] * K])
+                        for a in range(0, len(sym), ck["masks"] * K))
+        assert masks_b == want and sum(meta[14]["bit_masks"]) == 8 * len(masks_b)
+        # shorter feature streams: ceil(n_level / chunk) streams per level
+        for l, n_l in enumerate(reversed(meta[13])):
+            assert len(meta[10][l]) == -(-n_l // ck["feat"]) and len(meta[12][l]) == -(-n_l // ck["offsets"])
+
+
+@pytest.mark.parametrize("N", [3000, 10000])
+def test_container_bytes_match_the_committed_digest(tmp_path, N):
+    """Known-answer pin of the bitstream (tests/container_digest.py): re-encoding the golden model gives, byte for byte, the
+    files whose sha256 / length were committed from the MI355X (tools/make_container_golden.py), for both container
+    versions; so do the header's content and every decoded tensor."""
+    import json
+    from container_digest import container_digest
+    path = os.path.join(os.path.dirname(__file__), "golden", f"container_n{N}.json")
+    want = json.load(open(path))["containers"]
+    for w in want:
+        got = container_digest(w["N"], w["seed"], w["container_version"], tmp_path)
+        for f, (sha, size) in w["files"].items():
+            assert got["files"][f] == [sha, size], (w["container_version"], f, got["files"][f], [sha, size])
+        assert got["meta"] == w["meta"], ("meta.b content", w["container_version"])
+        assert got["decoded"] == w["decoded"], w["container_version"]
 
 
 def test_grouped_launch_is_byte_identical_to_per_group_launches():

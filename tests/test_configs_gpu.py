@@ -83,13 +83,14 @@ def test_c2_100k_anchors_800x800_forward_backward_vs_oracles(oracle32):
         assert float((err > 2e-4).mean()) <= 2e-3 and float(np.median(err)) <= 1e-6, (k, float(err.max()))
 
 
-def _roundtrip(pc, tmpdir, render_check=None):
+def _roundtrip(pc, tmpdir, render_check=None, version=1):
     """conduct_encoding -> files -> conduct_decoding on a fresh model; value-level equality of every attribute."""
     from contextgs_amd import context_model as cm
+    from contextgs_amd.codec_driver import conduct_encoding
     from contextgs_amd.synth import make_scene
     pc.eval()
     d = str(tmpdir)
-    pc.conduct_encoding(d)
+    conduct_encoding(pc, d, container_version=version)
     size = sum(os.path.getsize(os.path.join(d, x)) for x in os.listdir(d))
     N = pc._anchor.shape[0]
     dec = make_scene(N, seed=0, voxel_size=pc.voxel_size, requires_grad=False)
@@ -144,17 +145,23 @@ def test_c3_500k_anchors_1080p_encode_decode(tmp_path):
 
     size, nv = _roundtrip(pc, tmp_path / "c3", render_check)
     assert nv > 400_000 and 20e6 < size < 120e6
+    size2, _ = _roundtrip(pc, tmp_path / "c3v2", None, version=2)          # version 2: same symbols, shorter streams
+    assert abs(size2 - size) < 0.002 * size, (size, size2)
 
 
 def test_c5_3M_anchors_rate_sweep_roundtrip(tmp_path):
     from contextgs_amd.synth import make_scene
     pc = make_scene(3_000_000, seed=0, requires_grad=False)
     rng = torch.Generator(device="cuda").manual_seed(11)
+    import shutil
     sizes = []
-    for k, sigma in enumerate((1.0, 5.0)):          # feature spread as the rate proxy of the lambda sweep
+    # feature spread as the rate proxy of the five-point lambda sweep (scripts/train_blending.py:3)
+    for k, sigma in enumerate((1.0, 2.0, 3.0, 5.0, 8.0)):
         with torch.no_grad():
             pc._anchor_feat.copy_(torch.round(torch.randn(pc._anchor_feat.shape, device="cuda", generator=rng) * sigma))
-        size, nv = _roundtrip(pc, tmp_path / f"c5_{k}")
+        size, nv = _roundtrip(pc, tmp_path / f"c5_{k}", version=1 + (k % 2))      # both container versions along the sweep
+        shutil.rmtree(tmp_path / f"c5_{k}", ignore_errors=True)
         assert nv > 2_400_000
         sizes.append(size)
-    assert sizes[1] > 1.15 * sizes[0]               # more spread -> more bits
+    assert all(b > 1.03 * a for a, b in zip(sizes, sizes[1:])), sizes            # more spread -> more bits, monotonically
+    assert sizes[-1] > 1.3 * sizes[0], sizes

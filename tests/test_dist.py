@@ -379,3 +379,69 @@ def test_deferred_weight_gradients_follow_the_per_anchor_collectives():
         # step 1: W.grad carried over from step 0 (already averaged) + this step's average
         torch.testing.assert_close(results[1][0], ref[0][0] + ref[1][0])
         torch.testing.assert_close(results[1][1], ref[1][1]); torch.testing.assert_close(results[1][2], ref[1][2])
+
+
+def _stats_worker(rank, world, port, q):
+    """Two densification rounds of the statistics reduction (densify.reduce_statistics) on a stand-in model: per-rank
+    accumulations, the resets adjust_anchor applies above its thresholds, carry-over below them."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import densify
+
+        class PC:
+            pass
+        pc = PC()
+        n = 12
+        for name in densify._STATS:
+            setattr(pc, name, torch.zeros(n, 1))
+        out = []
+        for rnd in range(3):
+            g = torch.Generator().manual_seed(100 * rnd + rank)           # what THIS rank's views add in this round
+            for name in densify._STATS:
+                getattr(pc, name).add_(torch.randint(0, 5, (n, 1), generator=g).float())
+            densify.reduce_statistics(pc)
+            densify.reduce_statistics(pc)                                  # idempotent
+            out.append([getattr(pc, name).clone() for name in densify._STATS])
+            # adjust_anchor's resets: entries above a threshold are zeroed, the rest carry over (densify.py, :894-896)
+            for name in densify._STATS:
+                t = getattr(pc, name)
+                t[t > 6] = 0
+            pc._stats_base = [getattr(pc, name).clone() for name in densify._STATS]
+        q.put(_by_value((rank, out)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_statistics_carry_over_is_counted_once_across_densification_rounds():
+    """an in-place all-reduce of the statistics buffers every round counts the carry-over of un-reset entries
+    once per rank.  reduce_statistics sums only what the ranks added since they last agreed: three rounds on two ranks
+    equal ONE process that sees both ranks' views."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = _from_value(q.get(timeout=120))
+        res[r[0]] = r[1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the single-process run over the union of the views
+    n = 12
+    bufs = [torch.zeros(n, 1) for _ in range(4)]
+    for rnd in range(3):
+        for rank in range(world):
+            g = torch.Generator().manual_seed(100 * rnd + rank)
+            for t in bufs:
+                t.add_(torch.randint(0, 5, (n, 1), generator=g).float())
+        for k, t in enumerate(bufs):
+            assert torch.equal(res[0][rnd][k], t) and torch.equal(res[1][rnd][k], t), (rnd, k)
+        for t in bufs:
+            t[t > 6] = 0
+    assert any(float(t.sum()) > 0 for t in bufs)          # some entries did carry over

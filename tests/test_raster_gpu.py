@@ -251,9 +251,6 @@ def _bin_compare():
     ranges2 = torch.zeros(tiles * 2, dtype=torch.int32, device=dev)
     out = torch.zeros(2, dtype=torch.int64, device=dev)
     f = L.cgs_debug_bin_compare
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
-                  C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib.check(f(cfg.ref, Pn, R, R_ws, _lib.ptr(last_call["geom_ws"]), last_call["geom_ws"].numel(),
                  _lib.ptr(last_call["bin_ws"]), last_call["bin_ws"].numel(), _lib.ptr(last_call["img_ws"]),
                  last_call["img_ws"].numel(), _lib.ptr(bin2), bin2.numel(), _lib.ptr(ranges2), _lib.ptr(out),
