@@ -110,20 +110,23 @@ def write_file(path: str, blob, piece: int = 8 << 20):
             with open(path, "wb") as f:
                 f.write(mv)
         return [host_pool().submit(small)]
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    os.ftruncate(fd, n)
-
+    # nothing on the caller's thread touches the file: truncating an existing 80 MB file (the previous container in the same
+    # directory) alone takes ~10 ms.  Every slice job opens the file itself; the last job cuts it to its final length.
     def part(lo):
-        hi = min(n, lo + piece)
-        while lo < hi:
-            lo += os.pwrite(fd, mv[lo:hi], lo)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+        try:
+            hi = min(n, lo + piece)
+            while lo < hi:
+                lo += os.pwrite(fd, mv[lo:hi], lo)
+        finally:
+            os.close(fd)
     jobs = [host_pool().submit(part, lo) for lo in range(0, n, piece)]
 
-    def close():
+    def finish():
         for j in jobs:
             j.result()
-        os.close(fd)
-    return [host_pool().submit(close)]
+        os.truncate(path, n)
+    return [host_pool().submit(finish)]
 
 
 def bernoulli_encode_host(sym: np.ndarray, p0: float) -> bytes:

@@ -131,10 +131,10 @@ def _predict(pc, level, feat_in):
 _SIDE = {}
 
 
-def _side_stream(dev):
-    """One side stream per device for the life of the process (a fresh stream per container costs the caching allocator a
-    fresh pool, see codec.StagedFiles)."""
-    key = str(dev)
+def _side_stream(dev, tag=""):
+    """One side stream per device (and purpose) for the life of the process (a fresh stream per container costs the caching
+    allocator a fresh pool, see codec.StagedFiles)."""
+    key = str(dev) + tag
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
@@ -204,6 +204,17 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     plan, inverse_indices_list, mapping_list = level_plan(pc, _anchor, None)
 
     tr("level plan built")
+    mlp_job = None
+    if root:
+        # mlp.pt needs nothing the encoder computes after this point (level_scale is set): written by a host thread (its small device-to-host copies on a
+        # stream of their own, not behind the coder launch) while this thread drives the levels
+        dev_ = _mask.device
+
+        def write_mlp():
+            torch.cuda.set_device(dev_)
+            with torch.cuda.stream(_side_stream(dev_, "mlp")):
+                save_mlp_checkpoints(pc, path("mlp.pt"))
+        mlp_job = codec.host_pool().submit(write_mlp)
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
@@ -312,7 +323,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     if version == 2:
         meta.append({"version": 2, "chunk": chunk, "bit_masks": (mask_lens * 8).tolist()})
     torch.save(meta, meta_path)
-    save_mlp_checkpoints(pc, path("mlp.pt"))
+    mlp_job.result()
     bit_meta = os.path.getsize(meta_path) * 8
     mlp = pc.get_mlp_size()[0]
     r = lambda v: round(v / bit2MB_scale, 4)
