@@ -295,11 +295,13 @@ def to_host_pinned(t: torch.Tensor, key: str) -> np.ndarray:
     return stage.numpy()
 
 
-def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False):
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
     (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
     blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
-    b"".join(chunk strings) file), lens int64[S], min/max int32[S] (host)."""
+    b"".join(chunk strings) file), lens int64[S], min/max int32[S] (host).
+    lanes (container version 2): every [stream_off[s], stream_off[s+1]) is a BLOCK coded as 64 interleaved lane streams
+    behind a 128-byte header of their lengths (csrc/codec.hip, "Lane-parallel Gaussian codec")."""
     L = _lib.lib()
     _lib.require_device(x, mean, scale, Q)
     x, mean, scale, Q = _f(x).reshape(-1), _f(mean).reshape(-1), _f(scale).reshape(-1), _f(Q).reshape(-1)
@@ -316,7 +318,10 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
     _lib.check(L.cgs_gaussian_stream_minmax(_lib.ptr(x), _lib.ptr(Q), q_div, _lib.ptr(off_d), S, _lib.ptr(mn),
                                             _lib.ptr(mx), stream), "cgs_gaussian_stream_minmax")
     lens_sym = (off_h[1:] - off_h[:-1])
-    caps = (lens_sym * 2 + 16 + 7) // 8 * 8
+    if lanes:
+        caps = 128 + 64 * (((lens_sym + 63) // 64 * 2 + 16 + 7) // 8 * 8)        # cgs_lanes_block_slot_bytes
+    else:
+        caps = (lens_sym * 2 + 16 + 7) // 8 * 8
     out_off_h = torch.zeros(S + 1, dtype=torch.int64)
     out_off_h[1:] = torch.cumsum(caps, 0)
     out = torch.empty(int(out_off_h[-1]) + 16, dtype=torch.uint8, device=dev)
@@ -324,9 +329,10 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
     # [status, len_0 .. len_{S-1}] in one buffer: ONE device->host read decides everything below
     st_len = torch.zeros(S + 1, dtype=torch.int32, device=dev)
     status, out_len = st_len[:1], st_len[1:]
-    _lib.check(L.cgs_gaussian_ac_encode(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div,
-                                        _lib.ptr(off_d), S, _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(out), _lib.ptr(out_off),
-                                        _lib.ptr(out_len), _lib.ptr(status), stream), "cgs_gaussian_ac_encode")
+    enc = L.cgs_gaussian_ac_encode_lanes if lanes else L.cgs_gaussian_ac_encode
+    _lib.check(enc(_lib.ptr(x), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div,
+                   _lib.ptr(off_d), S, _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(out), _lib.ptr(out_off),
+                   _lib.ptr(out_len), _lib.ptr(status), stream), "cgs_gaussian_ac_encode")
     dst_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
     torch.cumsum(out_len, 0, out=dst_off[1:])
     st_len_h = st_len.cpu().numpy()
@@ -336,8 +342,12 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
                                                  else "stream overflowed its buffer"))
     lens = st_len_h[1:].astype(np.int64)
     packed = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device=dev)
-    _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
-                                     _lib.ptr(packed), stream), "cgs_streams_compact")
+    if lanes:
+        _lib.check(L.cgs_lanes_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(off_d), _lib.ptr(dst_off), S,
+                                       _lib.ptr(packed), stream), "cgs_lanes_compact")
+    else:
+        _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
+                                         _lib.ptr(packed), stream), "cgs_streams_compact")
     nbytes = int(lens.sum())
     if staging and nbytes > 0:
         # pinned, reused staging buffer: ~25 GB/s instead of a pageable copy (~5 GB/s, 25 ms for a 1 M-anchor model).
@@ -365,7 +375,7 @@ def _expand_q(Q, q_div):
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
 
 
-def gaussian_encode_groups(groups, staging=False):
+def gaussian_encode_groups(groups, staging=False, lanes=False):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
     staging: download through the module's reused pinned buffer; the blobs then alias it until the next staging call.
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
@@ -393,13 +403,13 @@ def gaussian_encode_groups(groups, staging=False):
         b = D.stream_blocks(E)
         s0, s1 = b[D.rank()], b[D.rank() + 1]
         e0, e1 = int(E[s0]), int(E[s1])
-        part = gaussian_encode_packed(X[e0:e1], M[e0:e1], Sc[e0:e1], Qe[e0:e1], E[s0:s1 + 1] - e0, 1)
+        part = gaussian_encode_packed(X[e0:e1], M[e0:e1], Sc[e0:e1], Qe[e0:e1], E[s0:s1 + 1] - e0, 1, lanes=lanes)
         parts = D.gather_objects(part, dst=0)
         if parts is None:
             return None
         blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
     else:
-        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging)
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes)
     out, s0, b0 = [], 0, 0
     for c in counts:
         nb = int(lens[s0:s0 + c].sum())
@@ -408,7 +418,7 @@ def gaussian_encode_groups(groups, staging=False):
     return out
 
 
-def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div=1):
+def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div=1, lanes=False):
     """Inverse of gaussian_encode_packed -> flat float32 [n] device tensor of dequantised values.
     blob: bytes / uint8 ndarray with the S streams back to back; lens: their byte lengths."""
     L = _lib.lib()
@@ -438,9 +448,10 @@ def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens,
     mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
     mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
     off_d = off_h.to(dev)
-    _lib.check(L.cgs_gaussian_ac_decode(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
-                                        _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
-                                        _lib.current_stream()), "cgs_gaussian_ac_decode")
+    dec = L.cgs_gaussian_ac_decode_lanes if lanes else L.cgs_gaussian_ac_decode
+    _lib.check(dec(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
+                   _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
+                   _lib.current_stream()), "cgs_gaussian_ac_decode")
     return x_out
 
 
@@ -547,7 +558,7 @@ class StagedFiles:
         return self.dev_buf[pos:pos + n]
 
 
-def gaussian_decode_groups(groups):
+def gaussian_decode_groups(groups, lanes=False):
     """groups = [(mean, scale, Q, stream_off, min_v, max_v, blob, lens, q_div), ...] -> [flat float32 values, ...];
     one coder launch for all streams of all groups."""
     if not groups:
@@ -577,10 +588,10 @@ def gaussian_decode_groups(groups):
         e0, e1 = int(E[s0]), int(E[s1])
         cum = np.concatenate([[0], np.cumsum(lens)])
         local = gaussian_decode_packed(M[e0:e1], Sc[e0:e1], Qe[e0:e1], E[s0:s1 + 1] - e0, mn[s0:s1], mx[s0:s1],
-                                       blob[int(cum[s0]):int(cum[s1])], lens[s0:s1], 1)
+                                       blob[int(cum[s0]):int(cum[s1])], lens[s0:s1], 1, lanes=lanes)
         flat = D.all_gather_rows(local, [int(E[b[r + 1]]) - int(E[b[r]]) for r in range(D.world())])
     else:
-        flat = gaussian_decode_packed(M, Sc, Qe, E, mn, mx, blob, lens, 1)
+        flat = gaussian_decode_packed(M, Sc, Qe, E, mn, mx, blob, lens, 1, lanes=lanes)
     return list(torch.split(flat, sizes))
 
 

@@ -41,12 +41,15 @@ MAX_BATCH = 1_000                                              # :1071
 
 # Container versions.  1 = the reference's container (default): one serial arithmetic-coded mask stream, 10 000-anchor hyper
 # strings, 1000-anchor chunk streams for every Gaussian-coded attribute, a 14-item meta list.  2 = the same files, symbols,
-# order and coder, re-cut for a device: the masks are chunk streams coded by the device coder (codec.BernoulliEncodeJob; no
-# serial host stream is left on either critical chain), and the chunk length is per attribute (a coder launch lasts as long
-# as its LONGEST stream — 50 000 serial symbols for a 1000-anchor feature chunk —, so version 2 cuts streams of ~10 000
-# symbols).  meta.b gets a 15th item {"version": 2, "chunk": {...}, "bit_masks": [...]}; a 14-item list is version 1.
+# order and coder, re-cut for a device: the masks are 1000-anchor chunk streams coded by the device coder
+# (codec.BernoulliEncodeJob; no serial host stream is left on either critical chain), and feat / scaling / offsets are cut
+# into BLOCKS of V2_BLOCK consecutive symbols, each coded as 64 interleaved lane streams by one wave (csrc/codec.hip,
+# "Lane-parallel Gaussian codec": the coder arithmetic runs 64-wide in vector registers instead of one serial chain per
+# wave on the scalar unit).  meta.b gets a 15th item {"version": 2, "block_symbols": ..., "chunk": {"masks": ...},
+# "bit_masks": [...]}; the per-stream lists of the header (bits, min, max) are per block; a 14-item list is version 1.
 CONTAINER_VERSION = 1
-V2_CHUNK = {"feat": 200, "scaling": 1000, "offsets": 400, "masks": 1000}       # anchors per chunk stream
+V2_BLOCK = 64 * 512                      # symbols per block: 512 per lane stream
+V2_CHUNK = {"masks": 1000}               # anchors per mask chunk stream
 
 
 def default_container_version():
@@ -114,6 +117,12 @@ def estimate_final_bits(pc):                                   # :980-1004
             f"masks {r(mk)}, MLPs {r(mlp)}, Total {r(a + f + s + o + h + mk + mlp)}")
 
 
+def _block_edges(n_sym, block=None):
+    """Element offsets of the version-2 blocks of a group of n_sym symbols."""
+    block = V2_BLOCK if block is None else int(block)
+    return torch.tensor(list(range(0, n_sym, block)) + [n_sym] if n_sym > 0 else [0], dtype=torch.int64)
+
+
 def _chunk_rows(n, batch=MAX_BATCH):
     edges = list(range(0, n, batch)) + [n]
     return edges if n > 0 else [0]
@@ -160,7 +169,8 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     version = default_container_version() if container_version is None else int(container_version)
     if version not in (1, 2):
         raise ValueError(f"container version {version}: 1 (the reference's container) or 2")
-    chunk = dict(V2_CHUNK) if version == 2 else {k: MAX_BATCH for k in V2_CHUNK}
+    chunk = dict(V2_CHUNK) if version == 2 else {"masks": MAX_BATCH}
+    lanes = version == 2
     torch.cuda.synchronize(); t1 = time.time()
     tr = _tracer("encode")
     print("Start encoding ...")
@@ -235,8 +245,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
-        rows_f, rows_s, rows_o = (torch.tensor(_chunk_rows(n_l, chunk[a]), dtype=torch.int64)
-                                  for a in ("feat", "scaling", "offsets"))
+        rows = torch.tensor(_chunk_rows(n_l), dtype=torch.int64)
 
         tr(f"level {level}: chunk rows")
         feat_q = STE_multistep.apply(_feat[orig], Qf.unsqueeze(1))
@@ -246,13 +255,18 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         m30 = _mask[orig].repeat(1, 1, 3).reshape(n_l, 3 * K).to(torch.bool)              # :1222-1223
         cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=m30.device)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
-        off_edges = cnt[rows_o.to(cnt.device)].cpu()
+        if lanes:      # version 2: blocks of V2_BLOCK symbols, whatever anchors they belong to
+            edges_f, edges_s = _block_edges(n_l * D), _block_edges(n_l * 6)
+            off_edges = _block_edges(int(cnt[-1].item()))
+        else:
+            edges_f, edges_s = rows * D, rows * 6
+            off_edges = cnt[rows.to(cnt.device)].cpu()
         tr(f"level {level}: offset stream edges on the host")
         live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the four operands
         pick = lambda t: t.reshape(-1).index_select(0, live)
 
-        groups += [(feat_q, mean_feat, scale_feat, Qf, rows_f * D, D),
-                   (scal_q, mean_scaling, scale_scaling, Qs, rows_s * 6, 6),
+        groups += [(feat_q, mean_feat, scale_feat, Qf, edges_f, D),
+                   (scal_q, mean_scaling, scale_scaling, Qs, edges_s, 6),
                    (pick(off_q), pick(mean_offsets), pick(scale_offsets), Qo.index_select(0, live // (3 * K)),
                     off_edges, 1)]
         tags += [("feat", level), ("scaling", level), ("offsets", level)]
@@ -272,7 +286,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         tr("hyper symbols on the host, rANS jobs submitted")
     torch.cuda.synchronize(); t0 = time.time()
     tr("levels done on the device")
-    coded = codec.gaussian_encode_groups(groups, staging=True)        # blobs alias a pinned buffer: written below
+    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes)   # blobs alias a pinned buffer: written below
     torch.cuda.synchronize(); t_codec = time.time() - t0
     tr("coder launch done, bitstream on the host")
     if not root:
@@ -321,7 +335,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
             min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
             bit_d["offsets"], N_levels_list]
     if version == 2:
-        meta.append({"version": 2, "chunk": chunk, "bit_masks": (mask_lens * 8).tolist()})
+        meta.append({"version": 2, "block_symbols": V2_BLOCK, "chunk": chunk, "bit_masks": (mask_lens * 8).tolist()})
     torch.save(meta, meta_path)
     mlp_job.result()
     bit_meta = os.path.getsize(meta_path) * 8
@@ -350,7 +364,9 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     version = int(extra.get("version", 1))
     if version not in (1, 2):
         raise RuntimeError(f"meta.b: container version {version} is newer than this decoder (1, 2)")
-    chunk = extra["chunk"] if version == 2 else {k: max_batch for k in V2_CHUNK}
+    chunk = extra["chunk"] if version == 2 else {"masks": max_batch}
+    lanes = version == 2
+    block = int(extra.get("block_symbols", V2_BLOCK))
     # (map_location: whatever tensors a header holds — the reference stores its minima / maxima as device tensors — are only
     #  ever read as Python numbers here: restoring them on the device would cost a copy each and a stream drain per .item())
     tr("meta.b loaded")
@@ -436,9 +452,11 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
 
     def live_slots(orig_, n_, rows_):
         m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
+        live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the three operands and the fill
+        if rows_ is None:                                        # version 2: blocks of `block` live symbols
+            return _block_edges(int(live.numel()), block), live
         cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
-        live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the three operands and the fill
         return cnt[rows_.to(dev)], live
 
     live_pre = {}
@@ -448,15 +466,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         torch.cuda.current_stream().wait_event(masks_ready)
         masks_decoded.record_stream(torch.cuda.current_stream())
         for (level_, _tc, orig_, _h) in plan:
-            n_ = int(orig_.shape[0])
-            live_pre[level_] = live_slots(orig_, n_, torch.tensor(_chunk_rows(n_, chunk["offsets"]), dtype=torch.int64))
-        if live_pre:
-            edges_h = torch.cat([e for (e, _l) in live_pre.values()]).cpu()
-            pos = 0
-            for level_, (e, l) in list(live_pre.items()):
-                live_pre[level_] = (edges_h[pos:pos + e.numel()], l)
-                pos += e.numel()
-        tr("offset stream edges of all levels on the host")
+            live_pre[level_] = live_slots(orig_, int(orig_.shape[0]), None)
+        tr("offset blocks of all levels on the host")
 
     def offset_groups(pending):
         groups, fills = [], []
@@ -484,12 +495,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
-        rows_f, rows_s, rows_o = (torch.tensor(_chunk_rows(n_l, chunk[a]), dtype=torch.int64)
-                                  for a in ("feat", "scaling", "offsets"))
-        pending_offsets.append((level, orig, n_l, rows_o, mean_offsets, scale_offsets, Qo))
-        groups = [(mean_feat, scale_feat, Qf, rows_f * D, min_feat_d[level], max_feat_d[level],
+        rows = torch.tensor(_chunk_rows(n_l, max_batch), dtype=torch.int64)
+        edges_f, edges_s = (_block_edges(n_l * D, block), _block_edges(n_l * 6, block)) if lanes else (rows * D, rows * 6)
+        pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
+        groups = [(mean_feat, scale_feat, Qf, edges_f, min_feat_d[level], max_feat_d[level],
                    *chunk_lens("feat", level, bit_feat_d[level]), D),
-                  (mean_scaling, scale_scaling, Qs, rows_s * 6, min_scaling_d[level], max_scaling_d[level],
+                  (mean_scaling, scale_scaling, Qs, edges_s, min_scaling_d[level], max_scaling_d[level],
                    *chunk_lens("scaling", level, bit_scaling_d[level]), 6)]
         fills = []
         if version == 2:
@@ -499,7 +510,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             groups += og
         elif level == last_level:
             fork = torch.cuda.current_stream().record_event()       # everything the offsets need exists before this point
-        decoded = codec.gaussian_decode_groups(groups)
+        decoded = codec.gaussian_decode_groups(groups, lanes=lanes)
         tr(f"level {level}: coder launch enqueued")
         feat_dec, scal_dec = decoded[0], decoded[1]
         for (orig_, n_, live), off_vals in zip(fills, decoded[2:]):

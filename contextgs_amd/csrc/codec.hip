@@ -920,6 +920,253 @@ extern "C" int cgs_bernoulli_ac_decode(uint32_t c1, const int64_t *stream_off, i
 }
 
 // ---------------------------------------------------------------------------------
+// Lane-parallel Gaussian codec (container version 2: feat / scaling / offsets)
+// ---------------------------------------------------------------------------------
+// The reference's container cuts every attribute into 1000-anchor chunk streams (scene/gaussian_model.py:1071,1192-1238):
+// few, long streams (50 000 symbols for a feature chunk).  A stream is a serial chain, so the kernels above give each one
+// a WAVE whose 64 lanes only prepare operands for a coder that runs on the scalar unit: ~130 scalar instructions per symbol,
+// one scalar unit per CU — 62 M symbols take ~17 ms (encode) / ~22 ms (decode, three dependent launches) at 1 M anchors
+// however short the streams are cut.  Version 2 re-cuts the SAME symbol sequence for the machine: a BLOCK of up to
+// 64 * L consecutive symbols is coded by one wave as 64 INTERLEAVED lane streams (lane l codes symbols l, l + 64, l + 128,
+// ... of the block), each lane running its own instance of the same arithmetic coder in vector registers.  Loads of
+// x / mean / scale stay coalesced (step t reads elements 64 t + lane), the coder arithmetic is 64-wide, and a block costs
+// L serial steps instead of 64 L.  Block layout in the file: 64 little-endian uint16 byte lengths, then the 64 lane streams
+// back to back; min / max of the block's symbols (CDF normalisation) and the block's byte length travel in meta.b like the
+// chunk streams' do.  Lane stream l of a block is byte for byte what AcEncoderT / the table coder produce for the block's
+// symbols l, l + 64, ... (tests/test_codec_gpu.py).
+#define LANES_HDR 128
+
+struct LaneBitSource {
+    const uint8_t *p;
+    uint64_t bb;      // next bits, MSB first; the top nb are valid, the rest zero
+    int nb;
+    __device__ void init(const uint8_t *b) { p = b; bb = 0; nb = 0; }
+    __device__ uint32_t get_bits(int n) {           // 1 <= n <= 32; may read up to 4 bytes past the lane stream (any bits do)
+        if (nb < n) {
+            uint32_t w;
+            __builtin_memcpy(&w, p, 4);
+            p += 4;
+            bb |= (uint64_t)__builtin_bswap32(w) << (32 - nb);
+            nb += 32;
+        }
+        const uint32_t r = (uint32_t)(bb >> (64 - n));
+        bb <<= n;
+        nb -= n;
+        return r;
+    }
+};
+
+struct LaneAcDecoder {
+    uint32_t low, high, value;
+    LaneBitSource in;
+    __device__ void init(const uint8_t *buf) {
+        low = 0; high = 0xFFFFFFFFu;
+        in.init(buf);
+        value = in.get_bits(32);
+    }
+    __device__ uint64_t num() const { return (((uint64_t)value - (uint64_t)low + 1) << AC_PRECISION) - 1; }
+    __device__ uint32_t span_m1() const { return high - low; }
+    __device__ void consume(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> AC_PRECISION);
+        low = low + (uint32_t)((span * (uint64_t)c_low) >> AC_PRECISION);
+        const AcRenorm r = ac_renorm(low, high);
+        const int n = r.k + r.u;
+        if (n == 0) return;
+        if (n <= 32) {
+            value = (uint32_t)(((uint64_t)value << n) | (uint64_t)in.get_bits(n));
+            if (r.u > 0) value ^= 0x80000000u;
+        } else {
+            value = r.k >= 32 ? in.get_bits(32) : ((value << r.k) | in.get_bits(r.k));
+            value = ((value << r.u) ^ 0x80000000u) | in.get_bits(r.u);
+        }
+    }
+};
+
+// bytes of the worst-case slot of one lane stream of a block with nsym symbols (multiple of 8)
+__host__ __device__ inline int64_t lanes_slot_bytes(int64_t nsym) { return (((nsym + 63) / 64) * 2 + 16 + 7) / 8 * 8; }
+
+extern "C" size_t cgs_lanes_block_slot_bytes(int64_t nsym) { return (size_t)(LANES_HDR + 64 * lanes_slot_bytes(nsym > 0 ? nsym : 0)); }
+
+// ONE WAVE PER BLOCK, one coder per lane.  out + out_off[b]: the block's worst-case region (cgs_lanes_block_slot_bytes): the
+// header's 64 lengths, then 64 lane slots of lanes_slot_bytes each.  out_len[b] = LANES_HDR + sum of the lane lengths.
+__global__ void __launch_bounds__(64)
+    gaussian_encode_lanes_kernel(const float *__restrict__ x, const float *__restrict__ mean, const float *__restrict__ scale,
+                                 const float *__restrict__ Q, int64_t q_div, const int64_t *__restrict__ blk_off, int n_blocks,
+                                 const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
+                                 uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
+                                 uint32_t *__restrict__ out_len, int32_t *__restrict__ status) {
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
+    const int64_t slot = lanes_slot_bytes(e - b);
+    uint8_t *base = out + out_off[blk];
+    uint8_t *mine = base + LANES_HDR + lane * slot;
+    AcEncoderT<WaveBitWriter> enc;                 // a lane-private instance: every member lives in this lane's registers
+    enc.init(mine, (size_t)slot);
+    const int lo = min_v[blk];
+    const int Lp = max_v[blk] - lo + 2;
+    const int max_sym = Lp - 2;
+    const float norm = (float)(65536 - (Lp - 1));
+    bool bad = Lp > 65536;
+    for (int64_t i = b + lane; i < e && !bad; i += 64) {
+        const float q = Q[i / q_div];
+        const int sym = (int)rintf(x[i] / q) - lo;
+        if (sym < 0 || sym > max_sym) { bad = true; break; }
+        const float inv = 1.f / scale[i];
+        const float m = mean[i];
+        const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
+        const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
+        enc.encode(c_low, c_high);
+    }
+    const uint32_t len = (uint32_t)enc.finish(mine);
+    ((uint16_t *)base)[lane] = (uint16_t)len;
+    uint32_t tot = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+    if (__ballot(bad) != 0ull && lane == 0) atomicMax(status, 1);
+    if (__ballot(enc.out.overflow || len > 65535u) != 0ull && lane == 0) atomicMax(status, 2);
+    if (lane == 0) out_len[blk] = LANES_HDR + tot;
+}
+
+// Pack the blocks: header + the 64 lane streams back to back at dst + dst_off[b] (the file layout).
+__global__ void __launch_bounds__(256)
+    lanes_compact_kernel(const uint8_t *__restrict__ src, const int64_t *__restrict__ src_off, const int64_t *__restrict__ blk_off,
+                         const int64_t *__restrict__ dst_off, int n_blocks, uint8_t *__restrict__ dst) {
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const uint8_t *base = src + src_off[blk];
+    uint8_t *d = dst + dst_off[blk];
+    const int64_t slot = lanes_slot_bytes(blk_off[blk + 1] - blk_off[blk]);
+    __shared__ uint32_t start[65];
+    if (tid == 0) {
+        uint32_t acc = LANES_HDR;
+        for (int l = 0; l < 64; ++l) { start[l] = acc; acc += ((const uint16_t *)base)[l]; }
+        start[64] = acc;
+    }
+    for (int i = tid; i < LANES_HDR; i += 256) d[i] = base[i];
+    __syncthreads();
+    // 4 threads per lane stream, byte copies (streams start at arbitrary byte offsets of the packed file)
+    const int l = tid >> 2, part = tid & 3;
+    const uint32_t len = start[l + 1] - start[l];
+    const uint8_t *sp = base + LANES_HDR + l * slot;
+    uint8_t *dp = d + start[l];
+    for (uint32_t i = part; i < len; i += 4) dp[i] = sp[i];
+}
+
+// Decoder, ONE WAVE PER BLOCK, one decoder per lane.  Symbol search per lane: a first guess from the inverse normal CDF
+// of target / norm, then a walk on the exact integer CDF (the same gaussian_cdf_int as the encoder) with the division-free
+// test cdf * span <= num.
+__global__ void __launch_bounds__(64)
+    gaussian_decode_lanes_kernel(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q,
+                                 int64_t q_div, const int64_t *__restrict__ blk_off, int n_blocks,
+                                 const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
+                                 const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off, float *__restrict__ x_out) {
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
+    const uint8_t *base = in + in_off[blk];
+    // exclusive prefix sum of the 64 lane lengths
+    const uint32_t mylen = ((const uint16_t *)base)[lane];
+    uint32_t incl = mylen;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    LaneAcDecoder dec;
+    dec.init(base + LANES_HDR + (incl - mylen));
+    const int lo = min_v[blk];
+    const int Lp = max_v[blk] - lo + 2;
+    const int max_sym = Lp - 2;
+    const float norm = (float)(65536 - (Lp - 1));
+    for (int64_t i = b + lane; i < e; i += 64) {
+        const float q = Q[i / q_div], m = mean[i], sc = scale[i];
+        const float inv = 1.f / sc;
+        const uint64_t num = dec.num();
+        const uint32_t sm1 = dec.span_m1();
+        // guess: target ~ num / span in [0, 2^16); cdf(j) ~ Phi(z_j) * norm + j
+        const float tgt = (float)num / ((float)sm1 + 1.f);
+        float u = (tgt + 0.5f) / 65536.f;
+        u = fminf(fmaxf(u, 1e-6f), 1.f - 1e-6f);
+        const float z = SQRT2F * erfinvf(2.f * u - 1.f);
+        int guess = (int)floorf((m + z * sc) / q + 0.5f) - lo;
+        guess = max(0, min(guess, max_sym));
+        // largest sym in [0, max_sym] with cdf(sym) <= target: gallop away from the guess, then bisect (a guess that is
+        // right or one off costs two or three erff; a symbol far in the tail costs O(log distance), never a linear walk)
+        int lo_j, hi_j;                     // le(lo_j) holds (or lo_j = 0), le(hi_j) fails (or hi_j = max_sym + 1)
+        uint32_t c_lo = 0, c_hi = AC_TOP;   // cdf at lo_j / hi_j where evaluated
+        bool lo_known = false;
+        {
+            const uint32_t cg = gaussian_cdf_int(guess, lo, norm, m, inv, q);
+            if (cdf_le_target(cg, sm1, num)) {
+                lo_j = guess; c_lo = cg; lo_known = true;
+                int d = 1;
+                hi_j = max_sym + 1;
+                while (lo_j + d <= max_sym) {
+                    const uint32_t cc = gaussian_cdf_int(lo_j + d, lo, norm, m, inv, q);
+                    if (cdf_le_target(cc, sm1, num)) { lo_j += d; c_lo = cc; d <<= 1; }
+                    else { hi_j = lo_j + d; c_hi = cc; break; }
+                }
+            } else {
+                hi_j = guess; c_hi = cg;
+                int d = 1;
+                lo_j = 0;
+                while (hi_j - d > 0) {
+                    const uint32_t cc = gaussian_cdf_int(hi_j - d, lo, norm, m, inv, q);
+                    if (!cdf_le_target(cc, sm1, num)) { hi_j -= d; c_hi = cc; d <<= 1; }
+                    else { lo_j = hi_j - d; c_lo = cc; lo_known = true; break; }
+                }
+            }
+            while (hi_j - lo_j > 1) {
+                const int mid = (lo_j + hi_j) >> 1;
+                const uint32_t cc = gaussian_cdf_int(mid, lo, norm, m, inv, q);
+                if (cdf_le_target(cc, sm1, num)) { lo_j = mid; c_lo = cc; lo_known = true; }
+                else { hi_j = mid; c_hi = cc; }
+            }
+        }
+        const int sym = lo_j;
+        const uint32_t c_low = lo_known ? c_lo : gaussian_cdf_int(sym, lo, norm, m, inv, q);
+        const uint32_t c_high = sym >= max_sym ? AC_TOP : c_hi;
+        x_out[i] = (float)(sym + lo) * q;
+        if (i + 64 < e) dec.consume(c_low, c_high);
+    }
+}
+
+extern "C" int cgs_gaussian_ac_encode_lanes(const float *x, const float *mean, const float *scale, const float *Q,
+                                            int64_t q_div, const int64_t *blk_off, int n_blocks, const int32_t *min_v,
+                                            const int32_t *max_v, uint8_t *out, const int64_t *out_off, uint32_t *out_len,
+                                            int32_t *status, void *stream) {
+    if (n_blocks < 0 || q_div < 1) { cgs_set_error("gaussian_ac_encode_lanes: bad args"); return CGS_ERR_ARG; }
+    if (n_blocks == 0) return CGS_OK;
+    hipLaunchKernelGGL(gaussian_encode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, x, mean, scale, Q,
+                       q_div, blk_off, n_blocks, min_v, max_v, out, out_off, out_len, status);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_lanes_compact(const uint8_t *src, const int64_t *src_off, const int64_t *blk_off, const int64_t *dst_off,
+                                 int n_blocks, uint8_t *dst, void *stream) {
+    if (n_blocks < 0) { cgs_set_error("lanes_compact: bad args"); return CGS_ERR_ARG; }
+    if (n_blocks == 0) return CGS_OK;
+    hipLaunchKernelGGL(lanes_compact_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, src, src_off, blk_off, dst_off,
+                       n_blocks, dst);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scale, const float *Q, int64_t q_div,
+                                            const int64_t *blk_off, int n_blocks, const int32_t *min_v, const int32_t *max_v,
+                                            const uint8_t *in, const int64_t *in_off, float *x_out, void *stream) {
+    if (n_blocks < 0 || q_div < 1) { cgs_set_error("gaussian_ac_decode_lanes: bad args"); return CGS_ERR_ARG; }
+    if (n_blocks == 0) return CGS_OK;
+    hipLaunchKernelGGL(gaussian_decode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, mean, scale, Q, q_div,
+                       blk_off, n_blocks, min_v, max_v, in, in_off, x_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // range-ANS for the hyper-prior symbols (host)
 // ---------------------------------------------------------------------------------
 // 32-bit state, 16-bit renormalisation words, frequency precision `prec` (16).

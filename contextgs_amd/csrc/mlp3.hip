@@ -38,6 +38,11 @@
 #define M3_BWD_WAVES 8
 #endif
 
+// M3_FUSED_WGRAD: the backward computes the weight gradients in the same launch (mlp3_bwd_wg_kernel); 0 = the round-3 pair
+// mlp3_bwd_kernel + wgrad_multi (kept for the data-only entry of the deferred weight-gradient mode and for A/B builds)
+#ifndef M3_FUSED_WGRAD
+#define M3_FUSED_WGRAD 1
+#endif
 // M3_PIPE: explicit register double-buffering of the LDS weight fragments in the forward kernel
 #ifndef M3_PIPE
 #define M3_PIPE 0
@@ -441,6 +446,286 @@ __global__ void __launch_bounds__(WAVES * 64)
 }
 
 
+// ---- backward with the weight gradients inside (round 4) ---------------------------------------------------------
+// mlp3_bwd_kernel hands dZ1cat / dZ2 (928 B per row) to a second launch (wgrad_multi) that re-reads them together with X and
+// Hcat (1.9 KB per row) only to contract them over the rows.  Here the same wave that forms dZ2 / dZ1 for its 16 rows also
+// accumulates the weight gradients of those rows, with the ROW index as the MFMA contraction and the 80 output tiles
+// (dW1cat [192 x 64] = 48 tiles, dW2 [(16 + 32 + 80) x 64] = 32 tiles; the bias gradients ride in the padding column of X
+// (col 54 = 1) and of H (col 50 = 1)) held in 320 accumulator registers per lane for the whole launch: one wave per SIMD
+// (4-wave workgroups, one per CU), the unified 512-entry VGPR + AGPR file.
+// Layouts: the data-gradient chain keeps layout F (lane (g, c): row c, features 16q + 4g + {0..3} = the D layout of the
+// transposed chain).  A row contraction needs both operands as lane (g, c): rows 4g + {0..3}, feature 16q + c (layout N =
+// what the D registers of a NON-transposed product would hold): MFMA k-step r then contracts rows {4g + r}.  F -> N is a
+// 16 x 16 transpose through a wave-private LDS patch (one ds_write_b128, four ds_read_b32, stride 20 floats: conflict-free
+// both ways); 36 of them per 16-row tile.
+// At the end the waves of a workgroup add their tiles into one LDS image [dW | db] per product (wave by wave: a fixed order),
+// the image goes to scratch and cgs_launch_wgrad_reduce sums the workgroups' images in block order: bit-reproducible.
+#define M3W_LD 20
+#ifndef M3W_XPREFETCH
+#define M3W_XPREFETCH 1      // X of the next tile is fetched during the last head of this one
+#endif
+#define M3W_PATCH (16 * M3W_LD)
+#define M3W_NPATCH 13          // per wave: H 0..3, dZ2 4..8, dZ1 9..12 (X uses 0..3 before the first head)
+#define M3W_WAVES 4
+#define M3W_E (M3_GLD * (M3_IN + 1) + (10 + 30 + 70) * (M3_HID + 1))
+
+__device__ __forceinline__ f32x4 m3w_f2n(float *patch, f32x4 v, int g, int c) {
+    *(f32x4 *)(patch + c * M3W_LD + 4 * g) = v;
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = patch[(4 * g + r) * M3W_LD + c];
+    return o;
+}
+
+// operands of one head for one 16-row tile (layout F), fetched one head ahead of their use
+template <int OUT, int ACT>
+struct M3wOps {
+    static constexpr int NT2 = (OUT + 15) / 16;
+    f32x4 dy[NT2], y[ACT != FRAG_ACT_NONE ? NT2 : 1], h[M3_NT1];
+    __device__ __forceinline__ void load(const M3Head &hd, int head, const float *__restrict__ Hcat, int64_t row, int g, bool valid) {
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            dy[u] = frag_load4<OUT>(hd.dY + row * OUT, u, g, valid);
+            if (ACT != FRAG_ACT_NONE) y[u] = frag_load4<OUT>(hd.Y + row * OUT, u, g, valid);
+        }
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) h[t] = frag_load4<M3_HID>(Hcat + row * M3_HLD + M3_HPITCH * head, t, g, valid);
+    }
+};
+
+__device__ __forceinline__ void m3w_put(float *patch, f32x4 v, int g, int c) { *(f32x4 *)(patch + c * M3W_LD + 4 * g) = v; }
+__device__ __forceinline__ f32x4 m3w_get(const float *patch, int g, int c) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = patch[(4 * g + r) * M3W_LD + c];
+    return o;
+}
+
+// One head of one tile.  Order of issue (one wave per SIMD: nothing else hides a latency): the F -> N transposes of H and
+// dZ2 are written and read back BEFORE the dH products, those of dZ1 before the dW2 products, so every LDS round trip has
+// a block of MFMAs in front of its first use; `prefetch` (the next head's global loads) is issued after the first batch of
+// transposes.
+template <int OUT, int ACT, class Prefetch>
+__device__ __forceinline__ void m3w_head(const float *lds, float *patches, const M3wOps<OUT, ACT> &op, f32x4 ones, int g, int c,
+                                         const f32x4 (&xn)[M3_NTI], f32x4 (&adx)[M3_NTI],
+                                         f32x4 (&aw2)[(OUT + 15) / 16][M3_NT1], f32x4 (&aw1)[M3_NT1][M3_NTI], Prefetch prefetch) {
+    using L = M3BwdLds<OUT>;
+    const float *W2n = lds, *W1n = W2n + L::OP * L::SA;
+    f32x4 b[L::NT2];
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u) {
+        b[u] = op.dy[u];
+        if (ACT != FRAG_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[u][r] *= frag_act_grad<ACT>(op.y[u][r]);
+        }
+    }
+    // patches 0..3: H, 4..8: dZ2
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) m3w_put(patches + t * M3W_PATCH, op.h[t], g, c);
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u) m3w_put(patches + (4 + u) * M3W_PATCH, b[u], g, c);
+    prefetch();
+    // dH = W2^T dZ2 (transposed chain, layout F)
+    f32x4 adh[M3_NT1];
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) adh[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (16 * u + j >= OUT) continue;
+#pragma unroll
+            for (int t = 0; t < M3_NT1; ++t)
+                adh[t] = frag_mfma(W2n[(16 * u + 4 * g + j) * L::SA + 16 * t + c], b[u][j], adh[t]);
+        }
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) adh[t][r] = op.h[t][r] > 0.f ? adh[t][r] : 0.f;
+        m3w_put(patches + (9 + t) * M3W_PATCH, adh[t], g, c);          // patches 9..12: dZ1
+    }
+    // dW2 += dZ2^T [H | 1] (row contraction, layout N): the N forms are read back just in time (4 registers at a time)
+    f32x4 hn[M3_NT1];
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) hn[t] = m3w_get(patches + t * M3W_PATCH, g, c);
+    if (c == M3_HID - 48) hn[3] = ones;                         // column 50 of [H | 1]
+#pragma unroll
+    for (int u = 0; u < L::NT2; ++u) {
+        const f32x4 zn = m3w_get(patches + (4 + u) * M3W_PATCH, g, c);
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aw2[u][t] = frag_mfma(zn[r], hn[t][r], aw2[u][t]);
+    }
+    // dX += W1^T dZ1
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * t + r >= M3_HID) continue;
+#pragma unroll
+            for (int v = 0; v < M3_NTI; ++v)
+                adx[v] = frag_mfma(W1n[(16 * t + 4 * g + r) * L::SB + 16 * v + c], adh[t][r], adx[v]);
+        }
+    // dW1 += dZ1^T [X | 1]
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) {
+        const f32x4 dn = m3w_get(patches + (9 + t) * M3W_PATCH, g, c);
+#pragma unroll
+        for (int v = 0; v < M3_NTI; ++v)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
+    }
+}
+
+template <bool ROWS>
+__global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+    mlp3_bwd_wg_kernel(M3Head h0, M3Head h1, M3Head h2, const float *__restrict__ X, int64_t ldx,
+                       const float *__restrict__ Hcat, float *__restrict__ dX, int64_t lddx, int64_t n, M3Rows R,
+                       float *__restrict__ partial) {
+    constexpr int WF = M3BwdLds<10>::FLOATS + M3BwdLds<30>::FLOATS + M3BwdLds<70>::FLOATS;
+    constexpr int PF = M3W_WAVES * M3W_NPATCH * M3W_PATCH;
+    static_assert(WF + PF >= M3W_E, "the LDS image of the weight gradients reuses the weight region");
+    __shared__ __attribute__((aligned(16))) float lds[WF + PF];
+    float *l0 = lds, *l1 = l0 + M3BwdLds<10>::FLOATS, *l2 = l1 + M3BwdLds<30>::FLOATS;
+    const int tid = threadIdx.x, nthr = M3W_WAVES * 64;
+    m3_stage_bwd<10>(l0, h0, tid, nthr);
+    m3_stage_bwd<30>(l1, h1, tid, nthr);
+    m3_stage_bwd<70>(l2, h2, tid, nthr);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    float *patches = lds + WF + wave * M3W_NPATCH * M3W_PATCH;
+    const int64_t ntiles = (n + 15) / 16;
+    f32x4 a2_0[1][M3_NT1], a2_1[2][M3_NT1], a2_2[5][M3_NT1], a1_0[M3_NT1][M3_NTI], a1_1[M3_NT1][M3_NTI], a1_2[M3_NT1][M3_NTI];
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < M3_NT1; ++t) {
+        a2_0[0][t] = zero;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) a2_1[u][t] = zero;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) a2_2[u][t] = zero;
+#pragma unroll
+        for (int v = 0; v < M3_NTI; ++v) { a1_0[t][v] = zero; a1_1[t][v] = zero; a1_2[t][v] = zero; }
+    }
+    const int64_t tstride = (int64_t)gridDim.x * M3W_WAVES;
+    int64_t tile = (int64_t)blockIdx.x * M3W_WAVES + wave;
+    M3wOps<10, 1> op0;
+    M3wOps<30, 2> op1;
+    M3wOps<70, 0> op2;
+    f32x4 xf[M3_NTI];
+    {
+        const int64_t row = tile * 16 + c;
+        const bool v0 = tile < ntiles && row < n;
+        op0.load(h0, 0, Hcat, row, g, v0);
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + row * ldx, q, g, v0);
+    }
+    for (; tile < ntiles; tile += tstride) {
+        const int64_t row0 = tile * 16;
+        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
+        const bool valid = row0 + c < n;
+        const int64_t rown = row0 + tstride * 16 + c;
+        const bool validn = rown < n;
+        // [X | 1] in layout N, and the ones column of [H | 1]: rows 4g + r of this tile that exist
+        f32x4 ones, xn[M3_NTI];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ones[r] = row0 + 4 * g + r < n ? 1.f : 0.f;
+#if !M3W_XPREFETCH
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + (row0 + c) * ldx, q, g, valid);
+#endif
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q) m3w_put(patches + q * M3W_PATCH, xf[q], g, c);
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q) xn[q] = m3w_get(patches + q * M3W_PATCH, g, c);
+        if (c == M3_IN - 48) xn[3] = ones;                      // column 54 of [X | 1]
+        f32x4 adx[M3_NTI];
+#pragma unroll
+        for (int v = 0; v < M3_NTI; ++v) adx[v] = zero;
+        m3w_head<10, 1>(l0, patches, op0, ones, g, c, xn, adx, a2_0, a1_0, [&]() { op1.load(h1, 1, Hcat, row0 + c, g, valid); });
+        m3w_head<30, 2>(l1, patches, op1, ones, g, c, xn, adx, a2_1, a1_1, [&]() { op2.load(h2, 2, Hcat, row0 + c, g, valid); });
+        m3w_head<70, 0>(l2, patches, op2, ones, g, c, xn, adx, a2_2, a1_2, [&]() {
+            op0.load(h0, 0, Hcat, rown, g, validn);
+#if M3W_XPREFETCH
+#pragma unroll
+            for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + rown * ldx, q, g, validn);
+#endif
+        });
+        if (ROWS) {
+            const int64_t row = row0 + c;
+            const int64_t srow = valid ? R.src_row[row] : 0;
+            float *dst = R.d_feat_src + srow * M3_HID;
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+                if (valid) *(f32x4_a4 *)(dst + 16 * v + 4 * g) = adx[v];
+            const float z52 = __shfl(adx[3][0], 16 + c, 64), z53 = __shfl(adx[3][1], 16 + c, 64);
+            if (g == 0 && valid) {
+                dst[48] = adx[3][0];
+                dst[49] = adx[3][1];
+                const float dvx = adx[3][2], dvy = adx[3][3], dvz = z52, dd = z53;
+                const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1],
+                            uz = R.anchor[3 * row + 2] - R.cam[2];
+                const float dist = sqrtf(ux * ux + uy * uy + uz * uz), inv = 1.f / dist;
+                const float vx = ux * inv, vy = uy * inv, vz = uz * inv;
+                const float dot = vx * dvx + vy * dvy + vz * dvz;
+                R.d_anchor[3 * row] = (dvx - vx * dot) * inv + vx * dd;
+                R.d_anchor[3 * row + 1] = (dvy - vy * dot) * inv + vy * dd;
+                R.d_anchor[3 * row + 2] = (dvz - vz * dot) * inv + vz * dd;
+            }
+        } else if (dX) {
+#pragma unroll
+            for (int v = 0; v < M3_NTI; ++v) frag_store4<M3_IN>(dX + (row0 + c) * lddx, v, g, valid, adx[v]);
+        }
+    }
+    // ---- the workgroup's image [dW1cat 192 x 54 | db1cat 192 | dW2_h OUT_h x 50 | db2_h OUT_h ...] ----
+    __syncthreads();
+    for (int i = tid; i < M3W_E; i += nthr) lds[i] = 0.f;
+    __syncthreads();
+    float *img1 = lds, *imgb1 = img1 + M3_GLD * M3_IN;
+    for (int w = 0; w < M3W_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int hd = 0; hd < 3; ++hd) {
+                const f32x4 (&a1)[M3_NT1][M3_NTI] = hd == 0 ? a1_0 : (hd == 1 ? a1_1 : a1_2);
+#pragma unroll
+                for (int t = 0; t < M3_NT1; ++t)
+#pragma unroll
+                    for (int v = 0; v < M3_NTI; ++v)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = M3_GPITCH * hd + 16 * t + 4 * g + r, k = 16 * v + c;
+                            if (k < M3_IN) img1[m * M3_IN + k] += a1[t][v][r];
+                            else if (k == M3_IN) imgb1[m] += a1[t][v][r];
+                        }
+            }
+            float *img2 = imgb1 + M3_GLD;
+#define M3W_IMG2(ACC, NT2_, OUT_)                                                          \
+            {                                                                               \
+                _Pragma("unroll") for (int u = 0; u < NT2_; ++u)                            \
+                _Pragma("unroll") for (int t = 0; t < M3_NT1; ++t)                          \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
+                    const int o = 16 * u + 4 * g + r, hh = 16 * t + c;                      \
+                    if (o < OUT_) {                                                         \
+                        if (hh < M3_HID) img2[o * M3_HID + hh] += ACC[u][t][r];             \
+                        else if (hh == M3_HID) img2[OUT_ * M3_HID + o] += ACC[u][t][r];     \
+                    }                                                                       \
+                }                                                                           \
+                img2 += OUT_ * (M3_HID + 1);                                                \
+            }
+            M3W_IMG2(a2_0, 1, 10)
+            M3W_IMG2(a2_1, 2, 30)
+            M3W_IMG2(a2_2, 5, 70)
+#undef M3W_IMG2
+        }
+        __syncthreads();
+    }
+    float *dstp = partial + (int64_t)blockIdx.x * M3W_E;
+    for (int i = tid; i < M3W_E; i += nthr) dstp[i] = lds[i];
+}
+
+
 static int m3_cus() {
     static int cus = 0;
     if (!cus) {
@@ -576,6 +861,32 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     h[0] = M3Head{W1[0], nullptr, W2[0], nullptr, const_cast<float *>(Y_op), dY_op, dZ2_op};
     h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};
     h[2] = M3Head{W1[2], nullptr, W2[2], nullptr, nullptr, dY_cov, nullptr};
+#if M3_FUSED_WGRAD
+    if (!data_only) {
+        // data AND weight gradients in one launch (mlp3_bwd_wg_kernel): dZ1cat / dZ2_* stay untouched
+        const int64_t tiles16 = (n + 15) / 16;
+        const int64_t wantw = (tiles16 + M3W_WAVES - 1) / M3W_WAVES;
+        const int gridw = (int)(wantw < m3_cus() ? wantw : m3_cus());
+        if (scratch && scratch_bytes >= (size_t)gridw * M3W_E * sizeof(float)) {
+            {
+                CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
+                if (rows)
+                    hipLaunchKernelGGL((mlp3_bwd_wg_kernel<true>), dim3(gridw), dim3(M3W_WAVES * 64), 0, stream, h[0], h[1], h[2], X,
+                                       ldx, Hcat, nullptr, 0, n, *rows, (float *)scratch);
+                else
+                    hipLaunchKernelGGL((mlp3_bwd_wg_kernel<false>), dim3(gridw), dim3(M3W_WAVES * 64), 0, stream, h[0], h[1], h[2], X,
+                                       ldx, Hcat, dX, lddx, n, M3Rows{}, (float *)scratch);
+                CGS_CHECK_HIP(hipGetLastError());
+            }
+            CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+            const CgsWgProduct prods[4] = {{nullptr, 0, M3_GLD, nullptr, 0, M3_IN, dW1cat, db1cat},
+                                           {nullptr, 0, 10, nullptr, 0, M3_HID, dW2[0], db2[0]},
+                                           {nullptr, 0, 30, nullptr, 0, M3_HID, dW2[1], db2[1]},
+                                           {nullptr, 0, 70, nullptr, 0, M3_HID, dW2[2], db2[2]}};
+            return cgs_launch_wgrad_reduce((const float *)scratch, gridw, prods, 4, stream);
+        }
+    }
+#endif
     const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
     const int64_t want = (tiles + WAVES - 1) / WAVES;
     const int grid = (int)(want < m3_cus() ? want : m3_cus());

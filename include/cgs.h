@@ -602,6 +602,34 @@ int cgs_gaussian_ac_decode(const float *mean, const float *scale,
 int cgs_streams_compact(const uint8_t *src, const int64_t *src_off,
                         const uint32_t *len, const int64_t *dst_off,
                         int n_streams, uint8_t *dst, void *stream);
+/* Container version 2, Gaussian-coded attributes: the same symbol sequence and
+ * the same coder as cgs_gaussian_ac_encode, cut into BLOCKS (blk_off, element
+ * offsets as stream_off above) that one wave codes as 64 INTERLEAVED lane
+ * streams — lane l codes the block's symbols l, l + 64, ... with its own
+ * coder in vector registers — instead of one serial stream per wave.  A block
+ * in the file = 64 little-endian uint16 lane-stream byte lengths, then the 64
+ * lane streams back to back; out_len[b] is its byte length.  Encode writes
+ * block b into its worst-case region out + out_off[b]
+ * (cgs_lanes_block_slot_bytes(symbols of the block) bytes, 8-byte aligned),
+ * cgs_lanes_compact packs the regions at dst + dst_off[b].  `in` must be
+ * readable 4 bytes past its last block.  min_v / max_v / status as above. */
+size_t cgs_lanes_block_slot_bytes(int64_t n_symbols);
+int cgs_gaussian_ac_encode_lanes(const float *x, const float *mean,
+                                 const float *scale, const float *Q,
+                                 int64_t q_div, const int64_t *blk_off,
+                                 int n_blocks, const int32_t *min_v,
+                                 const int32_t *max_v, uint8_t *out,
+                                 const int64_t *out_off, uint32_t *out_len,
+                                 int32_t *status, void *stream);
+int cgs_lanes_compact(const uint8_t *src, const int64_t *src_off,
+                      const int64_t *blk_off, const int64_t *dst_off,
+                      int n_blocks, uint8_t *dst, void *stream);
+int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scale,
+                                 const float *Q, int64_t q_div,
+                                 const int64_t *blk_off, int n_blocks,
+                                 const int32_t *min_v, const int32_t *max_v,
+                                 const uint8_t *in, const int64_t *in_off,
+                                 float *x_out, void *stream);
 /* Container version 2: the offset-mask symbols (scene/gaussian_model.py:1265-1269,
  * 1348-1353; utils/encodings.py:147-180 code them as ONE serial stream) cut into
  * chunk streams and coded by the same arithmetic coder, one wave per stream.

@@ -99,6 +99,60 @@ def test_row_broadcast_Q_and_reference_signatures(tmp_path):
     assert torch.equal(decoder_gaussian(mf, sf, 0.5, bstream=b, min_value=int(mn.item()), max_value=int(mx.item())), xs)
 
 
+def _split_block(blob):
+    """A version-2 block -> its 64 lane streams (header of 64 little-endian uint16 lengths, then the streams)."""
+    lens = np.frombuffer(blob[:128], dtype="<u2").astype(np.int64)
+    assert 128 + int(lens.sum()) == len(blob)
+    ends = 128 + np.cumsum(lens)
+    return [bytes(blob[e - n:e]) for e, n in zip(ends, lens)]
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 3000, 64 * 40 + 17])
+def test_lane_streams_equal_the_table_coder_on_device_table(n):
+    """Container version 2 (cgs_gaussian_ac_encode_lanes): lane stream l of a block is byte for byte what the table coder
+    (bit-exact vs the pure-Python oracle) emits for the block's symbols l, l + 64, ... on the device's own integer CDF rows;
+    lanes without a symbol hold the empty stream's closing bits."""
+    from contextgs_amd import codec
+    xq, mean, scale, Q = _params(n, 40 + n)
+    T = lambda a: torch.from_numpy(a).cuda()
+    blob, lens, mn, mx = codec.gaussian_encode_packed(T(xq), T(mean), T(scale), T(Q), [0, n], lanes=True)
+    assert lens.tolist() == [len(blob)]
+    table = codec.gaussian_cdf_table(T(mean), T(scale), T(Q), mn[0], mx[0])
+    sym = (np.round(xq / Q) - mn[0]).astype(np.int64)
+    got = _split_block(blob.tobytes())
+    for l in range(64):
+        want = ref.ac_encode(table[l::64].tolist(), sym[l::64].tolist())
+        assert got[l] == want, l
+    back = codec.gaussian_decode_packed(T(mean), T(scale), T(Q), [0, n], mn, mx, blob, lens, lanes=True)
+    assert torch.equal(back, T(xq))
+
+
+@pytest.mark.parametrize("edges,width", [([0, 1], 3.0), ([0, 5, 5, 1000, 4096, 4097, 20000], 3.0),
+                                         ([0, 32768, 65536, 100000], 3.0), ([0, 40000], 40.0), ([0, 70000, 70001], 0.05)])
+def test_lane_blocks_roundtrip_bit_exact(edges, width):
+    """Ragged blocks incl. empty ones, symbols far in the tails (width 40: the decoder's inverse-CDF guess is clamped and the
+    walk takes over) and nearly deterministic ones (width 0.05); rate within 3 % + the per-lane termination of the ideal."""
+    from contextgs_amd import codec
+    n = edges[-1]
+    xq, mean, scale, Q = _params(n, len(edges), width)
+    T = lambda a: torch.from_numpy(a).cuda()
+    blob, lens, mn, mx = codec.gaussian_encode_packed(T(xq), T(mean), T(scale), T(Q), edges, lanes=True)
+    assert len(lens) == len(edges) - 1 and int(lens.sum()) == len(blob)
+    back = codec.gaussian_decode_packed(T(mean), T(scale), T(Q), edges, mn, mx, blob, lens, lanes=True)
+    assert torch.equal(back, T(xq))
+    # same symbols through the wave-per-stream coder: the lane layout costs the header + 64 terminations per block
+    blob1, lens1, mn1, mx1 = codec.gaussian_encode_packed(T(xq), T(mean), T(scale), T(Q), edges)
+    assert np.array_equal(mn, mn1) and np.array_equal(mx, mx1)
+    for a, b in zip(lens, lens1):
+        assert int(a) <= int(b) + 128 + 64 * 3 + 8
+    # grouped form (what the container driver calls)
+    g = (T(xq), T(mean), T(scale), T(Q), edges, 1)
+    (blob2, lens2, mn2, mx2), = codec.gaussian_encode_groups([g], lanes=True)
+    assert blob2.tobytes() == blob.tobytes()
+    out, = codec.gaussian_decode_groups([(g[1], g[2], g[3], edges, mn2, mx2, blob2, lens2, 1)], lanes=True)
+    assert torch.equal(out, T(xq))
+
+
 @pytest.mark.parametrize("p0", [0.03, 0.31, 0.5, 0.97])
 def test_bernoulli_chunk_streams_equal_the_host_coder(p0):
     """Container version 2's mask streams (cgs_bernoulli_ac_encode / _decode, one wave per chunk stream): every stream is
@@ -200,13 +254,19 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed, version):
     else:
         # version 2: the same symbols cut into 1000-anchor chunk streams, each the oracle's stream for its symbols
         assert len(meta) == 15 and meta[14]["version"] == 2
-        ck, K = meta[14]["chunk"], enc.n_offsets
+        ck, K, B = meta[14]["chunk"], enc.n_offsets, meta[14]["block_symbols"]
         want = b"".join(ref.ac_encode([row] * len(sym[a:a + ck["masks"] * K]), sym[a:a + ck["masks"] * K])
                         for a in range(0, len(sym), ck["masks"] * K))
         assert masks_b == want and sum(meta[14]["bit_masks"]) == 8 * len(masks_b)
-        # shorter feature streams: ceil(n_level / chunk) streams per level
+        # feat / scaling: ceil(symbols / block) blocks per level, each a 128-byte header + 64 lane streams
         for l, n_l in enumerate(reversed(meta[13])):
-            assert len(meta[10][l]) == -(-n_l // ck["feat"]) and len(meta[12][l]) == -(-n_l // ck["offsets"])
+            assert len(meta[10][l]) == -(-n_l * enc.feat_dim // B) and len(meta[11][l]) == -(-n_l * 6 // B)
+            blob = open(os.path.join(d, f"feat{l}.b"), "rb").read()
+            assert len(blob) * 8 == sum(meta[10][l])
+            pos = 0
+            for bits in meta[10][l]:
+                _split_block(blob[pos:pos + bits // 8])
+                pos += bits // 8
 
 
 @pytest.mark.parametrize("N", [3000, 10000])

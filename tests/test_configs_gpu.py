@@ -146,7 +146,7 @@ def test_c3_500k_anchors_1080p_encode_decode(tmp_path):
     size, nv = _roundtrip(pc, tmp_path / "c3", render_check)
     assert nv > 400_000 and 20e6 < size < 120e6
     size2, _ = _roundtrip(pc, tmp_path / "c3v2", None, version=2)          # version 2: same symbols, shorter streams
-    assert abs(size2 - size) < 0.002 * size, (size, size2)
+    assert abs(size2 - size) < 0.006 * size, (size, size2)       # + 128-byte block headers and 64 stream ends per block
 
 
 def test_c5_3M_anchors_rate_sweep_roundtrip(tmp_path):

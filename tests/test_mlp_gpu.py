@@ -188,11 +188,19 @@ def _mlp_zoo_grads(defer, twice=False):
 def test_deferred_weight_gradients_are_the_inline_ones(twice):
     """mlp.defer_weight_gradients (what dist.GradientSync switches on for world > 1): the data-only backward entry points +
     cgs_mlp2_wgrad / cgs_anchor_mlp3_wgrad from the autograd engine's end-of-backward callback leave bit-identical .grad on
-    every parameter and input, including a second backward that accumulates."""
+    every parameter and input, including a second backward that accumulates.  One exception since round 4: the INLINE
+    backward of the anchor MLPs forms their weight gradients inside the backward kernel (mlp3_bwd_wg_kernel: per-wave register
+    accumulators, another summation order than the deferred wgrad_multi launch) — those twelve tensors (entries 8..19) agree
+    to fp32 rounding, not bit for bit; each path by itself is bit-reproducible (second half of the test)."""
     a, b = _mlp_zoo_grads(False, twice), _mlp_zoo_grads(True, twice)
     assert len(a) == len(b) and all(t is not None for t in a + b)
     for i, (u, v) in enumerate(zip(a, b)):
-        assert torch.equal(u, v), i
+        if 8 <= i < 20:
+            assert float((u - v).abs().max()) <= 2e-5 * max(1e-6, float(v.abs().max())), i
+        else:
+            assert torch.equal(u, v), i
+    for i, (u, v) in enumerate(zip(a, _mlp_zoo_grads(False, twice))):
+        assert torch.equal(u, v), ("inline path not reproducible", i)
 
 
 def test_deferral_leaves_non_leaf_weights_to_autograd_and_runs_the_hooks():
