@@ -54,6 +54,31 @@ def flat_grads(params):
     return [p.grad for p in params if p.grad is not None]
 
 
+class _LinearLoss:
+    """sum(image * w) + lam * rate as ONE autograd node (a dot product forward, g * w backward) instead of torch's
+    mul / sum / mul / add chain and its backward: the metric's fixed linear loss, five launches shorter."""
+    fn = None
+
+    @classmethod
+    def apply(cls, img, w, rate, lam):
+        import torch
+        if cls.fn is None:
+            class F(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, img, w, rate, lam):
+                    ctx.save_for_backward(w)
+                    ctx.lam, ctx.rate_shape = lam, (None if rate is None else rate.shape)
+                    out = torch.dot(img.reshape(-1), w.reshape(-1))
+                    return out if rate is None else torch.add(out, rate.reshape(()), alpha=lam)
+
+                @staticmethod
+                def backward(ctx, g):
+                    (w,) = ctx.saved_tensors
+                    return g * w, None, ((g * ctx.lam).reshape(ctx.rate_shape) if ctx.rate_shape is not None else None), None
+            cls.fn = F
+        return cls.fn.apply(img, w, rate, lam)
+
+
 def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
     """prefilter -> render -> backward (-> all-reduce). Returns the render dict.  gt: use the training image loss
     of train.py:199-209 (L1 + SSIM + scaling / rate / mask regularisers) instead of the fixed linear loss."""
@@ -64,9 +89,7 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
     vis = prefilter_voxel(cam, pc, pipe, bg)
     pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=False, step=step_sem)
     if gt is None:
-        loss = (pkg["render"] * w).sum()
-        if pkg["bit_per_param"] is not None:
-            loss = loss + 0.001 * pkg["bit_per_param"]          # lambda * rate term (train.py:206-209)
+        loss = _LinearLoss.apply(pkg["render"], w, pkg["bit_per_param"], 0.001)       # sum(image * w) + lambda * rate (train.py:206-209)
     else:
         from contextgs_amd.loss_utils import training_image_loss, scaling_reg, mask_reg
         loss = training_image_loss(pkg["render"], gt, 0.2)[0] + 0.01 * scaling_reg(pkg["scaling"])     # train.py:203-204
@@ -78,14 +101,14 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
     return pkg
 
 
-def timed(fn, steps, dist_on):
+def timed(fn, steps, dist_on, first=0):
     import torch
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(first, first + steps):
         fn(i)
     torch.cuda.synchronize()
     if dist_on:
@@ -98,6 +121,20 @@ def timed(fn, steps, dist_on):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def timed_segments(fn, steps, dist_on, segments=5):
+    """The K timed steps as `segments` consecutive, separately bracketed runs (barrier + synchronize on both sides of each,
+    MAX over ranks per segment).  Returns (sum of the segment times, per-segment seconds, steps per segment): the headline
+    rate is the MEDIAN segment's — one slow segment (a clock excursion, a host hiccup) does not decide the number — and the
+    spread is printed next to it."""
+    segments = max(1, min(segments, steps))
+    per = [steps // segments + (1 if s < steps % segments else 0) for s in range(segments)]
+    out, first = [], 0
+    for k in per:
+        out.append(timed(fn, k, dist_on, first))
+        first += k
+    return sum(out), out, per
 
 
 def read_prof():
@@ -142,6 +179,14 @@ def main():
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
+        # communicator creation and the first (lazy) collective of every flavour the step issues happen HERE, not in a timed
+        # region, whatever --warmup says: a float all-reduce (gradients), a MAX all-reduce (the has-grad mask), a broadcast
+        warm = torch.ones(1 << 20, device="cuda")
+        dist.all_reduce(warm)
+        dist.all_reduce(warm[:64].to(torch.uint8), op=dist.ReduceOp.MAX)
+        dist.broadcast(warm[:16], src=0)
+        torch.cuda.synchronize()
+        del warm
     from contextgs_amd import _lib
     from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
     L = _lib.lib()
@@ -174,14 +219,16 @@ def main():
     # `value` is timed with the library's per-kernel event bracketing OFF; the per-kernel table (roofline leg) comes from a
     # second, separately timed pass over the same K steps with it ON (HIP events on the launch stream around each kernel)
     L.cgs_prof_enable(0)
-    dt = timed(full, args.steps, dist_on)
+    dt, seg_s, seg_k = timed_segments(full, args.steps, dist_on)
     L.cgs_prof_enable(1)
     dt_prof = timed(full, args.steps, dist_on)
     prof = read_prof()
     L.cgs_prof_enable(0)
     views = args.steps * world
-    value = views / dt
-    ms_per_step = dt / args.steps * 1e3
+    seg_ms = sorted(t / k * 1e3 for t, k in zip(seg_s, seg_k))
+    ms_per_step = seg_ms[len(seg_ms) // 2]                     # median segment
+    value = world / (ms_per_step * 1e-3)
+    value_all_steps = views / dt
 
     value_raster = value_mid = None
     if not args.no_raster_only:
@@ -294,6 +341,7 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(kernels[dom]["GBps"] / HBM_PEAK_GBS, 4),
                         "traffic": traffic.get(dom), "alg_bytes_per_launch": kernels[dom]["alg_bytes"],
+                        "traffic_ratio": (round(traffic[dom] / kernels[dom]["alg_bytes"], 3) if traffic.get(dom) else None),
                         "avg_launch_us": kernels[dom]["avg_us"],
                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not this run)",
                         # what the kernel is actually limited by: VALU instructions x a NOMINAL 4 cycles / (SIMDs x
@@ -314,14 +362,15 @@ def main():
         lib_ms = sum(k["total_ms"] for k in kernels.values()) / max(1, args.steps)
         # the fused fp32-MFMA MLP family as a whole (forward, data gradient and weight gradient have the same contraction
         # sizes): the largest block of the step, bounded by the matrix cores in flops and by HBM in the intermediates the
-        # kernels hand each other (anchor MLPs: X 216 + Y 440 + Hcat 600 B per visible anchor forward, dY 440 + Y 160 + Hcat
-        # 600 read and dZ1 600 + dZ2 160 + dX 212 written backward, 1856 B read by the weight-gradient launch)
+        # kernels hand each other (anchor MLPs: 212 B gathered, X 216 + Y 440 + Hcat 600 B per visible anchor written forward;
+        # dY 440 + Y 160 + Hcat 600 + X 216 read and dX 212 written by the backward, which since round 4 also forms the weight
+        # gradients (mlp3_bwd_wg_kernel: no dZ1 / dZ2 hand-over, no second pass over the rows))
         mlp_group = None
         fam = [kernels[n_] for n_ in ("mlp_fwd", "mlp_bwd", "mlp_wgrad") if n_ in kernels]
         if fam:
             fam_ms = sum(k["total_ms"] for k in fam) / max(1, args.steps)
             tf = 3.0 * mlp_flops / (fam_ms * 1e-3) / 1e12
-            anchor_alg = n_vis * (212 + 216 + 440 + 600 + 440 + 160 + 600 + 600 + 160 + 212 + 1856)
+            anchor_alg = n_vis * (212 + 216 + 440 + 600 + 440 + 160 + 600 + 216 + 212)
             anchor_pmc = sum(traffic.get(k_, 0) for k_ in ("mlp3_fwd", "mlp3_bwd")) or None
             mlp_group = {"kernels": "mlp2_* / mlp3_* / wgrad_multi (all launches of a step)", "bound": "mfma",
                          "ms_per_step": round(fam_ms, 3), "share_of_hip_kernel_time": round(fam_ms / max(lib_ms, 1e-9), 3),
@@ -329,8 +378,9 @@ def main():
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                          "anchor_mlp_alg_bytes_per_step": anchor_alg,
                          "anchor_mlp_fwd_bwd_pmc_bytes": anchor_pmc,
-                         "note": "HBM-bound on hand-over intermediates, not on flops; fused alternatives measured in "
-                                 "profiles/r03_anchor_gen_experiments.txt"}
+                         "traffic_ratio": (round(anchor_pmc / anchor_alg, 3) if anchor_pmc else None),
+                         "note": "anchor backward + weight gradients are one launch since round 4 (profiles/r04_mlp3_bwd_wg.txt); the "
+                                 "rest is bound by hand-over intermediates and 16-wide tile padding, not by flops"}
 
         # stdout carries exactly ONE line (the JSON below): the codec driver's progress prints (they mirror the
         # reference's) and anything the baseline prints go to stderr
@@ -357,6 +407,10 @@ def main():
                                    f" + backward, 1 view/GPU/step" + (", grad all-reduce (RCCL)" if dist_on else ""),
                        "anchors": N, "image": [W, H], "views_per_step": world, "visible_anchors": n_vis,
                        "gaussians_per_view": P, "tile_pairs_per_view": R, "R_eff": R_eff, "parallelism": f"dp{world}"},
+            "timing": {"segments": len(seg_s), "steps_per_segment": seg_k, "ms_per_step_by_segment": [round(t / k * 1e3, 3) for t, k in zip(seg_s, seg_k)],
+                       "ms_per_step_min": round(seg_ms[0], 3), "ms_per_step_max": round(seg_ms[-1], 3),
+                       "value_over_all_steps": round(value_all_steps, 3),
+                       "note": "value / ms_per_step = the median of the separately bracketed segments of the K timed steps"},
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
             "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
@@ -538,6 +592,8 @@ def cpu_baseline(pc, cam, pipe, bg, w, pkg, ctx_sample=200_000):
     scale = N / n
     total = t_raster + (t_ctx + t_exp) * scale
     return {"value": round(1.0 / total, 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "what": "raster fwd+bwd full view (C/OpenMP) + context model fwd + expansion fwd on a 20 % anchor sample x5 (numpy); "
+                    "no context-model backward: an upper bound of the port's rate, not the same step",
             "seconds": {"rasterizer_fwd_bwd_full_view": round(t_raster, 2), "context_model_fwd_sample": round(t_ctx, 2),
                         "expansion_fwd_sample": round(t_exp, 2), "sample_to_full_scale": round(scale, 2)},
             "sample": f"1 view: rasterizer stages R1-R8 fwd+bwd of all {P} Gaussians at {cam.image_width}x{cam.image_height} "

@@ -19,6 +19,7 @@ There is no CPU fallback for the Gaussian codec: tensors must live on the HIP de
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -295,7 +296,7 @@ def to_host_pinned(t: torch.Tensor, key: str) -> np.ndarray:
     return stage.numpy()
 
 
-def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False):
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
     (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
     blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
@@ -335,6 +336,8 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
                    _lib.ptr(out_len), _lib.ptr(status), stream), "cgs_gaussian_ac_encode")
     dst_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
     torch.cumsum(out_len, 0, out=dst_off[1:])
+    if overlap is not None:
+        overlap()                 # host work of the caller's while the coder launch runs (the read below waits for it)
     st_len_h = st_len.cpu().numpy()
     st = int(st_len_h[0])
     if st != 0:
@@ -344,7 +347,7 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
     packed = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device=dev)
     if lanes:
         _lib.check(L.cgs_lanes_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(off_d), _lib.ptr(dst_off), S,
-                                       _lib.ptr(packed), stream), "cgs_lanes_compact")
+                                       _lib.ptr(packed), 2, stream), "cgs_lanes_compact")
     else:
         _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
                                          _lib.ptr(packed), stream), "cgs_streams_compact")
@@ -375,7 +378,7 @@ def _expand_q(Q, q_div):
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
 
 
-def gaussian_encode_groups(groups, staging=False, lanes=False):
+def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
     staging: download through the module's reused pinned buffer; the blobs then alias it until the next staging call.
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
@@ -409,7 +412,10 @@ def gaussian_encode_groups(groups, staging=False, lanes=False):
             return None
         blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
     else:
-        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes)
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes, overlap=overlap)
+        overlap = None
+    if overlap is not None:
+        overlap()
     out, s0, b0 = [], 0, 0
     for c in counts:
         nb = int(lens[s0:s0 + c].sum())
@@ -475,6 +481,17 @@ def _join_device_slices(parts):
 
 
 _PINNED = {}
+_LAST_STAGED = {}
+_STAGE_POOL = None
+
+
+def _stage_pool():
+    """A few threads of their own for file staging (the shared pool may be full of hyper-prior rANS jobs)."""
+    global _STAGE_POOL
+    if _STAGE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="cgs-stage")
+    return _STAGE_POOL
 
 
 _STAGE_STREAMS = {}
@@ -488,7 +505,6 @@ class StagedFiles:
     np.fromfile + np.concatenate + a pageable host-to-device copy (three passes over ~120 MB at 1 M anchors)."""
 
     def __init__(self, paths, device):
-        import os
         self.names = list(paths)
         sizes = [os.path.getsize(p_) for p_ in self.names]
         self.off = {}
@@ -510,42 +526,71 @@ class StagedFiles:
         with torch.cuda.stream(self.stream):
             self.dev_buf = torch.empty(pos + 64, dtype=torch.uint8, device=device)
         import threading
-        self.ready = {p_: threading.Event() for p_ in self.names}     # host side: the file's copy has been enqueued
+        self.ready = {p_: threading.Event() for p_ in self.names}     # host side: the file's copies have been enqueued
         self.events = {}                                              # device side: the file's bytes have arrived
         self.error = None
-        self._job = host_pool().submit(self._run)
+        key = (self.device.index if isinstance(self.device, torch.device) else 0)
+        prev = _LAST_STAGED.get(key)
+        if prev is not None:
+            prev.wait_all()           # its copies read the pinned buffer this container is about to overwrite
+        _LAST_STAGED[key] = self
+        pinned = _PINNED.get(key)
+        if pinned is None or pinned.numel() < self.total + 64:
+            pinned = _PINNED[key] = torch.empty(max(int(self.total * 1.25) + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        self._pinned, self._view = pinned, pinned.numpy()
+        # Pieces of <= 8 MB, read by a few dedicated threads (one thread copies ~8 GB/s out of the page cache: the 120 MB of a
+        # 1 M-anchor container took ~20 ms and was the decoder's critical chain), in the order the coder launches consume the
+        # files; each piece's host-to-device copy is enqueued by the thread that read it, the thread that completes a file
+        # records the file's event.
+        self._lock = threading.Lock()
+        self._left, self._jobs = {}, []
+        piece = 8 << 20
+        for p_ in self.names:
+            pos, n = self.off[p_]
+            parts = [(lo, min(n, lo + piece)) for lo in range(0, n, piece)] or [(0, 0)]
+            self._left[p_] = len(parts)
+            for (lo, hi) in parts:
+                self._jobs.append(_stage_pool().submit(self._piece, p_, pos, lo, hi))
 
-    def _run(self):
+    def _piece(self, p_, pos, lo, hi):
         try:
-            key = (self.device.index if isinstance(self.device, torch.device) else 0)
-            pinned = _PINNED.get(key)
-            if pinned is None or pinned.numel() < self.total + 64:
-                pinned = _PINNED[key] = torch.empty(max(self.total + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            view = pinned.numpy()
-            last = None
-            # file by file, in the order the coder launches consume them: the small coarse-level files are on the device
-            # after a millisecond, the 100 MB of the finest level arrive while the first launches run
-            for p_ in self.names:
-                pos, n = self.off[p_]
-                if n:
-                    with open(p_, "rb", buffering=0) as f:
-                        got = f.readinto(memoryview(view[pos:pos + n]))
-                        assert got == n, (p_, got, n)
-                ev = torch.cuda.Event()
-                with torch.cuda.stream(self.stream):
-                    if n:
-                        self.dev_buf[pos:pos + n].copy_(pinned[pos:pos + n], non_blocking=True)
+            if hi > lo:
+                fd = os.open(p_, os.O_RDONLY)
+                try:
+                    at = lo
+                    while at < hi:
+                        got = os.preadv(fd, [memoryview(self._view[pos + at:pos + hi])], at)
+                        assert got > 0, (p_, at, hi)
+                        at += got
+                finally:
+                    os.close(fd)
+            with torch.cuda.stream(self.stream):
+                if hi > lo:
+                    self.dev_buf[pos + lo:pos + hi].copy_(self._pinned[pos + lo:pos + hi], non_blocking=True)
+                with self._lock:
+                    self._left[p_] -= 1
+                    last = self._left[p_] == 0
+                if last:
+                    ev = torch.cuda.Event()
                     ev.record(self.stream)
-                self.events[p_] = last = ev
-                self.ready[p_].set()
-            if last is not None:
-                last.synchronize()    # the pinned buffer is reused by the next container: keep it until the copies are done
+                    self.events[p_] = ev
+                    self.ready[p_].set()
         except BaseException as e:    # wake the waiters, get() re-raises
             self.error = e
             for r in self.ready.values():
                 r.set()
             raise
         return True
+
+    def wait_all(self):
+        """Host-side: every copy has finished (the pinned buffer is reused by the next container)."""
+        for j in self._jobs:
+            try:
+                j.result()
+            except BaseException:
+                pass
+        for ev in list(self.events.values()):
+            ev.synchronize()
 
     def get(self, name):
         self.ready[name].wait()
@@ -593,6 +638,88 @@ def gaussian_decode_groups(groups, lanes=False):
     else:
         flat = gaussian_decode_packed(M, Sc, Qe, E, mn, mx, blob, lens, 1, lanes=lanes)
     return list(torch.split(flat, sizes))
+
+
+# ---- lane-parallel table codec (container version 2: hyper.b) ------------------------------------------------------
+def _table_blocks(C_, N, block):
+    """Blocks of <= `block` consecutive anchors of one channel, channel-major: (edges int64 [S+1], channel int32 [S])."""
+    per = list(range(0, N, block)) + [N] if N > 0 else [0]
+    edges, ch = [0], []
+    for c in range(C_):
+        for a, b in zip(per[:-1], per[1:]):
+            edges.append(c * N + b)
+            ch.append(c)
+    return torch.tensor(edges, dtype=torch.int64), torch.tensor(ch, dtype=torch.int32)
+
+
+def table_encode_lanes(sym, cdf, cdf_len, offset, block):
+    """sym int32 [C, N] device symbols; cdf / cdf_len / offset: EntropyBottleneck's device tables.  -> (blob uint8 ndarray of the
+    blocks back to back, lens int64 [S]); one launch, one wave per block, one coder per lane."""
+    L = _lib.lib()
+    _lib.require_device(sym, cdf, cdf_len, offset)
+    sym = sym.to(torch.int32).contiguous()
+    C_, N = int(sym.shape[0]), int(sym.shape[1])
+    edges_h, ch_h = _table_blocks(C_, N, int(block))
+    S = int(ch_h.numel())
+    if S == 0:
+        return np.zeros(0, np.uint8), np.zeros(0, np.int64)
+    dev = sym.device
+    lens_sym = edges_h[1:] - edges_h[:-1]
+    caps = 128 + 64 * (((lens_sym + 63) // 64 * 6 + 16 + 7) // 8 * 8)                       # cgs_lanes_block_slot_bytes(n, 6)
+    out_off_h = torch.zeros(S + 1, dtype=torch.int64)
+    out_off_h[1:] = torch.cumsum(caps, 0)
+    edges, ch, out_off = edges_h.to(dev), ch_h.to(dev), out_off_h.to(dev)
+    out = torch.empty(int(out_off_h[-1]) + 16, dtype=torch.uint8, device=dev)
+    st_len = torch.zeros(S + 1, dtype=torch.int32, device=dev)
+    cdf = cdf.to(torch.int32).contiguous()
+    cl, of = cdf_len.to(torch.int32).contiguous(), offset.to(torch.int32).contiguous()
+    stream = _lib.current_stream()
+    _lib.check(L.cgs_table_ac_encode_lanes(_lib.ptr(sym), _lib.ptr(edges), _lib.ptr(ch), S, _lib.ptr(cdf), int(cdf.shape[1]),
+                                           _lib.ptr(cl), _lib.ptr(of), _lib.ptr(out), _lib.ptr(out_off), _lib.ptr(st_len[1:]),
+                                           _lib.ptr(st_len[:1]), stream), "cgs_table_ac_encode_lanes")
+    dst_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(st_len[1:], 0, out=dst_off[1:])
+    st_len_h = st_len.cpu().numpy()
+    if int(st_len_h[0]) != 0:
+        raise RuntimeError("table codec: a lane slot overflowed (latents far outside the prior's support)")
+    lens = st_len_h[1:].astype(np.int64)
+    packed = torch.empty(max(int(lens.sum()), 1), dtype=torch.uint8, device=dev)
+    _lib.check(L.cgs_lanes_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(edges), _lib.ptr(dst_off), S, _lib.ptr(packed), 6,
+                                   stream), "cgs_lanes_compact")
+    return packed.cpu().numpy()[: int(lens.sum())], lens
+
+
+def table_decode_lanes(blob, lens, C_, N, cdf, cdf_len, offset, medians, block):
+    """Inverse of table_encode_lanes -> dequantised rows [N, C] float32 on the tables' device (symbol + medians[c]).
+    blob: bytes / uint8 ndarray / uint8 device tensor followed by >= 16 readable bytes."""
+    L = _lib.lib()
+    dev = cdf.device
+    out = torch.empty(N, C_, dtype=torch.float32, device=dev)
+    edges_h, ch_h = _table_blocks(C_, N, int(block))
+    S = int(ch_h.numel())
+    if S == 0:
+        return out
+    lens = np.asarray(lens, dtype=np.int64)
+    assert lens.shape[0] == S, "hyper.b: block count does not match the header"
+    if isinstance(blob, torch.Tensor) and blob.is_cuda:
+        in_d = blob
+    else:
+        buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        in_d = torch.zeros(buf.size + 16, dtype=torch.uint8, device=dev)
+        if buf.size:
+            in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
+    in_off_h = np.zeros(S + 1, dtype=np.int64)
+    np.cumsum(lens, out=in_off_h[1:])
+    assert int(in_off_h[-1]) <= int(in_d.numel())
+    # (every operand is held in a local until the launch is enqueued: a temporary's block goes back to the caching allocator the
+    #  moment its pointer has been read, and the next temporary's upload would land in it ahead of the kernel)
+    cdf = cdf.to(torch.int32).contiguous()
+    edges, ch, in_off = edges_h.to(dev), ch_h.to(dev), torch.from_numpy(in_off_h).to(dev)
+    cl, of, med = cdf_len.to(torch.int32).contiguous(), offset.to(torch.int32).contiguous(), medians.to(torch.float32).contiguous()
+    _lib.check(L.cgs_table_ac_decode_lanes(_lib.ptr(edges), _lib.ptr(ch), S, _lib.ptr(cdf), int(cdf.shape[1]), _lib.ptr(cl),
+                                           _lib.ptr(of), _lib.ptr(med), N, _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(out), C_,
+                                           _lib.current_stream()), "cgs_table_ac_decode_lanes")
+    return out
 
 
 def gaussian_cdf_table(mean, scale, Q, min_v, max_v, q_div=1):

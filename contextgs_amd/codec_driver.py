@@ -32,7 +32,7 @@ import torch.nn as nn
 
 from . import codec
 from . import dist as mgpu
-from .context_model import (extract_context_feat, find_divide_scale, grid_mlp, level_plan, multi_scale_generating,
+from .context_model import (context_rows, extract_context_feat, find_divide_scale, grid_mlp, level_plan, multi_scale_generating,
                             split_prediction)
 from .encodings import Q_anchor, Quantize_anchor, STE_multistep, decoder, encoder
 
@@ -42,7 +42,8 @@ MAX_BATCH = 1_000                                              # :1071
 # Container versions.  1 = the reference's container (default): one serial arithmetic-coded mask stream, 10 000-anchor hyper
 # strings, 1000-anchor chunk streams for every Gaussian-coded attribute, a 14-item meta list.  2 = the same files, symbols,
 # order and coder, re-cut for a device: the masks are 1000-anchor chunk streams coded by the device coder
-# (codec.BernoulliEncodeJob; no serial host stream is left on either critical chain), and feat / scaling / offsets are cut
+# (codec.BernoulliEncodeJob; no serial host stream is left on either critical chain), the hyper latents go through the device
+# table coder instead of host rANS strings (EntropyBottleneck.compress_lanes: same tables), and feat / scaling / offsets are cut
 # into BLOCKS of V2_BLOCK consecutive symbols, each coded as 64 interleaved lane streams by one wave (csrc/codec.hip,
 # "Lane-parallel Gaussian codec": the coder arithmetic runs 64-wide in vector registers instead of one serial chain per
 # wave on the scalar unit).  meta.b gets a 15th item {"version": 2, "block_symbols": ..., "chunk": {"masks": ...},
@@ -50,6 +51,7 @@ MAX_BATCH = 1_000                                              # :1071
 CONTAINER_VERSION = 1
 V2_BLOCK = 64 * 512                      # symbols per block: 512 per lane stream
 V2_CHUNK = {"masks": 1000}               # anchors per mask chunk stream
+V2_HYPER_BLOCK = 64 * 512                # anchors of one channel per hyper.b block (lane-parallel table coder)
 
 
 def default_container_version():
@@ -65,8 +67,10 @@ def save_mlp_checkpoints(pc, path):                            # :912-936
                 "level_scale": pc.level_scale}, path)
 
 
-def load_mlp_checkpoints(pc, path):                            # :939-950
-    ck = torch.load(path, weights_only=False)
+def load_mlp_checkpoints(pc, path, ck=None):                   # :939-950
+    """ck: the already loaded checkpoint dict (conduct_decoding reads mlp.pt on a host thread beside the header)."""
+    if ck is None:
+        ck = torch.load(path, weights_only=False)
     pc.mlp_opacity.load_state_dict(ck["opacity_mlp"])
     pc.mlp_cov.load_state_dict(ck["cov_mlp"])
     pc.mlp_color.load_state_dict(ck["color_mlp"])
@@ -214,17 +218,6 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     plan, inverse_indices_list, mapping_list = level_plan(pc, _anchor, None)
 
     tr("level plan built")
-    mlp_job = None
-    if root:
-        # mlp.pt needs nothing the encoder computes after this point (level_scale is set): written by a host thread (its small device-to-host copies on a
-        # stream of their own, not behind the coder launch) while this thread drives the levels
-        dev_ = _mask.device
-
-        def write_mlp():
-            torch.cuda.set_device(dev_)
-            with torch.cuda.stream(_side_stream(dev_, "mlp")):
-                save_mlp_checkpoints(pc, path("mlp.pt"))
-        mlp_job = codec.host_pool().submit(write_mlp)
     feat_after_Q = torch.zeros_like(_feat)
     grid_scaling_after_Q = torch.zeros_like(_scaling)
     already_coded = torch.zeros(_feat.shape[0], dtype=torch.bool, device=_feat.device)
@@ -276,17 +269,28 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         grid_scaling_after_Q[orig] = scal_q
         already_coded[orig] = True
         if level != 0:
-            content_pre_gathered = extract_context_feat(_anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
-                                                        inverse_indices_list, mapping_list, level)
+            content_pre_gathered = context_rows(pc, _anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
+                                                inverse_indices_list, mapping_list, level)
             tr(f"level {level}: context of the next level gathered")
 
     tr("levels enqueued")
-    if root:
+    hyper_v2 = None
+    if root and version == 2:
+        hyper_v2 = pc.latent_codec.compress_lanes(_hyper_latent.t().contiguous(), V2_HYPER_BLOCK)
+        tr("hyper blocks coded (device) and on the host")
+    elif root:
         hyper_jobs = pc.latent_codec.compress_chunks(_hyper_latent.t(), MAX_BATCH * 10, lazy=True)
         tr("hyper symbols on the host, rANS jobs submitted")
     torch.cuda.synchronize(); t0 = time.time()
     tr("levels done on the device")
-    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes)   # blobs alias a pinned buffer: written below
+    def write_mlp():
+        # mlp.pt on THIS thread while the coder launch runs (its small device-to-host copies on a side stream, not behind
+        # the launch).  A host thread of its own was tried: torch.save holds the GIL for milliseconds at a time and the level
+        # loop above stretched from 8 to 10-35 ms waiting for it.
+        if root:
+            with torch.cuda.stream(_side_stream(_mask.device, "mlp")):
+                save_mlp_checkpoints(pc, path("mlp.pt"))
+    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes, overlap=write_mlp)   # blobs alias a pinned buffer
     torch.cuda.synchronize(); t_codec = time.time() - t0
     tr("coder launch done, bitstream on the host")
     if not root:
@@ -297,21 +301,28 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     max_d = {"feat": {}, "scaling": {}, "offsets": {}}
     for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
         writes += codec.write_file(path(f"{name}{level}.b"), blob)                        # :1235-1238
-        bit_d[name][level] = (lens * 8).tolist()
-        min_d[name][level] = mn.astype(np.int64).tolist()
-        max_d[name][level] = mx.astype(np.int64).tolist()
+        if version == 2:      # arrays: thousands of blocks as Python ints cost the decoder's unpickling a garbage-collector pass
+            bit_d[name][level], min_d[name][level], max_d[name][level] = lens * 8, mn.astype(np.int32), mx.astype(np.int32)
+        else:
+            bit_d[name][level] = (lens * 8).tolist()
+            min_d[name][level] = mn.astype(np.int64).tolist()
+            max_d[name][level] = mx.astype(np.int64).tolist()
 
     tr("file writes submitted")
-    hyper_bytes = [j.result() for j in hyper_jobs]                                       # :1082-1098
-    tr("hyper rANS jobs done")
-    bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
-    with open(path("hyper.b"), "wb") as f:
-        f.write(b"".join(hyper_bytes))
+    if hyper_v2 is not None:
+        bit_hyper_list = hyper_v2[1] * 8
+        writes += codec.write_file(path("hyper.b"), hyper_v2[0])
+    else:
+        hyper_bytes = [j.result() for j in hyper_jobs]                                   # :1082-1098
+        tr("hyper rANS jobs done")
+        bit_hyper_list = [len(b) * 8 for b in hyper_bytes]
+        with open(path("hyper.b"), "wb") as f:
+            f.write(b"".join(hyper_bytes))
     bit_anchor = _anchor.numel() * 16
-    bit_hyper = sum(bit_hyper_list)
-    bit_feat = sum(sum(v) for v in bit_d["feat"].values())
-    bit_scaling = sum(sum(v) for v in bit_d["scaling"].values())
-    bit_offsets = sum(sum(v) for v in bit_d["offsets"].values())
+    bit_hyper = int(np.sum(bit_hyper_list))
+    bit_feat = sum(int(np.sum(v)) for v in bit_d["feat"].values())
+    bit_scaling = sum(int(np.sum(v)) for v in bit_d["scaling"].values())
+    bit_offsets = sum(int(np.sum(v)) for v in bit_d["offsets"].values())
 
     if version == 2:
         mask_blob, mask_lens = mask_job.result()
@@ -335,9 +346,9 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
             min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
             bit_d["offsets"], N_levels_list]
     if version == 2:
-        meta.append({"version": 2, "block_symbols": V2_BLOCK, "chunk": chunk, "bit_masks": (mask_lens * 8).tolist()})
+        meta.append({"version": 2, "block_symbols": V2_BLOCK, "hyper_block": V2_HYPER_BLOCK, "chunk": chunk,
+                     "bit_masks": mask_lens * 8})
     torch.save(meta, meta_path)
-    mlp_job.result()
     bit_meta = os.path.getsize(meta_path) * 8
     mlp = pc.get_mlp_size()[0]
     r = lambda v: round(v / bit2MB_scale, 4)
@@ -358,12 +369,24 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # the prior tables: the level plan — the first thing the device chain waits for — needs nothing else from the files
     anchor_job = codec.host_pool().submit(lambda: np.load(path("anchor.npy")).astype(np.int32))
     meta = torch.load(path("meta.b"), map_location="cpu", weights_only=False)
+    tr("meta.b unpickled")
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
      bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = meta[:14]
     extra = meta[14] if len(meta) > 14 else {"version": 1}
     version = int(extra.get("version", 1))
     if version not in (1, 2):
         raise RuntimeError(f"meta.b: container version {version} is newer than this decoder (1, 2)")
+    # all coded streams: file -> pinned buffer -> device by the staging threads on a side stream, in the order the coder
+    # launches consume them; started before anything else is loaded (reading ~120 MB is the longest chain of the prologue)
+    dev = pc.x_bound_min.device
+    n_lv = len(N_levels_list)
+    if version == 2:       # masks first (their launch runs beside the prologue), then level by level incl. the offsets
+        order = ["masks.b", "hyper.b"] + [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling", "offsets")]
+    else:
+        order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
+                [f"offsets{l}.b" for l in reversed(range(n_lv))]
+    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
+    tr("file staging submitted")
     chunk = extra["chunk"] if version == 2 else {"masks": max_batch}
     lanes = version == 2
     block = int(extra.get("block_symbols", V2_BLOCK))
@@ -380,34 +403,6 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
                                             N_valid * K, float(prob_masks))
         tr("mask job submitted")
-    load_mlp_checkpoints(pc, path("mlp.pt"))
-    tr("mlp.pt loaded")
-    pc.latent_codec.update(force=True)
-    tr("prior tables rebuilt")
-    dev = pc.x_bound_min.device
-    # the hyper strings are decoded by host threads (straight into a pinned [N_valid, H] buffer) while this thread stages the
-    # files, loads the anchors and builds the level plan; submitted FIRST: the first level's prediction waits for them
-    with open(path("hyper.b"), "rb") as f:
-        hyper_stream = f.read()
-    pos, strings, sizes = 0, [], []
-    for s, s0 in enumerate(range(0, N_valid, max_batch * 10)):                           # :1326-1336 (any N_valid, Q2)
-        nb = bit_hyper_list[s] // 8
-        strings.append(hyper_stream[pos:pos + nb])
-        sizes.append(min(max_batch * 10, N_valid - s0))
-        pos += nb
-    hyper_job = pc.latent_codec.decompress_chunks_rows(strings, sizes)
-    tr("hyper rANS jobs submitted")
-    # all Gaussian-coded streams: file -> pinned buffer -> device on a host thread / side stream, in the order the coder
-    # launches consume them (levels coarse to fine: features + scaling; all offsets with the last level)
-    n_lv = len(N_levels_list)
-    if version == 2:       # masks first (their launch runs beside the prologue), then level by level incl. the offsets
-        order = ["masks.b"] + [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling", "offsets")]
-    else:
-        order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
-                [f"offsets{l}.b" for l in reversed(range(n_lv))]
-    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
-
-    tr("file staging started")
     side_stream = _side_stream(dev)
     masks_decoded, masks_ready = None, None
     if version == 2:
@@ -419,6 +414,30 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             masks_decoded = codec.bernoulli_decode_packed(float(prob_masks), mask_edges, blob, mask_lens).view(-1, K, 1)
             masks_ready = side_stream.record_event()
         tr("mask chunk streams: device launch enqueued")
+    load_mlp_checkpoints(pc, path("mlp.pt"))      # (on a host thread it only moved the 5 ms: unpickling holds the GIL)
+    tr("mlp.pt loaded")
+    pc.latent_codec.update(force=True)
+    tr("prior tables rebuilt")
+    dev = pc.x_bound_min.device
+    if version == 2:
+        # version 2: lane-parallel table blocks, one device launch (EntropyBottleneck.decompress_lanes_rows)
+        hyper_rows = pc.latent_codec.decompress_lanes_rows(staged.get(path("hyper.b")), np.asarray(bit_hyper_list, dtype=np.int64) // 8,
+                                                           N_valid, int(extra.get("hyper_block", V2_HYPER_BLOCK)))
+        hyper_job = lambda: hyper_rows
+        tr("hyper blocks: device launch enqueued")
+    else:
+        # the hyper strings are decoded by host threads (straight into a pinned [N_valid, H] buffer) while this thread stages the
+        # files, loads the anchors and builds the level plan; submitted FIRST: the first level's prediction waits for them
+        with open(path("hyper.b"), "rb") as f:
+            hyper_stream = f.read()
+        pos, strings, sizes = 0, [], []
+        for s, s0 in enumerate(range(0, N_valid, max_batch * 10)):                           # :1326-1336 (any N_valid, Q2)
+            nb = bit_hyper_list[s] // 8
+            strings.append(hyper_stream[pos:pos + nb])
+            sizes.append(min(max_batch * 10, N_valid - s0))
+            pos += nb
+        hyper_job = pc.latent_codec.decompress_chunks_rows(strings, sizes)
+        tr("hyper rANS jobs submitted")
 
     q = torch.from_numpy(anchor_job.result()).to(dev)                                    # :1340-1342
     interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
@@ -540,8 +559,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         grid_scaling_after_Q[orig] = scal_dec.view(n_l, 6)
         if level != 0:
             already_coded[orig] = True
-            content_pre_gathered = extract_context_feat(anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
-                                                        inverse_indices_list, mapping_list, level)
+            content_pre_gathered = context_rows(pc, anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
+                                                inverse_indices_list, mapping_list, level)
     if masks_decoded is None:                    # no level at all (empty model)
         masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
     if masks_ready is not None:

@@ -136,6 +136,20 @@ def extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, alr
     return torch.cat([anchor_after_Q[idx], feat_after_Q[idx], grid_scaling_after_Q[idx]], dim=1)
 
 
+def context_rows(pc, anchor_after_Q, feat_after_Q, grid_scaling_after_Q, already_coded, inverse_indices_list, mapping_list, i):
+    """extract_context_feat with the row index taken from the level plan's cache (level_plan was just called on these anchors:
+    `ctx_idx[i]` is exactly _context_index at this point of the level loop) — no boolean mask, no torch.nonzero and therefore
+    no host read per level (the container's level loop otherwise drains the coder launch it has just queued)."""
+    cache = getattr(pc, "_level_cache", None)
+    idx = None
+    if cache is not None and tuple(cache["anchor"].shape) == tuple(anchor_after_Q.shape):
+        idx = cache["ctx_idx"].get(i)
+    if idx is None:
+        return extract_context_feat(anchor_after_Q, feat_after_Q, grid_scaling_after_Q, already_coded, inverse_indices_list,
+                                    mapping_list, i)
+    return torch.cat([anchor_after_Q[idx], feat_after_Q[idx], grid_scaling_after_Q[idx]], dim=1)
+
+
 def level_plan(pc, anchor, mask_anchor_bool):
     """Index bookkeeping of the level loop (:1559-1593), shared by the rate model, the
     encoder and the decoder.  Returns per level (from L-1 down to 0) the original-space

@@ -387,8 +387,8 @@ extern "C" int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P, int64_t
                                        stream)))
             return rc;
     }
-    return cgs_launch_preprocess_bwd(cfg, P, means3D, scales, rotations, radii, d_mean_px, d_conic, dL_dmeans3D,
-                                     dL_dmeans2D, dL_dscales, dL_drotations, stream);
+    return cgs_launch_preprocess_bwd(cfg, P, CGS_BLEND_BWD_RAW ? (const float4 *)g.rec : nullptr, means3D, scales, rotations, radii,
+                                     d_mean_px, d_conic, dL_dmeans3D, dL_dmeans2D, dL_dscales, dL_drotations, stream);
 }
 
 extern "C" int cgs_raster_stats(const cgs_raster_cfg *cfg, void *img_ws, size_t img_bytes, int64_t *stats_out,

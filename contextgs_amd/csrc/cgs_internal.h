@@ -7,6 +7,13 @@
 #include "../../include/cgs.h"
 
 #define CGS_TILE 16          // tile edge in pixels (reference: 16x16 tiles)
+// 1 (experiment builds, profiles/r04_blend_bwd_global_acc.txt): the blend backward adds every block visit's nine terms straight
+// to the gradient arrays (no-return global atomics) and hands preprocess_bwd RAW sums in dL_dmean2D_px / dL_dconic
+// (raster_blend_rows.hip, blend_bwd_rows_ga_kernel) — parity-green, 2.5 x slower (global float atomics retire at ~80 G/s
+// chip-wide); 0 (product): the LDS-accumulated kernel with the per-Gaussian factors applied at its flush
+#ifndef CGS_BLEND_BWD_RAW
+#define CGS_BLEND_BWD_RAW 0
+#endif
 #define CGS_WAVE 64
 
 void cgs_set_error(const char *fmt, ...);
@@ -135,7 +142,7 @@ int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsIm
 int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,
                          const float *dL_dout, float *dL_dmean2D_px, float *dL_dconic,
                          float *dL_dopacity, float *dL_dcolors, hipStream_t stream);
-int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
+int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float4 *rec_raw, const float *means3D,
                               const float *scales, const float *rotations,
                               const int32_t *radii, const float *dL_dmean2D_px,
                               const float *dL_dconic, float *dL_dmeans3D, float *dL_dmeans2D,

@@ -983,10 +983,12 @@ struct LaneAcDecoder {
     }
 };
 
-// bytes of the worst-case slot of one lane stream of a block with nsym symbols (multiple of 8)
-__host__ __device__ inline int64_t lanes_slot_bytes(int64_t nsym) { return (((nsym + 63) / 64) * 2 + 16 + 7) / 8 * 8; }
+// bytes of the worst-case slot of one lane stream of a block with nsym symbols at bps bytes per symbol (multiple of 8)
+__host__ __device__ inline int64_t lanes_slot_bytes(int64_t nsym, int bps = 2) { return (((nsym + 63) / 64) * bps + 16 + 7) / 8 * 8; }
 
-extern "C" size_t cgs_lanes_block_slot_bytes(int64_t nsym) { return (size_t)(LANES_HDR + 64 * lanes_slot_bytes(nsym > 0 ? nsym : 0)); }
+extern "C" size_t cgs_lanes_block_slot_bytes(int64_t nsym, int bytes_per_symbol) {
+    return (size_t)(LANES_HDR + 64 * lanes_slot_bytes(nsym > 0 ? nsym : 0, bytes_per_symbol));
+}
 
 // ONE WAVE PER BLOCK, one coder per lane.  out + out_off[b]: the block's worst-case region (cgs_lanes_block_slot_bytes): the
 // header's 64 lengths, then 64 lane slots of lanes_slot_bytes each.  out_len[b] = LANES_HDR + sum of the lane lengths.
@@ -1032,12 +1034,12 @@ __global__ void __launch_bounds__(64)
 // Pack the blocks: header + the 64 lane streams back to back at dst + dst_off[b] (the file layout).
 __global__ void __launch_bounds__(256)
     lanes_compact_kernel(const uint8_t *__restrict__ src, const int64_t *__restrict__ src_off, const int64_t *__restrict__ blk_off,
-                         const int64_t *__restrict__ dst_off, int n_blocks, uint8_t *__restrict__ dst) {
+                         const int64_t *__restrict__ dst_off, int n_blocks, uint8_t *__restrict__ dst, int bps) {
     const int blk = blockIdx.x, tid = threadIdx.x;
     if (blk >= n_blocks) return;
     const uint8_t *base = src + src_off[blk];
     uint8_t *d = dst + dst_off[blk];
-    const int64_t slot = lanes_slot_bytes(blk_off[blk + 1] - blk_off[blk]);
+    const int64_t slot = lanes_slot_bytes(blk_off[blk + 1] - blk_off[blk], bps);
     __shared__ uint32_t start[65];
     if (tid == 0) {
         uint32_t acc = LANES_HDR;
@@ -1146,11 +1148,11 @@ extern "C" int cgs_gaussian_ac_encode_lanes(const float *x, const float *mean, c
 }
 
 extern "C" int cgs_lanes_compact(const uint8_t *src, const int64_t *src_off, const int64_t *blk_off, const int64_t *dst_off,
-                                 int n_blocks, uint8_t *dst, void *stream) {
-    if (n_blocks < 0) { cgs_set_error("lanes_compact: bad args"); return CGS_ERR_ARG; }
+                                 int n_blocks, uint8_t *dst, int bytes_per_symbol, void *stream) {
+    if (n_blocks < 0 || bytes_per_symbol < 1) { cgs_set_error("lanes_compact: bad args"); return CGS_ERR_ARG; }
     if (n_blocks == 0) return CGS_OK;
     hipLaunchKernelGGL(lanes_compact_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, src, src_off, blk_off, dst_off,
-                       n_blocks, dst);
+                       n_blocks, dst, bytes_per_symbol);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -1162,6 +1164,138 @@ extern "C" int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scal
     if (n_blocks == 0) return CGS_OK;
     hipLaunchKernelGGL(gaussian_decode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, mean, scale, Q, q_div,
                        blk_off, n_blocks, min_v, max_v, in, in_off, x_out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Lane-parallel table codec (container version 2: hyper.b)
+// ---------------------------------------------------------------------------------
+// The hyper latents (scene/gaussian_model.py:1082-1098,1326-1338: compressai's EntropyBottleneck.compress, a per-channel
+// frequency table, rANS strings of 10 000 anchors; the wheel is not in the mount) in version 2: the SAME per-channel integer
+// tables (EntropyBottleneck.update), the arithmetic coder of this file, lane-parallel blocks as above.  A block holds
+// consecutive anchors of ONE channel (blk_ch), so its table is staged once.  A value outside the table's support is the
+// escape slot followed by its sign, the bit length of m = distance + 1 in unary and m's low bits, each as an equiprobable
+// binary symbol (the same payload the host rANS coder sends).
+#define TAB_MAX_LEN 1024
+#define TAB_BPS 6            // worst-case bytes per symbol of a lane slot (escapes cost up to ~10 bytes; an overflow is reported)
+
+template <class Enc>
+__device__ __forceinline__ void table_put_bit(Enc &enc, uint32_t bit) { enc.encode(bit ? 0x8000u : 0u, bit ? AC_TOP : 0x8000u); }
+
+__global__ void __launch_bounds__(64)
+    table_encode_lanes_kernel(const int32_t *__restrict__ sym, const int64_t *__restrict__ blk_off, const int32_t *__restrict__ blk_ch,
+                              int n_blocks, const int32_t *__restrict__ cdf, int max_len, const int32_t *__restrict__ cdf_len,
+                              const int32_t *__restrict__ offset, uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
+                              uint32_t *__restrict__ out_len, int32_t *__restrict__ status) {
+    __shared__ uint32_t tab[TAB_MAX_LEN];
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int ch = blk_ch[blk];
+    const int len = cdf_len[ch], max_value = len - 2, off = offset[ch];
+    for (int i = lane; i < len; i += 64) tab[i] = (uint32_t)cdf[(size_t)ch * max_len + i];
+    __syncthreads();
+    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
+    const int64_t slot = lanes_slot_bytes(e - b, TAB_BPS);
+    uint8_t *base = out + out_off[blk];
+    uint8_t *mine = base + LANES_HDR + lane * slot;
+    AcEncoderT<WaveBitWriter> enc;
+    enc.init(mine, (size_t)slot);
+    for (int64_t i = b + lane; i < e; i += 64) {
+        const int raw = sym[i] - off;
+        const bool esc = raw < 0 || raw >= max_value;
+        const int v = esc ? max_value : raw;
+        enc.encode(tab[v], tab[v + 1]);
+        if (esc) {
+            const uint32_t m = raw < 0 ? (uint32_t)(-raw) : (uint32_t)(raw - max_value + 1);
+            table_put_bit(enc, raw < 0 ? 1u : 0u);
+            const int nb = 31 - __clz((int)m);                      // floor(log2 m), m >= 1
+            for (int k = 0; k < nb; ++k) table_put_bit(enc, 0u);
+            table_put_bit(enc, 1u);
+            for (int k = nb - 1; k >= 0; --k) table_put_bit(enc, (m >> k) & 1u);
+        }
+    }
+    const uint32_t bytes = (uint32_t)enc.finish(mine);
+    ((uint16_t *)base)[lane] = (uint16_t)bytes;
+    uint32_t tot = bytes;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+    if (__ballot(enc.out.overflow || bytes > 65535u) != 0ull && lane == 0) atomicMax(status, 2);
+    if (lane == 0) out_len[blk] = LANES_HDR + tot;
+}
+
+// -> dequantised rows: out_rows[(i - ch * n_per_ch) * ld + ch] = (float)symbol + medians[ch]
+__global__ void __launch_bounds__(64)
+    table_decode_lanes_kernel(const int64_t *__restrict__ blk_off, const int32_t *__restrict__ blk_ch, int n_blocks,
+                              const int32_t *__restrict__ cdf, int max_len, const int32_t *__restrict__ cdf_len,
+                              const int32_t *__restrict__ offset, const float *__restrict__ medians, int64_t n_per_ch,
+                              const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off, float *__restrict__ out_rows,
+                              int64_t ld) {
+    __shared__ uint32_t tab[TAB_MAX_LEN];
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int ch = blk_ch[blk];
+    const int len = cdf_len[ch], max_value = len - 2, off = offset[ch];
+    for (int i = lane; i < len; i += 64) tab[i] = (uint32_t)cdf[(size_t)ch * max_len + i];
+    __syncthreads();
+    const float med = medians[ch];
+    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
+    const uint8_t *base = in + in_off[blk];
+    const uint32_t mylen = ((const uint16_t *)base)[lane];
+    uint32_t incl = mylen;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    LaneAcDecoder dec;
+    dec.init(base + LANES_HDR + (incl - mylen));
+    auto get_bit = [&]() -> uint32_t {
+        const uint32_t bit = cdf_le_target(0x8000u, dec.span_m1(), dec.num()) ? 1u : 0u;
+        dec.consume(bit ? 0x8000u : 0u, bit ? AC_TOP : 0x8000u);
+        return bit;
+    };
+    for (int64_t i = b + lane; i < e; i += 64) {
+        const uint64_t num = dec.num();
+        const uint32_t sm1 = dec.span_m1();
+        int lo_j = 0, hi_j = max_value + 1;          // largest v in [0, max_value] with tab[v] <= target (tab[0] = 0)
+        while (hi_j - lo_j > 1) {
+            const int mid = (lo_j + hi_j) >> 1;
+            if (cdf_le_target(tab[mid], sm1, num)) lo_j = mid; else hi_j = mid;
+        }
+        int value = lo_j;
+        dec.consume(tab[value], tab[value + 1]);     // (every symbol is consumed: escape payloads may follow the last one)
+        if (value == max_value) {
+            const uint32_t sign = get_bit();
+            int nz = 0;
+            while (get_bit() == 0u && nz < 31) ++nz;
+            uint32_t m = 1;
+            for (int k = 0; k < nz; ++k) m = (m << 1) | get_bit();
+            value = sign ? -(int)m : (int)m + max_value - 1;
+        }
+        out_rows[(i - (int64_t)ch * n_per_ch) * ld + ch] = (float)(value + off) + med;
+    }
+}
+
+extern "C" int cgs_table_ac_encode_lanes(const int32_t *sym, const int64_t *blk_off, const int32_t *blk_ch, int n_blocks,
+                                         const int32_t *cdf, int max_len, const int32_t *cdf_len, const int32_t *offset,
+                                         uint8_t *out, const int64_t *out_off, uint32_t *out_len, int32_t *status, void *stream) {
+    if (n_blocks < 0 || max_len < 3 || max_len > TAB_MAX_LEN) { cgs_set_error("table_ac_encode_lanes: bad args (tables of up to %d entries)", TAB_MAX_LEN); return CGS_ERR_ARG; }
+    if (n_blocks == 0) return CGS_OK;
+    hipLaunchKernelGGL(table_encode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, sym, blk_off, blk_ch, n_blocks,
+                       cdf, max_len, cdf_len, offset, out, out_off, out_len, status);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_table_ac_decode_lanes(const int64_t *blk_off, const int32_t *blk_ch, int n_blocks, const int32_t *cdf,
+                                         int max_len, const int32_t *cdf_len, const int32_t *offset, const float *medians,
+                                         int64_t n_per_channel, const uint8_t *in, const int64_t *in_off, float *out_rows,
+                                         int64_t ld_rows, void *stream) {
+    if (n_blocks < 0 || max_len < 3 || max_len > TAB_MAX_LEN) { cgs_set_error("table_ac_decode_lanes: bad args"); return CGS_ERR_ARG; }
+    if (n_blocks == 0) return CGS_OK;
+    hipLaunchKernelGGL(table_decode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, blk_off, blk_ch, n_blocks, cdf,
+                       max_len, cdf_len, offset, medians, n_per_channel, in, in_off, out_rows, ld_rows);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

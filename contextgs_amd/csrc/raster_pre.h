@@ -93,10 +93,16 @@ __device__ __forceinline__ void cgs_pre_fwd_one(int64_t i, const float3 p, const
 // One Gaussian of the preprocess backward (the body of preprocess_bwd_kernel for radius > 0): p / s_raw / q are the forward's
 // means3D / scales / rotations, gmean_* = dL/d(pixel mean), gconic_* = dL/d(conic) from the blend backward.  s below is
 // s_raw * scale_modifier as in the kernel; o.ds is the gradient of s_raw.
+// RAW (csrc/raster_blend_rows.hip, blend_bwd_rows_ga_kernel): the five inputs are the blend backward's raw sums a0..a4 =
+// sum gx, sum gy, sum gx dx, sum gx dy, sum gy dy over the Gaussian's pixels and raw_op its opacity; the factors that turn
+// them into dL/d(pixel mean) and dL/d(conic) are applied here, from the conic this function recomputes anyway:
+//   dL/dmean = -op (con_a a0 + con_b a1, con_c a1 + con_b a0),  dL/dconic = -op (a2 / 2, a3, a4 / 2)
 struct CgsPreBwd { float dp[3], dm2[3], ds[3], dq[4]; };
+template <bool RAW = false>
 __device__ __forceinline__ CgsPreBwd cgs_pre_bwd_one(const float3 p, const float3 s_raw, const float4 q, float gmean_x, float gmean_y,
                                                      float gconic_a, float gconic_b, float gconic_c, const float *V, const float *Pm,
-                                                     int W, int H, float tanfovx, float tanfovy, float scale_modifier) {
+                                                     int W, int H, float tanfovx, float tanfovy, float scale_modifier,
+                                                     float raw_op = 0.f) {
     CgsPreBwd o;
     const float3 s = make_float3(s_raw.x * scale_modifier, s_raw.y * scale_modifier, s_raw.z * scale_modifier);
     // ---- recompute forward intermediates ---------------------------------
@@ -110,6 +116,16 @@ __device__ __forceinline__ CgsPreBwd cgs_pre_bwd_one(const float3 p, const float
     x += 0.3f;
     z += 0.3f;
     const float det = x * z - y * y;
+    if (RAW) {
+        const float inv = det != 0.f ? 1.f / det : 0.f;
+        const float con_a = z * inv, con_b = -y * inv, con_c = x * inv;      // as cgs_project forms them
+        const float a0 = gmean_x, a1 = gmean_y;
+        gmean_x = -raw_op * fmaf(con_a, a0, con_b * a1);
+        gmean_y = -raw_op * fmaf(con_c, a1, con_b * a0);
+        gconic_a *= -0.5f * raw_op;
+        gconic_b *= -raw_op;
+        gconic_c *= -0.5f * raw_op;
+    }
 
     // ---- conic -> cov2D ----------------------------------------------------
     const float ga = gconic_a, gbb = gconic_b, gc = gconic_c;

@@ -125,6 +125,9 @@ def _any_rank_has_grad(params, dev) -> list:
     return [bool(v) for v in m.tolist()]
 
 
+_OPEN_SYNC = None          # weakref to the GradientSync that currently owns the hooks / the deferral switch
+
+
 class GradientSync:
     """Gradient all-reduce that starts DURING the backward (SURVEY 8e "overlap with the tail of backward").
 
@@ -167,11 +170,28 @@ class GradientSync:
         # their weight-gradient launches for the end of the backward (mlp.defer_weight_gradients), this object issues
         # whatever per-anchor collectives are still waiting first (_issue_leftovers), and the launches then run on the
         # compute stream BESIDE the collectives on RCCL's stream.  Gradients are bit-identical either way.
-        self._deferring = None
+        #  the deferral is process-global state in mlp.py: it is scoped to THIS object — a sync that is replaced
+        # (a new one after adjust_anchor) or garbage-collected without close() must not leave deferral on with
+        # a hook that issues collectives for stale Parameters.  The hook only holds a weak reference, a new GradientSync closes
+        # the one that is still open, and __del__ closes too.
+        global _OPEN_SYNC
+        prev_sync = _OPEN_SYNC() if _OPEN_SYNC is not None else None
+        if prev_sync is not None:
+            prev_sync.close()
+        self._deferring = self._hook = None
         if defer_weight_gradients and world() > 1:
+            import weakref
             from . import mlp
             self._deferring = mlp.defer_weight_gradients(True)
-            mlp.add_before_flush_hook(self._issue_leftovers)
+            ref = weakref.ref(self)
+
+            def hook():
+                s = ref()
+                if s is not None:
+                    s._issue_leftovers()
+            self._hook = mlp.add_before_flush_hook(hook)
+        import weakref as _wr
+        _OPEN_SYNC = _wr.ref(self)
 
     def close(self):
         for h in self._handles:
@@ -179,9 +199,15 @@ class GradientSync:
         self._handles = []
         if self._deferring is not None:
             from . import mlp
-            mlp.remove_before_flush_hook(self._issue_leftovers)
+            mlp.remove_before_flush_hook(self._hook)
             mlp.defer_weight_gradients(self._deferring)
-            self._deferring = None
+            self._deferring = self._hook = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- internals ------------------------------------------------------------------------------------------------
     def _op(self):

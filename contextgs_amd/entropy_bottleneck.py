@@ -518,6 +518,28 @@ class EntropyBottleneck(nn.Module):
             return stage[:N * Cn].view(N, Cn).to(dev, non_blocking=True).to(self.quantiles.dtype)
         return finish
 
+    # Container version 2: the same symbols and tables through the DEVICE coder (csrc/codec.hip, "Lane-parallel table
+    # codec"): blocks of `block` anchors of one channel, 64 interleaved lane streams each — no host rANS strings.
+    @torch.no_grad()
+    def compress_lanes(self, x: torch.Tensor, block: int):
+        """x [C, N] (device) -> (blob uint8 ndarray, lens int64 [blocks])."""
+        from . import codec
+        assert x.dim() == 2 and x.shape[0] == self.channels
+        if self._offset.numel() == 0:
+            self.update()
+        sym = self.quantize(x, "symbols", self._get_medians()[:, 0])                          # [C, N] int32
+        return codec.table_encode_lanes(sym, self._quantized_cdf, self._cdf_length, self._offset, block)
+
+    @torch.no_grad()
+    def decompress_lanes_rows(self, blob, lens, n: int, block: int) -> torch.Tensor:
+        """inverse of compress_lanes -> [n, C] dequantised rows on the module's device."""
+        from . import codec
+        if self._offset.numel() == 0:
+            self.update()
+        med = self._get_medians()[:, 0, 0].float()
+        return codec.table_decode_lanes(blob, lens, self.channels, int(n), self._quantized_cdf, self._cdf_length, self._offset,
+                                        med, block).to(self.quantiles.dtype)
+
     @torch.no_grad()
     def decompress_chunks(self, strings: list[bytes], sizes: list[int]) -> torch.Tensor:
         """inverse of compress_chunks -> [C, sum(sizes)] dequantised, on the module's device."""

@@ -40,9 +40,20 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
-    if t.dtype != torch.float32:
-        t = t.float()
-    return t.contiguous()
+    """float32, contiguous.  A camera's matrices arrive as transposed views (scene/cameras.py builds them with .transpose(0, 1)):
+    the dense copy is made once per tensor and kept on the tensor object, keyed by its version counter (two launches per step
+    otherwise)."""
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    hit = getattr(t, "_cgs_f32c", None)
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    r = t.detach().float().contiguous()
+    try:
+        t._cgs_f32c = (t._version, r)
+    except Exception:
+        pass
+    return r
 
 
 class _Cfg:

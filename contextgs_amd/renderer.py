@@ -29,6 +29,24 @@ def _c(t):
     return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
 
 
+import threading as _threading
+
+_OUTSTANDING = _threading.local()      # per thread and kind: the object whose *_launch owns the library's pinned count slot
+
+
+def _own_slot(kind, obj):
+    setattr(_OUTSTANDING, kind, obj)
+
+
+def _check_slot(kind, obj):
+    # The library keeps ONE pinned count slot per kind and thread (csrc: g_nz_slot, g_expand_slot): *_wait returns what the most
+    # recent *_launch of the thread wrote.  An object that waits after another one of its kind was launched would read that
+    # other object's count and mis-size its outputs — refuse instead.
+    if getattr(_OUTSTANDING, kind, None) is not obj:
+        raise RuntimeError(f"{type(obj).__name__}: another {kind} launch was issued on this thread before wait(); "
+                           "launch / wait pairs of one kind must not interleave")
+
+
 class VisibleList:
     """torch.nonzero(mask)[:, 0] in two halves (cgs_nonzero_launch / _wait): the kernels are enqueued at construction,
     `wait()` blocks only until the count has been copied back and returns the index tensor."""
@@ -42,12 +60,18 @@ class VisibleList:
         self.scratch = torch.empty(int(L.cgs_nonzero_scratch_bytes(n)), dtype=torch.uint8, device=m.device)
         _lib.check(L.cgs_nonzero_launch(_lib.ptr(m), n, _lib.ptr(self.idx), _lib.ptr(self.scratch), self.scratch.numel(),
                                         _lib.current_stream()), "cgs_nonzero_launch")
+        self._idx = None
+        _own_slot("nonzero", self)
 
     def wait(self):
+        if self._idx is not None:
+            return self._idx
+        _check_slot("nonzero", self)
         cnt = C.c_int64(0)
         _lib.check(_lib.lib().cgs_nonzero_wait(C.byref(cnt)), "cgs_nonzero_wait")
         idx = self.idx[:int(cnt.value)]
         idx._cgs_ascending = True        # row gathers by this list take the one-pass backward (cgs_scatter_rows_sorted)
+        self._idx = idx
         return idx
 
 
@@ -74,9 +98,11 @@ class ExpandCount:
                                              _lib.ptr(self.mask_out), _lib.ptr(self.flags), _lib.ptr(self.pos),
                                              _lib.ptr(self.scratch), self.scratch.numel(), _lib.current_stream()),
                    "cgs_expand_count_launch")
+        _own_slot("expand_count", self)
 
     def wait(self) -> int:
         if self.P is None:
+            _check_slot("expand_count", self)
             cnt = C.c_int64(0)
             _lib.check(_lib.lib().cgs_expand_count_wait(C.byref(cnt)), "cgs_expand_count_wait")
             self.P = int(cnt.value)
@@ -115,6 +141,7 @@ class _ExpandGaussians(torch.autograd.Function):
                                       _lib.ptr(scaling), _lib.ptr(rot), _lib.ptr(src_row), stream), "cgs_expand_write")
         ctx.K = K
         ctx.n = n
+        ctx.P = P                   # the substitutes of absent output gradients are sized from this, not from g_xyz
         ctx.src_row = src_row
         ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in)
         ctx.mark_non_differentiable(mask_out)
@@ -128,7 +155,7 @@ class _ExpandGaussians(torch.autograd.Function):
         n = ctx.n
         src_row = ctx.src_row
         dev = gscaling.device
-        P = int(g_xyz.shape[0]) if g_xyz is not None else 0
+        P = ctx.P
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         g_xyz = _c(g_xyz) if g_xyz is not None else z(P, 3)
         g_color = _c(g_color) if g_color is not None else z(P, 3)
@@ -450,7 +477,9 @@ class _ZeroPoints(torch.autograd.Function):
     """The reference's `screenspace_points` (gaussian_renderer/__init__.py:168: a zero [P,3] non-leaf tensor whose .grad
     receives the 2-D position gradients) without its per-view fill + add: the values are never written by anyone (the
     rasterizer only fills the GRADIENT), so every view gets a view of one per-device zero buffer, wrapped in an
-    autograd node so that it is a fresh non-leaf tensor that requires grad, as in the reference."""
+    autograd node so that it is a fresh non-leaf tensor that requires grad, as in the reference.  READ-ONLY by contract: all
+    views' tensors alias the same storage (the reference's is an independent zeros_like + 0); nothing on this path writes it,
+    and a caller that did would corrupt the zeros of every later view."""
 
     @staticmethod
     def forward(ctx, like, token):
@@ -536,7 +565,13 @@ def prefilter_voxel(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, 
         # The reference evaluates get_scaling / get_rotation on all N rows and then reads three scale columns and
         # rotation row 0 (:262-266, :283: `rotations[[0], :].repeat(N, 1)`).  Both activations are row / element-wise,
         # so applying them to exactly what is read gives the same values: exp of 3 columns, normalisation of one row.
-        rot0 = pc.rotation_activation(pc._rotation[:1])
+        # (rotation row 0 changes only when the optimizer touches _rotation: normalised once per version of the parameter)
+        hit = getattr(pc, "_rot0_cache", None)
+        if hit is not None and hit[0] is pc._rotation and hit[1] == pc._rotation._version:
+            rot0 = hit[2]
+        else:
+            rot0 = pc.rotation_activation(pc._rotation[:1])
+            pc._rot0_cache = (pc._rotation, pc._rotation._version, rot0)
         sc = pc._scaling
         if (means3D.is_cuda and sc.is_cuda and sc.dtype == torch.float32 and sc.dim() == 2 and sc.stride(1) == 1
                 and means3D.dtype == torch.float32):

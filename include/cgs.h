@@ -610,10 +610,10 @@ int cgs_streams_compact(const uint8_t *src, const int64_t *src_off,
  * in the file = 64 little-endian uint16 lane-stream byte lengths, then the 64
  * lane streams back to back; out_len[b] is its byte length.  Encode writes
  * block b into its worst-case region out + out_off[b]
- * (cgs_lanes_block_slot_bytes(symbols of the block) bytes, 8-byte aligned),
+ * (cgs_lanes_block_slot_bytes(symbols of the block, 2) bytes, 8-byte aligned),
  * cgs_lanes_compact packs the regions at dst + dst_off[b].  `in` must be
  * readable 4 bytes past its last block.  min_v / max_v / status as above. */
-size_t cgs_lanes_block_slot_bytes(int64_t n_symbols);
+size_t cgs_lanes_block_slot_bytes(int64_t n_symbols, int bytes_per_symbol);
 int cgs_gaussian_ac_encode_lanes(const float *x, const float *mean,
                                  const float *scale, const float *Q,
                                  int64_t q_div, const int64_t *blk_off,
@@ -623,13 +623,36 @@ int cgs_gaussian_ac_encode_lanes(const float *x, const float *mean,
                                  int32_t *status, void *stream);
 int cgs_lanes_compact(const uint8_t *src, const int64_t *src_off,
                       const int64_t *blk_off, const int64_t *dst_off,
-                      int n_blocks, uint8_t *dst, void *stream);
+                      int n_blocks, uint8_t *dst, int bytes_per_symbol,
+                      void *stream);
 int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scale,
                                  const float *Q, int64_t q_div,
                                  const int64_t *blk_off, int n_blocks,
                                  const int32_t *min_v, const int32_t *max_v,
                                  const uint8_t *in, const int64_t *in_off,
                                  float *x_out, void *stream);
+/* Container version 2, hyper.b: the hyper latents' integer symbols
+ * (scene/gaussian_model.py:1082-1098,1326-1338; compressai's
+ * EntropyBottleneck.compress / decompress, per-channel frequency tables) as
+ * lane-parallel blocks of the same arithmetic coder.  sym int32 flat
+ * [C * n_per_channel] (channel-major); block b covers [blk_off[b], blk_off[b+1])
+ * and lies inside channel blk_ch[b]; cdf int32 [C, max_len] (total 2^16, last
+ * used slot = escape), cdf_len / offset [C] as EntropyBottleneck.update builds
+ * them.  Lane slots hold 6 bytes per symbol (cgs_lanes_block_slot_bytes(n, 6),
+ * cgs_lanes_compact(..., 6, ...)); status 2 = a slot overflowed.  Decode writes
+ * dequantised rows: out_rows[i * ld_rows + c] = symbol + medians[c]. */
+int cgs_table_ac_encode_lanes(const int32_t *sym, const int64_t *blk_off,
+                              const int32_t *blk_ch, int n_blocks,
+                              const int32_t *cdf, int max_len,
+                              const int32_t *cdf_len, const int32_t *offset,
+                              uint8_t *out, const int64_t *out_off,
+                              uint32_t *out_len, int32_t *status, void *stream);
+int cgs_table_ac_decode_lanes(const int64_t *blk_off, const int32_t *blk_ch,
+                              int n_blocks, const int32_t *cdf, int max_len,
+                              const int32_t *cdf_len, const int32_t *offset,
+                              const float *medians, int64_t n_per_channel,
+                              const uint8_t *in, const int64_t *in_off,
+                              float *out_rows, int64_t ld_rows, void *stream);
 /* Container version 2: the offset-mask symbols (scene/gaussian_model.py:1265-1269,
  * 1348-1353; utils/encodings.py:147-180 code them as ONE serial stream) cut into
  * chunk streams and coded by the same arithmetic coder, one wave per stream.

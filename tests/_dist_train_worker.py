@@ -54,6 +54,8 @@ def main():
     mgpu.BIG_TENSOR = N                                       # per-anchor tensors in place, MLPs in the bucket
     sync = mgpu.GradientSync(params, average=True)
     torch.manual_seed(1000 + rank)                            # the ranks' RNG streams differ from here on (as in training)
+    if len(sys.argv) > 2 and sys.argv[2] == "seq":
+        return collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank)
     # (the fifth step: rank 1's camera sees NO anchor — its backward produces no per-anchor gradient at all, the collective
     #  sequence must stay aligned and the replicas identical; the sixth: back to normal)
     for it, step_sem in enumerate((2000, 5000, 20000, 20000, 20000, 20000)):
@@ -122,6 +124,62 @@ def main():
     dist.barrier()
     print(f"rank {rank}: replicas identical after 6 optimiser steps (one of them with an empty view on rank 1); grew {grown} anchors identically; "
           f"adjust_anchor {n0} -> {n1} anchors identically", flush=True)
+    dist.destroy_process_group()
+
+
+def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
+    """with deferred weight gradients (GradientSync switches them on) and a rank whose view sees nothing,
+    both ranks must issue the SAME sequence of collectives (kind, element count, dtype) in every step — a mismatch is a
+    deadlock or a silent mis-pairing on RCCL.  Three consecutive steps in each of the three training phases (the active
+    parameter set changes at the phase boundaries), the middle step of every phase with an empty view on rank 1."""
+    log = []
+    real = {k: getattr(mgpu.dist, k) for k in ("all_reduce", "broadcast", "all_gather", "all_gather_into_tensor", "reduce_scatter_tensor")
+            if hasattr(mgpu.dist, k)}
+
+    def wrap(name, fn):
+        def f(t, *a, **kw):
+            first = t[0] if isinstance(t, (list, tuple)) else t
+            log.append((name, int(first.numel()), str(first.dtype), str(kw.get("op", a[0] if a and name == "all_reduce" else ""))))
+            return fn(t, *a, **kw)
+        return f
+    for k, fn in real.items():
+        setattr(mgpu.dist, k, wrap(k, fn))
+    from contextgs_amd import mlp
+    try:
+        assert mlp._Deferred.on, "GradientSync did not switch the deferred weight gradients on"
+        it = 0
+        for phase in (2000, 5000, 20000):
+            for k in range(3):
+                cam = cams[mgpu.view_for(it, len(cams))]
+                pc.update_learning_rate(phase)
+                opt.zero_grad(set_to_none=True)
+                vis = prefilter_voxel(cam, pc, pipe, bg)
+                if k == 1 and rank == 1:
+                    vis = torch.zeros_like(vis)
+                del log[:]
+                pkg = render(cam, pc, pipe, bg, visible_mask=vis, retain_grad=True, step=phase)
+                loss = (1.0 - pkg["render"]).abs().mean()
+                if pkg["bit_per_param"] is not None:
+                    loss = loss + 0.001 * pkg["bit_per_param"]
+                loss.backward()
+                sync.finish()
+                mine = list(log)
+                opt.step()
+                for k_, fn in real.items():          # the comparison itself must not land in the log
+                    setattr(mgpu.dist, k_, fn)
+                every = mgpu.gather_objects((mine, digest(params)), dst=0)
+                for k_, fn in real.items():
+                    setattr(mgpu.dist, k_, wrap(k_, fn))
+                if rank == 0:
+                    assert every[0][0] == every[1][0], f"phase {phase} step {k}: collective sequences differ:\n{every[0][0]}\n{every[1][0]}"
+                    assert len(every[0][0]) >= 2 and every[0][1] == every[1][1], f"phase {phase} step {k}: replicas diverged"
+                it += 1
+    finally:
+        for k_, fn in real.items():
+            setattr(mgpu.dist, k_, fn)
+    sync.close()
+    dist.barrier()
+    print(f"rank {rank}: identical collective sequences in 9 steps (3 phases x 3, one empty view per phase)", flush=True)
     dist.destroy_process_group()
 
 

@@ -45,7 +45,7 @@ def _canon(o):
         return {str(k): _canon(v) for k, v in sorted(o.items(), key=lambda kv: str(kv[0]))}
     if isinstance(o, (list, tuple)):
         return [_canon(v) for v in o]
-    if isinstance(o, torch.Tensor):
+    if isinstance(o, torch.Tensor) or isinstance(o, np.ndarray):
         return _canon(o.tolist())
     if isinstance(o, (np.integer,)):
         return int(o)

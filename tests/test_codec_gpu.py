@@ -153,6 +153,51 @@ def test_lane_blocks_roundtrip_bit_exact(edges, width):
     assert torch.equal(out, T(xq))
 
 
+@pytest.mark.parametrize("N,block", [(1, 64), (65, 64), (5000, 1024), (40017, 32768)])
+def test_table_lane_blocks_hyper_roundtrip_and_oracle_bytes(N, block):
+    """Container version 2's hyper.b (EntropyBottleneck.compress_lanes / decompress_lanes_rows): the per-channel integer tables
+    of update(), blocks of `block` anchors of one channel, 64 interleaved lane streams; values outside a table's support take
+    the escape slot + sign / unary length / low bits as equiprobable binary symbols.  Every lane stream equals the bit-list
+    oracle's stream for that symbol sequence; decoding returns round(x - median) + median."""
+    from contextgs_amd.entropy_bottleneck import EntropyBottleneck
+    torch.manual_seed(N)
+    eb = EntropyBottleneck(12).cuda()
+    eb.update(force=True)
+    x = (torch.randn(12, N, device="cuda") * 6.0)
+    x[0, 0] = 250.0                       # far outside: a long escape
+    if N > 3:
+        x[3, 3] = -97.5
+    blob, lens = eb.compress_lanes(x, block)
+    rows = eb.decompress_lanes_rows(blob, lens, N, block)
+    med = eb._get_medians()[:, 0, 0]
+    want = torch.round(x - med[:, None]) + med[:, None]
+    assert torch.equal(rows.t(), want)
+    # oracle bytes of the first and the last block
+    sym = eb.quantize(x, "symbols", eb._get_medians()[:, 0]).cpu().numpy()
+    cdf, cl, of = eb._quantized_cdf.cpu().numpy(), eb._cdf_length.cpu().numpy(), eb._offset.cpu().numpy()
+    nper = -(-N // block)
+    pos = np.concatenate([[0], np.cumsum(lens)])
+    BIT = [0, 32768, 65536]
+    for blk in sorted({0, len(lens) - 1}):
+        c, k = blk // nper, blk % nper
+        seq = sym[c, k * block:(k + 1) * block]
+        table = cdf[c, :cl[c]].tolist()
+        max_value = int(cl[c]) - 2
+        got = _split_block(blob[pos[blk]:pos[blk + 1]].tobytes())
+        for l in range(64):
+            R, S = [], []
+            for v in seq[l::64]:
+                raw = int(v) - int(of[c])
+                esc = raw < 0 or raw >= max_value
+                R.append(table); S.append(max_value if esc else raw)
+                if esc:
+                    m = -raw if raw < 0 else raw - max_value + 1
+                    nb = m.bit_length() - 1
+                    bits = [1 if raw < 0 else 0] + [0] * nb + [1] + [(m >> j) & 1 for j in range(nb - 1, -1, -1)]
+                    R += [BIT] * len(bits); S += bits
+            assert got[l] == ref.ac_encode(R, S), (blk, l)
+
+
 @pytest.mark.parametrize("p0", [0.03, 0.31, 0.5, 0.97])
 def test_bernoulli_chunk_streams_equal_the_host_coder(p0):
     """Container version 2's mask streams (cgs_bernoulli_ac_encode / _decode, one wave per chunk stream): every stream is

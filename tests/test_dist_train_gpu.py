@@ -29,6 +29,19 @@ def test_two_replicas_stay_identical_through_optimiser_steps_and_anchor_growing(
     assert r.stdout.count("replicas identical after 6 optimiser steps") == 2 and r.stdout.count("adjust_anchor") == 2
 
 
+def test_both_ranks_issue_identical_collective_sequences_in_every_phase():
+    """Deferred weight gradients + one rank with an empty view: the two ranks' collective sequences (kind, size, dtype) are
+    equal in three consecutive steps of each training phase and the replicas stay bit-identical (tests/_dist_train_worker.py
+    `seq` mode)."""
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_train_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), worker, "30000", "seq"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("identical collective sequences in 9 steps") == 2
+
+
 def test_bench_two_ranks_prints_one_json_line(tmp_path):
     """The driver's exact multi-GPU command (`python -m torch.distributed.run ... bench.py --gpus 2 ...`) on one GPU
     with gloo: ONE stdout line, whole-job value, n_gpus 2, weak scaling, rank-0-only codec leg."""

@@ -52,13 +52,28 @@ def _kw(g):
                 rots=g["rotations"])
 
 
-def _check_image(a, b):
+ALLOWANCE = []      # (what, entries inside the allowance, entries, worst): printed at the end of the module (pytest -s / -rA)
+
+
+def _check_image(a, b, what="image"):
     d = np.abs(a - b)
     rmse = float(np.sqrt((d ** 2).mean()))
     assert rmse <= 1e-5, rmse
-    frac = float((d > 2e-5).mean())
+    n_out = int((d > 2e-5).sum())
+    ALLOWANCE.append((what, n_out, int(d.size), float(d.max())))
+    print(f"[allowance] {what}: {n_out} of {d.size} pixel values differ by more than 2e-5 (allowed {1e-4 * d.size:.0f}), max {d.max():.2e}")
+    frac = n_out / d.size
     assert frac <= 1e-4, (frac, d.max())
     assert d.max() <= 1.0 / 255 + 1e-4, d.max()
+
+
+def test_zzz_allowance_report():
+    """Not a check of its own: prints how much of each tolerance allowance the tests of this module actually used (VERDICT
+    r3: a regression INSIDE the allowance should be visible).  Runs last (name order)."""
+    for what, n_out, n, worst in ALLOWANCE:
+        print(f"[allowance] {what}: {n_out}/{n} outside the tight bound, worst {worst:.3e}")
+    used = [a for a in ALLOWANCE if a[1] > 0]
+    print(f"[allowance] {len(used)} of {len(ALLOWANCE)} comparisons used any of their allowance")
 
 
 CASES = [
@@ -78,7 +93,7 @@ def test_forward_matches_oracle(oracle32, P, W, H, seed, extent, srange):
     ref = oracle32.render(cam.oracle_dict(bg=bg), **_kw(g))
     out = _run_gpu(cam, g, bg)
     assert (out["radii"] == ref["radii"]).all()
-    _check_image(out["color"], ref["color"])
+    _check_image(out["color"], ref["color"], f"forward P={P} {W}x{H}")
 
 
 @pytest.mark.parametrize("P,W,H,seed,extent,srange", CASES[:3])
@@ -89,12 +104,15 @@ def test_backward_matches_oracle(oracle32, P, W, H, seed, extent, srange):
     w = np.random.default_rng(seed).normal(size=(3, H, W)).astype(np.float32)
     ref = oracle32.render(cam.oracle_dict(bg=bg), **_kw(g), dL_dout=w)
     out = _run_gpu(cam, g, bg, w)
-    _check_image(out["color"], ref["color"])
+    _check_image(out["color"], ref["color"], f"backward-run image P={P} {W}x{H}")
     for k in ["dL_dmeans3D", "dL_dmeans2D", "dL_dcolors", "dL_dopacities", "dL_dscales", "dL_drotations"]:
         a, b = out[k], ref[k]
         scale = max(1e-6, float(np.abs(b).max()))
         err = np.abs(a - b) / scale
         # a flipped alpha-threshold decision changes one pixel's contribution; allow a tiny fraction of outliers
+        n_out = int((err > 2e-4).sum())
+        ALLOWANCE.append((f"{k} P={P}", n_out, int(err.size), float(err.max())))
+        print(f"[allowance] {k} P={P}: {n_out} of {err.size} entries beyond 2e-4 of the maximum (allowed {2e-3 * err.size:.0f}), worst {err.max():.2e}")
         assert float((err > 2e-4).mean()) <= 2e-3, (k, float(err.max()), float((err > 2e-4).mean()))
         assert float(np.median(err)) <= 1e-6, (k, float(np.median(err)))
 
