@@ -36,7 +36,7 @@ names = {"blend_bwd_kernel": "blend_bwd", "blend_fwd_kernel": "blend_fwd",
          "blend_bwd_rows_kernel": "blend_bwd", "blend_fwd_rows_kernel": "blend_fwd", "preprocess_kernel": "preprocess_plain",
          "expand_preprocess_kernel": "preprocess",
          "preprocess_bwd_kernel": "preprocess_bwd", "expand_bwd_kernel": "expand_bwd", "expand_write_kernel": "expand_fwd",
-         "mlp3_bwd_kernel": "mlp3_bwd", "mlp3_fwd_kernel": "mlp3_fwd", "wgrad4_kernel": "wgrad4"}
+         "mlp3_bwd_kernel": "mlp3_bwd_data_only", "mlp3_bwd_wg_kernel": "mlp3_bwd", "mlp3_fwd_kernel": "mlp3_fwd", "wgrad4_kernel": "wgrad4"}
 rd, wr = dict(out)["FETCH_SIZE"], dict(out)["WRITE_SIZE"]
 tr = {}
 for k, (n, tot) in rd.items():
