@@ -106,6 +106,7 @@ SIGNATURES = {
     "cgs_anchor_mlp3_layout": (c_int, [c_void_p]),
     "cgs_gather_rows_segmented": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_scatter_rows_sorted": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "cgs_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_rowcat_fwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_rowcat_bwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p]),

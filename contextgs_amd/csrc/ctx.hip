@@ -387,6 +387,55 @@ extern "C" int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64
     return CGS_OK;
 }
 
+// out[i] = x[idx[i]] for narrow rows (w <= 256 floats): the forward of the unique-row gathers of the step (visible anchors'
+// positions [N,3], masks [N,10], the rate subset's rows; gaussian_renderer/__init__.py:44-50) — torch's index_select takes its
+// generic gather kernel for these shapes (29 us per call at 1 M rows, one 64-bit index load and one address computation per
+// FLOAT); a lane per row for w = 1 / 3, float2 / float4 lanes for even widths (the forms of cgs_scatter_rows_sorted).
+template <int W>
+__global__ void __launch_bounds__(256)
+    gather_rows_row_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx, int64_t n, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx[i];
+        float v[W];
+#pragma unroll
+        for (int c = 0; c < W; ++c) v[c] = x[r * W + c];
+#pragma unroll
+        for (int c = 0; c < W; ++c) out[i * W + c] = v[c];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gather_rows_vec_kernel(const T *__restrict__ x, const int64_t *__restrict__ idx, int64_t n, int wv, T *__restrict__ out) {
+    const int rpb = 256 / wv;
+    const int li = (int)threadIdx.x / wv, c = (int)threadIdx.x - li * wv;
+    if (li >= rpb) return;
+    for (int64_t i = (int64_t)blockIdx.x * rpb + li; i < n; i += (int64_t)gridDim.x * rpb) out[i * wv + c] = x[idx[i] * wv + c];
+}
+
+extern "C" int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, int w, float *out, void *stream) {
+    if (n < 0 || w < 1 || w > 256) { cgs_set_error("gather_rows: bad sizes (1 <= w <= 256)"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!x || !idx || !out) { cgs_set_error("gather_rows: NULL"); return CGS_ERR_ARG; }
+    CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
+    const bool al8 = (((uintptr_t)x | (uintptr_t)out) & 7) == 0, al16 = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    if (w == 3)
+        hipLaunchKernelGGL(gather_rows_row_kernel<3>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, n, out);
+    else if (w == 1)
+        hipLaunchKernelGGL(gather_rows_row_kernel<1>, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, n, out);
+    else if (w % 4 == 0 && al16)
+        hipLaunchKernelGGL(gather_rows_vec_kernel<float4>, dim3(stream_grid(n, (256 / (w / 4)) * 2)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)x, idx, n, w / 4, (float4 *)out);
+    else if (w % 2 == 0 && al8)
+        hipLaunchKernelGGL(gather_rows_vec_kernel<float2>, dim3(stream_grid(n, (256 / (w / 2)) * 2)), dim3(256), 0, (hipStream_t)stream,
+                           (const float2 *)x, idx, n, w / 2, (float2 *)out);
+    else
+        hipLaunchKernelGGL(gather_rows_vec_kernel<float>, dim3(stream_grid(n, (256 / w) * 4)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                           n, w, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Counter-based noise: u(seed, tensor, element) in [-0.5, 0.5), regenerated (not stored) by the backward.
 // 32-bit arithmetic on purpose (two v_mul_lo_u32 per value): the first version was splitmix64, whose three 64-bit

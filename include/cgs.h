@@ -348,6 +348,10 @@ int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t *const *id
  * visible-anchor list (gaussian_renderer/__init__.py:44-50) in one launch instead of a zero fill + a scatter. */
 int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w,
                             float *out, void *stream);
+/* out[i, 0:w] = x[idx[i], 0:w] (int64 row indices, 1 <= w <= 256, dense fp32 rows):
+ * the forward of the same gathers (x[visible rows], gaussian_renderer/__init__.py:44-50). */
+int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, int w,
+                    float *out, void *stream);
 /* Atomics-free backward of a context assembly whose first three sources are gathered parent rows
  * (anchor position [N,wa] by original row, coded features [n_parents,DF] and scaling [n_parents,DS]
  * by position in the coded prefix): the children of parent p are order[offs[p] .. offs[p+1])

@@ -366,3 +366,20 @@ def test_gather_rows_segmented_equals_cat_then_gather(with_idx):
         (C.c_int64 * k)(*[w if (t is None or t.numel() == 0) else int(t.stride(0)) for t in blocks]),
         (C.c_int64 * (k + 1))(*begin), _lib.ptr(idx), N, w, _lib.ptr(out), _lib.current_stream()), "cgs_gather_rows_segmented")
     assert torch.equal(out, ref_cat[idx] if with_idx else ref_cat)
+
+
+@pytest.mark.parametrize("shape", [(5000, 1), (5000, 3), (5000, 10, 1), (5000, 10), (5000, 12), (5000, 7), (5000, 50), (3, 3)])
+def test_gather_unique_forward_is_index_select(shape):
+    """cgs_gather_rows (lane-per-row / float2 / float4 forms, round 4) behind context_model.gather_unique: bit-equal to
+    x.index_select(0, idx) for ascending and for permuted unique indices, and the backward still scatters."""
+    from contextgs_amd.context_model import gather_unique
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    n = shape[0]
+    for idx in (torch.nonzero(torch.rand(n, device="cuda") < 0.9)[:, 0], torch.randperm(n, device="cuda")[: max(1, n // 3)]):
+        y = gather_unique(x, idx)
+        assert torch.equal(y, x.detach().index_select(0, idx))
+        g = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, g)
+        ref = torch.zeros_like(x).index_copy_(0, idx, g)
+        assert torch.equal(gx, ref)
