@@ -487,6 +487,8 @@ __global__ void __launch_bounds__(256)
     const uint32_t kf = ctx_noise_key(seed, 0), ks = ctx_noise_key(seed, 1), ko = ctx_noise_key(seed, 2);
     float pf = 0.f, ps = 0.f, po = 0.f;
     for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; r < n; r += ((int64_t)gridDim.x * 256) >> 4) {
+        // (every lane evaluates the three step sizes itself: lanes 0..2 computing them once and a ds_bpermute broadcast to the
+        //  16 lanes of the row measured SLOWER, 44 vs 41 us per ctx_fwd launch — the tanhf is not what these kernels wait for)
         const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
                     qo = ctx_step(q0o, qadj[r * 3 + 2]);
         if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);
@@ -526,6 +528,8 @@ __global__ void __launch_bounds__(256)
         const bool f1 = l + 16 < D2, hs = l < S2, ho = l < O2;
         const float2 z = make_float2(0.f, 0.f);
         const float2 a0 = l < D2 ? sf[l] : z, a1 = f1 ? sf[l + 16] : z, b = hs ? ss[l] : z, c = ho ? so[l] : z;
+        // (every lane evaluates the three step sizes itself: lanes 0..2 computing them once and a ds_bpermute broadcast to the
+        //  16 lanes of the row measured SLOWER, 44 vs 41 us per ctx_fwd launch — the tanhf is not what these kernels wait for)
         const float qf = ctx_step(q0f, qadj[r * 3 + 0]), qs = ctx_step(q0s, qadj[r * 3 + 1]),
                     qo = ctx_step(q0o, qadj[r * 3 + 2]);
         if (l < 3) Q[r * 3 + l] = l == 0 ? qf : (l == 1 ? qs : qo);

@@ -55,3 +55,19 @@ def test_knn_with_fewer_points_than_neighbours(n):
     # the mean over three neighbours needs three neighbours: a missing one counts as FLT_MAX (so does the public simple_knn)
     assert bool((d < 1e30).all()) == (n >= 4)
     assert float(knn.distCUDA2(torch.zeros(10, 3, device=DEV)).abs().max()) == 0.0
+
+
+def test_interleaved_count_launches_are_refused():
+    """the library keeps ONE pinned count slot per kind and thread; an object that waits after another launch of its
+    kind would read that launch's count.  renderer.ExpandCount / VisibleList refuse instead of mis-sizing their outputs."""
+    from contextgs_amd.renderer import ExpandCount, VisibleList
+    a = ExpandCount(torch.randn(100, 10, device="cuda"), torch.ones(100, 10, 1, device="cuda"), 10)
+    b = ExpandCount(torch.randn(50, 10, device="cuda"), torch.ones(50, 10, 1, device="cuda"), 10)
+    with pytest.raises(RuntimeError, match="interleave"):
+        a.wait()
+    assert 0 <= b.wait() <= 500 and b.wait() == b.P          # the owner still reads its own count (and caches it)
+    m1 = torch.rand(1000, device="cuda") < 0.5
+    v1, v2 = VisibleList(m1), VisibleList(~m1)
+    with pytest.raises(RuntimeError, match="interleave"):
+        v1.wait()
+    assert torch.equal(v2.wait(), torch.nonzero(~m1)[:, 0]) and v2.wait() is v2.wait()

@@ -1,5 +1,8 @@
 """Wave-iteration count of the blend kernels: current mapping (8x8 quadrant per wave, one Gaussian per iteration)
-vs four 4x4 blocks per wave walking their own lists (csrc/raster_debug.hip)."""
+vs four 4x4 blocks per wave walking their own lists (csrc/raster_debug.hip).
+
+The counting kernels are compiled into -DCGS_EXPERIMENTS builds only (not the product library): build one with
+`bash tools/variant_lib.sh occ raster_debug.hip` and run with CGS_LIB_PATH=tools/variants/libcgs_occ.so."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
