@@ -427,11 +427,133 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One product whose Q is one full 64-feature group plus a NARROW tail (64 < DB <= 80): the first-layer gradient of the level
+// MLPs' step-size branch, dW1 [100 x 71] += dZ1^T X over every row of a level (round 4).  wgrad_multi_kernel gives the 7-feature
+// tail a task of its own that issues the same 16 MFMAs per 4 rows as a full 64 x 64 pair (the launch was MFMA-bound on
+// padding: 64 MFMAs per 4 rows for 7 100 useful of 16 384 outputs, 248 us at 800 k rows).  Here a task is an A group against
+// ALL of Q: the wave that has A's fragment in registers also multiplies it with the tail tile (lane c carries feature 64 + c,
+// one 4-byte load), 20 MFMAs per task and 4 rows, 40 for the product instead of 64; the tasks of a launch stay of equal
+// weight (what the multi kernel's lock-step walk needs).  512 threads (8 waves: GA tasks x nsub sub-ranges), same LDS-image /
+// two-pass reduction and summation order rules as the other weight-gradient kernels (bit-reproducible).
+#ifndef WG_TAIL_MIN_WAVES
+#define WG_TAIL_MIN_WAVES 1      // 140 VGPRs, three waves per SIMD, no spills; 4 (128 VGPRs, 40 B of scratch) measured 1 % slower
+#endif
+template <int UNR>
+__global__ void __launch_bounds__(512, WG_TAIL_MIN_WAVES)
+    wgrad_tail_kernel(const float *__restrict__ P, int64_t ldp, int DA, const float *__restrict__ Q, int64_t ldq, int DB,
+                      int64_t n, int64_t rows_per_block, int GA, int nsub, float *__restrict__ partial) {
+    __shared__ float img[128 * 80 + 128];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int E = DA * DB + DA;
+    for (int i = tid; i < E; i += 512) img[i] = 0.f;
+    const int ga = wave % GA, sub = wave / GA;
+    const bool active = sub < nsub;
+    f32x4 acc[4][4], accT[4], bsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja) {
+        accT[ja] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (active) {
+        const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r_end = min(n, r_begin + rows_per_block);
+        const WgStream sa = wg_stream(P, ldp, DA, ga, c, r_begin, r_end);
+        const WgStream sb = wg_stream(Q, ldq, DB, 0, c, r_begin, r_end);
+        const WgStream st = wg_stream(Q, ldq, DB, 1, c, r_begin, r_end, true);
+        const int rows = (int)(r_end - r_begin), stride = nsub * 4 * UNR;
+        int row0 = sub * 4 * UNR;
+        WgFrag<UNR> f0, f1;
+        float t0[UNR], t1[UNR];
+        auto fetch = [&](WgFrag<UNR> &f, float (&t)[UNR], int rel) {
+            wg_fetch<UNR>(f, sa, sb, rel, g);
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) t[q] = wg_load4(st, rel + 4 * q + g)[0];
+        };
+        auto consume = [&](const WgFrag<UNR> &f, const float (&t)[UNR]) {
+            wg_consume<UNR>(f, sa, sb, acc, bsum);
+#pragma unroll
+            for (int q = 0; q < UNR; ++q) {
+                const f32x4 a = wg_mask(sa, f.a[q]);
+                const float tv = st.m[0] ? t[q] : 0.f;
+#pragma unroll
+                for (int ja = 0; ja < 4; ++ja) accT[ja] = frag_mfma(a[ja], tv, accT[ja]);
+            }
+        };
+        fetch(f0, t0, row0);
+        for (; row0 < rows; row0 += 2 * stride) {
+            fetch(f1, t1, row0 + stride);
+            WG_FENCE();
+            consume(f0, t0);
+            WG_FENCE();
+            fetch(f0, t0, row0 + 2 * stride);
+            WG_FENCE();
+            consume(f1, t1);
+            WG_FENCE();
+        }
+    }
+    __syncthreads();      // image zeroed
+    for (int s = 0; s < nsub; ++s) {              // the sub-waves of a task take turns (plain read-add-write, fixed order)
+        if (active && sub == s) {
+            float *const outW = img, *const outb = img + DA * DB;
+#pragma unroll
+            for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ar = 64 * ga + 4 * (4 * g + r) + ja;
+                    if (ar >= DA) continue;
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) outW[ar * DB + 4 * c + jb] += acc[ja][jb][r];     // 4c + jb < 64 < DB
+                    if (64 + c < DB) outW[ar * DB + 64 + c] += accT[ja][r];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = bsum[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                const int ac = 64 * ga + 4 * c + j;
+                if (g == 0 && ac < DA) outb[ac] += v;
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = partial + (int64_t)blockIdx.x * E;
+    for (int i = tid; i < E; i += 512) dst[i] = img[i];
+}
+
+static int launch_wgrad_tail(const CgsWgProduct &p, int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s) {
+    constexpr int UNR = 2;
+    const int GA = (p.DA + 63) / 64, nsub = 8 / GA, E = p.DA * p.DB + p.DA;
+    int64_t blocks = (n + 255) / 256;
+    int64_t cap = (int64_t)num_cus * 2;                       // 29 KB of LDS image, 512 threads: two workgroups per CU
+    const int64_t fit_blocks = (int64_t)(scratch_bytes / ((size_t)E * sizeof(float)));
+    if (cap > fit_blocks) cap = fit_blocks;
+    if (blocks > cap) blocks = cap;
+    int64_t rpb = (n + blocks - 1) / blocks;
+    const int64_t quantum = (int64_t)nsub * 4 * UNR;
+    rpb = (rpb + quantum - 1) / quantum * quantum;
+    blocks = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL((wgrad_tail_kernel<UNR>), dim3((unsigned)blocks), dim3(512), 0, s, p.P, p.ldp, p.DA, p.Q, p.ldq, p.DB, n, rpb,
+                       GA, nsub, (float *)scratch);
+    CGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, (const float *)scratch, (int)blocks, E,
+                       p.DA * p.DB, p.dW, p.db);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
 // prods: nprod (<= 4) products over the same n rows.  Returns CGS_ERR_WORKSPACE-free: falls back to one launch per
 // product (cgs_launch_wgrad2) when the combination does not fit one workgroup (tasks > 16, LDS image, no scratch).
 int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int num_cus, void *scratch,
                            size_t scratch_bytes, hipStream_t s) {
     if (n <= 0 || nprod <= 0) return CGS_OK;
+#ifndef WG_NO_TAIL_KERNEL
+    if (nprod == 1 && scratch && prods[0].DB > 64 && prods[0].DB <= 80 && prods[0].DA <= 128 && prods[0].db &&
+        (size_t)(prods[0].DA * prods[0].DB + prods[0].DA) * sizeof(float) <= scratch_bytes)
+        return launch_wgrad_tail(prods[0], n, num_cus, scratch, scratch_bytes, s);
+#endif
 #ifdef CGS_EXPERIMENTS
     static const bool disabled = getenv("CGS_WGRAD_NO_MULTI") != nullptr;
 #else
