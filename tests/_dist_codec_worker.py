@@ -56,8 +56,10 @@ def main():
     names = ["anchor.npy", "hyper.b", "masks.b"] + [f"{a}{l}.b" for a in ("feat", "scaling", "offsets") for l in range(3)]
     match, mismatch, errors = filecmp.cmpfiles(d_multi, d_single, names, shallow=False)
     assert not mismatch and not errors, (mismatch, errors)
-    meta_m, meta_s = (torch.load(os.path.join(d, "meta.b"), weights_only=False) for d in (d_multi, d_single))
+    from container_digest import _canon            # header lists hold numpy arrays in container version 2
+    meta_m, meta_s = (_canon(torch.load(os.path.join(d, "meta.b"), weights_only=False)) for d in (d_multi, d_single))
     assert meta_m == meta_s
+    assert (len(meta_m) == 15) == (os.environ.get("CGS_CONTAINER_VERSION") == "2")
     dist.barrier()
 
     dec_m = scrambled(N, seed)

@@ -17,10 +17,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("N", [7, 40, 2500, 12000])      # 7, 40: fewer streams than ranks in a launch
-def test_sharded_codec_equals_single_process(tmp_path, N):
+@pytest.mark.parametrize("N,version", [(7, 1), (40, 1), (2500, 1), (12000, 1), (40, 2), (12000, 2)])   # 7, 40: fewer streams than ranks
+def test_sharded_codec_equals_single_process(tmp_path, N, version):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_codec_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CGS_CONTAINER_VERSION=str(version))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), worker, str(tmp_path), str(N)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
