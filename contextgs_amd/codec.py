@@ -261,8 +261,7 @@ def bernoulli_decode_packed(p0, stream_off, blob, lens, device=None):
     in_off_h = np.zeros(S + 1, dtype=np.int64)
     np.cumsum(lens, out=in_off_h[1:])
     assert int(in_off_h[-1]) <= int(in_d.numel()), "stream lengths exceed the blob"
-    in_off = torch.from_numpy(in_off_h).to(dev)
-    off_d = off_h.to(dev)
+    in_off, off_d = _upload_small([in_off_h, off_h], dev)
     _lib.check(L.cgs_bernoulli_ac_decode(bernoulli_c1(p0), _lib.ptr(off_d), S, _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(out),
                                          _lib.current_stream()), "cgs_bernoulli_ac_decode")
     return out
@@ -294,6 +293,54 @@ def to_host_pinned(t: torch.Tensor, key: str) -> np.ndarray:
     stage.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
     return stage.numpy()
+
+
+_SMALL_RING = {"slots": [], "next": 0}
+
+
+_KEYED_SLOTS = {}
+
+
+def _upload_small(arrays, dev, key=None):
+    """Host index arrays (numpy / CPU tensors) -> device tensors through ONE non-blocking copy out of a pinned ring slot.
+    A `.to(device)` of a pageable host array blocks the host until everything queued on the stream has run (the copy is
+    stream-ordered and staged synchronously): four of them per coder launch made the decoder's level loop wait for the
+    previous level's launch before it could even build the next one (3.4 ms per level at 1 M anchors)."""
+    arrs = [a.numpy() if isinstance(a, torch.Tensor) else np.ascontiguousarray(a) for a in arrays]
+    sizes = [(a.nbytes + 15) // 16 * 16 for a in arrs]
+    total = max(sum(sizes), 16)
+    ring = _SMALL_RING
+    if key is not None:       # a purpose of its own (e.g. the MLP checkpoint, ~0.5 MB): one grow-only buffer, not a ring slot
+        slot = _KEYED_SLOTS.setdefault(key, {"buf": torch.empty(0, dtype=torch.uint8), "ev": None})
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        if slot["buf"].numel() < total:
+            slot["buf"] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+    elif len(ring["slots"]) < 16:
+        ring["slots"].append({"buf": torch.empty(max(total, 1 << 16), dtype=torch.uint8, pin_memory=True), "ev": None})
+        slot = ring["slots"][-1]
+    else:
+        slot = ring["slots"][ring["next"] % 16]
+        ring["next"] += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()              # the copy that last used this slot (16 uploads ago) has long finished
+        if slot["buf"].numel() < total:
+            slot["buf"] = torch.empty(int(total * 1.5), dtype=torch.uint8, pin_memory=True)
+    host = slot["buf"].numpy()
+    pos, spans = 0, []
+    for a, n in zip(arrs, sizes):
+        host[pos:pos + a.nbytes] = a.view(np.uint8).reshape(-1) if a.nbytes else host[pos:pos]
+        spans.append((pos, a.nbytes, a.dtype, a.shape))
+        pos += n
+    d = torch.empty(total, dtype=torch.uint8, device=dev)
+    d.copy_(slot["buf"][:total], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    slot["ev"] = ev
+    out = []
+    for (p0, nb, dt, shape) in spans:
+        out.append(d[p0:p0 + nb].view(torch.from_numpy(np.empty(0, dtype=dt)).dtype).view(shape))
+    return out
 
 
 def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None):
@@ -450,10 +497,8 @@ def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens,
         in_d = torch.empty(buf.size + 16, dtype=torch.uint8, device=dev)
         if buf.size:
             in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
-    in_off = torch.from_numpy(in_off_h).to(dev)
-    mn = torch.as_tensor(np.asarray(min_v, dtype=np.int32)).to(dev)
-    mx = torch.as_tensor(np.asarray(max_v, dtype=np.int32)).to(dev)
-    off_d = off_h.to(dev)
+    in_off, mn, mx, off_d = _upload_small([in_off_h, np.asarray(min_v, dtype=np.int32), np.asarray(max_v, dtype=np.int32), off_h],
+                                          dev)
     dec = L.cgs_gaussian_ac_decode_lanes if lanes else L.cgs_gaussian_ac_decode
     _lib.check(dec(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
                    _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
@@ -714,7 +759,7 @@ def table_decode_lanes(blob, lens, C_, N, cdf, cdf_len, offset, medians, block):
     # (every operand is held in a local until the launch is enqueued: a temporary's block goes back to the caching allocator the
     #  moment its pointer has been read, and the next temporary's upload would land in it ahead of the kernel)
     cdf = cdf.to(torch.int32).contiguous()
-    edges, ch, in_off = edges_h.to(dev), ch_h.to(dev), torch.from_numpy(in_off_h).to(dev)
+    edges, ch, in_off = _upload_small([edges_h, ch_h, in_off_h], dev)
     cl, of, med = cdf_len.to(torch.int32).contiguous(), offset.to(torch.int32).contiguous(), medians.to(torch.float32).contiguous()
     _lib.check(L.cgs_table_ac_decode_lanes(_lib.ptr(edges), _lib.ptr(ch), S, _lib.ptr(cdf), int(cdf.shape[1]), _lib.ptr(cl),
                                            _lib.ptr(of), _lib.ptr(med), N, _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(out), C_,

@@ -67,18 +67,55 @@ def save_mlp_checkpoints(pc, path):                            # :912-936
                 "level_scale": pc.level_scale}, path)
 
 
-def load_mlp_checkpoints(pc, path, ck=None):                   # :939-950
-    """ck: the already loaded checkpoint dict (conduct_decoding reads mlp.pt on a host thread beside the header)."""
+def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
+    """ck: an already loaded checkpoint dict; tr: the driver's tracer (CGS_CODEC_TRACE)."""
+    tr = tr or (lambda label: None)
     if ck is None:
-        ck = torch.load(path, weights_only=False)
+        # restored on the HOST, then every tensor of the checkpoint goes to the device in ONE pinned non-blocking copy
+        # (restoring ~60 small tensors on the device is ~60 blocking pageable copies: 3 ms of the decoder's prologue)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        tr("mlp.pt unpickled")
+        ck = _tensors_to_device(ck, pc.x_bound_min.device)
+        tr("mlp.pt on the device")
     pc.mlp_opacity.load_state_dict(ck["opacity_mlp"])
     pc.mlp_cov.load_state_dict(ck["cov_mlp"])
     pc.mlp_color.load_state_dict(ck["color_mlp"])
     _load_latent_codec(pc.latent_codec, ck["latent_codec"])
+    tr("mlp.pt: state dicts loaded")
     pc.latent_codec.update(force=True)
+    tr("prior tables rebuilt")
     pc.mlp_grid.load_state_dict(ck["grid_mlp"])
     pc.x_bound_min, pc.x_bound_max = ck["bound"]
     pc.level_scale = ck["level_scale"]
+
+
+def _tensors_to_device(obj, dev):
+    """Nested dict / list / tuple of CPU tensors -> the same structure of device tensors, one upload for all of them."""
+    flat = []
+
+    def collect(o):
+        if isinstance(o, torch.Tensor):
+            flat.append(o)
+        elif isinstance(o, dict):
+            for v in o.values():
+                collect(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                collect(v)
+    collect(obj)
+    if not flat or dev.type != "cuda":
+        return obj
+    up = iter(codec._upload_small([t.detach().contiguous() for t in flat], dev, key="checkpoint"))
+
+    def rebuild(o):
+        if isinstance(o, torch.Tensor):
+            return next(up)
+        if isinstance(o, dict):
+            return type(o)((k, rebuild(v)) for k, v in o.items())
+        if isinstance(o, (list, tuple)):
+            return type(o)(rebuild(v) for v in o)
+        return o
+    return rebuild(obj)
 
 
 _LEGACY_EB_KEY = re.compile(r"^_?(matrix|bias|factor)(\d+)$")
@@ -267,7 +304,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
 
         feat_after_Q[orig] = feat_q                                                      # :1240-1242
         grid_scaling_after_Q[orig] = scal_q
-        already_coded[orig] = True
+        already_coded.index_fill_(0, orig, True)   # (x[idx] = True uploads its scalar through a blocking pageable copy)
         if level != 0:
             content_pre_gathered = context_rows(pc, _anchor, feat_after_Q, grid_scaling_after_Q, already_coded,
                                                 inverse_indices_list, mapping_list, level)
@@ -367,7 +404,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     path = lambda name: os.path.join(pre_path_name, name)
     # anchor.npy (12 MB at 1 M anchors) is read and converted on a host thread while this one loads the header, the MLPs and
     # the prior tables: the level plan — the first thing the device chain waits for — needs nothing else from the files
-    anchor_job = codec.host_pool().submit(lambda: np.load(path("anchor.npy")).astype(np.int32))
+    def read_anchors():
+        a = np.load(path("anchor.npy"))
+        pinned = codec._pinned_staging(a.size * 4, "anchors")[:a.size * 4].view(torch.int32).view(a.shape)
+        np.copyto(pinned.numpy(), a, casting="unsafe")
+        return pinned
+    anchor_job = codec.host_pool().submit(read_anchors)
     meta = torch.load(path("meta.b"), map_location="cpu", weights_only=False)
     tr("meta.b unpickled")
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
@@ -403,6 +445,18 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
                                             N_valid * K, float(prob_masks))
         tr("mask job submitted")
+    load_mlp_checkpoints(pc, path("mlp.pt"), tr=tr)   # (on a host thread it only moved the time: unpickling holds the GIL; it
+    tr("mlp.pt loaded, prior tables rebuilt")     #  also rebuilds the hyper prior's CDF tables)
+    # the level plan (sorts and compactions: milliseconds of device work) needs the anchors and the checkpoint's bounds only:
+    # queued now, it runs while the host goes on with the mask / hyper launches
+    q = anchor_job.result().to(dev, non_blocking=True)           # :1340-1342 (pinned: the copy is queued, not waited for)
+    interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
+    anchor_decoded = q * interval + pc.x_bound_min
+    tr("anchors on the device")
+    if pc.level_scale is None:
+        pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
+    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
+    tr("level plan built")
     side_stream = _side_stream(dev)
     masks_decoded, masks_ready = None, None
     if version == 2:
@@ -414,10 +468,6 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             masks_decoded = codec.bernoulli_decode_packed(float(prob_masks), mask_edges, blob, mask_lens).view(-1, K, 1)
             masks_ready = side_stream.record_event()
         tr("mask chunk streams: device launch enqueued")
-    load_mlp_checkpoints(pc, path("mlp.pt"))      # (on a host thread it only moved the 5 ms: unpickling holds the GIL)
-    tr("mlp.pt loaded")
-    pc.latent_codec.update(force=True)
-    tr("prior tables rebuilt")
     dev = pc.x_bound_min.device
     if version == 2:
         # version 2: lane-parallel table blocks, one device launch (EntropyBottleneck.decompress_lanes_rows)
@@ -439,15 +489,6 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         hyper_job = pc.latent_codec.decompress_chunks_rows(strings, sizes)
         tr("hyper rANS jobs submitted")
 
-    q = torch.from_numpy(anchor_job.result()).to(dev)                                    # :1340-1342
-    interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
-    anchor_decoded = q * interval + pc.x_bound_min
-
-    tr("anchors on the device")
-    if pc.level_scale is None:
-        pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
-    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
-    tr("level plan built")
     hyper_decoded = hyper_job()                                                          # [N_valid, H]
     tr("hyper latents decoded (host rANS) and on the device")
 
@@ -511,6 +552,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             feat_in = torch.cat([anchor_decoded[orig], hyper_decoded[orig].float()], dim=1)
         else:
             feat_in = torch.cat([content_pre_gathered, hyper_decoded[orig]], dim=1)
+        tr(f"level {level}: input rows assembled")
         (mean_feat, scale_feat, mean_scaling, scale_scaling, mean_offsets, scale_offsets, Qf, Qs, Qo) = \
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
@@ -555,12 +597,15 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
                 tr("offsets launch enqueued")
             main.wait_stream(side_stream)
 
+        tr(f"level {level}: offsets placed")
         feat_after_Q[orig] = feat_dec.view(n_l, D)
         grid_scaling_after_Q[orig] = scal_dec.view(n_l, 6)
+        tr(f"level {level}: decoded rows placed")
         if level != 0:
-            already_coded[orig] = True
+            already_coded.index_fill_(0, orig, True)   # (x[idx] = True uploads its scalar through a blocking pageable copy)
             content_pre_gathered = context_rows(pc, anchor_decoded, feat_after_Q, grid_scaling_after_Q, already_coded,
                                                 inverse_indices_list, mapping_list, level)
+            tr(f"level {level}: context of the next level gathered")
     if masks_decoded is None:                    # no level at all (empty model)
         masks_decoded = torch.from_numpy(mask_job.result()).to(dev).to(torch.float32).view(-1, K, 1)
     if masks_ready is not None:

@@ -122,7 +122,7 @@ def _context_index(n, already_coded, inverse_indices_list, mapping_list, i):
     dev = already_coded.device
     if i > 1:
         to_be_gathered_mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        to_be_gathered_mask[mapping_to_orign(mapping_list, i - 1)] = True
+        to_be_gathered_mask.index_fill_(0, mapping_to_orign(mapping_list, i - 1), True)    # (no blocking scalar upload)
     else:
         to_be_gathered_mask = torch.ones(n, dtype=torch.bool, device=dev)
     to_be_gathered_mask = to_be_gathered_mask & (~already_coded)
@@ -188,7 +188,7 @@ def _cached_plan(pc, anchor, mask_anchor_bool):
     ctx_idx, ctx_pos, ctx_csr = {}, {}, {}
     coded = 0
     for (i, _tc, orig, _a) in plan:
-        already[orig] = True
+        already.index_fill_(0, orig, True)
         coded += int(orig.shape[0])
         if i != 0:
             idx = _context_index(n, already, inverse_indices_list, mapping_list, i)

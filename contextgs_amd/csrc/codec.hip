@@ -935,17 +935,37 @@ extern "C" int cgs_bernoulli_ac_decode(uint32_t c1, const int64_t *stream_off, i
 // chunk streams' do.  Lane stream l of a block is byte for byte what AcEncoderT / the table coder produce for the block's
 // symbols l, l + 64, ... (tests/test_codec_gpu.py).
 #define LANES_HDR 128
+#ifndef LANES_AHEAD
+#define LANES_AHEAD 3      // steps of operand prefetch in the lane kernels
+#endif
+
+// element -> step-size index (i / q_div) of a lane that walks i, i + 64, i + 128, ...: one 64-bit division at the start, then
+// an add and a compare per step (a variable 64-bit division is ~100 instructions, and a lane step is a serial chain)
+struct LaneQIndex {
+    int64_t quot, rem, div;
+    int dq, dr;
+    __device__ void init(int64_t i, int64_t q_div) {
+        quot = i / q_div; rem = i - quot * q_div; div = q_div;
+        dq = q_div > 64 ? 0 : (int)(64 / q_div);
+        dr = q_div > 64 ? 64 : (int)(64 % q_div);
+    }
+    __device__ void step() {
+        quot += dq; rem += dr;
+        if (rem >= div) { rem -= div; ++quot; }
+    }
+};
 
 struct LaneBitSource {
     const uint8_t *p;
     uint64_t bb;      // next bits, MSB first; the top nb are valid, the rest zero
+    uint32_t ahead;   // the dword at p, fetched when the previous one was consumed: a refill never waits for its own load
     int nb;
-    __device__ void init(const uint8_t *b) { p = b; bb = 0; nb = 0; }
-    __device__ uint32_t get_bits(int n) {           // 1 <= n <= 32; may read up to 4 bytes past the lane stream (any bits do)
+    __device__ void init(const uint8_t *b) { p = b; bb = 0; nb = 0; __builtin_memcpy(&ahead, p, 4); }
+    __device__ uint32_t get_bits(int n) {           // 1 <= n <= 32; may read up to 8 bytes past the lane stream (any bits do)
         if (nb < n) {
-            uint32_t w;
-            __builtin_memcpy(&w, p, 4);
+            const uint32_t w = ahead;
             p += 4;
+            __builtin_memcpy(&ahead, p, 4);
             bb |= (uint64_t)__builtin_bswap32(w) << (32 - nb);
             nb += 32;
         }
@@ -1011,12 +1031,28 @@ __global__ void __launch_bounds__(64)
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
     bool bad = Lp > 65536;
+    float q_n[LANES_AHEAD], x_n[LANES_AHEAD], m_n[LANES_AHEAD], sc_n[LANES_AHEAD];   // operands fetched LANES_AHEAD steps ahead
+    LaneQIndex qix;
+    qix.init(b + lane, q_div);
+#pragma unroll
+    for (int a = 0; a < LANES_AHEAD; ++a) {
+        const int64_t j = b + lane + 64 * a;
+        q_n[a] = 1.f; x_n[a] = 0.f; m_n[a] = 0.f; sc_n[a] = 1.f;
+        if (j < e) { q_n[a] = Q[qix.quot]; x_n[a] = x[j]; m_n[a] = mean[j]; sc_n[a] = scale[j]; }
+        qix.step();
+    }
     for (int64_t i = b + lane; i < e && !bad; i += 64) {
-        const float q = Q[i / q_div];
-        const int sym = (int)rintf(x[i] / q) - lo;
+        const float q = q_n[0], xv = x_n[0], m = m_n[0], inv = 1.f / sc_n[0];
+#pragma unroll
+        for (int a = 0; a + 1 < LANES_AHEAD; ++a) { q_n[a] = q_n[a + 1]; x_n[a] = x_n[a + 1]; m_n[a] = m_n[a + 1]; sc_n[a] = sc_n[a + 1]; }
+        {
+            const int64_t j = i + 64 * LANES_AHEAD;
+            if (j < e) { q_n[LANES_AHEAD - 1] = Q[qix.quot]; x_n[LANES_AHEAD - 1] = x[j]; m_n[LANES_AHEAD - 1] = mean[j];
+                         sc_n[LANES_AHEAD - 1] = scale[j]; }
+            qix.step();
+        }
+        const int sym = (int)rintf(xv / q) - lo;
         if (sym < 0 || sym > max_sym) { bad = true; break; }
-        const float inv = 1.f / scale[i];
-        const float m = mean[i];
         const uint32_t c_low = gaussian_cdf_int(sym, lo, norm, m, inv, q);
         const uint32_t c_high = sym == max_sym ? AC_TOP : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q);
         enc.encode(c_low, c_high);
@@ -1082,54 +1118,108 @@ __global__ void __launch_bounds__(64)
     const int Lp = max_v[blk] - lo + 2;
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
+    const float rnorm = 1.f / norm;
+    // operands of step t + 1 are fetched before step t's search and consume: with one or two waves per SIMD nothing else
+    // hides the load latency, and a lane's steps are a serial chain
+    // (LANES_AHEAD steps: a step is ~2-4 us of serial work, an HBM miss up to ~2 us — one step ahead still left waits)
+    float q_n[LANES_AHEAD], m_n[LANES_AHEAD], sc_n[LANES_AHEAD];
+    LaneQIndex qix;
+    qix.init(b + lane, q_div);
+#pragma unroll
+    for (int a = 0; a < LANES_AHEAD; ++a) {
+        const int64_t j = b + lane + 64 * a;
+        q_n[a] = 1.f; m_n[a] = 0.f; sc_n[a] = 1.f;
+        if (j < e) { q_n[a] = Q[qix.quot]; m_n[a] = mean[j]; sc_n[a] = scale[j]; }
+        qix.step();
+    }
     for (int64_t i = b + lane; i < e; i += 64) {
-        const float q = Q[i / q_div], m = mean[i], sc = scale[i];
+        const float q = q_n[0], m = m_n[0], sc = sc_n[0];
+#pragma unroll
+        for (int a = 0; a + 1 < LANES_AHEAD; ++a) { q_n[a] = q_n[a + 1]; m_n[a] = m_n[a + 1]; sc_n[a] = sc_n[a + 1]; }
+        {
+            const int64_t j = i + 64 * LANES_AHEAD;
+            if (j < e) { q_n[LANES_AHEAD - 1] = Q[qix.quot]; m_n[LANES_AHEAD - 1] = mean[j]; sc_n[LANES_AHEAD - 1] = scale[j]; }
+            qix.step();
+        }
         const float inv = 1.f / sc;
         const uint64_t num = dec.num();
         const uint32_t sm1 = dec.span_m1();
         // guess: target ~ num / span in [0, 2^16); cdf(j) ~ Phi(z_j) * norm + j
-        const float tgt = (float)num / ((float)sm1 + 1.f);
-        float u = (tgt + 0.5f) / 65536.f;
-        u = fminf(fmaxf(u, 1e-6f), 1.f - 1e-6f);
-        const float z = SQRT2F * erfinvf(2.f * u - 1.f);
-        int guess = (int)floorf((m + z * sc) / q + 0.5f) - lo;
+        // (v_rcp_f32 reciprocals: everything up to `guess` only steers the search, no decoded value depends on its rounding)
+        const float tgt = (float)num * __builtin_amdgcn_rcpf((float)sm1 + 1.f);
+        const float rq = __builtin_amdgcn_rcpf(q);
+        // cdf(j) = round(Phi_j * norm) + j.  Left of ~-4.3 sigma the first term is 0 and the CDF is the ramp cdf(j) = j: the symbol
+        // IS the target; right of +4.3 sigma it is the ramp norm + j: the symbol is target - norm.  In between, solve
+        // Phi_j * norm + j = t for j with the inverse normal CDF (the + j term taken at the mean's index).  A wrong guess only
+        // costs gallop steps; without the ramps a symbol far outside its predicted Gaussian (sigma at the 1e-9 clamp: every
+        // symbol but one) cost ~2 log2(distance) erff evaluations and the whole wave waited for it.
+        const float jm = m * rq - (float)lo;                                  // the mean, in symbol-index units
+        const float hw = 4.3f * sc * rq;
+        int guess;
+        if (tgt <= jm - hw) guess = (int)tgt;
+        else if (tgt - norm >= jm + hw + 1.f) guess = (int)(tgt - norm);
+        else {
+            const float u = fminf(fmaxf((tgt + 0.5f - jm) * rnorm, 1e-6f), 1.f - 1e-6f);
+            const float z = SQRT2F * erfinvf(2.f * u - 1.f);
+            guess = (int)floorf(jm + z * sc * rq + 0.5f);
+        }
         guess = max(0, min(guess, max_sym));
-        // largest sym in [0, max_sym] with cdf(sym) <= target: gallop away from the guess, then bisect (a guess that is
-        // right or one off costs two or three erff; a symbol far in the tail costs O(log distance), never a linear walk)
-        int lo_j, hi_j;                     // le(lo_j) holds (or lo_j = 0), le(hi_j) fails (or hi_j = max_sym + 1)
-        uint32_t c_lo = 0, c_hi = AC_TOP;   // cdf at lo_j / hi_j where evaluated
-        bool lo_known = false;
+        // largest sym in [0, max_sym] with cdf(sym) <= target.  First a WINDOW of four consecutive candidates around the guess,
+        // evaluated unconditionally: four independent erff chains that the lane's instruction stream can overlap, no
+        // data-dependent branch — and nearly always enough (the guess is the symbol or a neighbour).  Only a target outside
+        // the window gallops away from its end and bisects (O(log distance) evaluations, never a linear walk).
+        int sym;
+        uint32_t c_low, c_high;
         {
-            const uint32_t cg = gaussian_cdf_int(guess, lo, norm, m, inv, q);
-            if (cdf_le_target(cg, sm1, num)) {
-                lo_j = guess; c_lo = cg; lo_known = true;
-                int d = 1;
-                hi_j = max_sym + 1;
-                while (lo_j + d <= max_sym) {
-                    const uint32_t cc = gaussian_cdf_int(lo_j + d, lo, norm, m, inv, q);
-                    if (cdf_le_target(cc, sm1, num)) { lo_j += d; c_lo = cc; d <<= 1; }
-                    else { hi_j = lo_j + d; c_hi = cc; break; }
-                }
-            } else {
-                hi_j = guess; c_hi = cg;
-                int d = 1;
-                lo_j = 0;
-                while (hi_j - d > 0) {
-                    const uint32_t cc = gaussian_cdf_int(hi_j - d, lo, norm, m, inv, q);
-                    if (!cdf_le_target(cc, sm1, num)) { hi_j -= d; c_hi = cc; d <<= 1; }
-                    else { lo_j = hi_j - d; c_lo = cc; lo_known = true; break; }
-                }
+            const int w0 = max(0, min(guess - 1, max_sym - 3));           // window [w0, w0 + 3] inside [0, max_sym] (or beyond, see ok)
+            uint32_t cw[4];
+            bool le[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cw[k] = gaussian_cdf_int(w0 + k, lo, norm, m, inv, q);
+                le[k] = (w0 + k <= max_sym) && cdf_le_target(cw[k], sm1, num);
             }
-            while (hi_j - lo_j > 1) {
-                const int mid = (lo_j + hi_j) >> 1;
-                const uint32_t cc = gaussian_cdf_int(mid, lo, norm, m, inv, q);
-                if (cdf_le_target(cc, sm1, num)) { lo_j = mid; c_lo = cc; lo_known = true; }
-                else { hi_j = mid; c_hi = cc; }
+            const bool inside = (le[0] || w0 == 0) && (!le[3] || w0 + 3 >= max_sym);
+            if (inside) {
+                const int k = (int)le[1] + (int)le[2] + (int)le[3];        // le is a prefix of trues: index of the last one (0 if none)
+                sym = w0 + k;
+                c_low = k == 0 ? cw[0] : (k == 1 ? cw[1] : (k == 2 ? cw[2] : cw[3]));
+                c_high = sym >= max_sym ? AC_TOP : (k == 0 ? cw[1] : (k == 1 ? cw[2] : (k == 2 ? cw[3]
+                                                                   : gaussian_cdf_int(sym + 1, lo, norm, m, inv, q))));
+            } else {
+                int lo_j, hi_j;                     // le(lo_j) holds (or lo_j = 0), le(hi_j) fails (or hi_j = max_sym + 1)
+                uint32_t c_lo = 0, c_hi = AC_TOP;
+                bool lo_known = false;
+                if (le[3]) {                        // the target lies above the window
+                    lo_j = w0 + 3; c_lo = cw[3]; lo_known = true;
+                    int d = 4;
+                    hi_j = max_sym + 1;
+                    while (lo_j + d <= max_sym) {
+                        const uint32_t cc = gaussian_cdf_int(lo_j + d, lo, norm, m, inv, q);
+                        if (cdf_le_target(cc, sm1, num)) { lo_j += d; c_lo = cc; d <<= 1; }
+                        else { hi_j = lo_j + d; c_hi = cc; break; }
+                    }
+                } else {                            // below it
+                    hi_j = w0; c_hi = cw[0];
+                    int d = 4;
+                    lo_j = 0;
+                    while (hi_j - d > 0) {
+                        const uint32_t cc = gaussian_cdf_int(hi_j - d, lo, norm, m, inv, q);
+                        if (!cdf_le_target(cc, sm1, num)) { hi_j -= d; c_hi = cc; d <<= 1; }
+                        else { lo_j = hi_j - d; c_lo = cc; lo_known = true; break; }
+                    }
+                }
+                while (hi_j - lo_j > 1) {
+                    const int mid = (lo_j + hi_j) >> 1;
+                    const uint32_t cc = gaussian_cdf_int(mid, lo, norm, m, inv, q);
+                    if (cdf_le_target(cc, sm1, num)) { lo_j = mid; c_lo = cc; lo_known = true; }
+                    else { hi_j = mid; c_hi = cc; }
+                }
+                sym = lo_j;
+                c_low = lo_known ? c_lo : gaussian_cdf_int(sym, lo, norm, m, inv, q);
+                c_high = sym >= max_sym ? AC_TOP : c_hi;
             }
         }
-        const int sym = lo_j;
-        const uint32_t c_low = lo_known ? c_lo : gaussian_cdf_int(sym, lo, norm, m, inv, q);
-        const uint32_t c_high = sym >= max_sym ? AC_TOP : c_hi;
         x_out[i] = (float)(sym + lo) * q;
         if (i + 64 < e) dec.consume(c_low, c_high);
     }
