@@ -71,12 +71,12 @@ def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
     """ck: an already loaded checkpoint dict; tr: the driver's tracer (CGS_CODEC_TRACE)."""
     tr = tr or (lambda label: None)
     if ck is None:
-        # restored on the HOST, then every tensor of the checkpoint goes to the device in ONE pinned non-blocking copy
-        # (restoring ~60 small tensors on the device is ~60 blocking pageable copies: 3 ms of the decoder's prologue)
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        ck = read_mlp_checkpoint(path)
         tr("mlp.pt unpickled")
-        ck = _tensors_to_device(ck, pc.x_bound_min.device)
-        tr("mlp.pt on the device")
+    # restored on the HOST, then every tensor of the checkpoint goes to the device in ONE pinned non-blocking copy
+    # (restoring ~70 small tensors on the device is ~70 blocking pageable copies: 3 ms of the decoder's prologue)
+    ck = _tensors_to_device(ck, pc.x_bound_min.device)
+    tr("mlp.pt on the device")
     pc.mlp_opacity.load_state_dict(ck["opacity_mlp"])
     pc.mlp_cov.load_state_dict(ck["cov_mlp"])
     pc.mlp_color.load_state_dict(ck["color_mlp"])
@@ -89,13 +89,23 @@ def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
     pc.level_scale = ck["level_scale"]
 
 
+def read_mlp_checkpoint(path):
+    """mlp.pt -> the checkpoint dict with HOST tensors.  mmap: torch.load copies every storage out of the zip otherwise
+    (~70 small tensors: 4.5 ms plain, 2.6 ms mapped); a legacy (non-zip) file cannot be mapped and loads the plain way."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=False, mmap=True)
+    except (RuntimeError, ValueError):
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def _tensors_to_device(obj, dev):
     """Nested dict / list / tuple of CPU tensors -> the same structure of device tensors, one upload for all of them."""
     flat = []
 
     def collect(o):
         if isinstance(o, torch.Tensor):
-            flat.append(o)
+            if o.device.type == "cpu":
+                flat.append(o)
         elif isinstance(o, dict):
             for v in o.values():
                 collect(v)
@@ -109,7 +119,7 @@ def _tensors_to_device(obj, dev):
 
     def rebuild(o):
         if isinstance(o, torch.Tensor):
-            return next(up)
+            return next(up) if o.device.type == "cpu" else o
         if isinstance(o, dict):
             return type(o)((k, rebuild(v)) for k, v in o.items())
         if isinstance(o, (list, tuple)):
@@ -445,18 +455,12 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         mask_job = codec.host_pool().submit(codec.bernoulli_decode_host, np.fromfile(path("masks.b"), dtype=np.uint8),
                                             N_valid * K, float(prob_masks))
         tr("mask job submitted")
-    load_mlp_checkpoints(pc, path("mlp.pt"), tr=tr)   # (on a host thread it only moved the time: unpickling holds the GIL; it
-    tr("mlp.pt loaded, prior tables rebuilt")     #  also rebuilds the hyper prior's CDF tables)
-    # the level plan (sorts and compactions: milliseconds of device work) needs the anchors and the checkpoint's bounds only:
-    # queued now, it runs while the host goes on with the mask / hyper launches
-    q = anchor_job.result().to(dev, non_blocking=True)           # :1340-1342 (pinned: the copy is queued, not waited for)
-    interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
-    anchor_decoded = q * interval + pc.x_bound_min
-    tr("anchors on the device")
-    if pc.level_scale is None:
-        pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
-    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
-    tr("level plan built")
+    # mlp.pt gates everything below (bounds -> anchors -> level plan; prior tables -> hyper launch) and unpickling it is the
+    # longest host step of the prologue (on a host thread it only moved the time: unpickling holds the GIL).  The mask launch
+    # needs the header and masks.b only — staged by the time the checkpoint is unpickled — so it is queued right after,
+    # and its ~3 ms run beside the rest of the prologue instead of in front of the first level.
+    ck = read_mlp_checkpoint(path("mlp.pt"))
+    tr("mlp.pt unpickled")
     side_stream = _side_stream(dev)
     masks_decoded, masks_ready = None, None
     if version == 2:
@@ -468,6 +472,17 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             masks_decoded = codec.bernoulli_decode_packed(float(prob_masks), mask_edges, blob, mask_lens).view(-1, K, 1)
             masks_ready = side_stream.record_event()
         tr("mask chunk streams: device launch enqueued")
+    load_mlp_checkpoints(pc, path("mlp.pt"), ck=ck, tr=tr)           # (also rebuilds the hyper prior's CDF tables)
+    # the level plan (sorts and compactions: milliseconds of device work) needs the anchors and the checkpoint's bounds only:
+    # queued now, it runs while the host goes on with the mask / hyper launches
+    q = anchor_job.result().to(dev, non_blocking=True)           # :1340-1342 (pinned: the copy is queued, not waited for)
+    interval = (pc.x_bound_max - pc.x_bound_min) * Q_anchor + 1e-6
+    anchor_decoded = q * interval + pc.x_bound_min
+    tr("anchors on the device")
+    if pc.level_scale is None:
+        pc.level_scale = find_divide_scale(pc, anchor_decoded, pc.target_ratio, pc.level_num)
+    plan, inverse_indices_list, mapping_list = level_plan(pc, anchor_decoded, None)
+    tr("level plan built")
     dev = pc.x_bound_min.device
     if version == 2:
         # version 2: lane-parallel table blocks, one device launch (EntropyBottleneck.decompress_lanes_rows)
