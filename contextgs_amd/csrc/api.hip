@@ -42,7 +42,7 @@ size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P) {
     g->offsets = c.take<uint32_t>(n);
     g->sort_a = c.take<uint32_t>(n);
     g->sort_b = c.take<uint32_t>(n);
-    g->sort_c = c.take<uint32_t>(n);
+    g->sort_c = nullptr;     // (was the iota values of the depth sort: the sort's first pass generates them since round 4)
     g->sort_d = c.take<uint32_t>(n);
     g->total = c.take<uint32_t>(2);
     size_t sb = cgs_sort_scratch_bytes((int64_t)n);
@@ -186,8 +186,8 @@ static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStre
     // depth order (stable: ties keep ascending Gaussian id)
     {
         CgsProfScope prof(CGS_PROF_DEPTH_SORT, stream);
-        if ((rc = cgs_launch_iota(P, g.sort_c, stream))) return rc;
-        if ((rc = cgs_sort_pairs_u32(g.depth_key, g.sort_c, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
+        // (values = positions: the sort's first pass generates them, no iota launch)
+        if ((rc = cgs_sort_pairs_u32(g.depth_key, nullptr, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
                                      g.scratch, g.scratch_bytes, stream)))
             return rc;
     }

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
         const int64_t idx = wbase + (int64_t)r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[idx] : 0u;
+        val[r] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;   // vals_in == nullptr: values = positions
         const uint32_t d = (key[r] >> shift) & digit_mask;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -306,6 +306,8 @@ __global__ void __launch_bounds__(SORT_THREADS)
     }
 }
 
+int cgs_launch_iota(int64_t n, uint32_t *out, hipStream_t stream);      // raster_geom.hip
+
 static int64_t sort_blocks(int64_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 
 extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
@@ -314,32 +316,16 @@ extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
     return hist + cgs_scan_scratch_bytes((int64_t)RADIX * nb) + 256;
 }
 
-extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
-                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n,
-                                  int bit_lo, int bit_hi, void *scratch, size_t scratch_bytes,
-                                  void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (n < 0 || bit_lo < 0 || bit_hi > 32 || bit_hi < bit_lo) {
-        cgs_set_error("sort: bad arguments");
-        return CGS_ERR_ARG;
-    }
-    if (n >= (1ll << 32)) { cgs_set_error("sort: n must fit in uint32"); return CGS_ERR_ARG; }
-    const int bits = bit_hi - bit_lo;
-    const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
-    if (n == 0) return CGS_OK;
-    if (passes == 0) {
-        if (keys_out != keys_in)
-            CGS_CHECK_HIP(hipMemcpyAsync(keys_out, keys_in, n * 4, hipMemcpyDeviceToDevice, stream));
-        if (vals_out != vals_in)
-            CGS_CHECK_HIP(hipMemcpyAsync(vals_out, vals_in, n * 4, hipMemcpyDeviceToDevice, stream));
-        return CGS_OK;
-    }
+// (A one-sweep variant — global digit counts of all passes from one launch, per-(block, digit) status words chained by a
+//  decoupled look-back inside the scatter kernel: 6 launches instead of 16 — was built and measured in round 4: 315 us
+//  against 262 us for this three-kernel pass structure at 5.8 M keys.  ~1000 co-resident blocks publish their counts at
+//  the same moment and every thread then walks hundreds of predecessors' words one L2 round trip at a time;
+//  profiles/r04_onesweep_sort.txt.)
+static int sort_classic(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                        uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n, int bit_lo, int bit_hi, int passes, void *scratch,
+                        size_t scratch_bytes, hipStream_t stream) {
     const int64_t nb = sort_blocks(n);
     const size_t hist_bytes = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
-    if (scratch_bytes < cgs_sort_scratch_bytes(n)) {
-        cgs_set_error("sort: scratch too small (%zu < %zu)", scratch_bytes, cgs_sort_scratch_bytes(n));
-        return CGS_ERR_WORKSPACE;
-    }
     uint32_t *hist = (uint32_t *)scratch;
     char *scan_scratch = (char *)scratch + hist_bytes;
     const size_t scan_scratch_bytes = scratch_bytes - hist_bytes;
@@ -366,6 +352,38 @@ extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_
         dst_v = (dst_v == vals_out) ? vals_tmp : vals_out;
     }
     return CGS_OK;
+}
+
+extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                                  uint32_t *vals_out, uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n,
+                                  int bit_lo, int bit_hi, void *scratch, size_t scratch_bytes,
+                                  void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || bit_lo < 0 || bit_hi > 32 || bit_hi < bit_lo) {
+        cgs_set_error("sort: bad arguments");
+        return CGS_ERR_ARG;
+    }
+    if (n >= (1ll << 32)) { cgs_set_error("sort: n must fit in uint32"); return CGS_ERR_ARG; }
+    const int bits = bit_hi - bit_lo;
+    const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+    if (n == 0) return CGS_OK;
+    if (passes == 0) {
+        if (keys_out != keys_in)
+            CGS_CHECK_HIP(hipMemcpyAsync(keys_out, keys_in, n * 4, hipMemcpyDeviceToDevice, stream));
+        if (vals_in == nullptr) {
+            int rc = cgs_launch_iota(n, vals_out, stream);
+            if (rc) return rc;
+        } else if (vals_out != vals_in) {
+            CGS_CHECK_HIP(hipMemcpyAsync(vals_out, vals_in, n * 4, hipMemcpyDeviceToDevice, stream));
+        }
+        return CGS_OK;
+    }
+    if (scratch_bytes < cgs_sort_scratch_bytes(n)) {
+        cgs_set_error("sort: scratch too small (%zu < %zu)", scratch_bytes, cgs_sort_scratch_bytes(n));
+        return CGS_ERR_WORKSPACE;
+    }
+    return sort_classic(keys_in, vals_in, keys_out, vals_out, keys_tmp, vals_tmp, n, bit_lo, bit_hi, passes, scratch,
+                        scratch_bytes, stream);
 }
 
 // ----------------------------------------------------------------------------

@@ -212,7 +212,8 @@ int cgs_scan_exclusive_u32(const uint32_t *in, uint32_t *out, int64_t n,
 /* Stable LSD radix sort of (key,value) uint32 pairs on key bits
  * [bit_lo, bit_hi).  Result lands in keys_out/vals_out; keys_tmp/vals_tmp
  * are ping-pong buffers of the same size. scratch from
- * cgs_sort_scratch_bytes(n). */
+ * cgs_sort_scratch_bytes(n).  vals_in == NULL: the values are the input
+ * positions 0..n-1 (result = the sorting permutation). */
 size_t cgs_sort_scratch_bytes(int64_t n);
 int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in,
                        uint32_t *keys_out, uint32_t *vals_out,

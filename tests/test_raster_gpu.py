@@ -173,7 +173,7 @@ def test_scan_exact(n):
 
 
 @pytest.mark.parametrize("n,lo,hi", [(1, 0, 32), (1000, 0, 32), (4096, 0, 8), (4097, 0, 13), (300_000, 0, 32),
-                                     (2_000_003, 0, 13), (70_000, 4, 20)])
+                                     (2_000_003, 0, 13), (70_000, 4, 20), (6_000_001, 0, 32), (123_457, 3, 3)])
 def test_radix_sort_stable_exact(n, lo, hi):
     from contextgs_amd import _lib
     L = _lib.lib()
@@ -191,6 +191,15 @@ def test_radix_sort_stable_exact(n, lo, hi):
     order = torch.sort(digit, stable=True).indices
     assert torch.equal(vo.to(torch.int64), order)
     assert torch.equal(ko, keys[order])
+    # vals_in == NULL: the values are the input positions (the depth sort's call), and a second sort on the same scratch
+    # (the one-sweep path clears its own status words) gives the same answer
+    for _ in range(2):
+        vo.fill_(-1)
+        _lib.check(L.cgs_sort_pairs_u32(_lib.ptr(keys), None, _lib.ptr(ko), _lib.ptr(vo), _lib.ptr(kt),
+                                        _lib.ptr(vt), n, lo, hi, _lib.ptr(scratch), scratch.numel(),
+                                        _lib.current_stream()), "sort")
+        assert torch.equal(vo.to(torch.int64), order)
+        assert torch.equal(ko, keys[order])
 
 
 def test_full_hd_properties():
