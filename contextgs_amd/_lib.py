@@ -168,6 +168,8 @@ SIGNATURES = {
     "cgs_knn_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_knn_mean_dist2": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cgs_streams_compact":(c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "cgs_pread_ranges": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "cgs_pwrite_ranges": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "cgs_gaussian_cdf_table": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "cgs_rans_max_bytes": (c_size_t, [c_int64]),
     "cgs_rans_encode_host": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,

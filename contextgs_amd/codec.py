@@ -99,20 +99,35 @@ def host_pool():
     return _POOL
 
 
-def write_file(path: str, blob, piece: int = 8 << 20):
+def write_file(path: str, blob, piece: int = 8 << 20, ready=None):
     """Write a uint8 ndarray / bytes to `path` on the pool: files above `piece` bytes are written as concurrent os.pwrite
     slices (one thread copies ~9 GB/s into the page cache; the finest level's feature file is ~80 MB at 1 M anchors and
-    sat on the encoder's tail for 10 ms).  Returns the futures to wait on."""
+    sat on the encoder's tail for 10 ms).  Returns the futures to wait on.
+    ready: a StageReady whose download `blob` may still be part of — every slice waits for its own bytes only."""
     import os
     mv = memoryview(blob).cast("B") if not isinstance(blob, (bytes, bytearray)) else memoryview(blob)
     n = len(mv)
+    arrived = (lambda lo, hi: ready.wait(blob, lo, hi)) if ready is not None and isinstance(blob, np.ndarray) else (lambda lo, hi: None)
     if n <= piece:
         def small():
+            arrived(0, n)
             with open(path, "wb") as f:
                 f.write(mv)
         return [host_pool().submit(small)]
     # nothing on the caller's thread touches the file: truncating an existing 80 MB file (the previous container in the same
-    # directory) alone takes ~10 ms.  Every slice job opens the file itself; the last job cuts it to its final length.
+    # directory) alone takes ~10 ms.  One pool job per file; the slices themselves are written by C++ workers
+    # (cgs_pwrite_ranges: no interpreter thread per slice queueing for the GIL), in batches that follow the download.
+    if isinstance(blob, np.ndarray):
+        base = blob.ctypes.data
+
+        def big():
+            for b0 in range(0, n, 4 * piece):
+                b1 = min(n, b0 + 4 * piece)
+                arrived(b0, b1)
+                file_ranges(True, [(path, lo, min(b1, lo + piece) - lo, base + lo) for lo in range(b0, b1, piece)], 8)
+            os.truncate(path, n)
+        return [host_pool().submit(big)]
+
     def part(lo):
         fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
         try:
@@ -284,6 +299,39 @@ def _pinned_staging(nbytes: int, key: str = "bitstream") -> torch.Tensor:
     return buf
 
 
+_STAGE_PIECE = 8 << 20
+_STAGE_READY = None
+
+
+class StageReady:
+    """Arrival of a staged download, piece by piece (gaussian_encode_packed(staging=True))."""
+
+    def __init__(self, base, nbytes, events, keep):
+        self.base, self.nbytes, self.events, self._keep = base, nbytes, events, keep     # keep: the device source of the copies
+
+    def wait_all(self):
+        for ev in self.events:
+            ev.synchronize()
+        self._keep = None
+
+    def wait(self, arr, lo=0, hi=None):
+        """Block until bytes [lo, hi) of `arr` — a uint8 view into the staging buffer — have landed (no-op for other arrays)."""
+        a0 = arr.__array_interface__["data"][0] if isinstance(arr, np.ndarray) else None
+        if a0 is None or not (self.base <= a0 < self.base + self.nbytes):
+            return
+        hi = arr.nbytes if hi is None else hi
+        if hi <= lo:
+            return
+        first, last = (a0 - self.base + lo) // _STAGE_PIECE, (a0 - self.base + hi - 1) // _STAGE_PIECE
+        for i in range(first, min(last, len(self.events) - 1) + 1):
+            self.events[i].synchronize()
+
+
+def stage_ready():
+    """The arrival tracker of the last staged download of this process, or None when it was waited for inline."""
+    return _STAGE_READY
+
+
 def to_host_pinned(t: torch.Tensor, key: str) -> np.ndarray:
     """Device tensor -> numpy array backed by the reused pinned buffer `key` (valid until the next call with that key):
     a pinned download runs at PCIe rate, a pageable `.cpu()` at a fifth of it and on a runtime staging thread."""
@@ -343,7 +391,7 @@ def _upload_small(arrays, dev, key=None):
     return out
 
 
-def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None):
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None, deferred=False):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
     (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
     blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
@@ -399,12 +447,27 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
         _lib.check(L.cgs_streams_compact(_lib.ptr(out), _lib.ptr(out_off), _lib.ptr(out_len), _lib.ptr(dst_off), S,
                                          _lib.ptr(packed), stream), "cgs_streams_compact")
     nbytes = int(lens.sum())
+    global _STAGE_READY
+    _STAGE_READY = None
     if staging and nbytes > 0:
         # pinned, reused staging buffer: ~25 GB/s instead of a pageable copy (~5 GB/s, 25 ms for a 1 M-anchor model).
         # The returned blob ALIASES it: valid until the next staging call (the container driver writes the files first).
+        # deferred: the download is queued in pieces with an event each and NOT waited for: write_file(..., ready=
+        # stage_ready()) lets the writer threads start on a piece the moment it has landed, so the ~5 ms of PCIe and the
+        # ~5 ms of page-cache writes of a 1 M-anchor container overlap instead of adding up.
+        mnmx_h = mnmx.cpu().numpy()                   # (before the big copies: this read drains the stream)
         stage = _pinned_staging(nbytes)
-        stage[:nbytes].copy_(packed[:nbytes], non_blocking=True)
-        mnmx_h = mnmx.cpu().numpy()                   # synchronises the stream: the staged bytes are complete too
+        events = []
+        for lo in range(0, nbytes, _STAGE_PIECE):
+            hi = min(nbytes, lo + _STAGE_PIECE)
+            stage[lo:hi].copy_(packed[lo:hi], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            events.append(ev)
+        _STAGE_READY = StageReady(stage.data_ptr(), nbytes, events, packed)
+        if not deferred:
+            _STAGE_READY.wait_all()
+            _STAGE_READY = None
         blob = stage.numpy()[:nbytes]
     else:
         blob = packed.cpu().numpy()[:nbytes]
@@ -425,7 +488,7 @@ def _expand_q(Q, q_div):
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
 
 
-def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None):
+def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None, deferred=False):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
     staging: download through the module's reused pinned buffer; the blobs then alias it until the next staging call.
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
@@ -459,7 +522,7 @@ def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None):
             return None
         blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
     else:
-        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes, overlap=overlap)
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes, overlap=overlap, deferred=deferred)
         overlap = None
     if overlap is not None:
         overlap()
@@ -525,6 +588,22 @@ def _join_device_slices(parts):
     return torch.empty(0, dtype=torch.uint8, device=first.device).set_(first.untyped_storage(), first.storage_offset(), (total,), (1,))
 
 
+def file_ranges(write: bool, ranges, threads: int = 8):
+    """ranges = [(path, file offset, byte count, host address), ...] read (write=False) or written by C++ workers
+    (cgs_pread_ranges / cgs_pwrite_ranges): one call, the GIL released for its duration."""
+    ranges = [r for r in ranges if r[2] > 0]
+    if not ranges:
+        return
+    n = len(ranges)
+    paths = (C.c_char_p * n)(*[os.fsencode(r[0]) for r in ranges])
+    foff = (C.c_int64 * n)(*[int(r[1]) for r in ranges])
+    nb = (C.c_int64 * n)(*[int(r[2]) for r in ranges])
+    mem = (C.c_void_p * n)(*[int(r[3]) for r in ranges])
+    L = _lib.lib()
+    fn = L.cgs_pwrite_ranges if write else L.cgs_pread_ranges
+    _lib.check(fn(n, paths, foff, nb, mem, int(threads)), "cgs_pwrite_ranges" if write else "cgs_pread_ranges")
+
+
 _PINNED = {}
 _LAST_STAGED = {}
 _STAGE_POOL = None
@@ -535,7 +614,7 @@ def _stage_pool():
     global _STAGE_POOL
     if _STAGE_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        _STAGE_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="cgs-stage")
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=2, thread_name_prefix="cgs-stage")
     return _STAGE_POOL
 
 
@@ -549,7 +628,9 @@ class StagedFiles:
     names are consecutive slices, so the streams of one coder launch need no concatenation.  Replaces, per file,
     np.fromfile + np.concatenate + a pageable host-to-device copy (three passes over ~120 MB at 1 M anchors)."""
 
-    def __init__(self, paths, device):
+    def __init__(self, paths, device, start=None):
+        """start: number of leading files whose reads begin at once; the others wait for release() (the decoder reads its
+        checkpoint in between, on a quiet interpreter)."""
         self.names = list(paths)
         sizes = [os.path.getsize(p_) for p_ in self.names]
         self.off = {}
@@ -582,44 +663,57 @@ class StagedFiles:
         pinned = _PINNED.get(key)
         if pinned is None or pinned.numel() < self.total + 64:
             pinned = _PINNED[key] = torch.empty(max(int(self.total * 1.25) + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        self._pinned, self._view = pinned, pinned.numpy()
-        # Pieces of <= 8 MB, read by a few dedicated threads (one thread copies ~8 GB/s out of the page cache: the 120 MB of a
-        # 1 M-anchor container took ~20 ms and was the decoder's critical chain), in the order the coder launches consume the
-        # files; each piece's host-to-device copy is enqueued by the thread that read it, the thread that completes a file
-        # records the file's event.
-        self._lock = threading.Lock()
-        self._left, self._jobs = {}, []
-        piece = 8 << 20
-        for p_ in self.names:
-            pos, n = self.off[p_]
-            parts = [(lo, min(n, lo + piece)) for lo in range(0, n, piece)] or [(0, 0)]
-            self._left[p_] = len(parts)
-            for (lo, hi) in parts:
-                self._jobs.append(_stage_pool().submit(self._piece, p_, pos, lo, hi))
+        self._pinned = pinned
+        # ONE interpreter thread drives the staging; the reads themselves are plain C++ workers inside cgs_pread_ranges
+        # (csrc/file_io.cpp: 8 MB ranges, eight workers — one thread copies ~8 GB/s out of the page cache and the 120 MB of
+        # a 1 M-anchor container were the decoder's longest chain).  Eight interpreter threads calling os.preadv did the
+        # same reads, but each finished piece made its thread queue for the GIL and the decoder's prologue on the main
+        # thread ran 3-10 x slower beside them.  Files are staged in the order the coder launches consume them, in batches
+        # of <= 32 MB, each followed by its host-to-device copy; a file's event is recorded once its last byte is queued.
+        self._released = threading.Event()
+        self._start = len(self.names) if start is None else max(0, int(start))
+        if self._start >= len(self.names):
+            self._released.set()
+        self._job = _stage_pool().submit(self._run)
 
-    def _piece(self, p_, pos, lo, hi):
+    def release(self):
+        """Start the reads held back by `start`."""
+        self._released.set()
+
+    def _run(self):
         try:
-            if hi > lo:
-                fd = os.open(p_, os.O_RDONLY)
-                try:
-                    at = lo
-                    while at < hi:
-                        got = os.preadv(fd, [memoryview(self._view[pos + at:pos + hi])], at)
-                        assert got > 0, (p_, at, hi)
-                        at += got
-                finally:
-                    os.close(fd)
-            with torch.cuda.stream(self.stream):
-                if hi > lo:
-                    self.dev_buf[pos + lo:pos + hi].copy_(self._pinned[pos + lo:pos + hi], non_blocking=True)
-                with self._lock:
-                    self._left[p_] -= 1
-                    last = self._left[p_] == 0
-                if last:
+            piece, batch_bytes = 8 << 20, 32 << 20
+            base = self._pinned.data_ptr()
+            i = 0
+            while i < len(self.names):
+                if i >= self._start:
+                    self._released.wait()
+                # a batch: whole files from i on, up to batch_bytes (one file alone may exceed it: it is then split)
+                stop = len(self.names) if self._released.is_set() else self._start
+                j, size = i, 0
+                while j < stop and (j == i or size + self.off[self.names[j]][1] <= batch_bytes):
+                    size += self.off[self.names[j]][1]
+                    j += 1
+                lo0 = self.off[self.names[i]][0]
+                for b0 in range(0, max(size, 1), batch_bytes):
+                    b1 = min(size, b0 + batch_bytes)
+                    ranges = []
+                    for p_ in self.names[i:j]:
+                        pos, n = self.off[p_]
+                        f0, f1 = max(pos, lo0 + b0), min(pos + n, lo0 + b1)      # this file's part of [b0, b1)
+                        for q in range(f0, f1, piece):
+                            ranges.append((p_, q - pos, min(f1, q + piece) - q, base + q))
+                    file_ranges(False, ranges, 8)
+                    if b1 > b0:
+                        with torch.cuda.stream(self.stream):
+                            self.dev_buf[lo0 + b0:lo0 + b1].copy_(self._pinned[lo0 + b0:lo0 + b1], non_blocking=True)
+                with torch.cuda.stream(self.stream):
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
+                for p_ in self.names[i:j]:
                     self.events[p_] = ev
                     self.ready[p_].set()
+                i = j
         except BaseException as e:    # wake the waiters, get() re-raises
             self.error = e
             for r in self.ready.values():
@@ -629,15 +723,17 @@ class StagedFiles:
 
     def wait_all(self):
         """Host-side: every copy has finished (the pinned buffer is reused by the next container)."""
-        for j in self._jobs:
-            try:
-                j.result()
-            except BaseException:
-                pass
+        self.release()
+        try:
+            self._job.result()
+        except BaseException:
+            pass
         for ev in list(self.events.values()):
             ev.synchronize()
 
     def get(self, name):
+        if not self.ready[name].is_set() and self.names.index(name) >= self._start:
+            self.release()
         self.ready[name].wait()
         if self.error is not None:
             raise self.error

@@ -89,9 +89,101 @@ def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
     pc.level_scale = ck["level_scale"]
 
 
+_STORAGE_DTYPES = {"FloatStorage": torch.float32, "DoubleStorage": torch.float64, "HalfStorage": torch.float16,
+                   "BFloat16Storage": torch.bfloat16, "LongStorage": torch.int64, "IntStorage": torch.int32,
+                   "ShortStorage": torch.int16, "CharStorage": torch.int8, "ByteStorage": torch.uint8, "BoolStorage": torch.bool}
+
+
+class _StorageRef:
+    __slots__ = ("dtype", "key", "numel")
+
+    def __init__(self, dtype, key, numel):
+        self.dtype, self.key, self.numel = dtype, key, numel
+
+
+def _zip_members(buf):
+    """{name: (data offset, size)} of an uncompressed, non-zip64 archive held in `buf` — the layout torch.save writes.
+    (zipfile.ZipFile takes 1.2 ms for the 80 members of mlp.pt; this is two struct reads per member.)"""
+    import struct
+    eocd = buf.rfind(b"PK\x05\x06")
+    if eocd < 0:
+        raise ValueError("no end-of-central-directory record")
+    n_ent, cd_size, cd_off = struct.unpack_from("<HII", buf, eocd + 10)
+    if n_ent == 0xFFFF or cd_size == 0xFFFFFFFF or cd_off == 0xFFFFFFFF:
+        raise ValueError("zip64 archive")
+    out, p = {}, cd_off
+    for _ in range(n_ent):
+        if buf[p:p + 4] != b"PK\x01\x02":
+            raise ValueError("bad central directory")
+        method, = struct.unpack_from("<H", buf, p + 10)
+        csize, usize, nlen, elen, clen = struct.unpack_from("<IIHHH", buf, p + 20)
+        hoff, = struct.unpack_from("<I", buf, p + 42)
+        name = bytes(buf[p + 46:p + 46 + nlen]).decode("utf-8")
+        if method != 0 or csize != usize or 0xFFFFFFFF in (csize, hoff):
+            raise ValueError("compressed or zip64 member")
+        lnlen, lelen = struct.unpack_from("<HH", buf, hoff + 26)          # the LOCAL header's own name / extra lengths
+        out[name] = (hoff + 30 + lnlen + lelen, usize)
+        p += 46 + nlen + elen + clen
+    return out
+
+
+def _fast_checkpoint_load(path):
+    """torch.load(path, map_location="cpu") for the files THIS container holds (mlp.pt, meta.b: nested dicts / lists of
+    tensors, numpy arrays and Python numbers), without torch's per-tensor Python path (~60 us a tensor: 4.6 ms of the
+    decoder's 23 for mlp.pt's 74): the archive is mapped once, tensors are views into the mapping.  Only the globals such a
+    file needs are resolved; anything else raises and the caller falls back to torch.load."""
+    import collections
+    import io
+    import pickle
+    import mmap
+    with open(path, "rb") as f:
+        buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)       # private pages: the tensors below keep it alive
+    members = _zip_members(buf)
+    pkl = [n for n in members if n.endswith("/data.pkl")]
+    if len(pkl) != 1:
+        raise ValueError("not a torch.save archive")
+    root = pkl[0][:-len("data.pkl")]
+
+    def rebuild(st, storage_offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
+        off, nbytes = members[root + "data/" + st.key]
+        if st.numel * torch.empty(0, dtype=st.dtype).element_size() > nbytes:
+            raise ValueError("storage shorter than its tensor")
+        if st.numel == 0:
+            return torch.empty(tuple(size), dtype=st.dtype)
+        return torch.frombuffer(buf, dtype=st.dtype, count=st.numel, offset=off).as_strided(tuple(size), tuple(stride),
+                                                                                           storage_offset)
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "torch._utils" and name == "_rebuild_tensor_v2":
+                return rebuild
+            if module == "torch._utils" and name == "_rebuild_parameter":
+                return lambda data, requires_grad, backward_hooks: data
+            if module == "torch" and name in _STORAGE_DTYPES:
+                return _STORAGE_DTYPES[name]
+            if module == "collections" and name == "OrderedDict":
+                return collections.OrderedDict
+            if module.split(".")[0] == "numpy" or (module, name) == ("_codecs", "encode") or (
+                    module in ("builtins", "__builtin__") and name in ("bytes", "bytearray", "complex", "set", "frozenset")):
+                return super().find_class(module, name)                     # numpy arrays (protocol 2) and plain containers
+            raise pickle.UnpicklingError(f"global {module}.{name} is not one this loader resolves")
+
+        def persistent_load(self, pid):
+            if not (isinstance(pid, tuple) and len(pid) >= 5 and pid[0] == "storage" and isinstance(pid[1], torch.dtype)):
+                raise pickle.UnpicklingError("unexpected persistent id")
+            return _StorageRef(pid[1], str(pid[2]), int(pid[4]))
+
+    off, nbytes = members[pkl[0]]
+    return Unpickler(io.BytesIO(bytes(buf[off:off + nbytes]))).load()
+
+
 def read_mlp_checkpoint(path):
-    """mlp.pt -> the checkpoint dict with HOST tensors.  mmap: torch.load copies every storage out of the zip otherwise
-    (~70 small tensors: 4.5 ms plain, 2.6 ms mapped); a legacy (non-zip) file cannot be mapped and loads the plain way."""
+    """mlp.pt -> the checkpoint dict with HOST tensors: _fast_checkpoint_load, else torch.load (mapped: it copies every
+    storage out of the zip otherwise; a legacy non-zip file cannot be mapped and loads the plain way)."""
+    try:
+        return _fast_checkpoint_load(path)
+    except Exception:
+        pass
     try:
         return torch.load(path, map_location="cpu", weights_only=False, mmap=True)
     except (RuntimeError, ValueError):
@@ -337,17 +429,18 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         if root:
             with torch.cuda.stream(_side_stream(_mask.device, "mlp")):
                 save_mlp_checkpoints(pc, path("mlp.pt"))
-    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes, overlap=write_mlp)   # blobs alias a pinned buffer
-    torch.cuda.synchronize(); t_codec = time.time() - t0
-    tr("coder launch done, bitstream on the host")
+    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes, overlap=write_mlp, deferred=True)   # blobs alias a pinned buffer
+    ready = codec.stage_ready()          # the download is still in flight: the file writers below wait piece by piece
+    tr("coder launch done, download queued")
     if not root:
+        torch.cuda.synchronize()
         return mgpu.broadcast_object(None)            # the summary string of rank 0
 
     bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
     min_d = {"feat": {}, "scaling": {}, "offsets": {}}
     max_d = {"feat": {}, "scaling": {}, "offsets": {}}
     for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
-        writes += codec.write_file(path(f"{name}{level}.b"), blob)                        # :1235-1238
+        writes += codec.write_file(path(f"{name}{level}.b"), blob, ready=ready)           # :1235-1238
         if version == 2:      # arrays: thousands of blocks as Python ints cost the decoder's unpickling a garbage-collector pass
             bit_d[name][level], min_d[name][level], max_d[name][level] = lens * 8, mn.astype(np.int32), mx.astype(np.int32)
         else:
@@ -356,6 +449,8 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
             max_d[name][level] = mx.astype(np.int64).tolist()
 
     tr("file writes submitted")
+    torch.cuda.synchronize(); t_codec = time.time() - t0
+    tr("bitstream on the host")
     if hyper_v2 is not None:
         bit_hyper_list = hyper_v2[1] * 8
         writes += codec.write_file(path("hyper.b"), hyper_v2[0])
@@ -420,7 +515,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         np.copyto(pinned.numpy(), a, casting="unsafe")
         return pinned
     anchor_job = codec.host_pool().submit(read_anchors)
-    meta = torch.load(path("meta.b"), map_location="cpu", weights_only=False)
+    meta = read_mlp_checkpoint(path("meta.b"))        # (the same loader: nested lists / dicts of numbers, arrays, tensors)
     tr("meta.b unpickled")
     (N_full, max_batch, min_feat_d, max_feat_d, min_scaling_d, max_scaling_d, min_offsets_d, max_offsets_d, prob_masks,
      bit_hyper_list, bit_feat_d, bit_scaling_d, bit_offsets_d, N_levels_list) = meta[:14]
@@ -437,8 +532,10 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     else:
         order = [f"{a}{l}.b" for l in reversed(range(n_lv)) for a in ("feat", "scaling")] + \
                 [f"offsets{l}.b" for l in reversed(range(n_lv))]
-    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev)
-    tr("file staging submitted")
+    # (only masks.b starts now: the checkpoint is read first, on a quiet interpreter — beside eight reader threads that read
+    #  took 4-8 ms instead of 0.3; the other files are released right after it and are still early for the first level)
+    staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev, start=1 if version == 2 else 0)
+    tr("file staging prepared")
     chunk = extra["chunk"] if version == 2 else {"masks": max_batch}
     lanes = version == 2
     block = int(extra.get("block_symbols", V2_BLOCK))
@@ -461,6 +558,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # and its ~3 ms run beside the rest of the prologue instead of in front of the first level.
     ck = read_mlp_checkpoint(path("mlp.pt"))
     tr("mlp.pt unpickled")
+    staged.release()
     side_stream = _side_stream(dev)
     masks_decoded, masks_ready = None, None
     if version == 2:

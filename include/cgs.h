@@ -607,6 +607,17 @@ int cgs_gaussian_ac_decode(const float *mean, const float *scale,
 int cgs_streams_compact(const uint8_t *src, const int64_t *src_off,
                         const uint32_t *len, const int64_t *dst_off,
                         int n_streams, uint8_t *dst, void *stream);
+/* Host file I/O of the container (the .b files conduct_encoding writes with
+ * open(...).write(b"".join(...)) and conduct_decoding reads back,
+ * scene/gaussian_model.py:1235-1238, 1455-1481): range i = nbytes[i] bytes at
+ * file_off[i] of paths[i] <-> memory dst[i] / src[i], moved by `threads` plain
+ * C++ workers (no interpreter thread per piece: see csrc/file_io.cpp).  Host
+ * pointers (pinned or pageable).  pwrite creates missing files and never
+ * truncates.  Blocking; no stream. */
+int cgs_pread_ranges(int n, const char *const *paths, const int64_t *file_off,
+                     const int64_t *nbytes, void *const *dst, int threads);
+int cgs_pwrite_ranges(int n, const char *const *paths, const int64_t *file_off,
+                      const int64_t *nbytes, const void *const *src, int threads);
 /* Container version 2, Gaussian-coded attributes: the same symbol sequence and
  * the same coder as cgs_gaussian_ac_encode, cut into BLOCKS (blk_off, element
  * offsets as stream_off above) that one wave codes as 64 INTERLEAVED lane
