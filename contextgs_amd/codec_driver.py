@@ -67,8 +67,12 @@ def save_mlp_checkpoints(pc, path):                            # :912-936
                 "level_scale": pc.level_scale}, path)
 
 
-def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
-    """ck: an already loaded checkpoint dict; tr: the driver's tracer (CGS_CODEC_TRACE)."""
+def load_mlp_checkpoints(pc, path, ck=None, tr=None, stored_tables=False):          # :939-950
+    """ck: an already loaded checkpoint dict; tr: the driver's tracer (CGS_CODEC_TRACE).
+    stored_tables (container version 2): take the hyper prior's integer CDF tables the ENCODER used from the checkpoint
+    (`_quantized_cdf` / `_cdf_length` / `_offset`: buffers of the state dict torch.save wrote) instead of rebuilding them with
+    update(force=True) as the reference does (:946-947) — the decoder then codes with exactly the encoder's tables whatever
+    device evaluated the density, and skips ~2 ms of its prologue.  A checkpoint without them falls back to update()."""
     tr = tr or (lambda label: None)
     if ck is None:
         ck = read_mlp_checkpoint(path)
@@ -82,8 +86,16 @@ def load_mlp_checkpoints(pc, path, ck=None, tr=None):          # :939-950
     pc.mlp_color.load_state_dict(ck["color_mlp"])
     _load_latent_codec(pc.latent_codec, ck["latent_codec"])
     tr("mlp.pt: state dicts loaded")
-    pc.latent_codec.update(force=True)
-    tr("prior tables rebuilt")
+    lc, eb = ck["latent_codec"], pc.latent_codec
+    tabs = [lc.get(k) for k in ("_quantized_cdf", "_cdf_length", "_offset")] if stored_tables else [None]
+    if all(isinstance(t, torch.Tensor) and t.numel() > 0 for t in tabs) and tabs[0].dim() == 2 \
+            and tabs[0].shape[0] == tabs[1].numel() == tabs[2].numel() == eb.channels:
+        dev = eb.quantiles.device
+        eb._quantized_cdf, eb._cdf_length, eb._offset = (t.to(device=dev, dtype=torch.int32) for t in tabs)
+        tr("prior tables taken from the checkpoint")
+    else:
+        eb.update(force=True)
+        tr("prior tables rebuilt")
     pc.mlp_grid.load_state_dict(ck["grid_mlp"])
     pc.x_bound_min, pc.x_bound_max = ck["bound"]
     pc.level_scale = ck["level_scale"]
@@ -570,7 +582,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             masks_decoded = codec.bernoulli_decode_packed(float(prob_masks), mask_edges, blob, mask_lens).view(-1, K, 1)
             masks_ready = side_stream.record_event()
         tr("mask chunk streams: device launch enqueued")
-    load_mlp_checkpoints(pc, path("mlp.pt"), ck=ck, tr=tr)           # (also rebuilds the hyper prior's CDF tables)
+    load_mlp_checkpoints(pc, path("mlp.pt"), ck=ck, tr=tr, stored_tables=version == 2)     # (incl. the hyper prior's CDF tables)
     # the level plan (sorts and compactions: milliseconds of device work) needs the anchors and the checkpoint's bounds only:
     # queued now, it runs while the host goes on with the mask / hyper launches
     q = anchor_job.result().to(dev, non_blocking=True)           # :1340-1342 (pinned: the copy is queued, not waited for)
