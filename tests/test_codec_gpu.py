@@ -358,3 +358,52 @@ def test_grouped_launch_is_byte_identical_to_per_group_launches():
         dec_groups.append((g[1], g[2], g[3], g[4], mn2, mx2, blob, lens, g[5]))
     for g, out in zip(groups, codec.gaussian_decode_groups(dec_groups)):
         assert torch.equal(out, g[0])
+
+
+def test_staged_files_hold_release_and_deferred_download(tmp_path):
+    """The container's file plumbing: StagedFiles (files -> pinned -> device through cgs_pread_ranges, the files behind
+    `start` held until release() / the first get()) and the encoder's deferred download (pieces picked up by write_file as
+    they land, through cgs_pwrite_ranges)."""
+    from contextgs_amd import codec
+    rng = np.random.default_rng(11)
+    sizes = [1000, 0, (40 << 20) + 13, 70_000]                 # an empty file, one larger than a 32 MB batch
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    paths = []
+    for k, b in enumerate(blobs):
+        p = str(tmp_path / f"f{k}.b")
+        b.tofile(p)
+        paths.append(p)
+    dev = torch.device("cuda")
+    for start in (None, 1, 0):
+        st = codec.StagedFiles(paths, dev, start=start)
+        if start == 1:
+            assert torch.equal(st.get(paths[0]).cpu(), torch.from_numpy(blobs[0]))          # staged before the release
+            assert not st.ready[paths[2]].is_set()
+        for p, b in zip(reversed(paths), reversed(blobs)):                                   # get() of a held file releases
+            got = st.get(p)
+            torch.cuda.synchronize()
+            assert got.numel() == b.size and torch.equal(got.cpu(), torch.from_numpy(b))
+        st.wait_all()
+    os.remove(paths[3])
+    with pytest.raises(OSError):
+        codec.StagedFiles(paths, dev)             # sizes are read at construction: a vanished file fails there
+    # deferred download -> files
+    n = 3_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mean = torch.randn(n, device="cuda", generator=g)
+    scale = torch.rand(n, device="cuda", generator=g) * 2 + 0.05
+    Q = torch.ones(n, device="cuda")
+    x = torch.round(mean + scale * torch.randn(n, device="cuda", generator=g))
+    edges = torch.arange(0, n + 1, 32768).tolist()
+    if edges[-1] != n:
+        edges.append(n)
+    ref = codec.gaussian_encode_packed(x, mean, scale, Q, torch.tensor(edges), lanes=True)
+    blob, lens, mn, mx = codec.gaussian_encode_packed(x, mean, scale, Q, torch.tensor(edges), staging=True, lanes=True, deferred=True)
+    ready = codec.stage_ready()
+    assert ready is not None
+    out = str(tmp_path / "coded.b")
+    for j in codec.write_file(out, blob, piece=1 << 20, ready=ready):
+        j.result()
+    assert np.array_equal(np.fromfile(out, dtype=np.uint8), ref[0]) and np.array_equal(lens, ref[1])
+    ready.wait_all()
+    assert np.array_equal(blob, ref[0])
