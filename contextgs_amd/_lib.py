@@ -107,6 +107,8 @@ SIGNATURES = {
     "cgs_gather_rows_segmented": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_scatter_rows_sorted": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "cgs_mark_rows": (c_int, [c_void_p, c_int64, c_int64, C.c_uint32, c_void_p, c_void_p]),
+    "cgs_zero_unmarked_rows": (c_int, [c_void_p, C.c_uint32, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_rowcat_fwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_rowcat_bwd_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p]),

@@ -437,6 +437,59 @@ extern "C" int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, in
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Rows NOT in a list get zeros.  A backward that writes only the rows a view touched (rows idx[0..n) of an [n_full, w]
+// gradient buffer, distinct) used to start from torch.zeros: a full-buffer fill (144 MB + 200 MB per training view at 1 M
+// anchors for the 99.5 % of rows that are overwritten right after).  Instead: every listed row gets the call's generation
+// number in a persistent uint32 stamp array (cgs_mark_rows; no clearing between calls: generations only grow, the caller
+// restarts at a zeroed array after 2^32 - 1), and cgs_zero_unmarked_rows writes zeros to the rows whose stamp is older.
+__global__ void __launch_bounds__(256)
+    mark_rows_kernel(const int64_t *__restrict__ idx, int64_t n, uint32_t gen, uint32_t *__restrict__ stamp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stamp[idx[i]] = gen;
+}
+
+struct ZeroRowsArgs { float *dst[4]; int w[4]; int narr; };
+
+__global__ void __launch_bounds__(256)
+    zero_unmarked_rows_kernel(const uint32_t *__restrict__ stamp, uint32_t gen, int64_t n_full, ZeroRowsArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_full; r += (int64_t)gridDim.x * 256) {
+        if (stamp[r] == gen) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < a.narr) {
+                float *q = a.dst[k] + r * a.w[k];
+                for (int c = 0; c < a.w[k]; ++c) q[c] = 0.f;
+            }
+    }
+}
+
+extern "C" int cgs_mark_rows(const int64_t *idx, int64_t n, int64_t n_full, uint32_t gen, uint32_t *stamp, void *stream) {
+    if (n < 0 || n_full < 0 || gen == 0) { cgs_set_error("mark_rows: bad args (gen must be > 0)"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (!idx || !stamp) { cgs_set_error("mark_rows: NULL"); return CGS_ERR_ARG; }
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(stream_grid(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, idx, n, gen, stamp);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_zero_unmarked_rows(const uint32_t *stamp, uint32_t gen, int64_t n_full, int narr, float *const *dst,
+                                      const int *width, void *stream) {
+    if (n_full < 0 || narr < 1 || narr > 4 || !dst || !width) { cgs_set_error("zero_unmarked_rows: bad args (1..4 arrays)"); return CGS_ERR_ARG; }
+    if (n_full == 0) return CGS_OK;
+    if (!stamp) { cgs_set_error("zero_unmarked_rows: NULL"); return CGS_ERR_ARG; }
+    ZeroRowsArgs a;
+    a.narr = narr;
+    for (int k = 0; k < 4; ++k) {
+        a.dst[k] = k < narr ? dst[k] : nullptr;
+        a.w[k] = k < narr ? width[k] : 0;
+        if (k < narr && (!dst[k] || width[k] < 1)) { cgs_set_error("zero_unmarked_rows: array %d", k); return CGS_ERR_ARG; }
+    }
+    hipLaunchKernelGGL(zero_unmarked_rows_kernel, dim3(stream_grid(n_full, 256 * 4)), dim3(256), 0, (hipStream_t)stream, stamp, gen,
+                       n_full, a);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Counter-based noise: u(seed, tensor, element) in [-0.5, 0.5), regenerated (not stored) by the backward.
 // 32-bit arithmetic on purpose (two v_mul_lo_u32 per value): the first version was splitmix64, whose three 64-bit
 // multiplications (twelve quarter-rate 32-bit multiplies) made the noise kernels compute-bound at ~1.9 TB/s.

@@ -464,8 +464,12 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else (
             t.contiguous() if t.dtype == torch.float32 else t.float().contiguous())
         g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
-        # rows of the source no visible anchor reads keep a zero gradient; when every row is read: no fill
-        d_src = (torch.empty if n == ctx.n_src else torch.zeros)(ctx.n_src, 50, dtype=torch.float32, device=dev)
+        # rows of the source no visible anchor reads keep a zero gradient (ctx_ops.zero_unlisted_rows writes only those rows —
+        # a 200 MB fill at 1 M anchors otherwise); when every row is read there is nothing to zero
+        d_src = torch.empty(ctx.n_src, 50, dtype=torch.float32, device=dev)
+        if n != ctx.n_src:
+            from .ctx_ops import zero_unlisted_rows
+            zero_unlisted_rows(src_row, ctx.n_src, [d_src])
         d_anchor = torch.empty(n, 3, dtype=torch.float32, device=dev)
         _hld, _xld, gld, hp = _m3_layout()
         dz1 = torch.empty(n, gld, dtype=torch.float32, device=dev)

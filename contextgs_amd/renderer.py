@@ -168,11 +168,13 @@ class _ExpandGaussians(torch.autograd.Function):
         d_op, d_mask = e(op_raw), e(masks)
         if src_row is None:
             d_gs, d_off = e(gscaling), e(offsets)
-        else:       # rows of the larger arrays that no visible anchor reads get a zero gradient (one fill for both);
-            # when every anchor is visible (src_row is a permutation of all rows) every row is written: no fill
-            alloc = torch.empty if n == gscaling.shape[0] else torch.zeros
-            flat = alloc(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
+        else:       # rows of the larger arrays that no visible anchor reads get a zero gradient (zero_unlisted_rows: only those
+            # rows are written); when every anchor is visible (src_row names every row) there is nothing to zero
+            flat = torch.empty(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
             d_gs, d_off = flat[:gscaling.numel()].view_as(gscaling), flat[gscaling.numel():].view_as(offsets)
+            if n != gscaling.shape[0]:
+                from .ctx_ops import zero_unlisted_rows
+                zero_unlisted_rows(src_row, gscaling.shape[0], [d_gs, d_off])
         d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
         d_cov = e(cov_in)
         _lib.check(L.cgs_expand_backward(
@@ -271,10 +273,13 @@ class _ExpandRasterize(torch.autograd.Function):
         d_op, d_mask = e(op_raw), e(masks)
         if src_row is None:
             d_gs, d_off = e(gscaling), e(offsets)
-        else:       # rows of the larger arrays that no visible anchor reads get zeros; every row written -> no fill
-            alloc = torch.empty if n == gscaling.shape[0] else torch.zeros
-            flat = alloc(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
+        else:       # rows of the larger arrays that no visible anchor reads get zeros (ctx_ops.zero_unlisted_rows: only
+            #             THOSE rows are written, not a 144 MB fill); every row read -> nothing to zero
+            flat = torch.empty(gscaling.numel() + offsets.numel(), dtype=torch.float32, device=dev)
             d_gs, d_off = flat[:gscaling.numel()].view_as(gscaling), flat[gscaling.numel():].view_as(offsets)
+            if n != gscaling.shape[0]:
+                from .ctx_ops import zero_unlisted_rows
+                zero_unlisted_rows(src_row, gscaling.shape[0], [d_gs, d_off])
         d_color = torch.empty(n, 3 * K, dtype=torch.float32, device=dev)
         d_cov = e(cov_in)
         _lib.check(L.cgs_expand_backward(

@@ -353,6 +353,19 @@ int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64
  * the forward of the same gathers (x[visible rows], gaussian_renderer/__init__.py:44-50). */
 int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, int w,
                     float *out, void *stream);
+/* Zeros for the rows a row list does NOT name.  The backward of a view writes
+ * only the rows idx[0..n) (distinct) of an [n_full, w] gradient buffer
+ * (gaussian_renderer/__init__.py:73-81: `[visible_mask]` indexing; autograd
+ * zero-fills the rest): cgs_mark_rows stamps the listed rows with the call's
+ * generation number `gen` (> 0, strictly increasing per stamp array; the
+ * array starts zeroed and is never cleared), cgs_zero_unmarked_rows writes
+ * zeros to every row of up to four arrays dst[k] [n_full, width[k]] whose
+ * stamp differs from `gen`.  Replaces a full-buffer fill. */
+int cgs_mark_rows(const int64_t *idx, int64_t n, int64_t n_full, uint32_t gen,
+                  uint32_t *stamp, void *stream);
+int cgs_zero_unmarked_rows(const uint32_t *stamp, uint32_t gen, int64_t n_full,
+                           int narr, float *const *dst, const int *width,
+                           void *stream);
 /* Atomics-free backward of a context assembly whose first three sources are gathered parent rows
  * (anchor position [N,wa] by original row, coded features [n_parents,DF] and scaling [n_parents,DS]
  * by position in the coded prefix): the children of parent p are order[offs[p] .. offs[p+1])

@@ -383,3 +383,33 @@ def test_gather_unique_forward_is_index_select(shape):
         (gx,) = torch.autograd.grad(y, x, g)
         ref = torch.zeros_like(x).index_copy_(0, idx, g)
         assert torch.equal(gx, ref)
+
+
+def test_zero_unlisted_rows_equals_a_zero_fill():
+    """ctx_ops.zero_unlisted_rows (cgs_mark_rows + cgs_zero_unmarked_rows): after it and a write of the listed rows, the
+    buffers equal zeros().index_copy_(listed rows) — for a dense list, a sparse one, an empty one, repeated calls on the
+    same stamp array, five arrays (two launches) and a reused index tensor."""
+    from contextgs_amd import ctx_ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    n_full = 100_003
+    for n in (n_full - 517, 1000, 0, n_full - 1):
+        idx = torch.randperm(n_full, device="cuda", generator=g)[:n].contiguous()
+        widths = [(6,), (10, 3), (50,), (1,), (3,)]
+        vals = [torch.randn((n,) + w, device="cuda", generator=g) for w in widths]
+        for rep in range(2):                                   # the second pass reuses the marks of the same index tensor
+            bufs = [torch.full((n_full,) + w, float("nan"), device="cuda") for w in widths]
+            ctx_ops.zero_unlisted_rows(idx, n_full, bufs)
+            for b, v, w in zip(bufs, vals, widths):
+                b[idx] = v
+                ref = torch.zeros((n_full,) + w, device="cuda")
+                ref[idx] = v
+                assert torch.equal(b, ref)
+    # an index tensor modified in place is marked again
+    idx = torch.arange(10, device="cuda")
+    buf = torch.full((20, 2), float("nan"), device="cuda")
+    ctx_ops.zero_unlisted_rows(idx, 20, [buf])
+    assert torch.isnan(buf[:10]).all() and (buf[10:] == 0).all()
+    idx += 10
+    buf = torch.full((20, 2), float("nan"), device="cuda")
+    ctx_ops.zero_unlisted_rows(idx, 20, [buf])
+    assert torch.isnan(buf[10:]).all() and (buf[:10] == 0).all()
