@@ -112,6 +112,8 @@ def zero_unlisted_rows(idx, n_full, arrays):
     key = (str(dev), int(n_full))
     st = _ROW_STAMPS.get(key)
     if st is None or st[1] >= 0xFFFFFFF0:
+        if st is None and len(_ROW_STAMPS) >= 8:       # anchor counts change with densification: keep the newest few arrays
+            _ROW_STAMPS.pop(next(iter(_ROW_STAMPS)))
         st = _ROW_STAMPS[key] = [torch.zeros(max(int(n_full), 1), dtype=torch.int32, device=dev), 0, None, -1]
     stream = _lib.current_stream()
     last = st[2]() if st[2] is not None else None

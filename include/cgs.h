@@ -41,6 +41,12 @@
  *   cgs_bernoulli_ac_*         encoder / decoder of the offset masks
  *                              (utils/encodings.py:147-180) as chunk streams
  *                              on the device (container version 2)
+ *   cgs_pread_ranges,
+ *   cgs_pwrite_ranges          the container's file reads / writes
+ *                              (scene/gaussian_model.py:1235-1238, 1455-1481)
+ *   cgs_mark_rows,
+ *   cgs_zero_unmarked_rows     the zero rows autograd gives `x[visible_mask]`
+ *                              outside the mask (gaussian_renderer/__init__.py:73-81)
  */
 #ifndef CGS_H
 #define CGS_H
