@@ -101,6 +101,9 @@ def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):
     return pkg
 
 
+_HOST_S = []
+
+
 def timed(fn, steps, dist_on, first=0):
     import torch
     if dist_on:
@@ -110,6 +113,7 @@ def timed(fn, steps, dist_on, first=0):
     t0 = time.perf_counter()
     for i in range(first, first + steps):
         fn(i)
+    _HOST_S.append((time.perf_counter() - t0, steps))      # the host's enqueue loop (incl. its waits for the device's counts)
     torch.cuda.synchronize()
     if dist_on:
         import torch.distributed as dist
@@ -219,7 +223,10 @@ def main():
     # `value` is timed with the library's per-kernel event bracketing OFF; the per-kernel table (roofline leg) comes from a
     # second, separately timed pass over the same K steps with it ON (HIP events on the launch stream around each kernel)
     L.cgs_prof_enable(0)
+    del _HOST_S[:]
     dt, seg_s, seg_k = timed_segments(full, args.steps, dist_on)
+    host_ms = sorted(t / k * 1e3 for t, k in _HOST_S)
+    host_ms_per_step = host_ms[len(host_ms) // 2] if host_ms else None
     L.cgs_prof_enable(1)
     dt_prof = timed(full, args.steps, dist_on)
     prof = read_prof()
@@ -410,7 +417,10 @@ def main():
             "timing": {"segments": len(seg_s), "steps_per_segment": seg_k, "ms_per_step_by_segment": [round(t / k * 1e3, 3) for t, k in zip(seg_s, seg_k)],
                        "ms_per_step_min": round(seg_ms[0], 3), "ms_per_step_max": round(seg_ms[-1], 3),
                        "value_over_all_steps": round(value_all_steps, 3),
-                       "note": "value / ms_per_step = the median of the separately bracketed segments of the K timed steps"},
+                       "host_ms_per_step": None if host_ms_per_step is None else round(host_ms_per_step, 3),
+                       "note": "value / ms_per_step = the median of the separately bracketed segments of the K timed steps; "
+                               "host_ms_per_step = the host's enqueue loop of the median segment's kind (it includes the host's waits "
+                               "for the four per-view counts the device produces: profiles/r04_host_profile.txt)"},
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
             "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
