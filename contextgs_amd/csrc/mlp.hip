@@ -48,14 +48,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     __shared__ float b1s[HP];
     __shared__ float b2s[OP];
     const int tid = threadIdx.x, nthr = WAVES * 64;
-    for (int i = tid; i < XP * S1; i += nthr) {
-        const int k = i / S1, j = i % S1;
-        W1s[i] = (k < IN && j < HID) ? W1[j * IN + k] : 0.f;
-    }
-    for (int i = tid; i < HP * S2; i += nthr) {
-        const int h = i / S2, o = i % S2;
-        W2s[i] = (h < HID && o < OUT) ? W2[o * HID + h] : 0.f;
-    }
+    frag_stage_transposed<IN, HID, XP, S1>(W1s, W1, tid, nthr);       // W1s[k][j] = W1[j][k]
+    frag_stage_transposed<HID, OUT, HP, S2>(W2s, W2, tid, nthr);      // W2s[h][o] = W2[o][h]
     for (int i = tid; i < HP; i += nthr) b1s[i] = i < HID ? b1[i] : 0.f;
     for (int i = tid; i < OP; i += nthr) b2s[i] = i < OUT ? b2[i] : 0.f;
     __syncthreads();

@@ -72,14 +72,8 @@ template <int OUT>
 __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int tid, int nthr) {
     using L = M3FwdLds<OUT>;
     float *W1s = lds, *W2s = W1s + M3_XP * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
-    for (int i = tid; i < M3_XP * L::S1; i += nthr) {
-        const int k = i / L::S1, j = i % L::S1;
-        W1s[i] = (k < M3_IN && j < M3_HID) ? h.W1[j * M3_IN + k] : 0.f;
-    }
-    for (int i = tid; i < M3_HP * L::S2; i += nthr) {
-        const int hh = i / L::S2, o = i % L::S2;
-        W2s[i] = (hh < M3_HID && o < OUT) ? h.W2[o * M3_HID + hh] : 0.f;
-    }
+    frag_stage_transposed<M3_IN, M3_HID, M3_XP, L::S1>(W1s, h.W1, tid, nthr);      // W1s[k][j] = W1[j][k]
+    frag_stage_transposed<M3_HID, OUT, M3_HP, L::S2>(W2s, h.W2, tid, nthr);        // W2s[h][o] = W2[o][h]
     for (int i = tid; i < M3_HP; i += nthr) b1s[i] = i < M3_HID ? h.b1[i] : 0.f;
     for (int i = tid; i < L::OP; i += nthr) b2s[i] = i < OUT ? h.b2[i] : 0.f;
 }

@@ -59,6 +59,35 @@ __device__ __forceinline__ void frag_store4(float *__restrict__ rowp, int q, int
 // 32-lane LDS pass) land 16 banks apart
 constexpr int frag_pad4mod8(int x) { int s = 4; while (s < x) s += 8; return s; }
 
+// LDS staging of a weight matrix in TRANSPOSED form: dst [RP][S] (row stride S), dst[r][c] = src[c][r] for r < ROWS, c < COLS
+// (src row-major [COLS][ROWS], e.g. nn.Linear's weight [out][in] -> [in][out]), zeros in the padding.  The source is read in
+// ITS order — consecutive threads, consecutive addresses — and scattered into LDS; reading it in the destination's order is a
+// 4-byte gather with a row-length stride (64 cache lines per wave load).  Measured (round 4, same-box A/B of the headline
+// step, FRAG_STAGE_COALESCED=0 = the old loop): 129 vs 130-131 us per forward launch — the weights are L2-resident and the
+// gather was ~1 us of a launch, not the ~10 us it was suspected of.
+#ifndef FRAG_STAGE_COALESCED
+#define FRAG_STAGE_COALESCED 1
+#endif
+template <int ROWS, int COLS, int RP, int S>
+__device__ __forceinline__ void frag_stage_transposed(float *__restrict__ dst, const float *__restrict__ src, int tid, int nthr) {
+#if FRAG_STAGE_COALESCED
+    for (int i = tid; i < RP * S; i += nthr) {
+        const int r = i / S, c = i % S;
+        if (r >= ROWS || c >= COLS) dst[i] = 0.f;
+    }
+    for (int i = tid; i < COLS * ROWS; i += nthr) {
+        const int c = i / ROWS, r = i % ROWS;
+        dst[r * S + c] = src[i];
+    }
+#else
+    for (int i = tid; i < RP * S; i += nthr) {
+        const int r = i / S, c = i % S;
+        dst[i] = (r < ROWS && c < COLS) ? src[c * ROWS + r] : 0.f;
+    }
+#endif
+}
+
+
 #define FRAG_ACT_NONE 0
 #define FRAG_ACT_TANH 1
 #define FRAG_ACT_SIGMOID 2

@@ -27,10 +27,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     __shared__ float W2s[OUT * HP];
     __shared__ float red[OUT * HP + OUT];
     const int tid = threadIdx.x, nthr = WAVES * 64;
-    for (int i = tid; i < XP * S1; i += nthr) {
-        const int k = i / S1, j = i % S1;
-        W1s[i] = (k < IN && j < HID) ? W1[j * IN + k] : 0.f;
-    }
+    frag_stage_transposed<IN, HID, XP, S1>(W1s, W1, tid, nthr);       // W1s[k][j] = W1[j][k]
     for (int i = tid; i < HP * SB; i += nthr) {
         const int h = i / SB, k = i % SB;
         W1n[i] = (h < HID && k < IN) ? W1[h * IN + k] : 0.f;
