@@ -483,6 +483,24 @@ def gaussian_encode_streams(x, mean, scale, Q, stream_off, q_div=1):
     return [blob[e - n: e].tobytes() for e, n in zip(ends, lens)], mn, mx
 
 
+def _pack_flat(parts, dev):
+    """[tensor | (Q rows, q_div)] -> one flat float32 device tensor holding them back to back, each written ONCE into its
+    slice (a strided slice of the prediction, or a per-row step size broadcast over its q_div elements, used to be made
+    contiguous / expanded first and then copied again by torch.cat: ~1 GB of extra traffic per coder launch at 1 M anchors)."""
+    sizes = [int(p[0].numel()) * int(p[1]) if isinstance(p, tuple) else int(p.numel()) for p in parts]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    base = 0
+    for p, n in zip(parts, sizes):
+        if n:
+            if isinstance(p, tuple):
+                q, q_div = p[0].reshape(-1), int(p[1])
+                flat[base:base + n].view(q.numel(), q_div).copy_(q.unsqueeze(1).expand(q.numel(), q_div))
+            else:
+                flat[base:base + n].view(p.shape).copy_(p)
+        base += n
+    return flat, sizes
+
+
 def _expand_q(Q, q_div):
     Q = _f(Q).reshape(-1)
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
@@ -497,17 +515,20 @@ def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None, def
     if not groups:
         return []
     xs, ms, ss, qs, edges, counts, base = [], [], [], [], [torch.zeros(1, dtype=torch.int64)], [], 0
+    dev = groups[0][0].device
+    _lib.require_device(*[t for g_ in groups for t in g_[:4]])
     for (x, mean, scale, Q, off, q_div) in groups:
         off = torch.as_tensor(off, dtype=torch.int64).cpu()
-        xs.append(_f(x).reshape(-1)); ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1))
-        qs.append(_expand_q(Q, q_div))
+        xs.append(x); ms.append(mean); ss.append(scale)
+        qs.append((Q, int(q_div)))
         n_sym = int(off[-1]) if off.numel() else 0
-        if not (xs[-1].numel() == ms[-1].numel() == ss[-1].numel() == qs[-1].numel() == n_sym) or (off.numel() and int(off[0])):
+        if not (x.numel() == mean.numel() == scale.numel() == Q.numel() * int(q_div) == n_sym) or (off.numel() and int(off[0])):
             raise ValueError("gaussian_encode_groups: a group's x / mean / scale / Q sizes do not match its stream offsets")
         edges.append(off[1:] + base)
         counts.append(max(int(off.numel()) - 1, 0))
-        base += int(xs[-1].numel())
-    X, M, Sc, Qe, E = torch.cat(xs), torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges)
+        base += int(x.numel())
+    (X, _), (M, _), (Sc, _), (Qe, _) = (_pack_flat(p_, dev) for p_ in (xs, ms, ss, qs))
+    E = torch.cat(edges)
     from . import dist as D
     if D.world() > 1:
         # multi-GPU: rank r codes a contiguous block of the stream list; the ranks' packed bytes in rank
@@ -749,17 +770,21 @@ def gaussian_decode_groups(groups, lanes=False):
     one coder launch for all streams of all groups."""
     if not groups:
         return []
-    ms, ss, qs, edges, mns, mxs, blobs, lns, sizes, base = [], [], [], [torch.zeros(1, dtype=torch.int64)], [], [], [], [], [], 0
+    ms, ss, qs, edges, mns, mxs, blobs, lns, base = [], [], [], [torch.zeros(1, dtype=torch.int64)], [], [], [], [], 0
+    dev = groups[0][0].device
+    _lib.require_device(*[t for g_ in groups for t in g_[:3]])
     for (mean, scale, Q, off, mn, mx, blob, lens, q_div) in groups:
         off = torch.as_tensor(off, dtype=torch.int64).cpu()
-        ms.append(_f(mean).reshape(-1)); ss.append(_f(scale).reshape(-1)); qs.append(_expand_q(Q, q_div))
+        if not (mean.numel() == scale.numel() == Q.numel() * int(q_div)):
+            raise ValueError("gaussian_decode_groups: a group's mean / scale / Q sizes do not match")
+        ms.append(mean); ss.append(scale); qs.append((Q, int(q_div)))
         edges.append(off[1:] + base)
         mns.append(np.asarray(mn, dtype=np.int32).reshape(-1)); mxs.append(np.asarray(mx, dtype=np.int32).reshape(-1))
         blobs.append(blob if isinstance(blob, (np.ndarray, torch.Tensor)) else np.frombuffer(blob, dtype=np.uint8))
         lns.append(np.asarray(lens, dtype=np.int64).reshape(-1))
-        sizes.append(int(ms[-1].numel()))
-        base += sizes[-1]
-    M, Sc, Qe, E = torch.cat(ms), torch.cat(ss), torch.cat(qs), torch.cat(edges)
+        base += int(mean.numel())
+    (M, sizes), (Sc, _), (Qe, _) = (_pack_flat(p_, dev) for p_ in (ms, ss, qs))
+    E = torch.cat(edges)
     mn, mx, lens = np.concatenate(mns), np.concatenate(mxs), np.concatenate(lns)
     if all(isinstance(b_, torch.Tensor) for b_ in blobs):
         blob = _join_device_slices(blobs)
