@@ -708,7 +708,10 @@ class StagedFiles:
             i = 0
             while i < len(self.names):
                 if i >= self._start:
-                    self._released.wait()
+                    # (bounded: a caller that fails between construction and release() must not leave this pool thread — which
+                    #  the interpreter joins at exit — waiting for ever; after the timeout the files are simply staged)
+                    self._released.wait(10.0)
+                    self._released.set()
                 # a batch: whole files from i on, up to batch_bytes (one file alone may exceed it: it is then split)
                 stop = len(self.names) if self._released.is_set() else self._start
                 j, size = i, 0
