@@ -55,8 +55,8 @@ SIGNATURES = {
     "cgs_raster_preprocess": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p, C.POINTER(c_int64), c_void_p]),
     "cgs_raster_preprocess_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "cgs_raster_preprocess_wait": (c_int, [C.POINTER(c_int64)]),
+                                             c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, C.POINTER(C.c_uint64)]),
+    "cgs_raster_preprocess_wait": (c_int, [C.c_uint64, C.POINTER(c_int64)]),
     "cgs_raster_render_spec": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
                                        c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_render": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
@@ -66,7 +66,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "cgs_raster_preprocess_expand_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_int] + [c_void_p] * 9 + [c_int64, c_void_p,
-                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+                                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, C.POINTER(C.c_uint64)]),
     "cgs_raster_stats": (c_int, [C.POINTER(RasterCfg), c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_debug_bin_compare": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
                                       c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -134,6 +134,11 @@ SIGNATURES = {
     "cgs_noise_quant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_ctx_level_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                  c_int64] + [c_void_p] * 8 + [C.c_uint64, c_float, c_float, c_float] + [c_void_p] * 7),
+    "cgs_ctx_level_bwd_scratch_bytes": (c_size_t, []),
+    "cgs_ctx_level_bwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int64, C.c_uint64, c_float, c_float, c_float, c_void_p, c_int64] +
+                          [c_void_p] * 4 + [c_int64] + [c_void_p] * 11 + [c_size_t, c_void_p]),
     "cgs_level_rate_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "cgs_level_rate_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64] + [c_void_p] * 7 +
                            [c_int, c_void_p]),
@@ -186,8 +191,8 @@ SIGNATURES = {
     "cgs_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int64)]),
     "cgs_densify_stats": (c_int, [c_int64, c_int] + [c_void_p] * 11),
     "cgs_nonzero_scratch_bytes": (c_size_t, [c_int64]),
-    "cgs_nonzero_launch": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "cgs_nonzero_wait": (c_int, [C.POINTER(c_int64)]),
+    "cgs_nonzero_launch": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p, C.POINTER(C.c_uint64)]),
+    "cgs_nonzero_wait": (c_int, [C.c_uint64, C.POINTER(c_int64)]),
     "cgs_level_key_range": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "cgs_level_unique_scratch_bytes": (c_size_t, [c_int64]),
     "cgs_level_unique": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -209,8 +214,8 @@ SIGNATURES = {
     "cgs_expand_count": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_size_t, C.POINTER(c_int64), c_void_p]),
     "cgs_expand_count_launch": (c_int, [c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_size_t, c_void_p]),
-    "cgs_expand_count_wait": (c_int, [C.POINTER(c_int64)]),
+                                        c_size_t, c_void_p, C.POINTER(C.c_uint64)]),
+    "cgs_expand_count_wait": (c_int, [C.c_uint64, C.POINTER(c_int64)]),
     "cgs_expand_write": (c_int, [c_int64, c_int] + [c_void_p] * 15),
     "cgs_expand_backward": (c_int, [c_int64, c_int] + [c_void_p] * 22),
 }

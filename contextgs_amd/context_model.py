@@ -41,6 +41,7 @@ FUSED_TRAINING = True      # fused HIP stages for the training path (tests flip 
 HYPER_BLOCKS = _os.environ.get("CGS_HYPER_BLOCKS", "1") != "0"   # the noisy hyper latents leave their node one block per level
 ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = gather into coding order first
 RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
+LEVEL_FUSED = _os.environ.get("CGS_LEVEL_FUSED", "1") != "0"    # A/B knob: 0 = round 4's rowcat -> mlp2 -> noise_quant launches per level
 
 
 def _compose_down(index, maps):
@@ -554,6 +555,41 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 loc = locs[j] if locs is not None else torch.nonzero(choose_mask[orig])[:, 0]
             subset_mode = _mlp.supported(pc.get_grid_mlp[i]) and (not keep_stats or loc is not None)
             use_fused = fused and subset_mode
+            if (use_fused and LEVEL_FUSED and row_src is not None and joined
+                    and _ctx.level_fused_supported(pc.get_grid_mlp[i], anchor, hyp_l[j], row_src)):
+                # input-row assembly + hidden layer + step sizes + noisy values of every row: one launch each way
+                # (csrc/ctx_level.hip); the mean / scale outputs only on the rate subset's rows
+                sl = slice(row_off, row_off + n_l)
+                side = _ctx.RateSide() if (keep_stats and RATE_SIDE) else None
+                if ctx_src is None:
+                    # (masked anchors sit at the origin from level 1 up, :1758-1759: the product is folded into the gather)
+                    a_rows, pos_, base_f, base_s, csr = orig, None, None, None, None
+                    a_mask = mask_anchor_bool if (i >= 1 and mask_anchor_bool is not None) else None
+                else:
+                    a_rows, pos_, base_f, base_s, csr = ctx_src
+                    a_mask = None
+                hf, hs, ho, Q_all, pred_sub = _ctx.level_fused(
+                    anchor, base_f, base_s, hyp_l[j], pc.get_grid_mlp[i], 2 * (pc.feat_dim + 6 + 3 * K), loc if keep_stats else None,
+                    a_rows, a_mask, pos_, csr, row_src, perm[row_off:row_off + n_l], (big_f[sl], big_s[sl], big_o[sl]), side,
+                    (Q_FEAT0, Q_SCALING0, Q_OFFSETS0))
+                row_off += n_l
+                if keep_stats:
+                    span = None
+                    if chosen_rows is not None:
+                        lo_ = sum(int(l_.shape[0]) for l_ in locs[:j])
+                        span = (chosen_rows, lo_, lo_ + int(loc.shape[0]))
+                    sm = c.get("_sub_map")
+                    lvl0 = sum(sizes[:j])
+                    levels.append(dict(level=i, orig=orig, rows=orig[loc] if span is None else None, loc=loc, n_level=n_l,
+                                       fused=True, yf=hf, ys=hs, yo=ho, Q=Q_all, chosen=span, side=side, side_src=row_src,
+                                       sub_map=sm[lvl0:lvl0 + n_l] if (sm is not None and span is not None) else None,
+                                       pred=pred_sub))
+                feat_q.append(hf)
+                scal_q.append(hs)
+                off_q.append(ho)
+                if i != 0:
+                    ctx_src = _next_context(c, i, feat_q, scal_q, (big_f, big_s, row_off))
+                continue
             if ctx_src is None:                                                        # :1596-1600
                 if use_fused:
                     # (masked anchors sit at the origin from level 1 up, :1758-1759: the product is folded into the gather)

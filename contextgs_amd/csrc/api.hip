@@ -145,18 +145,29 @@ extern "C" int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const floa
 // cgs_raster_preprocess_launch enqueues projection, the depth sort and the pair-offset scan, and the 4-byte copy of the
 // pair count behind them; cgs_raster_preprocess_wait blocks on THAT copy's event only.  What the caller enqueues in between
 // (cgs_raster_render_spec) keeps the device busy while the host learns the count.  cgs_raster_preprocess = both.
-struct RasterCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
-static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false};
+struct RasterCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; uint64_t ticket; };
+static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false, 0};
+
+// Tickets of the *_launch / *_wait pairs: a slot holds ONE count per kind and host thread, so a second launch of the same kind
+// overwrites what an earlier launch's wait would have read.  Every launch hands out a ticket (kind in the top byte, a
+// per-thread serial below); the wait takes it back and refuses a ticket that is not the slot's current one instead of
+// returning another launch's count.
+uint64_t cgs_new_ticket(int kind) {
+    static thread_local uint64_t serial = 0;
+    return ((uint64_t)kind << 56) | (++serial & 0x00FFFFFFFFFFFFFFull);
+}
 static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream);
 
 extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
                                             const float *colors, const float *opacities, const float *scales,
                                             const float *rotations, void *geom_ws, size_t geom_bytes, int32_t *radii,
-                                            void *stream_) {
+                                            void *stream_, uint64_t *ticket) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterCountSlot &sl = g_raster_slot;
     int rc = check_cfg(cfg);
     if (rc) return rc;
+    if (!ticket) { cgs_set_error("cgs_raster_preprocess_launch: NULL ticket"); return CGS_ERR_ARG; }
+    *ticket = 0;
     if (P < 0 || P >= (1ll << 31)) { cgs_set_error("P out of range"); return CGS_ERR_ARG; }
     if (!sl.pinned) {
         CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
@@ -164,6 +175,7 @@ extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    *ticket = sl.ticket = cgs_new_ticket(1);
     if (P == 0) return CGS_OK;
     if (!means3D || !colors || !opacities || !scales || !rotations || !radii || !geom_ws) {
         cgs_set_error("cgs_raster_preprocess: NULL input");
@@ -215,11 +227,13 @@ extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, in
                                                    const float *offsets, const float *neural_opacity, const float *color_in,
                                                    const float *cov_in, const int64_t *src_row, int64_t P, float *scaling_out,
                                                    float *xyz_out, float *rot_out, void *geom_ws, size_t geom_bytes,
-                                                   int32_t *radii, void *stream_) {
+                                                   int32_t *radii, void *stream_, uint64_t *ticket) {
     hipStream_t stream = (hipStream_t)stream_;
     RasterCountSlot &sl = g_raster_slot;
     int rc = check_cfg(cfg);
     if (rc) return rc;
+    if (!ticket) { cgs_set_error("cgs_raster_preprocess_expand_launch: NULL ticket"); return CGS_ERR_ARG; }
+    *ticket = 0;
     if (P < 0 || P >= (1ll << 31) || n_anchor < 0 || K < 1 || n_anchor * (int64_t)K >= (1ll << 31) || P > n_anchor * (int64_t)K) {
         cgs_set_error("cgs_raster_preprocess_expand: sizes out of range");
         return CGS_ERR_ARG;
@@ -230,6 +244,7 @@ extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, in
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    *ticket = sl.ticket = cgs_new_ticket(1);
     if (P == 0) return CGS_OK;
     if (!flags || !pos || !anchor || !gscaling || !offsets || !neural_opacity || !color_in || !cov_in || !scaling_out || !radii ||
         !geom_ws) {
@@ -247,11 +262,15 @@ extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, in
     return raster_count_tail(P, g, sl, stream);
 }
 
-extern "C" int cgs_raster_preprocess_wait(int64_t *num_rendered_host) {
+extern "C" int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered_host) {
     RasterCountSlot &sl = g_raster_slot;
     if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
     *num_rendered_host = 0;
     if (!sl.pinned) { cgs_set_error("cgs_raster_preprocess_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (ticket == 0 || ticket != sl.ticket) {
+        cgs_set_error("cgs_raster_preprocess_wait: stale ticket (another preprocess launch was issued on this thread since)");
+        return CGS_ERR_ARG;
+    }
     if (sl.pending) {
         CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
         sl.pending = false;
@@ -266,10 +285,11 @@ extern "C" int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P, const
                                      int64_t *num_rendered_host, void *stream_) {
     if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
     *num_rendered_host = 0;
+    uint64_t ticket = 0;
     int rc = cgs_raster_preprocess_launch(cfg, P, means3D, colors, opacities, scales, rotations, geom_ws, geom_bytes, radii,
-                                          stream_);
+                                          stream_, &ticket);
     if (rc) return rc;
-    return cgs_raster_preprocess_wait(num_rendered_host);
+    return cgs_raster_preprocess_wait(ticket, num_rendered_host);
 }
 
 // ---- forward stage 2 -----------------------------------------------------------------

@@ -17,6 +17,7 @@
 #define CGS_WAVE 64
 
 void cgs_set_error(const char *fmt, ...);
+uint64_t cgs_new_ticket(int kind);      // api.hip: tickets of the *_launch / *_wait pairs (kind: 1 raster, 2 expand, 3 nonzero)
 
 #define CGS_CHECK_HIP(expr)                                                   \
     do {                                                                      \

@@ -172,14 +172,16 @@ extern "C" size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K) {
 // blocks on THAT copy only (hipEventSynchronize), so work the caller enqueued in between keeps
 // the GPU busy while the host learns the count (the reference's boolean indexing, :137, drains
 // the whole stream at this point).  cgs_expand_count = launch + wait.
-struct ExpandCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
-static thread_local ExpandCountSlot g_expand_slot = {nullptr, nullptr, false};
+struct ExpandCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; uint64_t ticket; };
+static thread_local ExpandCountSlot g_expand_slot = {nullptr, nullptr, false, 0};
 
 extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_raw, const float *mask,
                                        float *neural_opacity, uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
-                                       void *scratch, size_t scratch_bytes, void *stream_) {
+                                       void *scratch, size_t scratch_bytes, void *stream_, uint64_t *ticket) {
     hipStream_t stream = (hipStream_t)stream_;
     ExpandCountSlot &sl = g_expand_slot;
+    if (!ticket) { cgs_set_error("expand_count_launch: NULL ticket"); return CGS_ERR_ARG; }
+    *ticket = 0;
     if (n_anchor < 0 || K < 1 || K > EX_MAX_K) { cgs_set_error("expand_count: bad args"); return CGS_ERR_ARG; }
     if (!sl.pinned) {
         CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
@@ -187,6 +189,7 @@ extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    *ticket = sl.ticket = cgs_new_ticket(2);
     const int64_t n = n_anchor * K;
     if (n == 0) return CGS_OK;
     if (n >= (1ll << 31)) { cgs_set_error("expand_count: too many slots"); return CGS_ERR_ARG; }
@@ -208,11 +211,15 @@ extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_
     return CGS_OK;
 }
 
-extern "C" int cgs_expand_count_wait(int64_t *count_host) {
+extern "C" int cgs_expand_count_wait(uint64_t ticket, int64_t *count_host) {
     ExpandCountSlot &sl = g_expand_slot;
     if (!count_host) { cgs_set_error("expand_count_wait: NULL count_host"); return CGS_ERR_ARG; }
     *count_host = 0;
     if (!sl.pinned) { cgs_set_error("expand_count_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (ticket == 0 || ticket != sl.ticket) {
+        cgs_set_error("expand_count_wait: stale ticket (another expand_count launch was issued on this thread since)");
+        return CGS_ERR_ARG;
+    }
     if (sl.pending) {
         CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
         sl.pending = false;
@@ -226,10 +233,11 @@ extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, co
                                 void *scratch, size_t scratch_bytes, int64_t *count_host, void *stream_) {
     if (!count_host) { cgs_set_error("expand_count: NULL count_host"); return CGS_ERR_ARG; }
     *count_host = 0;
+    uint64_t ticket = 0;
     int rc = cgs_expand_count_launch(n_anchor, K, op_raw, mask, neural_opacity, mask_out, flags, pos, scratch, scratch_bytes,
-                                     stream_);
+                                     stream_, &ticket);
     if (rc) return rc;
-    return cgs_expand_count_wait(count_host);
+    return cgs_expand_count_wait(ticket, count_host);
 }
 
 extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags, const uint32_t *pos,

@@ -404,8 +404,8 @@ __global__ void __launch_bounds__(256)
     if (i < n && f[i]) idx[pos[i]] = i;
 }
 
-struct NzSlot { uint32_t *pinned; hipEvent_t ev; bool pending; };
-static thread_local NzSlot g_nz_slot = {nullptr, nullptr, false};
+struct NzSlot { uint32_t *pinned; hipEvent_t ev; bool pending; uint64_t ticket; };
+static thread_local NzSlot g_nz_slot = {nullptr, nullptr, false, 0};
 
 extern "C" size_t cgs_nonzero_scratch_bytes(int64_t n) {
     if (n < 1) n = 1;
@@ -413,9 +413,11 @@ extern "C" size_t cgs_nonzero_scratch_bytes(int64_t n) {
 }
 
 extern "C" int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_out, void *scratch, size_t scratch_bytes,
-                                  void *stream_) {
+                                  void *stream_, uint64_t *ticket) {
     hipStream_t stream = (hipStream_t)stream_;
     NzSlot &sl = g_nz_slot;
+    if (!ticket) { cgs_set_error("nonzero_launch: NULL ticket"); return CGS_ERR_ARG; }
+    *ticket = 0;
     if (n < 0 || n >= (1ll << 31)) { cgs_set_error("nonzero: bad n"); return CGS_ERR_ARG; }
     if (!sl.pinned) {
         CGS_CHECK_HIP(hipHostMalloc((void **)&sl.pinned, 64, hipHostMallocDefault));
@@ -423,6 +425,7 @@ extern "C" int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_o
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    *ticket = sl.ticket = cgs_new_ticket(3);
     if (n == 0) return CGS_OK;
     if (!mask || !idx_out || !scratch) { cgs_set_error("nonzero: NULL"); return CGS_ERR_ARG; }
     if (scratch_bytes < cgs_nonzero_scratch_bytes(n)) { cgs_set_error("nonzero: scratch too small"); return CGS_ERR_WORKSPACE; }
@@ -444,11 +447,15 @@ extern "C" int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_o
     return CGS_OK;
 }
 
-extern "C" int cgs_nonzero_wait(int64_t *count_host) {
+extern "C" int cgs_nonzero_wait(uint64_t ticket, int64_t *count_host) {
     NzSlot &sl = g_nz_slot;
     if (!count_host) { cgs_set_error("nonzero_wait: NULL"); return CGS_ERR_ARG; }
     *count_host = 0;
     if (!sl.pinned) { cgs_set_error("nonzero_wait: no launch on this thread"); return CGS_ERR_ARG; }
+    if (ticket == 0 || ticket != sl.ticket) {
+        cgs_set_error("nonzero_wait: stale ticket (another nonzero launch was issued on this thread since)");
+        return CGS_ERR_ARG;
+    }
     if (sl.pending) {
         CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
         sl.pending = false;

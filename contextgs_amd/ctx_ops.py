@@ -648,3 +648,168 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
     (None when nothing was compacted); `stale` says the
     anchors / mask no longer equal the reference copies (the caller rebuilds its plan and calls again)."""
     return choose_rows_end(choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds))
+
+
+# ---- one launch per level and direction for the every-row half of the level loop (csrc/ctx_level.hip) ---------------
+_LEVEL_DIMS = (50, 6, 30, 12, 100, 175)      # features, scaling, offsets, hyper, hidden, outputs of mlp_grid: the kernels' instance
+
+
+def level_fused_supported(seq, anchor, hyp, src) -> bool:
+    """Shapes / layouts cgs_ctx_level_* are instantiated for: the reference's dimensions (feat 50, scaling 6, 10 offsets,
+    hyper 12, mlp_grid {71|15} -> 100 -> 175) read through a RowSource."""
+    try:
+        l1, l2 = seq[0], seq[2]
+        ok = (len(seq) == 3 and l1.out_features == 100 and l2.out_features == 175 and l1.in_features in (71, 15))
+    except Exception:
+        return False
+    return bool(ok and src is not None and src.f.shape[1] == 50 and src.s.shape[1] == 6 and src.o.shape[1] == 30
+                and hyp.dim() == 2 and hyp.shape[1] == 12 and hyp.dtype == _f32 and hyp.is_cuda
+                and anchor.dtype == _f32 and anchor.is_cuda and anchor.dim() == 2 and anchor.shape[1] == 3)
+
+
+class _LevelFused(torch.autograd.Function):
+    """One level of the training level loop (scene/gaussian_model.py:1594-1616) as ONE node and one launch per direction for
+    the work that runs on every row: input-row assembly (:1596-1599 / :1711-1724), mlp_grid's hidden layer and three step-size
+    outputs (:1600-1608), the noisy values of the level's rows of the three parameter tensors (:1610-1616) — cgs_ctx_level_fwd /
+    cgs_ctx_level_bwd (weight gradients of that branch inside the backward kernel) — plus the mean / scale outputs on the rate
+    subset `loc` (the same fused MLP kernels as mlp._LevelMLP, on rows of the X the level kernel wrote).
+
+    cfg: dict(a_rows, a_mask, pos, csr, loc, n_stat, src, rows, seed, q0, outs, side) — see level_fused()."""
+
+    @staticmethod
+    def forward(ctx, anchor, base_f, base_s, hyp, W1, b1, W2, b2, _token, cfg):
+        from . import mlp as _mlp
+        L = _lib.lib()
+        _mlp._drop_stale_deferred()
+        src, rows, loc = cfg["src"], cfg["rows"], cfg["loc"]
+        anchor_c, hyp_c = _c(anchor.detach()), _c(hyp.detach())
+        W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
+        n, in_f = int(rows.shape[0]), int(W1c.shape[1])
+        hid, out, n_stat = int(W1c.shape[0]), int(W2c.shape[0]), int(cfg["n_stat"])
+        assert (hid, out, out - n_stat) == (100, 175, 3) and rows.dtype == torch.int64 and rows.is_contiguous()
+        ctxlevel = base_f is not None
+        assert in_f == (71 if ctxlevel else 15) and hyp_c.shape == (n, 12)
+        bf = _c(base_f.detach()) if ctxlevel else None
+        bs = _c(base_s.detach()) if ctxlevel else None
+        a_rows, pos, a_mask = cfg["a_rows"], cfg["pos"], cfg["a_mask"]
+        assert a_rows.dtype == torch.int64 and a_rows.is_contiguous() and int(a_rows.shape[0]) == n
+        if a_mask is not None:
+            a_mask = (a_mask if a_mask.dtype == torch.uint8 else a_mask.view(torch.uint8)).contiguous()
+        _lib.require_device(anchor_c, hyp_c, W1c, W2c, src.f)
+        dev = anchor_c.device
+        src.rows_read += n
+        yf, ys, yo = cfg["outs"]
+        assert yf.shape == (n, 50) and ys.shape == (n, 6) and yo.shape == (n, 30)
+        assert yf.is_contiguous() and ys.is_contiguous() and yo.is_contiguous()
+        X = torch.empty(n, in_f, dtype=_f32, device=dev)
+        Q = torch.empty(n, 3, dtype=_f32, device=dev)
+        stream = _lib.current_stream()
+        seed, q0 = int(cfg["seed"]), cfg["q0"]
+        _lib.check(L.cgs_ctx_level_fwd(
+            in_f, _lib.ptr(anchor_c), int(anchor_c.shape[0]), _lib.ptr(a_rows), _lib.ptr(a_mask), _lib.ptr(bf), _lib.ptr(bs),
+            int(bf.shape[0]) if ctxlevel else 0, _lib.ptr(pos), _lib.ptr(hyp_c), n, _lib.ptr(W1c), _lib.ptr(b1c), W2c.data_ptr() + 4 * n_stat * hid, b2c.data_ptr() + 4 * n_stat, _lib.ptr(src.f),
+            _lib.ptr(src.s), _lib.ptr(src.o), _lib.ptr(rows), seed, q0[0], q0[1], q0[2], _lib.ptr(X), _lib.ptr(yf), _lib.ptr(ys),
+            _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(src.sums_buffer()), stream), "cgs_ctx_level_fwd")
+        pred = x_sub = h_sub = None
+        m = 0
+        if loc is not None:
+            m = int(loc.shape[0])
+            x_sub = gather_rows_nograd(X, loc)
+            pred = torch.empty(m, out, dtype=_f32, device=dev)
+            h_sub = torch.empty(m, hid, dtype=_f32, device=dev)
+            _lib.check(L.cgs_mlp2_forward(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1c), _lib.ptr(b1c), _lib.ptr(W2c),
+                                          _lib.ptr(b2c), _lib.ptr(pred), out, _lib.ptr(h_sub), m, stream), "cgs_mlp2_forward")
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(X, x_sub, h_sub, W1c, b1c, W2c, b2c)
+        ctx.cfg, ctx.dims = cfg, (n, in_f, hid, out, n_stat, m)
+        ctx.shapes = (tuple(anchor.shape), None if bf is None else tuple(bf.shape), None if bs is None else tuple(bs.shape))
+        if pred is None:
+            pred = torch.empty(0, out, dtype=_f32, device=dev)
+        return yf, ys, yo, Q, pred
+
+    @staticmethod
+    def backward(ctx, gf, gs, go, gQ, d_pred):
+        from . import mlp as _mlp
+        L = _lib.lib()
+        X, x_sub, h_sub, W1, b1, W2, b2 = ctx.saved_tensors
+        cfg = ctx.cfg
+        n, in_f, hid, out, n_stat, m = ctx.dims
+        src, rows, loc = cfg["src"], cfg["rows"], cfg["loc"]
+        dev = X.device
+        stream = _lib.current_stream()
+        gf, gs, go, gQ = (None if t is None else _c(t) for t in (gf, gs, go, gQ))
+        dW1, db1, dW2, db2 = _mlp._zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))      # one fill for the module
+        ws = _mlp._wgrad_workspace(dev)
+        # the rate subset's branch first: its input gradient rides into the level kernel as compact rows
+        dx_sub = None
+        if d_pred is not None and m > 0:
+            d_pred = _c(d_pred)
+            dz1s = torch.empty(m, hid, dtype=_f32, device=dev)
+            dx_sub = torch.empty(m, in_f, dtype=_f32, device=dev)
+            _lib.check(L.cgs_mlp2_backward(in_f, hid, out, 0, _lib.ptr(x_sub), in_f, _lib.ptr(W1), None, _lib.ptr(W2), None,
+                                           _lib.ptr(d_pred), out, _lib.ptr(h_sub), _lib.ptr(dx_sub), in_f, 0, _lib.ptr(dz1s), None,
+                                           _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2), _lib.ptr(db2), m, _lib.ptr(ws), ws.numel(),
+                                           stream), "cgs_mlp2_backward")
+        side = cfg["side"] if (cfg["side"] is not None and cfg["side"].map is not None) else None
+        use_side = side is not None and side.f is not None and side.f.numel() > 0
+        smap = None
+        if use_side:
+            smap, sd = side.map, (side.f, side.s, side.o, side.q)
+        elif dx_sub is not None:
+            # no rate side (gradients of y / Q came through autograd) but a subset branch: its rows still need a map
+            smap = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            smap[loc] = torch.arange(m, dtype=torch.int32, device=dev)
+            z = torch.zeros(m, 50 + 6 + 30 + 3, dtype=_f32, device=dev)
+            sd = tuple(t.contiguous() for t in torch.split(z, [50, 6, 30, 3], dim=1))
+        else:
+            sd = (None,) * 4
+        dxf, dxs, dxo = src.grad_buffers()
+        dX = torch.empty(n, in_f, dtype=_f32, device=dev)
+        ws2 = torch.empty(int(L.cgs_ctx_level_bwd_scratch_bytes()), dtype=torch.uint8, device=dev)
+        _lib.check(L.cgs_ctx_level_bwd(
+            in_f, _lib.ptr(X), _lib.ptr(W1), _lib.ptr(b1), W2.data_ptr() + 4 * n_stat * hid, b2.data_ptr() + 4 * n_stat,
+            _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), n, int(cfg["seed"]), cfg["q0"][0], cfg["q0"][1], cfg["q0"][2],
+            _lib.ptr(rows), int(dxf.shape[0]), _lib.ptr(dxf), _lib.ptr(dxs), _lib.ptr(dxo), _lib.ptr(smap),
+            int(sd[0].shape[0]) if sd[0] is not None else 0, *[_lib.ptr(t) for t in sd],
+            _lib.ptr(dx_sub), _lib.ptr(dX), _lib.ptr(dW1), _lib.ptr(db1), dW2.data_ptr() + 4 * n_stat * hid,
+            db2.data_ptr() + 4 * n_stat, _lib.ptr(ws2), ws2.numel(), stream), "cgs_ctx_level_bwd")
+        if side is not None:
+            side.map = side.f = side.s = side.o = side.q = None
+        src.rows_written += n
+        need = ctx.needs_input_grad
+        a_shape, f_shape, s_shape = ctx.shapes
+        d_anchor = torch.zeros(a_shape, dtype=_f32, device=dev) if need[0] else None
+        d_f = d_s = None
+        if f_shape is not None:                  # context level: the parents' rows, summed over their children without atomics
+            offs, order, prow = cfg["csr"]
+            d_f = torch.empty(f_shape, dtype=_f32, device=dev) if need[1] else None
+            d_s = torch.empty(s_shape, dtype=_f32, device=dev) if need[2] else None
+            if d_anchor is not None or d_f is not None or d_s is not None:
+                _lib.check(L.cgs_ctx_gather_bwd(_lib.ptr(dX), in_f, int(f_shape[0]), _lib.ptr(offs), _lib.ptr(order), _lib.ptr(prow),
+                                                _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s), 3, 50, 6, stream),
+                           "cgs_ctx_gather_bwd")
+            d_hyp = dX[:, 59:] if need[3] else None          # a column slice: its consumer takes strided rows
+        else:                                    # first level: X = [anchor[a_rows] * mask | hyper]
+            d_hyp = dX[:, 3:] if need[3] else None
+            if d_anchor is not None:
+                a_mask = cfg["a_mask"]
+                if a_mask is not None:
+                    a_mask = (a_mask if a_mask.dtype == torch.uint8 else a_mask.view(torch.uint8)).contiguous()
+                # (the hyper columns of dX leave as the strided slice above: mode 0 = no store for that source)
+                _lib.check(L.cgs_rowcat_bwd_masked(2, _ptrs([d_anchor, None]), _ptrs([cfg["a_rows"], None]), _ptrs([a_mask, None]),
+                                                   _ints([3, 12]), _ints([3, 12]), _ints([1, 0]), n, _lib.ptr(dX), stream),
+                           "cgs_rowcat_bwd")
+        return d_anchor, d_f, d_s, d_hyp, dW1, db1, dW2, db2, None, None
+
+
+def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, pos, csr, src, rows, outs, side, q0, seed=None):
+    """One level of the training level loop.  anchor [N,3]; base_f / base_s: the coded prefix (None for the first level);
+    hyp [n,12] the level's noisy hyper latents; seq = mlp_grid[level]; loc: level rows of the rate subset (or None);
+    a_rows [n]: anchor row of every level row; a_mask: bool [N] (first level from level 1 up) or None; pos [n]: the parents'
+    prefix positions; csr: their children lists (cgs_ctx_gather_bwd); src / rows: RowSource and the level's slice of the coding
+    permutation; outs = (yf, ys, yo) slices to write; side: RateSide or None.
+    Returns (yf, ys, yo, Q [n,3], pred [len(loc),175] or an empty tensor)."""
+    l1, l2 = seq[0], seq[2]
+    cfg = dict(a_rows=a_rows, a_mask=a_mask, pos=pos, csr=csr, loc=loc, n_stat=int(n_stat), src=src, rows=rows,
+               seed=next_seed() if seed is None else int(seed), q0=tuple(float(v) for v in q0), outs=outs, side=side)
+    return _LevelFused.apply(anchor, base_f, base_s, hyp, l1.weight, l1.bias, l2.weight, l2.bias, src.token, cfg)

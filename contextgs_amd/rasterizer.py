@@ -99,7 +99,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def bin_and_blend(cfg, P, geom, img, color, stream):
+def bin_and_blend(cfg, P, geom, img, color, stream, ticket):
     """Everything of a view's forward behind a cgs_raster_preprocess*_launch on `geom`: the speculative binning + blend with
     the image size's pair capacity, the read of the pair count, and the re-render with the true count when the capacity did
     not hold.  Returns (binning workspace, the pair count it was carved with = the backward's `R`, the view's pair count)."""
@@ -115,7 +115,7 @@ def bin_and_blend(cfg, P, geom, img, color, stream):
         _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
                                             binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
                    "cgs_raster_render_spec")
-    _lib.check(L.cgs_raster_preprocess_wait(C.byref(R)), "cgs_raster_preprocess_wait")
+    _lib.check(L.cgs_raster_preprocess_wait(ticket, C.byref(R)), "cgs_raster_preprocess_wait")
     num_rendered = int(R.value)
     if num_rendered > _pair_capacity.get((H, W), 0):
         _pair_capacity[(H, W)] = pair_capacity_for(num_rendered)
@@ -148,10 +148,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom = _workspace(L.cgs_raster_geom_bytes(P), dev)
         img = _workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        ticket = C.c_uint64(0)
         _lib.check(L.cgs_raster_preprocess_launch(cfg.ref, P, _lib.ptr(means3D_c), _lib.ptr(colors_c), _lib.ptr(opac_c),
                                                   _lib.ptr(scales_c), _lib.ptr(rots_c), _lib.ptr(geom), geom.numel(),
-                                                  _lib.ptr(radii), stream), "cgs_raster_preprocess_launch")
-        binws, bin_R, _num_rendered = bin_and_blend(cfg, P, geom, img, color, stream)
+                                                  _lib.ptr(radii), stream, C.byref(ticket)), "cgs_raster_preprocess_launch")
+        binws, bin_R, _num_rendered = bin_and_blend(cfg, P, geom, img, color, stream, ticket)
         ctx.cfg = cfg
         ctx.num_rendered = bin_R
         ctx.save_for_backward(means3D_c, colors_c, opac_c, scales_c, rots_c, radii, geom, binws, img)

@@ -58,8 +58,9 @@ class VisibleList:
         n = int(m.numel())
         self.idx = torch.empty(n, dtype=torch.int64, device=m.device)
         self.scratch = torch.empty(int(L.cgs_nonzero_scratch_bytes(n)), dtype=torch.uint8, device=m.device)
+        self.ticket = C.c_uint64(0)      # the library refuses a wait whose ticket a later launch of the kind has replaced
         _lib.check(L.cgs_nonzero_launch(_lib.ptr(m), n, _lib.ptr(self.idx), _lib.ptr(self.scratch), self.scratch.numel(),
-                                        _lib.current_stream()), "cgs_nonzero_launch")
+                                        _lib.current_stream(), C.byref(self.ticket)), "cgs_nonzero_launch")
         self._idx = None
         _own_slot("nonzero", self)
 
@@ -68,7 +69,7 @@ class VisibleList:
             return self._idx
         _check_slot("nonzero", self)
         cnt = C.c_int64(0)
-        _lib.check(_lib.lib().cgs_nonzero_wait(C.byref(cnt)), "cgs_nonzero_wait")
+        _lib.check(_lib.lib().cgs_nonzero_wait(self.ticket, C.byref(cnt)), "cgs_nonzero_wait")
         idx = self.idx[:int(cnt.value)]
         idx._cgs_ascending = True        # row gathers by this list take the one-pass backward (cgs_scatter_rows_sorted)
         self._idx = idx
@@ -94,17 +95,18 @@ class ExpandCount:
         self.pos = torch.empty(slots, dtype=torch.int32, device=dev)
         self.scratch = torch.empty(L.cgs_expand_scratch_bytes(n, K), dtype=torch.uint8, device=dev)
         self.P = None
+        self.ticket = C.c_uint64(0)
         _lib.check(L.cgs_expand_count_launch(n, K, _lib.ptr(op_raw), _lib.ptr(masks), _lib.ptr(self.neural_opacity),
                                              _lib.ptr(self.mask_out), _lib.ptr(self.flags), _lib.ptr(self.pos),
-                                             _lib.ptr(self.scratch), self.scratch.numel(), _lib.current_stream()),
-                   "cgs_expand_count_launch")
+                                             _lib.ptr(self.scratch), self.scratch.numel(), _lib.current_stream(),
+                                             C.byref(self.ticket)), "cgs_expand_count_launch")
         _own_slot("expand_count", self)
 
     def wait(self) -> int:
         if self.P is None:
             _check_slot("expand_count", self)
             cnt = C.c_int64(0)
-            _lib.check(_lib.lib().cgs_expand_count_wait(C.byref(cnt)), "cgs_expand_count_wait")
+            _lib.check(_lib.lib().cgs_expand_count_wait(self.ticket, C.byref(cnt)), "cgs_expand_count_wait")
             self.P = int(cnt.value)
         return self.P
 
@@ -229,12 +231,13 @@ class _ExpandRasterize(torch.autograd.Function):
         geom = rz._workspace(L.cgs_raster_geom_bytes(P), dev)
         img = rz._workspace(L.cgs_raster_img_bytes(H, W), dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        ticket = C.c_uint64(0)
         _lib.check(L.cgs_raster_preprocess_expand_launch(
             cfg.ref, n, K, _lib.ptr(flags), _lib.ptr(pos), _lib.ptr(anchor), _lib.ptr(gscaling), _lib.ptr(offsets),
             _lib.ptr(neural_opacity), _lib.ptr(color_in), _lib.ptr(cov_in), _lib.ptr(src_row), P, _lib.ptr(scaling),
-            _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(geom), geom.numel(), _lib.ptr(radii), stream),
+            _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(geom), geom.numel(), _lib.ptr(radii), stream, C.byref(ticket)),
             "cgs_raster_preprocess_expand_launch")
-        binws, bin_R, _num_rendered = rz.bin_and_blend(cfg, P, geom, img, color, stream)
+        binws, bin_R, _num_rendered = rz.bin_and_blend(cfg, P, geom, img, color, stream, ticket)
         ctx.cfg, ctx.num_rendered, ctx.K, ctx.n, ctx.src_row, ctx.P = cfg, bin_R, K, n, src_row, P
         ctx.save_for_backward(flags, pos, gscaling, offsets, op_raw, masks, cov_in, xyz, scaling, rot, radii, geom, binws, img)
         ctx.mark_non_differentiable(radii, mask_out)

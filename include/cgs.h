@@ -123,13 +123,18 @@ int cgs_raster_preprocess(const cgs_raster_cfg *cfg, int64_t P,
 
 /* The same in two halves: _launch enqueues everything of stage 1 plus the 4-byte copy of the pair count and returns;
  * _wait blocks on THAT copy's event only (no stream drain) and returns the count.  Between the halves the caller may enqueue
- * cgs_raster_render_spec (below), so that the device works on the binning and the blend while the host learns the count. */
+ * cgs_raster_render_spec (below), so that the device works on the binning and the blend while the host learns the count.
+ * TICKETS (all three *_launch / *_wait pairs of this header): the library keeps one pinned count per kind and host thread, so
+ * a later launch of the same kind replaces what an earlier one's wait would read.  Every _launch writes a non-zero *ticket;
+ * _wait(ticket, .) on the same thread returns the count of THAT launch and fails (CGS_ERR_ARG, "stale ticket") when another
+ * launch of the kind was issued in between — it never returns another launch's count. */
 int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P,
                                  const float *means3D, const float *colors,
                                  const float *opacities, const float *scales,
                                  const float *rotations, void *geom_ws,
-                                 size_t geom_bytes, int32_t *radii, void *stream);
-int cgs_raster_preprocess_wait(int64_t *num_rendered_host);
+                                 size_t geom_bytes, int32_t *radii, void *stream,
+                                 uint64_t *ticket);
+int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered_host);
 
 /* Forward, stage 2: per-tile lists (stable by depth inside a tile), tile ranges, alpha blend.
  * out_color is [3, H, W]. */
@@ -181,7 +186,7 @@ int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anc
                                         const float *neural_opacity, const float *color_in,
                                         const float *cov_in, const int64_t *src_row, int64_t P,
                                         float *scaling_out, float *xyz_out, float *rot_out, void *geom_ws,
-                                        size_t geom_bytes, int32_t *radii, void *stream);
+                                        size_t geom_bytes, int32_t *radii, void *stream, uint64_t *ticket);
 size_t cgs_raster_bwd_scratch_bytes(int64_t P);
 
 /* Statistics of the last render held in img_ws (device reads; async):
@@ -486,6 +491,37 @@ int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
                        int K, int64_t ldpred, const float *g_sums, float *d_pred, float *d_yf,
                        float *d_ys, float *d_yo, float *dQ, float *d_masks,
                        int compact, void *stream);
+
+/* One launch per level and direction for the every-row half of the level loop, training path (round 5, csrc/ctx_level.hip;
+ * scene/gaussian_model.py:1594-1616 and its autograd) — replaces cgs_rowcat_fwd + cgs_mlp2_forward(., 100, 3) +
+ * cgs_noise_quant_fwd, and cgs_noise_quant_bwd + cgs_mlp2_backward(., 100, 3) + the first layer's cgs_mlp2_wgrad.
+ * in_dim 71 (context level): X[r] = [anchor[a_rows[r]] | base_f[pos[r]] | base_s[pos[r]] | hyp[r]] with base_f [., 50] /
+ * base_s [., 6] the coded prefix; in_dim 15 (first level): X[r] = [anchor[a_rows[r]] (* a_mask[a_rows[r]], uint8, may be
+ * NULL) | hyp[r]], hyp [n, 12].  W1 [100, in_dim], b1 [100]; W2q [3, 100] / b2q [3] = the LAST three rows of mlp_grid's second
+ * layer (the step-size adjustments).  Outputs: X [n, in_dim] (kept for the backward and the rate subset), Q [n,3] =
+ * clamp(q0 (1 + tanh(.)), 1e-9), y* = x*[rows[r]] + U(-1/2,1/2) Q (the counter-based noise of cgs_noise_quant_fwd: same
+ * element -> value map); xf [N,50], xs [N,6], xo [N,30]; sums3 as in cgs_noise_quant_fwd (may be NULL).
+ * Backward: dy* [n, .] (each may be NULL = zeros), dQ_ext [n,3] (may be NULL); rows rows[r] of the FULL-size dxf / dxs / dxo are
+ * overwritten with dy[r] (+ row side_map[r] of the compact side arrays when >= 0); dX [n, in_dim] = the input-row gradient
+ * (+ row side_map[r] of dx_sub [m, in_dim], may be NULL); dW1 / db1 / dW2q / db2q are ACCUMULATED into, without atomics
+ * (per-workgroup images in scratch >= cgs_ctx_level_bwd_scratch_bytes(), summed in a fixed order).
+ * n_anchor = rows of anchor / a_mask / xf / xs / xo / dxf / dxs / dxo, n_par = rows of base_f / base_s, m_side = rows of the side
+ * arrays and dx_sub: the kernels address every operand through bounds-checked raw buffers (32-bit offsets: an operand of 4 GB or
+ * more is refused with CGS_ERR_ARG). */
+int cgs_ctx_level_fwd(int in_dim, const float *anchor, int64_t n_anchor, const int64_t *a_rows,
+                      const uint8_t *a_mask, const float *base_f, const float *base_s, int64_t n_par,
+                      const int64_t *pos, const float *hyp, int64_t n, const float *W1, const float *b1, const float *W2q, const float *b2q,
+                      const float *xf, const float *xs, const float *xo, const int64_t *rows, uint64_t seed,
+                      float q0f, float q0s, float q0o, float *X, float *yf, float *ys, float *yo, float *Q,
+                      double *sums3, void *stream);
+size_t cgs_ctx_level_bwd_scratch_bytes(void);
+int cgs_ctx_level_bwd(int in_dim, const float *X, const float *W1, const float *b1, const float *W2q,
+                      const float *b2q, const float *dyf, const float *dys, const float *dyo,
+                      const float *dQ_ext, int64_t n, uint64_t seed, float q0f, float q0s, float q0o,
+                      const int64_t *rows, int64_t n_anchor, float *dxf, float *dxs, float *dxo,
+                      const int32_t *side_map, int64_t m_side, const float *side_f, const float *side_s, const float *side_o, const float *side_Q,
+                      const float *dx_sub, float *dX, float *dW1, float *db1, float *dW2q, float *db2q,
+                      void *scratch, size_t scratch_bytes, void *stream);
 
 /* Row strides (floats) of the buffers the anchor-MLP forward and backward hand to each other, so that callers size them:
  * out4 = {row stride of Hcat (150: head h in columns 50 h .. 50 h + 49), row stride of X_out of the _rows variant (54),
@@ -816,8 +852,8 @@ int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw,
 int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_raw,
                             const float *mask, float *neural_opacity,
                             uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
-                            void *scratch, size_t scratch_bytes, void *stream);
-int cgs_expand_count_wait(int64_t *count_host);
+                            void *scratch, size_t scratch_bytes, void *stream, uint64_t *ticket);
+int cgs_expand_count_wait(uint64_t ticket, int64_t *count_host);
 int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags,
                      const uint32_t *pos, const float *anchor,
                      const float *gscaling, const float *offsets,
@@ -892,8 +928,8 @@ int cgs_compact_rows(int nt, const float *const *src, float *const *dst, const i
  * so work enqueued in between keeps the device busy (torch.nonzero drains the stream). */
 size_t cgs_nonzero_scratch_bytes(int64_t n);
 int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_out, void *scratch,
-                       size_t scratch_bytes, void *stream);
-int cgs_nonzero_wait(int64_t *count_host);
+                       size_t scratch_bytes, void *stream, uint64_t *ticket);
+int cgs_nonzero_wait(uint64_t ticket, int64_t *count_host);
 
 /* ---- level division of the context model: utils/multi_level.py:3-31
  * `torch_unique_with_indices` on the integer voxel keys of scene/gaussian_model.py:1751-1765 ----

@@ -125,6 +125,10 @@ def test_row_source_and_rate_side_equal_the_autograd_formulation(monkeypatch, lo
         monkeypatch.setattr(ctx_ops, "next_seed", lambda: next(it))
         monkeypatch.setattr(cm, "ROW_SOURCE", short_cuts)
         monkeypatch.setattr(cm, "RATE_SIDE", short_cuts)
+        # both runs on the separate level launches: the fused level kernels (csrc/ctx_level.hip, the default) only exist on the
+        # RowSource path and form the step sizes in another summation order — their comparison with these launches, with and
+        # without the rate side, is tests/test_ctx_level_gpu.py
+        monkeypatch.setattr(cm, "LEVEL_FUSED", False)
         pkg = render(cams[2], pc, pipe, bg, visible_mask=vis, step=20000)
         loss = 0.0
         if loss_kind != "rate_only":
