@@ -28,6 +28,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense
+HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md: float4 copy on MI355X (the floor of ctx_group_roofline is priced against this)
+
+# which csrc files a counter figure of profiles/pmc_traffic.json depends on (the figure is dropped when one of them changed
+# since the passes ran: tools/pmc_gpu.sh records their sha256)
+PMC_SOURCES = {
+    "blend_fwd": ("raster_blend_rows.hip", "raster_math.h", "tile_bin.hip"),
+    "blend_bwd": ("raster_blend_rows.hip", "raster_math.h", "tile_bin.hip"),
+    "preprocess": ("expand_raster.hip", "raster_pre.h", "raster_geom.hip"),
+    "preprocess_bwd": ("raster_bwd.hip", "raster_pre.h"),
+    "expand_bwd": ("expand.hip",),
+    "mlp3_fwd": ("mlp3.hip", "mlp_frag.h"),
+    "mlp3_bwd": ("mlp3.hip", "mlp_frag.h"),
+    "ctx_group": ("ctx_level.hip", "ctx.hip", "ctx_plan.hip", "ctx_noise.h", "mlp.hip", "mlp_small.hip", "mlp_wgrad.hip", "mlp_frag.h",
+                  "eb.hip", "elementwise.hip", "rate_math.h"),
+}
+
+
+def _csrc_digest(fname):
+    import hashlib
+    path = os.path.join(ROOT, "contextgs_amd", "csrc", fname)
+    if not os.path.exists(path):
+        return None
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
 
 
 def parse():
@@ -305,24 +328,42 @@ def main():
         # fused-MLP kernel families are MFMA-bound: algorithmic flops of ALL their launches in one step
         # (three anchor MLPs on n_vis rows + one context MLP per level on that level's rows)
         mlp_flops = 0.0
+        level_flops = 0.0
         if args.step_semantics > 10000:
             lv = pkg_full["bpp_per_level"][2:] if pkg_full is not None else []
             # per level: the 3 step-size outputs on every row of the level, all 175 outputs on the rate subset
             # (15 % of the rows in expectation, scene/gaussian_model.py:1658-1661)
             dims = [(15, 100)] + [(71, 100)] * max(0, len(lv) - 1)
             for (i_, h_), (ratio, _bpp) in zip(dims, lv):
-                mlp_flops += 2.0 * ratio * N * (i_ * h_ + h_ * 3)
-                mlp_flops += 2.0 * 0.15 * ratio * N * (i_ * h_ + h_ * 175)
+                level_flops += 2.0 * ratio * N * (i_ * h_ + h_ * 3)
+                level_flops += 2.0 * 0.15 * ratio * N * (i_ * h_ + h_ * 175)
+        anchor_flops = 0.0
         for o_ in (10, 30, 70):
-            mlp_flops += 2.0 * n_vis * (54 * 50 + 50 * o_)
+            anchor_flops += 2.0 * n_vis * (54 * 50 + 50 * o_)
+        mlp_flops = anchor_flops + level_flops
         # PMC figures are NOT measured in this run (counters need their own rocprofv3 passes): they are read from the
         # committed profiles of the same workload (tools/pmc_gpu.sh, tools/pmc_blend.sh) and only attached at it
         traffic, valu = {}, {}
+        traffic_stale, ctx_traffic = [], None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
         if N == 1_000_000 and (W, H) == (1920, 1080):
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("bytes_per_launch", {})
+                # a counter figure is only attached to a kernel whose SOURCES are still the ones it was measured on: the file
+                # records sha256 of every csrc file at measurement time (tools/pmc_gpu.sh), compared here per kernel
+                tj = json.load(open(tpath))
+                recorded = tj.get("file_digests", {})
+                fresh = lambda files: bool(recorded) and all(recorded.get(f) == _csrc_digest(f) for f in files)
+                for k_, v_ in tj.get("bytes_per_launch", {}).items():
+                    if fresh(PMC_SOURCES.get(k_, ("cgs_internal.h",))):
+                        traffic[k_] = v_
+                    else:
+                        traffic_stale.append(k_)
+                if tj.get("ctx_group_bytes_per_step") is not None:
+                    if fresh(PMC_SOURCES["ctx_group"]):
+                        ctx_traffic = tj["ctx_group_bytes_per_step"]
+                    else:
+                        traffic_stale.append("ctx_group")
             if os.path.exists(vpath):
                 valu = json.load(open(vpath)).get("valu_busy_frac", {})
         kernels = {}
@@ -332,10 +373,11 @@ def main():
             if name in alg:
                 k["alg_bytes"] = alg[name]
                 k["GBps"] = round(alg[name] / (avg_us * 1e-6) / 1e9, 1)
-            if name in ("mlp_fwd", "mlp_bwd", "mlp_wgrad"):
-                # backward-main has the same contraction sizes transposed; the weight gradients too
-                k["alg_flops_per_step"] = mlp_flops
-                k["TFLOPs"] = round(mlp_flops / (ms / args.steps * 1e-3) / 1e12, 2)
+            if name in ("mlp_fwd", "mlp_bwd"):
+                # the anchor trio (since round 5 the level MLPs are timed under ctx_* / level_mlp_*: ctx_group_roofline);
+                # backward-main has the same contraction sizes transposed and, since round 4, the weight gradients inside
+                k["alg_flops_per_step"] = anchor_flops * (2.0 if name == "mlp_bwd" else 1.0)
+                k["TFLOPs"] = round(k["alg_flops_per_step"] / (ms / args.steps * 1e-3) / 1e12, 2)
             if name in traffic:
                 k["pmc_hbm_bytes"] = traffic[name]
             kernels[name] = k
@@ -350,7 +392,9 @@ def main():
                         "traffic": traffic.get(dom), "alg_bytes_per_launch": kernels[dom]["alg_bytes"],
                         "traffic_ratio": (round(traffic[dom] / kernels[dom]["alg_bytes"], 3) if traffic.get(dom) else None),
                         "avg_launch_us": kernels[dom]["avg_us"],
-                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not this run)",
+                        "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, not this run; attached only "
+                                          "when the kernel's source files still hash to what the passes ran on)",
+                        "traffic_stale": traffic_stale or None,
                         # what the kernel is actually limited by: VALU instructions x a NOMINAL 4 cycles / (SIMDs x
                         # duration).  The classes issue at ~2.7 / ~4.7 / ~8.3 cycles, the loop's mix prices at 83 % of
                         # the SIMD time, LDS float atomics take another ~17 % (profiles/r02_blend_bwd_experiments.txt)
@@ -373,21 +417,52 @@ def main():
         # dY 440 + Y 160 + Hcat 600 + X 216 read and dX 212 written by the backward, which since round 4 also forms the weight
         # gradients (mlp3_bwd_wg_kernel: no dZ1 / dZ2 hand-over, no second pass over the rows))
         mlp_group = None
-        fam = [kernels[n_] for n_ in ("mlp_fwd", "mlp_bwd", "mlp_wgrad") if n_ in kernels]
+        fam = [kernels[n_] for n_ in ("mlp_fwd", "mlp_bwd", "mlp_wgrad", "level_mlp_fwd", "level_mlp_bwd", "level_mlp_wgrad") if n_ in kernels]
         if fam:
+            # (the every-row half of the level MLPs runs inside ctx_fwd / ctx_bwd since round 5: its time is in ctx_group_roofline,
+            #  its flops stay in this family's numerator only for the share these launches still compute — the anchor trio and the
+            #  rate subset's 175-output branch)
             fam_ms = sum(k["total_ms"] for k in fam) / max(1, args.steps)
-            tf = 3.0 * mlp_flops / (fam_ms * 1e-3) / 1e12
+            sub_flops = 0.0
+            if args.step_semantics > 10000:
+                for (i_, h_), (ratio, _bpp) in zip(dims, lv):
+                    sub_flops += 2.0 * 0.15 * ratio * N * (i_ * h_ + h_ * 175)
+            tf = 3.0 * (anchor_flops + sub_flops) / (fam_ms * 1e-3) / 1e12
             anchor_alg = n_vis * (212 + 216 + 440 + 600 + 440 + 160 + 600 + 216 + 212)
             anchor_pmc = sum(traffic.get(k_, 0) for k_ in ("mlp3_fwd", "mlp3_bwd")) or None
             mlp_group = {"kernels": "mlp2_* / mlp3_* / wgrad_multi (all launches of a step)", "bound": "mfma",
                          "ms_per_step": round(fam_ms, 3), "share_of_hip_kernel_time": round(fam_ms / max(lib_ms, 1e-9), 3),
-                         "alg_flops_per_step": 3.0 * mlp_flops, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                         "alg_flops_per_step": 3.0 * (anchor_flops + sub_flops), "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                          "anchor_mlp_alg_bytes_per_step": anchor_alg,
                          "anchor_mlp_fwd_bwd_pmc_bytes": anchor_pmc,
                          "traffic_ratio": (round(anchor_pmc / anchor_alg, 3) if anchor_pmc else None),
                          "note": "anchor backward + weight gradients are one launch since round 4 (profiles/r04_mlp3_bwd_wg.txt); the "
                                  "rest is bound by hand-over intermediates and 16-wide tile padding, not by flops"}
+
+        # the context model's level loop as ONE group: every launch of this library under ctx_* / rate_* /
+        # level_mlp_* (level kernels, hyper prior, bookkeeping, rate terms, the rate subset's MLP branch and its weight gradients)
+        ctx_group = None
+        cfam = [(n_, kernels[n_]) for n_ in ("ctx_fwd", "ctx_bwd", "rate_fwd", "rate_bwd", "level_mlp_fwd", "level_mlp_bwd", "level_mlp_wgrad")
+                if n_ in kernels]
+        if cfam and args.step_semantics > 10000:
+            c_ms = sum(k["total_ms"] for _n, k in cfam) / max(1, args.steps)
+            c_launch = sum(k["launches"] for _n, k in cfam) / max(1, args.steps)
+            c_bytes = 2.0 * 794.0 * N                   # 450 B read + 344 B written per anchor per call, the same again backward
+            c_flops = 3.0 * level_flops                 # forward, data gradient, weight gradient
+            hbm_ms, mfma_ms = c_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3, c_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
+            ctx_group = {"kernels": "ctxl_* (fused level kernels), level_rate_*, mlp2_* / wgrad_multi on the rate subset, ctx_gather_bwd, "
+                                    "eb_bits_*, hyper noise, ctx_choose_* (all launches of this library in the level loop; the handful of "
+                                    "ATen launches between them are not timed here: profiles/r05_launch_attribution.txt)",
+                         "ms_per_step": round(c_ms, 3), "launches_per_step": round(c_launch, 1),
+                         "share_of_hip_kernel_time": round(c_ms / max(lib_ms, 1e-9), 3),
+                         "alg_bytes_per_step": c_bytes, "alg_flops_per_step": c_flops,
+                         "hbm_floor_ms": round(hbm_ms, 3), "mfma_floor_ms": round(mfma_ms, 3),
+                         "bound": "mfma" if mfma_ms > hbm_ms else "hbm",
+                         "frac": round(max(hbm_ms, mfma_ms) / max(c_ms, 1e-9), 4),
+                         "pmc_hbm_bytes_per_step": ctx_traffic,
+                         "traffic_ratio": (round(ctx_traffic / c_bytes, 3) if ctx_traffic else None),
+                         "by_scope_ms": {n_: round(k["total_ms"] / max(1, args.steps), 3) for n_, k in cfam}}
 
         # stdout carries exactly ONE line (the JSON below): the codec driver's progress prints (they mirror the
         # reference's) and anything the baseline prints go to stderr
@@ -424,7 +499,8 @@ def main():
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
             "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
-            "roofline": roofline, "blend_roofline": blend, "mlp_group_roofline": mlp_group, "kernels": kernels,
+            "roofline": roofline, "blend_roofline": blend, "mlp_group_roofline": mlp_group, "ctx_group_roofline": ctx_group,
+            "kernels": kernels,
             "hip_kernel_ms_per_step": round(lib_ms, 3),
             "ms_per_step_profiled_pass": round(dt_prof / args.steps * 1e3, 3),
             "cpu_baseline": cpu,

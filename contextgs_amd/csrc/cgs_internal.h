@@ -46,7 +46,9 @@ enum CgsProfId {
     CGS_PROF_FILTER = 0, CGS_PROF_PREPROCESS, CGS_PROF_DEPTH_SORT, CGS_PROF_OFFSETS_SCAN, CGS_PROF_EMIT_PAIRS,
     CGS_PROF_TILE_SORT, CGS_PROF_RANGES, CGS_PROF_BLEND_FWD, CGS_PROF_BLEND_BWD, CGS_PROF_PREPROCESS_BWD,
     CGS_PROF_EXPAND_FWD, CGS_PROF_EXPAND_BWD, CGS_PROF_RATE_FWD, CGS_PROF_RATE_BWD, CGS_PROF_MLP_FWD,
-    CGS_PROF_MLP_BWD, CGS_PROF_MLP_WGRAD, CGS_PROF_CTX_FWD, CGS_PROF_CTX_BWD, CGS_PROF_LOSS_FWD, CGS_PROF_LOSS_BWD, CGS_PROF_COUNT
+    CGS_PROF_MLP_BWD, CGS_PROF_MLP_WGRAD, CGS_PROF_CTX_FWD, CGS_PROF_CTX_BWD, CGS_PROF_LOSS_FWD, CGS_PROF_LOSS_BWD,
+    CGS_PROF_LMLP_FWD, CGS_PROF_LMLP_BWD, CGS_PROF_LMLP_WGRAD,      // the level MLPs of the context model (cgs_mlp2_*, cgs_ctx_level_bwd's reduction)
+    CGS_PROF_COUNT
 };
 extern int g_cgs_prof_on;
 void cgs_prof_begin(int id, hipStream_t stream);

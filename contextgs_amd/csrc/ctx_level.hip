@@ -180,10 +180,22 @@ __device__ __forceinline__ void cl_xrow_store(ClBuf b, uint32_t rowoff, int g, b
     cl_s96(b, cl_sel(on && 4 * g + 3 == R, o), x[NTI - 1]);
 }
 
+// LDS image of the first layer for the transposed chain: W1t[(k * 16 + c) * 8 + t] = W1[16 t + c][k] (zeros in the padding), so
+// that the seven A operands of a k-step (hidden tiles t = 0..6 of lane column c) are two 16-byte reads (conflict-free: eight
+// consecutive lanes cover 64 consecutive dwords) instead of seven 4-byte ones
+#define CL_W1T(XP) ((XP) * 128)
+template <int IN>
+__device__ __forceinline__ void cl_stage_w1t(float *__restrict__ W1t, const float *__restrict__ W1, int tid, int nthr) {
+    for (int i = tid; i < CL_W1T(ClShape<IN>::XP); i += nthr) {
+        const int k = i >> 7, c = (i >> 3) & 15, t = i & 7, j = 16 * t + c;
+        W1t[i] = (t < CL_NT1 && j < CL_HID && k < IN) ? W1[j * IN + k] : 0.f;
+    }
+}
+
 // H^T = relu(W1 X^T + b1): lane (g, c) ends with hidden units 16t + 4g + {0..3} of row c.  Forward and backward call THIS
 // chain, so the backward's recomputed hidden layer has the forward's bits.
 template <int IN>
-__device__ __forceinline__ void cl_layer1(const float *__restrict__ W1s, const float *__restrict__ b1s,
+__device__ __forceinline__ void cl_layer1(const float *__restrict__ W1t, const float *__restrict__ b1s,
                                           const f32x4 (&xb)[ClShape<IN>::NTI], int g, int c, f32x4 (&acc1)[CL_NT1]) {
 #pragma unroll
     for (int t = 0; t < CL_NT1; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -192,9 +204,10 @@ __device__ __forceinline__ void cl_layer1(const float *__restrict__ W1s, const f
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (16 * q + j >= IN) continue;
+            const float *wp = W1t + ((16 * q + 4 * g + j) * 16 + c) * 8;
+            const f32x4 lo = *(const f32x4 *)wp, hi = *(const f32x4 *)(wp + 4);
 #pragma unroll
-            for (int t = 0; t < CL_NT1; ++t)
-                acc1[t] = frag_mfma(W1s[(16 * q + 4 * g + j) * CL_S1 + 16 * t + c], xb[q][j], acc1[t]);
+            for (int t = 0; t < CL_NT1; ++t) acc1[t] = frag_mfma(t < 4 ? lo[t] : hi[t - 4], xb[q][j], acc1[t]);
         }
 #pragma unroll
     for (int t = 0; t < CL_NT1; ++t)
@@ -282,8 +295,30 @@ __device__ __forceinline__ void cl_row_noise(ClRow &u, uint32_t kf, uint32_t ks,
 
 __device__ __forceinline__ float cl_sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
+// timing ablations (tools/variant_lib.sh ... -DCL_ABL=<bits>, experiment builds only; WRONG results):
+//   backward: 1 no dW1 products, 2 no dX products / store, 4 no dx scatter + noise, 8 no side loads, 16 no dW2q products
+//   forward: 32 no noisy values (loads, hash, stores), 64 no X store, 128 no layer 1
+#if defined(CGS_EXPERIMENTS) && defined(CL_ABL)
+#define CL_ON(bit) (!((CL_ABL) & (bit)))
+#else
+#define CL_ON(bit) true
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
-#define CLF_WAVES 8
+#ifndef CLF_WAVES
+#define CLF_WAVES 8               // waves per workgroup of the forward
+#endif
+#ifndef CLF_OCC
+#define CLF_OCC 0                 // > 0: force this many waves per SIMD (register budget) — tuning knob of tools/variant_lib.sh
+#endif
+#ifndef CLF_GRID
+#define CLF_GRID 2                // workgroups per CU in the forward's persistent grid
+#endif
+#if CLF_OCC > 0
+#define CLF_ATTR __attribute__((amdgpu_waves_per_eu(CLF_OCC, CLF_OCC)))
+#else
+#define CLF_ATTR
+#endif
 
 struct ClFwdArgs {
     const float *anchor;          // [n_anchor, 3]
@@ -306,15 +341,15 @@ struct ClFwdArgs {
 struct ClfIdx { int64_t arow, ppos, srow; };
 
 template <int IN>
-__global__ void __launch_bounds__(CLF_WAVES * 64) ctxl_fwd_kernel(ClFwdArgs a) {
+__global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwdArgs a) {
     constexpr int NTI = ClShape<IN>::NTI, XP = ClShape<IN>::XP;
-    __shared__ float W1s[XP * CL_S1];        // [k][j]
+    __shared__ __attribute__((aligned(16))) float W1s[CL_W1T(XP)];        // cl_stage_w1t
     __shared__ float b1s[CL_HP];
     __shared__ float W2qs[3 * CL_HP];
     __shared__ float b2qs[4];
     __shared__ double part[CLF_WAVES][3];
     const int tid = threadIdx.x, nthr = CLF_WAVES * 64;
-    frag_stage_transposed<IN, CL_HID, XP, CL_S1>(W1s, a.W1, tid, nthr);
+    cl_stage_w1t<IN>(W1s, a.W1, tid, nthr);
     for (int i = tid; i < CL_HP; i += nthr) b1s[i] = i < CL_HID ? a.b1[i] : 0.f;
     for (int i = tid; i < 3 * CL_HP; i += nthr) W2qs[i] = (i % CL_HP) < CL_HID ? a.W2q[(i / CL_HP) * CL_HID + (i % CL_HP)] : 0.f;
     if (tid < 4) b2qs[tid] = tid < 3 ? a.b2q[tid] : 0.f;
@@ -365,12 +400,16 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) ctxl_fwd_kernel(ClFwdArgs a) {
         CLB_FENCE();
         // the next tile's operands (their indices arrived during the previous tile) and the indices of the tile after it
         cl_gather_issue<IN>(GB, gw, rn, ix.arow, ix.ppos, g, rn < n);
-        cl_row_issue(x, XB, (uint32_t)ix.srow, g, rn < n);
+        cl_row_issue(x, XB, (uint32_t)ix.srow, g, rn < n && CL_ON(32));
         ix = idx_issue(rn + tstride * 16);
         CLB_FENCE();
-        cl_xrow_store<IN>(bX, (uint32_t)row * (IN * 4), g, valid, xb);
+        if (CL_ON(64)) cl_xrow_store<IN>(bX, (uint32_t)row * (IN * 4), g, valid, xb);
         f32x4 acc1[CL_NT1];
-        cl_layer1<IN>(W1s, b1s, xb, g, c, acc1);
+        if (CL_ON(128)) cl_layer1<IN>(W1s, b1s, xb, g, c, acc1);
+        else {
+#pragma unroll
+            for (int t = 0; t < CL_NT1; ++t) acc1[t] = xb[t % NTI];
+        }
         float qa[3];
         cl_qadj(W2qs, b2qs, acc1, g, qa);
         const float qf = ctx_step(a.q0f, qa[0]), qs = ctx_step(a.q0s, qa[1]), qo = ctx_step(a.q0o, qa[2]);
@@ -380,7 +419,8 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) ctxl_fwd_kernel(ClFwdArgs a) {
         ps += cl_sum4(xc.S);
         po += cl_sum4(xc.O[0]) + cl_sum4(xc.O[1]);
         ClRow u;
-        cl_row_noise(u, kf, ks, ko, row, g);
+        if (CL_ON(32)) cl_row_noise(u, kf, ks, ko, row, g);
+        else u = xc;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -391,7 +431,7 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) ctxl_fwd_kernel(ClFwdArgs a) {
             xc.O[0][j] = xc.O[0][j] + u.O[0][j] * qo;
             xc.O[1][j] = xc.O[1][j] + u.O[1][j] * qo;
         }
-        cl_row_store(xc, YB, (uint32_t)row, g, valid);
+        cl_row_store(xc, YB, (uint32_t)row, g, valid && (CL_ON(32) || xc.F[0][0] == 1234.5f));
     }
     if (a.sums) {        // one atomic per block and quantity, spread over CTX_SUM_SLOTS cache lines
         const double sa = ctx_wave_sum((double)pf), sb = ctx_wave_sum((double)ps), sc = ctx_wave_sum((double)po);
@@ -493,20 +533,26 @@ __device__ __forceinline__ void clb_dx_and_sums(const ClRow &dy, const ClRow &sd
 
 template <int IN>
 __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) ctxl_bwd_kernel(ClBwdArgs a) {
-    constexpr int NTI = ClShape<IN>::NTI, XP = ClShape<IN>::XP, SB = ClShape<IN>::SB;
+    constexpr int NTI = ClShape<IN>::NTI, XP = ClShape<IN>::XP;
     constexpr int NPATCH = CL_NT1 + NTI;                     // per wave: H, then dZ1 0..6, X 7..
-    constexpr int WF = XP * CL_S1 + CL_HP * SB + CL_HP + 3 * CL_HP + 4;
+    // LDS: W1t (layer 1, cl_stage_w1t) | W1n4 [h][c][4]: W1[h][16 v + c], v < 4 | W1n1 [h][c]: W1[h][64 + c] | b1 | W2q | b2q
+    constexpr int N4 = CL_HP * 64, N1 = NTI > 4 ? CL_HP * 16 : 0;
+    constexpr int WF = CL_W1T(XP) + N4 + N1 + CL_HP + 3 * CL_HP + 4;
     constexpr int PF = CLB_WAVES * (NPATCH * CLB_PATCH + 64);      // + the wave's 16 x 4 patch of d qadj
     constexpr int E = CL_HID * IN + CL_HID + 3 * CL_HID + 3;
     static_assert(WF + PF >= E, "the LDS image of the weight gradients reuses the weight region");
     static_assert(WF % 4 == 0, "patches are written with 16-byte stores");
     __shared__ __attribute__((aligned(16))) float lds[WF + PF];
-    float *W1s = lds, *W1n = W1s + XP * CL_S1, *b1s = W1n + CL_HP * SB, *W2qs = b1s + CL_HP, *b2qs = W2qs + 3 * CL_HP;
+    float *W1s = lds, *W1n4 = W1s + CL_W1T(XP), *W1n1 = W1n4 + N4, *b1s = W1n1 + N1, *W2qs = b1s + CL_HP, *b2qs = W2qs + 3 * CL_HP;
     const int tid = threadIdx.x, nthr = CLB_WAVES * 64;
-    frag_stage_transposed<IN, CL_HID, XP, CL_S1>(W1s, a.W1, tid, nthr);         // W1s[k][j] = W1[j][k]
-    for (int i = tid; i < CL_HP * SB; i += nthr) {
-        const int h = i / SB, k = i % SB;
-        W1n[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;                // W1n[h][k]
+    cl_stage_w1t<IN>(W1s, a.W1, tid, nthr);
+    for (int i = tid; i < N4; i += nthr) {
+        const int h = i >> 6, c_ = (i >> 2) & 15, v = i & 3, k = 16 * v + c_;
+        W1n4[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;
+    }
+    for (int i = tid; i < N1; i += nthr) {
+        const int h = i >> 4, k = 64 + (i & 15);
+        W1n1[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;
     }
     for (int i = tid; i < CL_HP; i += nthr) b1s[i] = i < CL_HID ? a.b1[i] : 0.f;
     for (int i = tid; i < 3 * CL_HP; i += nthr) W2qs[i] = (i % CL_HP) < CL_HID ? a.W2q[(i / CL_HP) * CL_HID + (i % CL_HP)] : 0.f;
@@ -537,19 +583,22 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         for (int v = 0; v < NTI; ++v) aw1[t][v] = zero;
     }
 
-    auto op_issue = [&](ClbOps<IN> &op, int64_t row) {
+    // prefetch of the next tile's operands in two stages (register pressure): X and the scalars mid-tile, dy before the dW1
+    // products (its registers are those the dX chain has just released)
+    auto op_issue_x = [&](ClbOps<IN> &op, int64_t row) {
         const bool v = row < n;
         cl_xrow_load<IN>(bX, (uint32_t)row * (IN * 4), g, v, op.xb);
-        cl_row_issue(op.dy, DYB, (uint32_t)row, g, v);
         op.srow = cl_li64(bRows, cl_sel(v, (uint32_t)row * 8));
         op.sm = __builtin_amdgcn_raw_buffer_load_b32(bMap, (int)cl_sel(v, (uint32_t)row * 4), 0, 0);
         op.dq_ext = cl_l32(bQe, cl_sel(v && g < 3, (uint32_t)row * 12 + (uint32_t)g * 4));
     };
+    auto op_issue_dy = [&](ClbOps<IN> &op, int64_t row) { cl_row_issue(op.dy, DYB, (uint32_t)row, g, row < n); };
 
     const int64_t tstride = (int64_t)gridDim.x * CLB_WAVES;
     int64_t tile = (int64_t)blockIdx.x * CLB_WAVES + wave;
     ClbOps<IN> op;
-    op_issue(op, tile < ntiles ? tile * 16 + c : n);
+    op_issue_x(op, tile < ntiles ? tile * 16 + c : n);
+    op_issue_dy(op, tile < ntiles ? tile * 16 + c : n);
     for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16, row = row0 + c;
         const bool valid = row < n;
@@ -558,8 +607,8 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         const uint32_t sm = chosen ? (uint32_t)op.sm : 0u;
         // the rate subset's compact gradients of this row (needed after the first block of MFMAs)
         ClRow sd;
-        cl_row_issue(sd, SDB, sm, g, chosen);
-        const float sq = cl_l32(bSQ, cl_sel(chosen && g < 3, sm * 12 + (uint32_t)g * 4));
+        cl_row_issue(sd, SDB, sm, g, chosen && CL_ON(8));
+        const float sq = cl_l32(bSQ, cl_sel(chosen && g < 3 && CL_ON(8), sm * 12 + (uint32_t)g * 4));
         // [X | 1] towards layout N; H^T = relu(W1 X^T + b1) (the forward's chain, the forward's bits), H towards layout N
         cl_xrow_mask<IN>(g, op.xb);
 #pragma unroll
@@ -572,7 +621,8 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         cl_qadj(W2qs, b2qs, acc1, g, qa);
         // dx = dy (+ rate side), scattered to the parameter rows; sum_c dx u per tensor
         float af, as, ao;
-        clb_dx_and_sums(op.dy, sd, DXB, (uint32_t)op.srow, kf, ks, ko, row, g, valid, af, as, ao);
+        if (CL_ON(4)) clb_dx_and_sums(op.dy, sd, DXB, (uint32_t)op.srow, kf, ks, ko, row, g, valid, af, as, ao);
+        else { af = op.dy.F[0][0] + sd.F[0][0]; as = op.dy.S[0]; ao = op.dy.O[0][0]; }
         // lane g < 3 holds the external + side gradient of Q[row, g]: bring all three to every lane of the row
         const float ext = op.dq_ext + sq;
         const float e0 = __shfl(ext, c, 64), e1 = __shfl(ext, 16 + c, 64), e2 = __shfl(ext, 32 + c, 64);
@@ -587,8 +637,8 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         // this tile's global operands are consumed: the next tile's are fetched behind ~300 MFMAs
         CLB_FENCE();
         f32x4 dxs[NTI];
-        cl_xrow_load<IN>(bSub, sm * (IN * 4), g, chosen, dxs);
-        op_issue(op, row + tstride * 16);
+        cl_xrow_load<IN>(bSub, sm * (IN * 4), g, chosen && CL_ON(8), dxs);
+        op_issue_x(op, row + tstride * 16);
         CLB_FENCE();
         // rows 4g + r of this tile that exist (the ones columns of [X | 1] and [H | 1]); d qadj in layout N
         f32x4 ones, dqn;
@@ -603,8 +653,10 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         for (int t = 0; t < CL_NT1; ++t) {
             f32x4 hn = clb_get(patches + t * CLB_PATCH, g, c);
             if (t == CL_NT1 - 1 && c == CL_HID - 16 * (CL_NT1 - 1)) hn = ones;           // hidden index 100 of [H | 1]
+            if (CL_ON(16)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aw2[t] = frag_mfma(hn[r], dqn[r], aw2[t]);
+                for (int r = 0; r < 4; ++r) aw2[t] = frag_mfma(hn[r], dqn[r], aw2[t]);
+            } else aw2[t] += hn;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int hh = 16 * t + 4 * g + r;
@@ -619,30 +671,39 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         f32x4 adx[NTI];
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] = zero;
+        if (CL_ON(2)) {
 #pragma unroll
-        for (int t = 0; t < CL_NT1; ++t)
+            for (int t = 0; t < CL_NT1; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (16 * t + r >= CL_HID) continue;
+                for (int r = 0; r < 4; ++r) {
+                    if (16 * t + r >= CL_HID) continue;
+                    const int hc = (16 * t + 4 * g + r) * 16 + c;
+                    const f32x4 w4 = *(const f32x4 *)(W1n4 + hc * 4);
 #pragma unroll
-                for (int v = 0; v < NTI; ++v)
-                    adx[v] = frag_mfma(W1n[(16 * t + 4 * g + r) * SB + 16 * v + c], acc1[t][r], adx[v]);
-            }
+                    for (int v = 0; v < NTI && v < 4; ++v) adx[v] = frag_mfma(w4[v], acc1[t][r], adx[v]);
+                    if (NTI > 4) adx[NTI - 1] = frag_mfma(W1n1[hc], acc1[t][r], adx[NTI - 1]);
+                }
+        }
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] += dxs[v];          // (a dx_sub piece that runs past its row end is cut by the store)
-        cl_xrow_store<IN>(bdX, (uint32_t)row * (IN * 4), g, valid, adx);
+        cl_xrow_store<IN>(bdX, (uint32_t)row * (IN * 4), g, valid && (CL_ON(2) || adx[0][0] == 1234.5f), adx);
         // dW1 += dZ1^T [X | 1]
         f32x4 xn[NTI];
 #pragma unroll
         for (int q = 0; q < NTI; ++q) xn[q] = clb_get(patches + (CL_NT1 + q) * CLB_PATCH, g, c);
         if (c == IN - 16 * (NTI - 1)) xn[NTI - 1] = ones;                 // column IN of [X | 1]
+        CLB_FENCE();
+        op_issue_dy(op, row + tstride * 16);
+        CLB_FENCE();
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t) {
             const f32x4 dn = clb_get(patches + t * CLB_PATCH, g, c);
+            if (CL_ON(1)) {
 #pragma unroll
-            for (int v = 0; v < NTI; ++v)
+                for (int v = 0; v < NTI; ++v)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
+                    for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
+            } else aw1[t][0] += dn + xn[t % NTI];
         }
     }
     // ---- the workgroup's image [dW1 100 x IN | db1 100 | dW2q 3 x 100 | db2q 3]: the waves take turns (fixed order) ----
@@ -721,7 +782,7 @@ extern "C" int cgs_ctx_level_fwd(int in_dim, const float *anchor, int64_t n_anch
     a.q0f = q0f; a.q0s = q0s; a.q0o = q0o;
     a.X = X; a.yf = yf; a.ys = ys; a.yo = yo; a.Q = Q; a.sums = sums3;
     const int64_t tiles = (n + 15) / 16, want = (tiles + CLF_WAVES - 1) / CLF_WAVES;
-    const int64_t cap = 2ll * cl_cus();
+    const int64_t cap = (int64_t)CLF_GRID * cl_cus();
     const unsigned grid = (unsigned)(want < cap ? want : cap);
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
     if (in_dim == 71) hipLaunchKernelGGL((ctxl_fwd_kernel<71>), dim3(grid), dim3(CLF_WAVES * 64), 0, (hipStream_t)stream, a);
@@ -770,7 +831,7 @@ extern "C" int cgs_ctx_level_bwd(int in_dim, const float *X, const float *W1, co
         else hipLaunchKernelGGL((ctxl_bwd_kernel<15>), dim3((unsigned)grid), dim3(CLB_WAVES * 64), 0, (hipStream_t)stream, a);
         CGS_CHECK_HIP(hipGetLastError());
     }
-    CgsProfScope prof(CGS_PROF_MLP_WGRAD, (hipStream_t)stream);
+    CgsProfScope prof(CGS_PROF_LMLP_WGRAD, (hipStream_t)stream);
     const CgsWgProduct prods[2] = {{nullptr, 0, CL_HID, nullptr, 0, in_dim, dW1, db1}, {nullptr, 0, 3, nullptr, 0, CL_HID, dW2q, db2q}};
     return cgs_launch_wgrad_reduce((const float *)scratch, (int)grid, prods, 2, (hipStream_t)stream);
 }

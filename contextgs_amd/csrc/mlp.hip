@@ -319,7 +319,7 @@ extern "C" int cgs_mlp2_forward(int in, int hid, int out, int act, const float *
     if (n < 0) { cgs_set_error("mlp2_forward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !W1 || !b1 || !W2 || !b2 || !Y) { cgs_set_error("mlp2_forward: NULL"); return CGS_ERR_ARG; }
-    CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
+    CgsProfScope prof(CGS_PROF_LMLP_FWD, (hipStream_t)stream);
 #define X_(I, Hh, O, A) \
     if (in == I && hid == Hh && out == O && act == A) return launch_fwd<I, Hh, O, A>(X, ldx, W1, b1, W2, b2, Y, ldy, H, n, (hipStream_t)stream);
     MLP_CONFIGS(X_)
@@ -380,18 +380,18 @@ static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X,
         // no saved hidden layer: recompute it (instances for the tiny-output shapes only, csrc/mlp_small.hip)
         if (act != ACT_NONE || !b1 || !scratch) { cgs_set_error("mlp2_backward: H == NULL needs act 0, b1 and scratch"); return CGS_ERR_ARG; }
         {
-            CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
+            CgsProfScope prof(CGS_PROF_LMLP_BWD, stream);
             rc = cgs_launch_mlp2_bwd_recompute(in, hid, out, X, ldx, W1, b1, W2, dY, ldy, dX, lddx, accumulate_dx, dZ1, dW2,
                                                db2, n, num_cus(), scratch, scratch_bytes, stream);
         }
         if (rc == -1) { cgs_set_error("mlp2_backward: no recompute instance for %d -> %d -> %d", in, hid, out); return CGS_ERR_ARG; }
         if (rc || data_only) return rc;
-        CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+        CgsProfScope prof(CGS_PROF_LMLP_WGRAD, stream);
         const CgsWgProduct prod = {dZ1, hid, hid, X, ldx, in, dW1, db1};
         return cgs_launch_wgrad_multi(&prod, 1, n, num_cus(), scratch, scratch_bytes, stream);
     }
     {
-        CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
+        CgsProfScope prof(CGS_PROF_LMLP_BWD, stream);
         bool found = false;
 #define X_(I, Hh, O, A)                                                                                              \
     if (!found && in == I && hid == Hh && out == O && act == A) {                                                     \
@@ -403,7 +403,7 @@ static int mlp2_backward_impl(int in, int hid, int out, int act, const float *X,
         if (!found) { cgs_set_error("mlp2_backward: no kernel instance for %d -> %d -> %d act %d", in, hid, out, act); return CGS_ERR_ARG; }
         if (rc || data_only) return rc;
     }
-    CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+    CgsProfScope prof(CGS_PROF_LMLP_WGRAD, stream);
     const float *P2 = (act == ACT_NONE || !dZ2) ? dY : dZ2;
     const int64_t ldp2 = (act == ACT_NONE || !dZ2) ? ldy : out;
     const CgsWgProduct prods[2] = {{P2, ldp2, out, H, hid, hid, dW2, db2}, {dZ1, hid, hid, X, ldx, in, dW1, db1}};
@@ -420,7 +420,7 @@ extern "C" int cgs_mlp2_wgrad(int in, int hid, int out, const float *X, int64_t 
     if (n < 0) { cgs_set_error("mlp2_wgrad: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !dZ1 || !dW1 || !db1 || (H && (!dZ2 || !dW2 || !db2))) { cgs_set_error("mlp2_wgrad: NULL"); return CGS_ERR_ARG; }
-    CgsProfScope prof(CGS_PROF_MLP_WGRAD, stream);
+    CgsProfScope prof(CGS_PROF_LMLP_WGRAD, stream);
     if (!H) {
         const CgsWgProduct prod = {dZ1, hid, hid, X, ldx, in, dW1, db1};
         return cgs_launch_wgrad_multi(&prod, 1, n, num_cus(), scratch, scratch_bytes, stream);

@@ -16,7 +16,8 @@ int64_t g_launches[CGS_PROF_COUNT];
 const char *const kNames[CGS_PROF_COUNT] = {
     "filter", "preprocess", "depth_sort", "offsets_scan", "emit_pairs", "tile_sort", "ranges",
     "blend_fwd", "blend_bwd", "preprocess_bwd", "expand_fwd", "expand_bwd", "rate_fwd", "rate_bwd",
-    "mlp_fwd", "mlp_bwd", "mlp_wgrad", "ctx_fwd", "ctx_bwd", "loss_fwd", "loss_bwd"};
+    "mlp_fwd", "mlp_bwd", "mlp_wgrad", "ctx_fwd", "ctx_bwd", "loss_fwd", "loss_bwd",
+    "level_mlp_fwd", "level_mlp_bwd", "level_mlp_wgrad"};
 
 Pair get_pair() {
     if (!g_pool.empty()) { Pair p = g_pool.back(); g_pool.pop_back(); return p; }

@@ -478,25 +478,16 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     return xyz, color, opacity, scaling, rot, time_sub
 
 
-_ZERO_POOL = {}
-
-
 class _ZeroPoints(torch.autograd.Function):
     """The reference's `screenspace_points` (gaussian_renderer/__init__.py:168: a zero [P,3] non-leaf tensor whose .grad
-    receives the 2-D position gradients) without its per-view fill + add: the values are never written by anyone (the
-    rasterizer only fills the GRADIENT), so every view gets a view of one per-device zero buffer, wrapped in an
-    autograd node so that it is a fresh non-leaf tensor that requires grad, as in the reference.  READ-ONLY by contract: all
-    views' tensors alias the same storage (the reference's is an independent zeros_like + 0); nothing on this path writes it,
-    and a caller that did would corrupt the zeros of every later view."""
+    receives the 2-D position gradients): a FRESH zero tensor per view, as in the reference — independent storage, so a caller
+    that writes into one view's tensor does not touch another's (rounds 3-4 handed every view a slice of one pooled zero
+    buffer, "read-only by contract") — wrapped in an autograd node so that it is a non-leaf tensor that requires
+    grad without the reference's `+ 0` launch.  One fill of 12 B per Gaussian per view."""
 
     @staticmethod
     def forward(ctx, like, token):
-        P = int(like.shape[0])
-        dev = like.device
-        buf = _ZERO_POOL.get(dev)
-        if buf is None or buf.shape[0] < P:
-            buf = _ZERO_POOL[dev] = torch.zeros(max(P, 1) * 5 // 4, 3, dtype=torch.float32, device=dev)
-        return buf[:P]
+        return torch.zeros(int(like.shape[0]), 3, dtype=torch.float32, device=like.device)
 
     @staticmethod
     def backward(ctx, _g):

@@ -151,6 +151,8 @@ def test_levels_and_context_model(tag, N, seed):
         for a, b, step in ((f, g["msg_feat"], 1.0), (s, g["msg_scaling"], 1e-3), (o, g["msg_offsets"], 0.2)):
             d = np.abs(_sub(g, a.cpu().numpy()) - b)
             bad = d > 1e-4 * step
+            print(f"[allowance] msg eval {tag} step {step:g}: {int(bad.sum())} of {bad.size} entries off by a quantisation step "
+                  f"(allowed {int(5e-4 * bad.size)}), max |diff| {float(d.max()):.3g} (allowed {2.02 * step:.3g})")
             assert bad.mean() <= 5e-4, bad.mean()          # rounding-boundary flips only ...
             assert d.max() <= 2.02 * step                  # ... and a flip moves a value by ONE step Q < 2 Q0
         sums = cm.multi_scale_generating(pc, anchor[mab], pc._hyper_latent[mab], pc._anchor_feat[mab], pc._offset[mab],
@@ -178,17 +180,24 @@ def test_generate_neural_gaussians(tag, N, seed):
         for a, key in outs:
             b = g[key]
             d = np.abs(_sub(g, a.cpu().numpy()) - b)
-            assert (d > 1e-4 * (1 + np.abs(b))).mean() <= 2e-3, key
+            out_ = d > 1e-4 * (1 + np.abs(b))
+            print(f"[allowance] expansion eval {tag} {key}: {int(out_.sum())} of {out_.size} outside 1e-4 (allowed {int(2e-3 * out_.size)})")
+            assert out_.mean() <= 2e-3, key
     else:
         # a rounding-boundary flip in the context model moved a borderline opacity across 0: a Gaussian appears or
         # disappears.  At most a handful, and every OTHER row must still match: align the two row lists on xyz
+        print(f"[allowance] expansion eval {tag}: {n_got} Gaussians vs {n_ref} in the fixture (allowed difference {max(2, n_ref // 2000)}); "
+              "rows aligned on xyz")
         assert abs(n_got - n_ref) <= max(2, n_ref // 2000)
         assert "stride" not in g.files, "row alignment needs the full fixture"
         pairs = _align(xyz.cpu().numpy(), g["ev_xyz"], 1e-4, max(4, n_ref // 1000))
         assert pairs.shape[0] >= n_ref - max(4, n_ref // 1000)
         for a, key in outs[1:]:
             a_, b_ = a.cpu().numpy()[pairs[:, 0]], g[key][pairs[:, 1]]
-            assert (np.abs(a_ - b_) > 1e-4 * (1 + np.abs(b_))).mean() <= 2e-3, key
+            out_ = np.abs(a_ - b_) > 1e-4 * (1 + np.abs(b_))
+            print(f"[allowance] expansion eval {tag} {key} (aligned rows): {int(out_.sum())} of {out_.size} outside 1e-4 "
+                  f"(allowed {int(2e-3 * out_.size)})")
+            assert out_.mean() <= 2e-3, key
 
     pc.train()
     res = generate_neural_gaussians(cam, pc, vis, is_training=True, step=1000)

@@ -43,8 +43,23 @@ for k, (n, tot) in rd.items():
     base = k.replace("void ", "").split("<")[0].strip()
     if base in names and k in wr:
         tr[names[base]] = int((2 * tot / n + wr[k][1] / wr[k][0]) * 1024)
+# the context model's level loop as a group: (2 FETCH + WRITE) of every dispatch of its kernels, per training step (one step =
+# two dispatches of the level-0/1 backward kernel, or of noise_quant_bwd on the separate-launch path)
+ctx_keys = ("ctxl_", "level_rate_", "mlp2_", "wgrad_multi", "wgrad_reduce", "wgrad_tail", "mlp_small_reduce", "ctx_gather_bwd", "eb_bits_", "rowcat_",
+            "rowgather4", "gather_rows_segmented", "hyper_noise", "ctx_choose", "noise_quant_", "means_finalize", "rate_finish")
+tot_ctx, steps_ctx = 0.0, 0
+for k, (n, tot) in rd.items():
+    if any(s_ in k for s_ in ctx_keys) and k in wr:
+        tot_ctx += (2 * tot + wr[k][1]) * 1024
+    if "ctxl_bwd_kernel<71>" in k:
+        steps_ctx = n // 2
+import hashlib, os
+csrc = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "contextgs_amd", "csrc")
+digests = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h", ".cpp"))}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch",
-           "workload": "bench.py default (1M anchors, 1920x1080, full training step)", "bytes_per_launch": tr},
+           "workload": "bench.py default (1M anchors, 1920x1080, full training step)", "bytes_per_launch": tr,
+           "ctx_group_bytes_per_step": (int(tot_ctx / steps_ctx) if steps_ctx else None), "ctx_group_steps": steps_ctx,
+           "file_digests": digests},
           open("gpurun_out/pmc_traffic.json", "w"), indent=1)
 print(open("gpurun_out/pmc_hbm_summary.txt").read()[:3000])
 print(json.dumps(tr))
