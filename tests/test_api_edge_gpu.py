@@ -71,3 +71,36 @@ def test_interleaved_count_launches_are_refused():
     with pytest.raises(RuntimeError, match="interleave"):
         v1.wait()
     assert torch.equal(v2.wait(), torch.nonzero(~m1)[:, 0]) and v2.wait() is v2.wait()
+
+
+def test_launch_wait_tickets_are_checked_by_the_library():
+    """the guard of the *_launch / *_wait pairs lives in the C ABI, not only in renderer.py — every launch hands out
+    a ticket, a wait with a ticket that a later launch of the same kind has replaced fails with an error instead of returning that
+    launch's count; so does a ticket of another kind, and 0."""
+    import ctypes as C
+    from contextgs_amd import _lib
+    L = _lib.lib()
+    dev = "cuda"
+    m1 = (torch.rand(5000, device=dev) < 0.3).view(torch.uint8)
+    m2 = (torch.rand(700, device=dev) < 0.5).view(torch.uint8)
+
+    def launch(m):
+        idx = torch.empty(m.numel(), dtype=torch.int64, device=dev)
+        ws = torch.empty(int(L.cgs_nonzero_scratch_bytes(m.numel())), dtype=torch.uint8, device=dev)
+        t = C.c_uint64(0)
+        _lib.check(L.cgs_nonzero_launch(_lib.ptr(m), m.numel(), _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.current_stream(),
+                                        C.byref(t)), "cgs_nonzero_launch")
+        return t, idx, ws
+
+    t1, _i1, _w1 = launch(m1)
+    t2, i2, _w2 = launch(m2)
+    assert t1.value != 0 and t2.value != 0 and t1.value != t2.value
+    cnt = C.c_int64(-1)
+    assert L.cgs_nonzero_wait(t1, C.byref(cnt)) != 0 and b"stale ticket" in L.cgs_last_error()
+    assert L.cgs_nonzero_wait(C.c_uint64(0), C.byref(cnt)) != 0
+    assert L.cgs_expand_count_wait(t2, C.byref(cnt)) != 0            # a nonzero ticket is not an expand_count ticket
+    _lib.check(L.cgs_nonzero_wait(t2, C.byref(cnt)), "cgs_nonzero_wait")
+    assert cnt.value == int(m2.sum()) and torch.equal(i2[:cnt.value], torch.nonzero(m2)[:, 0])
+    _lib.check(L.cgs_nonzero_wait(t2, C.byref(cnt)), "cgs_nonzero_wait")      # waiting twice on the current ticket is fine
+    assert cnt.value == int(m2.sum())
+    assert L.cgs_nonzero_launch(_lib.ptr(m1), m1.numel(), None, None, 0, _lib.current_stream(), None) != 0     # NULL ticket
