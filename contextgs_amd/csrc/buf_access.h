@@ -1,0 +1,87 @@
+// Branch-free global access through RAW BUFFER instructions (hardware bounds check), shared by the fused level kernels
+// (ctx_level.hip) and the fused anchor-MLP kernels (mlp3.hip).
+//
+// A lane that has nothing to load — a row past the end, a piece another lane group owns — issues the same instruction with an
+// out-of-range offset and gets zeros: NO branch around the load, so no exec-mask join at which the compiler has to wait for it
+// (predicated global loads cost a full `s_waitcnt vmcnt(0)` at every join, which serialises a prefetch into its pieces:
+// profiles/r05_ctx_level.txt).  Offsets are 32-bit: an operand must stay below CL_MAX_BYTES (the host checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mlp_frag.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t ClBuf;
+#define CL_OOB 0xFFFFFF00u              // an offset no buffer reaches (the host refuses buffers >= 0xFFFFF000 bytes)
+#define CL_MAX_BYTES 0xFFFFF000ull
+
+__device__ __forceinline__ ClBuf cl_buf(const void *p, uint64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, p ? (int)(uint32_t)bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ f32x4 cl_l128(ClBuf b, uint32_t off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0));
+}
+// (results and operands cross between int and float vectors by WHOLE-vector bit casts only: extracting .x / .y / .z from the
+//  builtins' int vectors came back as the first component replicated — tools/micro/buf_probe.hip)
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 cl_l96(ClBuf b, uint32_t off) {
+    const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(b, (int)off, 0, 0));
+    return (f32x4){v[0], v[1], v[2], 0.f};
+}
+__device__ __forceinline__ f32x4 cl_l64(ClBuf b, uint32_t off) {
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0));
+    return (f32x4){v[0], v[1], 0.f, 0.f};
+}
+__device__ __forceinline__ float cl_l32(ClBuf b, uint32_t off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)off, 0, 0));
+}
+__device__ __forceinline__ int64_t cl_li64(ClBuf b, uint32_t off) {
+    return __builtin_bit_cast(int64_t, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0));
+}
+__device__ __forceinline__ void cl_s128(ClBuf b, uint32_t off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b, (int)off, 0, 0);
+}
+__device__ __forceinline__ void cl_s96(ClBuf b, uint32_t off, f32x4 v) {
+    const f32x3 t = (f32x3){v[0], v[1], v[2]};
+    __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3, t), b, (int)off, 0, 0);
+}
+__device__ __forceinline__ void cl_s64(ClBuf b, uint32_t off, f32x4 v) {
+    const f32x2 t = (f32x2){v[0], v[1]};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, t), b, (int)off, 0, 0);
+}
+__device__ __forceinline__ void cl_s32(ClBuf b, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, (int)off, 0, 0);
+}
+__device__ __forceinline__ uint32_t cl_sel(bool on, uint32_t off) { return on ? off : CL_OOB; }
+
+
+// columns [16q + 4g, +4) of a row of DIM floats at byte offset `rowoff` of buffer b (the fragment layout of mlp_frag.h); a piece
+// that starts inside the row but ends behind it carries the next row's first values: frag_bmask4 zeroes them at use
+template <int DIM>
+__device__ __forceinline__ f32x4 frag_bload4(ClBuf b, uint32_t rowoff, int q, int g, bool on) {
+    const int col0 = 16 * q + 4 * g;
+    return cl_l128(b, cl_sel(on && col0 < DIM, rowoff + (uint32_t)col0 * 4));
+}
+template <int DIM>
+__device__ __forceinline__ f32x4 frag_bmask4(f32x4 v, int q, int g) {
+    if (16 * q + 15 >= DIM) {          // only the tile that holds the row end
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (16 * q + 4 * g + j >= DIM) v[j] = 0.f;
+    }
+    return v;
+}
+// store of such a piece: 16 bytes when it lies inside the row, 12 / 8 / 4 when the row ends inside it
+template <int DIM>
+__device__ __forceinline__ void frag_bstore4(ClBuf b, uint32_t rowoff, int q, int g, bool on, f32x4 v) {
+    const int col0 = 16 * q + 4 * g;
+    const uint32_t o = rowoff + (uint32_t)col0 * 4;
+    if (16 * q + 15 < DIM) { cl_s128(b, cl_sel(on, o), v); return; }
+    cl_s128(b, cl_sel(on && col0 + 3 < DIM, o), v);
+    if (DIM % 4 == 3) cl_s96(b, cl_sel(on && col0 + 3 == DIM, o), v);
+    if (DIM % 4 == 2) cl_s64(b, cl_sel(on && col0 + 2 == DIM, o), v);
+    if (DIM % 4 == 1) cl_s32(b, cl_sel(on && col0 + 1 == DIM, o), v[0]);
+}

@@ -8,6 +8,7 @@
 // access per lane for every activation read/write — mlp_frag.h).
 #include "cgs_internal.h"
 #include "mlp_frag.h"
+#include "buf_access.h"
 
 #define M3_IN 54
 #define M3_HID 50
@@ -471,19 +472,33 @@ __device__ __forceinline__ f32x4 m3w_f2n(float *patch, f32x4 v, int g, int c) {
     return o;
 }
 
-// operands of one head for one 16-row tile (layout F), fetched one head ahead of their use
+// operands of one head for one 16-row tile (layout F), fetched one head ahead of their use — through raw buffer loads (round 5,
+// buf_access.h): no branch around a load, so no exec-mask join that drains the load queue in the middle of the prefetch (the
+// predicated global loads of round 4 cost 26 `s_waitcnt vmcnt(0)` per tile); the pieces that run past a row end are zeroed by
+// mask() when the head consumes them
+struct M3wBufs { ClBuf dY[3], Y[3], H, X; };
 template <int OUT, int ACT>
 struct M3wOps {
     static constexpr int NT2 = (OUT + 15) / 16;
     f32x4 dy[NT2], y[ACT != FRAG_ACT_NONE ? NT2 : 1], h[M3_NT1];
-    __device__ __forceinline__ void load(const M3Head &hd, int head, const float *__restrict__ Hcat, int64_t row, int g, bool valid) {
+    __device__ __forceinline__ void load(const M3wBufs &B, int head, int64_t row, int g, bool valid) {
+        const uint32_t ro = (uint32_t)row * (OUT * 4), rh = (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4;
 #pragma unroll
         for (int u = 0; u < NT2; ++u) {
-            dy[u] = frag_load4<OUT>(hd.dY + row * OUT, u, g, valid);
-            if (ACT != FRAG_ACT_NONE) y[u] = frag_load4<OUT>(hd.Y + row * OUT, u, g, valid);
+            dy[u] = frag_bload4<OUT>(B.dY[head], ro, u, g, valid);
+            if (ACT != FRAG_ACT_NONE) y[u] = frag_bload4<OUT>(B.Y[head], ro, u, g, valid);
         }
 #pragma unroll
-        for (int t = 0; t < M3_NT1; ++t) h[t] = frag_load4<M3_HID>(Hcat + row * M3_HLD + M3_HPITCH * head, t, g, valid);
+        for (int t = 0; t < M3_NT1; ++t) h[t] = frag_bload4<M3_HID>(B.H, rh, t, g, valid);
+    }
+    __device__ __forceinline__ void mask(int g) {
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            dy[u] = frag_bmask4<OUT>(dy[u], u, g);
+            if (ACT != FRAG_ACT_NONE) y[u] = frag_bmask4<OUT>(y[u], u, g);
+        }
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) h[t] = frag_bmask4<M3_HID>(h[t], t, g);
     }
 };
 
@@ -500,11 +515,12 @@ __device__ __forceinline__ f32x4 m3w_get(const float *patch, int g, int c) {
 // a block of MFMAs in front of its first use; `prefetch` (the next head's global loads) is issued after the first batch of
 // transposes.
 template <int OUT, int ACT, class Prefetch>
-__device__ __forceinline__ void m3w_head(const float *lds, float *patches, const M3wOps<OUT, ACT> &op, f32x4 ones, int g, int c,
+__device__ __forceinline__ void m3w_head(const float *lds, float *patches, M3wOps<OUT, ACT> &op, f32x4 ones, int g, int c,
                                          const f32x4 (&xn)[M3_NTI], f32x4 (&adx)[M3_NTI],
                                          f32x4 (&aw2)[(OUT + 15) / 16][M3_NT1], f32x4 (&aw1)[M3_NT1][M3_NTI], Prefetch prefetch) {
     using L = M3BwdLds<OUT>;
     const float *W2n = lds, *W1n = W2n + L::OP * L::SA;
+    op.mask(g);
     f32x4 b[L::NT2];
 #pragma unroll
     for (int u = 0; u < L::NT2; ++u) {
@@ -605,6 +621,15 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
     }
     const int64_t tstride = (int64_t)gridDim.x * M3W_WAVES;
     int64_t tile = (int64_t)blockIdx.x * M3W_WAVES + wave;
+    const uint64_t nb = (uint64_t)n;
+    M3wBufs B;
+    B.dY[0] = cl_buf(h0.dY, nb * 40); B.dY[1] = cl_buf(h1.dY, nb * 120); B.dY[2] = cl_buf(h2.dY, nb * 280);
+    B.Y[0] = cl_buf(h0.Y, nb * 40); B.Y[1] = cl_buf(h1.Y, nb * 120); B.Y[2] = cl_buf(h2.Y, nb * 280);
+    B.H = cl_buf(Hcat, nb * (M3_HLD * 4));
+    B.X = cl_buf(X, nb > 0 ? ((nb - 1) * (uint64_t)ldx + M3_IN) * 4 : 0);
+    const ClBuf bSrc = cl_buf(ROWS ? R.src_row : nullptr, nb * 8), bAnc = cl_buf(ROWS ? R.anchor : nullptr, nb * 12);
+    const float cam0 = ROWS ? R.cam[0] : 0.f, cam1 = ROWS ? R.cam[1] : 0.f, cam2 = ROWS ? R.cam[2] : 0.f;
+    const uint32_t ldx4 = (uint32_t)ldx * 4;
     M3wOps<10, 1> op0;
     M3wOps<30, 2> op1;
     M3wOps<70, 0> op2;
@@ -612,9 +637,9 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
     {
         const int64_t row = tile * 16 + c;
         const bool v0 = tile < ntiles && row < n;
-        op0.load(h0, 0, Hcat, row, g, v0);
+        op0.load(B, 0, row, g, v0);
 #pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + row * ldx, q, g, v0);
+        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, v0);
     }
     for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16;
@@ -628,28 +653,31 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
         for (int r = 0; r < 4; ++r) ones[r] = row0 + 4 * g + r < n ? 1.f : 0.f;
 #if !M3W_XPREFETCH
 #pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + (row0 + c) * ldx, q, g, valid);
+        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)(row0 + c) * ldx4, q, g, valid);
 #endif
+        // (ROWS) what the end of the tile needs from memory, issued here: the row's source index and its anchor
+        const int64_t srow_pre = ROWS ? cl_li64(bSrc, cl_sel(valid, (uint32_t)(row0 + c) * 8)) : 0;
+        const f32x4 anc_pre = ROWS ? cl_l96(bAnc, cl_sel(valid && g == 0, (uint32_t)(row0 + c) * 12)) : zero;
 #pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) m3w_put(patches + q * M3W_PATCH, xf[q], g, c);
+        for (int q = 0; q < M3_NTI; ++q) m3w_put(patches + q * M3W_PATCH, frag_bmask4<M3_IN>(xf[q], q, g), g, c);
 #pragma unroll
         for (int q = 0; q < M3_NTI; ++q) xn[q] = m3w_get(patches + q * M3W_PATCH, g, c);
         if (c == M3_IN - 48) xn[3] = ones;                      // column 54 of [X | 1]
         f32x4 adx[M3_NTI];
 #pragma unroll
         for (int v = 0; v < M3_NTI; ++v) adx[v] = zero;
-        m3w_head<10, 1>(l0, patches, op0, ones, g, c, xn, adx, a2_0, a1_0, [&]() { op1.load(h1, 1, Hcat, row0 + c, g, valid); });
-        m3w_head<30, 2>(l1, patches, op1, ones, g, c, xn, adx, a2_1, a1_1, [&]() { op2.load(h2, 2, Hcat, row0 + c, g, valid); });
+        m3w_head<10, 1>(l0, patches, op0, ones, g, c, xn, adx, a2_0, a1_0, [&]() { op1.load(B, 1, row0 + c, g, valid); });
+        m3w_head<30, 2>(l1, patches, op1, ones, g, c, xn, adx, a2_1, a1_1, [&]() { op2.load(B, 2, row0 + c, g, valid); });
         m3w_head<70, 0>(l2, patches, op2, ones, g, c, xn, adx, a2_2, a1_2, [&]() {
-            op0.load(h0, 0, Hcat, rown, g, validn);
+            op0.load(B, 0, rown, g, validn);
 #if M3W_XPREFETCH
 #pragma unroll
-            for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_load4<M3_IN>(X + rown * ldx, q, g, validn);
+            for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)rown * ldx4, q, g, validn);
 #endif
         });
         if (ROWS) {
             const int64_t row = row0 + c;
-            const int64_t srow = valid ? R.src_row[row] : 0;
+            const int64_t srow = valid ? srow_pre : 0;
             float *dst = R.d_feat_src + srow * M3_HID;
 #pragma unroll
             for (int v = 0; v < 3; ++v)
@@ -659,8 +687,7 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
                 dst[48] = adx[3][0];
                 dst[49] = adx[3][1];
                 const float dvx = adx[3][2], dvy = adx[3][3], dvz = z52, dd = z53;
-                const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1],
-                            uz = R.anchor[3 * row + 2] - R.cam[2];
+                const float ux = anc_pre[0] - cam0, uy = anc_pre[1] - cam1, uz = anc_pre[2] - cam2;
                 const float dist = sqrtf(ux * ux + uy * uy + uz * uz), inv = 1.f / dist;
                 const float vx = ux * inv, vy = uy * inv, vz = uz * inv;
                 const float dot = vx * dvx + vy * dvy + vz * dvz;
