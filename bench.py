@@ -233,9 +233,18 @@ def main():
         return cams[(i * world + rank) % n_views]
 
     sync = None
+    dist_report = None
     if dist_on:
+        from contextgs_amd import dist as cgs_dist
         from contextgs_amd.dist import GradientSync
         sync = GradientSync(params, average=True)
+        # BEFORE any timed region: who is in the group, and what one gradient all-reduce costs on this node (VERDICT r4 item 7;
+        # to be read against DESIGN.md section 5's prediction)
+        big_bytes = sum(p.numel() * 4 for p in params if p.numel() >= cgs_dist.BIG_TENSOR)
+        small_bytes = sum(p.numel() * 4 for p in params if p.numel() < cgs_dist.BIG_TENSOR)
+        dist_report = cgs_dist.diagnostics(big_bytes, max(4, small_bytes))
+        if rank == 0:
+            print("[bench] process group:", json.dumps(dist_report), file=sys.stderr, flush=True)
 
     full = lambda i: one_step(pc, cam_of(i), pipe, bg, w, args.step_semantics, params, sync)
     raster = lambda i: one_step(pc, cam_of(i), pipe, bg, w, 1000, params, sync)
@@ -247,7 +256,11 @@ def main():
     # second, separately timed pass over the same K steps with it ON (HIP events on the launch stream around each kernel)
     L.cgs_prof_enable(0)
     del _HOST_S[:]
+    if sync is not None:
+        sync.exposure_report()              # (clears the warm-up steps' records)
     dt, seg_s, seg_k = timed_segments(full, args.steps, dist_on)
+    if sync is not None and dist_report is not None:
+        dist_report["allreduce_exposed_ms_per_step"] = sync.exposure_report()
     host_ms = sorted(t / k * 1e3 for t, k in _HOST_S)
     host_ms_per_step = host_ms[len(host_ms) // 2] if host_ms else None
     L.cgs_prof_enable(1)
@@ -499,8 +512,12 @@ def main():
             "value_raster_only": None if value_raster is None else round(value_raster, 3),
             "value_mid_phase_noise": None if value_mid is None else round(value_mid, 3),
             "value_with_l1_ssim_loss": None if value_img_loss is None else round(value_img_loss, 3),
+            # the same step on the pair-heavy variant of the scene (0.01 voxel grid: ~136 M tile pairs per view, T&T-like): the
+            # headline scene has ~1.9 tiles per Gaussian and flatters the binning; details in extra.heavy_pairs
+            "value_heavy_pairs": (extra.get("heavy_pairs") or {}).get("value"),
             "roofline": roofline, "blend_roofline": blend, "mlp_group_roofline": mlp_group, "ctx_group_roofline": ctx_group,
             "kernels": kernels,
+            "dist": dist_report,
             "hip_kernel_ms_per_step": round(lib_ms, 3),
             "ms_per_step_profiled_pass": round(dt_prof / args.steps * 1e3, 3),
             "cpu_baseline": cpu,

@@ -127,6 +127,24 @@ def _any_rank_has_grad(params, dev) -> list:
 
 _OPEN_SYNC = None          # weakref to the GradientSync that currently owns the hooks / the deferral switch
 
+# The rows (anchors) this rank's view produced gradients for, noted by renderer.generate_neural_gaussians for the phases in
+# which only visible anchors are differentiated (step <= 10 000: no context model over all anchors); None = every row.
+# GradientSync(sparse="auto") reads it: the decision to take the touched-rows path is the PHASE (the same on every rank),
+# whether the compact exchange pays is decided on the UNION of the ranks' rows (also the same on every rank).
+_TOUCHED = {"rows": None, "n": 0}
+
+
+def note_touched_rows(mask, n_rows: int = 0):
+    """mask: bool [N] of the anchors whose per-anchor gradients this view can touch, or None for "all of them"."""
+    _TOUCHED["rows"], _TOUCHED["n"] = mask, int(n_rows)
+
+
+def _auto_rows(p):
+    m = _TOUCHED["rows"]
+    if m is None or p.dim() < 1 or p.shape[0] != m.shape[0]:
+        return None
+    return m
+
 
 class GradientSync:
     """Gradient all-reduce that starts DURING the backward (SURVEY 8e "overlap with the tail of backward").
@@ -148,10 +166,14 @@ class GradientSync:
     byte-mask all-reduce + a compact all-reduce), e.g. before iteration 10 000, when a view only produces gradients
     for the anchors it sees."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], average: bool = True, sparse=None,
+    def __init__(self, params: Iterable[torch.nn.Parameter], average: bool = True, sparse="auto",
                  sparse_below: float = 0.5, defer_weight_gradients: bool = True):
         self.params = [p for p in params if p.requires_grad]
-        self.average, self.sparse, self.sparse_below = average, sparse, sparse_below
+        # sparse="auto" (default since round 5): the rows the renderer noted for this step (note_touched_rows) in the phases
+        # whose gradients only reach visible anchors; a callable(param) -> row mask | None as before; None = always dense
+        self.average, self.sparse, self.sparse_below = average, (_auto_rows if sparse == "auto" else sparse), sparse_below
+        self._union = None                  # (row-mask object, union index | None) of this step: one mask exchange per step
+        self.exposed_ms, self._exposure = [], None      # per step: how long the compute stream stood behind the collectives
         self.big = [p for p in self.params if p.numel() >= BIG_TENSOR]
         self.small = [p for p in self.params if p.numel() < BIG_TENSOR]
         self.order = list(range(len(self.big)))              # issue order = indices into self.big
@@ -231,11 +253,17 @@ class GradientSync:
             self.bytes_reduced += p.grad.numel() * p.grad.element_size()
 
     def _issue_rows(self, p, rows, op):
-        """Union of the ranks' touched rows (byte mask, MAX), then a compact all-reduce of those rows if it pays."""
-        m = rows.to(torch.uint8).contiguous()
-        dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        idx = torch.nonzero(m)[:, 0]
-        self.bytes_reduced += m.numel()
+        """Union of the ranks' touched rows (byte mask, MAX), then a compact all-reduce of those rows if it pays.  The union of
+        one row-mask object is exchanged once per step and shared by every tensor that uses it (the six per-anchor tensors of
+        a view share the visible-anchor mask)."""
+        if self._union is not None and self._union[0] is rows:
+            idx = self._union[1]
+        else:
+            m = rows.to(torch.uint8).contiguous()
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
+            idx = torch.nonzero(m)[:, 0]
+            self.bytes_reduced += m.numel()
+            self._union = (rows, idx)
         if idx.numel() > self.sparse_below * p.shape[0]:
             self.bytes_reduced += p.grad.numel() * p.grad.element_size()
             return None, p.grad, dist.all_reduce(p.grad, op=op, async_op=True)
@@ -318,6 +346,16 @@ class GradientSync:
                 p.grad = flat[off:off + n].view_as(p)
                 off += n
             self._pending.append(("dense", None, flat, work))
+        ev0 = ev1 = None
+        t_host = 0.0
+        if self._pending and self._pending[0][2].is_cuda:
+            # how long the compute stream stands behind the collectives: an event before the first wait and one after the last
+            # (on RCCL `wait()` only makes the current stream wait for the communicator's stream)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        else:
+            import time as _time
+            t_host = _time.perf_counter()
         for kind, p, *rest in self._pending:
             if kind == "dense":
                 t, work = rest
@@ -331,6 +369,17 @@ class GradientSync:
                     t /= w
                 if idx is not None:                           # rows outside the union are zero on every rank already
                     p.grad.index_copy_(0, idx, t)
+        if ev0 is not None:
+            ev1.record()
+            if self._exposure is not None:                    # the previous step's pair is complete by now: no sync here
+                try:
+                    self.exposed_ms.append(self._exposure[0].elapsed_time(self._exposure[1]))
+                except RuntimeError:
+                    pass
+            self._exposure = (ev0, ev1)
+        elif self._pending:
+            import time as _time
+            self.exposed_ms.append((_time.perf_counter() - t_host) * 1e3)
         for k, p in enumerate(self.big):                      # predicted active, but no rank had a gradient: the zeros
             if k in self._active and not has_big[k]:           # that kept the collective sequence aligned are dropped
                 p.grad = None
@@ -346,6 +395,20 @@ class GradientSync:
     def _reset(self):
         self._ready, self._seen, self._next, self._pending, self.bytes_reduced = set(), [], 0, [], 0
         self._filled = set()
+        self._union = None
+
+    def exposure_report(self):
+        """Mean / max of the per-step time the compute stream waited for the collectives in finish() (ms), over the steps
+        recorded so far; the list is cleared."""
+        if self._exposure is not None:
+            try:
+                torch.cuda.synchronize()
+                self.exposed_ms.append(self._exposure[0].elapsed_time(self._exposure[1]))
+            except RuntimeError:
+                pass
+            self._exposure = None
+        v, self.exposed_ms = self.exposed_ms, []
+        return {"steps": len(v), "mean_ms": (sum(v) / len(v) if v else None), "max_ms": (max(v) if v else None)}
 
 
 _shared_rng_counter = [0]
@@ -459,3 +522,42 @@ def gather_bytes(chunks: List[bytes], dst: int = 0) -> List[bytes] | None:
         for j, b in enumerate(lst):
             merged[j * w + rr] = b
     return merged
+
+
+def diagnostics(payload_bytes: int, small_bytes: int = 350_000, reps: int = 5, device=None) -> dict | None:
+    """What a multi-GPU run should print BEFORE its timed region so that its scaling numbers can be read:
+    the ranks and devices the process group reports, and the measured time / bus bandwidth of one dense gradient all-reduce
+    of `payload_bytes` (444 B per anchor) and of the small-tensor bucket.  Bus bandwidth = 2 (G - 1) / G x bytes / time (the
+    ring's per-link traffic), to be compared with DESIGN.md section 5's per-link figures.  Collective on every rank; returns
+    the report on every rank (None at world 1)."""
+    import time as _time
+    w = world()
+    if w == 1:
+        return None
+    on_dev = dist.get_backend() == "nccl"
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu"))
+    name = torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"
+    ranks = gather_objects({"rank": rank(), "device": str(dev), "name": name, "pid": __import__("os").getpid()}, dst=0)
+    out = {"world": w, "backend": dist.get_backend(), "ranks": broadcast_object(ranks, src=0), "all_reduce": {}}
+    for tag, nbytes in (("per_anchor_payload", int(payload_bytes)), ("small_bucket", int(small_bytes))):
+        n = max(1, nbytes // 4)
+        buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        dist.all_reduce(buf)                     # first use of this size
+        times = []
+        for _ in range(reps):
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = _time.perf_counter()
+            dist.all_reduce(buf)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            times.append(_time.perf_counter() - t0)
+        t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=dev if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+        out["all_reduce"][tag] = {"bytes": n * 4, "median_ms": round(sec * 1e3, 4),
+                                  "algbw_GBps": round(n * 4 / sec / 1e9, 5),
+                                  "busbw_GBps": round(2.0 * (w - 1) / w * n * 4 / sec / 1e9, 5)}
+        del buf
+    return out

@@ -415,6 +415,11 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     # visible rows are distinct anchors: gather by index with a sort-free scatter backward (the reference's
     # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
     vis_idx = vis_pending.wait() if vis_pending is not None else torch.nonzero(visible_mask)[:, 0]
+    if is_training:
+        # multi-GPU: the per-anchor gradients of this view only reach the visible anchors unless the context model runs over all
+        # of them (dist.GradientSync(sparse="auto") exchanges the union of the ranks' rows instead of dense tensors)
+        from . import dist as _dist
+        _dist.note_touched_rows(None if use_context else visible_mask, int(vis_idx.shape[0]))
     sel = lambda t: gather_unique(t, vis_idx)
     anchor = sel(full_anchor)
     if use_context:

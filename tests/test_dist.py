@@ -445,3 +445,85 @@ def test_statistics_carry_over_is_counted_once_across_densification_rounds():
         for t in bufs:
             t[t > 6] = 0
     assert any(float(t.sum()) > 0 for t in bufs)          # some entries did carry over
+
+
+def _auto_rows_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        cd.BIG_TENSOR = 8
+        torch.manual_seed(0)
+        n = 64
+        a = torch.nn.Parameter(torch.randn(n, 3))             # three "per-anchor" tensors sharing the view's visible rows
+        b = torch.nn.Parameter(torch.randn(n, 2))
+        c = torch.nn.Parameter(torch.randn(n, 5))
+        lin = torch.nn.Linear(3, 2)
+        params = [a, b, c] + list(lin.parameters())
+        sync = cd.GradientSync(params, average=True)          # sparse="auto" is the default
+        out = []
+        for step, dense_phase in enumerate((False, False, True)):
+            for p in params:
+                p.grad = None
+            vis = torch.zeros(n, dtype=torch.bool)
+            vis[(n // 4) * rank:(n // 4) * (rank + 1)] = True          # DISJOINT quarters: the union is half of the rows
+            # what renderer.generate_neural_gaussians does: note the rows, or None when the context model touches every anchor
+            cd.note_touched_rows(None if dense_phase else vis, int(vis.sum()))
+            m = torch.ones(n, 1) if dense_phase else vis[:, None].float()
+            loss = (lin(a * m)).sum() * float(rank + 1) + (b * m).sum() + (c * m * float(step + 1)).sum()
+            local = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+            loss.backward()
+            nbytes = sync.finish()
+            ref = []
+            for g, p in zip(local, params):
+                g = torch.zeros_like(p) if g is None else g.clone()
+                dist.all_reduce(g)
+                ref.append(g / world)
+            out.append(([p.grad.tolist() for p in params], [t.tolist() for t in ref], nbytes))
+        rep = cd.diagnostics(n * 10 * 4, 64, reps=2)
+        exp = sync.exposure_report()
+        sync.close()
+        q.put(_by_value((rank, out, rep, exp)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_touched_rows_are_the_default_and_the_group_reports_itself():
+    """(b) with views that see disjoint sets of anchors the per-anchor gradients travel as the UNION of the
+    touched rows by default (one mask exchange per step shared by the tensors of the view), and dense again in the phase in
+    which the context model differentiates every anchor; (a) diagnostics() reports ranks and measured all-reduce bandwidths."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_auto_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = _from_value(q.get(timeout=120))
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 64
+    dense_big = n * (3 + 2 + 5) * 4
+    small = (6 + 2) * 4
+    for r in (0, 1):
+        for step, (grads, ref, nbytes) in enumerate(res[r][1]):
+            for g, e in zip(grads, ref):
+                assert torch.allclose(torch.tensor(g), torch.tensor(e), atol=1e-6), (step, g, e)
+        # sparse steps: ONE n-byte mask + half of the rows of each tensor (+ the small bucket); dense step: everything
+        assert res[r][1][0][2] == n + dense_big // 2 + small, res[r][1][0][2]
+        assert res[r][1][1][2] == n + dense_big // 2 + small
+        assert res[r][1][2][2] == dense_big + small
+        rep = res[r][2]
+        assert rep["world"] == 2 and rep["backend"] == "gloo" and [x["rank"] for x in rep["ranks"]] == [0, 1]
+        for tag in ("per_anchor_payload", "small_bucket"):
+            e = rep["all_reduce"][tag]
+            assert e["bytes"] > 0 and e["median_ms"] > 0 and e["busbw_GBps"] > 0
+        assert res[r][3]["steps"] == 3 and res[r][3]["mean_ms"] >= 0
+    for step in range(3):
+        for g0, g1 in zip(res[0][1][step][0], res[1][1][step][0]):
+            assert g0 == g1
