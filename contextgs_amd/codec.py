@@ -354,7 +354,10 @@ def _upload_small(arrays, dev, key=None):
     A `.to(device)` of a pageable host array blocks the host until everything queued on the stream has run (the copy is
     stream-ordered and staged synchronously): four of them per coder launch made the decoder's level loop wait for the
     previous level's launch before it could even build the next one (3.4 ms per level at 1 M anchors)."""
-    arrs = [a.numpy() if isinstance(a, torch.Tensor) else np.ascontiguousarray(a) for a in arrays]
+    # (reshape(-1): a 0-d array has no uint8 view — ADVICE r4 — and a scalar buffer of a checkpoint must travel too)
+    arrs = [np.ascontiguousarray(a.numpy() if isinstance(a, torch.Tensor) else a) for a in arrays]
+    shapes = [a.shape for a in arrs]
+    arrs = [a.reshape(-1) for a in arrs]
     sizes = [(a.nbytes + 15) // 16 * 16 for a in arrs]
     total = max(sum(sizes), 16)
     ring = _SMALL_RING
@@ -376,9 +379,9 @@ def _upload_small(arrays, dev, key=None):
             slot["buf"] = torch.empty(int(total * 1.5), dtype=torch.uint8, pin_memory=True)
     host = slot["buf"].numpy()
     pos, spans = 0, []
-    for a, n in zip(arrs, sizes):
+    for a, n, shp in zip(arrs, sizes, shapes):
         host[pos:pos + a.nbytes] = a.view(np.uint8).reshape(-1) if a.nbytes else host[pos:pos]
-        spans.append((pos, a.nbytes, a.dtype, a.shape))
+        spans.append((pos, a.nbytes, a.dtype, shp))
         pos += n
     d = torch.empty(total, dtype=torch.uint8, device=dev)
     d.copy_(slot["buf"][:total], non_blocking=True)

@@ -272,6 +272,25 @@ def estimate_final_bits(pc):                                   # :980-1004
             f"masks {r(mk)}, MLPs {r(mlp)}, Total {r(a + f + s + o + h + mk + mlp)}")
 
 
+V2_BLOCK_MIN = 64 * 128                  # shortest block of the per-group policy: 128 symbols per lane stream
+V2_BLOCK_POLICY = 1                      # 0 / absent: every group in blocks of "block_symbols"; 1: _block_for(n_sym)
+
+
+def _block_for(n_sym, policy=V2_BLOCK_POLICY, base=None):
+    """Symbols per block of a group of n_sym symbols.  A coder launch lasts as long as its longest lane stream (block / 64
+    serial symbols), and the decoder's three level launches depend on each other: the groups of the two small levels would
+    occupy a few dozen waves for 512-symbol chains.  Policy 1 halves the block until the group has >= 1024 blocks (or lane
+    streams of 128 symbols): the big level keeps 32 768-symbol blocks, the small ones get 8 192 — a 128-byte header per block,
+    +0.2 % of the container at 1 M anchors.  Encoder and decoder derive the size from n_sym alone."""
+    base = V2_BLOCK if base is None else int(base)
+    if not policy:
+        return base
+    b = base
+    while b > V2_BLOCK_MIN and n_sym // b < 1024:
+        b //= 2
+    return b
+
+
 def _block_edges(n_sym, block=None):
     """Element offsets of the version-2 blocks of a group of n_sym symbols."""
     block = V2_BLOCK if block is None else int(block)
@@ -400,8 +419,9 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         cnt = torch.zeros(n_l + 1, dtype=torch.int64, device=m30.device)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         if lanes:      # version 2: blocks of V2_BLOCK symbols, whatever anchors they belong to
-            edges_f, edges_s = _block_edges(n_l * D), _block_edges(n_l * 6)
-            off_edges = _block_edges(int(cnt[-1].item()))
+            n_off = int(cnt[-1].item())
+            edges_f, edges_s = _block_edges(n_l * D, _block_for(n_l * D)), _block_edges(n_l * 6, _block_for(n_l * 6))
+            off_edges = _block_edges(n_off, _block_for(n_off))
         else:
             edges_f, edges_s = rows * D, rows * 6
             off_edges = cnt[rows.to(cnt.device)].cpu()
@@ -500,7 +520,7 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
             min_d["offsets"], max_d["offsets"], prob_masks, bit_hyper_list, bit_d["feat"], bit_d["scaling"],
             bit_d["offsets"], N_levels_list]
     if version == 2:
-        meta.append({"version": 2, "block_symbols": V2_BLOCK, "hyper_block": V2_HYPER_BLOCK, "chunk": chunk,
+        meta.append({"version": 2, "block_symbols": V2_BLOCK, "block_policy": V2_BLOCK_POLICY, "hyper_block": V2_HYPER_BLOCK, "chunk": chunk,
                      "bit_masks": mask_lens * 8})
     torch.save(meta, meta_path)
     bit_meta = os.path.getsize(meta_path) * 8
@@ -551,6 +571,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     chunk = extra["chunk"] if version == 2 else {"masks": max_batch}
     lanes = version == 2
     block = int(extra.get("block_symbols", V2_BLOCK))
+    policy = int(extra.get("block_policy", 0))
+    block_of = lambda n_sym: _block_for(n_sym, policy, block)
     # (map_location: whatever tensors a header holds — the reference stores its minima / maxima as device tensors — are only
     #  ever read as Python numbers here: restoring them on the device would cost a copy each and a stream drain per .item())
     tr("meta.b loaded")
@@ -639,7 +661,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
         live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the three operands and the fill
         if rows_ is None:                                        # version 2: blocks of `block` live symbols
-            return _block_edges(int(live.numel()), block), live
+            return _block_edges(int(live.numel()), block_of(int(live.numel()))), live
         cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         return cnt[rows_.to(dev)], live
@@ -682,7 +704,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
         rows = torch.tensor(_chunk_rows(n_l, max_batch), dtype=torch.int64)
-        edges_f, edges_s = (_block_edges(n_l * D, block), _block_edges(n_l * 6, block)) if lanes else (rows * D, rows * 6)
+        edges_f, edges_s = ((_block_edges(n_l * D, block_of(n_l * D)), _block_edges(n_l * 6, block_of(n_l * 6))) if lanes
+                            else (rows * D, rows * 6))
         pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
         groups = [(mean_feat, scale_feat, Qf, edges_f, min_feat_d[level], max_feat_d[level],
                    *chunk_lens("feat", level, bit_feat_d[level]), D),

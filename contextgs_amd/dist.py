@@ -348,7 +348,8 @@ class GradientSync:
             self._pending.append(("dense", None, flat, work))
         ev0 = ev1 = None
         t_host = 0.0
-        if self._pending and self._pending[0][2].is_cuda:
+        _first = self._pending[0] if self._pending else None
+        if _first is not None and (_first[2] if _first[0] == "dense" else _first[3]).is_cuda:
             # how long the compute stream stands behind the collectives: an event before the first wait and one after the last
             # (on RCCL `wait()` only makes the current stream wait for the communicator's stream)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
