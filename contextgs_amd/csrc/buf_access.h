@@ -14,6 +14,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t ClBuf;
+#ifndef CL_ST_AUX
+#define CL_ST_AUX 0               // cache policy of the buffer stores (2 = non-temporal)
+#endif
+#ifndef CL_LD_AUX
+#define CL_LD_AUX 0               // cache policy of the buffer loads
+#endif
 #define CL_OOB 0xFFFFFF00u              // an offset no buffer reaches (the host refuses buffers >= 0xFFFFF000 bytes)
 #define CL_MAX_BYTES 0xFFFFF000ull
 
@@ -21,39 +27,39 @@ __device__ __forceinline__ ClBuf cl_buf(const void *p, uint64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, p ? (int)(uint32_t)bytes : 0, 0x00020000);
 }
 __device__ __forceinline__ f32x4 cl_l128(ClBuf b, uint32_t off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)off, 0, CL_LD_AUX));
 }
 // (results and operands cross between int and float vectors by WHOLE-vector bit casts only: extracting .x / .y / .z from the
 //  builtins' int vectors came back as the first component replicated — tools/micro/buf_probe.hip)
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 cl_l96(ClBuf b, uint32_t off) {
-    const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(b, (int)off, 0, 0));
+    const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(b, (int)off, 0, CL_LD_AUX));
     return (f32x4){v[0], v[1], v[2], 0.f};
 }
 __device__ __forceinline__ f32x4 cl_l64(ClBuf b, uint32_t off) {
-    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0));
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, CL_LD_AUX));
     return (f32x4){v[0], v[1], 0.f, 0.f};
 }
 __device__ __forceinline__ float cl_l32(ClBuf b, uint32_t off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)off, 0, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)off, 0, CL_LD_AUX));
 }
 __device__ __forceinline__ int64_t cl_li64(ClBuf b, uint32_t off) {
-    return __builtin_bit_cast(int64_t, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, 0));
+    return __builtin_bit_cast(int64_t, __builtin_amdgcn_raw_buffer_load_b64(b, (int)off, 0, CL_LD_AUX));
 }
 __device__ __forceinline__ void cl_s128(ClBuf b, uint32_t off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), b, (int)off, 0, CL_ST_AUX);
 }
 __device__ __forceinline__ void cl_s96(ClBuf b, uint32_t off, f32x4 v) {
     const f32x3 t = (f32x3){v[0], v[1], v[2]};
-    __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3, t), b, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3, t), b, (int)off, 0, CL_ST_AUX);
 }
 __device__ __forceinline__ void cl_s64(ClBuf b, uint32_t off, f32x4 v) {
     const f32x2 t = (f32x2){v[0], v[1]};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, t), b, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, t), b, (int)off, 0, CL_ST_AUX);
 }
 __device__ __forceinline__ void cl_s32(ClBuf b, uint32_t off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, (int)off, 0, CL_ST_AUX);
 }
 __device__ __forceinline__ uint32_t cl_sel(bool on, uint32_t off) { return on ? off : CL_OOB; }
 
