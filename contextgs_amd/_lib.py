@@ -68,6 +68,7 @@ SIGNATURES = {
     "cgs_raster_preprocess_expand_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_int] + [c_void_p] * 9 + [c_int64, c_void_p,
                                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, C.POINTER(C.c_uint64)]),
     "cgs_raster_stats": (c_int, [C.POINTER(RasterCfg), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_debug_set_bin_mode": (c_int, [c_int]),
     "cgs_debug_bin_compare": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
                                       c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "cgs_build_info": (C.c_char_p, []),
@@ -251,6 +252,9 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"CGS_LIB_PATH={LIB_PATH} was built from other sources ({info.split('|')[0][:12]}... vs "
                                    f"{want[:12]}...): rebuild it (tools/variant_lib.sh) or set CGS_LIB_ALLOW_STALE=1")
             print(f"[contextgs_amd] variant library {LIB_PATH} ({info[:12]}...|{info.split('|')[-1]})", file=sys.stderr)
+        if os.environ.get("CGS_BIN_MODE"):      # measurement switch (tools/bin_ab.sh): 1 = radix passes, 2 = two-level tile binning
+            if handle.cgs_debug_set_bin_mode(int(os.environ["CGS_BIN_MODE"])) != 0:
+                raise RuntimeError("CGS_BIN_MODE must be 0, 1 or 2")
         _lib = handle
     return _lib
 

@@ -42,7 +42,7 @@ size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P) {
     g->offsets = c.take<uint32_t>(n);
     g->sort_a = c.take<uint32_t>(n);
     g->sort_b = c.take<uint32_t>(n);
-    g->sort_c = nullptr;     // (was the iota values of the depth sort: the sort's first pass generates them since round 4)
+    g->sort_c = c.take<uint32_t>(n);
     g->sort_d = c.take<uint32_t>(n);
     g->total = c.take<uint32_t>(2);
     size_t sb = cgs_sort_scratch_bytes((int64_t)n);
@@ -64,6 +64,12 @@ size_t cgs_bin_carve(CgsBin *b, void *ws, size_t bytes, int64_t P, int64_t R) {
     b->gid_sorted = c.take<uint32_t>(n);
     b->scratch_bytes = cgs_sort_scratch_bytes((int64_t)n);
     b->scratch = c.take<char>(b->scratch_bytes);
+    const int64_t slots = cgs_bucket_count_slots((int64_t)n);
+    b->bk_tab = c.take<uint32_t>(cgs_bucket_tab_words());
+    b->bk_counts = c.take<uint32_t>((size_t)slots);
+    b->bk_scan = c.take<uint32_t>((size_t)slots);
+    b->bk_scan_scratch_bytes = cgs_scan_scratch_bytes(slots);
+    b->bk_scan_scratch = c.take<char>(b->bk_scan_scratch_bytes);
     return c.ok ? c.used() : 0;
 }
 
@@ -300,6 +306,23 @@ static int tile_bits(const cgs_raster_cfg *cfg) {
     return bits;
 }
 
+// Which binning: 0 = by the pair count per Gaussian (the two-level path from CGS_BUCKET_MIN_RATIO tiles per Gaussian on),
+// 1 = radix passes over (tile, Gaussian) pairs, 2 = two-level wherever the grid allows it.  cgs_debug_set_bin_mode is the
+// test / measurement hook (tests/test_raster_gpu.py runs the list comparisons under both).
+static int g_bin_mode = 0;
+#ifndef CGS_BUCKET_MIN_RATIO
+#define CGS_BUCKET_MIN_RATIO 6
+#endif
+extern "C" int cgs_debug_set_bin_mode(int mode) {
+    if (mode < 0 || mode > 2) { cgs_set_error("cgs_debug_set_bin_mode: 0 (auto), 1 (radix) or 2 (buckets)"); return CGS_ERR_ARG; }
+    g_bin_mode = mode;
+    return CGS_OK;
+}
+static bool use_buckets(const cgs_raster_cfg *cfg, int64_t P, int64_t R) {
+    if (g_bin_mode == 1 || !cgs_tile_bin_buckets_ok(cfg) || !cgs_tile_bin_buckets_fits(R)) return false;
+    return g_bin_mode == 2 || R >= (int64_t)CGS_BUCKET_MIN_RATIO * P;
+}
+
 static int raster_render_impl(const cgs_raster_cfg *cfg, int64_t P, int64_t R, bool spec, void *geom_ws,
                               size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
                               size_t img_bytes, float *out_color, hipStream_t stream) {
@@ -329,7 +352,10 @@ static int raster_render_impl(const cgs_raster_cfg *cfg, int64_t P, int64_t R, b
             cgs_set_error("binning workspace too small: %zu < %zu", bin_bytes, cgs_raster_bin_bytes(P, R));
             return CGS_ERR_WORKSPACE;
         }
-        if (bin16) {
+        if (bin16 && use_buckets(cfg, P, R)) {
+            // csrc/tile_bin.hip, two-level: bucket lists by one radix pass, tile lists by count + scan + fill
+            if ((rc = cgs_launch_tile_bin_buckets(cfg, P, R, g, b, im, stream, spec ? g.total : nullptr))) return rc;
+        } else if (bin16) {
             // csrc/tile_bin.hip: the first radix pass generates its pairs, 16-bit tile keys
             if ((rc = cgs_launch_tile_bin16(cfg, P, R, tile_bits(cfg), g, b, im, stream, spec ? g.total : nullptr))) return rc;
         } else {

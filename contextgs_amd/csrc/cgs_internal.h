@@ -91,7 +91,7 @@ struct CgsGeom {
     uint32_t *offsets;      // [P] exclusive scan of tiles[order[i]]
     uint32_t *sort_a;       // [P] ping-pong scratch (keys)
     uint32_t *sort_b;       // [P]
-    uint32_t *sort_c;       // [P] (vals)
+    uint32_t *sort_c;       // [P] bucket-pair offsets of the two-level binning (tile_bin.hip)
     uint32_t *sort_d;       // [P]
     uint32_t *total;        // [2] device: num_rendered
     void *scratch;          // scan/sort scratch
@@ -107,6 +107,12 @@ struct CgsBin {
     uint32_t *gid_sorted;   // [R] final per-tile lists (depth order inside each tile)
     void *scratch;
     size_t scratch_bytes;
+    // two-level binning (tile_bin.hip): bucket / chunk tables, per-(tile, chunk) counts and their scan
+    uint32_t *bk_tab;       // [cgs_bucket_tab_words()]
+    uint32_t *bk_counts;    // [cgs_bucket_count_slots(R)]
+    uint32_t *bk_scan;      // [cgs_bucket_count_slots(R)]
+    void *bk_scan_scratch;
+    size_t bk_scan_scratch_bytes;
 };
 
 struct CgsImg {
@@ -132,6 +138,12 @@ int cgs_launch_ranges(const cgs_raster_cfg *cfg, int64_t R, CgsBin &b, CgsImg &i
 // tile_bin.hip: binning with a pair-generating first radix pass and 16-bit tile keys (grids of <= 65536 tiles)
 int cgs_launch_gather_rects(int64_t P, CgsGeom &g, hipStream_t stream);
 bool cgs_tile_bin16_ok(int tile_bits);
+bool cgs_tile_bin_buckets_ok(const cgs_raster_cfg *cfg);
+bool cgs_tile_bin_buckets_fits(int64_t R);
+int64_t cgs_bucket_count_slots(int64_t R);
+size_t cgs_bucket_tab_words(void);
+int cgs_launch_tile_bin_buckets(const cgs_raster_cfg *cfg, int64_t P, int64_t R, CgsGeom &g, CgsBin &b, CgsImg &im,
+                                hipStream_t stream, const uint32_t *R_dev);
 int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int tile_bits, CgsGeom &g, CgsBin &b, CgsImg &im,
                           hipStream_t stream, const uint32_t *R_dev = nullptr);     // per-tile lists AND im.ranges
 // raster_blend_rows.hip: row-mapped variants (four 4x4 blocks per wave), selected by cgs_blend_rows_enabled()

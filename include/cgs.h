@@ -205,6 +205,13 @@ int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64_t R,
                           void *bin_ws, size_t bin_bytes, void *img_ws,
                           size_t img_bytes, void *bin_ws2, size_t bin_bytes2,
                           void *ranges2, int64_t *out2, void *stream);
+/* Test / measurement hook: which tile binning cgs_raster_render* uses.  0 = chosen per
+ * view by the pair count per Gaussian (default), 1 = radix passes over (tile, Gaussian)
+ * pairs, 2 = the two-level binning (buckets of 8 x 4 tiles) wherever the grid has
+ * <= 256 buckets.  Both leave the same lists and ranges (R3-R6 of SURVEY section 2.1;
+ * the reference's duplicateWithKeys + SortPairs + identifyTileRanges, whose sources
+ * are not in the mount). */
+int cgs_debug_set_bin_mode(int mode);
 /* "<sha256 of the sources the library was built from>|<compiler flags>"
  * (contextgs_amd/build.py); the loader refuses a CGS_LIB_PATH library whose
  * digest is not that of the sources next to it. */

@@ -285,16 +285,30 @@ def _bin_compare():
     return out.tolist(), R, R_ws
 
 
+@pytest.fixture
+def bin_mode(request):
+    """cgs_debug_set_bin_mode for one test: 1 = radix passes over (tile, Gaussian) pairs, 2 = two-level (bucket) binning"""
+    from contextgs_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.cgs_debug_set_bin_mode(request.param), "cgs_debug_set_bin_mode")
+    yield request.param
+    _lib.check(L.cgs_debug_set_bin_mode(0), "cgs_debug_set_bin_mode")
+
+
+@pytest.mark.parametrize("bin_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("P,W,H,scale_hi", [(4000, 256, 256, 0.05), (30000, 800, 800, 0.02), (20000, 1920, 1080, 0.08),
-                                             (300, 97, 61, 0.4), (60000, 64, 64, 0.3)])
-def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
+                                             (300, 97, 61, 0.4), (60000, 64, 64, 0.3), (50000, 1920, 1080, 0.5),
+                                             (3000, 2600, 1800, 0.2)])
+def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi, bin_mode):
     """csrc/tile_bin.hip (pair-generating first radix pass, 16-bit tile keys, ranges from the last pass) leaves the same
     per-tile lists, entry for entry, and the same tile ranges as the round-1 binning (emit_pairs + stable 32-bit pair sort,
     the path the oracle comparisons of rounds 1-2 ran on): one pass (256 tiles), 6+6 and 7+6 bit passes, a 28-tile grid
     with splats that cover all of it, and 16 tiles with ~40 000 entries each, half of them exact depth ties (pairs of Gaussians
     at the same position: the ids decide).  Three renders of each scene: with the pair count known on the host, speculative
     (count read on the device, capacity from the first render), and speculative with a capacity that is too small
-    (the view is rendered again with the true count)."""
+    (the view is rendered again with the true count).  Round 5: every scene under both binnings — the radix passes and the
+    two-level path (bucket lists, then count + scan + fill; csrc/tile_bin.hip) — plus 50 000 screen-filling splats at 1080p
+    (multi-chunk buckets, masks of all 32 tiles) and a 163 x 113 tile grid (more than 256 buckets: mode 2 falls back)."""
     from contextgs_amd import rasterizer as rz
     cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
     g = random_gaussians(P, seed=P, extent=1.0, scale_lo=0.003, scale_hi=scale_hi)
@@ -313,5 +327,6 @@ def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi):
     diff, R3, R_ws = _bin_compare()
     assert diff == [0, 0] and R3 == R and R_ws == (R if R > 4097 else 4097), (diff, R3, R_ws)
     assert R > 4097 or P == 300
+    print(f"[binning] mode {bin_mode}: P {P} {W}x{H}: {R} pairs")
     assert rz._pair_capacity[(H, W)] == (rz.pair_capacity_for(R) if R > 4097 else 4097)
     assert (third == first).all()

@@ -12,7 +12,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--anchors", type=int, default=1_000_000)
 ap.add_argument("--voxel", type=float, default=None)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--mode", type=int, default=0, help="cgs_debug_set_bin_mode: 0 auto, 1 radix passes, 2 two-level (buckets)")
 a = ap.parse_args()
+from contextgs_amd import _lib
+_lib.check(_lib.lib().cgs_debug_set_bin_mode(a.mode), "cgs_debug_set_bin_mode")
 pc = make_scene(a.anchors, seed=0, **({"voxel_size": a.voxel} if a.voxel else {}))
 pc.eval()
 pipe = SynthPipe(); bg = torch.zeros(3, device="cuda")
