@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(RB_THREADS)
         const uint32_t pos0 = (uint32_t)(nbatch - 1) * RB_THREADS + tid;
         if (pos0 < tlast) {
             pg = gid_sorted[range.x + pos0];
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7      // `rec` holds the records IN LIST ORDER (copied by the launcher)
+            pg = range.x + pos0;
+#endif
             p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
         }
     }
@@ -347,6 +350,9 @@ __global__ void __launch_bounds__(RB_THREADS)
         }
         if (bi > 0) {      // every position of an earlier batch is < tlast
             pg = gid_sorted[range.x + pos - RB_THREADS];
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
+            pg = range.x + pos - RB_THREADS;
+#endif
             p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
         }
 #pragma unroll
@@ -625,6 +631,16 @@ __global__ void __launch_bounds__(RB_THREADS)
 
 #endif  // CGS_BLEND_BWD_RAW
 
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
+__global__ void __launch_bounds__(256) rb_records_in_list_order_kernel(uint32_t R, const uint32_t *__restrict__ gid_sorted,
+                                                                       const float4 *__restrict__ rec, float4 *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t g = gid_sorted[i];
+    out[3 * (size_t)i] = rec[3 * (size_t)g]; out[3 * (size_t)i + 1] = rec[3 * (size_t)g + 1]; out[3 * (size_t)i + 2] = rec[3 * (size_t)g + 2];
+}
+#endif
+
 int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
@@ -647,8 +663,12 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 #endif
+    const float4 *rec = (const float4 *)g.rec;
+#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
+#include "../../tools/experiments/raster_blend_rows_sorted_records.inc"
+#endif
     hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
-                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, (const float4 *)g.rec,
+                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, rec,
                        cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last,
                        dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
