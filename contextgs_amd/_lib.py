@@ -159,13 +159,13 @@ SIGNATURES = {
     "cgs_gaussian_ac_encode_lanes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_gaussian_ac_decode_lanes": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_lanes_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "cgs_lanes_block_slot_bytes": (c_size_t, [c_int64, c_int]),
     "cgs_table_ac_encode_lanes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_table_ac_decode_lanes": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64,
-                                          c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_bernoulli_ac_encode": (c_int, [c_void_p, C.c_uint32, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_bernoulli_ac_decode": (c_int, [C.c_uint32, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cgs_means3_scratch_bytes": (c_size_t, []),

@@ -586,11 +586,38 @@ def gaussian_decode_packed(mean, scale, Q, stream_off, min_v, max_v, blob, lens,
             in_d[: buf.size].copy_(torch.from_numpy(np.ascontiguousarray(buf) if buf.flags.writeable else buf.copy()))
     in_off, mn, mx, off_d = _upload_small([in_off_h, np.asarray(min_v, dtype=np.int32), np.asarray(max_v, dtype=np.int32), off_h],
                                           dev)
-    dec = L.cgs_gaussian_ac_decode_lanes if lanes else L.cgs_gaussian_ac_decode
-    _lib.check(dec(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
-                   _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
-                   _lib.current_stream()), "cgs_gaussian_ac_decode")
+    if lanes:
+        _lib.check(L.cgs_gaussian_ac_decode_lanes(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
+                                                  _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
+                                                  _lib.ptr(decode_status(dev)), _lib.current_stream()), "cgs_gaussian_ac_decode_lanes")
+    else:
+        _lib.check(L.cgs_gaussian_ac_decode(_lib.ptr(mean), _lib.ptr(scale), _lib.ptr(Q), q_div, _lib.ptr(off_d), S,
+                                            _lib.ptr(mn), _lib.ptr(mx), _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(x_out),
+                                            _lib.current_stream()), "cgs_gaussian_ac_decode")
     return x_out
+
+
+_DECODE_STATUS = {}
+
+
+def decode_status(device, reset=False):
+    """The device int32 the lane decoders of container version 2 report a malformed block into (1 + block index of the launch
+    that saw it; 0 = fine).  conduct_decoding zeroes it first and reads it once at the end (decode_status_check)."""
+    key = str(device)
+    st = _DECODE_STATUS.get(key)
+    if st is None:
+        st = _DECODE_STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    elif reset:
+        st.zero_()
+    return st
+
+
+def decode_status_check(device):
+    bad = int(decode_status(device).item())
+    if bad:
+        decode_status(device, reset=True)
+        raise ValueError(f"container version 2: block {bad - 1} of a lane-coded file is malformed (its lane lengths do not add up to "
+                         "the block length of the header, or its min / max are out of range): truncated or corrupt container")
 
 
 def gaussian_decode_streams(mean, scale, Q, stream_off, min_v, max_v, streams, q_div=1):
@@ -631,6 +658,17 @@ def file_ranges(write: bool, ranges, threads: int = 8):
 _PINNED = {}
 _LAST_STAGED = {}
 _STAGE_POOL = None
+
+
+def _wait_staged(released, job, events):
+    """Host-side wait for a StagedFiles' reads and copies (see StagedFiles.wait_all)."""
+    released.set()
+    try:
+        job.result()
+    except BaseException:
+        pass
+    for ev in list(events.values()):
+        ev.synchronize()
 
 
 def _stage_pool():
@@ -680,10 +718,12 @@ class StagedFiles:
         self.events = {}                                              # device side: the file's bytes have arrived
         self.error = None
         key = (self.device.index if isinstance(self.device, torch.device) else 0)
-        prev = _LAST_STAGED.get(key)
+        # the previous container's copies read the pinned buffer this one is about to overwrite: wait for them.  Only what that
+        # takes is kept from it — its release switch, its job and its events (keeping the object itself pinned
+        # ~120 MB of device memory, the whole container, for the life of the process)
+        prev = _LAST_STAGED.pop(key, None)
         if prev is not None:
-            prev.wait_all()           # its copies read the pinned buffer this container is about to overwrite
-        _LAST_STAGED[key] = self
+            _wait_staged(*prev)
         pinned = _PINNED.get(key)
         if pinned is None or pinned.numel() < self.total + 64:
             pinned = _PINNED[key] = torch.empty(max(int(self.total * 1.25) + 64, 1 << 20), dtype=torch.uint8, pin_memory=True)
@@ -699,6 +739,7 @@ class StagedFiles:
         if self._start >= len(self.names):
             self._released.set()
         self._job = _stage_pool().submit(self._run)
+        _LAST_STAGED[key] = (self._released, self._job, self.events)
 
     def release(self):
         """Start the reads held back by `start`."""
@@ -750,13 +791,7 @@ class StagedFiles:
 
     def wait_all(self):
         """Host-side: every copy has finished (the pinned buffer is reused by the next container)."""
-        self.release()
-        try:
-            self._job.result()
-        except BaseException:
-            pass
-        for ev in list(self.events.values()):
-            ev.synchronize()
+        _wait_staged(self._released, self._job, self.events)
 
     def get(self, name):
         if not self.ready[name].is_set() and self.names.index(name) >= self._start:
@@ -890,7 +925,7 @@ def table_decode_lanes(blob, lens, C_, N, cdf, cdf_len, offset, medians, block):
     cl, of, med = cdf_len.to(torch.int32).contiguous(), offset.to(torch.int32).contiguous(), medians.to(torch.float32).contiguous()
     _lib.check(L.cgs_table_ac_decode_lanes(_lib.ptr(edges), _lib.ptr(ch), S, _lib.ptr(cdf), int(cdf.shape[1]), _lib.ptr(cl),
                                            _lib.ptr(of), _lib.ptr(med), N, _lib.ptr(in_d), _lib.ptr(in_off), _lib.ptr(out), C_,
-                                           _lib.current_stream()), "cgs_table_ac_decode_lanes")
+                                           _lib.ptr(decode_status(out.device)), _lib.current_stream()), "cgs_table_ac_decode_lanes")
     return out
 
 

@@ -567,6 +567,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     # (only masks.b starts now: the checkpoint is read first, on a quiet interpreter — beside eight reader threads that read
     #  took 4-8 ms instead of 0.3; the other files are released right after it and are still early for the first level)
     staged = codec.StagedFiles([path(f_) for f_ in order if os.path.exists(path(f_))], dev, start=1 if version == 2 else 0)
+    codec.decode_status(dev, reset=True)     # the lane decoders report a malformed block here (read once, after the last launch)
     tr("file staging prepared")
     chunk = extra["chunk"] if version == 2 else {"masks": max_batch}
     lanes = version == 2
@@ -762,6 +763,8 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     tr("levels enqueued")
     torch.cuda.synchronize(); t2 = time.time()
     tr("device done")
+    if version == 2:
+        codec.decode_status_check(dev)           # (after the synchronize: no extra wait)
     print("decoding time:", t2 - t1)
 
     z = lambda *s: torch.zeros(*s, device=dev)                                            # :1503-1533

@@ -1095,27 +1095,45 @@ __global__ void __launch_bounds__(256)
 // Decoder, ONE WAVE PER BLOCK, one decoder per lane.  Symbol search per lane: a first guess from the inverse normal CDF
 // of target / norm, then a walk on the exact integer CDF (the same gaussian_cdf_int as the encoder) with the division-free
 // test cdf * span <= num.
-__global__ void __launch_bounds__(64)
-    gaussian_decode_lanes_kernel(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q,
-                                 int64_t q_div, const int64_t *__restrict__ blk_off, int n_blocks,
-                                 const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
-                                 const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off, float *__restrict__ x_out) {
-    const int blk = blockIdx.x, lane = threadIdx.x;
-    if (blk >= n_blocks) return;
-    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
-    const uint8_t *base = in + in_off[blk];
-    // exclusive prefix sum of the 64 lane lengths
-    const uint32_t mylen = ((const uint16_t *)base)[lane];
+// The 64 lane lengths of a block header, read bytewise (blocks and files sit back to back at arbitrary byte offsets in a
+// container) and checked against the block's length from the header arrays: lane l's stream starts at *start; false (and
+// *status = 1 + block) when the lengths do not add up — a truncated or corrupt container must not steer reads out of the blob.
+__device__ __forceinline__ bool lanes_header(const uint8_t *base, int64_t block_bytes, int lane, int blk, uint32_t *start,
+                                             int32_t *status) {
+    const uint32_t mylen = (uint32_t)base[2 * lane] | ((uint32_t)base[2 * lane + 1] << 8);
     uint32_t incl = mylen;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
     }
+    *start = incl - mylen;
+    const uint32_t total = __shfl(incl, 63, 64);
+    const bool ok = (int64_t)total + LANES_HDR == block_bytes;
+    if (!ok && lane == 0 && status) atomicCAS(status, 0, 1 + blk);
+    return ok;
+}
+
+__global__ void __launch_bounds__(64)
+    gaussian_decode_lanes_kernel(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q,
+                                 int64_t q_div, const int64_t *__restrict__ blk_off, int n_blocks,
+                                 const int32_t *__restrict__ min_v, const int32_t *__restrict__ max_v,
+                                 const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off, float *__restrict__ x_out,
+                                 int32_t *__restrict__ status) {
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    if (blk >= n_blocks) return;
+    const int64_t b = blk_off[blk], e = blk_off[blk + 1];
+    const uint8_t *base = in + in_off[blk];
+    uint32_t start;
+    if (!lanes_header(base, in_off[blk + 1] - in_off[blk], lane, blk, &start, status)) return;
     LaneAcDecoder dec;
-    dec.init(base + LANES_HDR + (incl - mylen));
+    dec.init(base + LANES_HDR + start);
     const int lo = min_v[blk];
     const int Lp = max_v[blk] - lo + 2;
+    if (Lp < 2 || Lp > 65536) {          // (the CDF has Lp + 1 <= 2^16 + 1 entries: a header outside that is corrupt)
+        if (lane == 0 && status) atomicCAS(status, 0, 1 + blk);
+        return;
+    }
     const int max_sym = Lp - 2;
     const float norm = (float)(65536 - (Lp - 1));
     const float rnorm = 1.f / norm;
@@ -1249,11 +1267,12 @@ extern "C" int cgs_lanes_compact(const uint8_t *src, const int64_t *src_off, con
 
 extern "C" int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scale, const float *Q, int64_t q_div,
                                             const int64_t *blk_off, int n_blocks, const int32_t *min_v, const int32_t *max_v,
-                                            const uint8_t *in, const int64_t *in_off, float *x_out, void *stream) {
+                                            const uint8_t *in, const int64_t *in_off, float *x_out, int32_t *status,
+                                            void *stream) {
     if (n_blocks < 0 || q_div < 1) { cgs_set_error("gaussian_ac_decode_lanes: bad args"); return CGS_ERR_ARG; }
     if (n_blocks == 0) return CGS_OK;
     hipLaunchKernelGGL(gaussian_decode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, mean, scale, Q, q_div,
-                       blk_off, n_blocks, min_v, max_v, in, in_off, x_out);
+                       blk_off, n_blocks, min_v, max_v, in, in_off, x_out, status);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -1320,7 +1339,7 @@ __global__ void __launch_bounds__(64)
                               const int32_t *__restrict__ cdf, int max_len, const int32_t *__restrict__ cdf_len,
                               const int32_t *__restrict__ offset, const float *__restrict__ medians, int64_t n_per_ch,
                               const uint8_t *__restrict__ in, const int64_t *__restrict__ in_off, float *__restrict__ out_rows,
-                              int64_t ld) {
+                              int64_t ld, int32_t *__restrict__ status) {
     __shared__ uint32_t tab[TAB_MAX_LEN];
     const int blk = blockIdx.x, lane = threadIdx.x;
     if (blk >= n_blocks) return;
@@ -1331,15 +1350,10 @@ __global__ void __launch_bounds__(64)
     const float med = medians[ch];
     const int64_t b = blk_off[blk], e = blk_off[blk + 1];
     const uint8_t *base = in + in_off[blk];
-    const uint32_t mylen = ((const uint16_t *)base)[lane];
-    uint32_t incl = mylen;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
+    uint32_t start;
+    if (!lanes_header(base, in_off[blk + 1] - in_off[blk], lane, blk, &start, status)) return;
     LaneAcDecoder dec;
-    dec.init(base + LANES_HDR + (incl - mylen));
+    dec.init(base + LANES_HDR + start);
     auto get_bit = [&]() -> uint32_t {
         const uint32_t bit = cdf_le_target(0x8000u, dec.span_m1(), dec.num()) ? 1u : 0u;
         dec.consume(bit ? 0x8000u : 0u, bit ? AC_TOP : 0x8000u);
@@ -1381,11 +1395,11 @@ extern "C" int cgs_table_ac_encode_lanes(const int32_t *sym, const int64_t *blk_
 extern "C" int cgs_table_ac_decode_lanes(const int64_t *blk_off, const int32_t *blk_ch, int n_blocks, const int32_t *cdf,
                                          int max_len, const int32_t *cdf_len, const int32_t *offset, const float *medians,
                                          int64_t n_per_channel, const uint8_t *in, const int64_t *in_off, float *out_rows,
-                                         int64_t ld_rows, void *stream) {
+                                         int64_t ld_rows, int32_t *status, void *stream) {
     if (n_blocks < 0 || max_len < 3 || max_len > TAB_MAX_LEN) { cgs_set_error("table_ac_decode_lanes: bad args"); return CGS_ERR_ARG; }
     if (n_blocks == 0) return CGS_OK;
     hipLaunchKernelGGL(table_decode_lanes_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, blk_off, blk_ch, n_blocks, cdf,
-                       max_len, cdf_len, offset, medians, n_per_channel, in, in_off, out_rows, ld_rows);
+                       max_len, cdf_len, offset, medians, n_per_channel, in, in_off, out_rows, ld_rows, status);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -444,8 +444,11 @@ extern "C" int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, in
 // number in a persistent uint32 stamp array (cgs_mark_rows; no clearing between calls: generations only grow, the caller
 // restarts at a zeroed array after 2^32 - 1), and cgs_zero_unmarked_rows writes zeros to the rows whose stamp is older.
 __global__ void __launch_bounds__(256)
-    mark_rows_kernel(const int64_t *__restrict__ idx, int64_t n, uint32_t gen, uint32_t *__restrict__ stamp) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) stamp[idx[i]] = gen;
+    mark_rows_kernel(const int64_t *__restrict__ idx, int64_t n, int64_t n_full, uint32_t gen, uint32_t *__restrict__ stamp) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx[i];
+        if (r >= 0 && r < n_full) stamp[r] = gen;          // (an index outside the array is ignored, not written through)
+    }
 }
 
 struct ZeroRowsArgs { float *dst[4]; int w[4]; int narr; };
@@ -467,7 +470,7 @@ extern "C" int cgs_mark_rows(const int64_t *idx, int64_t n, int64_t n_full, uint
     if (n < 0 || n_full < 0 || gen == 0) { cgs_set_error("mark_rows: bad args (gen must be > 0)"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!idx || !stamp) { cgs_set_error("mark_rows: NULL"); return CGS_ERR_ARG; }
-    hipLaunchKernelGGL(mark_rows_kernel, dim3(stream_grid(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, idx, n, gen, stamp);
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(stream_grid(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, idx, n, n_full, gen, stamp);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -450,7 +450,10 @@ __global__ void __launch_bounds__(RB_THREADS)
 #if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 1      // timing only: plain stores instead of LDS float atomics
                 if (has && sub < RB_NGRAD) sacc[e][sub] = red;
 #else
-                if (has && sub < RB_NGRAD) atomicAdd(&sacc[e][sub], red);
+                // (red != 0: a row whose 16 pixels took nothing from its entry — the wave goes on while ANY row has a contribution —
+                //  would add nine zeros through the LDS float-atomic unit, the kernel's second bound: -6 %, same sums bit for bit;
+                //  profiles/r05_blend_bwd_ablations.txt)
+                if (has && sub < RB_NGRAD && red != 0.f) atomicAdd(&sacc[e][sub], red);
 #endif
             }
         }

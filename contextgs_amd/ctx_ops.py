@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import threading
 
 import torch
 
@@ -96,35 +97,37 @@ def gather_rows_nograd(x, idx):
     return out
 
 
-_ROW_STAMPS = {}      # (device, n_full) -> [uint32 stamp tensor, generation, weakref of the last marked index, its version]
+_ROW_STAMPS = {}      # (device, n_full) -> [uint32 stamp tensor, generation]
+_ROW_STAMPS_LOCK = threading.Lock()     # autograd runs backward nodes on its own threads
 
 
 def zero_unlisted_rows(idx, n_full, arrays):
-    """Zeros in every row of `arrays` ([n_full, ...] float32, same device) that `idx` (int64, distinct rows) does not name —
-    what torch.zeros gave the gradient buffers of a view's backward before the kernel overwrote the listed rows, without
+    """Zeros in every row of `arrays` ([n_full, ...] float32, same device) that `idx` (int64, distinct rows < n_full) does not
+    name — what torch.zeros gave the gradient buffers of a view's backward before the kernel overwrote the listed rows, without
     filling the 99 % that are overwritten anyway (cgs_mark_rows / cgs_zero_unmarked_rows).  The listed rows stay as they
-    are (uninitialised: the caller's kernel writes them).  A second call with the SAME index tensor reuses its marks."""
-    import weakref
+    are (uninitialised: the caller's kernel writes them).  Every call marks afresh (an index buffer refilled through
+    a raw pointer keeps its Python identity and version, so marks can not be reused on that evidence); an index >= n_full is
+    ignored by the kernel."""
     if int(n_full) == 0 or not arrays:
         return
     dev = arrays[0].device
     L = _lib.lib()
     key = (str(dev), int(n_full))
-    st = _ROW_STAMPS.get(key)
-    if st is None or st[1] >= 0xFFFFFFF0:
-        if st is None and len(_ROW_STAMPS) >= 8:       # anchor counts change with densification: keep the newest few arrays
-            _ROW_STAMPS.pop(next(iter(_ROW_STAMPS)))
-        st = _ROW_STAMPS[key] = [torch.zeros(max(int(n_full), 1), dtype=torch.int32, device=dev), 0, None, -1]
     stream = _lib.current_stream()
-    last = st[2]() if st[2] is not None else None
-    if last is not idx or st[3] != idx._version:
+    with _ROW_STAMPS_LOCK:
+        st = _ROW_STAMPS.get(key)
+        if st is None or st[1] >= 0xFFFFFFF0:
+            if st is None and len(_ROW_STAMPS) >= 8:       # anchor counts change with densification: keep the newest few arrays
+                _ROW_STAMPS.pop(next(iter(_ROW_STAMPS)))
+            st = _ROW_STAMPS[key] = [torch.zeros(max(int(n_full), 1), dtype=torch.int32, device=dev), 0]
         st[1] += 1
-        _lib.check(L.cgs_mark_rows(_lib.ptr(idx), int(idx.shape[0]), int(n_full), st[1], _lib.ptr(st[0]), stream), "cgs_mark_rows")
-        st[2], st[3] = weakref.ref(idx), idx._version
-    for a0 in range(0, len(arrays), 4):
-        part = arrays[a0:a0 + 4]
-        _lib.check(L.cgs_zero_unmarked_rows(_lib.ptr(st[0]), st[1], int(n_full), len(part), _ptrs(part),
-                                            _ints([int(a[0].numel()) for a in part]), stream), "cgs_zero_unmarked_rows")
+        gen, stamp = st[1], st[0]
+        # (enqueued under the lock: two backward threads on one stream must not interleave mark / zero pairs of one stamp array)
+        _lib.check(L.cgs_mark_rows(_lib.ptr(idx), int(idx.shape[0]), int(n_full), gen, _lib.ptr(stamp), stream), "cgs_mark_rows")
+        for a0 in range(0, len(arrays), 4):
+            part = arrays[a0:a0 + 4]
+            _lib.check(L.cgs_zero_unmarked_rows(_lib.ptr(stamp), gen, int(n_full), len(part), _ptrs(part),
+                                                _ints([int(a[0].numel()) for a in part]), stream), "cgs_zero_unmarked_rows")
 
 
 _seed_counter = itertools.count(1)

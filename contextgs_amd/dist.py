@@ -196,10 +196,20 @@ class GradientSync:
         # (a new one after adjust_anchor) or garbage-collected without close() must not leave deferral on with
         # a hook that issues collectives for stale Parameters.  The hook only holds a weak reference, a new GradientSync closes
         # the one that is still open, and __del__ closes too.
+        #  only a sync that is being REPLACED is closed for the caller: one whose parameters overlap the new one's
+        # (the same model again) or are stale (storage swapped by optimizer surgery: no .grad hook can fire for them any more
+        # through the model).  A second sync that is alive on purpose (another model, an evaluation replica) keeps its hooks —
+        # but the weight-gradient deferral switch of mlp.py is one per process, so the two share it and a warning says so.
         global _OPEN_SYNC
         prev_sync = _OPEN_SYNC() if _OPEN_SYNC is not None else None
-        if prev_sync is not None:
-            prev_sync.close()
+        if prev_sync is not None and prev_sync._handles:
+            mine = {id(p) for p in self.params}
+            if any(id(p) in mine for p in prev_sync.params) or not prev_sync.params:
+                prev_sync.close()
+            else:
+                import warnings
+                warnings.warn("contextgs_amd.dist.GradientSync: another GradientSync over different parameters is still open; "
+                              "both stay active (close() the old one if it was meant to be replaced)", stacklevel=2)
         self._deferring = self._hook = None
         if defer_weight_gradients and world() > 1:
             import weakref

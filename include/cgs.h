@@ -708,8 +708,12 @@ int cgs_gaussian_ac_decode_lanes(const float *mean, const float *scale,
                                  const int64_t *blk_off, int n_blocks,
                                  const int32_t *min_v, const int32_t *max_v,
                                  const uint8_t *in, const int64_t *in_off,
-                                 float *x_out, void *stream);
-/* Container version 2, hyper.b: the hyper latents' integer symbols
+                                 float *x_out, int32_t *status, void *stream);
+/* (both lane decoders: in_off has n_blocks + 1 entries; a block whose 64 lane
+ * lengths + 128 header bytes do not add up to in_off[b+1] - in_off[b], or whose
+ * min / max give a CDF of more than 2^16 entries, is not decoded and
+ * *status (device int32, zeroed by the caller, may be NULL) becomes 1 + b.)
+ * Container version 2, hyper.b: the hyper latents' integer symbols
  * (scene/gaussian_model.py:1082-1098,1326-1338; compressai's
  * EntropyBottleneck.compress / decompress, per-channel frequency tables) as
  * lane-parallel blocks of the same arithmetic coder.  sym int32 flat
@@ -730,7 +734,8 @@ int cgs_table_ac_decode_lanes(const int64_t *blk_off, const int32_t *blk_ch,
                               const int32_t *cdf_len, const int32_t *offset,
                               const float *medians, int64_t n_per_channel,
                               const uint8_t *in, const int64_t *in_off,
-                              float *out_rows, int64_t ld_rows, void *stream);
+                              float *out_rows, int64_t ld_rows, int32_t *status,
+                              void *stream);
 /* Container version 2: the offset-mask symbols (scene/gaussian_model.py:1265-1269,
  * 1348-1353; utils/encodings.py:147-180 code them as ONE serial stream) cut into
  * chunk streams and coded by the same arithmetic coder, one wave per stream.

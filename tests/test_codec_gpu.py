@@ -410,3 +410,36 @@ def test_staged_files_hold_release_and_deferred_download(tmp_path):
     assert np.array_equal(np.fromfile(out, dtype=np.uint8), ref[0]) and np.array_equal(lens, ref[1])
     ready.wait_all()
     assert np.array_equal(blob, ref[0])
+
+
+def test_a_corrupt_lane_block_is_reported_not_decoded(tmp_path):
+    """ container version 2: the lane decoders read the 64 lane lengths of a block header bytewise and check them against
+    the block length of meta.b — flipping a length byte in feat0.b makes conduct_decoding raise instead of steering device reads
+    by the corrupt value; the untouched container still decodes afterwards (the status word is per decoding)."""
+    import golden_inputs as gi
+    from contextgs_amd.codec_driver import conduct_encoding
+    from contextgs_amd.model import GaussianModel
+
+    def build():
+        pc = GaussianModel(voxel_size=0.01)
+        sd = pc.state_dict()
+        for k, v in gi.mlp_weights(2).items():
+            sd[k] = torch.from_numpy(v).cuda()
+        pc.load_state_dict(sd, strict=False)
+        st = gi.anchor_state(3000, 2)
+        pc.set_state(st["anchor"], st["offset"], st["mask"], st["feat"], st["hyper"], st["scaling"])
+        pc.update_anchor_bound()
+        pc.eval()
+        return pc
+
+    d = str(tmp_path / "bits")
+    conduct_encoding(build(), d, container_version=2)
+    f = os.path.join(d, "feat0.b")
+    good = open(f, "rb").read()
+    bad = bytearray(good)
+    bad[0] ^= 0x40                       # lane 0's length, low byte
+    open(f, "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="malformed"):
+        build().conduct_decoding(d)
+    open(f, "wb").write(good)
+    build().conduct_decoding(d)

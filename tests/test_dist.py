@@ -527,3 +527,28 @@ def test_touched_rows_are_the_default_and_the_group_reports_itself():
     for step in range(3):
         for g0, g1 in zip(res[0][1][step][0], res[1][1][step][0]):
             assert g0 == g1
+
+
+def test_a_new_sync_closes_the_one_it_replaces_and_leaves_an_unrelated_one_alone():
+    """ A GradientSync over (some of) the same parameters replaces the open one — the documented pattern after
+    adjust_anchor, where the per-anchor Parameters are new objects and the MLP Parameters are not; a sync over OTHER
+    parameters (a second model) stays open next to it and the constructor warns instead of silently removing its hooks."""
+    import warnings
+    import torch
+    from contextgs_amd import dist as cd
+    big = lambda: torch.nn.Parameter(torch.zeros(cd.BIG_TENSOR // 4 + 4, 4))
+    w = torch.nn.Parameter(torch.zeros(3, 3))
+    a1, a2 = big(), big()
+    s1 = cd.GradientSync([w, a1])
+    assert s1._handles
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        s2 = cd.GradientSync([w, a2])                    # same model after optimizer surgery: a1 is gone, w is shared
+    assert not s1._handles and s2._handles
+    other = [torch.nn.Parameter(torch.zeros(2, 2)), big()]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        s3 = cd.GradientSync(other)
+    assert s2._handles and s3._handles, "an unrelated sync must keep its hooks"
+    assert any("still open" in str(r.message) for r in rec)
+    s2.close(); s3.close()

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
 F="--no-cpu-baseline --no-raster-only --no-codec --no-image-loss --no-eval-fps --steps 20 --warmup 5"
 for scene in headline heavy; do
- for v in product rbabl1 rbabl2 rbabl7; do
+ for v in ${VARIANTS:-product rbabl1 rbabl2 rbabl7}; do
   if [ $v = product ]; then E="X=1"; else E="CGS_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/libcgs_$v.so CGS_LIB_ALLOW_STALE=1"; fi
   if [ $scene = heavy ]; then cmd="python $GRAFT_REPO_ROOT/tools/heavy_steps.py --steps 16"; else cmd="python $GRAFT_REPO_ROOT/bench.py $F --no-heavy"; fi
   rm -rf /tmp/ba_$v; mkdir -p /tmp/ba_$v
