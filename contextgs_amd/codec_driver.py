@@ -273,22 +273,32 @@ def estimate_final_bits(pc):                                   # :980-1004
 
 
 V2_BLOCK_MIN = 64 * 128                  # shortest block of the per-group policy: 128 symbols per lane stream
-V2_BLOCK_POLICY = 1                      # 0 / absent: every group in blocks of "block_symbols"; 1: _block_for(n_sym)
+V2_BLOCK_POLICY = 2                      # 0 / absent: every group in blocks of "block_symbols"; 1, 2: _block_for
 
 
 def _block_for(n_sym, policy=V2_BLOCK_POLICY, base=None):
-    """Symbols per block of a group of n_sym symbols.  A coder launch lasts as long as its longest lane stream (block / 64
-    serial symbols), and the decoder's three level launches depend on each other: the groups of the two small levels would
-    occupy a few dozen waves for 512-symbol chains.  Policy 1 halves the block until the group has >= 1024 blocks (or lane
-    streams of 128 symbols): the big level keeps 32 768-symbol blocks, the small ones get 8 192 — a 128-byte header per block,
-    +0.2 % of the container at 1 M anchors.  Encoder and decoder derive the size from n_sym alone."""
+    """Symbols per block.  A coder launch lasts as long as its longest lane stream (block / 64 serial symbols), and the decoder's
+    three level launches depend on each other: the two small levels would occupy a few dozen waves for 512-symbol chains.
+    Policy 2 (what the encoder writes): ONE block size per LEVEL — n_sym = the level's feature symbols (anchors x 50), the same
+    size for its scaling and offset groups, which ride in the same launch — halved until the level's features make >= 256 blocks
+    (one wave per CU) or lane streams are 128 symbols long: at 1 M and at 500 k anchors the big level keeps 32 768-symbol
+    blocks, the middle one gets 16 384, the small one 8 192 (a block costs a 128-byte header and 64 stream ends, ~0.6 % of its
+    bytes at 32 768 symbols: +0.15 % of the container for the shorter blocks).
+    Policy 1 (containers written earlier in round 5; decoded, no longer written): per GROUP, n_sym = the group's own symbols,
+    halved until >= 1024 blocks.  Encoder and decoder derive the size from the counts in the header alone."""
     base = V2_BLOCK if base is None else int(base)
     if not policy:
         return base
+    want = 1024 if int(policy) == 1 else 256
     b = base
-    while b > V2_BLOCK_MIN and n_sym // b < 1024:
+    while b > V2_BLOCK_MIN and n_sym // b < want:
         b //= 2
     return b
+
+
+def _level_blocks(n_level, n_group, D, policy, base=None):
+    """Block size of a group of n_group symbols in a level of n_level anchors (see _block_for)."""
+    return _block_for(n_group if int(policy or 0) == 1 else n_level * D, policy, base)
 
 
 def _block_edges(n_sym, block=None):
@@ -420,8 +430,9 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         if lanes:      # version 2: blocks of V2_BLOCK symbols, whatever anchors they belong to
             n_off = int(cnt[-1].item())
-            edges_f, edges_s = _block_edges(n_l * D, _block_for(n_l * D)), _block_edges(n_l * 6, _block_for(n_l * 6))
-            off_edges = _block_edges(n_off, _block_for(n_off))
+            B_l = _level_blocks(n_l, n_l * D, D, V2_BLOCK_POLICY)          # one block size for the level's three groups
+            edges_f, edges_s = _block_edges(n_l * D, B_l), _block_edges(n_l * 6, B_l)
+            off_edges = _block_edges(n_off, B_l)
         else:
             edges_f, edges_s = rows * D, rows * 6
             off_edges = cnt[rows.to(cnt.device)].cpu()
@@ -573,7 +584,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     lanes = version == 2
     block = int(extra.get("block_symbols", V2_BLOCK))
     policy = int(extra.get("block_policy", 0))
-    block_of = lambda n_sym: _block_for(n_sym, policy, block)
+    block_of = lambda n_level, n_group: _level_blocks(n_level, n_group, D, policy, block)
     # (map_location: whatever tensors a header holds — the reference stores its minima / maxima as device tensors — are only
     #  ever read as Python numbers here: restoring them on the device would cost a copy each and a stream drain per .item())
     tr("meta.b loaded")
@@ -662,7 +673,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
         m30 = masks_decoded[orig_].repeat(1, 1, 3).reshape(n_, 3 * K).to(torch.bool)
         live = torch.nonzero(m30.reshape(-1))[:, 0]              # ONE compaction index for the three operands and the fill
         if rows_ is None:                                        # version 2: blocks of `block` live symbols
-            return _block_edges(int(live.numel()), block_of(int(live.numel()))), live
+            return _block_edges(int(live.numel()), block_of(n_, int(live.numel()))), live
         cnt = torch.zeros(n_ + 1, dtype=torch.int64, device=dev)
         cnt[1:] = torch.cumsum(m30.sum(1), 0)
         return cnt[rows_.to(dev)], live
@@ -705,7 +716,7 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
             _predict(pc, level, feat_in)
         tr(f"level {level}: predicted (enqueued)")
         rows = torch.tensor(_chunk_rows(n_l, max_batch), dtype=torch.int64)
-        edges_f, edges_s = ((_block_edges(n_l * D, block_of(n_l * D)), _block_edges(n_l * 6, block_of(n_l * 6))) if lanes
+        edges_f, edges_s = ((_block_edges(n_l * D, block_of(n_l, n_l * D)), _block_edges(n_l * 6, block_of(n_l, n_l * 6))) if lanes
                             else (rows * D, rows * 6))
         pending_offsets.append((level, orig, n_l, rows, mean_offsets, scale_offsets, Qo))
         groups = [(mean_feat, scale_feat, Qf, edges_f, min_feat_d[level], max_feat_d[level],

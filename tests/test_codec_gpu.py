@@ -299,14 +299,14 @@ def test_container_encode_decode_roundtrip(tmp_path, N, seed, version):
     else:
         # version 2: the same symbols cut into 1000-anchor chunk streams, each the oracle's stream for its symbols
         assert len(meta) == 15 and meta[14]["version"] == 2
-        from contextgs_amd.codec_driver import _block_for
+        from contextgs_amd.codec_driver import _level_blocks
         ck, K = meta[14]["chunk"], enc.n_offsets
-        B_of = lambda n_sym: _block_for(n_sym, int(meta[14].get("block_policy", 0)), int(meta[14]["block_symbols"]))
         want = b"".join(ref.ac_encode([row] * len(sym[a:a + ck["masks"] * K]), sym[a:a + ck["masks"] * K])
                         for a in range(0, len(sym), ck["masks"] * K))
         assert masks_b == want and sum(meta[14]["bit_masks"]) == 8 * len(masks_b)
         # feat / scaling: ceil(symbols / block) blocks per level, each a 128-byte header + 64 lane streams
         for l, n_l in enumerate(reversed(meta[13])):
+            B_of = lambda n_sym: _level_blocks(n_l, n_sym, enc.feat_dim, int(meta[14].get("block_policy", 0)), int(meta[14]["block_symbols"]))
             assert (len(meta[10][l]) == -(-n_l * enc.feat_dim // B_of(n_l * enc.feat_dim))
                     and len(meta[11][l]) == -(-n_l * 6 // B_of(n_l * 6)))
             blob = open(os.path.join(d, f"feat{l}.b"), "rb").read()

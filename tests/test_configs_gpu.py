@@ -146,7 +146,10 @@ def test_c3_500k_anchors_1080p_encode_decode(tmp_path):
     size, nv = _roundtrip(pc, tmp_path / "c3", render_check)
     assert nv > 400_000 and 20e6 < size < 120e6
     size2, _ = _roundtrip(pc, tmp_path / "c3v2", None, version=2)          # version 2: same symbols, shorter streams
-    assert abs(size2 - size) < 0.006 * size, (size, size2)       # + 128-byte block headers and 64 stream ends per block
+    # + 128-byte block headers and 64 stream ends per block: ~0.6 % at 32 768-symbol blocks, the two small levels' shorter
+    # blocks (codec_driver._block_for: their launches are a quarter / half as long) add ~0.15 %
+    print(f"[c3] container version 2: {size2} bytes against {size} (+{(size2 - size) / size * 100:.2f} %)")
+    assert abs(size2 - size) < 0.008 * size, (size, size2)
 
 
 def test_c5_3M_anchors_rate_sweep_roundtrip(tmp_path):
