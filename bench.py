@@ -569,7 +569,12 @@ def heavy_variant(args, L, pipe, bg, w, cams, steps=20):
     out = {"workload": f"{args.anchors} anchors, voxel 0.01, {args.width}x{args.height}, step={args.step_semantics}",
            "value": round(steps / dt, 3), "unit": "views/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "gaussians_per_view": int(pkg["radii"].numel()), "tile_pairs_per_view": int(last_call["num_rendered"]),
-           "R_eff": int(st[0])}
+           "R_eff": int(st[0]),
+           # which tile binning the library took for this view (csrc/api.hip use_buckets; CGS_BIN_MODE forces one)
+           "binning": ("two-level (8x4-tile buckets)" if os.environ.get("CGS_BIN_MODE", "0") == "2" or
+                       (os.environ.get("CGS_BIN_MODE", "0") == "0" and int(last_call["num_rendered"]) >= 6 * int(pkg["radii"].numel()))
+                       else "radix passes over (tile, Gaussian) pairs"),
+           "emit_pairs_is": "bucket pass (two-level) / first radix pass", "tile_sort_is": "count + scan + fill (two-level) / second radix pass"}
     for k in ("blend_fwd", "blend_bwd", "tile_sort", "emit_pairs"):
         if k in prof:
             out[k + "_avg_us"] = round(prof[k][0] / prof[k][1] * 1e3, 1)

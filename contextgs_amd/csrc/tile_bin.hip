@@ -755,7 +755,7 @@ int cgs_launch_tile_bin_buckets(const cgs_raster_cfg *cfg, int64_t P, int64_t R,
     uint2 *cranges = (uint2 *)(tab + BK_TAB_CR);
     uint32_t *cid = b.gid_a, *cmask = b.tile_key_a;
     int rc;
-    const bool tr = getenv("CGS_BK_TRACE") != nullptr;
+    static const bool tr = getenv("CGS_BK_TRACE") != nullptr;      // debugging: synchronise and report after every launch
 #define BK_TR(name) do { if (tr) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[bk] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
     {
         CgsProfScope prof(CGS_PROF_EMIT_PAIRS, stream);

@@ -6,8 +6,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 CMD="timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-raster-only --no-codec --no-heavy --no-eval-fps --no-image-loss"
 rm -rf /tmp/pmc_r /tmp/pmc_w
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -o r -- $CMD > gpurun_out/pmc_r.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- $CMD > gpurun_out/pmc_w.log 2>&1
+timeout -k 5 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -o r -- $CMD > gpurun_out/pmc_r.log 2>&1
+timeout -k 5 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o w -- $CMD > gpurun_out/pmc_w.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 out = []

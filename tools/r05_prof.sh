@@ -2,6 +2,6 @@
 # rocprofv3 kernel trace of the headline bench command (no codec / cpu baseline / heavy / eval legs) -> gpurun_out/r05_rocprof_bench_1m.txt
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 rm -rf /tmp/prof_full && mkdir -p /tmp/prof_full
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o p -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-codec --no-heavy --no-eval-fps $@ > $GRAFT_REPO_ROOT/gpurun_out/r05_bench_1m_profiled_cmd.json 2> /dev/null)
+(cd /tmp && timeout -k 5 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_full -o p -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-codec --no-heavy --no-eval-fps $@ > $GRAFT_REPO_ROOT/gpurun_out/r05_bench_1m_profiled_cmd.json 2> /dev/null)
 python tools/rocprof_summary.py /tmp/prof_full gpurun_out/r05_rocprof_bench_1m.txt 70 > /dev/null; head -64 gpurun_out/r05_rocprof_bench_1m.txt | cut -c1-150
 tail -c 1500 gpurun_out/r05_bench_1m_profiled_cmd.json
