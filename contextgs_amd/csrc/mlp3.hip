@@ -79,10 +79,21 @@ __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int ti
     for (int i = tid; i < L::OP; i += nthr) b2s[i] = i < OUT ? h.b2[i] : 0.f;
 }
 
+// (round 5) the forward's stores and loads go through raw buffer instructions (buf_access.h): the predicated global accesses
+// of rounds 1-4 — 59 of them behind 88 branches — had a `s_waitcnt vmcnt(0)` at 25 exec-mask joins per tile; the tile loop now
+// waits with partial counts only.  Measured on one box: 517 us either way at 1 M anchors (tools/m3fwd_ab.sh) — with 16 waves
+// per CU the other waves covered those drains; the kernel stays bound by its 1.26 KB of stores per anchor in 64-byte chunks
+// that straddle sectors (profiles/r03_row_alignment.txt).  Kept for the bounds-checked tails and the shared helpers.
+#ifndef M3_FWD_BUF
+#define M3_FWD_BUF 1
+#endif
+#define M3_MAX_ROWS (4ll << 20)          // x 600-byte Hcat rows = 2.5 GB: every operand of a launch stays below CL_MAX_BYTES
+struct M3FwdBufs { ClBuf H, Y[3], Xo, X, src, feat, anc; };
+
 template <int OUT, int ACT, int RT>
 __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const f32x4 (&xb)[RT][M3_NTI],
                                             const bool (&valid)[RT], int64_t row0, int g, int c,
-                                            float *__restrict__ Hcat) {
+                                            float *__restrict__ Hcat, const M3FwdBufs &B) {
     using L = M3FwdLds<OUT>;
     const float *W1s = lds, *W2s = W1s + M3_XP * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
     f32x4 acc1[M3_NT1][RT];
@@ -140,7 +151,11 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             const int64_t row = row0 + rt * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc1[t][rt][r] = fmaxf(acc1[t][rt][r] + b1s[16 * t + 4 * g + r], 0.f);
+#if M3_FWD_BUF
+            frag_bstore4<M3_HID>(B.H, (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4, t, g, valid[rt], acc1[t][rt]);
+#else
             if (Hcat) frag_store4<M3_HID>(Hcat + row * M3_HLD + M3_HPITCH * head, t, g, valid[rt], acc1[t][rt]);
+#endif
         }
     f32x4 acc2[L::NT2][RT];
 #pragma unroll
@@ -196,7 +211,11 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
+#if M3_FWD_BUF
+            frag_bstore4<OUT>(B.Y[head], (uint32_t)row * (OUT * 4), u, g, valid[rt], y);
+#else
             frag_store4<OUT>(h.Y + row * OUT, u, g, valid[rt], y);
+#endif
         }
 }
 
@@ -227,6 +246,20 @@ __device__ __forceinline__ f32x4 m3_load_x_rows(const M3Rows &R, int64_t row, in
     return v;
 }
 
+// the same row through buffer loads: `srow` = src_row[row] (fetched a tile earlier by the caller), no branch anywhere
+__device__ __forceinline__ f32x4 m3_load_x_rows_b(const M3FwdBufs &B, float cam0, float cam1, float cam2, int64_t row, int64_t srow,
+                                                  int q, int g, bool valid) {
+    const uint32_t fo = (uint32_t)srow * (M3_HID * 4);
+    if (q < 3) return cl_l128(B.feat, cl_sel(valid, fo + (uint32_t)(16 * q + 4 * g) * 4));
+    const f32x4 f2 = cl_l64(B.feat, cl_sel(valid && g == 0, fo + 48 * 4));                    // features 48, 49
+    const f32x4 a = cl_l96(B.anc, cl_sel(valid && g < 2, (uint32_t)row * 12));
+    const float ux = a[0] - cam0, uy = a[1] - cam1, uz = a[2] - cam2;
+    const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
+    const f32x4 v0 = (f32x4){f2[0], f2[1], ux / dist, uy / dist}, v1 = (f32x4){uz / dist, dist, 0.f, 0.f};
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    return !valid ? z : (g == 0 ? v0 : (g == 1 ? v1 : z));
+}
+
 template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES, bool ROWS>
 __global__ void __launch_bounds__(WAVES * 64)
     mlp3_fwd_kernel(const float *__restrict__ X, int64_t ldx, M3Head h0, M3Head h1, M3Head h2,
@@ -244,6 +277,65 @@ __global__ void __launch_bounds__(WAVES * 64)
     f32x4 xb[RT][M3_NTI], xn[RT][M3_NTI];
     bool valid[RT], validn[RT];
     const int64_t tile0 = (int64_t)blockIdx.x * WAVES + wave, tstride = (int64_t)gridDim.x * WAVES;
+    M3FwdBufs B;
+#if M3_FWD_BUF
+    {
+        const uint64_t nb = (uint64_t)n;
+        B.H = cl_buf(Hcat, nb * (M3_HLD * 4));
+        B.Y[0] = cl_buf(h0.Y, nb * (O0 * 4)); B.Y[1] = cl_buf(h1.Y, nb * (O1 * 4)); B.Y[2] = cl_buf(h2.Y, nb * (O2 * 4));
+        B.Xo = cl_buf(ROWS ? R.X_out : nullptr, nb * (M3_XLD * 4));
+        B.X = cl_buf(ROWS ? nullptr : X, nb > 0 ? ((nb - 1) * (uint64_t)ldx + M3_IN) * 4 : 0);
+        B.src = cl_buf(ROWS ? R.src_row : nullptr, nb * 8);
+        B.feat = cl_buf(ROWS ? R.feat_src : nullptr, CL_MAX_BYTES);       // (its row count is not an argument: bounded by src_row)
+        B.anc = cl_buf(ROWS ? R.anchor : nullptr, nb * 12);
+    }
+    const float cam0 = ROWS ? R.cam[0] : 0.f, cam1 = ROWS ? R.cam[1] : 0.f, cam2 = ROWS ? R.cam[2] : 0.f;
+    const uint32_t ldx4 = (uint32_t)ldx * 4;
+    // src_row of the tile AFTER the next one is in flight while the next tile's rows are gathered through src_row of the next
+    int64_t srow_n[RT], srow_nn[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t row = tile0 * 16 * RT + rt * 16 + c, rown = row + tstride * 16 * RT;
+        valid[rt] = tile0 < ntiles && row < n;
+        const int64_t srow = ROWS ? cl_li64(B.src, cl_sel(valid[rt], (uint32_t)row * 8)) : 0;
+        srow_n[rt] = ROWS ? cl_li64(B.src, cl_sel(rown < n, (uint32_t)rown * 8)) : 0;
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q)
+            xb[rt][q] = ROWS ? m3_load_x_rows_b(B, cam0, cam1, cam2, row, srow, q, g, valid[rt])
+                             : frag_bmask4<M3_IN>(frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, valid[rt]), q, g);
+    }
+    for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
+        const int64_t row0 = tile * 16 * RT;
+        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c, rownn = row + tstride * 16 * RT;
+            validn[rt] = row < n;
+            srow_nn[rt] = ROWS ? cl_li64(B.src, cl_sel(rownn < n, (uint32_t)rownn * 8)) : 0;
+#pragma unroll
+            for (int q = 0; q < M3_NTI; ++q)
+                xn[rt][q] = ROWS ? m3_load_x_rows_b(B, cam0, cam1, cam2, row, srow_n[rt], q, g, validn[rt])
+                                 : frag_bmask4<M3_IN>(frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, validn[rt]), q, g);
+        }
+        if (ROWS) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < M3_NTI; ++q)
+                    frag_bstore4<M3_IN>(B.Xo, (uint32_t)(row0 + rt * 16 + c) * (M3_XLD * 4), q, g, valid[rt], xb[rt][q]);
+        }
+        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B);
+        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B);
+        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            valid[rt] = validn[rt];
+            srow_n[rt] = srow_nn[rt];
+#pragma unroll
+            for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = xn[rt][q];
+        }
+    }
+#else
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int64_t row = tile0 * 16 * RT + rt * 16 + c;
@@ -270,9 +362,9 @@ __global__ void __launch_bounds__(WAVES * 64)
                 for (int q = 0; q < M3_NTI; ++q)
                     frag_store4<M3_IN>(R.X_out + (row0 + rt * 16 + c) * M3_XLD, q, g, valid[rt], xb[rt][q]);
         }
-        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat);
-        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat);
-        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat);
+        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B);
+        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B);
+        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             valid[rt] = validn[rt];
@@ -280,6 +372,7 @@ __global__ void __launch_bounds__(WAVES * 64)
             for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = xn[rt][q];
         }
     }
+#endif
 }
 
 // ---- backward ------------------------------------------------------------------------------------
@@ -781,12 +874,19 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
-    const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
-    const int64_t want = (tiles + WAVES - 1) / WAVES;
-    const int grid = (int)(want < m3_cus() ? want : m3_cus());
+    if (ldx < M3_IN || ldx > 4096) { cgs_set_error("anchor_mlp3_forward: ldx out of range"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
-                       X, ldx, h[0], h[1], h[2], Hcat, n, M3Rows{});
+    // the kernel addresses its operands through 32-bit byte offsets (raw buffers): M3_MAX_ROWS rows per launch
+    const int64_t step = ldx <= 256 ? M3_MAX_ROWS : M3_MAX_ROWS / 16;
+    for (int64_t r0 = 0; r0 < n; r0 += step) {
+        const int64_t m = n - r0 < step ? n - r0 : step;
+        for (int i = 0; i < 3; ++i) h[i].Y = ys[i] + r0 * (i == 0 ? 10 : (i == 1 ? 30 : 70));
+        const int64_t tiles = (m + 16 * RT - 1) / (16 * RT);
+        const int64_t want = (tiles + WAVES - 1) / WAVES;
+        const int grid = (int)(want < m3_cus() ? want : m3_cus());
+        hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                           X + r0 * ldx, ldx, h[0], h[1], h[2], Hcat ? Hcat + r0 * M3_HLD : nullptr, m, M3Rows{});
+    }
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -810,13 +910,19 @@ extern "C" int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t
     M3Head h[3];
     float *ys[3] = {Y_op, Y_color, Y_cov};
     for (int i = 0; i < 3; ++i) h[i] = M3Head{W1[i], b1[i], W2[i], b2[i], ys[i], nullptr, nullptr};
-    const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
-    const int64_t want = (tiles + WAVES - 1) / WAVES;
-    const int grid = (int)(want < m3_cus() ? want : m3_cus());
-    M3Rows R{feat_src, src_row, anchor_vis, cam3, X_out, nullptr, nullptr};
     CgsProfScope prof(CGS_PROF_MLP_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
-                       nullptr, 0, h[0], h[1], h[2], Hcat, n, R);
+    // 32-bit byte offsets inside the kernel (raw buffers): M3_MAX_ROWS rows per launch; feat_src itself must stay below 4 GB
+    // (21 M source rows)
+    for (int64_t r0 = 0; r0 < n; r0 += M3_MAX_ROWS) {
+        const int64_t m = n - r0 < M3_MAX_ROWS ? n - r0 : M3_MAX_ROWS;
+        for (int i = 0; i < 3; ++i) h[i].Y = ys[i] + r0 * (i == 0 ? 10 : (i == 1 ? 30 : 70));
+        const int64_t tiles = (m + 16 * RT - 1) / (16 * RT);
+        const int64_t want = (tiles + WAVES - 1) / WAVES;
+        const int grid = (int)(want < m3_cus() ? want : m3_cus());
+        M3Rows R{feat_src, src_row + r0, anchor_vis + 3 * r0, cam3, X_out ? X_out + r0 * M3_XLD : nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                           nullptr, 0, h[0], h[1], h[2], Hcat ? Hcat + r0 * M3_HLD : nullptr, m, R);
+    }
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -883,7 +989,8 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     h[1] = M3Head{W1[1], nullptr, W2[1], nullptr, const_cast<float *>(Y_color), dY_color, dZ2_color};
     h[2] = M3Head{W1[2], nullptr, W2[2], nullptr, nullptr, dY_cov, nullptr};
 #if M3_FUSED_WGRAD
-    if (!data_only) {
+    // (the fused kernel addresses its operands through 32-bit byte offsets: beyond M3_MAX_ROWS rows the two-launch form runs)
+    if (!data_only && n <= M3_MAX_ROWS && ldx <= 256) {
         // data AND weight gradients in one launch (mlp3_bwd_wg_kernel): dZ1cat / dZ2_* stay untouched
         const int64_t tiles16 = (n + 15) / 16;
         const int64_t wantw = (tiles16 + M3W_WAVES - 1) / M3W_WAVES;
