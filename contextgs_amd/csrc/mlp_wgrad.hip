@@ -600,10 +600,16 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
     for (int k = nprod; k < WGM_MAX_PROD; ++k) { pr.dW[k] = nullptr; pr.db[k] = nullptr; pr.off[k] = E; pr.dadb[k] = 0; }
     pr.off[WGM_MAX_PROD] = E;
     pr.nprod = nprod;
-    constexpr int UNR = 2;
+#ifndef WGM_UNR
+#define WGM_UNR 2
+#endif
+    constexpr int UNR = WGM_UNR;
     a.ntask = ntask;
     a.E = E;
-    int64_t blocks = (n + 255) / 256;
+#ifndef WGM_MIN_ROWS
+#define WGM_MIN_ROWS 256         // rows per workgroup at least: a workgroup zeroes, combines and writes a ~100 KB image whatever its rows
+#endif
+    int64_t blocks = (n + WGM_MIN_ROWS - 1) / WGM_MIN_ROWS;
     int64_t cap = num_cus;
     const int64_t fit_blocks = (int64_t)(scratch_bytes / ((size_t)E * sizeof(float)));
     if (cap > fit_blocks) cap = fit_blocks;
