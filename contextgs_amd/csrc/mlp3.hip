@@ -81,12 +81,9 @@ __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int ti
 
 // (round 5) the forward's stores and loads go through raw buffer instructions (buf_access.h): the predicated global accesses
 // of rounds 1-4 — 59 of them behind 88 branches — had a `s_waitcnt vmcnt(0)` at 25 exec-mask joins per tile; the tile loop now
-// waits with partial counts only.  Measured on one box: 517 us either way at 1 M anchors (tools/m3fwd_ab.sh) — with 16 waves
+// waits with partial counts only.  Measured on one box: 517 us either way at 1 M anchors (profiles/r05_mlp3_fwd_buffer_ab.txt) — with 16 waves
 // per CU the other waves covered those drains; the kernel stays bound by its 1.26 KB of stores per anchor in 64-byte chunks
 // that straddle sectors (profiles/r03_row_alignment.txt).  Kept for the bounds-checked tails and the shared helpers.
-#ifndef M3_FWD_BUF
-#define M3_FWD_BUF 1
-#endif
 #define M3_MAX_ROWS (4ll << 20)          // x 600-byte Hcat rows = 2.5 GB: every operand of a launch stays below CL_MAX_BYTES
 struct M3FwdBufs { ClBuf H, Y[3], Xo, X, src, feat, anc; };
 
@@ -151,11 +148,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             const int64_t row = row0 + rt * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc1[t][rt][r] = fmaxf(acc1[t][rt][r] + b1s[16 * t + 4 * g + r], 0.f);
-#if M3_FWD_BUF
             frag_bstore4<M3_HID>(B.H, (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4, t, g, valid[rt], acc1[t][rt]);
-#else
-            if (Hcat) frag_store4<M3_HID>(Hcat + row * M3_HLD + M3_HPITCH * head, t, g, valid[rt], acc1[t][rt]);
-#endif
         }
     f32x4 acc2[L::NT2][RT];
 #pragma unroll
@@ -211,11 +204,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
-#if M3_FWD_BUF
             frag_bstore4<OUT>(B.Y[head], (uint32_t)row * (OUT * 4), u, g, valid[rt], y);
-#else
-            frag_store4<OUT>(h.Y + row * OUT, u, g, valid[rt], y);
-#endif
         }
 }
 
@@ -232,21 +221,7 @@ struct M3Rows {
     float *d_anchor;            // backward: [n, 3]
 };
 
-__device__ __forceinline__ f32x4 m3_load_x_rows(const M3Rows &R, int64_t row, int q, int g, bool valid) {
-    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!valid) return v;
-    const float *fr = R.feat_src + R.src_row[row] * M3_HID;          // 50 features per row
-    const int col0 = 16 * q + 4 * g;
-    if (col0 + 3 < M3_HID) return *(const f32x4_a4 *)(fr + col0);
-    if (col0 >= M3_IN) return v;
-    const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1], uz = R.anchor[3 * row + 2] - R.cam[2];
-    const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
-    if (col0 == 48) { v[0] = fr[48]; v[1] = fr[49]; v[2] = ux / dist; v[3] = uy / dist; }
-    else { v[0] = uz / dist; v[1] = dist; }                          // col0 == 52
-    return v;
-}
-
-// the same row through buffer loads: `srow` = src_row[row] (fetched a tile earlier by the caller), no branch anywhere
+// through buffer loads: `srow` = src_row[row] (fetched a tile earlier by the caller), no branch anywhere
 __device__ __forceinline__ f32x4 m3_load_x_rows_b(const M3FwdBufs &B, float cam0, float cam1, float cam2, int64_t row, int64_t srow,
                                                   int q, int g, bool valid) {
     const uint32_t fo = (uint32_t)srow * (M3_HID * 4);
@@ -278,7 +253,6 @@ __global__ void __launch_bounds__(WAVES * 64)
     bool valid[RT], validn[RT];
     const int64_t tile0 = (int64_t)blockIdx.x * WAVES + wave, tstride = (int64_t)gridDim.x * WAVES;
     M3FwdBufs B;
-#if M3_FWD_BUF
     {
         const uint64_t nb = (uint64_t)n;
         B.H = cl_buf(Hcat, nb * (M3_HLD * 4));
@@ -335,44 +309,6 @@ __global__ void __launch_bounds__(WAVES * 64)
             for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = xn[rt][q];
         }
     }
-#else
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int64_t row = tile0 * 16 * RT + rt * 16 + c;
-        valid[rt] = tile0 < ntiles && row < n;
-#pragma unroll
-        for (int q = 0; q < M3_NTI; ++q)
-            xb[rt][q] = ROWS ? m3_load_x_rows(R, row, q, g, valid[rt]) : frag_load4<M3_IN>(X + row * ldx, q, g, valid[rt]);
-    }
-    for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
-        const int64_t row0 = tile * 16 * RT;
-        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the tile loop (LICM would spill them)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c;
-            validn[rt] = row < n;
-#pragma unroll
-            for (int q = 0; q < M3_NTI; ++q)
-                xn[rt][q] = ROWS ? m3_load_x_rows(R, row, q, g, validn[rt]) : frag_load4<M3_IN>(X + row * ldx, q, g, validn[rt]);
-        }
-        if (ROWS && R.X_out) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int q = 0; q < M3_NTI; ++q)
-                    frag_store4<M3_IN>(R.X_out + (row0 + rt * 16 + c) * M3_XLD, q, g, valid[rt], xb[rt][q]);
-        }
-        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B);
-        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B);
-        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            valid[rt] = validn[rt];
-#pragma unroll
-            for (int q = 0; q < M3_NTI; ++q) xb[rt][q] = xn[rt][q];
-        }
-    }
-#endif
 }
 
 // ---- backward ------------------------------------------------------------------------------------
