@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import itertools
 import threading
+import weakref
 
 import torch
 
@@ -191,13 +192,17 @@ class RowSource:
 class _RowSourceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, feat, scal, off):
-        ctx.src = src
+        # (a WEAK reference: `src` keeps this node's output — its token — so a strong one would be a cycle through the C++
+        #  node, invisible to Python's collector; the level nodes that consumed the token hold `src` until the graph is freed)
+        ctx.src_ref = weakref.ref(src)
         ctx.set_materialize_grads(False)     # the token's gradient carries nothing: no zeros(1) for it
         return feat.new_empty(1)             # (its VALUE is never read either: no fill launch)
 
     @staticmethod
     def backward(ctx, _g):
-        src = ctx.src
+        src = ctx.src_ref()
+        if src is None:                      # no level ever took the token: nothing was read, nothing to hand on
+            return None, None, None, None
         if src.rows_written != src.rows_read:
             raise RuntimeError("RowSource: a level that read rows in the forward did not run its backward "
                                f"({src.rows_written} of {src.rows_read} rows have gradients)")
@@ -724,7 +729,10 @@ class _LevelFused(torch.autograd.Function):
                                           _lib.ptr(b2c), _lib.ptr(pred), out, _lib.ptr(h_sub), m, stream), "cgs_mlp2_forward")
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(X, x_sub, h_sub, W1c, b1c, W2c, b2c)
-        ctx.cfg, ctx.dims = cfg, (n, in_f, hid, out, n_stat, m)
+        # (without "outs": they are this node's OUTPUTS — an output kept on its own ctx is a reference cycle through the C++
+        #  node that Python's collector cannot see: every step's level nodes, RowSource and ~350 MB of level tensors stayed
+        #  alive for the life of the process, found in round 5 when the device filled up — tools/leak_probe.py)
+        ctx.cfg, ctx.dims = {k: v for k, v in cfg.items() if k != "outs"}, (n, in_f, hid, out, n_stat, m)
         ctx.shapes = (tuple(anchor.shape), None if bf is None else tuple(bf.shape), None if bs is None else tuple(bs.shape))
         if pred is None:
             pred = torch.empty(0, out, dtype=_f32, device=dev)

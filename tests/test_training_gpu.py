@@ -264,3 +264,31 @@ def test_visible_list_equals_torch_nonzero(n, p):
     filler = torch.ones(1000, device="cuda").cumsum(0)          # work enqueued between the two halves
     got = pending.wait()
     assert got.dtype == torch.int64 and torch.equal(got, torch.nonzero(mask)[:, 0]) and float(filler[-1]) == 1000.0
+
+
+@pytest.mark.parametrize("step", [5000, 20000])
+def test_training_steps_do_not_accumulate_device_memory(step):
+    """Live device memory after step k is what it was after step 2, for both training phases: no autograd node keeps one of
+    its own outputs (a cycle through the C++ node that Python's collector cannot break).  Round 5's fused level node did —
+    ~350 MB per step at 1 M anchors, every level node and RowSource of every step — until the device was full and each step
+    paid an allocator retry (tools/leak_probe.py)."""
+    import gc
+    from contextgs_amd.renderer import prefilter_voxel, render
+    pc, cams, pipe, bg = _setup(N=60000)
+    params = [p for p in pc.parameters() if p.requires_grad]
+    live = []
+    for i in range(7):
+        for p in params:
+            p.grad = None
+        cam = cams[i % len(cams)]
+        pkg = render(cam, pc, pipe, bg, visible_mask=prefilter_voxel(cam, pc, pipe, bg), step=step)
+        loss = pkg["render"].mean() + (0.001 * pkg["bit_per_param"] if pkg["bit_per_param"] is not None else 0.0)
+        loss.backward()
+        del pkg, loss
+        torch.cuda.synchronize()
+        live.append(torch.cuda.memory_allocated())
+    gc.collect()
+    ctxs = [type(o).__name__ for o in gc.get_objects() if type(o).__name__ in ("_LevelFusedBackward", "_RowSourceFnBackward", "_NoiseQuantBackward")]
+    print(f"[leak] live bytes after steps 2..6: {live[2:]}, context nodes alive: {len(ctxs)}")
+    assert max(live[3:]) - live[2] <= 8 << 20, live          # (views differ by a few thousand Gaussians: a few MB either way)
+    assert len(ctxs) <= 4, ctxs                              # at most the last step's nodes (3 levels + the token node), not 7 steps' worth
