@@ -273,12 +273,13 @@ def main():
     views = args.steps * world
     seg_ms = sorted(t / k * 1e3 for t, k in zip(seg_s, seg_k))
     ms_per_step = seg_ms[len(seg_ms) // 2]                     # median segment
-    # Shared hosts: the GPU boxes of this pool are slots of one 256-core host (load average ~25 from the other slots).  The
-    # host's enqueue loop of a step takes ~4.4 ms of CPU against ~7.5 ms of kernels, so a neighbour that slows the host
-    # 2-3 x makes the step host-bound for as long as it runs: whole processes were seen at 14.6 ms per step with every kernel at
-    # its usual duration (tools/heavy_diag.py, tools/numa_probe.py).  N = 1 only: when the K timed steps
-    # took more than 1.3 x this library's kernel time of the same steps (normally 1.09 x), they are timed again — at most two
-    # more attempts, 5 s apart — and the least disturbed attempt is reported; EVERY attempt is listed in `timing.attempts`.
+    # A disturbed run says so.  The host's enqueue loop of a step takes ~4 ms of CPU against ~7.5 ms of kernels, so anything
+    # that slows the host by 2 x makes the step host-bound with every kernel at its usual duration: the boxes of this pool are
+    # slots of one 256-core host (load average ~25 from the other slots), and a hipMalloc inside a step costs ~7 ms on some of
+    # them (how round 5's leak of the fused level node showed up: 14.6 ms steps; HISTORY.md "Round 5").  N = 1 only: when the K
+    # timed steps took more than RETIME_RATIO (1.3) x this library's kernel time of the same steps (normally 1.09 x), they are
+    # timed again — at most two more attempts, 5 s apart — and the least disturbed attempt is reported; EVERY attempt is listed
+    # in `timing.attempts`.
     lib_ms_now = sum(v[0] for v in prof.values()) / max(1, args.steps)
     attempts = [{"ms_per_step": round(ms_per_step, 3), "ms_per_step_by_segment": [round(t / k * 1e3, 3) for t, k in zip(seg_s, seg_k)]}]
     while world == 1 and ms_per_step > RETIME_RATIO * lib_ms_now and len(attempts) < 3:
@@ -613,8 +614,8 @@ def heavy_variant(args, L, pipe, bg, w, cams, steps=20):
            "value": round(steps / dt, 3), "unit": "views/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "ms_per_step_by_segment": [round(t / steps * 1e3, 3) for t in segs],
            "attempts_ms_per_step": attempts, "kernel_ms_per_step_of_the_profiled_pass": round(lib_ms_now, 3),
-           # what to look at when a run shows 19 ms per step here (seen in some processes, never reproduced in isolation:
-           # tools/heavy_diag.py): the host's enqueue loop per segment and what the caching allocator did during the timed steps
+           # the host's enqueue loop per segment and what the caching allocator did during the timed steps (a device allocation
+           # inside a step costs up to ~7 ms on some boxes: tools/heavy_diag.py)
            "host_ms_per_step_by_segment": host_ms,
            "allocator": {k: int(ms1[k] - ms0[k]) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")},
            "reserved_GiB": round(torch.cuda.memory_reserved() / 2 ** 30, 1),

@@ -16,8 +16,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
-import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -97,53 +95,10 @@ def pair_capacity_for(num_rendered: int) -> int:
     return ((num_rendered + num_rendered // 4 + 4096 + (1 << 20) - 1) >> 20) << 20
 
 
-# The rasterizer's big workspaces (geometry ~0.6 GB, binning up to several GB, backward scratch) come from a pool of their own,
-# not from torch's caching allocator.  Their sizes follow the view's Gaussian count, so consecutive views ask for slightly
-# different sizes; a request a little LARGER than every block its size class has free makes the caching allocator carve it
-# out of the next bigger free block — the multi-GB binning workspace of the previous view — and the next binning workspace then
-# needs a fresh hipMalloc.  At 136 M pairs per view that leaked ~4 GB of reserved memory every other step; once the device was
-# full every step paid an out-of-memory retry (all cached blocks freed and allocated again): 7.8 -> 19.3 ms per step, kernels
-# unchanged (round 5, tools/heavy_diag.py).  The pool rounds a request up to 1/8-octave size classes and hands out a VIEW of
-# a pooled buffer; the buffer returns to its class's free list when the view dies (the autograd node that holds it has run).
-# Same-stream reuse is ordered by the stream, exactly as with the caching allocator.
-_POOL_FREE: dict = {}        # (device, class bytes) -> [buffers]
-_POOL_LOCK = threading.Lock()
-_POOL_KEEP = 3               # free buffers kept per class
-
-
-def _size_class(nbytes: int) -> int:
-    nbytes = max(int(nbytes), 256)
-    if nbytes <= (1 << 20):
-        return 1 << 20
-    q = 1 << (nbytes.bit_length() - 4)          # an eighth of the power of two below
-    return (nbytes + q - 1) // q * q
-
-
-def _pool_release(key, buf):
-    with _POOL_LOCK:
-        free = _POOL_FREE.setdefault(key, [])
-        if len(free) < _POOL_KEEP:
-            free.append(buf)
-
-
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    nbytes = max(int(nbytes), 256)
-    dev = torch.device(device)
-    key = (str(dev), _size_class(nbytes))
-    with _POOL_LOCK:
-        free = _POOL_FREE.get(key)
-        buf = free.pop() if free else None
-    if buf is None:
-        buf = torch.empty(key[1], dtype=torch.uint8, device=dev)
-    view = buf[:nbytes]
-    weakref.finalize(view, _pool_release, key, buf)
-    return view
-
-
-def workspace_pool_clear():
-    """Drop the pooled workspaces (e.g. before a phase with other image sizes; torch.cuda.empty_cache() then returns them)."""
-    with _POOL_LOCK:
-        _POOL_FREE.clear()
+    # (plain caching-allocator blocks.  A pool of size-classed buffers of our own was tried in round 5 while hunting 19 ms steps
+    #  at 136 M pairs — it was not the cause (a leak in ctx_ops._LevelFused was) and cost 0.3 ms of host time per step: removed)
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 def bin_and_blend(cfg, P, geom, img, color, stream, ticket):
