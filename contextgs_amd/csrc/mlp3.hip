@@ -489,6 +489,12 @@ __global__ void __launch_bounds__(WAVES * 64)
 #define M3W_XPREFETCH 1      // X of the next tile is fetched during the last head of this one
 #endif
 #define M3W_PATCH (16 * M3W_LD)
+#ifndef M3W_PREFETCH_AT
+#define M3W_PREFETCH_AT 2    // where in a head the next head's global operands are requested: 0 after the transposes are written, 1 after dH, 2 after dW2
+#endif
+#ifndef M3W_EARLY
+#define M3W_EARLY 0         // a loop's first LDS operands are requested one loop ahead
+#endif
 #define M3W_NPATCH 13          // per wave: H 0..3, dZ2 4..8, dZ1 9..12 (X uses 0..3 before the first head)
 #define M3W_WAVES 4
 #define M3W_E (M3_GLD * (M3_IN + 1) + (10 + 30 + 70) * (M3_HID + 1))
@@ -564,57 +570,109 @@ __device__ __forceinline__ void m3w_head(const float *lds, float *patches, M3wOp
     for (int t = 0; t < M3_NT1; ++t) m3w_put(patches + t * M3W_PATCH, op.h[t], g, c);
 #pragma unroll
     for (int u = 0; u < L::NT2; ++u) m3w_put(patches + (4 + u) * M3W_PATCH, b[u], g, c);
-    prefetch();
+    if (M3W_PREFETCH_AT == 0) prefetch();
+    // (round 5) Every MFMA group's LDS operands are read one group ahead, behind scheduling fences, and each loop's FIRST
+    // operands one loop ahead (M3W_EARLY): with one wave per SIMD a read issued just in time leaves the matrix pipe idle for
+    // its whole round trip — 375 of the 616 MFMAs of a tile had an lgkmcnt wait right in front of them (1023 -> 880 us).
+    auto ldw2 = [&](int u, int j) {
+        f32x4 w;
+#pragma unroll
+        for (int t = 0; t < M3_NT1; ++t) w[t] = W2n[(16 * u + 4 * g + j) * L::SA + 16 * t + c];
+        return w;
+    };
+    auto ldw1 = [&](int t, int r) {
+        f32x4 w;
+#pragma unroll
+        for (int v = 0; v < M3_NTI; ++v) w[v] = W1n[(16 * t + 4 * g + r) * L::SB + 16 * v + c];
+        return w;
+    };
     // dH = W2^T dZ2 (transposed chain, layout F)
-    f32x4 adh[M3_NT1];
+    f32x4 adh[M3_NT1], hn[M3_NT1], zc;
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t) adh[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 wc = ldw2(0, 0);
+        if (M3W_EARLY) {                        // the N forms of H and of the first dZ2 tile: needed by the dW2 products
 #pragma unroll
-    for (int u = 0; u < L::NT2; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (16 * u + j >= OUT) continue;
-#pragma unroll
-            for (int t = 0; t < M3_NT1; ++t)
-                adh[t] = frag_mfma(W2n[(16 * u + 4 * g + j) * L::SA + 16 * t + c], b[u][j], adh[t]);
+            for (int t = 0; t < M3_NT1; ++t) hn[t] = m3w_get(patches + t * M3W_PATCH, g, c);
+            zc = m3w_get(patches + 4 * M3W_PATCH, g, c);
         }
+#pragma unroll
+        for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (16 * u + j >= OUT) continue;
+                const int un = j == 3 ? u + 1 : u, jn = j == 3 ? 0 : j + 1;
+                f32x4 wn = wc;
+                if (un < L::NT2 && 16 * un + jn < OUT) wn = ldw2(un, jn);
+                M3_FENCE();
+#pragma unroll
+                for (int t = 0; t < M3_NT1; ++t) adh[t] = frag_mfma(wc[t], b[u][j], adh[t]);
+                M3_FENCE();
+                wc = wn;
+            }
+    }
+    if (M3W_PREFETCH_AT == 1) prefetch();
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) adh[t][r] = op.h[t][r] > 0.f ? adh[t][r] : 0.f;
         m3w_put(patches + (9 + t) * M3W_PATCH, adh[t], g, c);          // patches 9..12: dZ1
     }
-    // dW2 += dZ2^T [H | 1] (row contraction, layout N): the N forms are read back just in time (4 registers at a time)
-    f32x4 hn[M3_NT1];
+    // dW2 += dZ2^T [H | 1] (row contraction, layout N)
+    if (!M3W_EARLY) {
 #pragma unroll
-    for (int t = 0; t < M3_NT1; ++t) hn[t] = m3w_get(patches + t * M3W_PATCH, g, c);
+        for (int t = 0; t < M3_NT1; ++t) hn[t] = m3w_get(patches + t * M3W_PATCH, g, c);
+        zc = m3w_get(patches + 4 * M3W_PATCH, g, c);
+    }
     if (c == M3_HID - 48) hn[3] = ones;                         // column 50 of [H | 1]
+    f32x4 wx, dc;
+    if (M3W_EARLY) {                            // first operands of the dX and dW1 loops, in flight during the dW2 products
+        wx = ldw1(0, 0);
+        dc = m3w_get(patches + 9 * M3W_PATCH, g, c);
+    }
 #pragma unroll
     for (int u = 0; u < L::NT2; ++u) {
-        const f32x4 zn = m3w_get(patches + (4 + u) * M3W_PATCH, g, c);
+        f32x4 zn = zc;
+        if (u + 1 < L::NT2) zn = m3w_get(patches + (4 + u + 1) * M3W_PATCH, g, c);
+        M3_FENCE();
 #pragma unroll
         for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aw2[u][t] = frag_mfma(zn[r], hn[t][r], aw2[u][t]);
+            for (int r = 0; r < 4; ++r) aw2[u][t] = frag_mfma(zc[r], hn[t][r], aw2[u][t]);
+        M3_FENCE();
+        zc = zn;
     }
+    if (M3W_PREFETCH_AT == 2) prefetch();
     // dX += W1^T dZ1
+    if (!M3W_EARLY) wx = ldw1(0, 0);
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (16 * t + r >= M3_HID) continue;
+            const int tn = r == 3 ? t + 1 : t, rn = r == 3 ? 0 : r + 1;
+            f32x4 wn = wx;
+            if (tn < M3_NT1 && 16 * tn + rn < M3_HID) wn = ldw1(tn, rn);
+            M3_FENCE();
 #pragma unroll
-            for (int v = 0; v < M3_NTI; ++v)
-                adx[v] = frag_mfma(W1n[(16 * t + 4 * g + r) * L::SB + 16 * v + c], adh[t][r], adx[v]);
+            for (int v = 0; v < M3_NTI; ++v) adx[v] = frag_mfma(wx[v], adh[t][r], adx[v]);
+            M3_FENCE();
+            wx = wn;
         }
     // dW1 += dZ1^T [X | 1]
+    if (!M3W_EARLY) dc = m3w_get(patches + 9 * M3W_PATCH, g, c);
 #pragma unroll
     for (int t = 0; t < M3_NT1; ++t) {
-        const f32x4 dn = m3w_get(patches + (9 + t) * M3W_PATCH, g, c);
+        f32x4 dn = dc;
+        if (t + 1 < M3_NT1) dn = m3w_get(patches + (9 + t + 1) * M3W_PATCH, g, c);
+        M3_FENCE();
 #pragma unroll
         for (int v = 0; v < M3_NTI; ++v)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
+            for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dc[r], xn[v][r], aw1[t][v]);
+        M3_FENCE();
+        dc = dn;
     }
 }
 
