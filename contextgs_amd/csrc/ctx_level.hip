@@ -42,6 +42,10 @@ struct ClShape {
 };
 
 // no IR-level motion of the loads (memory clobber) and no machine-scheduler motion (sched_barrier) across
+#ifndef CL_PIPE
+#define CL_PIPE 1             // LDS operands of the next MFMA group are read before the current group is issued
+#endif
+#define CL_FENCE() CLB_FENCE()
 #define CLB_FENCE()                        \
     do {                                   \
         asm volatile("" ::: "memory");     \
@@ -152,6 +156,31 @@ __device__ __forceinline__ void cl_layer1(const float *__restrict__ W1t, const f
                                           const f32x4 (&xb)[ClShape<IN>::NTI], int g, int c, f32x4 (&acc1)[CL_NT1]) {
 #pragma unroll
     for (int t = 0; t < CL_NT1; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (the eight weights of group k + 1 are read before the seven MFMAs of group k are issued, behind scheduling fences: a read
+    //  issued just in time leaves the matrix pipe of a one-wave-per-SIMD kernel idle for its round trip; same products, same order)
+#if CL_PIPE
+    {
+        const float *wp0 = W1t + ((4 * g) * 16 + c) * 8;
+        f32x4 lo = *(const f32x4 *)wp0, hi = *(const f32x4 *)(wp0 + 4);
+#pragma unroll
+        for (int q = 0; q < ClShape<IN>::NTI; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (16 * q + j >= IN) continue;
+                const int qn = j == 3 ? q + 1 : q, jn = j == 3 ? 0 : j + 1;
+                f32x4 lon = lo, hin = hi;
+                if (qn < ClShape<IN>::NTI && 16 * qn + jn < IN) {
+                    const float *wp = W1t + ((16 * qn + 4 * g + jn) * 16 + c) * 8;
+                    lon = *(const f32x4 *)wp; hin = *(const f32x4 *)(wp + 4);
+                }
+                CL_FENCE();
+#pragma unroll
+                for (int t = 0; t < CL_NT1; ++t) acc1[t] = frag_mfma(t < 4 ? lo[t] : hi[t - 4], xb[q][j], acc1[t]);
+                CL_FENCE();
+                lo = lon; hi = hin;
+            }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < ClShape<IN>::NTI; ++q)
 #pragma unroll
@@ -162,6 +191,7 @@ __device__ __forceinline__ void cl_layer1(const float *__restrict__ W1t, const f
 #pragma unroll
             for (int t = 0; t < CL_NT1; ++t) acc1[t] = frag_mfma(t < 4 ? lo[t] : hi[t - 4], xb[q][j], acc1[t]);
         }
+#endif
 #pragma unroll
     for (int t = 0; t < CL_NT1; ++t)
 #pragma unroll
@@ -602,9 +632,14 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         }
         if (c >= 4) dqn = zero;
         // per hidden tile: dW2q^T += [H | 1]^T dq (row contraction), then dZ1 = relu'(.) * W2q^T dq over the same patch
+        f32x4 hn_next = clb_get(patches, g, c);
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t) {
-            f32x4 hn = clb_get(patches + t * CLB_PATCH, g, c);
+            f32x4 hn = hn_next;
+            if (CL_PIPE && t + 1 < CL_NT1) {          // the next tile of H^T is in flight during this tile's products
+                hn_next = clb_get(patches + (t + 1) * CLB_PATCH, g, c);
+                CLB_FENCE();
+            }
             if (t == CL_NT1 - 1 && c == CL_HID - 16 * (CL_NT1 - 1)) hn = ones;           // hidden index 100 of [H | 1]
             if (CL_ON(16)) {
 #pragma unroll
@@ -619,22 +654,34 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
                 acc1[t][r] = acc1[t][r] > 0.f ? dz : 0.f;
             }
             clb_put(patches + t * CLB_PATCH, acc1[t], g, c);
+            if (!CL_PIPE && t + 1 < CL_NT1) hn_next = clb_get(patches + (t + 1) * CLB_PATCH, g, c);
         }
         // dX = W1^T dZ1 (+ the subset's mean / scale branch)
         f32x4 adx[NTI];
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] = zero;
         if (CL_ON(2)) {
+            f32x4 w4 = *(const f32x4 *)(W1n4 + ((4 * g) * 16 + c) * 4);
+            float w1 = NTI > 4 ? W1n1[(4 * g) * 16 + c] : 0.f;
 #pragma unroll
             for (int t = 0; t < CL_NT1; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (16 * t + r >= CL_HID) continue;
-                    const int hc = (16 * t + 4 * g + r) * 16 + c;
-                    const f32x4 w4 = *(const f32x4 *)(W1n4 + hc * 4);
+                    const int tn = r == 3 ? t + 1 : t, rn = r == 3 ? 0 : r + 1;
+                    f32x4 w4n = w4;
+                    float w1n = w1;
+                    if (tn < CL_NT1 && 16 * tn + rn < CL_HID) {
+                        const int hcn = (16 * tn + 4 * g + rn) * 16 + c;
+                        w4n = *(const f32x4 *)(W1n4 + hcn * 4);
+                        if (NTI > 4) w1n = W1n1[hcn];
+                    }
+                    if (CL_PIPE) CLB_FENCE();
 #pragma unroll
                     for (int v = 0; v < NTI && v < 4; ++v) adx[v] = frag_mfma(w4[v], acc1[t][r], adx[v]);
-                    if (NTI > 4) adx[NTI - 1] = frag_mfma(W1n1[hc], acc1[t][r], adx[NTI - 1]);
+                    if (NTI > 4) adx[NTI - 1] = frag_mfma(w1, acc1[t][r], adx[NTI - 1]);
+                    if (CL_PIPE) CLB_FENCE();
+                    w4 = w4n; w1 = w1n;
                 }
         }
 #pragma unroll
@@ -648,15 +695,19 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         CLB_FENCE();
         op_issue_dy(op, row + tstride * 16);
         CLB_FENCE();
+        f32x4 dn_next = clb_get(patches, g, c);
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t) {
-            const f32x4 dn = clb_get(patches + t * CLB_PATCH, g, c);
+            const f32x4 dn = dn_next;
+            if (t + 1 < CL_NT1) dn_next = clb_get(patches + (t + 1) * CLB_PATCH, g, c);
+            if (CL_PIPE) CLB_FENCE();
             if (CL_ON(1)) {
 #pragma unroll
                 for (int v = 0; v < NTI; ++v)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
             } else aw1[t][0] += dn + xn[t % NTI];
+            if (CL_PIPE) CLB_FENCE();
         }
     }
     // ---- the workgroup's image [dW1 100 x IN | db1 100 | dW2q 3 x 100 | db2q 3]: the waves take turns (fixed order) ----
