@@ -298,7 +298,8 @@ def bin_mode(request):
 @pytest.mark.parametrize("bin_mode", [1, 2], indirect=True)
 @pytest.mark.parametrize("P,W,H,scale_hi", [(4000, 256, 256, 0.05), (30000, 800, 800, 0.02), (20000, 1920, 1080, 0.08),
                                              (300, 97, 61, 0.4), (60000, 64, 64, 0.3), (50000, 1920, 1080, 0.5),
-                                             (3000, 2600, 1800, 0.2)])
+                                             (3000, 2600, 1800, 0.2), (70000, 1000, 700, 0.15), (9000, 333, 777, 0.6),
+                                             (1025, 2048, 512, 0.9), (200000, 1280, 720, 0.01)])
 def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi, bin_mode):
     """csrc/tile_bin.hip (pair-generating first radix pass, 16-bit tile keys, ranges from the last pass) leaves the same
     per-tile lists, entry for entry, and the same tile ranges as the round-1 binning (emit_pairs + stable 32-bit pair sort,
@@ -308,7 +309,9 @@ def test_tile_lists_equal_the_pair_sort(P, W, H, scale_hi, bin_mode):
     (count read on the device, capacity from the first render), and speculative with a capacity that is too small
     (the view is rendered again with the true count).  Round 5: every scene under both binnings — the radix passes and the
     two-level path (bucket lists, then count + scan + fill; csrc/tile_bin.hip) — plus 50 000 screen-filling splats at 1080p
-    (multi-chunk buckets, masks of all 32 tiles) and a 163 x 113 tile grid (more than 256 buckets: mode 2 falls back)."""
+    (multi-chunk buckets, masks of all 32 tiles), a 163 x 113 tile grid (more than 256 buckets: mode 2 falls back), odd grids
+    (63 x 44, 21 x 49 tiles: partial buckets on both edges), a 128 x 32 grid of exactly 128 buckets with splats across all of it,
+    and 200 000 tiny splats (one or two tiles each: bucket lists of a few entries per chunk)."""
     from contextgs_amd import rasterizer as rz
     cam = look_at_camera((0.3, -3.0, 0.5), (0, 0, 0), W, H, fovx_deg=55.0)
     g = random_gaussians(P, seed=P, extent=1.0, scale_lo=0.003, scale_hi=scale_hi)
