@@ -143,6 +143,10 @@ SIGNATURES = {
     "cgs_level_rate_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "cgs_level_rate_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64] + [c_void_p] * 7 +
                            [c_int, c_void_p]),
+    "cgs_rate_sub_fwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 10 + [c_int, c_void_p, c_void_p]),
+    "cgs_rate_sub_bwd_scratch_bytes": (c_size_t, [c_int, c_int64]),
+    "cgs_rate_sub_bwd": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 10 + [c_int] + [c_void_p] * 12 +
+                         [c_size_t, c_void_p]),
     "cgs_eb_likelihood_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_eb_likelihood_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_ac_max_bytes": (c_size_t, [c_int64]),

@@ -42,6 +42,7 @@ HYPER_BLOCKS = _os.environ.get("CGS_HYPER_BLOCKS", "1") != "0"   # the noisy hyp
 ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = gather into coding order first
 RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
 LEVEL_FUSED = _os.environ.get("CGS_LEVEL_FUSED", "1") != "0"    # A/B knob: 0 = round 4's rowcat -> mlp2 -> noise_quant launches per level
+RATE_FUSED = _os.environ.get("CGS_RATE_FUSED", "1") != "0"      # A/B knob: 0 = round 5's gather -> mlp2 -> level_rate launches on the rate subset
 
 
 def _compose_down(index, maps):
@@ -471,7 +472,7 @@ def gather_rows(x, idx):
 
 
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
-                               keep_stats, choose_mask=None, draw_choose=False, begun=None):
+                               keep_stats, choose_mask=None, draw_choose=False, begun=None, allow_rate_lazy=False):
     """The level loop of multi_scale_generating (:1556-1652) in coding order.
 
     Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
@@ -547,6 +548,16 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
         big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=anchor.device)
         big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=anchor.device)
         big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=anchor.device)
+    # The mean / scale outputs of the rate subset can stay INSIDE the rate kernels (cgs_rate_sub_*, round 6) when the rate model
+    # will take its one-node path (rate_model: every level fused, the subset listed level by level, the live fraction a host
+    # number) — decided here, before the first level runs, from the same predicates the loop and rate_model use
+    rate_lazy = bool(
+        allow_rate_lazy and RATE_FUSED and fused and LEVEL_FUSED and RATE_SIDE and keep_stats and choose_mask is not None
+        and chosen_rows is not None and locs is not None and row_src is not None
+        and (mask_anchor_bool is None or c.get("live_count") is not None) and pc._anchor_feat.is_cuda
+        and all(sizes[j_] == 0 or (_mlp.supported(pc.get_grid_mlp[i_])
+                                   and _ctx.level_fused_supported(pc.get_grid_mlp[i_], anchor, hyp_l[j_], row_src))
+                for j_, (i_, _t, _o, _a2) in enumerate(c["plan"])))
     for j, (i, _tc, orig, _a) in enumerate(c["plan"]):
         n_l = sizes[j]
         if n_l > 0:
@@ -571,7 +582,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 hf, hs, ho, Q_all, pred_sub = _ctx.level_fused(
                     anchor, base_f, base_s, hyp_l[j], pc.get_grid_mlp[i], 2 * (pc.feat_dim + 6 + 3 * K), loc if keep_stats else None,
                     a_rows, a_mask, pos_, csr, row_src, perm[row_off:row_off + n_l], (big_f[sl], big_s[sl], big_o[sl]), side,
-                    (Q_FEAT0, Q_SCALING0, Q_OFFSETS0))
+                    (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), rate_lazy=rate_lazy and keep_stats)
                 row_off += n_l
                 if keep_stats:
                     span = None
@@ -583,13 +594,15 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                     levels.append(dict(level=i, orig=orig, rows=orig[loc] if span is None else None, loc=loc, n_level=n_l,
                                        fused=True, yf=hf, ys=hs, yo=ho, Q=Q_all, chosen=span, side=side, side_src=row_src,
                                        sub_map=sm[lvl0:lvl0 + n_l] if (sm is not None and span is not None) else None,
-                                       pred=pred_sub))
+                                       pred=pred_sub, lazy=rate_lazy))
                 feat_q.append(hf)
                 scal_q.append(hs)
                 off_q.append(ho)
                 if i != 0:
                     ctx_src = _next_context(c, i, feat_q, scal_q, (big_f, big_s, row_off))
                 continue
+            if rate_lazy:
+                raise RuntimeError("context model: a level left the fused path after the rate subset was made lazy")
             if ctx_src is None:                                                        # :1596-1600
                 if use_fused:
                     # (masked anchors sit at the origin from level 1 up, :1758-1759: the product is folded into the gather)
@@ -791,6 +804,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         divisors = [1.0, float(max(1, n_hyper))] + [float(max(1, r) * feat_dim) for r in level_rows]
         each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
         return out4[0], out4[1], out4[2], out4[3], each_level_bpp
+    if any(L.get("lazy") for L in levels):
+        raise RuntimeError("rate_model: levels with a lazy mean / scale branch need the one-node rate path")
     masks30 = None                              # [N, 3K] mask weights, only the unfused levels read it
     zero = torch.zeros((), device=dev)
     s_feat, s_scaling, s_offsets = zero, zero, zero
@@ -935,13 +950,16 @@ def multi_scale_generating(pc, anchor, hyper, feat, grid_offsets, grid_scaling, 
                        else draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits))
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
-        choose_mask=choose_mask)
+        choose_mask=choose_mask, allow_rate_lazy=not return_sum_bits)
     if predict_bpp and return_sum_bits:
         return rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, True, choose_mask)
     feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q = (_unpermute(c, t) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:
         return feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q
-    rates = rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False, choose_mask)
+    # (levels whose mean / scale branch lives in the rate kernels need the one-node rate path, i.e. the live count as a host number)
+    lazy = any(L.get("lazy") for L in levels)
+    rates = rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False, choose_mask,
+                       live_count=c.get("live_count") if lazy else None)
     return (feat_after_Q, grid_scaling_after_Q, grid_offsets_after_Q) + tuple(rates)
 
 
@@ -979,7 +997,7 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
             choose_mask = draw_choose_mask(anchor, mask_anchor_bool, False)
     c, feat_p, scal_p, off_p, likelihood_hyper, levels = context_model_coding_order(
         pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats=predict_bpp,
-        choose_mask=choose_mask, draw_choose=draw, begun=begun)
+        choose_mask=choose_mask, draw_choose=draw, begun=begun, allow_rate_lazy=True)
     if draw:
         choose_mask = c.get("_choose_mask")
     if c["covers_all"]:

@@ -190,3 +190,4 @@ struct CgsWgProduct { const float *P; int64_t ldp; int DA; const float *Q; int64
 int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int num_cus, void *scratch,
                            size_t scratch_bytes, hipStream_t s);
 int cgs_launch_wgrad_reduce(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, hipStream_t s);
+int cgs_launch_wgrad_reduce_assign(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, hipStream_t s);

@@ -24,33 +24,9 @@
 #include "cgs_internal.h"
 #include "mlp_frag.h"
 #include "buf_access.h"
+#include "ctx_rows.h"
 #include "ctx_noise.h"
 
-#define CL_D 50
-#define CL_S 6
-#define CL_O 30
-#define CL_HY 12
-#define CL_HID 100
-#define CL_NT1 7
-#define CL_HP 112
-#define CL_S1 116                 // frag_pad4mod8(112)
-
-template <int IN>
-struct ClShape {
-    static constexpr int NTI = (IN + 15) / 16, XP = NTI * 16;
-    static constexpr int SB = frag_pad4mod8(XP);
-};
-
-// no IR-level motion of the loads (memory clobber) and no machine-scheduler motion (sched_barrier) across
-#ifndef CL_PIPE
-#define CL_PIPE 1             // LDS operands of the next MFMA group are read before the current group is issued
-#endif
-#define CL_FENCE() CLB_FENCE()
-#define CLB_FENCE()                        \
-    do {                                   \
-        asm volatile("" ::: "memory");     \
-        __builtin_amdgcn_sched_barrier(0); \
-    } while (0)
 
 // ---- the MLP input row ---------------------------------------------------------------------------------------
 // Column order = the reference's cat (:1596-1599): [anchor 0..2 | feat 3..52 | scaling 53..58 | hyper 59..70] (IN = 71),
@@ -108,34 +84,6 @@ __device__ __forceinline__ void cl_gather_merge(const ClGatherRaw<IN> &w, int g,
     }
 }
 
-// a row of [n, IN] (X, dX, dx_sub) as fragments: q < NTI - 1 (or IN 15) full pieces, the last tile's pieces end at column IN
-template <int IN>
-__device__ __forceinline__ void cl_xrow_load(ClBuf b, uint32_t rowoff, int g, bool on, f32x4 (&x)[ClShape<IN>::NTI]) {
-    constexpr int NTI = ClShape<IN>::NTI;
-#pragma unroll
-    for (int q = 0; q < NTI; ++q) {
-        const int col0 = 16 * q + 4 * g;                  // (lane dependent through g)
-        x[q] = cl_l128(b, cl_sel(on && col0 < IN, rowoff + (uint32_t)col0 * 4));
-    }
-}
-// a 16-byte piece that starts inside the row but ends behind it carries the next row's first values: zero them at use
-template <int IN>
-__device__ __forceinline__ void cl_xrow_mask(int g, f32x4 (&x)[ClShape<IN>::NTI]) {
-    constexpr int q = ClShape<IN>::NTI - 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (16 * q + 4 * g + j >= IN) x[q][j] = 0.f;
-}
-template <int IN>
-__device__ __forceinline__ void cl_xrow_store(ClBuf b, uint32_t rowoff, int g, bool on, const f32x4 (&x)[ClShape<IN>::NTI]) {
-    constexpr int NTI = ClShape<IN>::NTI, R = IN - 16 * (NTI - 1);       // columns of the last tile: 7 (IN 71) or 15 (IN 15)
-#pragma unroll
-    for (int q = 0; q < NTI - 1; ++q) cl_s128(b, cl_sel(on, rowoff + (uint32_t)(16 * q + 4 * g) * 4), x[q]);
-    const uint32_t o = rowoff + (uint32_t)(16 * (NTI - 1) + 4 * g) * 4;
-    // lanes whose piece lies wholly inside the row store 16 bytes; the lane holding the row's last 3 columns stores 12
-    cl_s128(b, cl_sel(on && 4 * g + 3 < R, o), x[NTI - 1]);
-    cl_s96(b, cl_sel(on && 4 * g + 3 == R, o), x[NTI - 1]);
-}
 
 // LDS image of the first layer for the transposed chain: W1t[(k * 16 + c) * 8 + t] = W1[16 t + c][k] (zeros in the padding), so
 // that the seven A operands of a k-step (hidden tiles t = 0..6 of lane column c) are two 16-byte reads (conflict-free: eight
@@ -217,38 +165,6 @@ __device__ __forceinline__ void cl_qadj(const float *__restrict__ W2qs, const fl
     qa[0] = p0 + b2qs[0]; qa[1] = p1 + b2qs[1]; qa[2] = p2 + b2qs[2];
 }
 
-// ---- a lane's share of the 86 parameter values of a row (features 50, scaling 6, offsets 30) -------------------
-// 16-byte pieces, so that a wave instruction touches 16 rows x 64 contiguous bytes:
-//   F[i], i < 3: feature columns 16 i + 4 g + {0..3};  F[3]: columns 48, 49 (lane g == 0 only)
-//   S: scaling columns 0..3 (g == 1) / 4, 5 (g == 2);  O[i]: offset columns 16 i + 4 g + {0..3} (O[1] of g == 3: 28, 29)
-struct ClRow { f32x4 F[4], S, O[2]; };
-struct ClRowBufs { ClBuf f, s, o; };
-
-// loads as issued: the pieces of lanes that own only two of their four values carry the next row's first values in [2], [3]
-__device__ __forceinline__ void cl_row_issue(ClRow &v, const ClRowBufs &B, uint32_t row, int g, bool on) {
-    const uint32_t of = row * (CL_D * 4), os = row * (CL_S * 4), oo = row * (CL_O * 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) v.F[i] = cl_l128(B.f, cl_sel(on, of + (uint32_t)(16 * i + 4 * g) * 4));
-    v.F[3] = cl_l64(B.f, cl_sel(on && g == 0, of + 48 * 4));
-    v.S = cl_l128(B.s, cl_sel(on && (g == 1 || g == 2), os + (g == 2 ? 16u : 0u)));
-    v.O[0] = cl_l128(B.o, cl_sel(on, oo + (uint32_t)(4 * g) * 4));
-    v.O[1] = cl_l128(B.o, cl_sel(on, oo + (uint32_t)(16 + 4 * g) * 4));
-}
-__device__ __forceinline__ void cl_row_mask(ClRow &v, int g) {
-    if (g == 2) { v.S[2] = 0.f; v.S[3] = 0.f; }
-    if (g == 3) { v.O[1][2] = 0.f; v.O[1][3] = 0.f; }
-}
-__device__ __forceinline__ void cl_row_store(const ClRow &v, const ClRowBufs &B, uint32_t row, int g, bool on) {
-    const uint32_t of = row * (CL_D * 4), os = row * (CL_S * 4), oo = row * (CL_O * 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) cl_s128(B.f, cl_sel(on, of + (uint32_t)(16 * i + 4 * g) * 4), v.F[i]);
-    cl_s64(B.f, cl_sel(on && g == 0, of + 48 * 4), v.F[3]);
-    cl_s128(B.s, cl_sel(on && g == 1, os), v.S);
-    cl_s64(B.s, cl_sel(on && g == 2, os + 16), v.S);
-    cl_s128(B.o, cl_sel(on, oo + (uint32_t)(4 * g) * 4), v.O[0]);
-    cl_s128(B.o, cl_sel(on && g != 3, oo + (uint32_t)(16 + 4 * g) * 4), v.O[1]);
-    cl_s64(B.o, cl_sel(on && g == 3, oo + 28 * 4), v.O[1]);
-}
 
 // the noise of the lane's pieces of level row r (same element -> value map as noise_quant_*_kernel: element r * W + column of
 // tensor 0 / 1 / 2); pieces / values the lane does not own get 0
@@ -276,7 +192,6 @@ __device__ __forceinline__ void cl_row_noise(ClRow &u, uint32_t kf, uint32_t ks,
     }
 }
 
-__device__ __forceinline__ float cl_sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // timing ablations (tools/variant_lib.sh ... -DCL_ABL=<bits>, experiment builds only; WRONG results):
 //   backward: 1 no dW1 products, 2 no dX products / store, 4 no dx scatter + noise, 8 no side loads, 16 no dW2q products

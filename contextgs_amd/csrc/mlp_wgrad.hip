@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(1024)
 }
 
 __global__ void __launch_bounds__(256)
-    wgrad_multi_reduce_kernel(const float *__restrict__ partial, int blocks, int E, WgmProducts pr) {
+    wgrad_multi_reduce_kernel(const float *__restrict__ partial, int blocks, int E, WgmProducts pr, int assign) {
     __shared__ float s[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + tx;
@@ -422,8 +422,9 @@ __global__ void __launch_bounds__(256)
         for (int q = 0; q < WGM_MAX_PROD; ++q)
             if (q == k) { dW = pr.dW[q]; db = pr.db[q]; off = pr.off[q]; dadb = pr.dadb[q]; }
         const int le = e - off;
-        if (le < dadb) dW[le] += t;
-        else if (db) db[le - dadb] += t;
+        // assign: the images cover every entry, the destination needs no zero fill
+        if (le < dadb) dW[le] = assign ? t : dW[le] + t;
+        else if (db) db[le - dadb] = assign ? t : db[le - dadb] + t;
     }
 }
 
@@ -621,7 +622,7 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
     hipLaunchKernelGGL((wgrad_multi_kernel<UNR>), dim3((unsigned)blocks), dim3(1024), 0, s, a, n, rpb, (float *)scratch);
     CGS_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, (const float *)scratch,
-                       (int)blocks, E, pr);
+                       (int)blocks, E, pr, 0);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -629,7 +630,15 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
 // Sum `blocks` per-workgroup images laid out [dW | db] per product (the layout of WgmProducts) into the products'
 // gradient buffers: the reduction half of the two-pass scheme, for kernels that build the images themselves
 // (anchor_gen.hip).
+static int wgrad_reduce_launch(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, int assign, hipStream_t s);
 int cgs_launch_wgrad_reduce(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, hipStream_t s) {
+    return wgrad_reduce_launch(partial, blocks, prods, nprod, 0, s);
+}
+// the same, ASSIGNING the sums (the images cover every entry of the products: no zero fill of the destination)
+int cgs_launch_wgrad_reduce_assign(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, hipStream_t s) {
+    return wgrad_reduce_launch(partial, blocks, prods, nprod, 1, s);
+}
+static int wgrad_reduce_launch(const float *partial, int blocks, const CgsWgProduct *prods, int nprod, int assign, hipStream_t s) {
     if (nprod <= 0 || nprod > WGM_MAX_PROD || blocks <= 0) { cgs_set_error("wgrad_reduce: bad args"); return CGS_ERR_ARG; }
     WgmProducts pr;
     int E = 0;
@@ -640,7 +649,7 @@ int cgs_launch_wgrad_reduce(const float *partial, int blocks, const CgsWgProduct
     for (int k = nprod; k < WGM_MAX_PROD; ++k) { pr.dW[k] = nullptr; pr.db[k] = nullptr; pr.off[k] = E; pr.dadb[k] = 0; }
     pr.off[WGM_MAX_PROD] = E;
     pr.nprod = nprod;
-    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, partial, blocks, E, pr);
+    hipLaunchKernelGGL(wgrad_multi_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, s, partial, blocks, E, pr, assign);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -224,6 +224,10 @@ class RateSide:
 
     def __init__(self):
         self.map = self.f = self.s = self.o = self.q = None
+        # the fused rate-subset path (cgs_rate_sub_*, `rate_lazy` levels): forward -> rate node: the level's input rows and
+        # mlp_grid's weights; rate node's backward -> level node's backward: the input-row gradient of the mean / scale branch
+        # [m, in] and the weight gradients of that branch (dW1, db1, dW2, db2: the level kernel accumulates its own into them)
+        self.X = self.weights = self.dx = self.dW = None
 
 
 class _NoiseQuant(torch.autograd.Function):
@@ -415,6 +419,17 @@ class _RateAll(torch.autograd.Function):
         for j in range(nl):
             yf, ys, yo, Q, pred, loc = lv[6 * j:6 * j + 6]
             lo, hi = meta["spans"][j]
+            side = meta["sides"][j]
+            if side is not None and side.X is not None:          # a rate_lazy level: MLP branch + rate terms in one launch
+                n_sub = int(loc.shape[0])
+                assert hi - lo == n_sub
+                if n_sub > 0:
+                    W1, b1, W2, b2 = side.weights
+                    _lib.check(Lc.cgs_rate_sub_fwd(
+                        int(side.X.shape[1]), _lib.ptr(side.X), int(side.X.shape[0]), _lib.ptr(loc), n_sub, _lib.ptr(W1), _lib.ptr(b1),
+                        _lib.ptr(W2), _lib.ptr(b2), _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), masks.data_ptr() + 4 * K * lo,
+                        _lib.ptr(x_means), use_clamp, S.data_ptr() + 12 * j, stream), "cgs_rate_sub_fwd")
+                continue
             n_sub = int(pred.shape[0])
             assert hi - lo == n_sub and int(loc.shape[0]) == n_sub
             _lib.check(Lc.cgs_level_rate_fwd(
@@ -446,13 +461,42 @@ class _RateAll(torch.autograd.Function):
         dh = torch.empty(1, dtype=_f32, device=dev)
         _lib.check(Lc.cgs_rate_finish_bwd(_lib.ptr(_c(g)), nl, float(rate), float(n_f), float(n_s), float(n_o),
                                           _lib.ptr(dS), _lib.ptr(dh), stream), "cgs_rate_finish_bwd")
-        d_masks = torch.zeros_like(masks) if ctx.needs_input_grad[1] else None      # the kernels add into it
+        all_lazy = all(sd is not None and sd.X is not None for sd in meta["sides"])
+        # (the level-rate kernels add into it; the fused rate-subset kernels write every row of their span)
+        d_masks = (torch.empty_like if all_lazy else torch.zeros_like)(masks) if ctx.needs_input_grad[1] else None
         grads = []
         for j in range(nl):
             yf, ys, yo, Q, pred, loc = lv[6 * j:6 * j + 6]
             lo, _hi = meta["spans"][j]
             n_sub, n_l, D = int(pred.shape[0]), int(yf.shape[0]), int(yf.shape[1])
             side = meta["sides"][j]
+            if side is not None and side.X is not None:
+                n_sub = int(loc.shape[0])
+                grads += [None, None, None, None, None, None]
+                if n_sub == 0:      # nothing chosen on this level: no side arrays, the level node zero-fills its weight gradients
+                    side.X = side.weights = None
+                    continue
+                X, (W1, b1, W2, b2) = side.X, side.weights
+                in_f = int(X.shape[1])
+                flat = torch.empty(n_sub * (D + 6 + 3 * K + 3 + in_f), dtype=_f32, device=dev)
+                d_yf, d_ys, d_yo, dQ, dx = torch.split(flat, [n_sub * D, n_sub * 6, n_sub * 3 * K, n_sub * 3, n_sub * in_f])
+                wflat = torch.empty(W1.numel() + b1.numel() + W2.numel() + b2.numel(), dtype=_f32, device=dev)
+                dW1, db1, dW2, db2 = (t.view(w.shape) for t, w in zip(torch.split(wflat, [W1.numel(), b1.numel(), W2.numel(), b2.numel()]),
+                                                                      (W1, b1, W2, b2)))
+                ws = torch.empty(int(Lc.cgs_rate_sub_bwd_scratch_bytes(in_f, n_sub)), dtype=torch.uint8, device=dev)
+                _lib.check(Lc.cgs_rate_sub_bwd(
+                    in_f, _lib.ptr(X), int(X.shape[0]), _lib.ptr(loc), n_sub, _lib.ptr(W1), _lib.ptr(b1), _lib.ptr(W2), _lib.ptr(b2),
+                    _lib.ptr(yf), _lib.ptr(ys), _lib.ptr(yo), _lib.ptr(Q), masks.data_ptr() + 4 * K * lo, _lib.ptr(x_means), use_clamp,
+                    dS.data_ptr() + 12 * j, _lib.ptr(d_yf), _lib.ptr(d_ys), _lib.ptr(d_yo), _lib.ptr(dQ), _lib.ptr(dx),
+                    None if d_masks is None else d_masks.data_ptr() + 4 * K * lo, _lib.ptr(dW1), _lib.ptr(db1), _lib.ptr(dW2),
+                    _lib.ptr(db2), _lib.ptr(ws), ws.numel(), stream), "cgs_rate_sub_bwd")
+                mp = meta["maps"][j]
+                if mp is None:
+                    mp = torch.full((n_l,), -1, dtype=torch.int32, device=dev)
+                    mp[loc] = torch.arange(n_sub, dtype=torch.int32, device=dev)
+                side.map, side.f, side.s, side.o, side.q = mp, d_yf.view(n_sub, D), d_ys.view(n_sub, 6), d_yo.view(n_sub, 3 * K), dQ.view(n_sub, 3)
+                side.dx, side.dW = dx.view(n_sub, in_f), (dW1, db1, dW2, db2)
+                continue
             n_o_rows = n_sub if side is not None else n_l
             flat = (torch.empty if side is not None else torch.zeros)(n_o_rows * (D + 6 + 3 * K + 3), dtype=_f32, device=dev)
             d_yf, d_ys, d_yo, dQ = torch.split(flat, [n_o_rows * D, n_o_rows * 6, n_o_rows * 3 * K, n_o_rows * 3])
@@ -720,7 +764,12 @@ class _LevelFused(torch.autograd.Function):
             _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(src.sums_buffer()), stream), "cgs_ctx_level_fwd")
         pred = x_sub = h_sub = None
         m = 0
-        if loc is not None:
+        lazy = bool(cfg.get("rate_lazy")) and loc is not None and cfg["side"] is not None
+        if lazy:
+            # the mean / scale outputs of the chosen rows are formed inside the rate kernels (cgs_rate_sub_*): nothing here
+            m = int(loc.shape[0])
+            cfg["side"].X, cfg["side"].weights = X, (W1c, b1c, W2c, b2c)
+        elif loc is not None:
             m = int(loc.shape[0])
             x_sub = gather_rows_nograd(X, loc)
             pred = torch.empty(m, out, dtype=_f32, device=dev)
@@ -733,6 +782,7 @@ class _LevelFused(torch.autograd.Function):
         #  node that Python's collector cannot see: every step's level nodes, RowSource and ~350 MB of level tensors stayed
         #  alive for the life of the process, found in round 5 when the device filled up — tools/leak_probe.py)
         ctx.cfg, ctx.dims = {k: v for k, v in cfg.items() if k != "outs"}, (n, in_f, hid, out, n_stat, m)
+        ctx.lazy = lazy
         ctx.shapes = (tuple(anchor.shape), None if bf is None else tuple(bf.shape), None if bs is None else tuple(bs.shape))
         if pred is None:
             pred = torch.empty(0, out, dtype=_f32, device=dev)
@@ -749,11 +799,18 @@ class _LevelFused(torch.autograd.Function):
         dev = X.device
         stream = _lib.current_stream()
         gf, gs, go, gQ = (None if t is None else _c(t) for t in (gf, gs, go, gQ))
-        dW1, db1, dW2, db2 = _mlp._zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))      # one fill for the module
-        ws = _mlp._wgrad_workspace(dev)
-        # the rate subset's branch first: its input gradient rides into the level kernel as compact rows
+        side0 = cfg["side"]
         dx_sub = None
-        if d_pred is not None and m > 0:
+        if ctx.lazy and side0 is not None and side0.dW is not None:
+            # the rate node's backward (cgs_rate_sub_bwd) already ran: its weight gradients are the start of this module's
+            # (no zero fill), its input-row gradient rides into the level kernel as compact rows
+            (dW1, db1, dW2, db2), dx_sub = side0.dW, side0.dx
+            side0.dW = side0.dx = side0.X = side0.weights = None
+        else:
+            dW1, db1, dW2, db2 = _mlp._zeros_views(dev, (hid, in_f), (hid,), (out, hid), (out,))      # one fill for the module
+        ws = None if ctx.lazy else _mlp._wgrad_workspace(dev)
+        # the rate subset's branch first: its input gradient rides into the level kernel as compact rows
+        if (not ctx.lazy) and d_pred is not None and m > 0:
             d_pred = _c(d_pred)
             dz1s = torch.empty(m, hid, dtype=_f32, device=dev)
             dx_sub = torch.empty(m, in_f, dtype=_f32, device=dev)
@@ -766,7 +823,7 @@ class _LevelFused(torch.autograd.Function):
         smap = None
         if use_side:
             smap, sd = side.map, (side.f, side.s, side.o, side.q)
-        elif dx_sub is not None:
+        elif dx_sub is not None and not ctx.lazy:
             # no rate side (gradients of y / Q came through autograd) but a subset branch: its rows still need a map
             smap = torch.full((n,), -1, dtype=torch.int32, device=dev)
             smap[loc] = torch.arange(m, dtype=torch.int32, device=dev)
@@ -813,14 +870,18 @@ class _LevelFused(torch.autograd.Function):
         return d_anchor, d_f, d_s, d_hyp, dW1, db1, dW2, db2, None, None
 
 
-def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, pos, csr, src, rows, outs, side, q0, seed=None):
+def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, pos, csr, src, rows, outs, side, q0, seed=None,
+                rate_lazy=False):
     """One level of the training level loop.  anchor [N,3]; base_f / base_s: the coded prefix (None for the first level);
     hyp [n,12] the level's noisy hyper latents; seq = mlp_grid[level]; loc: level rows of the rate subset (or None);
     a_rows [n]: anchor row of every level row; a_mask: bool [N] (first level from level 1 up) or None; pos [n]: the parents'
     prefix positions; csr: their children lists (cgs_ctx_gather_bwd); src / rows: RowSource and the level's slice of the coding
     permutation; outs = (yf, ys, yo) slices to write; side: RateSide or None.
+    rate_lazy (needs side): the mean / scale outputs of the chosen rows are NOT formed here — rate_all() runs them inside
+    the fused rate kernels (cgs_rate_sub_*) from the X this node leaves on `side`; pred is then an empty tensor.
     Returns (yf, ys, yo, Q [n,3], pred [len(loc),175] or an empty tensor)."""
     l1, l2 = seq[0], seq[2]
     cfg = dict(a_rows=a_rows, a_mask=a_mask, pos=pos, csr=csr, loc=loc, n_stat=int(n_stat), src=src, rows=rows,
-               seed=next_seed() if seed is None else int(seed), q0=tuple(float(v) for v in q0), outs=outs, side=side)
+               seed=next_seed() if seed is None else int(seed), q0=tuple(float(v) for v in q0), outs=outs, side=side,
+               rate_lazy=bool(rate_lazy))
     return _LevelFused.apply(anchor, base_f, base_s, hyp, l1.weight, l1.bias, l2.weight, l2.bias, src.token, cfg)

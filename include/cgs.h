@@ -499,6 +499,33 @@ int cgs_level_rate_bwd(const float *yf, const float *ys, const float *yo,
                        float *d_ys, float *d_yo, float *dQ, float *d_masks,
                        int compact, void *stream);
 
+/* The rate of one level's chosen rows with mlp_grid's mean / scale branch inside (round 6,
+ * csrc/rate_sub.hip): scene/gaussian_model.py:1600-1608 restricted to the rows loc[0..m) of
+ * the level + :1658-1669 + utils/entropy_models.py:30-50, ONE launch forward — the [m,175]
+ * prediction never exists in memory — and the backward with its weight gradients in three.
+ * in_dim 71 / 15; X [n,in_dim]: the level's input rows as cgs_ctx_level_fwd wrote them;
+ * W1 [100,in_dim], b1 [100], W2 [175,100], b2 [175]: mlp_grid[level]; yf / ys / yo / Q: the
+ * level's noisy values [n,50] [n,6] [n,30] and step sizes [n,3]; masks [m,10]: the mask
+ * weights of the chosen rows (NULL = ones); x_means [3] (use_clamp).  sums3 [3] is
+ * ACCUMULATED into.  The backward writes the compact side arrays of cgs_ctx_level_bwd
+ * (side_f [m,50], side_s [m,6], side_o [m,30], side_Q [m,3], dx_sub [m,in_dim]), d_masks
+ * [m,10] (may be NULL; every row written) and ASSIGNS dW1 / db1 / dW2 [175,100] / db2 [175]
+ * (the three step-size rows: zeros — cgs_ctx_level_bwd accumulates them).
+ * scratch >= cgs_rate_sub_bwd_scratch_bytes(in_dim, m). */
+int cgs_rate_sub_fwd(int in_dim, const float *X, int64_t n, const int64_t *loc, int64_t m,
+                     const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *yf, const float *ys, const float *yo, const float *Q,
+                     const float *masks, const float *x_means, int use_clamp, float *sums3,
+                     void *stream);
+size_t cgs_rate_sub_bwd_scratch_bytes(int in_dim, int64_t m);
+int cgs_rate_sub_bwd(int in_dim, const float *X, int64_t n, const int64_t *loc, int64_t m,
+                     const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *yf, const float *ys, const float *yo, const float *Q,
+                     const float *masks, const float *x_means, int use_clamp,
+                     const float *g_sums3, float *side_f, float *side_s, float *side_o,
+                     float *side_Q, float *dx_sub, float *d_masks, float *dW1, float *db1,
+                     float *dW2, float *db2, void *scratch, size_t scratch_bytes, void *stream);
+
 /* One launch per level and direction for the every-row half of the level loop, training path (round 5, csrc/ctx_level.hip;
  * scene/gaussian_model.py:1594-1616 and its autograd) — replaces cgs_rowcat_fwd + cgs_mlp2_forward(., 100, 3) +
  * cgs_noise_quant_fwd, and cgs_noise_quant_bwd + cgs_mlp2_backward(., 100, 3) + the first layer's cgs_mlp2_wgrad.
