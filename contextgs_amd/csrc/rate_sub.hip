@@ -33,9 +33,15 @@
 #define RS_SA 116                 // row stride of the [o'][h] image of W2: b32 reads at (4g + j) * SA + c are conflict-free
 #define RS_OUT 175                // rows of W2 (172 mean / scale rows + the 3 step-size rows cgs_ctx_level_* own)
 #define RS_K 10                   // mask weights per anchor
-#ifndef RS_WAVES
-#define RS_WAVES 8
+#ifndef RS_WAVES_F
+#define RS_WAVES_F 8              // waves per workgroup, forward (one workgroup per CU: the weights fill 128 KB of LDS)
 #endif
+#ifndef RS_WAVES_B
+#define RS_WAVES_B 8              // backward: two waves per SIMD, 256 registers each
+#endif
+#ifndef RS_STAGGER
+#define RS_STAGGER 0              // > 0: the second wave of every SIMD starts RS_STAGGER x 4096 cycles late (MFMA phase of one wave
+#endif                            //      over the element maths of the other)
 
 // permuted output row o' = 16 (2 b + is_scale) + 4 g + r  ->  row of mlp_grid's second layer, -1 = padding
 __host__ __device__ __forceinline__ int rs_w2row(int op) {
@@ -50,6 +56,15 @@ __host__ __device__ __forceinline__ int rs_w2row(int op) {
     const int e = (b == 4 ? 0 : 16) + l;
     if (e >= 30) return -1;
     return (sc ? 142 : 112) + e;
+}
+
+// the inverse: row of the second layer (< 172) -> permuted output row
+__device__ __forceinline__ int rs_w2perm(int row) {
+    int sc = 0, e = row, base;
+    if (row < 100) { sc = row >= 50; e = row - 50 * sc; base = e < 48 ? 32 * (e >> 4) + (e & 15) : 96 + (e - 48); }
+    else if (row < 112) { sc = row >= 106; e = row - 100 - 6 * sc; base = e < 4 ? 100 + e : 104 + (e - 4); }
+    else { sc = row >= 142; e = row - 112 - 30 * sc; base = e < 16 ? 128 + e : 160 + (e - 16); }
+    return base + 16 * sc;
 }
 
 struct RsArgs {
@@ -77,7 +92,8 @@ struct RsOps {             // the global operands of one 16-row tile, fetched on
 };
 
 template <int IN, bool BWD>
-__global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
+__global__ void __launch_bounds__((BWD ? RS_WAVES_B : RS_WAVES_F) * 64) rs_main_kernel(RsArgs a) {
+    constexpr int RS_WAVES = BWD ? RS_WAVES_B : RS_WAVES_F;
     constexpr int NTI = ClShape<IN>::NTI, XP = ClShape<IN>::XP, SB = ClShape<IN>::SB;
     __shared__ __attribute__((aligned(16))) float W2n[RS_OP * RS_SA];      // [o'][h]
     __shared__ __attribute__((aligned(16))) float W1n[CL_HP * SB];         // [h][k]
@@ -85,18 +101,49 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
     __shared__ float b2p[RS_OP];
     __shared__ float part[RS_WAVES][3];
     const int tid = threadIdx.x, nthr = RS_WAVES * 64;
-    for (int i = tid; i < RS_OP * RS_SA; i += nthr) {
-        const int op = i / RS_SA, h = i % RS_SA, row = rs_w2row(op);
-        W2n[i] = (row >= 0 && h < CL_HID) ? a.W2[row * CL_HID + h] : 0.f;
-    }
-    for (int i = tid; i < CL_HP * SB; i += nthr) {
-        const int h = i / SB, k = i % SB;
-        W1n[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;
+    // The weights are read in THEIR order (coalesced 16-byte loads, nothing between a load and the next: all of a thread's loads
+    // are in flight together) and scattered into the LDS images; walking the images and gathering cost ~15 us per launch — 43
+    // dependent round trips per thread — which is half the kernel on the small levels.
+    for (int i = tid; i < (RS_OP * RS_SA + CL_HP * SB) / 4; i += nthr) {
+        float *dst = i < RS_OP * RS_SA / 4 ? W2n + 4 * i : W1n + 4 * (i - RS_OP * RS_SA / 4);
+        *(f32x4 *)dst = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int i = tid; i < CL_HP; i += nthr) b1s[i] = i < CL_HID ? a.b1[i] : 0.f;
     for (int i = tid; i < RS_OP; i += nthr) {
         const int row = rs_w2row(i);
         b2p[i] = row >= 0 ? a.b2[row] : 0.f;
+    }
+    __syncthreads();
+    {
+        constexpr int N2 = (RS_OUT - 3) * CL_HID / 4;        // the 172 mean / scale rows as float4s (rows are 400 bytes)
+        constexpr int PER = (N2 + RS_WAVES * 64 - 1) / (RS_WAVES * 64);
+        f32x4 v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * nthr;
+            v[k] = i < N2 ? *(const f32x4 *)(a.W2 + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * nthr;
+            if (i < N2) {
+                const int row = (4 * i) / CL_HID, h = (4 * i) % CL_HID;
+                *(f32x4 *)(W2n + rs_w2perm(row) * RS_SA + h) = v[k];
+            }
+        }
+        constexpr int N1 = CL_HID * IN;
+        constexpr int PER1 = (N1 + RS_WAVES * 64 - 1) / (RS_WAVES * 64);
+        float w[PER1];
+#pragma unroll
+        for (int k = 0; k < PER1; ++k) {
+            const int i = tid + k * nthr;
+            w[k] = i < N1 ? a.W1[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < PER1; ++k) {
+            const int i = tid + k * nthr;
+            if (i < N1) W1n[(i / IN) * SB + i % IN] = w[k];
+        }
     }
     __syncthreads();
 
@@ -126,6 +173,10 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
 
     const int64_t tstride = (int64_t)gridDim.x * RS_WAVES;
     int64_t tile = (int64_t)blockIdx.x * RS_WAVES + wave;
+#if RS_STAGGER > 0
+    if ((wave >> 2) & 1)
+        for (int i = 0; i < RS_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
     float accb[3] = {0.f, 0.f, 0.f};
     RsOps<IN> opn;
     int64_t rn;
@@ -148,17 +199,37 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
         CLB_FENCE();
 
         // ---- H^T = relu(W1 X^T + b1): lane (g, c) ends with hidden units 16t + 4g + {0..3} of row c ----
+        // (every MFMA group's LDS operands are read one group ahead, behind scheduling fences: a just-in-time ds_read leaves the
+        //  matrix pipe idle for its round trip — with two waves per SIMD nothing else covers it; groups keep >= 2 independent
+        //  accumulators between dependent MFMAs)
         f32x4 acc1[CL_NT1];
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            // groups (q, half): hidden tiles 0..3 / 4..6 of input tile q
+            f32x4 wc[4], wn[4];
 #pragma unroll
-        for (int q = 0; q < NTI; ++q)
+            for (int i = 0; i < 4; ++i) wc[i] = *(const f32x4 *)(W1n + (16 * i + c) * SB + 4 * g);
 #pragma unroll
-            for (int t = 0; t < CL_NT1; ++t) {
-                const f32x4 w = *(const f32x4 *)(W1n + (16 * t + c) * SB + 16 * q + 4 * g);
+            for (int grp = 0; grp < 2 * NTI; ++grp) {
+                const int q = grp >> 1, t0 = (grp & 1) * 4, nt = (grp & 1) ? 3 : 4;
+                if (grp + 1 < 2 * NTI) {
+                    const int qn = (grp + 1) >> 1, tn = ((grp + 1) & 1) * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[t] = frag_mfma(w[j], op.xb[q][j], acc1[t]);
+                    for (int i = 0; i < 4; ++i)
+                        if (tn + i < CL_NT1) wn[i] = *(const f32x4 *)(W1n + (16 * (tn + i) + c) * SB + 16 * qn + 4 * g);
+                }
+                CLB_FENCE();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < nt) acc1[t0 + i] = frag_mfma(wc[i][j], op.xb[q][j], acc1[t0 + i]);
+                CLB_FENCE();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wc[i] = wn[i];
             }
+        }
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t)
 #pragma unroll
@@ -189,18 +260,27 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
         f32x4 acc2[RS_NT2];
 #pragma unroll
         for (int u = 0; u < RS_NT2; ++u) acc2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 wa = *(const f32x4 *)(W2n + c * RS_SA + 4 * g), wb = *(const f32x4 *)(W2n + (16 + c) * RS_SA + 4 * g);
 #pragma unroll
-        for (int t = 0; t < CL_NT1; ++t)
-#pragma unroll
-            for (int u = 0; u < RS_NT2; u += 2) {
-                const f32x4 wa = *(const f32x4 *)(W2n + (16 * u + c) * RS_SA + 16 * t + 4 * g);
-                const f32x4 wb = *(const f32x4 *)(W2n + (16 * (u + 1) + c) * RS_SA + 16 * t + 4 * g);
+            for (int grp = 0; grp < CL_NT1 * (RS_NT2 / 2); ++grp) {
+                const int t = grp / (RS_NT2 / 2), u = 2 * (grp % (RS_NT2 / 2));
+                f32x4 na = wa, nb = wb;
+                if (grp + 1 < CL_NT1 * (RS_NT2 / 2)) {
+                    const int tn = (grp + 1) / (RS_NT2 / 2), un = 2 * ((grp + 1) % (RS_NT2 / 2));
+                    na = *(const f32x4 *)(W2n + (16 * un + c) * RS_SA + 16 * tn + 4 * g);
+                    nb = *(const f32x4 *)(W2n + (16 * (un + 1) + c) * RS_SA + 16 * tn + 4 * g);
+                }
+                CLB_FENCE();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc2[u] = frag_mfma(wa[r], acc1[t][r], acc2[u]);
                     acc2[u + 1] = frag_mfma(wb[r], acc1[t][r], acc2[u + 1]);
                 }
+                CLB_FENCE();
+                wa = na; wb = nb;
             }
+        }
         // ---- the rate terms of the lane's 24 element slots (utils/entropy_models.py:30-50) ----
         ClRow sd;
         float gq[3] = {0.f, 0.f, 0.f};
@@ -305,16 +385,26 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
         f32x4 adh[CL_NT1];
 #pragma unroll
         for (int t = 0; t < CL_NT1; ++t) adh[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            float wc[CL_NT1], wn[CL_NT1];
 #pragma unroll
-        for (int u = 0; u < RS_NT2; ++u)
+            for (int t = 0; t < CL_NT1; ++t) wc[t] = W2n[(4 * g) * RS_SA + 16 * t + c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int st = 0; st < 4 * RS_NT2; ++st) {
+                const int u = st >> 2, j = st & 3;
+                if (st + 1 < 4 * RS_NT2) {
+                    const int un = (st + 1) >> 2, jn = (st + 1) & 3;
 #pragma unroll
-                for (int t = 0; t < CL_NT1; ++t) {
-                    const float wv = W2n[(16 * u + 4 * g + j) * RS_SA + 16 * t + c];
-                    adh[t] = frag_mfma(wv, acc2[u][j], adh[t]);
+                    for (int t = 0; t < CL_NT1; ++t) wn[t] = W2n[(16 * un + 4 * g + jn) * RS_SA + 16 * t + c];
                 }
+                CLB_FENCE();
+#pragma unroll
+                for (int t = 0; t < CL_NT1; ++t) adh[t] = frag_mfma(wc[t], acc2[u][j], adh[t]);
+                CLB_FENCE();
+#pragma unroll
+                for (int t = 0; t < CL_NT1; ++t) wc[t] = wn[t];
             }
+        }
         {
             const ClBuf bZ1 = cl_buf(a.dZ1t, tb * CL_HP * 4);
 #pragma unroll
@@ -328,17 +418,27 @@ __global__ void __launch_bounds__(RS_WAVES * 64) rs_main_kernel(RsArgs a) {
         f32x4 adx[NTI];
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            constexpr int NST = 4 * CL_NT1;          // k-steps (t, r): hidden units 16t + 4g' + r (those >= 100 carry zeros)
+            float wc[NTI], wn[NTI];
 #pragma unroll
-        for (int t = 0; t < CL_NT1; ++t)
+            for (int v = 0; v < NTI; ++v) wc[v] = W1n[(4 * g) * SB + 16 * v + c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (16 * t + r >= CL_HID) continue;
+            for (int st = 0; st < NST; ++st) {
+                const int t = st >> 2, r = st & 3;
+                if (st + 1 < NST) {
+                    const int tn = (st + 1) >> 2, rn = (st + 1) & 3;
 #pragma unroll
-                for (int v = 0; v < NTI; ++v) {
-                    const float wv = W1n[(16 * t + 4 * g + r) * SB + 16 * v + c];
-                    adx[v] = frag_mfma(wv, adh[t][r], adx[v]);
+                    for (int v = 0; v < NTI; ++v) wn[v] = W1n[(16 * tn + 4 * g + rn) * SB + 16 * v + c];
                 }
+                CLB_FENCE();
+#pragma unroll
+                for (int v = 0; v < NTI; ++v) adx[v] = frag_mfma(wc[v], adh[t][r], adx[v]);
+                CLB_FENCE();
+#pragma unroll
+                for (int v = 0; v < NTI; ++v) wc[v] = wn[v];
             }
+        }
         cl_xrow_store<IN>(cl_buf(a.dx_sub, mb * IN * 4), (uint32_t)s * (IN * 4), g, valid, adx);
     }
     if (!BWD) {
@@ -376,32 +476,40 @@ __device__ __forceinline__ void rw_accumulate(ClBuf A, int colsA, int a0, ClBuf 
     for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 an[NA], bn[NB];
-    auto issue = [&](int64_t tile) {
+    // operands TWO tiles ahead (a tile is ~0.75 us of MFMAs, a load from HBM / the other XCDs' L2 takes longer under load)
+    f32x4 an[2][NA], bn[2][NB];
+    auto issue = [&](int64_t tile, f32x4 (&pa)[NA], f32x4 (&pb)[NB]) {
         const bool on = tile < t1;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            an[i] = cl_l128(A, cl_sel(on, (((uint32_t)tile * (uint32_t)colsA + (uint32_t)(16 * (a0 + i) + c)) * 16 + 4 * (uint32_t)g) * 4));
+            pa[i] = cl_l128(A, cl_sel(on, (((uint32_t)tile * (uint32_t)colsA + (uint32_t)(16 * (a0 + i) + c)) * 16 + 4 * (uint32_t)g) * 4));
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            bn[j] = cl_l128(B, cl_sel(on, (((uint32_t)tile * (uint32_t)colsB + (uint32_t)(16 * j + c)) * 16 + 4 * (uint32_t)g) * 4));
+            pb[j] = cl_l128(B, cl_sel(on, (((uint32_t)tile * (uint32_t)colsB + (uint32_t)(16 * j + c)) * 16 + 4 * (uint32_t)g) * 4));
     };
-    issue(t0);
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        f32x4 av[NA], bv[NB];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) av[i] = an[i];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bv[j] = bn[j];
-        CLB_FENCE();
-        issue(tile + 1);
-        CLB_FENCE();
+    auto products = [&](const f32x4 (&av)[NA], const f32x4 (&bv)[NB]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < NA; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = frag_mfma(av[i][r], bv[j][r], acc[i][j]);
+    };
+    issue(t0, an[0], bn[0]);
+    issue(t0 + 1, an[1], bn[1]);
+    for (int64_t tile = t0; tile < t1; tile += 2) {          // (two tiles per trip: the two register stages keep their names)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            f32x4 av[NA], bv[NB];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) av[i] = an[st][i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bv[j] = bn[st][j];
+            CLB_FENCE();
+            issue(tile + st + 2, an[st], bn[st]);
+            CLB_FENCE();
+            products(av, bv);              // (a tile past the end was loaded as zeros: adds nothing)
+        }
     }
 }
 
@@ -494,8 +602,8 @@ static int rs_check(const char *what, int in_dim, const float *X, int64_t n, con
     return CGS_OK;
 }
 
-static int64_t rs_grid(int64_t m) {
-    const int64_t tiles = (m + 15) / 16, want = (tiles + RS_WAVES - 1) / RS_WAVES;
+static int64_t rs_grid(int64_t m, int waves) {
+    const int64_t tiles = (m + 15) / 16, want = (tiles + waves - 1) / waves;
     return want < rs_cus() ? want : rs_cus();
 }
 
@@ -513,10 +621,10 @@ extern "C" int cgs_rate_sub_fwd(int in_dim, const float *X, int64_t n, const int
     RsArgs a = {};
     a.X = X; a.loc = loc; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.yf = yf; a.ys = ys; a.yo = yo; a.Q = Q; a.masks = masks;
     a.x_means = use_clamp ? x_means : nullptr; a.n = n; a.m = m; a.use_clamp = use_clamp ? 1 : 0; a.sums = sums3;
-    const unsigned grid = (unsigned)rs_grid(m);
+    const unsigned grid = (unsigned)rs_grid(m, RS_WAVES_F);
     CgsProfScope prof(CGS_PROF_RATE_FWD, (hipStream_t)stream);
-    if (in_dim == 71) hipLaunchKernelGGL((rs_main_kernel<71, false>), dim3(grid), dim3(RS_WAVES * 64), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((rs_main_kernel<15, false>), dim3(grid), dim3(RS_WAVES * 64), 0, (hipStream_t)stream, a);
+    if (in_dim == 71) hipLaunchKernelGGL((rs_main_kernel<71, false>), dim3(grid), dim3(RS_WAVES_F * 64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rs_main_kernel<15, false>), dim3(grid), dim3(RS_WAVES_F * 64), 0, (hipStream_t)stream, a);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -562,11 +670,11 @@ extern "C" int cgs_rate_sub_bwd(int in_dim, const float *X, int64_t n, const int
     a.side_f = side_f; a.side_s = side_s; a.side_o = side_o; a.side_Q = side_Q; a.dx_sub = dx_sub; a.d_masks = masks ? d_masks : nullptr;
     a.dZ2t = ws; a.Ht = a.dZ2t + ntiles * 16 * RS_OP; a.dZ1t = a.Ht + ntiles * 16 * CL_HP; a.Xt = a.dZ1t + ntiles * 16 * CL_HP;
     float *partial = a.Xt + ntiles * 16 * xp;
-    const unsigned grid = (unsigned)rs_grid(m);
+    const unsigned grid = (unsigned)rs_grid(m, RS_WAVES_B);
     {
         CgsProfScope prof(CGS_PROF_RATE_BWD, (hipStream_t)stream);
-        if (in_dim == 71) hipLaunchKernelGGL((rs_main_kernel<71, true>), dim3(grid), dim3(RS_WAVES * 64), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((rs_main_kernel<15, true>), dim3(grid), dim3(RS_WAVES * 64), 0, (hipStream_t)stream, a);
+        if (in_dim == 71) hipLaunchKernelGGL((rs_main_kernel<71, true>), dim3(grid), dim3(RS_WAVES_B * 64), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((rs_main_kernel<15, true>), dim3(grid), dim3(RS_WAVES_B * 64), 0, (hipStream_t)stream, a);
         CGS_CHECK_HIP(hipGetLastError());
     }
     CgsProfScope prof(CGS_PROF_LMLP_WGRAD, (hipStream_t)stream);
