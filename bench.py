@@ -278,21 +278,30 @@ def main():
     # slots of one 256-core host (load average ~25 from the other slots), and a hipMalloc inside a step costs ~7 ms on some of
     # them (how round 5's leak of the fused level node showed up: 14.6 ms steps; HISTORY.md "Round 5").  N = 1 only: when the K
     # timed steps took more than RETIME_RATIO (1.3) x this library's kernel time of the same steps (normally 1.09 x), they are
-    # timed again — at most two more attempts, 5 s apart — and the least disturbed attempt is reported; EVERY attempt is listed
+    # timed again — at most two more attempts, 5 s apart — and `value` is the MEDIAN over every segment of every attempt (not the best one); EVERY attempt is listed
     # in `timing.attempts`.
     lib_ms_now = sum(v[0] for v in prof.values()) / max(1, args.steps)
     attempts = [{"ms_per_step": round(ms_per_step, 3), "ms_per_step_by_segment": [round(t / k * 1e3, 3) for t, k in zip(seg_s, seg_k)]}]
-    while world == 1 and ms_per_step > RETIME_RATIO * lib_ms_now and len(attempts) < 3:
+    all_seg_ms, all_host = list(seg_ms), list(host_ms)
+    last = ms_per_step
+    while world == 1 and last > RETIME_RATIO * lib_ms_now and len(attempts) < 3:
         time.sleep(5.0)
         del _HOST_S[:]
         dt2, seg_s2, seg_k2 = timed_segments(full, args.steps, dist_on)
         seg_ms2 = sorted(t / k * 1e3 for t, k in zip(seg_s2, seg_k2))
-        attempts.append({"ms_per_step": round(seg_ms2[len(seg_ms2) // 2], 3),
+        last = seg_ms2[len(seg_ms2) // 2]
+        attempts.append({"ms_per_step": round(last, 3),
                          "ms_per_step_by_segment": [round(t / k * 1e3, 3) for t, k in zip(seg_s2, seg_k2)]})
-        if seg_ms2[len(seg_ms2) // 2] < ms_per_step:
-            dt, seg_s, seg_k, seg_ms, ms_per_step = dt2, seg_s2, seg_k2, seg_ms2, seg_ms2[len(seg_ms2) // 2]
-            host_ms = sorted(t / k * 1e3 for t, k in _HOST_S)
-            host_ms_per_step = host_ms[len(host_ms) // 2] if host_ms else None
+        all_seg_ms += seg_ms2
+        all_host += [t / k * 1e3 for t, k in _HOST_S]
+        dt += dt2
+    if len(attempts) > 1:
+        #  NOT the best attempt: the median over every segment of every attempt that was timed
+        all_seg_ms.sort()
+        all_host.sort()
+        ms_per_step = all_seg_ms[len(all_seg_ms) // 2]
+        host_ms_per_step = all_host[len(all_host) // 2] if all_host else None
+        views = args.steps * world * len(attempts)
     value = world / (ms_per_step * 1e-3)
     value_all_steps = views / dt
 

@@ -368,14 +368,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #define AG_OFF_COV (AG_OFF_COL + 30 * 50 + 30)
 #define AG_E (AG_OFF_COV + 70 * 50 + 70)
 
-#ifndef AG_ABL
-#define AG_ABL 0             // CGS_EXPERIMENTS builds only (wrong results): 1 = plain LDS stores instead of float atomics,
-#endif                       // 2 = no weight-gradient products at all
-#if AG_ABL == 1
-#define AG_IMG_ADD(p, v) (*(p) = (v))
-#else
 #define AG_IMG_ADD(p, v) atomicAdd((p), (v))
-#endif
 
 struct AgBwdArgs {
     AgRows R;
@@ -479,7 +472,6 @@ __device__ __forceinline__ void ag_head_bwd(const float *W1p, const float *W2p, 
         }
         return;
     }
-    if (AG_ABL == 2) return;
     // ---- weight gradients: row index as the MFMA contraction ----
     // dW1[hid][col] += sum_rows dZ1[row][hid] X[row][col]  (col 54 of the padded X tile is 1: the bias gradient)
 #pragma unroll

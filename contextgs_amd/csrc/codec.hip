@@ -763,30 +763,6 @@ __global__ void __launch_bounds__(256)
     table[idx] = (uint16_t)gaussian_cdf_int(j, min_v, (float)(65536 - (Lp - 1)), mean[i], 1.f / scale[i], Q[i / q_div]);
 }
 
-// test hook: the decoder core on the device over an explicit table (one lane)
-__global__ void ac_decode_table_kernel(const uint16_t *__restrict__ cdf, int Lp, int64_t n,
-                                       const uint8_t *__restrict__ in, int64_t in_len, int16_t *__restrict__ out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    AcDecoder dec;
-    dec.init(in, (size_t)in_len);
-    const int max_sym = Lp - 2;
-    for (int64_t i = 0; i < n; ++i) {
-        const uint16_t *row = cdf + i * Lp;
-        const int s = ac_search([&](int m) { return (uint32_t)row[m]; }, dec.target(), max_sym);
-        out[i] = (int16_t)s;
-        if (i == n - 1) break;
-        dec.consume(row[s], s == max_sym ? AC_TOP : (uint32_t)row[s + 1]);
-    }
-}
-
-extern "C" int cgs_ac_decode_table_device(const uint16_t *cdf, int Lp, int64_t n, const uint8_t *in, int64_t in_len,
-                                          int16_t *sym_out, void *stream) {
-    if (n <= 0) return CGS_OK;
-    hipLaunchKernelGGL(ac_decode_table_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cdf, Lp, n, in, in_len, sym_out);
-    CGS_CHECK_HIP(hipGetLastError());
-    return CGS_OK;
-}
-
 extern "C" int cgs_gaussian_stream_minmax(const float *x, const float *Q, int64_t q_div, const int64_t *stream_off,
                                           int n_streams, int32_t *min_out, int32_t *max_out, void *stream) {
     if (n_streams < 0 || q_div < 1) { cgs_set_error("stream_minmax: bad args"); return CGS_ERR_ARG; }

@@ -645,24 +645,16 @@ __global__ void __launch_bounds__(256)
                     for (int k = 0; k < 2; ++k) { const int c = l + 16 * k; if (c < O) go[k] += so[sm * O + c]; }
                     if (l < 3) side_q = sQ[sm * 3 + l];
                 }
-#if defined(CGS_EXPERIMENTS) && defined(NQB_ABL)
-                // timing ablations (wrong gradients): 1 = constant instead of the noise hash, 2 = no dx stores
-#define NQB_NOISE(key, e) (NQB_ABL == 1 ? 0.37f : ctx_noise_k(key, e))
-#define NQB_STORE(p, v) do { if (NQB_ABL != 2 || (v) == 12345.f) (p) = (v); } while (0)
-#else
-#define NQB_NOISE(key, e) ctx_noise_k(key, e)
-#define NQB_STORE(p, v) (p) = (v)
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int c = l + 16 * k;
-                    if (c < D) { NQB_STORE(dxf[sr * D + c], gf[k]); af += gf[k] * NQB_NOISE(kf, (uint64_t)r * D + c); }
+                    if (c < D) { dxf[sr * D + c] = gf[k]; af += gf[k] * ctx_noise_k(kf, (uint64_t)r * D + c); }
                 }
-                if (l < S) { NQB_STORE(dxs[sr * S + l], gs); as += gs * NQB_NOISE(ks, (uint64_t)r * S + l); }
+                if (l < S) { dxs[sr * S + l] = gs; as += gs * ctx_noise_k(ks, (uint64_t)r * S + l); }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int c = l + 16 * k;
-                    if (c < O) { NQB_STORE(dxo[sr * O + c], go[k]); ao += go[k] * NQB_NOISE(ko, (uint64_t)r * O + c); }
+                    if (c < O) { dxo[sr * O + c] = go[k]; ao += go[k] * ctx_noise_k(ko, (uint64_t)r * O + c); }
                 }
             } else {
             for (int c = l; c < D; c += 16) { float g = dyf ? dyf[r * D + c] : 0.f; if (sm >= 0) g += sf[sm * D + c]; dxf[sr * D + c] = g; af += g * ctx_noise_k(kf, (uint64_t)r * D + c); }

@@ -193,14 +193,6 @@ __device__ __forceinline__ void cl_row_noise(ClRow &u, uint32_t kf, uint32_t ks,
 }
 
 
-// timing ablations (tools/variant_lib.sh ... -DCL_ABL=<bits>, experiment builds only; WRONG results):
-//   backward: 1 no dW1 products, 2 no dX products / store, 4 no dx scatter + noise, 8 no side loads, 16 no dW2q products
-//   forward: 32 no noisy values (loads, hash, stores), 64 no X store, 128 no layer 1
-#if defined(CGS_EXPERIMENTS) && defined(CL_ABL)
-#define CL_ON(bit) (!((CL_ABL) & (bit)))
-#else
-#define CL_ON(bit) true
-#endif
 
 // ------------------------------------------------------------------------------------------------------------
 #ifndef CLF_WAVES
@@ -298,16 +290,12 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
         CLB_FENCE();
         // the next tile's operands (their indices arrived during the previous tile) and the indices of the tile after it
         cl_gather_issue<IN>(GB, gw, rn, ix.arow, ix.ppos, g, rn < n);
-        cl_row_issue(x, XB, (uint32_t)ix.srow, g, rn < n && CL_ON(32));
+        cl_row_issue(x, XB, (uint32_t)ix.srow, g, rn < n);
         ix = idx_issue(rn + tstride * 16);
         CLB_FENCE();
-        if (CL_ON(64)) cl_xrow_store<IN>(bX, (uint32_t)row * (IN * 4), g, valid, xb);
+        cl_xrow_store<IN>(bX, (uint32_t)row * (IN * 4), g, valid, xb);
         f32x4 acc1[CL_NT1];
-        if (CL_ON(128)) cl_layer1<IN>(W1s, b1s, xb, g, c, acc1);
-        else {
-#pragma unroll
-            for (int t = 0; t < CL_NT1; ++t) acc1[t] = xb[t % NTI];
-        }
+        cl_layer1<IN>(W1s, b1s, xb, g, c, acc1);
         float qa[3];
         cl_qadj(W2qs, b2qs, acc1, g, qa);
         const float qf = ctx_step(a.q0f, qa[0]), qs = ctx_step(a.q0s, qa[1]), qo = ctx_step(a.q0o, qa[2]);
@@ -317,8 +305,7 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
         ps += cl_sum4(xc.S);
         po += cl_sum4(xc.O[0]) + cl_sum4(xc.O[1]);
         ClRow u;
-        if (CL_ON(32)) cl_row_noise(u, kf, ks, ko, row, g);
-        else u = xc;
+        cl_row_noise(u, kf, ks, ko, row, g);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -329,7 +316,7 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
             xc.O[0][j] = xc.O[0][j] + u.O[0][j] * qo;
             xc.O[1][j] = xc.O[1][j] + u.O[1][j] * qo;
         }
-        cl_row_store(xc, YB, (uint32_t)row, g, valid && (CL_ON(32) || xc.F[0][0] == 1234.5f));
+        cl_row_store(xc, YB, (uint32_t)row, g, valid);
     }
     if (a.sums) {        // one atomic per block and quantity, spread over CTX_SUM_SLOTS cache lines
         const double sa = ctx_wave_sum((double)pf), sb = ctx_wave_sum((double)ps), sc = ctx_wave_sum((double)po);
@@ -505,8 +492,8 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         const uint32_t sm = chosen ? (uint32_t)op.sm : 0u;
         // the rate subset's compact gradients of this row (needed after the first block of MFMAs)
         ClRow sd;
-        cl_row_issue(sd, SDB, sm, g, chosen && CL_ON(8));
-        const float sq = cl_l32(bSQ, cl_sel(chosen && g < 3 && CL_ON(8), sm * 12 + (uint32_t)g * 4));
+        cl_row_issue(sd, SDB, sm, g, chosen);
+        const float sq = cl_l32(bSQ, cl_sel(chosen && g < 3, sm * 12 + (uint32_t)g * 4));
         // [X | 1] towards layout N; H^T = relu(W1 X^T + b1) (the forward's chain, the forward's bits), H towards layout N
         cl_xrow_mask<IN>(g, op.xb);
 #pragma unroll
@@ -519,8 +506,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         cl_qadj(W2qs, b2qs, acc1, g, qa);
         // dx = dy (+ rate side), scattered to the parameter rows; sum_c dx u per tensor
         float af, as, ao;
-        if (CL_ON(4)) clb_dx_and_sums(op.dy, sd, DXB, (uint32_t)op.srow, kf, ks, ko, row, g, valid, af, as, ao);
-        else { af = op.dy.F[0][0] + sd.F[0][0]; as = op.dy.S[0]; ao = op.dy.O[0][0]; }
+        clb_dx_and_sums(op.dy, sd, DXB, (uint32_t)op.srow, kf, ks, ko, row, g, valid, af, as, ao);
         // lane g < 3 holds the external + side gradient of Q[row, g]: bring all three to every lane of the row
         const float ext = op.dq_ext + sq;
         const float e0 = __shfl(ext, c, 64), e1 = __shfl(ext, 16 + c, 64), e2 = __shfl(ext, 32 + c, 64);
@@ -535,7 +521,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         // this tile's global operands are consumed: the next tile's are fetched behind ~300 MFMAs
         CLB_FENCE();
         f32x4 dxs[NTI];
-        cl_xrow_load<IN>(bSub, sm * (IN * 4), g, chosen && CL_ON(8), dxs);
+        cl_xrow_load<IN>(bSub, sm * (IN * 4), g, chosen, dxs);
         op_issue_x(op, row + tstride * 16);
         CLB_FENCE();
         // rows 4g + r of this tile that exist (the ones columns of [X | 1] and [H | 1]); d qadj in layout N
@@ -556,10 +542,8 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
                 CLB_FENCE();
             }
             if (t == CL_NT1 - 1 && c == CL_HID - 16 * (CL_NT1 - 1)) hn = ones;           // hidden index 100 of [H | 1]
-            if (CL_ON(16)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) aw2[t] = frag_mfma(hn[r], dqn[r], aw2[t]);
-            } else aw2[t] += hn;
+            for (int r = 0; r < 4; ++r) aw2[t] = frag_mfma(hn[r], dqn[r], aw2[t]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int hh = 16 * t + 4 * g + r;
@@ -575,7 +559,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         f32x4 adx[NTI];
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] = zero;
-        if (CL_ON(2)) {
+        {
             f32x4 w4 = *(const f32x4 *)(W1n4 + ((4 * g) * 16 + c) * 4);
             float w1 = NTI > 4 ? W1n1[(4 * g) * 16 + c] : 0.f;
 #pragma unroll
@@ -601,7 +585,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         }
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] += dxs[v];          // (a dx_sub piece that runs past its row end is cut by the store)
-        cl_xrow_store<IN>(bdX, (uint32_t)row * (IN * 4), g, valid && (CL_ON(2) || adx[0][0] == 1234.5f), adx);
+        cl_xrow_store<IN>(bdX, (uint32_t)row * (IN * 4), g, valid, adx);
         // dW1 += dZ1^T [X | 1]
         f32x4 xn[NTI];
 #pragma unroll
@@ -616,12 +600,10 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
             const f32x4 dn = dn_next;
             if (t + 1 < CL_NT1) dn_next = clb_get(patches + (t + 1) * CLB_PATCH, g, c);
             if (CL_PIPE) CLB_FENCE();
-            if (CL_ON(1)) {
 #pragma unroll
-                for (int v = 0; v < NTI; ++v)
+            for (int v = 0; v < NTI; ++v)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
-            } else aw1[t][0] += dn + xn[t % NTI];
+                for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dn[r], xn[v][r], aw1[t][v]);
             if (CL_PIPE) CLB_FENCE();
         }
     }

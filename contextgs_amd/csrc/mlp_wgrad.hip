@@ -219,11 +219,7 @@ __global__ void __launch_bounds__(256)
 static int wgrad_blocks_per_cu() {
     static int v = 0;
     if (!v) {
-#ifdef CGS_EXPERIMENTS
-        const char *e = getenv("CGS_WGRAD_BLOCKS_PER_CU");
-#else
         const char *e = nullptr;
-#endif
         v = e ? atoi(e) : 1;
         if (v < 1) v = 1;
         if (v > 2) v = 2;
@@ -237,11 +233,7 @@ size_t cgs_wgrad_scratch_bytes_for(int num_cus) { return (size_t)2 * num_cus * 2
 int cgs_launch_wgrad2(const float *P, int64_t ldp, int DA, const float *Q, int64_t ldq, int DB, float *dW, float *db,
                       int64_t n, int num_cus, void *scratch, size_t scratch_bytes, hipStream_t s) {
     if (n <= 0) return CGS_OK;
-#ifdef CGS_EXPERIMENTS
-    static const int UNR = getenv("CGS_WGRAD_UNR") ? atoi(getenv("CGS_WGRAD_UNR")) : 2;
-#else
     constexpr int UNR = 2;
-#endif
     const int GA = (DA + 63) / 64, GB = (DB + 63) / 64, npairs = GA * GB;
     const int E = DA * DB + DA;
     if (npairs > 8 || E > WG_MAX_E) { cgs_set_error("wgrad: %d x %d not supported", DA, DB); return CGS_ERR_ARG; }
@@ -555,11 +547,7 @@ int cgs_launch_wgrad_multi(const CgsWgProduct *prods, int nprod, int64_t n, int 
         (size_t)(prods[0].DA * prods[0].DB + prods[0].DA) * sizeof(float) <= scratch_bytes)
         return launch_wgrad_tail(prods[0], n, num_cus, scratch, scratch_bytes, s);
 #endif
-#ifdef CGS_EXPERIMENTS
-    static const bool disabled = getenv("CGS_WGRAD_NO_MULTI") != nullptr;
-#else
     constexpr bool disabled = false;
-#endif
     WgmArgs a;
     WgmProducts pr;
     int ntask = 0, E = 0;

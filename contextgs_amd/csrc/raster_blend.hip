@@ -55,70 +55,29 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-#ifdef CGS_EXPERIMENTS   // round 1's quadrant-mapped kernels: experiment builds only (tools/)
-#include "../../tools/experiments/raster_blend_quadrant_1.inc"
-#endif  // CGS_EXPERIMENTS
 // The product library has ONE blend path: the row-mapped kernels of raster_blend_rows.hip.  The quadrant-mapped kernels
 // of this file (round 1's mapping) and every timing ablation exist only in -DCGS_EXPERIMENTS builds (tools/), where
 // CGS_BLEND_ROWS=0 selects them.
-#ifdef CGS_EXPERIMENTS
-static bool blend_rows_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("CGS_BLEND_ROWS"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
-}
-#endif
 
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_FWD, stream);
-#ifndef CGS_EXPERIMENTS
     (void)tx; (void)ty;
     return cgs_launch_blend_fwd_rows(cfg, g, b, im, out_color, stream);
-#else
-    if (blend_rows_enabled()) return cgs_launch_blend_fwd_rows(cfg, g, b, im, out_color, stream);
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,
-                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,
-                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, out_color, im.final_T,
-                       im.n_contrib, im.tile_last);
-    CGS_CHECK_LAUNCH(stream, cfg->debug);
-    return CGS_OK;
-#endif
 }
 
 // ---------------------------------------------------------------------------
 // Backward
 // ---------------------------------------------------------------------------
-#ifdef CGS_EXPERIMENTS
-#include "../../tools/experiments/raster_blend_quadrant_2.inc"
-#endif  // CGS_EXPERIMENTS
 
 int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
                          float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                          hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     CgsProfScope prof(CGS_PROF_BLEND_BWD, stream);
-#ifndef CGS_EXPERIMENTS
     (void)tx; (void)ty;
     return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
-#else
-    if (blend_rows_enabled() && !getenv("CGS_BWD_ABLATE")) {
-        return cgs_launch_blend_bwd_rows(cfg, g, b, im, dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, stream);
-    }
-    static int ablate = -1;     // CGS_BWD_ABLATE=1..3: timing experiments only (wrong results)
-    if (ablate < 0) { const char *e = getenv("CGS_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }
-#define BWD_LAUNCH(A)                                                                                               \
-    hipLaunchKernelGGL(blend_bwd_kernel<A>, dim3((unsigned)(tx * ty)), dim3(BLEND_THREADS), 0, stream,             \
-                       cfg->image_width, cfg->image_height, tx, (const uint2 *)im.ranges,                          \
-                       (const uint32_t *)b.gid_sorted, (const float4 *)g.rec, cfg->bg, (const float *)im.final_T,   \
-                       (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last, dL_dout, dL_dmean2D_px,      \
-                       dL_dconic, dL_dopacity, dL_dcolors)
-    switch (ablate) { case 1: BWD_LAUNCH(1); break; case 2: BWD_LAUNCH(2); break; case 3: BWD_LAUNCH(3); break; default: BWD_LAUNCH(0); }
-#undef BWD_LAUNCH
-    CGS_CHECK_LAUNCH(stream, cfg->debug);
-    return CGS_OK;
-#endif
 }
 
 // R_eff / non-empty tile statistics for the roofline accounting.

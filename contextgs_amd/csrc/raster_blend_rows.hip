@@ -29,23 +29,6 @@
 #define RB_INV_LOG2E 0.6931471805599453f
 #define RB_NGRAD 9
 
-#if defined(CGS_EXPERIMENTS) && defined(RB_COUNT)
-__device__ unsigned long long g_rb_iters[4];      // [0] forward wave iterations, [1] backward, [2] backward past the `continue`
-extern "C" int cgs_debug_rb_iters(unsigned long long *out4_host, int reset) {
-    if (out4_host) hipMemcpyFromSymbol(out4_host, HIP_SYMBOL(g_rb_iters), sizeof(g_rb_iters));
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rb_iters), z, sizeof(z)); }
-    return 0;
-}
-#define RB_COUNT_DECL unsigned int rb_n0 = 0, rb_n1 = 0
-#define RB_COUNT_INC0 ++rb_n0
-#define RB_COUNT_INC1 ++rb_n1
-#define RB_COUNT_FLUSH(A, B) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_rb_iters[A], (unsigned long long)rb_n0); atomicAdd(&g_rb_iters[B], (unsigned long long)rb_n1); } } while (0)
-#else
-#define RB_COUNT_DECL
-#define RB_COUNT_INC0
-#define RB_COUNT_INC1
-#define RB_COUNT_FLUSH(A, B)
-#endif
 
 namespace {
 
@@ -190,7 +173,6 @@ __global__ void __launch_bounds__(RB_THREADS)
     float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
     uint32_t last = 0;
     bool done = !inside;
-    RB_COUNT_DECL;
 
     // The batch after the one being walked is fetched into registers BEFORE the walk starts (gid -> three dependent
     // 16-byte gathers, ~2 us of latency per batch) and handed to LDS at the top of the next round.
@@ -224,9 +206,6 @@ __global__ void __launch_bounds__(RB_THREADS)
         S.smask[tid] = (uint16_t)m16;
         __syncthreads();
         const uint32_t base_pos = start - range.x;
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL_NOWALK)
-        if (range.x == 0xFFFFFFFFu)
-#endif
         if (rb_ballot(!done) != 0ull) {
             const uint32_t cnt = rb_list_build(S, L.blk, lane, RB_THREADS);
             uint32_t i = 0, lastb = 0;             // lastb: batch index + 1 of the pixel's last contribution in this batch
@@ -234,7 +213,6 @@ __global__ void __launch_bounds__(RB_THREADS)
             // every lane of a row advances i together (also the lanes whose pixel is finished); the wave leaves when no
             // unfinished pixel has entries left
             while (rb_ballot(!done && i < cnt) != 0ull) {
-                RB_COUNT_INC0;
                 const bool has = i < cnt;
                 const uint32_t e = e_next;
                 i += has ? 1u : 0u;
@@ -259,8 +237,6 @@ __global__ void __launch_bounds__(RB_THREADS)
             last = lastb ? base_pos + lastb : last;
         }
     }
-
-    RB_COUNT_FLUSH(0, 3);
     if (inside) {
         const size_t pix = (size_t)L.py * W + L.px;
         const size_t hw = (size_t)H * W;
@@ -318,7 +294,6 @@ __global__ void __launch_bounds__(RB_THREADS)
     const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
     const float neg_bg_T = -T_final * bg_dot;
     float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;       // scalar colour recurrence (see raster_blend.hip)
-    RB_COUNT_DECL;
 
     const int nbatch = (int)((tlast + RB_THREADS - 1) / RB_THREADS);
     // the batch after the one being walked is fetched into registers before the walk starts (see the forward)
@@ -328,9 +303,6 @@ __global__ void __launch_bounds__(RB_THREADS)
         const uint32_t pos0 = (uint32_t)(nbatch - 1) * RB_THREADS + tid;
         if (pos0 < tlast) {
             pg = gid_sorted[range.x + pos0];
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7      // `rec` holds the records IN LIST ORDER (copied by the launcher)
-            pg = range.x + pos0;
-#endif
             p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
         }
     }
@@ -350,9 +322,6 @@ __global__ void __launch_bounds__(RB_THREADS)
         }
         if (bi > 0) {      // every position of an earlier batch is < tlast
             pg = gid_sorted[range.x + pos - RB_THREADS];
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
-            pg = range.x + pos - RB_THREADS;
-#endif
             p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
         }
 #pragma unroll
@@ -360,9 +329,6 @@ __global__ void __launch_bounds__(RB_THREADS)
         S.smask[tid] = (uint16_t)m16;
         __syncthreads();
 
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL_NOWALK)
-        if (range.x == 0xFFFFFFFFu)
-#endif
         {
             // entries behind the LAST contribution of every pixel of this 4x4 block (n_contrib: where the forward stopped)
             // cannot contribute to it: they never enter the block's list (the tile-wide bound `tlast` is the maximum over
@@ -370,7 +336,6 @@ __global__ void __launch_bounds__(RB_THREADS)
             int i = (int)rb_list_build(S, L.blk, lane, (int)blk_last - (int)base_pos - 1) - 1;
             uint32_t e_next = S.list[L.blk][max(i, 0)];
             while (rb_ballot(i >= 0) != 0ull) {
-                RB_COUNT_INC0;
                 const bool has = i >= 0;
                 const uint32_t e = e_next;
                 i -= has ? 1 : 0;
@@ -381,11 +346,6 @@ __global__ void __launch_bounds__(RB_THREADS)
                 const RbEval ev = rb_eval(r0, r1, pxf, pyf);
                 const bool act = has && (position <= my_last) && ev.hit;
                 if (rb_ballot(act) == 0ull) continue;
-                RB_COUNT_INC1;
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 4      // timing only: walk + evaluation, nothing else
-                if (act && ev.alpha == 12345.f) atomicAdd(&sacc[e][0], ev.g + blue);
-                continue;
-#endif
                 // Branch-free: a lane whose pixel takes no contribution runs the same updates on alpha = 0, G = 0, for which
                 // every one of them is an exact no-op (T / 1 = T, w = 0, the colour recurrence with alpha = 0 hands on
                 // the value the next contributing step would have computed) — two selects instead of a divergent block,
@@ -415,13 +375,6 @@ __global__ void __launch_bounds__(RB_THREADS)
                 v[6] = w * gr;
                 v[7] = w * gg;
                 v[8] = w * gb;
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 3      // timing only: no row reduction, no accumulation
-                {
-                    const float sm = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
-                    if (sm == 12345.f) atomicAdd(&sacc[e][0], sm);
-                    continue;
-                }
-#endif
                 // transposing reduction inside each 16-lane row (identical to raster_blend.hip); every row then adds
                 // into the accumulator of ITS OWN Gaussian
                 const bool b0 = lane & 1, b1 = lane & 2;
@@ -447,20 +400,13 @@ __global__ void __launch_bounds__(RB_THREADS)
                 asm volatile("" : "+v"(b2[0]), "+v"(b2[1]), "+v"(c8));
                 const int sub = lane & 15;
                 const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 1      // timing only: plain stores instead of LDS float atomics
-                if (has && sub < RB_NGRAD) sacc[e][sub] = red;
-#else
                 // (red != 0: a row whose 16 pixels took nothing from its entry — the wave goes on while ANY row has a contribution —
                 //  would add nine zeros through the LDS float-atomic unit, the kernel's second bound: -6 %, same sums bit for bit;
                 //  profiles/r05_blend_bwd_ablations.txt)
                 if (has && sub < RB_NGRAD && red != 0.f) atomicAdd(&sacc[e][sub], red);
-#endif
             }
         }
         __syncthreads();
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 2      // timing only: no flush to global memory
-        if (tlast != 0x7fffffffu) continue;
-#endif
         if (pos < tlast) {
             const float a0 = sacc[tid][0], a1 = sacc[tid][1], a2 = sacc[tid][2], a3 = sacc[tid][3],
                         a4 = sacc[tid][4], a5 = sacc[tid][5], a6 = sacc[tid][6], a7 = sacc[tid][7],
@@ -482,167 +428,9 @@ __global__ void __launch_bounds__(RB_THREADS)
             }
         }
     }
-    RB_COUNT_FLUSH(1, 2);
-}
-
-#if CGS_BLEND_BWD_RAW
-// Backward, round 4 experiment (built, parity-green, NOT adopted: profiles/r04_blend_bwd_global_acc.txt): NO tile-level accumulator.  The rows kernel above sums the nine per-(block, Gaussian) terms of a visit into
-// an LDS image of the batch (ds_add_f32 from nine lanes of each row) and flushes the image entry by entry; the LDS float-atomic
-// unit retires ~0.6 lanes per clock on gfx950 and that accumulation was ~170 us of the kernel's ~1020.  Here the nine lanes
-// that hold a visit's reduced terms add them straight to the per-Gaussian gradient arrays with no-return global atomics
-// (global_atomic_add_f32: performed in L2, fire-and-forget for the wave) — 2.6 x more of them than the flush issued (one per
-// block visit instead of one per tile entry), but no LDS atomic, no per-batch zeroing of the image, no flush phase and one
-// workgroup barrier less per batch, and 14.5 KB of LDS instead of 22.6.  dL_dmean2D_px / dL_dconic receive the RAW sums
-// (sum gx, sum gy | sum gx dx, sum gx dy, sum gy dy): the per-Gaussian factors the flush applied (opacity, the pre-scaled conic)
-// are applied by preprocess_bwd_kernel<RAW = true>, which reads those arrays once per Gaussian anyway.
-__global__ void __launch_bounds__(RB_THREADS)
-    blend_bwd_rows_ga_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
-                             const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
-                             const float *__restrict__ bg, const float *__restrict__ final_T,
-                             const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ tile_last,
-                             const float *__restrict__ dL_dout, float *__restrict__ dL_dmean2D_px,
-                             float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
-                             float *__restrict__ dL_dcolors) {
-    __shared__ float4 srec[RB_THREADS * 2];
-    __shared__ float2 sbg[RB_THREADS];          // {blue, Gaussian id (bits)}
-    __shared__ RbLists S;
-
-    const int tile = blockIdx.x;
-    const uint32_t tlast = tile_last[tile];
-    if (tlast == 0) return;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RbLane L = rb_lane(tx, ty, wave, lane);
-    const bool inside = L.px < W && L.py < H;
-    const float pxf = (float)L.px, pyf = (float)L.py;
-    const uint2 range = ranges[tile];
-    const size_t pix = (size_t)L.py * W + L.px, hw = (size_t)H * W;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t my_last = inside ? n_contrib[pix] : 0u;
-    uint32_t blk_last = my_last;       // maximum over the 16 lanes (pixels) of the row
-    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0xB1, 0xF, 0xF, false));
-    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x4E, 0xF, 0xF, false));
-    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x124, 0xF, 0xF, false));
-    blk_last = max(blk_last, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)blk_last, 0x128, 0xF, 0xF, false));
-    float T = T_final;
-    float gr = 0.f, gg = 0.f, gb = 0.f;
-    if (inside) { gr = dL_dout[pix]; gg = dL_dout[hw + pix]; gb = dL_dout[2 * hw + pix]; }
-    const float bg_dot = bg[0] * gr + bg[1] * gg + bg[2] * gb;
-    const float neg_bg_T = -T_final * bg_dot;
-    float acc_dot = 0.f, last_cdot = 0.f, last_alpha = 0.f;       // scalar colour recurrence (see raster_blend.hip)
-    // lane sub (0..8) of a row owns term `sub` of a visit: its destination array and element stride are lane constants
-    const int sub = lane & 15;
-    float *const lane_base = sub < 2 ? dL_dmean2D_px + sub : (sub < 5 ? dL_dconic + (sub - 2) : (sub == 5 ? dL_dopacity : dL_dcolors + (sub - 6)));
-    const uint32_t lane_stride = sub < 2 ? 2u : (sub == 5 ? 1u : 3u);
-
-    const int nbatch = (int)((tlast + RB_THREADS - 1) / RB_THREADS);
-    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
-    uint32_t pg = 0;
-    {
-        const uint32_t pos0 = (uint32_t)(nbatch - 1) * RB_THREADS + tid;
-        if (pos0 < tlast) {
-            pg = gid_sorted[range.x + pos0];
-            p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
-        }
-    }
-    for (int bi = nbatch - 1; bi >= 0; --bi) {
-        const uint32_t base_pos = (uint32_t)bi * RB_THREADS;
-        const uint32_t pos = base_pos + tid;
-        uint32_t m16 = 0;
-        __syncthreads();   // the previous batch's walk is over before LDS is reused
-        if (pos < tlast) {
-            srec[tid * 2] = p0;
-            srec[tid * 2 + 1] = p1;
-            sbg[tid] = make_float2(p2.x, __uint_as_float(pg));
-            m16 = rb_block_mask(p0.x, p0.y, p2.y, p2.z, p2.w, tx * CGS_TILE, ty * CGS_TILE);
-        } else {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            srec[tid * 2] = z; srec[tid * 2 + 1] = z; sbg[tid] = make_float2(0.f, 0.f);
-        }
-        if (bi > 0) {      // every position of an earlier batch is < tlast
-            pg = gid_sorted[range.x + pos - RB_THREADS];
-            p0 = rec[3 * (size_t)pg]; p1 = rec[3 * (size_t)pg + 1]; p2 = rec[3 * (size_t)pg + 2];
-        }
-        S.smask[tid] = (uint16_t)m16;
-        __syncthreads();
-
-        int i = (int)rb_list_build(S, L.blk, lane, (int)blk_last - (int)base_pos - 1) - 1;
-        uint32_t e_next = S.list[L.blk][max(i, 0)];
-        while (rb_ballot(i >= 0) != 0ull) {
-            const bool has = i >= 0;
-            const uint32_t e = e_next;
-            i -= has ? 1 : 0;
-            e_next = S.list[L.blk][max(i, 0)];                   // next entry's index: in flight during this iteration
-            const uint32_t position = base_pos + e + 1u;         // 1-based
-            const float4 r0 = srec[e * 2], r1 = srec[e * 2 + 1];
-            const float2 bgid = sbg[e];
-            const float blue = bgid.x;
-            const RbEval ev = rb_eval(r0, r1, pxf, pyf);
-            const bool act = has && (position <= my_last) && ev.hit;
-            if (rb_ballot(act) == 0ull) continue;
-            const float alpha = act ? ev.alpha : 0.f, Gm = act ? ev.g : 0.f;
-            const float om = 1.f - alpha;
-            float inv_om = __builtin_amdgcn_rcpf(om);
-            inv_om = inv_om * fmaf(-om, inv_om, 2.f);
-            T = T * inv_om;
-            const float w = alpha * T;
-            acc_dot = fmaf(last_alpha, last_cdot, (1.f - last_alpha) * acc_dot);
-            last_cdot = fmaf(r1.z, gr, fmaf(r1.w, gg, blue * gb));
-            float dL_dalpha = (last_cdot - acc_dot) * T;
-            last_alpha = alpha;
-            dL_dalpha = fmaf(neg_bg_T, inv_om, dL_dalpha);
-            const float gG = Gm * dL_dalpha;
-            const float gx = gG * ev.dx, gy = gG * ev.dy;
-            float v[RB_NGRAD];
-            v[0] = gx;
-            v[1] = gy;
-            v[2] = gx * ev.dx;
-            v[3] = gx * ev.dy;
-            v[4] = gy * ev.dy;
-            v[5] = gG;
-            v[6] = w * gr;
-            v[7] = w * gg;
-            v[8] = w * gb;
-            const bool b0 = lane & 1, b1 = lane & 2;
-            float a4[4], b2[2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float keep = b0 ? v[2 * q + 1] : v[2 * q], send = b0 ? v[2 * q] : v[2 * q + 1];
-                a4[q] = keep + rb_dpp<0xB1>(send);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float keep = b1 ? a4[2 * q + 1] : a4[2 * q], send = b1 ? a4[2 * q] : a4[2 * q + 1];
-                b2[q] = keep + rb_dpp<0x4E>(send);
-            }
-            float c8 = v[8];
-            c8 += rb_dpp<0xB1>(c8);
-            c8 += rb_dpp<0x4E>(c8);
-            b2[0] += rb_dpp<0x124>(b2[0]); b2[0] += rb_dpp<0x128>(b2[0]);
-            b2[1] += rb_dpp<0x124>(b2[1]); b2[1] += rb_dpp<0x128>(b2[1]);
-            c8 += rb_dpp<0x124>(c8); c8 += rb_dpp<0x128>(c8);
-            asm volatile("" : "+v"(b2[0]), "+v"(b2[1]), "+v"(c8));
-            const float red = sub < 4 ? b2[0] : (sub < 8 ? b2[1] : c8);
-            // (a row whose 16 pixels all took nothing adds zeros: skipped — other rows of the wave may have hit)
-            if (has && sub < RB_NGRAD && red != 0.f)
-                atomicAdd(lane_base + (size_t)__float_as_uint(bgid.y) * lane_stride, red);
-        }
-    }
 }
 
 
-#endif  // CGS_BLEND_BWD_RAW
-
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
-__global__ void __launch_bounds__(256) rb_records_in_list_order_kernel(uint32_t R, const uint32_t *__restrict__ gid_sorted,
-                                                                       const float4 *__restrict__ rec, float4 *__restrict__ out) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t g = gid_sorted[i];
-    out[3 * (size_t)i] = rec[3 * (size_t)g]; out[3 * (size_t)i + 1] = rec[3 * (size_t)g + 1]; out[3 * (size_t)i + 2] = rec[3 * (size_t)g + 2];
-}
-#endif
 
 int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                               hipStream_t stream) {
@@ -658,18 +446,7 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
                               float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
-#if CGS_BLEND_BWD_RAW
-    hipLaunchKernelGGL(blend_bwd_rows_ga_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
-                       cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, (const float4 *)g.rec,
-                       cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last,
-                       dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
-    CGS_CHECK_LAUNCH(stream, cfg->debug);
-    return CGS_OK;
-#endif
     const float4 *rec = (const float4 *)g.rec;
-#if defined(CGS_EXPERIMENTS) && defined(RB_ABL) && RB_ABL == 7
-#include "../../tools/experiments/raster_blend_rows_sorted_records.inc"
-#endif
     hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
                        cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, rec,
                        cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last,

@@ -4,9 +4,6 @@
 // Uses only the bounding boxes of the alpha >= 1/255 ellipses, like the blend kernels' own quadrant masks.
 #include "cgs_internal.h"
 
-#ifdef CGS_EXPERIMENTS   // counting kernels behind tools/blend_occupancy.py: experiment builds only
-#include "../../tools/experiments/raster_debug_counters_1.inc"
-#endif  // CGS_EXPERIMENTS
 
 // ---- test hook: the per-tile lists of csrc/tile_bin.hip against the round-1 binning (emit_pairs + 32-bit pair sort) ----
 // Re-bins the geometry of the last forward into a SECOND binning workspace with the round-1 path and counts the entries
@@ -53,6 +50,3 @@ extern "C" int cgs_debug_bin_compare(const cgs_raster_cfg *cfg, int64_t P, int64
     return CGS_OK;
 }
 
-#ifdef CGS_EXPERIMENTS
-#include "../../tools/experiments/raster_debug_counters_2.inc"
-#endif  // CGS_EXPERIMENTS

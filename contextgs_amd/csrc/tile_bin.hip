@@ -254,10 +254,6 @@ __global__ void __launch_bounds__(TB_THREADS)
         }
         const uint32_t d = (key[r] >> shift) & mask;
         uint64_t peers = __ballot(valid);
-#if defined(CGS_EXPERIMENTS) && defined(TB_ABL) && TB_ABL == 1      // timing only: no digit match, identity placement
-        rank[r] = (uint32_t)(wave * (TB_TILE / TB_WAVES) + r * 64 + lane);
-        continue;
-#endif
 #pragma unroll
         for (int b = 0; b < nbits; ++b) {
             const bool bit = (d >> b) & 1u;
@@ -311,11 +307,7 @@ __global__ void __launch_bounds__(TB_THREADS)
         const uint32_t j = wbase + (uint32_t)(r * 64 + lane);
         if (j < R) {
             const uint32_t d = (key[r] >> shift) & mask;
-#if defined(CGS_EXPERIMENTS) && defined(TB_ABL) && TB_ABL == 1
-            const uint32_t slot = rank[r];
-#else
             const uint32_t slot = wcnt[wave][d] + rank[r];
-#endif
             skey[slot] = (uint16_t)key[r];
             sval[slot] = val[r];
             // (the masks go out from the registers: staging them too costs 16 KB of LDS = two workgroups per CU less)
@@ -324,17 +316,10 @@ __global__ void __launch_bounds__(TB_THREADS)
     }
     __syncthreads();
     const int count = (int)min((uint32_t)TB_TILE, R - base);
-#if defined(CGS_EXPERIMENTS) && defined(TB_ABL) && TB_ABL == 2      // timing only: no global stores
-    if (R != 0xFFFFFFFFu) return;
-#endif
     for (int j = tid; j < count; j += TB_THREADS) {
         const uint32_t k = skey[j];
         const uint32_t d = (k >> shift) & mask;
-#if defined(CGS_EXPERIMENTS) && defined(TB_ABL) && TB_ABL == 1
-        const uint32_t pos = base + (uint32_t)j + (gbase[d] & 0u) + (lstart[d] & 0u);
-#else
         const uint32_t pos = gbase[d] + (uint32_t)j;
-#endif
         vals_out[pos] = sval[j];
         if (FINAL && !COARSE) {           // (the bucket pass is ONE pass: its runs start where the scanned histogram says)
             // equal keys are adjacent in the staged order (same digit; inside a digit the arrival order is the order

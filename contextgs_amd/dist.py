@@ -173,6 +173,8 @@ class GradientSync:
         # whose gradients only reach visible anchors; a callable(param) -> row mask | None as before; None = always dense
         self.average, self.sparse, self.sparse_below = average, (_auto_rows if sparse == "auto" else sparse), sparse_below
         self._union = None                  # (row-mask object, union index | None) of this step: one mask exchange per step
+        self._viol = []                     # (param, device bool: gradient outside the noted rows) of this step's compact exchanges
+        self._dense_only = set()            # ids of parameters that showed gradient outside the noted rows once: dense from then on
         self.exposed_ms, self._exposure = [], None      # per step: how long the compute stream stood behind the collectives
         self.big = [p for p in self.params if p.numel() >= BIG_TENSOR]
         self.small = [p for p in self.params if p.numel() < BIG_TENSOR]
@@ -232,7 +234,11 @@ class GradientSync:
         if self._deferring is not None:
             from . import mlp
             mlp.remove_before_flush_hook(self._hook)
-            mlp.defer_weight_gradients(self._deferring)
+            #  the deferral switch is one per process: a sync that is closed late (garbage collection of a replaced
+            # one) must not turn it off under the sync that is open NOW
+            cur = _OPEN_SYNC() if _OPEN_SYNC is not None else None
+            if cur is None or cur is self or cur._deferring is None:
+                mlp.defer_weight_gradients(self._deferring)
             self._deferring = self._hook = None
 
     def __del__(self):
@@ -254,7 +260,7 @@ class GradientSync:
             p.grad = p.grad.contiguous()
         op, in_coll = self._op()
         rows = None
-        if self.sparse is not None and p.dim() >= 1 and p.shape[0] > 1:
+        if self.sparse is not None and p.dim() >= 1 and p.shape[0] > 1 and id(p) not in self._dense_only:
             rows = self.sparse(p)
         if rows is not None:
             self._pending.append(("rows", p, *self._issue_rows(p, rows, op)))
@@ -277,6 +283,14 @@ class GradientSync:
         if idx.numel() > self.sparse_below * p.shape[0]:
             self.bytes_reduced += p.grad.numel() * p.grad.element_size()
             return None, p.grad, dist.all_reduce(p.grad, op=op, async_op=True)
+        #  the noted rows are what the RENDERER differentiates; a loss term outside it (train.py:209's mask
+        # regulariser on `_mask`, 3000 < step <= 10000) puts gradient on every row.  Rows outside the union are not exchanged
+        # here, so: note (on the device, no host read) whether this rank has any; finish() takes the MAX over ranks with the
+        # has-gradient mask it exchanges anyway and repairs such a tensor with one dense collective, after which the tensor
+        # stays on the dense path.
+        outside = torch.ones(p.shape[0], dtype=torch.bool, device=p.grad.device)
+        outside[idx] = False
+        self._viol.append((p, (p.grad.reshape(p.shape[0], -1).ne(0).any(dim=1) & outside).any()))
         compact = p.grad.index_select(0, idx).contiguous()
         self.bytes_reduced += compact.numel() * compact.element_size()
         return idx, compact, dist.all_reduce(compact, op=op, async_op=True)
@@ -330,8 +344,14 @@ class GradientSync:
         local = [0 if (p.grad is None or id(p) in self._filled) else 1 for p in every]
         on_dev = dist.get_backend() == "nccl"
         m = torch.tensor(local, dtype=torch.int32, device=every[0].device if on_dev else "cpu")
+        # + one entry per big tensor: "a compact exchange of this step left gradient outside the exchanged rows on some rank"
+        viol_local = torch.zeros(len(self.big), dtype=torch.int32, device=m.device)
+        for p_, flag in self._viol:
+            viol_local[self._pos[id(p_)]] = flag.to(device=m.device, dtype=torch.int32)
+        m = torch.cat([m, viol_local])
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        has = [bool(v) for v in m.tolist()]
+        flags = m.tolist()
+        has, viol = [bool(v) for v in flags[:len(every)]], [bool(v) for v in flags[len(every):]]
         has_big, has_small = has[:len(self.big)], has[len(self.big):]
         for k in range(len(self.big)):                       # mispredicted inactive: reduce now (same order on every rank)
             if has_big[k] and k not in self._active:
@@ -378,8 +398,20 @@ class GradientSync:
                 work.wait()
                 if self.average and not in_coll:
                     t /= w
-                if idx is not None:                           # rows outside the union are zero on every rank already
+                if idx is not None:
                     p.grad.index_copy_(0, idx, t)
+                    if viol[self._pos[id(p)]]:
+                        # some rank has gradient outside the exchanged rows: reduce those rows now (the union's rows, already
+                        # reduced, enter as zeros and are restored afterwards); same decision and order on every rank
+                        self._dense_only.add(id(p))
+                        rest = p.grad.clone()
+                        rest[idx] = 0
+                        dist.all_reduce(rest, op=op)
+                        if self.average and not in_coll:
+                            rest /= w
+                        rest[idx] = t
+                        p.grad.copy_(rest)
+                        self.bytes_reduced += rest.numel() * rest.element_size()
         if ev0 is not None:
             ev1.record()
             if self._exposure is not None:                    # the previous step's pair is complete by now: no sync here
@@ -407,6 +439,7 @@ class GradientSync:
         self._ready, self._seen, self._next, self._pending, self.bytes_reduced = set(), [], 0, [], 0
         self._filled = set()
         self._union = None
+        self._viol = []
 
     def exposure_report(self):
         """Mean / max of the per-step time the compute stream waited for the collectives in finish() (ms), over the steps
@@ -460,8 +493,16 @@ def broadcast_parameters(params: Iterable[torch.nn.Parameter], src: int = 0) -> 
     """Make every replica start from rank `src`'s parameters."""
     if world() == 1:
         return
-    for p in params:
-        dist.broadcast(p.data, src=src)
+    # (ADVICE r5) a write through `.data` / a collective does not bump the tensor's version counter, which caches keyed on it
+    # (EntropyBottleneck.update's tables) would then survive: write through an alias that shares the counter, bump it, and
+    # tell the caches explicitly
+    with torch.no_grad():
+        for p in params:
+            t = p.detach()
+            dist.broadcast(t, src=src)
+            t.add_(0)                            # in-place no-op: bumps the shared version counter
+    from . import entropy_bottleneck as _eb
+    _eb.invalidate_tables()
 
 
 def stream_blocks(edges, w: int | None = None) -> list[int]:

@@ -26,6 +26,17 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+
+#  update(force=True) keeps its tables while every parameter is at the (storage, version) they were built from; a
+# write that bypasses the version counter (`p.data`, a collective, a raw pointer) calls invalidate_tables() — dist.broadcast_parameters
+# does (load_state_dict / restore copy in place and bump the counters).
+_TABLE_GENERATION = [0]
+
+
+def invalidate_tables():
+    _TABLE_GENERATION[0] += 1
+
+
 class _LowerBound(torch.autograd.Function):
     """max(x, bound) whose gradient also passes where it moves x towards the bound's
     feasible side (the usual likelihood lower bound)."""
@@ -409,7 +420,7 @@ class EntropyBottleneck(nn.Module):
             return False
         # (the tables are a function of the parameters alone: a forced update with every parameter at the version — and the
         #  storage — the last tables were built from rebuilds the same tables; it costs 1.4 ms and three host reads per encode)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in self.parameters())
+        key = (_TABLE_GENERATION[0],) + tuple((p_.data_ptr(), p_._version) for p_ in self.parameters())
         built = getattr(self, "_tables_key", None)
         if (self._offset.numel() > 0 and built is not None and built[0] == key
                 and built[1] == (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, self._offset.data_ptr(), self._offset._version)):

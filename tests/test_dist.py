@@ -552,3 +552,86 @@ def test_a_new_sync_closes_the_one_it_replaces_and_leaves_an_unrelated_one_alone
     assert s2._handles and s3._handles, "an unrelated sync must keep its hooks"
     assert any("still open" in str(r.message) for r in rec)
     s2.close(); s3.close()
+
+
+def _dense_outside_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        cd.BIG_TENSOR = 8
+        torch.manual_seed(0)
+        n = 64
+        feat = torch.nn.Parameter(torch.randn(n, 3))          # gradient confined to the view's rows
+        mask = torch.nn.Parameter(torch.randn(n, 2))          # + a dense regulariser on EVERY row (train.py:209, 3000 < step <= 10000)
+        params = [feat, mask]
+        sync = cd.GradientSync(params, average=False)         # SUM: outside rows must become world x g, not g
+        out = []
+        for step in range(3):
+            for p in params:
+                p.grad = None
+            vis = torch.zeros(n, dtype=torch.bool)
+            vis[(n // 4) * rank:(n // 4) * (rank + 1)] = True
+            cd.note_touched_rows(vis, int(vis.sum()))
+            m = vis[:, None].float()
+            loss = (feat * m).sum() * float(rank + 1) + (mask * m).sum() * float(step + 1) + 0.5 * torch.sigmoid(mask).mean()
+            local = torch.autograd.grad(loss, params, retain_graph=True)
+            loss.backward()
+            nbytes = sync.finish()
+            ref = []
+            for g in local:
+                g = g.clone()
+                dist.all_reduce(g)
+                ref.append(g)
+            out.append(([p.grad.clone() for p in params], ref, nbytes, sorted(len(sync._dense_only) for _ in (0,))))
+        sync.close()
+        q.put(_by_value((rank, out)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_dense_regulariser_outside_the_noted_rows_is_reduced_too():
+    """sparse="auto" exchanges only the union of the rows the renderer noted; a loss term outside the
+    renderer (the mask regulariser of train.py:209) puts gradient on every row of `_mask`.  Under SUM those rows must come out
+    as the sum over ranks — detected on the step it happens (repaired by one dense collective), dense from then on."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dense_outside_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = _from_value(q.get(timeout=120))
+        res[r[0]] = r[1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 64
+    for r in (0, 1):
+        for step, (grads, ref, nbytes, n_dense) in enumerate(res[r]):
+            for g, e in zip(grads, ref):
+                assert torch.allclose(g, e, atol=1e-6), (r, step, (g - e).abs().max())
+            assert n_dense == [1]                    # `mask` left the touched-rows path on the first step, `feat` never does
+        # step 0: mask exchanged compactly, found out, repaired densely; later steps: feat compact (half the rows), mask dense
+        assert res[r][1][2] == n + n * 3 * 4 // 2 + n * 2 * 4, res[r][1][2]
+        assert res[r][0][2] > res[r][1][2]
+
+
+def test_broadcast_invalidates_the_entropy_bottleneck_tables():
+    """ADVICE r5 (low): update(force=True) reuses its tables while the parameters are at the version they were built from;
+    dist.broadcast_parameters writes the parameters without that version moving on its own."""
+    from contextgs_amd import entropy_bottleneck as eb
+    g0 = eb._TABLE_GENERATION[0]
+    eb.invalidate_tables()
+    assert eb._TABLE_GENERATION[0] == g0 + 1
+    import inspect
+    from contextgs_amd import dist as cd
+    assert "invalidate_tables" in inspect.getsource(cd.broadcast_parameters)
+    p = torch.nn.Parameter(torch.zeros(3))
+    v0 = p._version
+    with torch.no_grad():
+        p.detach().add_(0)
+    assert p._version > v0                           # the alias shares the counter: what broadcast_parameters relies on
