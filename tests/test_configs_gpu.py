@@ -1,6 +1,8 @@
-"""BASELINE.json's configurations c2, c3 and c5 at FULL size on one MI355X (c1 is the CPU oracle's plumbing case,
-tests/test_oracle_raster.py; c4's single-GPU training step runs in tests/test_training_gpu.py, its 8-GPU half is the
-driver's scaling run).
+"""BASELINE.json's configurations c1, c2, c3 and c5 at FULL size on one MI355X (c4's single-GPU training step runs in
+tests/test_training_gpu.py, its 8-GPU half is the driver's scaling run).
+
+c1: 10 k anchors, 256x256, forward only: prefilter -> expansion -> rasterizer forward against the CPU oracles (the
+    configuration the reference itself can run on the CPU: BASELINE.md section 3 "report c1 always"); the CPU oracle is timed.
 
 c2: ~100 k anchors, 800x800, forward + backward: the visibility filter, the anchor -> Gaussian expansion and the
     rasterizer (image + six gradient tensors) against the CPU oracles on the SAME full-size inputs.
@@ -24,6 +26,60 @@ def _settings(cam, bg):
         image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
         tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
         projmatrix=cam.full_proj_transform, sh_degree=1, campos=cam.camera_center, prefiltered=False, debug=False)
+
+
+def test_c1_10k_anchors_256x256_vs_oracle(oracle32):
+    """BASELINE configs[0]: the whole forward path (a1 prefilter, a2 expansion, a4 rasterizer forward) at the size of the
+    reference's CPU-runnable case, every stage against its oracle; prints the CPU oracle's time next to the device's."""
+    import time
+    from contextgs_amd.rasterizer import GaussianRasterizer
+    from contextgs_amd.renderer import generate_neural_gaussians, prefilter_voxel
+    from contextgs_amd.synth import SynthPipe, make_scene, orbit_cameras
+    from oracle import context_ref as cr
+    N, W, H = 10_000, 256, 256
+    pc = make_scene(N, seed=0)
+    pc.eval()
+    cam_np = orbit_cameras(8, W, H)[1]
+    cam = cam_np.to_torch("cuda")
+    bg = torch.zeros(3, device="cuda")
+    f = lambda t: t.detach().cpu().numpy()
+    with torch.no_grad():
+        vis = prefilter_voxel(cam, pc, SynthPipe(), bg)
+        rot0 = pc.get_rotation[[0], :].repeat(N, 1)
+        t0 = time.perf_counter()
+        ref_r = oracle32.visible_filter(cam_np.oracle_dict(), f(pc.get_anchor), f(pc.get_scaling[:, :3]), f(rot0))
+        t_filter = time.perf_counter() - t0
+        assert np.array_equal(f(vis), ref_r > 0) and int(vis.sum()) > N // 4
+        xyz, color, opacity, scaling, rot, neural_opacity, mask = generate_neural_gaussians(
+            cam, pc, vis, is_training=True, step=1000)[:7]
+        Wd = {k: f(v) for k, v in pc.state_dict().items()}
+        v = f(vis)
+        t0 = time.perf_counter()
+        o_xyz, o_color, o_op, o_sc, o_rot, o_no, o_sel = cr.expand(
+            Wd, f(pc.get_anchor)[v], f(pc._anchor_feat)[v], f(pc._offset)[v], f(pc.get_scaling)[v], f(pc.get_mask)[v],
+            f(cam.camera_center))
+        t_expand = time.perf_counter() - t0
+        flips = int((f(mask) != o_sel).sum())
+        assert flips <= 1, flips
+        if flips == 0:
+            for a, b in ((xyz, o_xyz), (color, o_color), (opacity, o_op), (scaling, o_sc), (rot, o_rot)):
+                assert np.allclose(f(a), b, rtol=1e-4, atol=3e-6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img, radii = GaussianRasterizer(_settings(cam, bg))(
+            means3D=xyz, means2D=torch.zeros_like(xyz), shs=None, colors_precomp=color, opacities=opacity, scales=scaling,
+            rotations=rot, cov3D_precomp=None)
+        torch.cuda.synchronize()
+        t_dev = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ref = oracle32.render(cam_np.oracle_dict(bg=(0, 0, 0)), f(xyz), f(color), f(opacity), f(scaling), f(rot))
+        t_raster = time.perf_counter() - t0
+    assert np.array_equal(f(radii), ref["radii"])
+    d = np.abs(f(img) - ref["color"])
+    assert float(np.sqrt((d ** 2).mean())) <= 1e-5 and float((d > 2e-5).mean()) <= 1e-4 and d.max() <= 1 / 255 + 1e-4
+    print(f"[c1] 10k anchors 256x256 forward: {int(vis.sum())} visible anchors, {xyz.shape[0]} Gaussians; CPU oracle "
+          f"filter {t_filter * 1e3:.1f} ms + expansion {t_expand * 1e3:.1f} ms + rasterizer {t_raster * 1e3:.1f} ms; "
+          f"device rasterizer call (incl. host) {t_dev * 1e3:.2f} ms")
 
 
 def test_c2_100k_anchors_800x800_forward_backward_vs_oracles(oracle32):

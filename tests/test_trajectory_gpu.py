@@ -137,12 +137,24 @@ def test_training_trajectory_matches_the_reference_loop(monkeypatch):
     print(f"[trajectory] worst relative deviations over {len(its)} iterations: loss {worst['loss']:.2e}, bit_per_param {worst['bpp']:.2e}, "
           f"parameter |sum| {worst['sum']:.2e}")
     # final per-anchor tensors.  Adam moves an entry by ~its learning rate per step whatever the gradient's SIZE, so an entry whose
-    # gradient is round-off noise on both sides (offsets of Gaussians that barely touch a pixel) may end 28 learning rates apart:
-    # all entries within 2e-2 of the tensor's largest magnitude, all but 6 % of them within 2e-5 (the counts are printed; the hyper latents, whose only gradient is the 8 context iterations' rate term, sit at 4 %)
+    # gradient is round-off noise may end many learning rates apart — on BOTH sides: two runs of the reference's own script
+    # (tools/make_trajectory_golden.py, CPU thread order of its reductions) differ by up to 3.5e-3 of the tensor maximum in
+    # `offset`, 2.6e-3 in `hyper`, 1.5e-3 in `scaling` (round 6, recorded in the generator's docstring).  The fixture therefore
+    # carries, per entry, gstrength = the largest |gradient| / max |gradient of the tensor| the REFERENCE saw over the iterations
+    # since the tensors took their final shape, and the bound depends on it (no blanket allowance):
+    #   gstrength >= 1e-2 (Adam moved the entry on a gradient far above round-off): EVERY such entry within TIGHT of the maximum
+    #   gstrength >= 1e-4: every such entry within MID;   all entries: within 2e-2.
+    TIGHT, MID = 3e-4, 5e-3
     for name, attr in tc.PER_ANCHOR.items():
         a, b = getattr(pc, attr).detach().cpu().numpy(), g["final_" + name]
         assert a.shape == b.shape, name
         big = max(float(np.abs(b).max()), 1e-12)
         err = np.abs(a - b) / big
-        print(f"[trajectory] final {name:8s} max err / max {float(err.max()):.2e}, outside 2e-5: {int((err > 2e-5).sum())} of {err.size}")
-        assert float(err.max()) <= 2e-2 and float((err > 2e-5).mean()) <= 6e-2, (name, float(err.max()))
+        st = g["gstrength_" + name] if ("gstrength_" + name) in g.files else np.ones_like(err)
+        strong, mid = st >= 1e-2, st >= 1e-4
+        e_s = float(err[strong].max()) if strong.any() else 0.0
+        e_m = float(err[mid].max()) if mid.any() else 0.0
+        print(f"[trajectory] final {name:8s} max err / max: all {float(err.max()):.2e} | gstrength >= 1e-4 ({int(mid.sum())} entries) "
+              f"{e_m:.2e} | >= 1e-2 ({int(strong.sum())} entries) {e_s:.2e}; outside 2e-5: {int((err > 2e-5).sum())} of {err.size} "
+              f"(strong: {int((err[strong] > 2e-5).sum())})")
+        assert float(err.max()) <= 2e-2 and e_m <= MID and e_s <= TIGHT, (name, float(err.max()), e_m, e_s)
