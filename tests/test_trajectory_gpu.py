@@ -139,22 +139,29 @@ def test_training_trajectory_matches_the_reference_loop(monkeypatch):
     # final per-anchor tensors.  Adam moves an entry by ~its learning rate per step whatever the gradient's SIZE, so an entry whose
     # gradient is round-off noise may end many learning rates apart — on BOTH sides: two runs of the reference's own script
     # (tools/make_trajectory_golden.py, CPU thread order of its reductions) differ by up to 3.5e-3 of the tensor maximum in
-    # `offset`, 2.6e-3 in `hyper`, 1.5e-3 in `scaling` (round 6, recorded in the generator's docstring).  The fixture therefore
-    # carries, per entry, gstrength = the largest |gradient| / max |gradient of the tensor| the REFERENCE saw over the iterations
-    # since the tensors took their final shape, and the bound depends on it (no blanket allowance):
-    #   gstrength >= 1e-2 (Adam moved the entry on a gradient far above round-off): EVERY such entry within TIGHT of the maximum
-    #   gstrength >= 1e-4: every such entry within MID;   all entries: within 2e-2.
-    TIGHT, MID = 3e-4, 5e-3
+    # `offset`, 2.6e-3 in `hyper`, 1.5e-3 in `scaling` (round 6, recorded in the generator's docstring).  With Adam's state young
+    # (28 steps, half the anchors born in the densification round) ONE iteration whose gradient is round-off noise — its sign
+    # then differs between two implementations — moves the entry a full learning rate the other way, however strong its
+    # gradient was in the other iterations.  The fixture therefore carries, per entry, gweakest = the SMALLEST non-zero
+    # |gradient| / max |gradient of the tensor| the reference saw since the tensors took their final shape, and the bound
+    # depends on it (no blanket allowance; measured maxima on the MI355X in brackets):
+    #   gweakest >= 1e-3 (never moved on noise; 36 k offset entries, a few dozen to ~1000 in the other tensors): EVERY such entry
+    #                     within TIGHT = 1e-4 of the tensor's maximum [3.2e-5]
+    #   gweakest >= 1e-5: every such entry within MID = 2e-3 [4.8e-4];   all entries: within 2e-2 [1.2e-2].
+    TIGHT, MID = 1e-4, 2e-3
+    bad = []
     for name, attr in tc.PER_ANCHOR.items():
         a, b = getattr(pc, attr).detach().cpu().numpy(), g["final_" + name]
         assert a.shape == b.shape, name
         big = max(float(np.abs(b).max()), 1e-12)
         err = np.abs(a - b) / big
-        st = g["gstrength_" + name] if ("gstrength_" + name) in g.files else np.ones_like(err)
-        strong, mid = st >= 1e-2, st >= 1e-4
+        st, wk = g["gstrength_" + name], g["gweakest_" + name]
+        strong, mid = (wk >= 1e-3) | (st == 0), (wk >= 1e-5) | (st == 0)          # (st == 0: never received a gradient)
         e_s = float(err[strong].max()) if strong.any() else 0.0
         e_m = float(err[mid].max()) if mid.any() else 0.0
-        print(f"[trajectory] final {name:8s} max err / max: all {float(err.max()):.2e} | gstrength >= 1e-4 ({int(mid.sum())} entries) "
-              f"{e_m:.2e} | >= 1e-2 ({int(strong.sum())} entries) {e_s:.2e}; outside 2e-5: {int((err > 2e-5).sum())} of {err.size} "
+        print(f"[trajectory] final {name:8s} max err / max: all {float(err.max()):.2e} | weakest gradient >= 1e-5 of the largest ({int(mid.sum())} entries) "
+              f"{e_m:.2e} | >= 1e-3 ({int(strong.sum())} entries) {e_s:.2e}; outside 2e-5: {int((err > 2e-5).sum())} of {err.size} "
               f"(strong: {int((err[strong] > 2e-5).sum())})")
-        assert float(err.max()) <= 2e-2 and e_m <= MID and e_s <= TIGHT, (name, float(err.max()), e_m, e_s)
+        if not (float(err.max()) <= 2e-2 and e_m <= MID and e_s <= TIGHT):
+            bad.append((name, float(err.max()), e_m, e_s))
+    assert not bad, bad
