@@ -240,12 +240,16 @@ def main():
     if dist_on:
         from contextgs_amd import dist as cgs_dist
         from contextgs_amd.dist import GradientSync
-        sync = GradientSync(params, average=True)
         # BEFORE any timed region: who is in the group, and what one gradient all-reduce costs on this node (VERDICT r4 item 7;
-        # to be read against DESIGN.md section 5's prediction)
+        # to be read against DESIGN.md section 5's prediction) — and from it whether the per-anchor
+        # gradients travel as six in-place collectives or as one flat bucket
         big_bytes = sum(p.numel() * 4 for p in params if p.numel() >= cgs_dist.BIG_TENSOR)
         small_bytes = sum(p.numel() * 4 for p in params if p.numel() < cgs_dist.BIG_TENSOR)
         dist_report = cgs_dist.diagnostics(big_bytes, max(4, small_bytes))
+        choice = cgs_dist.choose_big_mode(dist_report, sum(1 for p in params if p.numel() >= cgs_dist.BIG_TENSOR))
+        choice["mode"] = cgs_dist.broadcast_object(choice["mode"], src=0)        # (measured per rank: every rank takes rank 0's)
+        dist_report["per_anchor_gradients"] = choice
+        sync = GradientSync(params, average=True, big_mode=choice["mode"])
         if rank == 0:
             print("[bench] process group:", json.dumps(dist_report), file=sys.stderr, flush=True)
 
@@ -659,7 +663,8 @@ def codec_bench(pc, cams=None, pipe=None, bg=None):
     from contextgs_amd.synth import make_scene
     from contextgs_amd.codec_driver import conduct_encoding
 
-    def round_trip(version, with_fps):
+    def round_trip(version, with_fps, pc=pc):
+        from contextgs_amd import context_model as cm
         d = tempfile.mkdtemp(prefix="cgs_bits_")
         try:
             n_valid = int(pc.get_mask_anchor.sum())
@@ -695,13 +700,25 @@ def codec_bench(pc, cams=None, pipe=None, bg=None):
             # and the feature / scaling / offset tensors non-trivial
             exact_vals = bool(all(torch.isfinite(t).all().item() and t.abs().sum().item() > 0
                                   for t in (dec._anchor_feat[:n_valid], dec._scaling[:n_valid], dec._offset[:n_valid])))
+            #  ... and bit-equal to the encoder's own quantised values: the eval-mode context model over the
+            # valid anchors of the ENCODER's model (what tests/test_configs_gpu.py::_roundtrip checks), untimed
+            with torch.no_grad():
+                m = pc.get_mask_anchor
+                fq, sq, oq = cm.multi_scale_generating(pc, pc.get_anchor[m], pc._hyper_latent[m], pc._anchor_feat[m], pc._offset[m],
+                                                       pc.get_scaling[m], pc.get_mask[m], None, predict_bpp=False, training=False)
+                exact_all = bool(exact and torch.equal(dec._hyper_latent[:n_valid], torch.round(pc._hyper_latent[m]))
+                                 and torch.equal(dec._anchor_feat[:n_valid], fq) and torch.equal(dec._scaling[:n_valid], sq)
+                                 and torch.equal(dec._offset[:n_valid], oq * pc.get_mask[m]))
+                del fq, sq, oq
             return {"container_version": version, "test_fps": fps, "encode_Manchors_per_s": round(n_valid / te / 1e6, 4),
                     "decode_Manchors_per_s": round(n_valid / td / 1e6, 4), "encode_s": round(te, 4), "decode_s": round(td, 4),
                     "encode_s_runs": [round(x, 4) for x in enc_s], "decode_s_runs": [round(x, 4) for x in dec_s],
                     "valid_anchors": n_valid, "bitstream_MB": round(size / 2**20, 3),
                     "encode_s_min_med_max": [round(min(enc_s), 4), round(te, 4), round(max(enc_s), 4)],
                     "decode_s_min_med_max": [round(min(dec_s), 4), round(td, 4), round(max(dec_s), 4)],
-                    "decoded_anchor_and_masks_bit_exact": exact, "decoded_values_finite_nonzero": exact_vals}
+                    "decoded_anchor_and_masks_bit_exact": exact, "decoded_values_finite_nonzero": exact_vals,
+                    "decoded_feat_scaling_offsets_hyper_bit_exact_vs_encoder_quantised": exact_all,
+                    "max_over_median": {"encode": round(max(enc_s) / te, 3), "decode": round(max(dec_s) / td, 3)}}
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
@@ -712,6 +729,19 @@ def codec_bench(pc, cams=None, pipe=None, bg=None):
         v2 = round_trip(2, False)            # same symbols re-cut for the device (codec_driver.CONTAINER_VERSION notes)
         v2.pop("test_fps")
         out["container_v2"] = v2
+        # BASELINE config c3 (Tanks&Temples/train scale: ~500 k anchors, 3-level context encode + decode), both containers
+        torch.cuda.empty_cache()
+        pc3 = make_scene(500_000, seed=0, requires_grad=False)
+        pc3.eval()
+        c3 = {}
+        for ver in (1, 2):
+            r = round_trip(ver, False, pc=pc3)
+            r.pop("test_fps")
+            c3[f"container_v{ver}"] = {k: r[k] for k in ("encode_Manchors_per_s", "decode_Manchors_per_s", "encode_s", "decode_s",
+                                                         "valid_anchors", "bitstream_MB", "max_over_median",
+                                                         "decoded_feat_scaling_offsets_hyper_bit_exact_vs_encoder_quantised")}
+        out["c3_500k"] = c3
+        del pc3
         return out
     finally:
         if was:

@@ -167,8 +167,13 @@ class GradientSync:
     for the anchors it sees."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], average: bool = True, sparse="auto",
-                 sparse_below: float = 0.5, defer_weight_gradients: bool = True):
+                 sparse_below: float = 0.5, defer_weight_gradients: bool = True, big_mode: str = "per_tensor"):
         self.params = [p for p in params if p.requires_grad]
+        # big_mode: "per_tensor" (in place, one collective per per-anchor tensor, started from the gradient hooks: overlaps the
+        # tail of the backward) or "bucket" (all of them packed into ONE flat buffer in finish(): one collective, two extra
+        # passes over the payload, no overlap) — choose_big_mode() picks from measured collective latency / bandwidth
+        assert big_mode in ("per_tensor", "bucket")
+        self.big_mode = big_mode
         # sparse="auto" (default since round 5): the rows the renderer noted for this step (note_touched_rows) in the phases
         # whose gradients only reach visible anchors; a callable(param) -> row mask | None as before; None = always dense
         self.average, self.sparse, self.sparse_below = average, (_auto_rows if sparse == "auto" else sparse), sparse_below
@@ -176,8 +181,8 @@ class GradientSync:
         self._viol = []                     # (param, device bool: gradient outside the noted rows) of this step's compact exchanges
         self._dense_only = set()            # ids of parameters that showed gradient outside the noted rows once: dense from then on
         self.exposed_ms, self._exposure = [], None      # per step: how long the compute stream stood behind the collectives
-        self.big = [p for p in self.params if p.numel() >= BIG_TENSOR]
-        self.small = [p for p in self.params if p.numel() < BIG_TENSOR]
+        self.big = [p for p in self.params if p.numel() >= BIG_TENSOR] if big_mode == "per_tensor" else []
+        self.small = [p for p in self.params if p.numel() < BIG_TENSOR] if big_mode == "per_tensor" else list(self.params)
         self.order = list(range(len(self.big)))              # issue order = indices into self.big
         self._pos = {id(p): k for k, p in enumerate(self.big)}
         self._ready, self._seen, self._next, self._pending = set(), [], 0, []
@@ -426,7 +431,16 @@ class GradientSync:
         for k, p in enumerate(self.big):                      # predicted active, but no rank had a gradient: the zeros
             if k in self._active and not has_big[k]:           # that kept the collective sequence aligned are dropped
                 p.grad = None
-        self._active = {k for k in range(len(self.big)) if has_big[k]}
+        active = {k for k in range(len(self.big)) if has_big[k]}
+        # (round 6) the completion order is a property of the PHASE: before iteration 10 000 the per-anchor gradients come out
+        # of the expansion's backward, afterwards feat / scaling / offsets / anchor leave the context model's last kernels while
+        # `_mask` is final right after the rate node — with the order of the first step ever kept for good, `_mask` waited
+        # head-of-line behind tensors that finish a millisecond later.  Whenever the set of tensors with a gradient changes
+        # (same decision on every rank: it comes from the MAX-reduced mask), the order is adopted again from rank 0's
+        # completion order of THIS step.
+        if active != self._active:
+            self._order_synced = False
+        self._active = active
         if not self._order_synced:                            # adopt rank 0's completion order from now on
             seen = self._seen + [k for k in range(len(self.big)) if k not in self._seen]
             self.order = broadcast_object(seen, src=0)
@@ -453,6 +467,23 @@ class GradientSync:
             self._exposure = None
         v, self.exposed_ms = self.exposed_ms, []
         return {"steps": len(v), "mean_ms": (sum(v) / len(v) if v else None), "max_ms": (max(v) if v else None)}
+
+
+def choose_big_mode(report: dict, n_big_tensors: int = 6, copy_GBps: float = 3000.0) -> dict:
+    """Per-tensor in-place all-reduces or one flat bucket for the per-anchor gradients?  From diagnostics()' measurements on
+    THIS group: per tensor = n collectives whose fixed cost is the small all-reduce's latency, but they start from the gradient
+    hooks and run beside the backward; bucket = one collective + a pack and an unpack pass over the payload (HBM copies at
+    ~copy_GBps) with nothing overlapped.  Returns {"mode", "est_per_tensor_ms", "est_bucket_ms", ...}: the payload's transfer time
+    is the same in both and cancels; what differs is (n - 1) collective latencies against two copy passes."""
+    ar = report.get("all_reduce", {}) if report else {}
+    big, small = ar.get("per_anchor_payload"), ar.get("small_bucket")
+    if not big or not small:
+        return {"mode": "per_tensor", "why": "no measurement"}
+    lat = float(small["median_ms"])
+    copy_ms = 2.0 * float(big["bytes"]) / (copy_GBps * 1e9) * 1e3
+    est_pt, est_b = float(big["median_ms"]) + (n_big_tensors - 1) * lat, float(big["median_ms"]) + copy_ms
+    return {"mode": "per_tensor" if est_pt <= est_b else "bucket", "est_per_tensor_ms": round(est_pt, 3),
+            "est_bucket_ms": round(est_b, 3), "small_allreduce_latency_ms": round(lat, 4), "pack_unpack_ms": round(copy_ms, 3)}
 
 
 _shared_rng_counter = [0]

@@ -144,7 +144,21 @@ def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
         return f
     for k, fn in real.items():
         setattr(mgpu.dist, k, wrap(k, fn))
-    from contextgs_amd import mlp
+    from contextgs_amd import mlp, _lib
+    #  where in the sequence the context model's level backward starts: the per-anchor tensor that is FINAL
+    # before it — `_mask`: its gradient comes from the expansion's and the rate node's backward, both in front of the level
+    # kernels — must be on the wire by then.  (`_offset` / `_scaling` / `_anchor_feat` / `_anchor` are NOT: from iteration
+    # 10 000 on they pass through the level kernels (quantisation noise, scene/gaussian_model.py:1610-1616) and their gradients
+    # leave the LAST of those kernels.)
+    Lc = _lib.lib()
+    real_bwd = Lc.cgs_ctx_level_bwd
+
+    class _LogBwd:
+        def __call__(self, *a):
+            log.append(("ctxl_bwd", 0, "", ""))
+            return real_bwd(*a)
+    Lc.cgs_ctx_level_bwd = _LogBwd()
+    n_mask = int(pc._mask.numel())
     try:
         assert mlp._Deferred.on, "GradientSync did not switch the deferred weight gradients on"
         it = 0
@@ -170,6 +184,15 @@ def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
                 every = mgpu.gather_objects((mine, digest(params)), dst=0)
                 for k_, fn in real.items():
                     setattr(mgpu.dist, k_, wrap(k_, fn))
+                if phase == 20000 and k == 2:
+                    # third step of the context phase: the issue order was re-adopted from this phase's completion order
+                    names = [e[0] for e in mine]
+                    assert "ctxl_bwd" in names, "the level backward did not run in the context phase"
+                    first_bwd = names.index("ctxl_bwd")
+                    mask_at = [i for i, e in enumerate(mine) if e[0] == "all_reduce" and e[1] == n_mask and "float32" in e[2]]
+                    assert mask_at and mask_at[0] < first_bwd, (
+                        f"rank {rank}: `_mask`'s all-reduce (entry {mask_at}) was not issued before the level backward (entry {first_bwd})")
+                    print(f"rank {rank}: `_mask` all-reduce issued at entry {mask_at[0]}, level backward starts at entry {first_bwd}", flush=True)
                 if rank == 0:
                     assert every[0][0] == every[1][0], f"phase {phase} step {k}: collective sequences differ:\n{every[0][0]}\n{every[1][0]}"
                     assert len(every[0][0]) >= 2 and every[0][1] == every[1][1], f"phase {phase} step {k}: replicas diverged"
@@ -177,6 +200,7 @@ def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
     finally:
         for k_, fn in real.items():
             setattr(mgpu.dist, k_, fn)
+        Lc.cgs_ctx_level_bwd = real_bwd
     sync.close()
     dist.barrier()
     print(f"rank {rank}: identical collective sequences in 9 steps (3 phases x 3, one empty view per phase)", flush=True)

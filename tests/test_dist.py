@@ -635,3 +635,61 @@ def test_broadcast_invalidates_the_entropy_bottleneck_tables():
     with torch.no_grad():
         p.detach().add_(0)
     assert p._version > v0                           # the alias shares the counter: what broadcast_parameters relies on
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from contextgs_amd import dist as cd
+        cd.BIG_TENSOR = 8
+        torch.manual_seed(0)
+        a = torch.nn.Parameter(torch.randn(64, 3))
+        lin = torch.nn.Linear(3, 2)
+        params = [a] + list(lin.parameters())
+        out = {}
+        for mode in ("per_tensor", "bucket"):
+            sync = cd.GradientSync(params, average=True, big_mode=mode, sparse=None)
+            for p in params:
+                p.grad = None
+            (lin(a).sum() * float(rank + 1)).backward()
+            nbytes = sync.finish()
+            out[mode] = ([p.grad.clone() for p in params], nbytes)
+            sync.close()
+        rep = cd.diagnostics(64 * 3 * 4, 32, reps=2)
+        q.put(_by_value((rank, out, cd.choose_big_mode(rep, 1))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_mode_reduces_the_same_gradients_and_the_choice_is_computed_from_measurements():
+    """GradientSync(big_mode="bucket") (one flat collective for the per-anchor tensors) gives the gradients of
+    the per-tensor mode; choose_big_mode() turns diagnostics()' measured latencies into the choice bench.py prints."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = _from_value(q.get(timeout=120))
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        g_pt, g_b = res[r][1]["per_tensor"][0], res[r][1]["bucket"][0]
+        for x, y in zip(g_pt, g_b):
+            assert torch.allclose(x, y, atol=1e-6)
+        assert res[r][1]["per_tensor"][1] == res[r][1]["bucket"][1] == (64 * 3 + 6 + 2) * 4
+        c = res[r][2]
+        assert c["mode"] in ("per_tensor", "bucket") and c["est_per_tensor_ms"] > 0 and c["est_bucket_ms"] > 0
+    from contextgs_amd import dist as cd
+    fake = {"all_reduce": {"per_anchor_payload": {"bytes": 444_000_000, "median_ms": 2.0}, "small_bucket": {"bytes": 4000, "median_ms": 0.02}}}
+    assert cd.choose_big_mode(fake, 6)["mode"] == "per_tensor"           # 5 x 20 us of latency < two passes over 444 MB
+    fake["all_reduce"]["small_bucket"]["median_ms"] = 0.2
+    assert cd.choose_big_mode(fake, 6)["mode"] == "bucket"
+    assert cd.choose_big_mode(None)["mode"] == "per_tensor"
