@@ -392,11 +392,13 @@ class _GatherUnique(torch.autograd.Function):
     indexing_backward kernels per 14 steps at 1 M anchors)."""
 
     @staticmethod
-    def forward(ctx, x, idx, complete=False):
+    def forward(ctx, x, idx, complete=False, values=None):
         ctx.save_for_backward(idx)
         ctx.shape = x.shape
         ctx.complete = complete and idx.shape[0] == x.shape[0]
         ctx.ascending = bool(getattr(idx, "_cgs_ascending", False))
+        if values is not None:          # the rows were gathered earlier in the forward (gather_unique_attach)
+            return values.view_as(values)
         return _index_rows(x.detach(), idx)
 
     @staticmethod
@@ -410,11 +412,11 @@ class _GatherUnique(torch.autograd.Function):
             out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
             _lib.check(_lib.lib().cgs_scatter_rows_sorted(_lib.ptr(g), _lib.ptr(idx), n, N, int(out[0].numel()), _lib.ptr(out),
                                                          _lib.current_stream()), "cgs_scatter_rows_sorted")
-            return out, None, None
+            return out, None, None, None
         # `complete`: idx is a permutation of all rows, every row is written, no zero fill needed
         out = (torch.empty if ctx.complete else torch.zeros)(ctx.shape, dtype=g.dtype, device=g.device)
         out.index_copy_(0, idx, g.contiguous())
-        return out, None, None
+        return out, None, None, None
 
 
 class _JoinRows(torch.autograd.Function):
@@ -445,6 +447,13 @@ def gather_unique(x, idx, complete=False):
     if _rowcat_ok(x):                # one-source rowcat: row gather forward, plain row scatter backward (HIP)
         return _ctx.rowcat([(x.reshape(x.shape[0], -1), idx, True)]).view((idx.shape[0],) + tuple(x.shape[1:]))
     return _GatherUnique.apply(x, idx, complete) if x.requires_grad else _index_rows(x, idx)
+
+
+def gather_unique_attach(x, idx, values):
+    """The autograd node of gather_unique(x, idx) around rows that were gathered EARLIER (values = _index_rows(x.detach(), idx)):
+    the launch stays where it hides a host wait, the node is created where the backward should run it (see
+    ctx_ops._MaskSTEAttach)."""
+    return _GatherUnique.apply(x, idx, False, values) if x.requires_grad else values
 
 
 class _GatherRows(torch.autograd.Function):
@@ -1013,8 +1022,9 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
         outs = tuple(gather_unique(_unpermute(c, t), vis_idx) for t in (feat_p, scal_p, off_p))
     if not predict_bpp:
         return outs
-    rate = lambda: tuple(rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, False,
-                                    choose_mask, live_count=c.get("live_count")))
+    # (binary_grid_masks may be a callable: the caller creates the mask's autograd node after the level loop's nodes)
+    rate = lambda: tuple(rate_model(pc, anchor, binary_grid_masks() if callable(binary_grid_masks) else binary_grid_masks,
+                                    mask_anchor_bool, likelihood_hyper, levels, False, choose_mask, live_count=c.get("live_count")))
     if defer_rate:      # the caller enqueues the rate model where it fills a read-back bubble (renderer.py)
         return outs + (rate,)
     return outs + rate()

@@ -603,6 +603,42 @@ class _MaskSTE(torch.autograd.Function):
         return d
 
 
+class _MaskSTEAttach(torch.autograd.Function):
+    """The autograd node of mask_ste() created LATER than its values: `values` = the mask mask_ste_values() computed earlier
+    in the forward.  The autograd engine runs ready nodes in the reverse order of their creation; a node created at the top of
+    render() (where the anchor mask is needed for the level plan) is run after every node of the context model, so `_mask`'s
+    gradient — complete once the expansion's and the rate model's backward are done — became final only after the level kernels
+    and its all-reduce (dist.GradientSync) could not start beside them."""
+
+    @staticmethod
+    def forward(ctx, logits, values):
+        ctx.save_for_backward(logits.detach())
+        ctx.set_materialize_grads(False)
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        if g is None:
+            return None, None
+        x = _c(x)
+        d = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_mask_ste_bwd(_lib.ptr(x), _lib.ptr(_c(g)), x.numel(), _lib.ptr(d), _lib.current_stream()),
+                   "cgs_mask_ste_bwd")
+        return d, None
+
+
+def mask_ste_values(logits):
+    """(mask, any_alive) of mask_ste() WITHOUT an autograd node (attach one later: mask_ste_attach)."""
+    with torch.no_grad():
+        m, alive = _MaskSTE.apply(logits.detach())
+    return m, alive
+
+
+def mask_ste_attach(logits, values):
+    return _MaskSTEAttach.apply(logits, values)
+
+
 def mask_ste(logits):
     """(mask, any_alive): mask = ((sigmoid(m) > 0.01) - sigmoid(m)) + sigmoid(m) with the sigmoid's gradient
     (scene/gaussian_model.py:295-299), any_alive[a] = some offset of anchor a has mask > 0 (:302-310)."""

@@ -401,12 +401,25 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     vis_pending = VisibleList(visible_mask) if visible_mask.is_cuda else None
     full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
     use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
-    begun = binary_all = mask_anchor_bool = rate_thunk = None
+    begun = binary_all = mask_anchor_bool = rate_thunk = late_mask = None
     if use_context:
         # everything of the context model that does not depend on the visible set is enqueued BEFORE the read-back of
         # the visible count below (the accessors, the step's bookkeeping kernel): the GPU works through it while the
         # host waits, and the context model's own count read-back finds its data already there
-        if hasattr(pc, "get_mask_pair"):
+        late_mask = None
+        if (is_training and hasattr(pc, "get_mask_pair") and not pc.decoded_version and pc._mask.is_cuda and pc._mask.requires_grad
+                and torch.is_grad_enabled()):
+            # the mask VALUES now (the level plan needs the anchor mask), its autograd nodes after the level loop's
+            # (ctx_ops._MaskSTEAttach: `_mask`'s gradient is then final BEFORE the level kernels run in the backward)
+            from . import ctx_ops as _ctx_ops
+            binary_vals, mask_anchor_bool = _ctx_ops.mask_ste_values(pc._mask)
+            late_mask = {"vals": binary_vals, "node": None}
+
+            def binary_all():
+                if late_mask["node"] is None:
+                    late_mask["node"] = _ctx_ops.mask_ste_attach(pc._mask, late_mask["vals"])
+                return late_mask["node"]
+        elif hasattr(pc, "get_mask_pair"):
             binary_all, mask_anchor_bool = pc.get_mask_pair()
         else:                                   # the reference's own GaussianModel
             binary_all = pc.get_mask
@@ -425,7 +438,12 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if use_context:
         # enqueued here, in front of the context model's count read-back: the host falls behind the device while it
         # waits there, and a gather the device still has queued covers part of the catch-up
-        binary_grid_masks = sel(binary_all)
+        if late_mask is not None:
+            from .context_model import _index_rows
+            late_mask["vis_vals"] = _index_rows(late_mask["vals"], vis_idx)
+            binary_grid_masks = None
+        else:
+            binary_grid_masks = sel(binary_all)
     if not use_context:
         # raw features of the visible anchors: left as (source, rows) when nothing is added to them, so that the
         # anchor-MLP kernel gathers them itself
@@ -463,6 +481,9 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         feat, grid_scaling, grid_offsets = res[:3]
         if is_training:
             rate_thunk = res[3]         # the rate model (:1657-1707) is enqueued behind the expansion's count (see below)
+        if late_mask is not None:       # the level loop's nodes exist: now the mask's
+            from .context_model import gather_unique_attach
+            binary_grid_masks = gather_unique_attach(binary_all(), vis_idx, late_mask["vis_vals"])
 
     K = pc.n_offsets
     rate_out = []
