@@ -503,6 +503,35 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
             choose_mask = _LazyChooseMask(int(anchor.shape[0]), chosen_rows, anchor.device)
         c["_choose_mask"] = choose_mask
     perm, sizes = c["perm"], c["sizes"]
+    # (host work that launches nothing — the row source, the level outputs' buffers, the path predicates — comes BEFORE the hyper
+    #  step's launches: the device is idle behind the rate subset's read-back at this point and whatever the host still has to do
+    #  between the hyper step's ~95 us kernel and the first level kernel shows as a gap; profiles/r06_gpu_idle_gaps.txt)
+    # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
+    full = c["covers_all"]
+    if c.get("identity"):       # parameters are stored in coding order: the level slices are views, nothing moves
+        in_order = lambda t: t
+    else:
+        in_order = lambda t: gather_unique(t, perm, full)
+    # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
+    fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
+    # When every level takes the fused path, features / scaling / offsets are not gathered at all: the level kernels
+    # read their rows of the parameter tensors through perm[lo:hi] and scatter the gradients back (ctx_ops.RowSource)
+    row_src = None
+    if (fused and ROW_SOURCE and not c.get("identity") and (not keep_stats or choose_mask is not None)
+            and all(_mlp.supported(pc.get_grid_mlp[i_]) for (i_, _t, _o, _a) in c["plan"])
+            and grid_offsets.dim() == 3 and (feat.requires_grad or grid_scaling.requires_grad or grid_offsets.requires_grad)):
+        row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, full)
+        row_src.sums_buffer()            # (its zero fill is queued here, in front of the hyper step's kernel)
+        feat_l = scal_l = off_l = None
+    else:
+        feat_l = torch.split(in_order(feat), sizes)
+        scal_l = torch.split(in_order(grid_scaling), sizes)
+        off_l = torch.split(in_order(grid_offsets), sizes)
+    n_tot = int(perm.shape[0])
+    if fused:
+        big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=anchor.device)
+        big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=anchor.device)
+        big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=anchor.device)
     # :1556.  Only the rate subset's hyper likelihood is ever read (:1662), and only as a sum of bits: on the fused
     # training path the bottleneck returns the noisy latents already in coding order plus that sum (two launches);
     # otherwise the likelihood of the chosen rows / of all rows as a tensor
@@ -527,36 +556,12 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     if pc.disable_hyper and hyper_feat is not None:
         hyper_feat = hyper_feat * 0
 
-    # one gather per tensor into coding order, then contiguous per-level slices (split backward = one cat)
-    full = c["covers_all"]
-    if c.get("identity"):       # parameters are stored in coding order: the level slices are views, nothing moves
-        in_order = lambda t: t
-    else:
-        in_order = lambda t: gather_unique(t, perm, full)
-    # training path on the device: the level's element-wise stages run as fused HIP kernels (ctx_ops)
-    fused = FUSED_TRAINING and training and anchor.is_cuda and not pc.adaptQ_per_channel
-    # When every level takes the fused path, features / scaling / offsets are not gathered at all: the level kernels
-    # read their rows of the parameter tensors through perm[lo:hi] and scatter the gradients back (ctx_ops.RowSource)
-    row_src = None
-    if (fused and ROW_SOURCE and not c.get("identity") and (not keep_stats or choose_mask is not None)
-            and all(_mlp.supported(pc.get_grid_mlp[i_]) for (i_, _t, _o, _a) in c["plan"])
-            and grid_offsets.dim() == 3 and (feat.requires_grad or grid_scaling.requires_grad or grid_offsets.requires_grad)):
-        row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, full)
-        feat_l = scal_l = off_l = None
-    else:
-        feat_l = torch.split(in_order(feat), sizes)
-        scal_l = torch.split(in_order(grid_scaling), sizes)
-        off_l = torch.split(in_order(grid_offsets), sizes)
     hyp_l = hyp_p if isinstance(hyp_p, tuple) else torch.split(hyp_p if hyp_p is not None else in_order(hyper_feat), sizes)
 
     feat_q, scal_q, off_q, levels = [], [], [], []
     ctx_src = None                      # (idx, pos, base_f, base_s): the coded context of the next level
     # the fused levels write their outputs side by side into these (coding order), so no cat is needed at the end
-    n_tot, row_off, joined = int(perm.shape[0]), 0, fused
-    if fused:
-        big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=anchor.device)
-        big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=anchor.device)
-        big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=anchor.device)
+    row_off, joined = 0, fused
     # The mean / scale outputs of the rate subset can stay INSIDE the rate kernels (cgs_rate_sub_*, round 6) when the rate model
     # will take its one-node path (rate_model: every level fused, the subset listed level by level, the live fraction a host
     # number) — decided here, before the first level runs, from the same predicates the loop and rate_model use

@@ -717,16 +717,30 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
     const ClBuf bSrc = cl_buf(ROWS ? R.src_row : nullptr, nb * 8), bAnc = cl_buf(ROWS ? R.anchor : nullptr, nb * 12);
     const float cam0 = ROWS ? R.cam[0] : 0.f, cam1 = ROWS ? R.cam[1] : 0.f, cam2 = ROWS ? R.cam[2] : 0.f;
     const uint32_t ldx4 = (uint32_t)ldx * 4;
+    // (round 6) X == NULL (ROWS): the forward did not keep its assembled input rows (216 of the 1256 bytes per anchor it
+    // stores: the forward is bound by exactly those stores) — the rows are assembled again here, by the forward's own loader
+    // from the same operands: the same bits
+    const bool regather = ROWS && X == nullptr;
+    M3FwdBufs FB;
+    FB.feat = cl_buf(regather ? R.feat_src : nullptr, CL_MAX_BYTES);
+    FB.anc = bAnc;
+    auto load_x = [&](f32x4 (&x)[M3_NTI], int64_t row, int64_t srow, bool v) {
+#pragma unroll
+        for (int q = 0; q < M3_NTI; ++q)
+            x[q] = regather ? m3_load_x_rows_b(FB, cam0, cam1, cam2, row, srow, q, g, v)
+                            : frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, v);
+    };
     M3wOps<10, 1> op0;
     M3wOps<30, 2> op1;
     M3wOps<70, 0> op2;
     f32x4 xf[M3_NTI];
+    int64_t srow_next = 0;                  // (regather) source row of the NEXT tile's row c, fetched a tile ahead
     {
         const int64_t row = tile * 16 + c;
         const bool v0 = tile < ntiles && row < n;
         op0.load(B, 0, row, g, v0);
-#pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, v0);
+        const int64_t s0 = regather ? cl_li64(bSrc, cl_sel(v0, (uint32_t)row * 8)) : 0;
+        load_x(xf, row, s0, v0);
     }
     for (; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16;
@@ -738,12 +752,12 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
         f32x4 ones, xn[M3_NTI];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ones[r] = row0 + 4 * g + r < n ? 1.f : 0.f;
-#if !M3W_XPREFETCH
-#pragma unroll
-        for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)(row0 + c) * ldx4, q, g, valid);
-#endif
         // (ROWS) what the end of the tile needs from memory, issued here: the row's source index and its anchor
         const int64_t srow_pre = ROWS ? cl_li64(bSrc, cl_sel(valid, (uint32_t)(row0 + c) * 8)) : 0;
+#if !M3W_XPREFETCH
+        load_x(xf, row0 + c, srow_pre, valid);
+#endif
+        if (regather) srow_next = cl_li64(bSrc, cl_sel(validn, (uint32_t)rown * 8));
         const f32x4 anc_pre = ROWS ? cl_l96(bAnc, cl_sel(valid && g == 0, (uint32_t)(row0 + c) * 12)) : zero;
 #pragma unroll
         for (int q = 0; q < M3_NTI; ++q) m3w_put(patches + q * M3W_PATCH, frag_bmask4<M3_IN>(xf[q], q, g), g, c);
@@ -758,8 +772,7 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
         m3w_head<70, 0>(l2, patches, op2, ones, g, c, xn, adx, a2_2, a1_2, [&]() {
             op0.load(B, 0, rown, g, validn);
 #if M3W_XPREFETCH
-#pragma unroll
-            for (int q = 0; q < M3_NTI; ++q) xf[q] = frag_bload4<M3_IN>(B.X, (uint32_t)rown * ldx4, q, g, validn);
+            load_x(xf, rown, srow_next, validn);
 #endif
         });
         if (ROWS) {
@@ -947,7 +960,7 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
 // Backward of cgs_anchor_mlp3_forward_rows: X is the [n,54] side output of the forward; instead of a dense dX the
 // feature columns are stored into rows src_row[r] of d_feat_src [*,50] (distinct rows; rows no visible anchor reads
 // are the caller's to zero) and the view columns are pulled back to d_anchor_vis [n,3].
-extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_row, const float *anchor_vis,
+extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
                                              const float *cam3, const float *const *W1, const float *const *W2,
                                              const float *Y_op, const float *Y_color, const float *dY_op,
                                              const float *dY_color, const float *dY_cov, const float *Hcat,
@@ -957,7 +970,11 @@ extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_
                                              void *stream_) {
     if (n == 0) return CGS_OK;           // no visible anchor: nothing to do (empty tensors arrive as NULL pointers)
     if (!src_row || !anchor_vis || !cam3 || !d_feat_src || !d_anchor_vis) { cgs_set_error("anchor_mlp3_backward_rows: NULL"); return CGS_ERR_ARG; }
-    M3Rows R{nullptr, src_row, anchor_vis, cam3, nullptr, d_feat_src, d_anchor_vis};
+    if (!X && (!feat_src || !dW1cat || n > M3_MAX_ROWS)) {
+        cgs_set_error("anchor_mlp3_backward_rows: X == NULL needs feat_src, the fused weight-gradient form and <= %lld rows", (long long)M3_MAX_ROWS);
+        return CGS_ERR_ARG;
+    }
+    M3Rows R{X ? nullptr : feat_src, src_row, anchor_vis, cam3, nullptr, d_feat_src, d_anchor_vis};
     return m3_backward(X, M3_XLD, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat, nullptr, 0, dZ1cat, dZ2_op, dZ2_color,
                        dW1cat, db1cat, dW2, db2, n, scratch, scratch_bytes, &R, stream_);
 }
@@ -972,8 +989,9 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     if (n == 0) return CGS_OK;
     // dW1cat == NULL: data gradients only — the weight-gradient launch is the caller's to make later (cgs_anchor_mlp3_wgrad)
     const bool data_only = !dW1cat;
-    if (!X || !W1 || !W2 || !Y_op || !Y_color || !dY_op || !dY_color || !dY_cov || !Hcat || !dZ1cat || !dZ2_op ||
-        !dZ2_color || (data_only ? (db1cat || dW2 || db2) : (!db1cat || !dW2 || !db2))) {
+    const bool no_x = !X && rows && rows->feat_src;          // the rows are assembled again by the fused kernel
+    if ((!X && !no_x) || !W1 || !W2 || !Y_op || !Y_color || !dY_op || !dY_color || !dY_cov || !Hcat || (!no_x && (!dZ1cat || !dZ2_op ||
+        !dZ2_color)) || (data_only ? (db1cat || dW2 || db2) : (!db1cat || !dW2 || !db2))) {
         cgs_set_error("anchor_mlp3_backward: NULL (or a partial set of weight-gradient pointers)");
         return CGS_ERR_ARG;
     }
@@ -1009,6 +1027,7 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
         }
     }
 #endif
+    if (no_x) { cgs_set_error("anchor_mlp3_backward: X == NULL but the fused weight-gradient form could not run (scratch)"); return CGS_ERR_WORKSPACE; }
     const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
     const int64_t want = (tiles + WAVES - 1) / WAVES;
     const int grid = (int)(want < m3_cus() ? want : m3_cus());

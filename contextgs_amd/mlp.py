@@ -418,6 +418,13 @@ class _AnchorMLP3(torch.autograd.Function):
         return (dx,) + (None,) * 12
 
 
+# A/B knob, default: the forward KEEPS its assembled rows.  CGS_M3_KEEP_X=0: it does not (forward 480 -> 438 us at 1 M anchors:
+# it is bound by the bytes it stores) and the fused backward assembles them again (903 -> 957 us: one wave per SIMD, every
+# instruction of the re-gather is added time) — a net loss of ~12 us per step, same box, two pairs: profiles/r06_mlp3_xout_ab.txt
+KEEP_X_OFF = os.environ.get("CGS_M3_KEEP_X", "1") == "0"
+_M3_REGATHER_MAX_ROWS = 4_000_000                                # the fused backward's row limit (32-bit buffer offsets)
+
+
 class _AnchorMLP3Rows(torch.autograd.Function):
     """The three anchor MLPs on rows assembled inside the kernel: [feat_src[src_row] | view direction | distance]
     (gaussian_renderer/__init__.py:106-127); backward scatters the feature gradient into the source rows and pulls the
@@ -442,14 +449,18 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
         hld, xld, _gld, _gp = _m3_layout()
         hcat = torch.empty(n, hld, dtype=torch.float32, device=dev) if need_grad else None
-        x = torch.empty(n, xld, dtype=torch.float32, device=dev) if need_grad else None
+        # (round 6) the assembled input rows are kept only for the deferred weight-gradient launch of the multi-GPU step; the
+        # fused backward of the single-GPU step assembles them again (216 of the 1256 bytes per anchor the forward is bound by)
+        keep_x = need_grad and (_Deferred.on or n > _M3_REGATHER_MAX_ROWS or not KEEP_X_OFF)
+        x = torch.empty(n, xld, dtype=torch.float32, device=dev) if keep_x else None
         _lib.check(L.cgs_anchor_mlp3_forward_rows(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
                                                   _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
                                                   _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n,
                                                   _lib.current_stream()), "cgs_anchor_mlp3_forward_rows")
         if need_grad:
-            ctx.save_for_backward(x, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
+            ctx.save_for_backward(x if keep_x else feat_src, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
             ctx.n_src = int(feat_src.shape[0])
+            ctx.keep_x = keep_x
         ctx.params = params
         return y_op, y_color, y_cov
 
@@ -458,9 +469,12 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         L = _lib.lib()
         saved = ctx.saved_tensors
         x, src_row, anchor_vis, cam, y_op, y_color, hcat = saved[:7]
+        feat_src = None
+        if not ctx.keep_x:
+            feat_src, x = x, None
         W1, W2 = list(saved[7:10]), list(saved[10:13])
-        n = x.shape[0]
-        dev = x.device
+        n = int(src_row.shape[0])
+        dev = hcat.device
         z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else (
             t.contiguous() if t.dtype == torch.float32 else t.float().contiguous())
         g_op, g_color, g_cov = z(g_op, (n, 10)), z(g_color, (n, 30)), z(g_cov, (n, 70))
@@ -478,9 +492,9 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
-        defer = _can_defer(ctx.params) and n > 0
+        defer = _can_defer(ctx.params) and n > 0 and x is not None
         _lib.check(L.cgs_anchor_mlp3_backward_rows(
-            _lib.ptr(x), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam), _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op),
+            _lib.ptr(x), _lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam), _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op),
             _lib.ptr(y_color), _lib.ptr(g_op), _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(d_src),
             _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), None if defer else _lib.ptr(dW1cat),
             None if defer else _lib.ptr(db1cat), None if defer else _ptr_array(dW2), None if defer else _ptr_array(db2), n,

@@ -597,7 +597,9 @@ int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t *src_row,
                                  const float *const *W1, const float *const *b1,
                                  const float *const *W2, const float *const *b2, float *Y_op,
                                  float *Y_color, float *Y_cov, float *Hcat, int64_t n, void *stream);
-int cgs_anchor_mlp3_backward_rows(const float *X, const int64_t *src_row, const float *anchor_vis,
+/* (round 6) X_out may be NULL in the forward; the backward then takes X == NULL and feat_src (the forward's): its fused
+ * data + weight-gradient kernel assembles the rows again from the same operands (needs dW1cat != NULL, n <= 4 M rows). */
+int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
                                   const float *cam3, const float *const *W1, const float *const *W2,
                                   const float *Y_op, const float *Y_color, const float *dY_op,
                                   const float *dY_color, const float *dY_cov, const float *Hcat,

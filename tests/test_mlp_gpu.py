@@ -109,12 +109,16 @@ def test_anchor_mlp3_matches_three_torch_mlps(n):
         assert (a - b).abs().max() <= tol, (i, float((a - b).abs().max()), float(b.abs().max()))
 
 
-def test_anchor_mlp3_rows_equals_the_materialised_input():
-    """cgs_anchor_mlp3_{forward,backward}_rows (input row = [feat_src[src_row] | view direction | distance] assembled in
+@pytest.mark.parametrize("keep_x", [True, False])
+def test_anchor_mlp3_rows_equals_the_materialised_input(keep_x, monkeypatch):
+    """(keep_x False: the forward does not store its assembled rows and the fused backward assembles them again — round 6's
+    X-less mode, measured slower in the step and left off: profiles/r06_mlp3_xout_ab.txt.)
+    cgs_anchor_mlp3_{forward,backward}_rows (input row = [feat_src[src_row] | view direction | distance] assembled in
     the kernel, gradient scattered into the source rows / pulled back to the anchors) against the same three MLPs on the
     torch-assembled [n,54] input (gaussian_renderer/__init__.py:106-110)."""
     import torch.nn as nn
     from contextgs_amd import mlp
+    monkeypatch.setattr(mlp, "KEEP_X_OFF", not keep_x)
     torch.manual_seed(3)
     dev = "cuda"
     mk = lambda out, act: nn.Sequential(nn.Linear(54, 50), nn.ReLU(True), nn.Linear(50, out), *([act()] if act else [])).to(dev)
