@@ -24,7 +24,18 @@
 #define EB_BOUND 1e-9f
 
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float eb_rcp(float d) {          // 1 / d: hardware reciprocal + one Newton step (the IEEE sequence is 16 instructions)
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return eb_rcp(1.f + __expf(-x)); }
+// tanh of the density's hidden units (24 per element and evaluation pair: the library's tanhf, a 38-instruction divergent
+// routine, WAS this file's kernels — round 6): 1 - 2 / (1 + exp(2 z)) with one v_exp_f32; absolute error ~1e-7, which is what
+// enters y = z + f tanh(z) (the relative error near z = 0 does not: nothing divides by it); |z| clamped where tanh is +-1 in fp32
+__device__ __forceinline__ float eb_tanh(float z) {
+    const float zc = fminf(fmaxf(z, -20.f), 20.f);
+    return 1.f - 2.f * eb_rcp(1.f + __builtin_amdgcn_exp2f(zc * 2.8853900817779268f));
+}
 
 struct EbTrace {           // intermediates of one evaluation
     float u, y0[3], t0[3], y[3][3], t[3][3];   // y[k-1], t[k-1] for k = 1..3
@@ -56,7 +67,7 @@ __device__ __forceinline__ float eb_eval(const float p[EB_P], float u, EbTrace &
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float z = p[OFF_M0 + i] * u + p[OFF_B0 + i];
-        tr.t0[i] = tanhf(z);
+        tr.t0[i] = eb_tanh(z);
         tr.y0[i] = z + p[OFF_F0 + i] * tr.t0[i];
     }
     float prev[3] = {tr.y0[0], tr.y0[1], tr.y0[2]};
@@ -67,7 +78,7 @@ __device__ __forceinline__ float eb_eval(const float p[EB_P], float u, EbTrace &
         for (int i = 0; i < 3; ++i) {
             const float z = p[OFF_M(k) + 3 * i] * prev[0] + p[OFF_M(k) + 3 * i + 1] * prev[1] +
                             p[OFF_M(k) + 3 * i + 2] * prev[2] + p[OFF_B(k) + i];
-            tr.t[k - 1][i] = tanhf(z);
+            tr.t[k - 1][i] = eb_tanh(z);
             cur[i] = z + p[OFF_F(k) + i] * tr.t[k - 1][i];
             tr.y[k - 1][i] = cur[i];
         }
@@ -324,13 +335,20 @@ __global__ void __launch_bounds__(256)
     float p[EB_P];
     eb_load_params(raw, c, p);
     float acc = 0.f;
-    for (int64_t row = w_in_c * 64 + lane; row < n; row += waves_per_c * 64) {
-        const float x = v[(rows ? rows[row] : row) * C + c];
+    // (the row gather of the NEXT element is in flight while this one is evaluated: ~3 waves per SIMD do not hide a dependent
+    //  index -> value round trip per element by themselves)
+    const int64_t step = waves_per_c * 64;
+    int64_t row = w_in_c * 64 + lane;
+    float xn = row < n ? v[(rows ? rows[row] : row) * C + c] : 0.f;
+    for (; row < n; row += step) {
+        const float x = xn;
+        const int64_t rnext = row + step;
+        if (rnext < n) xn = v[(rows ? rows[rnext] : rnext) * C + c];
         EbTrace tl, tu;
         const float lo = eb_eval(p, x - 0.5f, tl), up = eb_eval(p, x + 0.5f, tu);
         const float sm = lo + up;
         const float s = sm > 0.f ? -1.f : (sm < 0.f ? 1.f : 0.f);
-        acc -= log2f(fmaxf(fabsf(sigmoidf(s * up) - sigmoidf(s * lo)), EB_BOUND));
+        acc -= __log2f(fmaxf(fabsf(sigmoidf(s * up) - sigmoidf(s * lo)), EB_BOUND));       // (argument >= 1e-9: normal)
     }
     double d = (double)acc;
 #pragma unroll
@@ -367,8 +385,13 @@ __global__ void __launch_bounds__(256)
     const float gs = *g_sum;
 #pragma unroll
     for (int i = 0; i < EB_P; ++i) gp[i] = 0.f;
-    for (int64_t row = w_in_c * 64 + lane; row < n; row += waves_per_c * 64) {
-        const float x = v[(rows ? rows[row] : row) * C + c];
+    const int64_t step = waves_per_c * 64;
+    int64_t row = w_in_c * 64 + lane;
+    float xn = row < n ? v[(rows ? rows[row] : row) * C + c] : 0.f;
+    for (; row < n; row += step) {
+        const float x = xn;
+        const int64_t rnext = row + step;
+        if (rnext < n) xn = v[(rows ? rows[rnext] : rnext) * C + c];      // (one wave per SIMD here: nothing else hides the gather)
         EbTrace tl, tu;
         const float lo = eb_eval(p, x - 0.5f, tl), up = eb_eval(p, x + 0.5f, tu);
         const float sm = lo + up;
@@ -376,7 +399,7 @@ __global__ void __launch_bounds__(256)
         const float su = sigmoidf(s * up), sl = sigmoidf(s * lo);
         const float d = su - sl;
         const float lik = fmaxf(fabsf(d), EB_BOUND);
-        const float g = -gs / (lik * EB_LN2);                       // d(-log2 lik)/d lik
+        const float g = -gs * eb_rcp(lik * EB_LN2);                 // d(-log2 lik)/d lik
         const bool pass = (fabsf(d) >= EB_BOUND) || (g < 0.f);      // LowerBound: as eb_likelihood_bwd_kernel
         const float gd = pass ? g * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 0.f;
         const float g_up = gd * su * (1.f - su) * s;
@@ -416,7 +439,10 @@ extern "C" int cgs_eb_bits_fwd(const float *v, const int64_t *rows, const float 
     if (n < 0 || C < 1 || !out || !scratch || scratch_bytes < cgs_eb_bits_scratch_bytes()) { cgs_set_error("eb_bits_fwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) { CGS_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream)); return CGS_OK; }
     if (!v || !raw) { cgs_set_error("eb_bits_fwd: NULL"); return CGS_ERR_ARG; }
-    int grid = eb_grid(n, C, 8);
+#ifndef EB_BITS_FWD_BPC
+#define EB_BITS_FWD_BPC 2        // workgroups per CU (3 waves per SIMD would fit); every workgroup ends with an atomic on ONE
+#endif                           // counter (~25 ns each, serial in L2): 8 per CU = 2 040 of them cost 90 us, 3: 50 us, 2: 41 us (same box)
+    int grid = eb_grid(n, C, EB_BITS_FWD_BPC);
     if (grid > EB_BITS_MAX_BLOCKS) grid = EB_BITS_MAX_BLOCKS / C * C;
     hipLaunchKernelGGL(eb_bits_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, rows, raw, n, C, (double *)scratch,
                        (unsigned int *)((char *)scratch + (size_t)EB_BITS_MAX_BLOCKS * sizeof(double)), out);
