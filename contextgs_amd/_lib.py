@@ -115,6 +115,8 @@ SIGNATURES = {
                                       c_void_p]),
     "cgs_ctx_gather_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p]),
+    "cgs_ctx_gather_bwd_acc": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int, c_int, c_void_p]),
     "cgs_noise_quant_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     C.c_uint64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),

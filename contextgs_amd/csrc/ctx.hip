@@ -899,7 +899,7 @@ __global__ void __launch_bounds__(256)
     ctx_gather_bwd_kernel(const float *__restrict__ dout, int64_t ldo, int64_t n_parents,
                           const int64_t *__restrict__ offs, const int64_t *__restrict__ order,
                           const int64_t *__restrict__ parent_row, float *__restrict__ d_anchor,
-                          float *__restrict__ d_f, float *__restrict__ d_s, int wa, int DF, int DS) {
+                          float *__restrict__ d_f, float *__restrict__ d_s, int wa, int DF, int DS, int acc_anchor) {
     const int lane = threadIdx.x & 63;
     const int W = wa + DF + DS;
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_parents; p += (int64_t)gridDim.x * 4) {
@@ -933,16 +933,27 @@ __global__ void __launch_bounds__(256)
             const int c = lane + 64 * h;
             const float v = h ? acc1 : acc0;
             if (c >= W) continue;
-            if (c < wa) { if (d_anchor && e > b) d_anchor[parent_row[p] * wa + c] = v; }
+            if (c < wa) {       // (acc_anchor: the rows also carry what an earlier launch left there — distinct rows within a launch)
+                if (d_anchor && e > b) { float *q = d_anchor + parent_row[p] * wa + c; *q = acc_anchor ? *q + v : v; }
+            }
             else if (c < wa + DF) { if (d_f) d_f[p * DF + (c - wa)] = v; }
             else if (d_s) d_s[p * DS + (c - wa - DF)] = v;
         }
     }
 }
 
+extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
+                                      const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
+                                      float *d_s, int wa, int DF, int DS, int accumulate_anchor, void *stream);
 extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
                                   const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
                                   float *d_s, int wa, int DF, int DS, void *stream) {
+    return cgs_ctx_gather_bwd_acc(dout, ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, 0, stream);
+}
+// accumulate_anchor != 0: d_anchor rows are ADDED to (the levels of one backward share one anchor-gradient buffer)
+extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
+                                      const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
+                                      float *d_s, int wa, int DF, int DS, int accumulate_anchor, void *stream) {
     if (n_parents < 0 || wa < 0 || DF < 0 || DS < 0 || wa + DF + DS < 1 || wa + DF + DS > 128 || ldo < wa + DF + DS) {
         cgs_set_error("ctx_gather_bwd: bad args");
         return CGS_ERR_ARG;
@@ -951,7 +962,7 @@ extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_pare
     if (!dout || !offs || !order || (d_anchor && !parent_row)) { cgs_set_error("ctx_gather_bwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(ctx_gather_bwd_kernel, dim3(stream_grid(n_parents, 4 * 8)), dim3(256), 0, (hipStream_t)stream, dout,
-                       ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS);
+                       ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, accumulate_anchor ? 1 : 0);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -13,6 +13,8 @@ import itertools
 import threading
 import weakref
 
+import os
+
 import torch
 
 from . import _lib
@@ -159,6 +161,12 @@ class RowSource:
         self.complete = bool(complete)          # the levels' rows cover every row: no zero fill needed
         self.rows_read = self.rows_written = 0
         self.grads = None
+        # (round 6) ONE anchor-gradient buffer for the levels of a backward: every fused level gathers anchor rows (its own, or
+        # its parents'), and as separate [N,3] outputs that was a zero fill per level + autograd's adds (3 fills + 2 adds of
+        # 12 MB at 1 M anchors).  The levels that asked for the anchor gradient register in the forward; in the backward the first
+        # one to run creates the zeroed buffer, each ADDS its rows, and the last one hands the buffer to autograd.
+        self.anchor_users = 0
+        self.anchor_acc = None
         self.sums = None            # device double [3]: sums of the values the levels read (RowSource.means())
         self.token = _RowSourceFn.apply(self, feat, scal, off)
 
@@ -739,6 +747,7 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
 
 
 # ---- one launch per level and direction for the every-row half of the level loop (csrc/ctx_level.hip) ---------------
+ANCHOR_SHARED = os.environ.get("CGS_ANCHOR_SHARED", "1") != "0"      # A/B knob: 0 = one zero-filled [N,3] anchor gradient per level (rounds 5)
 _LEVEL_DIMS = (50, 6, 30, 12, 100, 175)      # features, scaling, offsets, hyper, hidden, outputs of mlp_grid: the kernels' instance
 
 
@@ -820,6 +829,9 @@ class _LevelFused(torch.autograd.Function):
         ctx.cfg, ctx.dims = {k: v for k, v in cfg.items() if k != "outs"}, (n, in_f, hid, out, n_stat, m)
         ctx.lazy = lazy
         ctx.shapes = (tuple(anchor.shape), None if bf is None else tuple(bf.shape), None if bs is None else tuple(bs.shape))
+        ctx.share_anchor = bool(ANCHOR_SHARED and ctx.needs_input_grad[0])
+        if ctx.share_anchor:
+            src.anchor_users += 1
         if pred is None:
             pred = torch.empty(0, out, dtype=_f32, device=dev)
         return yf, ys, yo, Q, pred
@@ -882,15 +894,21 @@ class _LevelFused(torch.autograd.Function):
         src.rows_written += n
         need = ctx.needs_input_grad
         a_shape, f_shape, s_shape = ctx.shapes
-        d_anchor = torch.zeros(a_shape, dtype=_f32, device=dev) if need[0] else None
+        shared = ctx.share_anchor and need[0]
+        if shared:
+            if src.anchor_acc is None:
+                src.anchor_acc = torch.zeros(a_shape, dtype=_f32, device=dev)
+            d_anchor = src.anchor_acc
+        else:
+            d_anchor = torch.zeros(a_shape, dtype=_f32, device=dev) if need[0] else None
         d_f = d_s = None
         if f_shape is not None:                  # context level: the parents' rows, summed over their children without atomics
             offs, order, prow = cfg["csr"]
             d_f = torch.empty(f_shape, dtype=_f32, device=dev) if need[1] else None
             d_s = torch.empty(s_shape, dtype=_f32, device=dev) if need[2] else None
             if d_anchor is not None or d_f is not None or d_s is not None:
-                _lib.check(L.cgs_ctx_gather_bwd(_lib.ptr(dX), in_f, int(f_shape[0]), _lib.ptr(offs), _lib.ptr(order), _lib.ptr(prow),
-                                                _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s), 3, 50, 6, stream),
+                _lib.check(L.cgs_ctx_gather_bwd_acc(_lib.ptr(dX), in_f, int(f_shape[0]), _lib.ptr(offs), _lib.ptr(order), _lib.ptr(prow),
+                                                    _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s), 3, 50, 6, int(shared), stream),
                            "cgs_ctx_gather_bwd")
             d_hyp = dX[:, 59:] if need[3] else None          # a column slice: its consumer takes strided rows
         else:                                    # first level: X = [anchor[a_rows] * mask | hyper]
@@ -900,9 +918,16 @@ class _LevelFused(torch.autograd.Function):
                 if a_mask is not None:
                     a_mask = (a_mask if a_mask.dtype == torch.uint8 else a_mask.view(torch.uint8)).contiguous()
                 # (the hyper columns of dX leave as the strided slice above: mode 0 = no store for that source)
+                # (shared buffer: these rows may carry an earlier level's sums — mode 2 adds; the rows are distinct, the atomics uncontended)
                 _lib.check(L.cgs_rowcat_bwd_masked(2, _ptrs([d_anchor, None]), _ptrs([cfg["a_rows"], None]), _ptrs([a_mask, None]),
-                                                   _ints([3, 12]), _ints([3, 12]), _ints([1, 0]), n, _lib.ptr(dX), stream),
+                                                   _ints([3, 12]), _ints([3, 12]), _ints([2 if shared else 1, 0]), n, _lib.ptr(dX), stream),
                            "cgs_rowcat_bwd")
+        if shared:
+            src.anchor_users -= 1
+            if src.anchor_users > 0:
+                d_anchor = None                 # a later level of this backward hands the shared buffer on
+            else:
+                src.anchor_acc = None
         return d_anchor, d_f, d_s, d_hyp, dW1, db1, dW2, db2, None, None
 
 

@@ -394,6 +394,11 @@ int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
                        const int64_t *offs, const int64_t *order,
                        const int64_t *parent_row, float *d_anchor, float *d_f,
                        float *d_s, int wa, int DF, int DS, void *stream);
+/* the same; accumulate_anchor != 0: the d_anchor rows are added to (one anchor-gradient buffer shared by the levels of a backward) */
+int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents,
+                       const int64_t *offs, const int64_t *order,
+                       const int64_t *parent_row, float *d_anchor, float *d_f,
+                       float *d_s, int wa, int DF, int DS, int accumulate_anchor, void *stream);
 /* Adaptive step sizes + training noise (:1603-1616):
  *   Q[r,k] = max(q0_k * (1 + tanh(qadj[r,k])), 1e-9),  k = feat, scaling, offsets
  *   yf = xf + u * Q[r,0], ys = xs + u * Q[r,1], yo = xo + u * Q[r,2],  u ~ U[-0.5, 0.5)

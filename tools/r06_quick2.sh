@@ -1,0 +1,12 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+(timeout 1200 python -m pytest tests/test_context_gpu.py tests/test_training_parity_gpu.py tests/test_rate_sub_gpu.py tests/test_ctx_level_gpu.py tests/test_training_gpu.py tests/test_ctx_ops_gpu.py tests/test_edge_cases_gpu.py tests/test_dist_train_gpu.py -x -q 2>&1 | tail -3) > gpurun_out/r06_tq.log 2>&1; cat gpurun_out/r06_tq.log
+FLAGS="--no-cpu-baseline --no-heavy --no-eval-fps --no-codec --no-raster-only --no-image-loss"
+for rep in 1 2; do for sh in 0 1; do
+CGS_ANCHOR_SHARED=$sh timeout 600 python bench.py $FLAGS > gpurun_out/r06_bench_q.json 2> gpurun_out/bench.err
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r06_bench_q.json").read().strip().splitlines()[-1])
+print("anchor_shared=$sh value", d["value"], "ms", d["ms_per_step"], "host", d["timing"]["host_ms_per_step"], "kernels", d.get("hip_kernel_ms_per_step"), "ctx", d["ctx_group_roofline"].get("ms_per_step"))
+PY
+done; done
