@@ -17,7 +17,7 @@
 #include "cgs_internal.h"
 
 #define CP_THREADS 256
-#define CP_PER_THREAD 16          // (round 6: 4 -> 16: every workgroup ends with ~5 atomics on ONE cache line of `meta`; 977 workgroups of them were most of this kernel's 36 us)
+#define CP_PER_THREAD 4           // (16 was tried in round 6 for fewer closing atomics: flags 36 -> 41 us, compact 11 -> 25 us: worse)
 #define CP_CHUNK (CP_THREADS * CP_PER_THREAD)
 #define CP_MAX_LEVELS 8
 
