@@ -41,7 +41,7 @@ PMC_SOURCES = {
     "mlp3_fwd": ("mlp3.hip", "mlp_frag.h"),
     "mlp3_bwd": ("mlp3.hip", "mlp_frag.h"),
     "ctx_group": ("ctx_level.hip", "ctx.hip", "ctx_plan.hip", "ctx_noise.h", "mlp.hip", "mlp_small.hip", "mlp_wgrad.hip", "mlp_frag.h",
-                  "eb.hip", "elementwise.hip", "rate_math.h"),
+                  "eb.hip", "elementwise.hip", "rate_math.h", "rate_sub.hip", "ctx_rows.h", "buf_access.h"),
 }
 
 
@@ -414,7 +414,11 @@ def main():
                     else:
                         traffic_stale.append("ctx_group")
             if os.path.exists(vpath):
-                valu = json.load(open(vpath)).get("valu_busy_frac", {})
+                vj = json.load(open(vpath))
+                vrec = vj.get("file_digests", {})
+                # (round 6) the same rule as for the traffic figures: only while the blend kernels' sources are the measured ones
+                if vrec and all(vrec.get(f) == _csrc_digest(f) for f in PMC_SOURCES["blend_bwd"]):
+                    valu = vj.get("valu_busy_frac", {})
         kernels = {}
         for name, (ms, n) in prof.items():
             avg_us = ms / n * 1e3

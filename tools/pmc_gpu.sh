@@ -45,7 +45,7 @@ for k, (n, tot) in rd.items():
         tr[names[base]] = int((2 * tot / n + wr[k][1] / wr[k][0]) * 1024)
 # the context model's level loop as a group: (2 FETCH + WRITE) of every dispatch of its kernels, per training step (one step =
 # two dispatches of the level-0/1 backward kernel, or of noise_quant_bwd on the separate-launch path)
-ctx_keys = ("ctxl_", "level_rate_", "mlp2_", "wgrad_multi", "wgrad_reduce", "wgrad_tail", "mlp_small_reduce", "ctx_gather_bwd", "eb_bits_", "rowcat_",
+ctx_keys = ("ctxl_", "rs_main", "rs_wgrad", "level_rate_", "mlp2_", "wgrad_multi", "wgrad_reduce", "wgrad_tail", "mlp_small_reduce", "ctx_gather_bwd", "eb_bits_", "rowcat_",
             "rowgather4", "gather_rows_segmented", "hyper_noise", "ctx_choose", "noise_quant_", "means_finalize", "rate_finish")
 tot_ctx, steps_ctx = 0.0, 0
 for k, (n, tot) in rd.items():
