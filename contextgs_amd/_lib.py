@@ -127,6 +127,8 @@ SIGNATURES = {
     "cgs_rate_finish_fwd": (c_int, [c_void_p, c_int, c_void_p, c_float, C.c_double, C.c_double, C.c_double, c_float, c_void_p,
                                     c_void_p, c_void_p]),
     "cgs_rate_finish_bwd": (c_int, [c_void_p, c_int, c_float, C.c_double, C.c_double, C.c_double, c_void_p, c_void_p, c_void_p]),
+    "cgs_rate_finish_bwd4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, C.c_double, C.c_double, C.c_double, c_void_p,
+                                     c_void_p, c_void_p]),
     "cgs_ctx_choose_blocks": (c_size_t, [c_int64]),
     "cgs_ctx_choose_flags": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, C.c_uint64, c_float, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

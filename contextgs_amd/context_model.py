@@ -419,6 +419,55 @@ class _GatherUnique(torch.autograd.Function):
         return out, None, None, None
 
 
+class _GatherUniquePair(torch.autograd.Function):
+    """(x[idx_a], x.reshape(N, -1)[idx_b]) — two lists of distinct rows of the SAME tensor, possibly overlapping — as ONE node:
+    the backward writes one gradient buffer (zero fill + scatter of the first list in one pass when it is ascending, the second
+    list's rows added on top) instead of two full-size buffers and the engine's add of the two.  The mask weights' two readers
+    (the visible anchors' rows for the expansion, gaussian_renderer/__init__.py:80, and the rate subset's rows,
+    scene/gaussian_model.py:1664-1669): fill [N,K] + index_copy_ + add [N,K,1] = 38 us -> one row-add of 15 % of the rows.
+    vals_a: the first list's rows gathered earlier in the forward (see gather_unique_attach), or None."""
+
+    @staticmethod
+    def forward(ctx, x, idx_a, vals_a, idx_b):
+        ctx.save_for_backward(idx_a, idx_b)
+        ctx.shape = x.shape
+        ctx.ascending = bool(getattr(idx_a, "_cgs_ascending", False))
+        ctx.set_materialize_grads(False)
+        xd = x.detach()
+        xa = vals_a.view_as(vals_a) if vals_a is not None else _index_rows(xd, idx_a)
+        return xa, _index_rows(xd.reshape(xd.shape[0], -1), idx_b)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        idx_a, idx_b = ctx.saved_tensors
+        if ga is None and gb is None:
+            return None, None, None, None
+        like = ga if ga is not None else gb
+        N = int(ctx.shape[0])
+        w = 1
+        for d in ctx.shape[1:]:
+            w *= int(d)
+        n = int(idx_a.shape[0])
+        if (ga is not None and ctx.ascending and ga.is_cuda and ga.dtype == torch.float32 and N > 0 and 8 * n >= N
+                and idx_a.dtype == torch.int64 and 1 <= w <= 256):
+            ga = ga.contiguous()
+            out = torch.empty(ctx.shape, dtype=ga.dtype, device=ga.device)
+            _lib.check(_lib.lib().cgs_scatter_rows_sorted(_lib.ptr(ga), _lib.ptr(idx_a), n, N, w, _lib.ptr(out),
+                                                         _lib.current_stream()), "cgs_scatter_rows_sorted")
+        else:
+            out = torch.zeros(ctx.shape, dtype=like.dtype, device=like.device)
+            if ga is not None:
+                out.index_copy_(0, idx_a, ga.contiguous())
+        if gb is not None:
+            out.view(N, w).index_add_(0, idx_b, gb.reshape(-1, w).contiguous())     # distinct rows: one add per element, no order to depend on
+        return out, None, None, None
+
+
+def gather_unique_pair_attach(x, idx_a, vals_a, idx_b):
+    """See _GatherUniquePair."""
+    return _GatherUniquePair.apply(x, idx_a, vals_a, idx_b)
+
+
 class _JoinRows(torch.autograd.Function):
     """The row slices `parts` (consecutive, covering `whole`) were written in place by the fused kernels:
     return `whole` as their concatenation without copying; the backward hands each part a view of the gradient."""
@@ -427,10 +476,15 @@ class _JoinRows(torch.autograd.Function):
     def forward(ctx, whole, *parts):
         ctx.sizes = [int(p.shape[0]) for p in parts]
         assert sum(ctx.sizes) == whole.shape[0]
+        ctx.set_materialize_grads(False)     # (a context level that summed its prefix gradient in place returns none: no zero tensor for it)
         return whole.view_as(whole)
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None,) * (1 + len(ctx.sizes))
+        g = g.contiguous()
+        _ctx.note_joined_grad(g)        # (a context level may add its prefix gradient into the rows in front of its own: ctx_ops._grad_prefix)
         return (None, *torch.split(g, ctx.sizes))
 
 
@@ -488,6 +542,7 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     likelihood_hyper [N-ordered], levels) where `levels` holds, per coded level, the slices the rate model
     needs (only when keep_stats)."""
     K = pc.n_offsets
+    _ctx._JOINED_GRADS.clear()
     if pc.level_scale is None:                                                         # :1559
         sel = anchor[mask_anchor_bool] if mask_anchor_bool is not None else anchor
         pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
@@ -754,8 +809,10 @@ def draw_choose_mask(anchor, mask_anchor_bool, return_sum_bits):
 
 
 def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper, levels, return_sum_bits,
-               choose_mask=None, live_count=None):
-    """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows."""
+               choose_mask=None, live_count=None, masks_chosen_given=None):
+    """:1657-1707 — bits of a random 15 % subset (all anchors for return_sum_bits), per level on the level's rows.
+    masks_chosen_given: binary_grid_masks.reshape(n, K)[levels[0]["chosen"][0]] gathered by the caller (one node with the
+    visible rows' gather, _GatherUniquePair), or None."""
     K = pc.n_offsets
     n = anchor.shape[0]
     dev = anchor.device
@@ -799,7 +856,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         # every level on the fused rate kernel, the subset listed level after level, the live fraction a host number:
         # the whole of :1658-1705 is ONE autograd node (a launch per level + one for the scalar tail, each way)
         chosen_all = levels[0]["chosen"][0]
-        masks_chosen = gather_unique(binary_grid_masks.reshape(n, K), chosen_all)
+        masks_chosen = (masks_chosen_given if masks_chosen_given is not None
+                        else gather_unique(binary_grid_masks.reshape(n, K), chosen_all))
         tensors, spans, sides, maps, level_rows = [], [], [], [], []
         n_feat = n_scaling = n_offsets = 0
         for L in levels:
@@ -813,7 +871,7 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
         dead = 0.0 if mask_anchor_bool is None else 1.0 - live_count / mask_anchor_bool.numel()
         meta = dict(use_clamp=_enc.use_clamp, K=K, spans=spans, sides=sides, maps=maps,
                     finish=(float(mask_anchor_rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead)))
-        out4, raw = _ctx.rate_all(hyper_sum, masks_chosen, x_means_fused, meta, tensors)
+        out4, raw = _ctx.rate_all(hyper_sum, masks_chosen, x_means_fused, meta, tensors)      # (out4: four 0-dim tensors)
         feat_dim = pc.feat_dim + 6 + 3 * K
         divisors = [1.0, float(max(1, n_hyper))] + [float(max(1, r) * feat_dim) for r in level_rows]
         each_level_bpp = LevelBppReport(raw, [L["n_level"] / n for L in levels], divisors)
@@ -838,7 +896,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
                 # the mask rows of ALL levels' chosen anchors in one gather (one scatter + one zero fill on the way
                 # back instead of an [N,K] gradient buffer and an accumulation per level)
                 if masks_chosen is None:
-                    masks_chosen = gather_unique(binary_grid_masks.reshape(n, K), L["chosen"][0])
+                    masks_chosen = (masks_chosen_given if masks_chosen_given is not None
+                                    else gather_unique(binary_grid_masks.reshape(n, K), L["chosen"][0]))
                 m_rows, g_rows = masks_chosen[L["chosen"][1]:L["chosen"][2]], None
             else:
                 m_rows, g_rows = binary_grid_masks.reshape(n, K), L["rows"]
@@ -1028,8 +1087,14 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     if not predict_bpp:
         return outs
     # (binary_grid_masks may be a callable: the caller creates the mask's autograd node after the level loop's nodes)
-    rate = lambda: tuple(rate_model(pc, anchor, binary_grid_masks() if callable(binary_grid_masks) else binary_grid_masks,
-                                    mask_anchor_bool, likelihood_hyper, levels, False, choose_mask, live_count=c.get("live_count")))
+    rate = lambda masks_chosen=None: tuple(rate_model(
+        pc, anchor, binary_grid_masks() if callable(binary_grid_masks) else binary_grid_masks, mask_anchor_bool, likelihood_hyper,
+        levels, False, choose_mask, live_count=c.get("live_count"), masks_chosen_given=masks_chosen))
+    # the rows whose mask weights the rate model will gather, when it is one list for all levels (the caller may gather them in
+    # the same node as its own rows of the mask: _GatherUniquePair)
+    rate.chosen_rows = (levels[0]["chosen"][0] if (levels and all(L.get("fused") and L.get("chosen") is not None
+                                                                     and L["chosen"][0] is levels[0]["chosen"][0] for L in levels))
+                        else None)
     if defer_rate:      # the caller enqueues the rate model where it fills a read-back bubble (renderer.py)
         return outs + (rate,)
     return outs + rate()

@@ -934,10 +934,12 @@ __global__ void __launch_bounds__(256)
             const float v = h ? acc1 : acc0;
             if (c >= W) continue;
             if (c < wa) {       // (acc_anchor: the rows also carry what an earlier launch left there — distinct rows within a launch)
-                if (d_anchor && e > b) { float *q = d_anchor + parent_row[p] * wa + c; *q = acc_anchor ? *q + v : v; }
+                if (d_anchor && e > b) { float *q = d_anchor + parent_row[p] * wa + c; *q = (acc_anchor & 1) ? *q + v : v; }
             }
-            else if (c < wa + DF) { if (d_f) d_f[p * DF + (c - wa)] = v; }
-            else if (d_s) d_s[p * DS + (c - wa - DF)] = v;
+            // (bits 1 / 2: d_f / d_s already hold the other gradient of the parents' rows — the level outputs' gradient buffer —
+            //  and receive the children's sums on top: no separate buffer, no add launch behind this one)
+            else if (c < wa + DF) { if (d_f) { float *q = d_f + p * DF + (c - wa); *q = (acc_anchor & 2) ? *q + v : v; } }
+            else if (d_s) { float *q = d_s + p * DS + (c - wa - DF); *q = (acc_anchor & 4) ? *q + v : v; }
         }
     }
 }
@@ -950,7 +952,8 @@ extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_pare
                                   float *d_s, int wa, int DF, int DS, void *stream) {
     return cgs_ctx_gather_bwd_acc(dout, ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, 0, stream);
 }
-// accumulate_anchor != 0: d_anchor rows are ADDED to (the levels of one backward share one anchor-gradient buffer)
+// accumulate_anchor: bit 0 = d_anchor rows are ADDED to (the levels of one backward share one anchor-gradient buffer);
+// bit 1 / bit 2 = d_f / d_s rows are added to (they are the first rows of the gradient buffer of the level outputs)
 extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
                                       const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
                                       float *d_s, int wa, int DF, int DS, int accumulate_anchor, void *stream) {
@@ -962,7 +965,7 @@ extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_
     if (!dout || !offs || !order || (d_anchor && !parent_row)) { cgs_set_error("ctx_gather_bwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(ctx_gather_bwd_kernel, dim3(stream_grid(n_parents, 4 * 8)), dim3(256), 0, (hipStream_t)stream, dout,
-                       ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, accumulate_anchor ? 1 : 0);
+                       ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, accumulate_anchor & 7);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
@@ -992,13 +995,16 @@ __global__ void rate_finish_fwd_kernel(const float *__restrict__ S, const float 
     raw[1] = sh;
 }
 
-__global__ void rate_finish_bwd_kernel(const float *__restrict__ g4, RateFinishArgs a, float *__restrict__ dS,
+__global__ void rate_finish_bwd_kernel(const float *__restrict__ ga, const float *__restrict__ gb, const float *__restrict__ gc,
+                                       const float *__restrict__ gd, RateFinishArgs a, float *__restrict__ dS,
                                        float *__restrict__ dh) {
+    // (one pointer per output: an output the loss does not read has no gradient tensor at all)
     const int i = threadIdx.x;
-    const float g0 = g4[0] * a.rate * a.inv_ntot;
+    const float g0 = (ga ? ga[0] : 0.f) * a.rate * a.inv_ntot;
     if (i < 3 * a.L) {
         const int k = i % 3;
-        dS[i] = g0 + g4[1 + k] * a.rate * (k == 0 ? a.inv_nf : (k == 1 ? a.inv_ns : a.inv_no));
+        const float *gp = k == 0 ? gb : (k == 1 ? gc : gd);
+        dS[i] = g0 + (gp ? gp[0] : 0.f) * a.rate * (k == 0 ? a.inv_nf : (k == 1 ? a.inv_ns : a.inv_no));
     }
     if (i == 0) dh[0] = g0;
 }
@@ -1014,13 +1020,21 @@ extern "C" int cgs_rate_finish_fwd(const float *S, int L, const float *hsum, flo
     return CGS_OK;
 }
 
-extern "C" int cgs_rate_finish_bwd(const float *g4, int L, float rate, double n_feat, double n_scaling, double n_offsets,
-                                   float *dS, float *dh, void *stream) {
-    if (L < 0 || L > 16 || !g4 || !dS || !dh) { cgs_set_error("rate_finish_bwd: bad args"); return CGS_ERR_ARG; }
+extern "C" int cgs_rate_finish_bwd4(const float *g_all, const float *g_feat, const float *g_scaling, const float *g_offsets, int L,
+                                    float rate, double n_feat, double n_scaling, double n_offsets, float *dS, float *dh,
+                                    void *stream) {
+    if (L < 0 || L > 16 || !dS || !dh) { cgs_set_error("rate_finish_bwd: bad args"); return CGS_ERR_ARG; }
     const double nt = n_feat + n_scaling + n_offsets;
     RateFinishArgs a{rate, (float)(1.0 / (n_feat > 1 ? n_feat : 1)), (float)(1.0 / (n_scaling > 1 ? n_scaling : 1)),
                      (float)(1.0 / (n_offsets > 1 ? n_offsets : 1)), (float)(1.0 / (nt > 1 ? nt : 1)), 0.f, L};
-    hipLaunchKernelGGL(rate_finish_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g4, a, dS, dh);
+    hipLaunchKernelGGL(rate_finish_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g_all, g_feat, g_scaling, g_offsets, a, dS,
+                       dh);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
+}
+
+extern "C" int cgs_rate_finish_bwd(const float *g4, int L, float rate, double n_feat, double n_scaling, double n_offsets,
+                                   float *dS, float *dh, void *stream) {
+    if (!g4) { cgs_set_error("rate_finish_bwd: bad args"); return CGS_ERR_ARG; }
+    return cgs_rate_finish_bwd4(g4, g4 + 1, g4 + 2, g4 + 3, L, rate, n_feat, n_scaling, n_offsets, dS, dh, stream);
 }

@@ -205,13 +205,59 @@ __global__ void __launch_bounds__(SORT_THREADS)
     hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
+// Exclusive scan of every digit's row of the [RADIX][nblocks] table in place (workgroup d owns digit d: nblocks entries, a few
+// per thread) + the digit's total.  The scatter kernel adds the digits' exclusive prefix itself (a 256-entry scan it already has
+// the code for): ONE launch between histogram and scatter instead of the generic scan's two (reduce + apply over the
+// 256 x nblocks table, ~17 us per pass at 5.8 M keys; four passes per depth sort).
+__global__ void __launch_bounds__(SORT_THREADS)
+    radix_digit_scan_kernel(uint32_t *__restrict__ hist /*[RADIX][nblocks]*/, uint32_t *__restrict__ totals /*[RADIX]*/,
+                            int64_t nblocks) {
+    __shared__ uint32_t wsum[SORT_WAVES];
+    __shared__ uint32_t carry_s;
+    uint32_t *row = hist + (int64_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += SORT_THREADS * 4) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < nblocks) ? row[i0 + k] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = carry_s;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) run += (w < wave) ? wsum[w] : 0u;
+        run += inc - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < nblocks) row[i0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == SORT_THREADS - 1) carry_s = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
 __global__ void __launch_bounds__(SORT_THREADS)
     radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                         const uint32_t *__restrict__ hist_scanned, int64_t n, int shift,
-                         uint32_t digit_mask) {
+                         const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ digit_totals,
+                         int64_t n, int shift, uint32_t digit_mask) {
     __shared__ uint32_t wcnt[SORT_WAVES][RADIX];   // running per-wave digit counts -> bases
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (thread d owns digit d further down: its two table entries are requested now, the ranking below hides the latency)
+    const uint32_t gtot = digit_totals[threadIdx.x];
+    const uint32_t hrow = hist_scanned[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -254,7 +300,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
     // 4-byte stores per instruction.
     __shared__ uint32_t lstart[RADIX];     // first LDS slot of the digit
     __shared__ uint32_t gbase[RADIX];      // first global position of this block's items of the digit
-    __shared__ uint32_t wsum[SORT_WAVES];
+    __shared__ uint32_t wsum[SORT_WAVES], gsum[SORT_WAVES];
     __shared__ uint32_t skey[SORT_TILE], sval[SORT_TILE];
     {
         const int d = threadIdx.x;
@@ -268,14 +314,22 @@ __global__ void __launch_bounds__(SORT_THREADS)
             const uint32_t up = __shfl_up(inc, o, 64);
             if (lane >= o) inc += up;
         }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
+        // ... and of the digits' global totals (hist_scanned rows are per-digit exclusive scans over the blocks:
+        // radix_digit_scan_kernel): first global position of digit d = sum of the totals of the digits below it
+        uint32_t ginc = gtot;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) woff += (w < wave) ? wsum[w] : 0u;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(ginc, o, 64);
+            if (lane >= o) ginc += up;
+        }
+        if (lane == 63) { wsum[wave] = inc; gsum[wave] = ginc; }
+        __syncthreads();
+        uint32_t woff = 0, goff = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) { woff += (w < wave) ? wsum[w] : 0u; goff += (w < wave) ? gsum[w] : 0u; }
         uint32_t run = woff + inc - tot;
         lstart[d] = run;
-        gbase[d] = hist_scanned[(int64_t)d * gridDim.x + blockIdx.x];
+        gbase[d] = goff + ginc - gtot + hrow;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) {
             const uint32_t c = wcnt[w][d];
@@ -313,7 +367,7 @@ static int64_t sort_blocks(int64_t n) { return (n + SORT_TILE - 1) / SORT_TILE; 
 extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
     int64_t nb = sort_blocks(n > 0 ? n : 1);
     size_t hist = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
-    return hist + cgs_scan_scratch_bytes((int64_t)RADIX * nb) + 256;
+    return hist + cgs_scan_scratch_bytes((int64_t)RADIX * nb) + 256 + RADIX * sizeof(uint32_t);
 }
 
 // (A one-sweep variant — global digit counts of all passes from one launch, per-(block, digit) status words chained by a
@@ -327,8 +381,7 @@ static int sort_classic(const uint32_t *keys_in, const uint32_t *vals_in, uint32
     const int64_t nb = sort_blocks(n);
     const size_t hist_bytes = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
     uint32_t *hist = (uint32_t *)scratch;
-    char *scan_scratch = (char *)scratch + hist_bytes;
-    const size_t scan_scratch_bytes = scratch_bytes - hist_bytes;
+    uint32_t *totals = (uint32_t *)((char *)scratch + hist_bytes);      // [RADIX] digit totals of the pass
 
     // Choose the ping-pong start so that the last pass lands in *_out.
     const uint32_t *src_k = keys_in, *src_v = vals_in;
@@ -341,10 +394,10 @@ static int sort_classic(const uint32_t *keys_in, const uint32_t *vals_in, uint32
         hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k, hist,
                            n, shift, mask);
         CGS_CHECK_HIP(hipGetLastError());
-        int rc = scan_rec(hist, hist, (int64_t)RADIX * nb, scan_scratch, scan_scratch_bytes, nullptr, stream);
-        if (rc) return rc;
+        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RADIX), dim3(SORT_THREADS), 0, stream, hist, totals, nb);
+        CGS_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k,
-                           src_v, dst_k, dst_v, (const uint32_t *)hist, n, shift, mask);
+                           src_v, dst_k, dst_v, (const uint32_t *)hist, (const uint32_t *)totals, n, shift, mask);
         CGS_CHECK_HIP(hipGetLastError());
         src_k = dst_k;
         src_v = dst_v;

@@ -452,10 +452,13 @@ class _RateAll(torch.autograd.Function):
         ctx.save_for_backward(masks, x_means, *lv)
         ctx.meta = meta
         ctx.mark_non_differentiable(raw)
-        return out, raw
+        # the four entries leave as four outputs: the training loss reads the first only (train.py:207), and selecting it from a [4]
+        # output cost a zero fill + a copy in the backward (SelectBackward0); an unread entry now simply has no gradient
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3], raw
 
     @staticmethod
-    def backward(ctx, g, _g_raw):
+    def backward(ctx, g0, g1, g2, g3, _g_raw):
         Lc = _lib.lib()
         masks, x_means = ctx.saved_tensors[:2]
         lv = ctx.saved_tensors[2:]
@@ -467,8 +470,9 @@ class _RateAll(torch.autograd.Function):
         stream = _lib.current_stream()
         dS = torch.empty(nl, 3, dtype=_f32, device=dev)
         dh = torch.empty(1, dtype=_f32, device=dev)
-        _lib.check(Lc.cgs_rate_finish_bwd(_lib.ptr(_c(g)), nl, float(rate), float(n_f), float(n_s), float(n_o),
-                                          _lib.ptr(dS), _lib.ptr(dh), stream), "cgs_rate_finish_bwd")
+        g0, g1, g2, g3 = (None if t is None else _c(t) for t in (g0, g1, g2, g3))
+        _lib.check(Lc.cgs_rate_finish_bwd4(_lib.ptr(g0), _lib.ptr(g1), _lib.ptr(g2), _lib.ptr(g3), nl, float(rate), float(n_f),
+                                           float(n_s), float(n_o), _lib.ptr(dS), _lib.ptr(dh), stream), "cgs_rate_finish_bwd")
         all_lazy = all(sd is not None and sd.X is not None for sd in meta["sides"])
         # (the level-rate kernels add into it; the fused rate-subset kernels write every row of their span)
         d_masks = (torch.empty_like if all_lazy else torch.zeros_like)(masks) if ctx.needs_input_grad[1] else None
@@ -529,8 +533,9 @@ class _RateAll(torch.autograd.Function):
 
 
 def rate_all(hsum, masks, x_means, meta, level_tensors):
-    """See _RateAll.  level_tensors: flat list (yf, ys, yo, Q, pred, loc) per level."""
-    return _RateAll.apply(hsum, masks, x_means, meta, *level_tensors)
+    """See _RateAll.  level_tensors: flat list (yf, ys, yo, Q, pred, loc) per level.  Returns ((four 0-dim tensors), raw)."""
+    o = _RateAll.apply(hsum, masks, x_means, meta, *level_tensors)
+    return o[:4], o[4]
 
 
 class _CtxAssemble(torch.autograd.Function):
@@ -748,6 +753,34 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
 
 # ---- one launch per level and direction for the every-row half of the level loop (csrc/ctx_level.hip) ---------------
 ANCHOR_SHARED = os.environ.get("CGS_ANCHOR_SHARED", "1") != "0"      # A/B knob: 0 = one zero-filled [N,3] anchor gradient per level (rounds 5)
+PREFIX_INPLACE = os.environ.get("CGS_PREFIX_INPLACE", "1") != "0"    # A/B knob: 0 = the coded prefix's gradient as its own tensors, summed by autograd
+
+
+_JOINED_GRADS = {}       # data pointer -> (rows, width) of the gradients _JoinRows' backward split this step (cleared per forward)
+
+
+def note_joined_grad(g):
+    """_JoinRows.backward: `g` [rows, w] is the gradient of level outputs lying side by side in coding order."""
+    if g is not None and g.dim() == 2 and g.dtype == _f32 and g.is_contiguous() and g.is_cuda:
+        _JOINED_GRADS[g.data_ptr()] = (int(g.shape[0]), int(g.shape[1]))
+
+
+def _grad_prefix(part, n_prefix):
+    """`part` = rows [n_prefix, n_prefix + n) of a gradient buffer _JoinRows' backward split (note_joined_grad) -> that buffer's
+    first n_prefix rows as a view, else None.
+
+    The coded prefix a context level reads IS the earlier levels' outputs, and their gradient from the joined tensor lies in
+    the same buffer right in front of this level's rows: the level's backward adds the parents' sums THERE
+    (cgs_ctx_gather_bwd_acc bits 1 / 2) and returns no gradient for the prefix.  Autograd still runs the earlier levels'
+    nodes after this one (the edges exist), they find the sums in their own slice.  Before: a [prefix, 50] + [prefix, 6]
+    tensor per context level and six add launches by the engine per step (profiles/r06_launch_attribution.txt)."""
+    if part is None or n_prefix <= 0 or part.dim() != 2 or part.dtype != _f32 or not part.is_contiguous() or part.requires_grad:
+        return None
+    w = int(part.shape[1])
+    rec = _JOINED_GRADS.get(part.data_ptr() - 4 * w * n_prefix)
+    if rec is None or rec[1] != w or rec[0] < n_prefix + int(part.shape[0]) or part.storage_offset() < w * n_prefix:
+        return None
+    return torch.as_strided(part, (n_prefix, w), (w, 1), part.storage_offset() - w * n_prefix)
 _LEVEL_DIMS = (50, 6, 30, 12, 100, 175)      # features, scaling, offsets, hyper, hidden, outputs of mlp_grid: the kernels' instance
 
 
@@ -904,12 +937,20 @@ class _LevelFused(torch.autograd.Function):
         d_f = d_s = None
         if f_shape is not None:                  # context level: the parents' rows, summed over their children without atomics
             offs, order, prow = cfg["csr"]
-            d_f = torch.empty(f_shape, dtype=_f32, device=dev) if need[1] else None
-            d_s = torch.empty(s_shape, dtype=_f32, device=dev) if need[2] else None
+            # the prefix rows' gradient buffers, when this level's own gradients are row slices right behind them (_grad_prefix)
+            in_f_ = _grad_prefix(gf, int(f_shape[0])) if (PREFIX_INPLACE and need[1] and f_shape[1] == 50) else None
+            in_s_ = _grad_prefix(gs, int(s_shape[0])) if (PREFIX_INPLACE and need[2] and s_shape[1] == 6) else None
+            d_f = in_f_ if in_f_ is not None else (torch.empty(f_shape, dtype=_f32, device=dev) if need[1] else None)
+            d_s = in_s_ if in_s_ is not None else (torch.empty(s_shape, dtype=_f32, device=dev) if need[2] else None)
             if d_anchor is not None or d_f is not None or d_s is not None:
+                acc = int(shared) | (2 if in_f_ is not None else 0) | (4 if in_s_ is not None else 0)
                 _lib.check(L.cgs_ctx_gather_bwd_acc(_lib.ptr(dX), in_f, int(f_shape[0]), _lib.ptr(offs), _lib.ptr(order), _lib.ptr(prow),
-                                                    _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s), 3, 50, 6, int(shared), stream),
+                                                    _lib.ptr(d_anchor), _lib.ptr(d_f), _lib.ptr(d_s), 3, 50, 6, acc, stream),
                            "cgs_ctx_gather_bwd")
+            if in_f_ is not None:
+                d_f = None                  # (already summed into the earlier levels' slices)
+            if in_s_ is not None:
+                d_s = None
             d_hyp = dX[:, 59:] if need[3] else None          # a column slice: its consumer takes strided rows
         else:                                    # first level: X = [anchor[a_rows] * mask | hyper]
             d_hyp = dX[:, 3:] if need[3] else None

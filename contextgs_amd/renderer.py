@@ -188,6 +188,7 @@ class _ExpandGaussians(torch.autograd.Function):
         return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None, None
 
 
+MASK_PAIR_NODE = os.environ.get("CGS_MASK_PAIR_NODE", "1") != "0"    # A/B knob: 0 = the mask weights' two row gathers as two nodes (round 5)
 FUSE_VIEW = os.environ.get("CGS_FUSE_VIEW", "1") != "0"    # tuning / A-B knob: expansion fused with the rasterizer's preprocess
 
 
@@ -482,8 +483,15 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         if is_training:
             rate_thunk = res[3]         # the rate model (:1657-1707) is enqueued behind the expansion's count (see below)
         if late_mask is not None:       # the level loop's nodes exist: now the mask's
-            from .context_model import gather_unique_attach
-            binary_grid_masks = gather_unique_attach(binary_all(), vis_idx, late_mask["vis_vals"])
+            from .context_model import gather_unique_attach, gather_unique_pair_attach
+            chosen = getattr(rate_thunk, "chosen_rows", None) if rate_thunk is not None else None
+            if chosen is not None and MASK_PAIR_NODE and chosen.is_cuda:
+                # the visible rows (for the expansion) and the rate subset's rows of the mask weights through ONE node: one
+                # gradient buffer instead of two and the engine's add (context_model._GatherUniquePair)
+                binary_grid_masks, m_chosen = gather_unique_pair_attach(binary_all(), vis_idx, late_mask["vis_vals"], chosen)
+                rate_thunk = (lambda f, m: (lambda: f(m)))(rate_thunk, m_chosen)
+            else:
+                binary_grid_masks = gather_unique_attach(binary_all(), vis_idx, late_mask["vis_vals"])
 
     K = pc.n_offsets
     rate_out = []

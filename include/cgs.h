@@ -394,7 +394,8 @@ int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_parents,
                        const int64_t *offs, const int64_t *order,
                        const int64_t *parent_row, float *d_anchor, float *d_f,
                        float *d_s, int wa, int DF, int DS, void *stream);
-/* the same; accumulate_anchor != 0: the d_anchor rows are added to (one anchor-gradient buffer shared by the levels of a backward) */
+/* the same; accumulate_anchor is a bit set: bit 0 = the d_anchor rows are added to (one anchor-gradient buffer shared by the
+ * levels of a backward), bit 1 / bit 2 = the d_f / d_s rows are added to (they already hold the parents' other gradient) */
 int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents,
                        const int64_t *offs, const int64_t *order,
                        const int64_t *parent_row, float *d_anchor, float *d_f,
@@ -450,6 +451,11 @@ int cgs_rate_finish_fwd(const float *S, int L, const float *hsum, float rate, do
                         float *raw, void *stream);
 int cgs_rate_finish_bwd(const float *g4, int L, float rate, double n_feat, double n_scaling,
                         double n_offsets, float *dS, float *dh, void *stream);
+/* the same with one (nullable) one-element gradient per entry of out4: an entry the loss does not read (train.py:207 reads
+ * bit_per_param only) has no gradient tensor, and no zero-filled [4] buffer has to be built for the others */
+int cgs_rate_finish_bwd4(const float *g_all, const float *g_feat, const float *g_scaling,
+                         const float *g_offsets, int L, float rate, double n_feat, double n_scaling,
+                         double n_offsets, float *dS, float *dh, void *stream);
 /* Per-step bookkeeping of the training context model (csrc/ctx_plan.hip; scene/gaussian_model.py:1658-1661
  * `choose_mask`, restricted per level).  choose_flags: for coding-order position r (anchor a = perm[r], or r
  * when perm is NULL) flag[r] = (u(seed, a) <= thresh, or given[a] when given != NULL) && mask[a]; writes
