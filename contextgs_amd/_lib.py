@@ -57,6 +57,10 @@ SIGNATURES = {
     "cgs_raster_preprocess_launch": (c_int, [C.POINTER(RasterCfg), c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, C.POINTER(C.c_uint64)]),
     "cgs_raster_preprocess_wait": (c_int, [C.c_uint64, C.POINTER(c_int64)]),
+    "cgs_raster_preprocess_wait2": (c_int, [C.c_uint64, C.POINTER(c_int64), C.POINTER(c_int)]),
+    "cgs_debug_set_depth_keys_full": (c_int, [c_int]),
+    "cgs_sort_depth_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p,
+                                    C.c_uint32, c_void_p]),
     "cgs_raster_render_spec": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,
                                        c_void_p, c_size_t, c_void_p, c_void_p]),
     "cgs_raster_render": (c_int, [C.POINTER(RasterCfg), c_int64, c_int64, c_void_p, c_size_t, c_void_p, c_size_t,

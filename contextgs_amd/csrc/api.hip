@@ -44,7 +44,7 @@ size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P) {
     g->sort_b = c.take<uint32_t>(n);
     g->sort_c = c.take<uint32_t>(n);
     g->sort_d = c.take<uint32_t>(n);
-    g->total = c.take<uint32_t>(2);
+    g->total = c.take<uint32_t>(4);        // pair count | bucket-pair count | depth-range report of the depth sort | -
     size_t sb = cgs_sort_scratch_bytes((int64_t)n);
     size_t sc = cgs_scan_scratch_bytes((int64_t)n);
     g->scratch_bytes = sb > sc ? sb : sc;
@@ -151,8 +151,19 @@ extern "C" int cgs_filter_voxel(const cgs_raster_cfg *cfg, int64_t N, const floa
 // cgs_raster_preprocess_launch enqueues projection, the depth sort and the pair-offset scan, and the 4-byte copy of the
 // pair count behind them; cgs_raster_preprocess_wait blocks on THAT copy's event only.  What the caller enqueues in between
 // (cgs_raster_render_spec) keeps the device busy while the host learns the count.  cgs_raster_preprocess = both.
-struct RasterCountSlot { uint32_t *pinned; hipEvent_t ev; bool pending; uint64_t ticket; };
-static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false, 0};
+struct RasterCountSlot {
+    uint32_t *pinned; hipEvent_t ev; bool pending; uint64_t ticket;
+    // what a second depth sort of the launch needs (see raster_count_tail): valid from _launch to _wait
+    int64_t P; void *geom_ws; size_t geom_bytes; hipStream_t stream; uint32_t epoch; bool ranged; bool spec_between; bool resorted;
+};
+static thread_local RasterCountSlot g_raster_slot = {nullptr, nullptr, false, 0, 0, nullptr, 0, nullptr, 0, false, false, false};
+// Depth keys of a view sort on 27 bits (three passes) while every live depth stays below ~13107 (cgs_sort_depth_keys); the first
+// view that reports a depth beyond that is sorted again on the full 32 bits (four passes) and so is every later view of the thread.
+static thread_local bool g_depth_keys_full = false;
+extern "C" int cgs_sort_depth_keys(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_out, uint32_t *keys_tmp,
+                                   uint32_t *vals_tmp, int64_t n, void *scratch, size_t scratch_bytes, uint32_t *overflow,
+                                   uint32_t epoch, void *stream);
+extern "C" int cgs_debug_set_depth_keys_full(int on) { const int was = g_depth_keys_full; g_depth_keys_full = on != 0; return was; }
 
 // Tickets of the *_launch / *_wait pairs: a slot holds ONE count per kind and host thread, so a second launch of the same kind
 // overwrites what an earlier launch's wait would have read.  Every launch hands out a ticket (kind in the top byte, a
@@ -162,7 +173,7 @@ uint64_t cgs_new_ticket(int kind) {
     static thread_local uint64_t serial = 0;
     return ((uint64_t)kind << 56) | (++serial & 0x00FFFFFFFFFFFFFFull);
 }
-static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream);
+static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream, bool full_keys = false);
 
 extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P, const float *means3D,
                                             const float *colors, const float *opacities, const float *scales,
@@ -181,6 +192,7 @@ extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    sl.ranged = sl.spec_between = sl.resorted = false;
     *ticket = sl.ticket = cgs_new_ticket(1);
     if (P == 0) return CGS_OK;
     if (!means3D || !colors || !opacities || !scales || !rotations || !radii || !geom_ws) {
@@ -195,19 +207,29 @@ extern "C" int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P
     if ((rc = cgs_launch_preprocess(cfg, P, means3D, colors, opacities, scales, rotations, g, radii, false,
                                     stream)))
         return rc;
+    sl.P = P; sl.geom_ws = geom_ws; sl.geom_bytes = geom_bytes; sl.stream = stream;
     return raster_count_tail(P, g, sl, stream);
 }
 
 // depth sort, tile rectangles in depth order, pair-offset scan and the copy of the pair count behind a preprocess launch
-static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream) {
+static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStream_t stream, bool full_keys) {
     int rc;
     // depth order (stable: ties keep ascending Gaussian id)
     {
         CgsProfScope prof(CGS_PROF_DEPTH_SORT, stream);
         // (values = positions: the sort's first pass generates them, no iota launch)
-        if ((rc = cgs_sort_pairs_u32(g.depth_key, nullptr, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32,
-                                     g.scratch, g.scratch_bytes, stream)))
-            return rc;
+        sl.ranged = !(full_keys || g_depth_keys_full);
+        if (sl.ranged) {
+            // 27-bit keys, three passes; a live depth beyond the range writes this launch's epoch to g.total[2], which travels
+            // to the host with the pair count: cgs_raster_preprocess_wait then sorts again on 32 bits
+            sl.epoch = (uint32_t)(sl.ticket & 0x7FFFFFFFu) + 1u;
+            rc = cgs_sort_depth_keys(g.depth_key, g.sort_a, g.order, g.sort_b, g.sort_d, P, g.scratch, g.scratch_bytes,
+                                     g.total + 2, sl.epoch, stream);
+        } else {
+            rc = cgs_sort_pairs_u32(g.depth_key, nullptr, g.sort_a, g.order, g.sort_b, g.sort_d, P, 0, 32, g.scratch,
+                                    g.scratch_bytes, stream);
+        }
+        if (rc) return rc;
     }
     {
         CgsProfScope prof(CGS_PROF_OFFSETS_SCAN, stream);
@@ -217,7 +239,7 @@ static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStre
                                                stream)))
             return rc;
     }
-    CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, g.total, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
     sl.pending = true;
     return CGS_OK;
@@ -250,6 +272,7 @@ extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, in
     }
     sl.pending = false;
     sl.pinned[0] = 0;
+    sl.ranged = sl.spec_between = sl.resorted = false;
     *ticket = sl.ticket = cgs_new_ticket(1);
     if (P == 0) return CGS_OK;
     if (!flags || !pos || !anchor || !gscaling || !offsets || !neural_opacity || !color_in || !cov_in || !scaling_out || !radii ||
@@ -265,11 +288,13 @@ extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, in
     const CgsExpandSrc x{n_anchor, K, flags, pos, anchor, gscaling, offsets, neural_opacity, color_in, cov_in, src_row};
     if ((xyz_out == nullptr) != (rot_out == nullptr)) { cgs_set_error("cgs_raster_preprocess_expand: xyz_out and rot_out go together"); return CGS_ERR_ARG; }
     if ((rc = cgs_launch_expand_preprocess(cfg, x, scaling_out, xyz_out, rot_out, g, radii, stream))) return rc;
+    sl.P = P; sl.geom_ws = geom_ws; sl.geom_bytes = geom_bytes; sl.stream = stream;
     return raster_count_tail(P, g, sl, stream);
 }
 
-extern "C" int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered_host) {
+extern "C" int cgs_raster_preprocess_wait2(uint64_t ticket, int64_t *num_rendered_host, int *order_changed) {
     RasterCountSlot &sl = g_raster_slot;
+    if (order_changed) *order_changed = 0;
     if (!num_rendered_host) { cgs_set_error("num_rendered_host is NULL"); return CGS_ERR_ARG; }
     *num_rendered_host = 0;
     if (!sl.pinned) { cgs_set_error("cgs_raster_preprocess_wait: no launch on this thread"); return CGS_ERR_ARG; }
@@ -280,8 +305,33 @@ extern "C" int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered
     if (sl.pending) {
         CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
         sl.pending = false;
+        if (sl.ranged && sl.pinned[2] == sl.epoch) {
+            // a live depth beyond the 27-bit key range (~13107): the order in the workspace is not the depth order.  Sort this
+            // view again on the full 32 bits — the depth keys are intact — and keep to that for the thread's later views.
+            g_depth_keys_full = true;
+            CgsGeom g;
+            if (!cgs_geom_carve(&g, sl.geom_ws, sl.geom_bytes, sl.P)) { cgs_set_error("geometry workspace too small"); return CGS_ERR_WORKSPACE; }
+            int rc = raster_count_tail(sl.P, g, sl, sl.stream, true);
+            if (rc) return rc;
+            CGS_CHECK_HIP(hipEventSynchronize(sl.ev));
+            sl.pending = false;
+            sl.resorted = true;
+        }
     }
+    if (sl.resorted && order_changed) *order_changed = 1;
     *num_rendered_host = (int64_t)sl.pinned[0];
+    return CGS_OK;
+}
+
+extern "C" int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered_host) {
+    int changed = 0;
+    int rc = cgs_raster_preprocess_wait2(ticket, num_rendered_host, &changed);
+    if (rc) return rc;
+    if (changed && g_raster_slot.spec_between) {
+        cgs_set_error("cgs_raster_preprocess_wait: the view was sorted again on 32-bit depth keys after cgs_raster_render_spec ran on the "
+                      "first order; call cgs_raster_render with the returned count (or use cgs_raster_preprocess_wait2)");
+        return CGS_ERR_RESPEC;
+    }
     return CGS_OK;
 }
 
@@ -384,6 +434,7 @@ extern "C" int cgs_raster_render(const cgs_raster_cfg *cfg, int64_t P, int64_t R
 extern "C" int cgs_raster_render_spec(const cgs_raster_cfg *cfg, int64_t P, int64_t R_cap, void *geom_ws,
                                       size_t geom_bytes, void *bin_ws, size_t bin_bytes, void *img_ws,
                                       size_t img_bytes, float *out_color, void *stream_) {
+    g_raster_slot.spec_between = true;
     return raster_render_impl(cfg, P, R_cap, true, geom_ws, geom_bytes, bin_ws, bin_bytes, img_ws, img_bytes, out_color,
                               (hipStream_t)stream_);
 }

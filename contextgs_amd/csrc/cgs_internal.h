@@ -174,6 +174,22 @@ struct CgsExpandSrc {
 int cgs_launch_expand_preprocess(const cgs_raster_cfg *cfg, const CgsExpandSrc &x, float *scaling_out, float *xyz_out,
                                  float *rot_out, CgsGeom &g, int32_t *radii, hipStream_t stream);
 
+// XCD-aware work assignment for kernels whose NEIGHBOURING work items write adjacent memory (radix passes: a tile's run for a
+// digit starts where its predecessor's ends).  Workgroups are dealt to the eight XCDs round robin (workgroup i -> XCD i % 8,
+// each with its own L2): item = workgroup id puts neighbours on different XCDs, every short run then leaves its L2 as a partial
+// line of its own.  Here XCD x takes the x-th eighth of the items, so neighbours meet in one L2.  Launch cgs_xcd_grid(n)
+// workgroups; cgs_xcd_item(n) is the workgroup's item or -1 for a padding workgroup.
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t cgs_xcd_item(int64_t n_items) {
+    const int64_t chunk = (n_items + 7) / 8;
+    const int64_t t = (int64_t)(blockIdx.x & 7u) * chunk + (int64_t)(blockIdx.x >> 3);
+    return ((int64_t)(blockIdx.x >> 3) < chunk && t < n_items) ? t : -1;
+}
+#endif
+static inline unsigned cgs_xcd_grid(int64_t n_items) { return (unsigned)(8 * ((n_items + 7) / 8)); }
+// prims.hip: per-digit exclusive scans over the columns of a [digits][ncols] table in place + the digits' totals (one launch)
+int cgs_launch_digit_scan(uint32_t *hist, uint32_t *totals, int digits, int64_t ncols, hipStream_t stream);
+
 static inline int cgs_tiles_x(const cgs_raster_cfg *c) { return (c->image_width + CGS_TILE - 1) / CGS_TILE; }
 static inline int cgs_tiles_y(const cgs_raster_cfg *c) { return (c->image_height + CGS_TILE - 1) / CGS_TILE; }
 

@@ -188,29 +188,74 @@ extern "C" int cgs_scan_exclusive_u32(const uint32_t *in, uint32_t *out, int64_t
 // [b*SORT_TILE, (b+1)*SORT_TILE); inside it wave w owns a contiguous quarter
 // and walks it in rounds of 64 so that (wave, round, lane) is ascending input
 // order — that is what makes the per-digit ranks stable.
+//
+// BITS = digit width (8: 256 digits, one per thread; 9: 512 digits, two consecutive ones per thread).  XF: the keys read
+// from keys_in are DEPTH keys (float bits of a view depth > 0.2, or 0xFFFFFFFF for a culled Gaussian) and are sorted as
+// cgs_depth_key27(): 27 bits = three 9-bit passes instead of four 8-bit ones (see cgs_sort_depth_keys).
 
+// float bits of the near plane (raster_math.h: t.z <= 0.2f is culled): every live depth key lies above it
+#define CGS_DEPTH_KEY_BASE 0x3E4CCCCDu
+#define CGS_DEPTH_KEY_MAX 0x07FFFFFFu        // 2^27 - 1: culled Gaussians (their position in the order is never read: 0 tiles)
+
+// Order-preserving on (0.2, ~13107): bits(z) - bits(0.2).  A live key outside that range saturates and reports itself
+// (*overflow = epoch): the caller sorts that view again on the full 32 bits.
+__device__ __forceinline__ uint32_t cgs_depth_key27(uint32_t k, uint32_t *overflow, uint32_t epoch) {
+    if (k == 0xFFFFFFFFu) return CGS_DEPTH_KEY_MAX;
+    const uint32_t d = k - CGS_DEPTH_KEY_BASE;          // (k below the base wraps to a huge value: reported like a far one)
+    if (d >= CGS_DEPTH_KEY_MAX) {
+        *overflow = epoch;                              // (same value from every reporting lane: a benign race)
+        return CGS_DEPTH_KEY_MAX;
+    }
+    return d;
+}
+
+// Hardware workgroup -> tile: cgs_xcd_item() (cgs_internal.h).  The runs two NEIGHBOURING tiles write for a digit are adjacent in
+// the output (a tile's run starts where its predecessor's ends); with tile = workgroup id neighbours always sit on different
+// XCDs (workgroups go to the eight XCDs round robin) and every run is a partial-line write of its own, with the XCD-aware
+// assignment they share an L2 that merges them: three 9-bit passes 192 -> 172 us, four 8-bit passes 214 -> 208 us at 5.8 M keys
+// (tools/sort_micro.py, profiles/r06_depth_sort.txt).  SORT_XCD_MAP 0: tile = workgroup id.
+#ifndef SORT_XCD_MAP
+#define SORT_XCD_MAP 1
+#endif
+__device__ __forceinline__ int64_t sort_tile_of_block(int64_t nb) {
+#if SORT_XCD_MAP
+    return cgs_xcd_item(nb);
+#else
+    return (int64_t)blockIdx.x < nb ? (int64_t)blockIdx.x : -1;
+#endif
+}
+static unsigned sort_grid(int64_t nb) { return cgs_xcd_grid(nb); }
+
+template <int BITS, bool XF>
 __global__ void __launch_bounds__(SORT_THREADS)
-    radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist /*[RADIX][nblocks]*/,
-                      int64_t n, int shift, uint32_t digit_mask) {
-    __shared__ uint32_t h[RADIX];
-    h[threadIdx.x] = 0;
+    radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist /*[1 << BITS][nblocks]*/,
+                      int64_t n, int64_t nb, int shift, uint32_t digit_mask, uint32_t *overflow, uint32_t epoch) {
+    constexpr int NR = 1 << BITS;
+    __shared__ uint32_t h[NR];
+    const int64_t tile = sort_tile_of_block(nb);
+    if (tile < 0) return;
+    for (int d = threadIdx.x; d < NR; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t base = tile * SORT_TILE;
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
         int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & digit_mask], 1u);
+        if (idx < n) {
+            uint32_t k = keys[idx];
+            if (XF) k = cgs_depth_key27(k, overflow, epoch);
+            atomicAdd(&h[(k >> shift) & digit_mask], 1u);
+        }
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < NR; d += SORT_THREADS) hist[(int64_t)d * nb + tile] = h[d];
 }
 
-// Exclusive scan of every digit's row of the [RADIX][nblocks] table in place (workgroup d owns digit d: nblocks entries, a few
-// per thread) + the digit's total.  The scatter kernel adds the digits' exclusive prefix itself (a 256-entry scan it already has
-// the code for): ONE launch between histogram and scatter instead of the generic scan's two (reduce + apply over the
-// 256 x nblocks table, ~17 us per pass at 5.8 M keys; four passes per depth sort).
+// Exclusive scan of every digit's row of the [digits][nblocks] table in place (workgroup d owns digit d: nblocks entries, a few
+// per thread) + the digit's total.  The scatter kernel adds the digits' exclusive prefix itself (a scan over the digits it
+// already has the code for): ONE launch between histogram and scatter instead of the generic scan's two (reduce + apply over
+// the 256 x nblocks table, ~17 us per pass at 5.8 M keys).
 __global__ void __launch_bounds__(SORT_THREADS)
-    radix_digit_scan_kernel(uint32_t *__restrict__ hist /*[RADIX][nblocks]*/, uint32_t *__restrict__ totals /*[RADIX]*/,
+    radix_digit_scan_kernel(uint32_t *__restrict__ hist /*[gridDim.x][nblocks]*/, uint32_t *__restrict__ totals /*[gridDim.x]*/,
                             int64_t nblocks) {
     __shared__ uint32_t wsum[SORT_WAVES];
     __shared__ uint32_t carry_s;
@@ -248,34 +293,49 @@ __global__ void __launch_bounds__(SORT_THREADS)
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
+template <int BITS, bool XF>
 __global__ void __launch_bounds__(SORT_THREADS)
     radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                          uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                          const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ digit_totals,
-                         int64_t n, int shift, uint32_t digit_mask) {
-    __shared__ uint32_t wcnt[SORT_WAVES][RADIX];   // running per-wave digit counts -> bases
+                         int64_t n, int64_t nb, int shift, uint32_t digit_mask) {
+    constexpr int NR = 1 << BITS;
+    constexpr int DPT = NR / SORT_THREADS;         // digits per thread: thread t owns digits t * DPT .. t * DPT + DPT - 1
+    const int64_t tile = sort_tile_of_block(nb);
+    if (tile < 0) return;
+    // (16-bit counters and one global-minus-local base per digit: 38 KB of LDS per workgroup at 512 digits = four workgroups
+    //  per CU; with 32-bit counters and separate bases it was 44 KB = three, and the pass 40 % slower than the 256-digit one)
+    __shared__ uint16_t wcnt[SORT_WAVES][NR];      // running per-wave digit counts -> bases (a tile has 4096 items)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (thread d owns digit d further down: its two table entries are requested now, the ranking below hides the latency)
-    const uint32_t gtot = digit_totals[threadIdx.x];
-    const uint32_t hrow = hist_scanned[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
+    // (the table entries of the thread's digits are requested now, the ranking below hides the latency)
+    uint32_t gtot[DPT], hrow[DPT];
 #pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) wcnt[w][threadIdx.x] = 0;
+    for (int j = 0; j < DPT; ++j) {
+        const int d = threadIdx.x * DPT + j;
+        gtot[j] = digit_totals[d];
+        hrow[j] = hist_scanned[(int64_t)d * nb + tile];
+    }
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w)
+        for (int d = threadIdx.x; d < NR; d += SORT_THREADS) wcnt[w][d] = 0;
     __syncthreads();
 
-    const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (SORT_TILE / SORT_WAVES);
+    const int64_t wbase = tile * SORT_TILE + (int64_t)wave * (SORT_TILE / SORT_WAVES);
     uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
-    volatile uint32_t *my = wcnt[wave];
+    volatile uint16_t *my = wcnt[wave];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t dummy_overflow;
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int64_t idx = wbase + (int64_t)r * 64 + lane;
         const bool valid = idx < n;
         key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        if (XF) key[r] = cgs_depth_key27(key[r], &dummy_overflow, 0u);      // (the histogram kernel of this pass reported overflows)
         val[r] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;   // vals_in == nullptr: values = positions
         const uint32_t d = (key[r] >> shift) & digit_mask;
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -285,7 +345,7 @@ __global__ void __launch_bounds__(SORT_THREADS)
             const int leader = __builtin_ctzll(peers);
             if (lane == leader) {
                 old = my[d];
-                my[d] = old + (uint32_t)__builtin_popcountll(peers);
+                my[d] = (uint16_t)(old + (uint32_t)__builtin_popcountll(peers));
             }
             old = __shfl(old, leader, 64);
             rank[r] = old + (uint32_t)__builtin_popcountll(peers & lt_mask);
@@ -294,47 +354,49 @@ __global__ void __launch_bounds__(SORT_THREADS)
         }
     }
     __syncthreads();
-    // Thread t owns digit t.  Items are first placed in LDS in (digit, wave, round, lane) order — the order they
-    // must have in the output — and then streamed out: consecutive LDS slots of one digit go to consecutive global
-    // addresses, so a wave writes a few contiguous runs (avg. SORT_TILE / RADIX items each) instead of 64 isolated
+    // Thread t owns DPT consecutive digits.  Items are first placed in LDS in (digit, wave, round, lane) order — the order
+    // they must have in the output — and then streamed out: consecutive LDS slots of one digit go to consecutive global
+    // addresses, so a wave writes a few contiguous runs (avg. SORT_TILE / digits items each) instead of 64 isolated
     // 4-byte stores per instruction.
-    __shared__ uint32_t lstart[RADIX];     // first LDS slot of the digit
-    __shared__ uint32_t gbase[RADIX];      // first global position of this block's items of the digit
+    __shared__ uint32_t gdelta[NR];        // (first global position of this block's items of the digit) - (its first LDS slot)
     __shared__ uint32_t wsum[SORT_WAVES], gsum[SORT_WAVES];
     __shared__ uint32_t skey[SORT_TILE], sval[SORT_TILE];
     {
-        const int d = threadIdx.x;
-        uint32_t tot = 0;
+        uint32_t tot[DPT], mine = 0, gmine = 0;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) tot += wcnt[w][d];
-        // exclusive scan of tot over the 256 digits: inclusive wave scan + wave offsets
-        uint32_t inc = tot;
+        for (int j = 0; j < DPT; ++j) {
+            tot[j] = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += up;
+            for (int w = 0; w < SORT_WAVES; ++w) tot[j] += wcnt[w][threadIdx.x * DPT + j];
+            mine += tot[j];
+            gmine += gtot[j];
         }
-        // ... and of the digits' global totals (hist_scanned rows are per-digit exclusive scans over the blocks:
-        // radix_digit_scan_kernel): first global position of digit d = sum of the totals of the digits below it
-        uint32_t ginc = gtot;
+        // exclusive scans over the digits of (this block's counts, the global digit totals): inclusive wave scan + wave offsets
+        // (hist_scanned rows are per-digit exclusive scans over the blocks — radix_digit_scan_kernel — so the first global
+        //  position of digit d = sum of the totals of the digits below it + this block's entry of d's row)
+        uint32_t inc = mine, ginc = gmine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(ginc, o, 64);
-            if (lane >= o) ginc += up;
+            const uint32_t up = __shfl_up(inc, o, 64), gup = __shfl_up(ginc, o, 64);
+            if (lane >= o) { inc += up; ginc += gup; }
         }
         if (lane == 63) { wsum[wave] = inc; gsum[wave] = ginc; }
         __syncthreads();
         uint32_t woff = 0, goff = 0;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; ++w) { woff += (w < wave) ? wsum[w] : 0u; goff += (w < wave) ? gsum[w] : 0u; }
-        uint32_t run = woff + inc - tot;
-        lstart[d] = run;
-        gbase[d] = goff + ginc - gtot + hrow;
+        uint32_t run = woff + inc - mine, grun = goff + ginc - gmine;
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; ++w) {
-            const uint32_t c = wcnt[w][d];
-            wcnt[w][d] = run;              // LDS slot of wave w's first item with digit d
-            run += c;
+        for (int j = 0; j < DPT; ++j) {
+            const int d = threadIdx.x * DPT + j;
+            gdelta[d] = grun + hrow[j] - run;
+            grun += gtot[j];
+#pragma unroll
+            for (int w = 0; w < SORT_WAVES; ++w) {
+                const uint32_t c = wcnt[w][d];
+                wcnt[w][d] = (uint16_t)run;    // LDS slot of wave w's first item with digit d
+                run += c;
+            }
         }
     }
     __syncthreads();
@@ -343,18 +405,18 @@ __global__ void __launch_bounds__(SORT_THREADS)
         const int64_t idx = wbase + (int64_t)r * 64 + lane;
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & digit_mask;
-            const uint32_t slot = wcnt[wave][d] + rank[r];
+            const uint32_t slot = (uint32_t)wcnt[wave][d] + rank[r];
             skey[slot] = key[r];
             sval[slot] = val[r];
         }
     }
     __syncthreads();
-    const int64_t tile_base = (int64_t)blockIdx.x * SORT_TILE;
+    const int64_t tile_base = tile * SORT_TILE;
     const int count = (int)((n - tile_base) < (int64_t)SORT_TILE ? (n - tile_base) : (int64_t)SORT_TILE);
     for (int j = threadIdx.x; j < count; j += SORT_THREADS) {
         const uint32_t k = skey[j];
         const uint32_t d = (k >> shift) & digit_mask;
-        const uint32_t pos = gbase[d] + ((uint32_t)j - lstart[d]);
+        const uint32_t pos = gdelta[d] + (uint32_t)j;
         keys_out[pos] = k;
         vals_out[pos] = sval[j];
     }
@@ -363,11 +425,12 @@ __global__ void __launch_bounds__(SORT_THREADS)
 int cgs_launch_iota(int64_t n, uint32_t *out, hipStream_t stream);      // raster_geom.hip
 
 static int64_t sort_blocks(int64_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+#define SORT_MAX_RADIX 512
 
 extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
     int64_t nb = sort_blocks(n > 0 ? n : 1);
-    size_t hist = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
-    return hist + cgs_scan_scratch_bytes((int64_t)RADIX * nb) + 256 + RADIX * sizeof(uint32_t);
+    size_t hist = cgs_align_up((size_t)SORT_MAX_RADIX * nb * sizeof(uint32_t), 256);
+    return hist + 256 + SORT_MAX_RADIX * sizeof(uint32_t);
 }
 
 // (A one-sweep variant — global digit counts of all passes from one launch, per-(block, digit) status words chained by a
@@ -375,30 +438,53 @@ extern "C" size_t cgs_sort_scratch_bytes(int64_t n) {
 //  against 262 us for this three-kernel pass structure at 5.8 M keys.  ~1000 co-resident blocks publish their counts at
 //  the same moment and every thread then walks hundreds of predecessors' words one L2 round trip at a time;
 //  profiles/r04_onesweep_sort.txt.)
+// (the tile binning's passes use the same one-launch column scan: tile_bin.hip)
+int cgs_launch_digit_scan(uint32_t *hist, uint32_t *totals, int digits, int64_t ncols, hipStream_t stream) {
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3((unsigned)digits), dim3(SORT_THREADS), 0, stream, hist, totals, ncols);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+template <int BITS, bool XF>
+static int sort_pass(const uint32_t *src_k, const uint32_t *src_v, uint32_t *dst_k, uint32_t *dst_v, uint32_t *hist,
+                     uint32_t *totals, int64_t n, int64_t nb, int shift, uint32_t mask, uint32_t *overflow, uint32_t epoch,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL((radix_hist_kernel<BITS, XF>), dim3(sort_grid(nb)), dim3(SORT_THREADS), 0, stream, src_k, hist, n, nb, shift,
+                       mask, overflow, epoch);
+    CGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(1u << BITS), dim3(SORT_THREADS), 0, stream, hist, totals, nb);
+    CGS_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((radix_scatter_kernel<BITS, XF>), dim3(sort_grid(nb)), dim3(SORT_THREADS), 0, stream, src_k, src_v, dst_k,
+                       dst_v, (const uint32_t *)hist, (const uint32_t *)totals, n, nb, shift, mask);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// depth27: keys_in are depth keys, sorted as cgs_depth_key27() in three 9-bit passes (keys_out then holds the 27-bit keys)
 static int sort_classic(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                         uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n, int bit_lo, int bit_hi, int passes, void *scratch,
-                        size_t scratch_bytes, hipStream_t stream) {
+                        size_t scratch_bytes, hipStream_t stream, bool depth27 = false, uint32_t *overflow = nullptr,
+                        uint32_t epoch = 0) {
+    (void)scratch_bytes;
     const int64_t nb = sort_blocks(n);
-    const size_t hist_bytes = cgs_align_up((size_t)RADIX * nb * sizeof(uint32_t), 256);
+    const int bits_per = depth27 ? 9 : RADIX_BITS;
+    const size_t hist_bytes = cgs_align_up((size_t)(1u << bits_per) * nb * sizeof(uint32_t), 256);
     uint32_t *hist = (uint32_t *)scratch;
-    uint32_t *totals = (uint32_t *)((char *)scratch + hist_bytes);      // [RADIX] digit totals of the pass
+    uint32_t *totals = (uint32_t *)((char *)scratch + hist_bytes);      // [digits] totals of the pass
 
     // Choose the ping-pong start so that the last pass lands in *_out.
     const uint32_t *src_k = keys_in, *src_v = vals_in;
     uint32_t *dst_k = (passes & 1) ? keys_out : keys_tmp;
     uint32_t *dst_v = (passes & 1) ? vals_out : vals_tmp;
     for (int p = 0; p < passes; ++p) {
-        const int shift = bit_lo + p * RADIX_BITS;
-        const int nb_bits = (bit_hi - shift) < RADIX_BITS ? (bit_hi - shift) : RADIX_BITS;
+        const int shift = bit_lo + p * bits_per;
+        const int nb_bits = (bit_hi - shift) < bits_per ? (bit_hi - shift) : bits_per;
         const uint32_t mask = (1u << nb_bits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k, hist,
-                           n, shift, mask);
-        CGS_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(radix_digit_scan_kernel, dim3(RADIX), dim3(SORT_THREADS), 0, stream, hist, totals, nb);
-        CGS_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nb), dim3(SORT_THREADS), 0, stream, src_k,
-                           src_v, dst_k, dst_v, (const uint32_t *)hist, (const uint32_t *)totals, n, shift, mask);
-        CGS_CHECK_HIP(hipGetLastError());
+        int rc;
+        if (!depth27) rc = sort_pass<RADIX_BITS, false>(src_k, src_v, dst_k, dst_v, hist, totals, n, nb, shift, mask, nullptr, 0, stream);
+        else if (p == 0) rc = sort_pass<9, true>(src_k, src_v, dst_k, dst_v, hist, totals, n, nb, shift, mask, overflow, epoch, stream);
+        else rc = sort_pass<9, false>(src_k, src_v, dst_k, dst_v, hist, totals, n, nb, shift, mask, nullptr, 0, stream);
+        if (rc) return rc;
         src_k = dst_k;
         src_v = dst_v;
         dst_k = (dst_k == keys_out) ? keys_tmp : keys_out;
@@ -437,6 +523,24 @@ extern "C" int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_
     }
     return sort_classic(keys_in, vals_in, keys_out, vals_out, keys_tmp, vals_tmp, n, bit_lo, bit_hi, passes, scratch,
                         scratch_bytes, stream);
+}
+
+// Stable sort of DEPTH keys (float bits of view depths above the 0.2 near plane; 0xFFFFFFFF = culled, never read back) with
+// values = positions: the order of cgs_sort_pairs_u32(keys, NULL, ..., 0, 32) for every live key whenever no live depth
+// reaches ~13107 (bits(z) - bits(0.2) < 2^27 - 1) — three 9-bit passes over 27-bit keys instead of four 8-bit passes.
+// A live key outside the range makes the first pass write `epoch` to *overflow (device memory, otherwise untouched): the
+// order is then NOT valid and the caller sorts again with cgs_sort_pairs_u32.  keys_out receives the 27-bit keys.
+extern "C" int cgs_sort_depth_keys(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_out, uint32_t *keys_tmp,
+                                   uint32_t *vals_tmp, int64_t n, void *scratch, size_t scratch_bytes, uint32_t *overflow,
+                                   uint32_t epoch, void *stream_) {
+    if (n < 0 || n >= (1ll << 32) || !overflow) { cgs_set_error("sort_depth_keys: bad arguments"); return CGS_ERR_ARG; }
+    if (n == 0) return CGS_OK;
+    if (scratch_bytes < cgs_sort_scratch_bytes(n)) {
+        cgs_set_error("sort: scratch too small (%zu < %zu)", scratch_bytes, cgs_sort_scratch_bytes(n));
+        return CGS_ERR_WORKSPACE;
+    }
+    return sort_classic(keys_in, nullptr, keys_out, vals_out, keys_tmp, vals_tmp, n, 0, 27, 3, scratch, scratch_bytes,
+                        (hipStream_t)stream_, true, overflow, epoch);
 }
 
 // ----------------------------------------------------------------------------

@@ -26,6 +26,10 @@
 #define TB_TILE (TB_THREADS * TB_ITEMS)
 #define TB_WAVES (TB_THREADS / CGS_WAVE)
 #define TB_MAXR 256
+#ifndef TB_XCD_MAP
+#define TB_XCD_MAP 0      // 1: columns dealt to the XCDs in contiguous eighths (cgs_xcd_item) — what wins 10 % in the depth sort LOSES
+                          // 9-10 us per pass here (same-box A/B, profiles/r06_depth_sort.txt); 0: column = workgroup id
+#endif
 
 int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch, size_t scratch_bytes,
                                  uint32_t *grand_total, hipStream_t stream);
@@ -159,7 +163,13 @@ __global__ void __launch_bounds__(TB_THREADS)
     tb_hist_kernel(const uint16_t *__restrict__ keys, const uint32_t *__restrict__ offsets,
                    const uint32_t *__restrict__ rect_lo, const uint32_t *__restrict__ rect_hi,
                    const uint32_t *__restrict__ bf, int64_t P, uint32_t R, uint32_t tiles_x,
-                   uint32_t *__restrict__ hist /*[rows][nblocks]*/, int shift, int nbits, const uint32_t *__restrict__ R_dev) {
+                   uint32_t *__restrict__ hist /*[rows][ncol]*/, int shift, int nbits, const uint32_t *__restrict__ R_dev,
+                   uint32_t ncol, int xcd) {
+    // column of this workgroup: its id, or (xcd) the XCD-aware assignment of cgs_xcd_item() — neighbouring columns, whose runs are
+    // adjacent in the output, on the same XCD's L2 (prims.hip: sort_tile_of_block)
+    const int64_t col_ = xcd ? cgs_xcd_item((int64_t)ncol) : (int64_t)blockIdx.x;
+    if (col_ < 0) return;
+    const uint32_t col = (uint32_t)col_;
     if (R_dev) R = min(*R_dev, R);         // speculative launch: R (argument) is the capacity, the count is on the device
     __shared__ uint32_t h[TB_MAXR];
     __shared__ uint32_t sidx[GEN ? TB_TILE : 1];
@@ -169,8 +179,8 @@ __global__ void __launch_bounds__(TB_THREADS)
     h[tid] = 0;
     // A block owns a COLUMN of the histogram = `per` consecutive blocks of TB_TILE pairs (per = 1 when the grid has a block per
     // TB_TILE pairs: the fine passes; the bucket pass runs a fixed grid because its pair count is known on the device only).
-    const uint32_t nblk = (R + (uint32_t)TB_TILE - 1u) / (uint32_t)TB_TILE, per = max(1u, (nblk + gridDim.x - 1u) / gridDim.x);
-    const uint32_t b0 = blockIdx.x * per, b1 = min(nblk, b0 + per);
+    const uint32_t nblk = (R + (uint32_t)TB_TILE - 1u) / (uint32_t)TB_TILE, per = max(1u, (nblk + ncol - 1u) / ncol);
+    const uint32_t b0 = col * per, b1 = min(nblk, b0 + per);
     __syncthreads();
     for (uint32_t blk = b0; blk < b1; ++blk) {
         const uint32_t base = blk * (uint32_t)TB_TILE;
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(TB_THREADS)
         }
         __syncthreads();                    // (the owner index is rebuilt by the next block of the column)
     }
-    if (tid < (1 << nbits)) hist[(int64_t)tid * gridDim.x + blockIdx.x] = h[tid];     // (a column past the pairs writes zeros)
+    if (tid < (1 << nbits)) hist[(int64_t)tid * ncol + col] = h[tid];     // (a column past the pairs writes zeros)
 }
 
 // One stable radix pass.  GEN: the block's pairs come from gen_pair (first pass); otherwise from (keys_in, vals_in).
@@ -203,11 +213,14 @@ __global__ void __launch_bounds__(TB_THREADS)
                       const uint32_t *__restrict__ bf, int64_t P, uint32_t R, uint32_t tiles_x,
                       uint16_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint2 *__restrict__ ranges,
                       const uint32_t *__restrict__ hist_scanned, int shift, const uint32_t *__restrict__ R_dev,
-                      uint32_t *__restrict__ mask_out = nullptr) {
+                      uint32_t ncol, int xcd, const uint32_t *__restrict__ digit_totals, uint32_t *__restrict__ mask_out = nullptr) {
+    const int64_t col_ = xcd ? cgs_xcd_item((int64_t)ncol) : (int64_t)blockIdx.x;      // (see tb_hist_kernel)
+    if (col_ < 0) return;
+    const uint32_t col = (uint32_t)col_;
     if (R_dev) R = min(*R_dev, R);
     constexpr int nbits = NBITS;
-    const uint32_t nblk = (R + (uint32_t)TB_TILE - 1u) / (uint32_t)TB_TILE, per = max(1u, (nblk + gridDim.x - 1u) / gridDim.x);
-    const uint32_t b0 = blockIdx.x * per, b1 = min(nblk, b0 + per);   // this block's column (see tb_hist_kernel)
+    const uint32_t nblk = (R + (uint32_t)TB_TILE - 1u) / (uint32_t)TB_TILE, per = max(1u, (nblk + ncol - 1u) / ncol);
+    const uint32_t b0 = col * per, b1 = min(nblk, b0 + per);   // this block's column (see tb_hist_kernel)
     if (b0 >= b1) return;
     __shared__ uint32_t wcnt[TB_WAVES][TB_MAXR];
     __shared__ uint32_t lstart[TB_MAXR], gbase[TB_MAXR];
@@ -218,7 +231,24 @@ __global__ void __launch_bounds__(TB_THREADS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
     // thread d: where the column's next item of digit d goes (advanced by every block of the column)
-    uint32_t gcur = tid < (1 << nbits) ? hist_scanned[(int64_t)tid * gridDim.x + blockIdx.x] : 0u;
+    uint32_t gcur = tid < (1 << nbits) ? hist_scanned[(int64_t)tid * ncol + col] : 0u;
+    if (digit_totals) {
+        // hist_scanned holds per-digit exclusive scans over the columns (cgs_launch_digit_scan: one launch instead of the generic
+        // scan's two): the digit's first global position = the totals of the digits below it, summed here
+        const uint32_t gt = tid < (1 << nbits) ? digit_totals[tid] : 0u;
+        uint32_t ginc = gt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(ginc, o, 64);
+            if (lane >= o) ginc += up;
+        }
+        if (lane == 63) wsum[wave] = ginc;
+        __syncthreads();
+        uint32_t goff = 0;
+#pragma unroll
+        for (int w = 0; w < TB_WAVES; ++w) goff += (w < wave) ? wsum[w] : 0u;
+        gcur += goff + ginc - gt;
+    }
     for (uint32_t blk = b0; blk < b1; ++blk) {
     __syncthreads();                                        // the previous block's staging is drained
 #pragma unroll
@@ -633,10 +663,14 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
     const uint32_t *offsets = g.offsets, *rlo = g.sort_b, *rhi = g.sort_d, *order = g.order;
     int rc;
     // the digit width is a template parameter: the ballot match unrolls to exactly that many steps
+    // (columns XCD-aware, per-digit column scans + digit totals: cgs_xcd_item / cgs_launch_digit_scan, as in the depth sort)
+    uint32_t *totals = (uint32_t *)scan_scratch;                    // [TB_MAXR]
+    (void)scan_bytes;
+    const unsigned grid = TB_XCD_MAP ? cgs_xcd_grid(nb) : (unsigned)nb;
 #define TB_SCATTER_N(GEN, FINAL, N, KIN, VIN, KOUT, VOUT, SHIFT)                                                          \
-    hipLaunchKernelGGL((tb_scatter_kernel<GEN, FINAL, N>), dim3((unsigned)nb), dim3(TB_THREADS), 0, stream, KIN, VIN,     \
+    hipLaunchKernelGGL((tb_scatter_kernel<GEN, FINAL, N>), dim3(grid), dim3(TB_THREADS), 0, stream, KIN, VIN,             \
                        offsets, rlo, rhi, order, (const uint32_t *)bf, P, (uint32_t)R, tiles_x, KOUT, VOUT, im.ranges,    \
-                       (const uint32_t *)hist, SHIFT, R_dev)
+                       (const uint32_t *)hist, SHIFT, R_dev, (uint32_t)nb, TB_XCD_MAP, (const uint32_t *)totals)
 #define TB_SCATTER(GEN, FINAL, NB, KIN, VIN, KOUT, VOUT, SHIFT)                                                           \
     do { switch (NB) {                                                                                                    \
         case 1: TB_SCATTER_N(GEN, FINAL, 1, KIN, VIN, KOUT, VOUT, SHIFT); break;                                          \
@@ -654,13 +688,11 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
         const int64_t nthr = nb + 1 > nt ? nb + 1 : nt;
         hipLaunchKernelGGL(block_first_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, nb, P, offsets, bf,
                            nt, im.ranges, R_dev, (uint32_t)R);
-        hipLaunchKernelGGL(tb_hist_kernel<true>, dim3((unsigned)nb), dim3(TB_THREADS), 0, stream,
+        hipLaunchKernelGGL(tb_hist_kernel<true>, dim3(grid), dim3(TB_THREADS), 0, stream,
                            (const uint16_t *)nullptr, offsets, rlo, rhi, (const uint32_t *)bf, P, (uint32_t)R, tiles_x,
-                           hist, 0, bits_a, R_dev);
+                           hist, 0, bits_a, R_dev, (uint32_t)nb, TB_XCD_MAP);
         CGS_CHECK_HIP(hipGetLastError());
-        if ((rc = cgs_scan_exclusive_u32_total(hist, hist, (int64_t)(1 << bits_a) * nb, scan_scratch, scan_bytes, nullptr,
-                                               stream)))
-            return rc;
+        if ((rc = cgs_launch_digit_scan(hist, totals, 1 << bits_a, nb, stream))) return rc;
         if (bits_b)
             TB_SCATTER(true, false, bits_a, (const uint16_t *)nullptr, (const uint32_t *)nullptr, key_a, b.gid_a, 0);
         else
@@ -670,13 +702,11 @@ int cgs_launch_tile_bin16(const cgs_raster_cfg *cfg, int64_t P, int64_t R, int t
     }
     if (bits_b) {
         CgsProfScope prof(CGS_PROF_TILE_SORT, stream);
-        hipLaunchKernelGGL(tb_hist_kernel<false>, dim3((unsigned)nb), dim3(TB_THREADS), 0, stream,
+        hipLaunchKernelGGL(tb_hist_kernel<false>, dim3(grid), dim3(TB_THREADS), 0, stream,
                            (const uint16_t *)key_a, offsets, rlo, rhi, (const uint32_t *)bf, P, (uint32_t)R, tiles_x, hist,
-                           bits_a, bits_b, R_dev);
+                           bits_a, bits_b, R_dev, (uint32_t)nb, TB_XCD_MAP);
         CGS_CHECK_HIP(hipGetLastError());
-        if ((rc = cgs_scan_exclusive_u32_total(hist, hist, (int64_t)(1 << bits_b) * nb, scan_scratch, scan_bytes, nullptr,
-                                               stream)))
-            return rc;
+        if ((rc = cgs_launch_digit_scan(hist, totals, 1 << bits_b, nb, stream))) return rc;
         TB_SCATTER(false, true, bits_b, (const uint16_t *)key_a, (const uint32_t *)b.gid_a, (uint16_t *)nullptr,
                    b.gid_sorted, bits_a);
         CGS_CHECK_LAUNCH(stream, cfg->debug);
@@ -756,7 +786,7 @@ int cgs_launch_tile_bin_buckets(const cgs_raster_cfg *cfg, int64_t P, int64_t R,
         BK_TR("block_first");
         hipLaunchKernelGGL((tb_hist_kernel<true, true>), dim3((unsigned)nbc), dim3(TB_THREADS), 0, stream,
                            (const uint16_t *)nullptr, (const uint32_t *)coff, rlo, rhi, (const uint32_t *)bf, P, (uint32_t)R, bx,
-                           hist, 0, bits, (const uint32_t *)Rc_dev);
+                           hist, 0, bits, (const uint32_t *)Rc_dev, (uint32_t)nbc, 0);
         CGS_CHECK_HIP(hipGetLastError());
         BK_TR("hist");
         if ((rc = cgs_scan_exclusive_u32_total(hist, hist, (int64_t)(1 << bits) * nbc, scan_scratch, scan_bytes, nullptr, stream)))
@@ -766,7 +796,7 @@ int cgs_launch_tile_bin_buckets(const cgs_raster_cfg *cfg, int64_t P, int64_t R,
     hipLaunchKernelGGL((tb_scatter_kernel<true, true, N, true>), dim3((unsigned)nbc), dim3(TB_THREADS), 0, stream,        \
                        (const uint16_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)coff, rlo, rhi, order,     \
                        (const uint32_t *)bf, P, (uint32_t)R, bx, (uint16_t *)nullptr, cid, cranges, (const uint32_t *)hist, 0, \
-                       (const uint32_t *)Rc_dev, cmask)
+                       (const uint32_t *)Rc_dev, (uint32_t)nbc, 0, (const uint32_t *)nullptr, cmask)
         switch (bits) {
             case 1: BK_SCATTER_N(1); break;
             case 2: BK_SCATTER_N(2); break;

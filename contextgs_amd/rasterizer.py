@@ -117,12 +117,13 @@ def bin_and_blend(cfg, P, geom, img, color, stream, ticket):
         _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),
                                             binws.numel(), _lib.ptr(img), img.numel(), _lib.ptr(color), stream),
                    "cgs_raster_render_spec")
-    _lib.check(L.cgs_raster_preprocess_wait(ticket, C.byref(R)), "cgs_raster_preprocess_wait")
+    resorted = C.c_int(0)        # the view was sorted again on 32-bit depth keys (a depth beyond ~13107): the speculative render is void
+    _lib.check(L.cgs_raster_preprocess_wait2(ticket, C.byref(R), C.byref(resorted)), "cgs_raster_preprocess_wait")
     num_rendered = int(R.value)
     if num_rendered > _pair_capacity.get((H, W), 0):
         _pair_capacity[(H, W)] = pair_capacity_for(num_rendered)
     bin_R = cap                              # the count the binning workspace was carved with (the backward's `R`)
-    if not cap or num_rendered > cap:
+    if not cap or num_rendered > cap or resorted.value:
         bin_R = num_rendered
         binws = _workspace(L.cgs_raster_bin_bytes(P, num_rendered), dev)
         _lib.check(L.cgs_raster_render(cfg.ref, P, num_rendered, _lib.ptr(geom), geom.numel(), _lib.ptr(binws),

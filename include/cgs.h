@@ -65,6 +65,7 @@ extern "C" {
 #define CGS_ERR_HIP 2
 #define CGS_ERR_WORKSPACE 3
 #define CGS_ERR_BOUNDS 4
+#define CGS_ERR_RESPEC 5 /* cgs_raster_preprocess_wait: render again with cgs_raster_render (see there) */
 
 int cgs_version(void);
 const char *cgs_last_error(void);
@@ -135,6 +136,17 @@ int cgs_raster_preprocess_launch(const cgs_raster_cfg *cfg, int64_t P,
                                  size_t geom_bytes, int32_t *radii, void *stream,
                                  uint64_t *ticket);
 int cgs_raster_preprocess_wait(uint64_t ticket, int64_t *num_rendered_host);
+/* DEPTH ORDER on 27-bit keys.  The depth sort of a view (the reference sorts 64-bit tile|depth keys per tile pair,
+ * gaussian_renderer/__init__.py:197-205 -> its CUDA extension) runs on bits(z) - bits(0.2): three 9-bit passes instead of
+ * four 8-bit ones, exact while every live depth is below ~13107 (cgs_sort_depth_keys below).  The first pass reports a live
+ * depth beyond that to the host together with the pair count; _wait then sorts the view AGAIN on the full 32 bits before it
+ * returns (same result as before, one sort later; the thread's later views go straight to 32 bits).  What a caller must know:
+ * a cgs_raster_render_spec enqueued between _launch and _wait ran on the first order.  cgs_raster_preprocess_wait2 reports
+ * that in *order_changed (the caller renders again with cgs_raster_render); cgs_raster_preprocess_wait returns
+ * CGS_ERR_RESPEC in that case (count valid, same remedy) and CGS_OK otherwise. */
+int cgs_raster_preprocess_wait2(uint64_t ticket, int64_t *num_rendered_host, int *order_changed);
+/* test hook: force (1) / release (0) the 32-bit depth sort for this host thread; returns the previous setting */
+int cgs_debug_set_depth_keys_full(int on);
 
 /* Forward, stage 2: per-tile lists (stable by depth inside a tile), tile ranges, alpha blend.
  * out_color is [3, H, W]. */
@@ -238,6 +250,15 @@ int cgs_sort_pairs_u32(const uint32_t *keys_in, const uint32_t *vals_in,
                        uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n,
                        int bit_lo, int bit_hi, void *scratch,
                        size_t scratch_bytes, void *stream);
+/* Stable sort of DEPTH keys — float bits of view depths above the 0.2 near plane, 0xFFFFFFFF for a culled Gaussian (whose
+ * place in the order is never read) — with values = positions: for the live keys the order of
+ * cgs_sort_pairs_u32(keys_in, NULL, ..., 0, 32, ...) whenever bits(z) - bits(0.2) < 2^27 - 1 for all of them (z < ~13107),
+ * in three 9-bit passes over those 27-bit keys (keys_out receives them).  A live key outside the range makes the first
+ * pass write `epoch` to *overflow (device memory, not touched otherwise): the order is then not valid and the caller sorts
+ * again with cgs_sort_pairs_u32; keys_in is never modified. */
+int cgs_sort_depth_keys(const uint32_t *keys_in, uint32_t *keys_out, uint32_t *vals_out,
+                        uint32_t *keys_tmp, uint32_t *vals_tmp, int64_t n, void *scratch,
+                        size_t scratch_bytes, uint32_t *overflow, uint32_t epoch, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* Per-kernel timing (used by bench.py's roofline leg)                  */

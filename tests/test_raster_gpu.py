@@ -202,6 +202,75 @@ def test_radix_sort_stable_exact(n, lo, hi):
         assert torch.equal(ko, keys[order])
 
 
+@pytest.mark.parametrize("n", [1, 4097, 300_000, 6_000_001])
+def test_depth_key_sort_equals_the_32_bit_sort(n):
+    """cgs_sort_depth_keys (27-bit keys, three 9-bit passes) == cgs_sort_pairs_u32 on the full float bits for depths inside the
+    range, culled Gaussians (0xFFFFFFFF) anywhere behind the live ones; a depth beyond the range is REPORTED."""
+    from contextgs_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    # depths 0.2 .. ~12000, log-uniform, with exact duplicates (stability) and 5 % culled
+    z = torch.exp(torch.empty(n, device="cuda").uniform_(math.log(0.2001), math.log(12000.0), generator=gen))
+    z[1::2] = z[0::2][: n // 2].clone()
+    keys = z.view(torch.int32).clone()
+    culled = torch.rand(n, device="cuda", generator=gen) < 0.05
+    keys[culled] = -1                                              # 0xFFFFFFFF
+    ko, vo, kt, vt, ko2, vo2 = (torch.empty_like(keys) for _ in range(6))
+    scratch = torch.empty(L.cgs_sort_scratch_bytes(n), dtype=torch.uint8, device="cuda")
+    flag = torch.zeros(4, dtype=torch.int32, device="cuda")
+    st = _lib.current_stream()
+    _lib.check(L.cgs_sort_depth_keys(_lib.ptr(keys), _lib.ptr(ko), _lib.ptr(vo), _lib.ptr(kt), _lib.ptr(vt), n, _lib.ptr(scratch),
+                                     scratch.numel(), _lib.ptr(flag), 77, st), "sort_depth_keys")
+    _lib.check(L.cgs_sort_pairs_u32(_lib.ptr(keys), None, _lib.ptr(ko2), _lib.ptr(vo2), _lib.ptr(kt), _lib.ptr(vt), n, 0, 32,
+                                    _lib.ptr(scratch), scratch.numel(), st), "sort")
+    assert int(flag[0]) == 0
+    live = int((~culled).sum())
+    assert torch.equal(vo[:live], vo2[:live])                       # the live keys: the same order, entry for entry
+    assert bool(culled[vo[live:].long()].all())                     # behind them only culled ones
+    # one live depth beyond the range: reported with the caller's epoch, input keys untouched
+    before = keys.clone()
+    keys[n // 2] = torch.tensor([20000.0], device="cuda").view(torch.int32)[0]
+    before[n // 2] = keys[n // 2]
+    _lib.check(L.cgs_sort_depth_keys(_lib.ptr(keys), _lib.ptr(ko), _lib.ptr(vo), _lib.ptr(kt), _lib.ptr(vt), n, _lib.ptr(scratch),
+                                     scratch.numel(), _lib.ptr(flag), 78, st), "sort_depth_keys")
+    assert int(flag[0]) == 78 and torch.equal(keys, before)
+
+
+def test_a_depth_beyond_the_27_bit_range_falls_back_to_the_32_bit_sort():
+    """A view with live depths beyond ~13107: the preprocess wait sorts again on 32 bits, the speculative render is redone,
+    the image equals the one of a thread that sorts on 32 bits from the start; later views of the thread stay on 32 bits."""
+    from contextgs_amd import _lib
+    from contextgs_amd.rasterizer import GaussianRasterizer
+    L = _lib.lib()
+    cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), 256, 256)
+    g = random_gaussians(3000, seed=5, extent=1.0, scale_lo=0.01, scale_hi=0.05)
+    t = {k: torch.tensor(v, device="cuda") for k, v in g.items()}
+    # 40 large, far Gaussians straight ahead (z ~ 20000 .. 60000), overlapping on screen: their order matters
+    far = 40
+    t["means3D"][:far, :2] = torch.randn(far, 2, device="cuda") * 300.0
+    t["means3D"][:far, 2] = torch.linspace(20000.0, 60000.0, far, device="cuda").flip(0)      # NOT in index order
+    t["scales"][:far] = 1500.0
+    t["opacities"][:far] = 0.6
+    rast = GaussianRasterizer(_settings(cam, (0.1, 0.2, 0.3)))
+
+    def run():
+        return rast(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=None, colors_precomp=t["colors"],
+                    opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)[0]
+
+    was = L.cgs_debug_set_depth_keys_full(1)
+    try:
+        ref = run()
+        L.cgs_debug_set_depth_keys_full(0)
+        run(); run()                                # (the pair capacity of this image size is learnt: the next view speculates)
+        L.cgs_debug_set_depth_keys_full(0)
+        out = run()                                 # ranged sort -> reported -> sorted again inside the wait, rendered again
+        assert L.cgs_debug_set_depth_keys_full(0) == 1, "the thread did not switch to 32-bit depth keys"
+        assert torch.equal(out, ref)
+        assert float((ref - torch.tensor([0.1, 0.2, 0.3], device="cuda").view(3, 1, 1)).abs().max()) > 0.05
+    finally:
+        L.cgs_debug_set_depth_keys_full(was)
+
+
 def test_full_hd_properties():
     """BASELINE-size image (1920x1080), many Gaussians: properties that do not need the oracle.
     linearity in the colours (render(c1)+render(c2) == render(c1+c2) with bg=0), bounded output,
