@@ -43,6 +43,7 @@ ROW_SOURCE = _os.environ.get("CGS_ROW_SOURCE", "1") != "0"      # A/B knob: 0 = 
 RATE_SIDE = _os.environ.get("CGS_RATE_SIDE", "1") != "0"        # A/B knob: 0 = rate gradients through autograd (dense buffers + adds)
 LEVEL_FUSED = _os.environ.get("CGS_LEVEL_FUSED", "1") != "0"    # A/B knob: 0 = round 4's rowcat -> mlp2 -> noise_quant launches per level
 RATE_FUSED = _os.environ.get("CGS_RATE_FUSED", "1") != "0"      # A/B knob: 0 = round 5's gather -> mlp2 -> level_rate launches on the rate subset
+EARLY_LEVELS = _os.environ.get("CGS_EARLY_LEVELS", "1") != "0"  # A/B knob: 0 = the level kernels are enqueued behind the rate subset's read-back (rounds 5-6a)
 
 
 def _compose_down(index, maps):
@@ -304,8 +305,10 @@ def _plan_and_chosen(pc, anchor, mask_anchor_bool, choose_mask, draw=False, begu
         cache = _cached_plan(pc, anchor, mask_anchor_bool)               # builds (device sorts + host reads)
     if not cache["covers_all"]:
         return cache, None, None
-    use_begun = (begun is not None and not fresh and begun["cache"] is cache and begun["anchor"] is anchor
+    use_begun = (begun is not None and not begun.get("used") and not fresh and begun["cache"] is cache and begun["anchor"] is anchor
                  and begun["mask"] is mask_anchor_bool)
+    if use_begun:
+        begun["used"] = True             # (its handle is read once)
     seed = begun["seed"] if use_begun else (_ctx.next_seed() if draw else 0)
     for attempt in range(2):
         if use_begun and attempt == 0:
@@ -534,8 +537,90 @@ def gather_rows(x, idx):
     return _GatherRows.apply(x, idx) if x.requires_grad else x.index_select(0, idx)
 
 
+class _EarlyMismatch(Exception):
+    """The level kernels were enqueued ahead of the rate subset's read-back and what came back does not fit them (the plan was
+    rebuilt, or a level left the fused path): the caller runs the step's context model again the plain way."""
+
+
+def _early_levels(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, begun):
+    """Enqueue the step's level kernels (cgs_ctx_level_fwd, one per level) NOW, in front of the read-back of the rate subset's
+    counts: they read the anchors, the parameters, the noisy hyper latents begin_step() launched and the plan — nothing the host
+    has to wait for — and take ~0.4 ms of the device, which used to sit idle for ~130 us in three gaps while the host, just
+    back from the read-back, prepared them one after the other (profiles/r06_gpu_idle_gaps.txt).  The autograd nodes are created
+    later, by the level loop, around these results (ctx_ops.level_fused(pre=)).  None when the step is not the all-fused one."""
+    c = begun["cache"]
+    K, D = pc.n_offsets, pc.feat_dim
+    if (begun.get("used") or c is not getattr(pc, "_level_cache", None) or pc.level_scale is None
+            or c["key"] != _plan_key(pc, anchor, mask_anchor_bool) or not c["covers_all"] or c.get("identity")
+            or begun["anchor"] is not anchor or begun["mask"] is not mask_anchor_bool):
+        return None
+    if not (FUSED_TRAINING and ROW_SOURCE and LEVEL_FUSED and RATE_FUSED and RATE_SIDE and not pc.adaptQ_per_channel):
+        return None
+    pre = begun.get("hyper_pre")
+    if (pre is None or pre[0] is not hyper or pc.disable_hyper or hyper.dtype != torch.float32
+            or not (isinstance(pc.latent_codec, _EntropyBottleneck) and pc.latent_codec.filters == (3, 3, 3, 3))):
+        return None
+    if not (grid_offsets.dim() == 3 and pc._anchor_feat.is_cuda
+            and (feat.requires_grad or grid_scaling.requires_grad or grid_offsets.requires_grad)):
+        return None
+    sizes, perm, plan = c["sizes"], c["perm"], c["plan"]
+    if any(n_ <= 0 for n_ in sizes) or not all(_mlp.supported(pc.get_grid_mlp[i_]) for (i_, _t, _o, _a) in plan):
+        return None
+    v_blocks = torch.split(pre[1], sizes)
+    row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, True)
+    if not all(_ctx.level_fused_supported(pc.get_grid_mlp[i_], anchor, v_blocks[j_], row_src) for j_, (i_, _t, _o, _a) in enumerate(plan)):
+        return None
+    row_src.sums_buffer()
+    n_tot = int(perm.shape[0])
+    dev = anchor.device
+    big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=dev)
+    big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=dev)
+    big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=dev)
+    out, row_off, src_vals = [], 0, None
+    for j, (i, _tc, orig, _a) in enumerate(plan):
+        n_l = sizes[j]
+        sl = slice(row_off, row_off + n_l)
+        if src_vals is None:
+            a_rows, pos_, bf, bs = orig, None, None, None
+            a_mask = mask_anchor_bool if (i >= 1 and mask_anchor_bool is not None) else None
+        else:
+            (a_rows, pos_, bf, bs), a_mask = src_vals, None
+        seed = _ctx.next_seed()
+        res = _ctx.level_fused_launch(anchor, bf, bs, v_blocks[j], pc.get_grid_mlp[i], 2 * (D + 6 + 3 * K), a_rows, a_mask, pos_,
+                                      row_src, perm[row_off:row_off + n_l], (big_f[sl], big_s[sl], big_o[sl]),
+                                      (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), seed)
+        out.append((res, seed))
+        row_off += n_l
+        if i != 0:          # (what _next_context hands the next level, as values: the coded prefix lies at the front of the buffers)
+            src_vals = (c["ctx_idx"][i], c["ctx_pos"][i], big_f[:row_off], big_s[:row_off])
+    return dict(cache=c, row_src=row_src, big=(big_f, big_s, big_o), levels=out, inputs=(hyper, feat, grid_offsets, grid_scaling))
+
+
+def early_levels_begin(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, begun):
+    """_early_levels for a caller that knows it will run the training context model on exactly these tensors: the renderer calls it
+    right behind begin_step(), i.e. even before it reads the visible-anchor count — the level kernels do not depend on the view.
+    The result waits in begun["early"] for context_model_coding_order."""
+    if EARLY_LEVELS and begun is not None and anchor.is_cuda and torch.is_grad_enabled():
+        begun["early"] = _early_levels(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, begun)
+
+
 def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
                                keep_stats, choose_mask=None, draw_choose=False, begun=None, allow_rate_lazy=False):
+    """_coding_order_impl with the level kernels enqueued ahead of the rate subset's read-back when the step allows it
+    (_early_levels); if what comes back does not fit them, once more the plain way."""
+    args = (pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training, keep_stats)
+    try:
+        return _coding_order_impl(*args, choose_mask=choose_mask, draw_choose=draw_choose, begun=begun,
+                                  allow_rate_lazy=allow_rate_lazy, early_ok=EARLY_LEVELS)
+    except _EarlyMismatch:
+        if begun is not None:
+            begun["used"] = True
+        return _coding_order_impl(*args, choose_mask=choose_mask, draw_choose=draw_choose, begun=begun,
+                                  allow_rate_lazy=allow_rate_lazy, early_ok=False)
+
+
+def _coding_order_impl(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, training,
+                       keep_stats, choose_mask=None, draw_choose=False, begun=None, allow_rate_lazy=False, early_ok=False):
     """The level loop of multi_scale_generating (:1556-1652) in coding order.
 
     Returns (cache, feat_Q, scaling_Q, offsets_Q [rows in coding order: row r is anchor cache['perm'][r]],
@@ -546,10 +631,20 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     if pc.level_scale is None:                                                         # :1559
         sel = anchor[mask_anchor_bool] if mask_anchor_bool is not None else anchor
         pc.level_scale = find_divide_scale(pc, sel, pc.target_ratio, pc.level_num)
+    early = None
+    if (early_ok and begun is not None and training and keep_stats and allow_rate_lazy and anchor.is_cuda
+            and (draw_choose or choose_mask is not None)):
+        early = begun.pop("early", None)
+        if early is not None and not all(a_ is b_ for a_, b_ in zip(early["inputs"], (hyper, feat, grid_offsets, grid_scaling))):
+            early = None                    # (launched for other tensors: its buffers are simply dropped)
+        if early is None:
+            early = _early_levels(pc, anchor, hyper, feat, grid_offsets, grid_scaling, mask_anchor_bool, begun)
     # level plan (cached) + the rate subset's rows per level, with one host read for both
     c, locs, chosen_rows = _plan_and_chosen(pc, anchor, mask_anchor_bool,
                                             choose_mask if (keep_stats and anchor.is_cuda) else None,
                                             draw=draw_choose and keep_stats and choose_mask is None, begun=begun)
+    if early is not None and (c is not early["cache"] or locs is None or chosen_rows is None):
+        raise _EarlyMismatch()
     if draw_choose and keep_stats and choose_mask is None:
         # the kernels drew the subset: keep a bool mask around for the (rare) level that does not take the fused path
         if chosen_rows is None:            # anchors the plan does not cover: the torch draw
@@ -575,15 +670,22 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
     if (fused and ROW_SOURCE and not c.get("identity") and (not keep_stats or choose_mask is not None)
             and all(_mlp.supported(pc.get_grid_mlp[i_]) for (i_, _t, _o, _a) in c["plan"])
             and grid_offsets.dim() == 3 and (feat.requires_grad or grid_scaling.requires_grad or grid_offsets.requires_grad)):
-        row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, full)
-        row_src.sums_buffer()            # (its zero fill is queued here, in front of the hyper step's kernel)
+        if early is not None:
+            row_src = early["row_src"]
+        else:
+            row_src = _ctx.RowSource(feat, grid_scaling, grid_offsets, full)
+            row_src.sums_buffer()            # (its zero fill is queued here, in front of the hyper step's kernel)
         feat_l = scal_l = off_l = None
     else:
+        if early is not None:
+            raise _EarlyMismatch()
         feat_l = torch.split(in_order(feat), sizes)
         scal_l = torch.split(in_order(grid_scaling), sizes)
         off_l = torch.split(in_order(grid_offsets), sizes)
     n_tot = int(perm.shape[0])
-    if fused:
+    if early is not None:
+        big_f, big_s, big_o = early["big"]
+    elif fused:
         big_f = torch.empty(n_tot, feat.shape[1], dtype=torch.float32, device=anchor.device)
         big_s = torch.empty(n_tot, grid_scaling.shape[1], dtype=torch.float32, device=anchor.device)
         big_o = torch.empty(n_tot, 3 * K, dtype=torch.float32, device=anchor.device)
@@ -648,10 +750,11 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 else:
                     a_rows, pos_, base_f, base_s, csr = ctx_src
                     a_mask = None
+                pre_j, seed_j = early["levels"][j] if early is not None else (None, None)
                 hf, hs, ho, Q_all, pred_sub = _ctx.level_fused(
                     anchor, base_f, base_s, hyp_l[j], pc.get_grid_mlp[i], 2 * (pc.feat_dim + 6 + 3 * K), loc if keep_stats else None,
                     a_rows, a_mask, pos_, csr, row_src, perm[row_off:row_off + n_l], (big_f[sl], big_s[sl], big_o[sl]), side,
-                    (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), rate_lazy=rate_lazy and keep_stats)
+                    (Q_FEAT0, Q_SCALING0, Q_OFFSETS0), seed=seed_j, rate_lazy=rate_lazy and keep_stats, pre=pre_j)
                 row_off += n_l
                 if keep_stats:
                     span = None
@@ -670,6 +773,8 @@ def context_model_coding_order(pc, anchor, hyper, feat, grid_offsets, grid_scali
                 if i != 0:
                     ctx_src = _next_context(c, i, feat_q, scal_q, (big_f, big_s, row_off))
                 continue
+            if early is not None:
+                raise _EarlyMismatch()
             if rate_lazy:
                 raise RuntimeError("context model: a level left the fused path after the rate subset was made lazy")
             if ctx_src is None:                                                        # :1596-1600
@@ -1074,7 +1179,9 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     if draw:
         choose_mask = c.get("_choose_mask")
     if c["covers_all"]:
-        pos = c["inv_perm"][vis_idx]
+        # (the renderer may have formed the rows already, for its early launch of the anchor MLPs: the same tensor is handed on)
+        e_pos = begun.get("early_pos") if begun is not None else None
+        pos = e_pos[1] if (e_pos is not None and e_pos[0] is vis_idx and e_pos[2] is c) else c["inv_perm"][vis_idx]
         lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32 and LAZY_MODE > 0
         if lazy and LAZY_MODE == 1:
             outs = (LazyRows(feat_p, pos), gather_unique(scal_p, pos), gather_unique(off_p, pos))

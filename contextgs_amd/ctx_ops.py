@@ -807,11 +807,14 @@ class _LevelFused(torch.autograd.Function):
     cfg: dict(a_rows, a_mask, pos, csr, loc, n_stat, src, rows, seed, q0, outs, side) — see level_fused()."""
 
     @staticmethod
-    def forward(ctx, anchor, base_f, base_s, hyp, W1, b1, W2, b2, _token, cfg):
+    def launch(anchor, base_f, base_s, hyp, W1, b1, W2, b2, cfg):
+        """The forward's launch on plain values (no autograd): (X, Q, (W1c, b1c, W2c, b2c)).  Called by forward(), or EARLIER by
+        level_fused_launch() — the level kernels of a step need nothing the host has to wait for, so context_model enqueues them in
+        front of the rate subset's read-back and hands the result to forward() through cfg["pre"]."""
         from . import mlp as _mlp
         L = _lib.lib()
         _mlp._drop_stale_deferred()
-        src, rows, loc = cfg["src"], cfg["rows"], cfg["loc"]
+        src, rows = cfg["src"], cfg["rows"]
         anchor_c, hyp_c = _c(anchor.detach()), _c(hyp.detach())
         W1c, b1c, W2c, b2c = (t.detach().contiguous() for t in (W1, b1, W2, b2))
         n, in_f = int(rows.shape[0]), int(W1c.shape[1])
@@ -840,6 +843,21 @@ class _LevelFused(torch.autograd.Function):
             int(bf.shape[0]) if ctxlevel else 0, _lib.ptr(pos), _lib.ptr(hyp_c), n, _lib.ptr(W1c), _lib.ptr(b1c), W2c.data_ptr() + 4 * n_stat * hid, b2c.data_ptr() + 4 * n_stat, _lib.ptr(src.f),
             _lib.ptr(src.s), _lib.ptr(src.o), _lib.ptr(rows), seed, q0[0], q0[1], q0[2], _lib.ptr(X), _lib.ptr(yf), _lib.ptr(ys),
             _lib.ptr(yo), _lib.ptr(Q), _lib.ptr(src.sums_buffer()), stream), "cgs_ctx_level_fwd")
+        return X, Q, (W1c, b1c, W2c, b2c)
+
+    @staticmethod
+    def forward(ctx, anchor, base_f, base_s, hyp, W1, b1, W2, b2, _token, cfg):
+        from . import mlp as _mlp
+        L = _lib.lib()
+        src, rows, loc = cfg["src"], cfg["rows"], cfg["loc"]
+        pre = cfg.get("pre")
+        X, Q, (W1c, b1c, W2c, b2c) = pre if pre is not None else _LevelFused.launch(anchor, base_f, base_s, hyp, W1, b1, W2, b2, cfg)
+        n, in_f = int(rows.shape[0]), int(W1c.shape[1])
+        hid, out, n_stat = int(W1c.shape[0]), int(W2c.shape[0]), int(cfg["n_stat"])
+        ctxlevel = base_f is not None
+        dev = X.device
+        yf, ys, yo = cfg["outs"]
+        stream = _lib.current_stream()
         pred = x_sub = h_sub = None
         m = 0
         lazy = bool(cfg.get("rate_lazy")) and loc is not None and cfg["side"] is not None
@@ -859,9 +877,9 @@ class _LevelFused(torch.autograd.Function):
         # (without "outs": they are this node's OUTPUTS — an output kept on its own ctx is a reference cycle through the C++
         #  node that Python's collector cannot see: every step's level nodes, RowSource and ~350 MB of level tensors stayed
         #  alive for the life of the process, found in round 5 when the device filled up — tools/leak_probe.py)
-        ctx.cfg, ctx.dims = {k: v for k, v in cfg.items() if k != "outs"}, (n, in_f, hid, out, n_stat, m)
+        ctx.cfg, ctx.dims = {k: v for k, v in cfg.items() if k not in ("outs", "pre")}, (n, in_f, hid, out, n_stat, m)
         ctx.lazy = lazy
-        ctx.shapes = (tuple(anchor.shape), None if bf is None else tuple(bf.shape), None if bs is None else tuple(bs.shape))
+        ctx.shapes = (tuple(anchor.shape), None if base_f is None else tuple(base_f.shape), None if base_s is None else tuple(base_s.shape))
         ctx.share_anchor = bool(ANCHOR_SHARED and ctx.needs_input_grad[0])
         if ctx.share_anchor:
             src.anchor_users += 1
@@ -972,8 +990,17 @@ class _LevelFused(torch.autograd.Function):
         return d_anchor, d_f, d_s, d_hyp, dW1, db1, dW2, db2, None, None
 
 
+def level_fused_launch(anchor, base_f, base_s, hyp, seq, n_stat, a_rows, a_mask, pos, src, rows, outs, q0, seed):
+    """The launch of level_fused() on plain values, for a caller that creates the node later: returns `pre` for level_fused(pre=)
+    (same arguments, same seed).  base_f / base_s: the coded prefix's VALUES (the buffers the earlier levels' launches wrote)."""
+    l1, l2 = seq[0], seq[2]
+    cfg = dict(a_rows=a_rows, a_mask=a_mask, pos=pos, n_stat=int(n_stat), src=src, rows=rows, seed=int(seed),
+               q0=tuple(float(v) for v in q0), outs=outs)
+    return _LevelFused.launch(anchor, base_f, base_s, hyp, l1.weight, l1.bias, l2.weight, l2.bias, cfg)
+
+
 def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, pos, csr, src, rows, outs, side, q0, seed=None,
-                rate_lazy=False):
+                rate_lazy=False, pre=None):
     """One level of the training level loop.  anchor [N,3]; base_f / base_s: the coded prefix (None for the first level);
     hyp [n,12] the level's noisy hyper latents; seq = mlp_grid[level]; loc: level rows of the rate subset (or None);
     a_rows [n]: anchor row of every level row; a_mask: bool [N] (first level from level 1 up) or None; pos [n]: the parents'
@@ -985,5 +1012,5 @@ def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, p
     l1, l2 = seq[0], seq[2]
     cfg = dict(a_rows=a_rows, a_mask=a_mask, pos=pos, csr=csr, loc=loc, n_stat=int(n_stat), src=src, rows=rows,
                seed=next_seed() if seed is None else int(seed), q0=tuple(float(v) for v in q0), outs=outs, side=side,
-               rate_lazy=bool(rate_lazy))
+               rate_lazy=bool(rate_lazy), pre=pre)
     return _LevelFused.apply(anchor, base_f, base_s, hyp, l1.weight, l1.bias, l2.weight, l2.bias, src.token, cfg)

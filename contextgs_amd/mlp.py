@@ -431,7 +431,10 @@ class _AnchorMLP3Rows(torch.autograd.Function):
     view gradient back to the anchors — no [n,54] gather / scatter kernels around the MLP."""
 
     @staticmethod
-    def forward(ctx, feat_src, src_row, anchor_vis, cam, *params):
+    def launch(feat_src, src_row, anchor_vis, cam, params, need_grad):
+        """The forward's launch on plain values: a dict forward() accepts as `pre`.  The renderer calls it EARLY — right after the
+        visible-anchor list is known, on the buffer the step's level kernels are writing — so that the 0.5 ms kernel is in the
+        queue while the host creates the context model's autograd nodes (renderer.generate_neural_gaussians)."""
         L = _lib.lib()
         _drop_stale_deferred()
         f32c = lambda t: t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
@@ -440,10 +443,8 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         assert feat_src.dim() == 2 and feat_src.shape[1] == 50 and cam.numel() == 3 and src_row.dtype == torch.int64
         p = [t.detach().contiguous() for t in params]
         W1, b1, W2, b2 = p[0::4], p[1::4], p[2::4], p[3::4]
-        ctx.set_materialize_grads(False)
         n = int(src_row.shape[0])
         dev = feat_src.device
-        need_grad = any(ctx.needs_input_grad)
         y_op = torch.empty(n, 10, dtype=torch.float32, device=dev)
         y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
@@ -457,6 +458,27 @@ class _AnchorMLP3Rows(torch.autograd.Function):
                                                   _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
                                                   _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n,
                                                   _lib.current_stream()), "cgs_anchor_mlp3_forward_rows")
+        return dict(feat_src=feat_src, src_row=src_row, anchor_vis=anchor_vis, cam=cam, W1=W1, W2=W2, y=(y_op, y_color, y_cov), hcat=hcat,
+                    x=x, keep_x=keep_x, need_grad=need_grad, deferred=_Deferred.on,
+                    key=(feat_src.data_ptr(), tuple(feat_src.shape), anchor_vis.data_ptr(), n))
+
+    @staticmethod
+    def forward(ctx, feat_src, src_row, anchor_vis, cam, pre, *params):
+        ctx.set_materialize_grads(False)
+        need_grad = any(ctx.needs_input_grad)
+        if pre is not None:
+            # an early launch is taken only if it ran on exactly these operands (else: dropped, launched again)
+            fs_, av_ = feat_src.detach(), anchor_vis.detach()
+            if not (pre["src_row"] is src_row and pre["need_grad"] == need_grad and pre["deferred"] == _Deferred.on
+                    and fs_.dtype == torch.float32 and fs_.is_contiguous() and av_.dtype == torch.float32 and av_.is_contiguous()
+                    and pre["key"] == (fs_.data_ptr(), tuple(fs_.shape), av_.data_ptr(), int(src_row.shape[0]))):
+                pre = None
+        if pre is None:
+            pre = _AnchorMLP3Rows.launch(feat_src, src_row, anchor_vis, cam, params, need_grad)
+        feat_src, anchor_vis, cam = pre["feat_src"], pre["anchor_vis"], pre["cam"]
+        W1, W2 = pre["W1"], pre["W2"]
+        y_op, y_color, y_cov = pre["y"]
+        hcat, x, keep_x = pre["hcat"], pre["x"], pre["keep_x"]
         if need_grad:
             ctx.save_for_backward(x if keep_x else feat_src, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
             ctx.n_src = int(feat_src.shape[0])
@@ -499,7 +521,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
             _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), None if defer else _lib.ptr(dW1cat),
             None if defer else _lib.ptr(db1cat), None if defer else _ptr_array(dW2), None if defer else _ptr_array(db2), n,
             _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward_rows")
-        grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None]
+        grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None, None]
         wgrads = []
         for i in range(3):
             wgrads += [dW1cat[hp * i:hp * i + 50], db1cat[hp * i:hp * i + 50], dW2[i], db2[i]]
@@ -510,13 +532,22 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         return tuple(grads) + (None,) * 12
 
 
-def anchor_mlp3_rows(feat_src, src_row, anchor_vis, cam_center, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):
+def anchor_mlp3_rows(feat_src, src_row, anchor_vis, cam_center, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential, pre=None):
     """(mlp_opacity(x), mlp_color(x), mlp_cov(x)) with x[r] = [feat_src[src_row[r]] | unit view vector | distance] of
-    anchor_vis[r] seen from cam_center, assembled inside the fused launch."""
+    anchor_vis[r] seen from cam_center, assembled inside the fused launch.  pre: anchor_mlp3_rows_launch() of the same operands."""
     params = []
     for s in (mo, mc, mv):
         params += [s[0].weight, s[0].bias, s[2].weight, s[2].bias]
-    return _AnchorMLP3Rows.apply(feat_src, src_row, anchor_vis, cam_center, *params)
+    return _AnchorMLP3Rows.apply(feat_src, src_row, anchor_vis, cam_center, pre, *params)
+
+
+def anchor_mlp3_rows_launch(feat_src, src_row, anchor_vis, cam_center, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential,
+                            need_grad=True):
+    """The launch of anchor_mlp3_rows() on plain values, ahead of the node (see _AnchorMLP3Rows.launch)."""
+    params = []
+    for s in (mo, mc, mv):
+        params += [s[0].weight, s[0].bias, s[2].weight, s[2].bias]
+    return _AnchorMLP3Rows.launch(feat_src, src_row, anchor_vis, cam_center, params, need_grad)
 
 
 def anchor_mlp3(x, mo: nn.Sequential, mc: nn.Sequential, mv: nn.Sequential):

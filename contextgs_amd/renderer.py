@@ -188,6 +188,7 @@ class _ExpandGaussians(torch.autograd.Function):
         return d_anchor, d_gs, d_off, d_mask, d_op, d_color, d_cov, None, None, None
 
 
+EARLY_MLP3 = os.environ.get("CGS_EARLY_MLP3", "1") != "0"            # A/B knob: 0 = the anchor MLPs are enqueued where their node is created
 MASK_PAIR_NODE = os.environ.get("CGS_MASK_PAIR_NODE", "1") != "0"    # A/B knob: 0 = the mask weights' two row gathers as two nodes (round 5)
 FUSE_VIEW = os.environ.get("CGS_FUSE_VIEW", "1") != "0"    # tuning / A-B knob: expansion fused with the rasterizer's preprocess
 
@@ -335,7 +336,7 @@ def _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offse
 
 
 def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K, between=None,
-                      view=None):
+                      view=None, mlp_pre=None):
     """The same stage as separate launches: fused three-MLP kernel (or torch) + the expansion kernels.
     between: called after the expansion's survivor count has been ENQUEUED and before it is read — work it launches
     (the step's rate model) runs on the device while the host waits for the count."""
@@ -346,7 +347,7 @@ def _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_off
         # and the [feat, view, dist] concatenation happen inside the fused three-MLP kernel's operand load (and its
         # backward scatters straight into the source rows): no [n,54] gather / scatter / norm / div launches
         op_raw, color_in, cov_in = mlp.anchor_mlp3_rows(feat.src, feat.idx, anchor, viewpoint_camera.camera_center,
-                                                        mo, mc, mv)
+                                                        mo, mc, mv, pre=mlp_pre)
     else:
         ob_view = anchor - viewpoint_camera.camera_center                               # :106-110
         ob_dist = ob_view.norm(dim=1, keepdim=True)
@@ -402,7 +403,7 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     vis_pending = VisibleList(visible_mask) if visible_mask.is_cuda else None
     full_anchor = pc.get_anchor                      # one Quantize_anchor launch per call (the reference re-derives
     use_context = (is_training and step > 10000) or (not is_training and not pc.decoded_version)   # it ~5x)
-    begun = binary_all = mask_anchor_bool = rate_thunk = late_mask = None
+    begun = binary_all = mask_anchor_bool = rate_thunk = late_mask = scaling_all = None
     if use_context:
         # everything of the context model that does not depend on the visible set is enqueued BEFORE the read-back of
         # the visible count below (the accessors, the step's bookkeeping kernel): the GPU works through it while the
@@ -426,6 +427,13 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
             binary_all = pc.get_mask
             mask_anchor_bool = binary_all.detach().sum(dim=1)[:, 0] > 0
         begun = begin_step(pc, full_anchor, mask_anchor_bool, is_training)
+        if begun is not None and is_training:
+            # the level kernels of the step's context model depend on nothing the host still has to read (not on the view either):
+            # they go into the queue here, 0.4 ms of device work behind which the read-backs below and the small launches between
+            # them disappear (context_model._early_levels)
+            from .context_model import early_levels_begin
+            scaling_all = pc.get_scaling
+            early_levels_begin(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset, scaling_all, mask_anchor_bool, begun)
     # visible rows are distinct anchors: gather by index with a sort-free scatter backward (the reference's
     # boolean-mask indexing, :44-50, backpropagates through index_put_(accumulate) = a device sort per tensor)
     vis_idx = vis_pending.wait() if vis_pending is not None else torch.nonzero(visible_mask)[:, 0]
@@ -436,6 +444,21 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         _dist.note_touched_rows(None if use_context else visible_mask, int(vis_idx.shape[0]))
     sel = lambda t: gather_unique(t, vis_idx)
     anchor = sel(full_anchor)
+    early = begun.get("early") if begun is not None else None
+    if early is not None and is_training and EARLY_MLP3 and torch.is_grad_enabled():
+        # The three anchor MLPs of the view, enqueued NOW on the buffer the level kernels (already in the queue) are writing:
+        # their operands — the coded features in coding order, the visible anchors' rows of it, the camera — are all known here,
+        # and the host has ~0.3 ms of node creation in front of it (hyper step, three level nodes, the mask's node) during which
+        # the device would finish the level kernels and idle (profiles/r06_gpu_idle_gaps.txt).  The node is created later, by
+        # _generate_unfused, around this launch (mlp.anchor_mlp3_rows(pre=)); if the step turns out different (the plan was
+        # rebuilt, another expansion path), the launch is dropped and repeated there.
+        mo_, mc_, mv_ = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
+        if (mlp.anchor_mlp3_supported(mo_, mc_, mv_) and early["big"][0].shape[1] == 50
+                and not anchor_gen.supported(mo_, mc_, mv_, pc.n_offsets, full_anchor)):
+            pos_e = early["cache"]["inv_perm"][vis_idx]
+            begun["early_pos"] = (vis_idx, pos_e, early["cache"])      # (multi_scale_generating_visible hands the same rows on)
+            early["mlp3"] = mlp.anchor_mlp3_rows_launch(early["big"][0], pos_e, anchor.detach(), viewpoint_camera.camera_center,
+                                                        mo_, mc_, mv_)
     if use_context:
         # enqueued here, in front of the context model's count read-back: the host falls behind the device while it
         # waits there, and a gather the device still has queued covers part of the catch-up
@@ -476,7 +499,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         # (get_mask_anchor, scene/gaussian_model.py:302-310, is "any offset alive" of the SAME mask values: both came
         # from one evaluation above instead of running the sigmoid / threshold / STE chain twice)
         res = multi_scale_generating_visible(pc, full_anchor, pc._hyper_latent, pc._anchor_feat, pc._offset,
-                                             pc.get_scaling, binary_all, mask_anchor_bool, vis_idx,
+                                             scaling_all if scaling_all is not None else pc.get_scaling, binary_all,
+                                             mask_anchor_bool, vis_idx,
                                              training=is_training, predict_bpp=is_training, defer_feat=True,
                                              begun=begun, defer_rate=True)
         feat, grid_scaling, grid_offsets = res[:3]
@@ -499,7 +523,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     out = _generate_fused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K)
     if out is None:
         out = _generate_unfused(viewpoint_camera, pc, anchor, feat, grid_scaling, grid_offsets, binary_grid_masks, K,
-                                between=run_rate, view=_view if is_training else None)
+                                between=run_rate, view=_view if is_training else None,
+                                mlp_pre=early.get("mlp3") if early is not None else None)
     elif run_rate is not None:
         run_rate()
     if rate_out:
