@@ -292,3 +292,73 @@ def test_training_steps_do_not_accumulate_device_memory(step):
     print(f"[leak] live bytes after steps 2..6: {live[2:]}, context nodes alive: {len(ctxs)}")
     assert max(live[3:]) - live[2] <= 8 << 20, live          # (views differ by a few thousand Gaussians: a few MB either way)
     assert len(ctxs) <= 4, ctxs                              # at most the last step's nodes (3 levels + the token node), not 7 steps' worth
+
+
+def _ctx_step(pc, cam, pipe, bg):
+    from contextgs_amd.renderer import prefilter_voxel, render
+    for p in pc.parameters():
+        p.grad = None
+    vis = prefilter_voxel(cam, pc, pipe, bg)
+    pkg = render(cam, pc, pipe, bg, visible_mask=vis, step=20000)
+    loss = (1.0 - pkg["render"]).abs().mean() + 0.001 * pkg["bit_per_param"]
+    loss.backward()
+    return pkg, float(loss)
+
+
+def test_early_launches_fall_back_when_the_plan_turns_out_stale():
+    """The level kernels / anchor MLPs are enqueued ahead of the read-back that validates the cached level plan
+    (context_model._early_levels).  Moving anchors between two steps makes the plan stale AFTER they were enqueued: the step must
+    rebuild the plan and run the plain way (context_model._EarlyMismatch), with finite results and gradients everywhere."""
+    from contextgs_amd import context_model as cm
+    pc, cams, pipe, bg = _setup(N=12000, W=256, H=144, seed=7)
+    _ctx_step(pc, cams[0], pipe, bg)                     # builds the plan
+    _ctx_step(pc, cams[1], pipe, bg)                     # a step on the cached plan: the early path
+    cache = pc._level_cache
+    seen = {"n": 0}
+    orig = cm._early_levels
+
+    def counting(*a, **k):
+        r = orig(*a, **k)
+        seen["n"] += r is not None
+        return r
+    cm._early_levels = counting
+    try:
+        with torch.no_grad():
+            pc._anchor.add_(3.0 * float(pc.voxel_size) * torch.randn_like(pc._anchor))      # other voxels, other levels
+        pkg, loss = _ctx_step(pc, cams[2], pipe, bg)
+    finally:
+        cm._early_levels = orig
+    assert seen["n"] >= 1, "the early path was not taken: the test does not exercise the fallback"
+    assert pc._level_cache is not cache, "the plan was not rebuilt"
+    assert math.isfinite(loss) and torch.isfinite(pkg["render"]).all()
+    for name in ("_anchor", "_offset", "_mask", "_anchor_feat", "_scaling", "_hyper_latent"):
+        g = getattr(pc, name).grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+    _ctx_step(pc, cams[3], pipe, bg)                     # and the next step is an early one again, on the new plan
+
+
+def test_early_launches_change_nothing_but_the_order():
+    """Same seeds, same scene: a training step with the early launches and one without give the same image, rate and gradients
+    (the kernels and their operands are the same, only their place in the queue differs)."""
+    from contextgs_amd import context_model as cm, ctx_ops, renderer as rd
+    outs = []
+    for early in (True, False):
+        pc, cams, pipe, bg = _setup(N=12000, W=256, H=144, seed=9)
+        old = (cm.EARLY_LEVELS, rd.EARLY_MLP3)
+        cm.EARLY_LEVELS, rd.EARLY_MLP3 = early, early
+        try:
+            _ctx_step(pc, cams[0], pipe, bg)             # builds the plan (never early)
+            import itertools
+            ctx_ops._seed_counter = itertools.count(1000)        # the same stream ids for both runs
+            pkg, loss = _ctx_step(pc, cams[1], pipe, bg)
+        finally:
+            cm.EARLY_LEVELS, rd.EARLY_MLP3 = old
+        outs.append((pkg["render"].detach().clone(), float(pkg["bit_per_param"]), pc._anchor_feat.grad.clone(), pc._mask.grad.clone(),
+                     [p.grad.clone() for p in pc.mlp_grid.parameters()]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]                  # forward: bit for bit
+    # (gradients: the blend backward's flush adds with float atomics, whose order differs from run to run of the SAME schedule too)
+    close = lambda x, y: float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-12
+    assert close(a[2], b[2]) and close(a[3], b[3])
+    for x, y in zip(a[4], b[4]):
+        assert close(x, y)
