@@ -386,6 +386,13 @@ def _index_rows(x, idx):
         _lib.check(_lib.lib().cgs_gather_rows(_lib.ptr(x), _lib.ptr(idx), n, w, _lib.ptr(out), _lib.current_stream()),
                    "cgs_gather_rows")
         return out
+    if (x.is_cuda and x.dtype == torch.int64 and x.dim() == 1 and idx.dtype == torch.int64 and x.is_contiguous() and idx.is_contiguous()
+            and n > 0 and x.shape[0] > 0):
+        # an index vector through an index vector (inv_perm[vis_idx]): the same kernel on the rows' bits, two float lanes per entry
+        # (plain moves: every bit pattern survives) instead of torch's generic index kernel (10 -> 6 us at 1 M entries)
+        out = torch.empty(n, dtype=torch.int64, device=x.device)
+        _lib.check(_lib.lib().cgs_gather_rows(_lib.ptr(x), _lib.ptr(idx), n, 2, _lib.ptr(out), _lib.current_stream()), "cgs_gather_rows")
+        return out
     return x.index_select(0, idx)
 
 
@@ -1181,7 +1188,7 @@ def multi_scale_generating_visible(pc, anchor, hyper, feat, grid_offsets, grid_s
     if c["covers_all"]:
         # (the renderer may have formed the rows already, for its early launch of the anchor MLPs: the same tensor is handed on)
         e_pos = begun.get("early_pos") if begun is not None else None
-        pos = e_pos[1] if (e_pos is not None and e_pos[0] is vis_idx and e_pos[2] is c) else c["inv_perm"][vis_idx]
+        pos = e_pos[1] if (e_pos is not None and e_pos[0] is vis_idx and e_pos[2] is c) else _index_rows(c["inv_perm"], vis_idx)
         lazy = defer_feat and feat_p.is_cuda and feat_p.dtype == torch.float32 and LAZY_MODE > 0
         if lazy and LAZY_MODE == 1:
             outs = (LazyRows(feat_p, pos), gather_unique(scal_p, pos), gather_unique(off_p, pos))

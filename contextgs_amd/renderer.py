@@ -455,7 +455,8 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         mo_, mc_, mv_ = pc.get_opacity_mlp, pc.get_color_mlp, pc.get_cov_mlp
         if (mlp.anchor_mlp3_supported(mo_, mc_, mv_) and early["big"][0].shape[1] == 50
                 and not anchor_gen.supported(mo_, mc_, mv_, pc.n_offsets, full_anchor)):
-            pos_e = early["cache"]["inv_perm"][vis_idx]
+            from .context_model import _index_rows
+            pos_e = _index_rows(early["cache"]["inv_perm"], vis_idx)
             begun["early_pos"] = (vis_idx, pos_e, early["cache"])      # (multi_scale_generating_visible hands the same rows on)
             early["mlp3"] = mlp.anchor_mlp3_rows_launch(early["big"][0], pos_e, anchor.detach(), viewpoint_camera.camera_center,
                                                         mo_, mc_, mv_)
