@@ -982,7 +982,8 @@ def rate_model(pc, anchor, binary_grid_masks, mask_anchor_bool, likelihood_hyper
             level_rows.append(n_sub)
         dead = 0.0 if mask_anchor_bool is None else 1.0 - live_count / mask_anchor_bool.numel()
         meta = dict(use_clamp=_enc.use_clamp, K=K, spans=spans, sides=sides, maps=maps,
-                    finish=(float(mask_anchor_rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead)))
+                    finish=(float(mask_anchor_rate), float(n_feat), float(n_scaling), float(n_offsets), float(dead)),
+                    sum_table=src0.rate_sum_table(len(levels)) if src0 is not None else None)
         out4, raw = _ctx.rate_all(hyper_sum, masks_chosen, x_means_fused, meta, tensors)      # (out4: four 0-dim tensors)
         feat_dim = pc.feat_dim + 6 + 3 * K
         divisors = [1.0, float(max(1, n_hyper))] + [float(max(1, r) * feat_dim) for r in level_rows]

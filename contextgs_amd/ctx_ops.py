@@ -174,8 +174,21 @@ class RowSource:
         """The accumulator the level kernels add the sums of their source rows to: private to this RowSource (two sources
         alive at once — interleaved forwards, a second stream — never share partial sums), zeroed at creation."""
         if self.sums is None:
-            self.sums = torch.zeros(int(_lib.lib().cgs_means_accum_doubles()), dtype=torch.float64, device=self.f.device)
+            # (+ 16 doubles behind the accumulator: the step's [levels, 3] table of rate sums is carved from the same zero fill,
+            #  rate_sum_table)
+            nd = int(_lib.lib().cgs_means_accum_doubles())
+            self._sums_all = torch.zeros(nd + 16, dtype=torch.float64, device=self.f.device)
+            self.sums = self._sums_all[:nd]
+            self._table_taken = False
         return self.sums
+
+    def rate_sum_table(self, levels: int):
+        """A zeroed float32 [levels, 3] table for the rate node of THIS step (cgs_rate_sub_fwd / cgs_level_rate_fwd add their three
+        sums into a row): the tail of the accumulator's allocation, zeroed by the same fill — once per RowSource; None otherwise."""
+        if self.sums is None or self._table_taken or 3 * levels > 32:
+            return None
+        self._table_taken = True
+        return self._sums_all[self.sums.shape[0]:].view(_f32)[:3 * levels].view(levels, 3)
 
     def means(self):
         """float32 [3] = (features.mean(), scaling.mean(), offsets.mean()) once every row has been read by a level:
@@ -422,7 +435,9 @@ class _RateAll(torch.autograd.Function):
         lv = [t.contiguous() if k % 6 == 5 else _c(t) for k, t in enumerate(lv)]     # every 6th is loc (int64)
         _lib.require_device(masks, x_means, lv[0], lv[4])
         dev = masks.device
-        S = torch.zeros(nl, 3, dtype=_f32, device=dev)
+        S = meta.get("sum_table")           # (zeroed with the row source's accumulator: RowSource.rate_sum_table)
+        if S is None or tuple(S.shape) != (nl, 3):
+            S = torch.zeros(nl, 3, dtype=_f32, device=dev)
         stream = _lib.current_stream()
         for j in range(nl):
             yf, ys, yo, Q, pred, loc = lv[6 * j:6 * j + 6]

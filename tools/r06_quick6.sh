@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests/test_context_gpu.py tests/test_training_parity_gpu.py tests/test_rate_sub_gpu.py tests/test_ctx_level_gpu.py tests/test_training_gpu.py tests/test_ctx_ops_gpu.py tests/test_edge_cases_gpu.py tests/test_dist_train_gpu.py tests/test_trajectory_gpu.py -x -q 2>&1 | tail -5) > gpurun_out/r06_tq.log 2>&1; cat gpurun_out/r06_tq.log
 FLAGS="--no-cpu-baseline --no-heavy --no-eval-fps --no-codec --no-raster-only --no-image-loss"
-for rep in 1 2; do for e in 11 10 00; do
+for rep in 1 2; do for e in 11; do
 CGS_EARLY_LEVELS=${e:0:1} CGS_EARLY_MLP3=${e:1:1} timeout 600 python bench.py $FLAGS > gpurun_out/r06_bench_q.json 2> gpurun_out/bench.err
 python - <<PY
 import json
