@@ -81,28 +81,13 @@ RETIME_RATIO = float(os.environ.get("CGS_BENCH_RETIME_RATIO", "1.3"))     # see 
 
 
 class _LinearLoss:
-    """sum(image * w) + lam * rate as ONE autograd node (a dot product forward, g * w backward) instead of torch's
-    mul / sum / mul / add chain and its backward: the metric's fixed linear loss, five launches shorter."""
-    fn = None
+    """sum(image * w) + lam * rate as ONE autograd node and one launch each way (contextgs_amd.loss_utils.weighted_image_sum,
+    cgs_weighted_sum_*): the metric's fixed linear loss.  (Rounds 2-5 ran it as a dot-product node: five launches.)"""
 
-    @classmethod
-    def apply(cls, img, w, rate, lam):
-        import torch
-        if cls.fn is None:
-            class F(torch.autograd.Function):
-                @staticmethod
-                def forward(ctx, img, w, rate, lam):
-                    ctx.save_for_backward(w)
-                    ctx.lam, ctx.rate_shape = lam, (None if rate is None else rate.shape)
-                    out = torch.dot(img.reshape(-1), w.reshape(-1))
-                    return out if rate is None else torch.add(out, rate.reshape(()), alpha=lam)
-
-                @staticmethod
-                def backward(ctx, g):
-                    (w,) = ctx.saved_tensors
-                    return g * w, None, ((g * ctx.lam).reshape(ctx.rate_shape) if ctx.rate_shape is not None else None), None
-            cls.fn = F
-        return cls.fn.apply(img, w, rate, lam)
+    @staticmethod
+    def apply(img, w, rate, lam):
+        from contextgs_amd.loss_utils import weighted_image_sum
+        return weighted_image_sum(img, w, rate, lam)
 
 
 def one_step(pc, cam, pipe, bg, w, step_sem, params, sync, gt=None):

@@ -111,6 +111,10 @@ SIGNATURES = {
     "cgs_anchor_mlp3_layout": (c_int, [c_void_p]),
     "cgs_gather_rows_segmented": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_scatter_rows_sorted": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "cgs_add_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "cgs_weighted_sum_scratch_bytes": (c_size_t, []),
+    "cgs_weighted_sum_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "cgs_weighted_sum_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "cgs_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "cgs_mark_rows": (c_int, [c_void_p, c_int64, c_int64, C.c_uint32, c_void_p, c_void_p]),
     "cgs_zero_unmarked_rows": (c_int, [c_void_p, C.c_uint32, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -469,7 +469,7 @@ class _GatherUniquePair(torch.autograd.Function):
             if ga is not None:
                 out.index_copy_(0, idx_a, ga.contiguous())
         if gb is not None:
-            out.view(N, w).index_add_(0, idx_b, gb.reshape(-1, w).contiguous())     # distinct rows: one add per element, no order to depend on
+            _ctx.add_rows_(out, idx_b, gb)           # distinct rows: one add per element, no order to depend on
         return out, None, None, None
 
 

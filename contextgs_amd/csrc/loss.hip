@@ -308,3 +308,88 @@ extern "C" int cgs_sigmoid_mean_bwd(const float *x, const float *g, int64_t n, f
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
+
+
+// ---- weighted image sum: sum_i img[i] * w[i] (+ lam * rate) and its backward ----------------------------------------------
+// The fixed linear objective a throughput measurement puts behind render() (bench.py: sum(image * w) + lambda * bit_per_param,
+// train.py:206-209 with the image term made linear) as ONE launch each way instead of dot (2 launches) + add and two muls.
+// Deterministic: per-workgroup partial sums in double, the last workgroup to finish adds them in workgroup order and clears the
+// counter for the next call (scratch = WS_BLOCKS doubles + one zero-initialised uint32, owned by the caller).
+#define WS_BLOCKS 1024
+__global__ void __launch_bounds__(256)
+    wsum_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, const float *__restrict__ rate, float lam,
+                    double *__restrict__ partial, unsigned int *__restrict__ counter, float *__restrict__ out) {
+    __shared__ double sh[4];
+    __shared__ bool last;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    const int64_t n4 = ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) ? n / 4 : 0;
+    for (int64_t i = t0; i < n4; i += stride) {
+        const float4 x = ((const float4 *)a)[i], y = ((const float4 *)b)[i];
+        acc += (double)(x.x * y.x) + (double)(x.y * y.y) + (double)(x.z * y.z) + (double)(x.w * y.w);
+    }
+    for (int64_t i = 4 * n4 + t0; i < n; i += stride) acc += (double)(a[i] * b[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double v = 0.0;
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) v += ((volatile double *)partial)[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]) + (rate ? lam * rate[0] : 0.f);
+        *counter = 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    wsum_bwd_kernel(const float *__restrict__ g, const float *__restrict__ w, int64_t n, float lam, float *__restrict__ dimg,
+                    float *__restrict__ drate) {
+    const float gv = g[0];
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n4 = ((((uintptr_t)w | (uintptr_t)dimg) & 15) == 0) ? n / 4 : 0;
+    for (int64_t i = t0; i < n4; i += stride) {
+        const float4 y = ((const float4 *)w)[i];
+        ((float4 *)dimg)[i] = make_float4(gv * y.x, gv * y.y, gv * y.z, gv * y.w);
+    }
+    for (int64_t i = 4 * n4 + t0; i < n; i += stride) dimg[i] = gv * w[i];
+    if (drate && t0 == 0) drate[0] = gv * lam;
+}
+
+extern "C" size_t cgs_weighted_sum_scratch_bytes(void) { return (size_t)WS_BLOCKS * sizeof(double) + 256; }
+
+extern "C" int cgs_weighted_sum_fwd(const float *img, const float *w, int64_t n, const float *rate, float lam, void *scratch,
+                                    size_t scratch_bytes, float *out, void *stream) {
+    if (n < 0 || !out || !scratch || scratch_bytes < cgs_weighted_sum_scratch_bytes() || (n && (!img || !w))) {
+        cgs_set_error("weighted_sum_fwd: bad args");
+        return CGS_ERR_ARG;
+    }
+    double *partial = (double *)scratch;
+    unsigned int *counter = (unsigned int *)((char *)scratch + (size_t)WS_BLOCKS * sizeof(double));
+    const int64_t want = (n / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > WS_BLOCKS ? WS_BLOCKS : want));
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, w, n, rate, lam, partial, counter, out);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_weighted_sum_bwd(const float *g, const float *w, int64_t n, float lam, float *dimg, float *drate, void *stream) {
+    if (n < 0 || !g || (n && (!w || !dimg))) { cgs_set_error("weighted_sum_bwd: bad args"); return CGS_ERR_ARG; }
+    const int64_t want = (n / 4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, w, n, lam, dimg, drate);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}

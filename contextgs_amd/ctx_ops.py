@@ -104,6 +104,22 @@ _ROW_STAMPS = {}      # (device, n_full) -> [uint32 stamp tensor, generation]
 _ROW_STAMPS_LOCK = threading.Lock()     # autograd runs backward nodes on its own threads
 
 
+def add_rows_(out, idx, g):
+    """out[idx] += g for DISTINCT rows idx (out [N, ...], g [n, ...] fp32): cgs_add_rows on the device, index_add_ elsewhere."""
+    n = int(idx.shape[0])
+    if n == 0:
+        return out
+    w = int(out[0].numel())
+    if (out.is_cuda and out.dtype == _f32 and g.dtype == _f32 and out.is_contiguous() and idx.dtype == torch.int64
+            and idx.is_contiguous() and 1 <= w <= 256 and int(g.numel()) == n * w):
+        g = g.contiguous()
+        _lib.check(_lib.lib().cgs_add_rows(_lib.ptr(g), _lib.ptr(idx), n, int(out.shape[0]), w, _lib.ptr(out), _lib.current_stream()),
+                   "cgs_add_rows")
+        return out
+    out.view(out.shape[0], -1).index_add_(0, idx, g.reshape(n, -1).to(out.dtype))
+    return out
+
+
 def zero_unlisted_rows(idx, n_full, arrays):
     """Zeros in every row of `arrays` ([n_full, ...] float32, same device) that `idx` (int64, distinct rows < n_full) does not
     name — what torch.zeros gave the gradient buffers of a view's backward before the kernel overwrote the listed rows, without

@@ -163,7 +163,8 @@ class _HyperStep(torch.autograd.Function):
             (C_.c_int64 * k)(*lds), (C_.c_int64 * (k + 1))(*begin), _lib.ptr(inv_perm), N, C, _lib.ptr(g_x), stream),
             "cgs_gather_rows_segmented")
         if g_sub is not None:
-            g_x.index_add_(0, rows_orig, g_sub)          # the rate subset's rows (distinct), in parameter order
+            from .ctx_ops import add_rows_
+            add_rows_(g_x, rows_orig, g_sub)             # the rate subset's rows (distinct), in parameter order
         return g_x, None, None, None, g_p, None, None, None, None
 
     @staticmethod

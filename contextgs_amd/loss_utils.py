@@ -116,3 +116,45 @@ def mask_reg(mask: torch.Tensor):
     if mask.numel() == 0:
         return torch.mean(torch.sigmoid(mask))
     return _MeanReg.apply(mask, 1)
+
+
+_WSUM_SCRATCH = {}
+
+
+class _WeightedImageSum(torch.autograd.Function):
+    """sum(image * w) + lam * rate as ONE node and one launch each way (cgs_weighted_sum_*): the linear objective bench.py puts
+    behind render() — torch's mul / sum / mul / add chain and its backward are nine launches, a dot-product node five."""
+
+    @staticmethod
+    def forward(ctx, img, w, rate, lam):
+        L = _lib.lib()
+        _lib.require_device(img, w)
+        img_c, w_c = img.detach().float().contiguous(), w.detach().float().contiguous()
+        assert img_c.numel() == w_c.numel()
+        dev = img_c.device
+        ws = _WSUM_SCRATCH.get(dev)
+        if ws is None:
+            ws = _WSUM_SCRATCH[dev] = torch.zeros(int(L.cgs_weighted_sum_scratch_bytes()), dtype=torch.uint8, device=dev)
+        rate_c = None if rate is None else rate.detach().float().reshape(1).contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(L.cgs_weighted_sum_fwd(_lib.ptr(img_c), _lib.ptr(w_c), img_c.numel(), _lib.ptr(rate_c), float(lam), _lib.ptr(ws),
+                                          ws.numel(), _lib.ptr(out), _lib.current_stream()), "cgs_weighted_sum_fwd")
+        ctx.save_for_backward(w_c)
+        ctx.lam, ctx.img_shape, ctx.rate_shape = float(lam), img.shape, (None if rate is None else rate.shape)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (w_c,) = ctx.saved_tensors
+        L = _lib.lib()
+        g = g.float().reshape(1).contiguous()
+        dimg = torch.empty(ctx.img_shape, dtype=torch.float32, device=w_c.device)
+        drate = torch.empty(1, dtype=torch.float32, device=w_c.device) if ctx.rate_shape is not None else None
+        _lib.check(L.cgs_weighted_sum_bwd(_lib.ptr(g), _lib.ptr(w_c), w_c.numel(), ctx.lam, _lib.ptr(dimg), _lib.ptr(drate),
+                                          _lib.current_stream()), "cgs_weighted_sum_bwd")
+        return dimg, None, (None if drate is None else drate.reshape(ctx.rate_shape)), None
+
+
+def weighted_image_sum(image, w, rate=None, lam=0.0):
+    """sum(image * w) + lam * rate (rate: a one-element tensor or None) — see _WeightedImageSum."""
+    return _WeightedImageSum.apply(image, w, rate, lam)

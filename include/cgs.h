@@ -388,6 +388,11 @@ int cgs_rowcat_bwd_masked(int nsrc, void *const *ddata, const int64_t *const *id
  * visible-anchor list (gaussian_renderer/__init__.py:44-50) in one launch instead of a zero fill + a scatter. */
 int cgs_scatter_rows_sorted(const float *g, const int64_t *idx, int64_t n, int64_t N, int w,
                             float *out, void *stream);
+/* out[idx[i], 0:w] += g[i, 0:w] for DISTINCT row indices idx [n] (any order; rows < N): the second reader of a tensor adding
+ * its rows' gradient into the first reader's buffer (the rate subset's rows of the mask weights and of the hyper latents,
+ * scene/gaussian_model.py:1662-1669) without float atomics. */
+int cgs_add_rows(const float *g, const int64_t *idx, int64_t n, int64_t N, int w, float *out,
+                 void *stream);
 /* out[i, 0:w] = x[idx[i], 0:w] (int64 row indices, 1 <= w <= 256, dense fp32 rows):
  * the forward of the same gathers (x[visible rows], gaussian_renderer/__init__.py:44-50). */
 int cgs_gather_rows(const float *x, const int64_t *idx, int64_t n, int w,
@@ -1032,6 +1037,16 @@ int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, int W,
 int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *maps,
                     const float *g, int C, int H, int W, float *dimg,
                     void *stream);
+
+/* sum_i img[i] * w[i] + lam * rate[0] (rate may be NULL) -> out [1], and its backward dimg = g[0] * w, drate[0] = g[0] * lam
+ * (drate may be NULL): the linear objective a throughput measurement puts behind render() (train.py:206-209 with the image term
+ * made linear), one launch each way, deterministic (per-workgroup partials in double, added in workgroup order).  scratch:
+ * cgs_weighted_sum_scratch_bytes() bytes, ZERO-initialised once by the caller and reused across calls on one stream. */
+size_t cgs_weighted_sum_scratch_bytes(void);
+int cgs_weighted_sum_fwd(const float *img, const float *w, int64_t n, const float *rate, float lam,
+                         void *scratch, size_t scratch_bytes, float *out, void *stream);
+int cgs_weighted_sum_bwd(const float *g, const float *w, int64_t n, float lam, float *dimg,
+                         float *drate, void *stream);
 
 /* ---- the regularisers next to the image loss (train.py:203,209) ----
  * scaling_reg = scaling.prod(dim=1).mean() over the visible Gaussians' scales [P,3], and

@@ -146,3 +146,24 @@ def test_hip_regularisers_reject_bad_arguments():
     assert L.cgs_sigmoid_mean_fwd(x.data_ptr() + 4, 8, _lib.ptr(out), _lib.current_stream()) != 0      # misaligned
     assert torch.isnan(scaling_reg(torch.ones(0, 3, device="cuda")))     # empty view: nan, like the reference's expression
     assert torch.isnan(mask_reg(torch.ones(0, 10, 1, device="cuda")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,with_rate", [(1, True), (1023, False), (3 * 180 * 320, True), (3 * 1080 * 1920, True)])
+def test_weighted_image_sum_matches_torch_fp64(n, with_rate):
+    """sum(image * w) + lam * rate (cgs_weighted_sum_*, the bench's linear objective) against the fp64 expression: value within the
+    fp32 products' rounding, gradients exact (g * w, g * lam), two calls bit-identical (deterministic reduction order)."""
+    import torch
+    from contextgs_amd.loss_utils import weighted_image_sum
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    img = torch.rand(n, device="cuda", generator=gen).requires_grad_(True)
+    w = torch.randn(n, device="cuda", generator=gen)
+    rate = torch.tensor(3.25, device="cuda", requires_grad=True) if with_rate else None
+    out = weighted_image_sum(img, w, rate, 0.001)
+    ref = (img.detach().double() * w.double()).sum() + (0.001 * 3.25 if with_rate else 0.0)
+    assert abs(float(out) - float(ref)) <= 1e-6 * float((img.detach().double() * w.double()).abs().sum()) + 1e-7
+    assert torch.equal(weighted_image_sum(img, w, rate, 0.001), out)
+    (2.0 * out).backward()
+    assert torch.equal(img.grad, 2.0 * w)
+    if with_rate:
+        assert abs(float(rate.grad) - 0.002) < 1e-9
