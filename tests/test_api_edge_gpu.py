@@ -104,3 +104,83 @@ def test_launch_wait_tickets_are_checked_by_the_library():
     _lib.check(L.cgs_nonzero_wait(t2, C.byref(cnt)), "cgs_nonzero_wait")      # waiting twice on the current ticket is fine
     assert cnt.value == int(m2.sum())
     assert L.cgs_nonzero_launch(_lib.ptr(m1), m1.numel(), None, None, 0, _lib.current_stream(), None) != 0     # NULL ticket
+
+
+def test_old_wait_reports_a_void_speculative_render_after_a_depth_resort():
+    """C ABI, round 6: a view with live depths beyond the 27-bit key range is sorted again on 32 bits inside the wait.  A caller
+    that enqueued cgs_raster_render_spec between _launch and _wait must learn that its render ran on the first order:
+    cgs_raster_preprocess_wait returns CGS_ERR_RESPEC (count valid), cgs_raster_preprocess_wait2 sets *order_changed; without a
+    speculative render in between the old wait just returns CGS_OK."""
+    import ctypes as C
+    from contextgs_amd import _lib
+    from contextgs_amd.rasterizer import _Cfg, GaussianRasterizationSettings
+    from contextgs_amd.synth import look_at_camera, random_gaussians
+    import math
+    L = _lib.lib()
+    cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), 128, 128).to_torch("cuda")
+    g = random_gaussians(2000, seed=3, extent=1.0, scale_lo=0.01, scale_hi=0.05)
+    t = {k: torch.tensor(v, device="cuda") for k, v in g.items()}
+    t["means3D"][:20, :2] = 0.0
+    t["means3D"][:20, 2] = torch.linspace(20000.0, 40000.0, 20, device="cuda")
+    t["scales"][:20] = 1500.0
+    rs = GaussianRasterizationSettings(
+        image_height=128, image_width=128, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device="cuda"), scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=1, campos=cam.camera_center, prefiltered=False, debug=False)
+    cfg = _Cfg(rs)
+    P = 2000
+    st = _lib.current_stream()
+
+    def launch():
+        radii = torch.empty(P, dtype=torch.int32, device="cuda")
+        geom = torch.empty(int(L.cgs_raster_geom_bytes(P)), dtype=torch.uint8, device="cuda")
+        tk = C.c_uint64(0)
+        _lib.check(L.cgs_raster_preprocess_launch(cfg.ref, P, _lib.ptr(t["means3D"]), _lib.ptr(t["colors"]), _lib.ptr(t["opacities"]),
+                                                  _lib.ptr(t["scales"]), _lib.ptr(t["rotations"]), _lib.ptr(geom), geom.numel(),
+                                                  _lib.ptr(radii), st, C.byref(tk)), "launch")
+        return tk, geom, radii
+
+    def spec(geom):
+        cap = 1 << 20
+        binws = torch.empty(int(L.cgs_raster_bin_bytes(P, cap)), dtype=torch.uint8, device="cuda")
+        img = torch.empty(int(L.cgs_raster_img_bytes(128, 128)), dtype=torch.uint8, device="cuda")
+        color = torch.empty(3, 128, 128, device="cuda")
+        _lib.check(L.cgs_raster_render_spec(cfg.ref, P, cap, _lib.ptr(geom), geom.numel(), _lib.ptr(binws), binws.numel(),
+                                            _lib.ptr(img), img.numel(), _lib.ptr(color), st), "spec")
+        return binws, img, color
+
+    was = L.cgs_debug_set_depth_keys_full(0)
+    try:
+        R = C.c_int64(0)
+        # (1) no speculative render in between: the old wait is fine, and the thread switched to 32-bit keys
+        tk, geom, _r = launch()
+        assert L.cgs_raster_preprocess_wait(tk, C.byref(R)) == 0 and R.value > 0
+        assert L.cgs_debug_set_depth_keys_full(0) == 1
+        # (2) with one: CGS_ERR_RESPEC = 5 from the old wait, the count still delivered
+        tk, geom, _r = launch()
+        keep = spec(geom)
+        R2 = C.c_int64(0)
+        assert L.cgs_raster_preprocess_wait(tk, C.byref(R2)) == 5 and b"cgs_raster_render" in L.cgs_last_error()
+        assert R2.value == R.value
+        L.cgs_debug_set_depth_keys_full(0)
+        # (3) wait2 reports it instead
+        tk, geom, _r = launch()
+        keep = spec(geom)
+        ch = C.c_int(0)
+        _lib.check(L.cgs_raster_preprocess_wait2(tk, C.byref(R2), C.byref(ch)), "wait2")
+        assert ch.value == 1 and R2.value == R.value
+        del keep
+    finally:
+        L.cgs_debug_set_depth_keys_full(was)
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n,N,w", [(0, 10, 3), (1, 1, 1), (5000, 20000, 10), (149741, 1000000, 12), (1000, 1000, 256)])
+def test_add_rows_equals_index_add_on_distinct_rows(n, N, w):
+    from contextgs_amd import ctx_ops
+    gen = torch.Generator(device="cuda").manual_seed(n + w)
+    out = torch.randn(N, w, device="cuda", generator=gen)
+    idx = torch.randperm(N, device="cuda", generator=gen)[:n].contiguous()
+    g = torch.randn(n, w, device="cuda", generator=gen)
+    ref = out.clone().index_add_(0, idx, g)
+    assert torch.equal(ctx_ops.add_rows_(out, idx, g), ref)
