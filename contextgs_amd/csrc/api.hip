@@ -81,6 +81,7 @@ size_t cgs_img_carve(CgsImg *im, void *ws, size_t bytes, int32_t H, int32_t W) {
     im->final_T = c.take<float>(hw);
     im->n_contrib = c.take<uint32_t>(hw);
     im->tile_last = c.take<uint32_t>(tiles);
+    im->tile_order = c.take<uint32_t>(tiles);
     return c.ok ? c.used() : 0;
 }
 
@@ -417,6 +418,7 @@ static int raster_render_impl(const cgs_raster_cfg *cfg, int64_t P, int64_t R, b
         }
     }
     if (!(bin16 && R > 0) && (rc = cgs_launch_ranges(cfg, R, b, im, stream))) return rc;
+    if ((rc = cgs_launch_tile_order(cfg, im, stream))) return rc;
     return cgs_launch_blend_fwd(cfg, g, b, im, out_color, stream);
 }
 

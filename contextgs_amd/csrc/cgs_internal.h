@@ -120,6 +120,7 @@ struct CgsImg {
     float *final_T;         // [H*W]
     uint32_t *n_contrib;    // [H*W] 1-based position (within the tile list) of the last contributor
     uint32_t *tile_last;    // [tiles] max over the tile's pixels of n_contrib
+    uint32_t *tile_order;   // [tiles] tile ids, longest lists first (the blend kernels' workgroup -> tile map)
 };
 
 size_t cgs_geom_carve(CgsGeom *g, void *ws, size_t bytes, int64_t P);
@@ -152,6 +153,7 @@ int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
 int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, const float *dL_dout,
                               float *dL_dmean2D_px, float *dL_dconic, float *dL_dopacity, float *dL_dcolors,
                               hipStream_t stream);
+int cgs_launch_tile_order(const cgs_raster_cfg *cfg, CgsImg &im, hipStream_t stream);      // raster_blend_rows.hip
 int cgs_launch_blend_fwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,
                          float *out_color, hipStream_t stream);
 int cgs_launch_blend_bwd(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im,

@@ -28,6 +28,9 @@
 #define RB_T_EPS 0.0001f
 #define RB_INV_LOG2E 0.6931471805599453f
 #define RB_NGRAD 9
+#ifndef RB_TILE_ORDER
+#define RB_TILE_ORDER 1      // 0: tile = workgroup id (raster order)
+#endif
 
 
 namespace {
@@ -156,12 +159,13 @@ __global__ void __launch_bounds__(RB_THREADS)
     blend_fwd_rows_kernel(int W, int H, int tiles_x, const uint2 *__restrict__ ranges,
                           const uint32_t *__restrict__ gid_sorted, const float4 *__restrict__ rec,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ final_T,
-                          uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ tile_last) {
+                          uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ tile_last,
+                          const uint32_t *__restrict__ tile_order) {
     __shared__ float4 srec[RB_THREADS * 3];
     __shared__ RbLists S;
     __shared__ uint32_t wave_last[4];
 
-    const int tile = blockIdx.x;
+    const int tile = RB_TILE_ORDER ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;        // longest lists first (tile_order_kernel)
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RbLane L = rb_lane(tx, ty, wave, lane);
@@ -261,7 +265,7 @@ __global__ void __launch_bounds__(RB_THREADS)
                           const uint32_t *__restrict__ n_contrib, const uint32_t *__restrict__ tile_last,
                           const float *__restrict__ dL_dout, float *__restrict__ dL_dmean2D_px,
                           float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
-                          float *__restrict__ dL_dcolors) {
+                          float *__restrict__ dL_dcolors, const uint32_t *__restrict__ tile_order) {
     // 22.6 KB of LDS per workgroup = seven workgroups per CU: two float4 per record plus its blue component (the third
     // float4 only carries cull extents the staging thread has in registers), no copy of the Gaussian ids (the flush reads
     // gid_sorted again)
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     __shared__ float sacc[RB_THREADS][RB_NGRAD];
     __shared__ RbLists S;
 
-    const int tile = blockIdx.x;
+    const int tile = RB_TILE_ORDER ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;        // longest lists first (tile_order_kernel)
     const uint32_t tlast = tile_last[tile];
     if (tlast == 0) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -432,12 +436,107 @@ __global__ void __launch_bounds__(RB_THREADS)
 
 
 
+// Workgroup -> tile map of the blend kernels: tiles in descending order of their list length CLASS (octaves), raster order
+// inside a class.  A view's tiles differ by two orders of magnitude in work and the hardware starts workgroups in index order:
+// with tile = workgroup id the last wave of workgroups holds whatever tiles the raster order put last, and the kernel ends when
+// the longest of them does; longest first, the tail is made of the shortest lists (LPT scheduling): blend forward 452 -> 401 us,
+// backward 958 -> 901 us on the headline scene (same box, profiles/r06_tile_order.txt).  Raster order inside a class keeps
+// neighbouring tiles — which read the same Gaussians' records — running together: with an arbitrary order inside
+// quarter-octave classes the heavy-pair scene LOST 2 % of its step.  One workgroup: a stable counting sort, thread t owns
+// a contiguous run of tiles and one counter per class ([class][thread] in LDS, scanned in that order).  Deterministic.
+#define TO_CLASSES 16
+#define TO_THREADS 1024
+#ifndef TO_DENSE
+#define TO_DENSE 4096u      // mean list length above which a view keeps the raster order
+#endif
+#ifndef TO_TOP
+#define TO_TOP 13            // lists of >= 2^(TO_TOP - 1) = 4096 entries share the top class (see below)
+#endif
+// 0: empty; class c >= 1: [2^(c-1), 2^c) entries; everything from 4096 entries on is ONE class: such lists saturate their pixels
+// long before their end, their length says nothing about their work, and sorting them by it only takes neighbouring tiles apart
+// (the heavy-pair scene — every list 16 k entries, a few hundred walked — lost 12-18 % of its blend kernels to that).
+__device__ __forceinline__ int to_class(uint32_t len) {
+    if (len == 0) return 0;
+    const int c = 32 - __clz(len);
+    return c < TO_TOP ? c : TO_TOP;
+}
+__global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(int nt, const uint2 *__restrict__ ranges, uint32_t *__restrict__ order) {
+    __shared__ uint32_t cnt[TO_CLASSES][TO_THREADS];       // 64 KB
+    __shared__ uint32_t wsum[TO_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nt + TO_THREADS - 1) / TO_THREADS;
+    const int t0 = tid * per, t1 = min(nt, t0 + per);
+#pragma unroll
+    for (int c = 0; c < TO_CLASSES; ++c) cnt[c][tid] = 0;
+    uint32_t total = 0;
+    for (int t = t0; t < t1; ++t) {
+        const uint2 r = ranges[t];
+        const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
+        total += len >> 4;                                        // (in units of 16 entries: no overflow at 2^32 pairs)
+        cnt[to_class(len)][tid] += 1;
+    }
+    // A view of LONG lists (mean above TO_DENSE entries per tile: the heavy-pair scene has 16 k) keeps the raster order: its
+    // tiles saturate after a few hundred entries whatever their length, there is no tail to cut, and running the densest tiles
+    // together costs the blend kernels 12-18 % (they stream their long lists through the same L2s at the same time, where the
+    // raster order mixes them with light tiles) — measured on both scenes, profiles/r06_tile_order.txt.
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (lane == 0) wsum[wave] = total;
+    __syncthreads();
+    total = 0;
+    for (int w = 0; w < TO_THREADS / 64; ++w) total += wsum[w];
+    __syncthreads();
+    if ((uint64_t)total * 16u > (uint64_t)nt * TO_DENSE) {
+        for (int t = t0; t < t1; ++t) order[t] = (uint32_t)t;
+        return;
+    }
+    // exclusive scan of the flat array in (class DESCENDING, thread ascending) order: thread j owns flat entries 16 j .. 16 j + 15
+    uint32_t v[TO_CLASSES], mine = 0;
+#pragma unroll
+    for (int k = 0; k < TO_CLASSES; ++k) {
+        const int f = tid * TO_CLASSES + k;                    // flat index: class = 15 - f / 1024, thread = f % 1024
+        v[k] = cnt[TO_CLASSES - 1 - f / TO_THREADS][f % TO_THREADS];
+        mine += v[k];
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TO_CLASSES; ++k) {
+        const int f = tid * TO_CLASSES + k;
+        cnt[TO_CLASSES - 1 - f / TO_THREADS][f % TO_THREADS] = run;
+        run += v[k];
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const uint2 r = ranges[t];
+        const int c = to_class(r.y > r.x ? r.y - r.x : 0u);
+        order[cnt[c][tid]++] = (uint32_t)t;
+    }
+}
+
+int cgs_launch_tile_order(const cgs_raster_cfg *cfg, CgsImg &im, hipStream_t stream) {
+    const int nt = cgs_tiles_x(cfg) * cgs_tiles_y(cfg);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(TO_THREADS), 0, stream, nt, (const uint2 *)im.ranges, im.tile_order);
+    CGS_CHECK_LAUNCH(stream, cfg->debug);
+    return CGS_OK;
+}
+
 int cgs_launch_blend_fwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, CgsImg &im, float *out_color,
                               hipStream_t stream) {
     const int tx = cgs_tiles_x(cfg), ty = cgs_tiles_y(cfg);
     hipLaunchKernelGGL(blend_fwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
                        cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted,
-                       (const float4 *)g.rec, cfg->bg, out_color, im.final_T, im.n_contrib, im.tile_last);
+                       (const float4 *)g.rec, cfg->bg, out_color, im.final_T, im.n_contrib, im.tile_last,
+                       (const uint32_t *)im.tile_order);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 }
@@ -450,7 +549,7 @@ int cgs_launch_blend_bwd_rows(const cgs_raster_cfg *cfg, CgsGeom &g, CgsBin &b, 
     hipLaunchKernelGGL(blend_bwd_rows_kernel, dim3((unsigned)(tx * ty)), dim3(RB_THREADS), 0, stream, cfg->image_width,
                        cfg->image_height, tx, (const uint2 *)im.ranges, (const uint32_t *)b.gid_sorted, rec,
                        cfg->bg, (const float *)im.final_T, (const uint32_t *)im.n_contrib, (const uint32_t *)im.tile_last,
-                       dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors);
+                       dL_dout, dL_dmean2D_px, dL_dconic, dL_dopacity, dL_dcolors, (const uint32_t *)im.tile_order);
     CGS_CHECK_LAUNCH(stream, cfg->debug);
     return CGS_OK;
 }
