@@ -218,6 +218,8 @@ SIGNATURES = {
     "cgs_l1_ssim_partials": (c_size_t, [c_int, c_int, c_int]),
     "cgs_l1_ssim_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "cgs_l1_ssim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cgs_l1_ssim_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "cgs_l1_ssim_bwd_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cgs_reg_partials": (c_size_t, [c_int64]),
     "cgs_scaling_reg_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_scaling_reg_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

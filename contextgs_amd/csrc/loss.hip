@@ -110,7 +110,11 @@ __global__ void __launch_bounds__(256)
 // dimg = g[0] / n * sign(img - gt) + g[1] / n * (conv(A) + 2 img conv(B) + gt conv(Cc)),  n = C H W
 __global__ void __launch_bounds__(256)
     l1_ssim_bwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ maps,
-                       const float *__restrict__ g, int H, int W, SsimWin win, float *__restrict__ dimg) {
+                       const float *__restrict__ g, const float *__restrict__ g_loss, float lam, int H, int W, SsimWin win,
+                       float *__restrict__ dimg) {
+    // g [2] (may be null): gradients of (L1, SSIM); g_loss [1] (may be null): gradient of (1 - lam) L1 + lam (1 - SSIM)
+    const float gl = g_loss ? g_loss[0] : 0.f;
+    const float g0 = (g ? g[0] : 0.f) + gl * (1.f - lam), g1 = (g ? g[1] : 0.f) - gl * lam;
     __shared__ float sm[3][SS_P][SS_P + 1];
     __shared__ float hq[3][SS_P][SS_T + 1];
     const int c = blockIdx.z, C = gridDim.z;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(256)
         const float inv_n = 1.f / ((float)C * (float)H * (float)W);
         const float d = x - y;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dimg[o] = g[0] * inv_n * sgn + g[1] * inv_n * (cA + 2.f * x * cB + y * cC);
+        dimg[o] = g0 * inv_n * sgn + g1 * inv_n * (cA + 2.f * x * cB + y * cC);
     }
 }
 
@@ -177,7 +181,50 @@ extern "C" int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *m
     static const SsimWin win = ssim_window();
     const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
     CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g, H, W, win, dimg);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g, (const float *)nullptr, 0.f,
+                       H, W, win, dimg);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+// The training image loss of train.py:199-204 as ONE value: out3 = (loss, L1, SSIM) with loss = (1 - lam) L1 + lam (1 - SSIM),
+// from the forward kernel's per-workgroup partial sums — one single-workgroup launch (fixed summation order) instead of torch's
+// sum / div / rsub / mul / add chain (~8 launches); and its backward with the gradient of `loss` (plus, optionally, of L1 / SSIM)
+// read on the device: no [2]-vector to build on the host side (~6 launches).
+__global__ void __launch_bounds__(256)
+    l1_ssim_finish_kernel(const float *__restrict__ partials, int64_t np, float inv_n, float lam, float *__restrict__ out3) {
+    __shared__ double sh[2][4];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < np; i += 256) { a += (double)partials[2 * i]; b += (double)partials[2 * i + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l1 = (float)((sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) * (double)inv_n);
+        const float ss = (float)((sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) * (double)inv_n);
+        out3[0] = (1.f - lam) * l1 + lam * (1.f - ss);
+        out3[1] = l1;
+        out3[2] = ss;
+    }
+}
+
+extern "C" int cgs_l1_ssim_finish(const float *partials, int C, int H, int W, float lam, float *out3, void *stream) {
+    if (C < 1 || H < 1 || W < 1 || !partials || !out3) { cgs_set_error("l1_ssim_finish: bad args"); return CGS_ERR_ARG; }
+    hipLaunchKernelGGL(l1_ssim_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials,
+                       (int64_t)cgs_l1_ssim_partials(C, H, W), 1.f / ((float)C * (float)H * (float)W), lam, out3);
+    CGS_CHECK_HIP(hipGetLastError());
+    return CGS_OK;
+}
+
+extern "C" int cgs_l1_ssim_bwd_loss(const float *img, const float *gt, const float *maps, const float *g_loss, const float *g2,
+                                    float lam, int C, int H, int W, float *dimg, void *stream) {
+    if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_bwd: bad shape"); return CGS_ERR_ARG; }
+    if (!img || !gt || !maps || (!g_loss && !g2) || !dimg) { cgs_set_error("l1_ssim_bwd: NULL"); return CGS_ERR_ARG; }
+    static const SsimWin win = ssim_window();
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g2, g_loss, lam, H, W, win, dimg);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }

@@ -69,8 +69,56 @@ def ssim(img1, img2, window_size=11, size_average=True):            # :33-63
     return l1_ssim(img1, img2)[1]
 
 
+class _TrainImageLoss(torch.autograd.Function):
+    """(loss, L1, SSIM) with loss = (1 - lam) L1 + lam (1 - SSIM) as ONE node: the forward kernel, a single-workgroup finish
+    launch (partials -> the three values) and one backward launch that reads the gradient of `loss` on the device — the scalar
+    arithmetic around _L1Ssim cost ~14 tiny launches per training step (profiles/r06_loss.txt)."""
+
+    @staticmethod
+    def forward(ctx, img, gt, lam):
+        _lib.require_device(img, gt)
+        x = img if (img.dtype == torch.float32 and img.is_contiguous()) else img.float().contiguous()
+        y = gt if (gt.dtype == torch.float32 and gt.is_contiguous()) else gt.float().contiguous()
+        if x.shape != y.shape or x.dim() != 3:
+            raise ValueError("training_image_loss expects two [C,H,W] images of the same shape")
+        C, H, W = x.shape
+        L = _lib.lib()
+        need = ctx.needs_input_grad[0]
+        maps = torch.empty(3, C, H, W, dtype=torch.float32, device=x.device) if need else None
+        partials = torch.empty(int(L.cgs_l1_ssim_partials(C, H, W)), 2, dtype=torch.float32, device=x.device)
+        st = _lib.current_stream()
+        _lib.check(L.cgs_l1_ssim_fwd(_lib.ptr(x), _lib.ptr(y), C, H, W, _lib.ptr(maps), _lib.ptr(partials), st), "cgs_l1_ssim_fwd")
+        out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        _lib.check(L.cgs_l1_ssim_finish(_lib.ptr(partials), C, H, W, float(lam), _lib.ptr(out3), st), "cgs_l1_ssim_finish")
+        if need:
+            ctx.save_for_backward(x, y, maps)
+        ctx.lam = float(lam)
+        ctx.set_materialize_grads(False)
+        return out3[0], out3[1], out3[2]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_l1, g_ssim):
+        x, y, maps = ctx.saved_tensors
+        C, H, W = x.shape
+        g2 = None
+        if g_l1 is not None or g_ssim is not None:      # (L1 / SSIM read by the objective as well: rare — they are logged)
+            z = torch.zeros((), dtype=torch.float32, device=x.device)
+            g2 = torch.stack([z if g_l1 is None else g_l1.float().reshape(()), z if g_ssim is None else g_ssim.float().reshape(())])
+        if g_loss is None and g2 is None:
+            return None, None, None
+        gl = None if g_loss is None else g_loss.float().reshape(1).contiguous()
+        dimg = torch.empty_like(x)
+        _lib.check(_lib.lib().cgs_l1_ssim_bwd_loss(_lib.ptr(x), _lib.ptr(y), _lib.ptr(maps), _lib.ptr(gl), _lib.ptr(g2), ctx.lam, C, H, W,
+                                                   _lib.ptr(dimg), _lib.current_stream()), "cgs_l1_ssim_bwd_loss")
+        return dimg, None, None
+
+
 def training_image_loss(image, gt, lambda_dssim: float = 0.2):
-    """(1 - lambda) L1 + lambda (1 - SSIM) of train.py:199-204, both terms from the same launch."""
+    """((1 - lambda) L1 + lambda (1 - SSIM), L1, SSIM) of train.py:199-204 from one node (three launches per training step)."""
+    if image.dim() == 4 and image.shape[0] == 1:
+        image, gt = image[0], gt[0]
+    if image.is_cuda and image.dim() == 3 and image.shape == gt.shape:
+        return _TrainImageLoss.apply(image, gt, float(lambda_dssim))
     l1, s = l1_ssim(image, gt)
     return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - s), l1, s
 

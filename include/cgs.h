@@ -1037,6 +1037,13 @@ int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, int W,
 int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *maps,
                     const float *g, int C, int H, int W, float *dimg,
                     void *stream);
+/* train.py:199-204 as one value: out3 = (loss, L1, SSIM), loss = (1 - lam) L1 + lam (1 - SSIM), from cgs_l1_ssim_fwd's partials
+ * (one single-workgroup launch, fixed summation order); and the backward with the gradient of `loss` read on the device
+ * (g_loss [1]; g2 [2] = optional extra gradients of (L1, SSIM); either may be NULL, not both). */
+int cgs_l1_ssim_finish(const float *partials, int C, int H, int W, float lam, float *out3,
+                       void *stream);
+int cgs_l1_ssim_bwd_loss(const float *img, const float *gt, const float *maps, const float *g_loss,
+                         const float *g2, float lam, int C, int H, int W, float *dimg, void *stream);
 
 /* sum_i img[i] * w[i] + lam * rate[0] (rate may be NULL) -> out [1], and its backward dimg = g[0] * w, drate[0] = g[0] * lam
  * (drate may be NULL): the linear objective a throughput measurement puts behind render() (train.py:206-209 with the image term

@@ -167,3 +167,28 @@ def test_weighted_image_sum_matches_torch_fp64(n, with_rate):
     assert torch.equal(img.grad, 2.0 * w)
     if with_rate:
         assert abs(float(rate.grad) - 0.002) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_training_image_loss_one_node_matches_goldens(tag):
+    """training_image_loss (train.py:199-204 as one node: forward kernel + finish + one backward launch) against the reference's
+    goldens and against the two-output node it replaces; the extra outputs (L1, SSIM) stay differentiable."""
+    import torch
+    from contextgs_amd.loss_utils import l1_ssim, training_image_loss
+    c = _case(tag)
+    img = torch.tensor(c["img"], device="cuda", requires_grad=True)
+    gt = torch.tensor(c["gt"], device="cuda")
+    loss, l1, s = training_image_loss(img, gt, 0.2)
+    assert abs(float(l1) - float(c["l1"])) < 1e-6 and abs(float(s) - float(c["ssim"])) < 2e-6
+    assert abs(float(loss) - (0.8 * float(c["l1"]) + 0.2 * (1.0 - float(c["ssim"])))) < 2e-6
+    (g,) = torch.autograd.grad(loss, [img], retain_graph=True)
+    assert np.abs(g.cpu().numpy() - c["grad"]).max() < 2e-7 + 2e-4 * np.abs(c["grad"]).max()
+    l1b, sb = l1_ssim(img, gt)
+    (gb,) = torch.autograd.grad(0.8 * l1b + 0.2 * (1.0 - sb), [img])
+    assert float((g - gb).abs().max()) <= 1e-6 * float(gb.abs().max()) + 1e-12
+    # an objective that also reads L1 and SSIM directly
+    (g2,) = torch.autograd.grad(2.0 * loss + 0.5 * l1 - 0.25 * s, [img])
+    l1c, sc = l1_ssim(img, gt)
+    (g2b,) = torch.autograd.grad(2.0 * (0.8 * l1c + 0.2 * (1.0 - sc)) + 0.5 * l1c - 0.25 * sc, [img])
+    assert float((g2 - g2b).abs().max()) <= 2e-6 * float(g2b.abs().max()) + 1e-12
