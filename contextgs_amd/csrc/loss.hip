@@ -406,20 +406,30 @@ extern "C" int cgs_sigmoid_mean_bwd(const float *x, const float *g, int64_t n, f
 // train.py:206-209 with the image term made linear) as ONE launch each way instead of dot (2 launches) + add and two muls.
 // Deterministic: per-workgroup partial sums in double, the last workgroup to finish adds them in workgroup order and clears the
 // counter for the next call (scratch = WS_BLOCKS doubles + one zero-initialised uint32, owned by the caller).
-#define WS_BLOCKS 1024
+#define WS_BLOCKS 256       // (one same-address atomic per workgroup closes the launch: ~25 ns each, 1024 of them were most of the kernel)
 __global__ void __launch_bounds__(256)
     wsum_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, const float *__restrict__ rate, float lam,
                     double *__restrict__ partial, unsigned int *__restrict__ counter, float *__restrict__ out) {
     __shared__ double sh[4];
     __shared__ bool last;
     const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double acc = 0.0;
+    // a thread's own terms (a few dozen) are added in fp32, four independent chains with two 16-byte loads per operand in flight;
+    // everything across threads and workgroups in double
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
     const int64_t n4 = ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) ? n / 4 : 0;
-    for (int64_t i = t0; i < n4; i += stride) {
+    int64_t i = t0;
+    for (; i + stride < n4; i += 2 * stride) {
         const float4 x = ((const float4 *)a)[i], y = ((const float4 *)b)[i];
-        acc += (double)(x.x * y.x) + (double)(x.y * y.y) + (double)(x.z * y.z) + (double)(x.w * y.w);
+        const float4 x2 = ((const float4 *)a)[i + stride], y2 = ((const float4 *)b)[i + stride];
+        f0 = fmaf(x.x, y.x, f0); f1 = fmaf(x.y, y.y, f1); f2 = fmaf(x.z, y.z, f2); f3 = fmaf(x.w, y.w, f3);
+        f0 = fmaf(x2.x, y2.x, f0); f1 = fmaf(x2.y, y2.y, f1); f2 = fmaf(x2.z, y2.z, f2); f3 = fmaf(x2.w, y2.w, f3);
     }
-    for (int64_t i = 4 * n4 + t0; i < n; i += stride) acc += (double)(a[i] * b[i]);
+    for (; i < n4; i += stride) {
+        const float4 x = ((const float4 *)a)[i], y = ((const float4 *)b)[i];
+        f0 = fmaf(x.x, y.x, f0); f1 = fmaf(x.y, y.y, f1); f2 = fmaf(x.z, y.z, f2); f3 = fmaf(x.w, y.w, f3);
+    }
+    for (int64_t j = 4 * n4 + t0; j < n; j += stride) f0 = fmaf(a[j], b[j], f0);
+    double acc = ((double)f0 + (double)f1) + ((double)f2 + (double)f3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
