@@ -967,6 +967,60 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The same sums with FOUR parents per wave (round 6): a 16-lane group owns a parent, a lane four consecutive columns (one 16-byte
+// load per child row: 15 lanes cover the 59 columns of the reference's shapes, wa 3 + DF 50 + DS 6), and four children's rows are
+// requested before the first is added.  The one-parent-per-wave kernel above is a chain of three dependent round trips per parent
+// (list bounds, child indices, rows) with ~5 children each: 1.4 TB/s; four independent chains per wave and a quarter of the
+// instructions per byte.  Same additions in the same (child) order per column.
+__global__ void __launch_bounds__(256)
+    ctx_gather_bwd4_kernel(const float *__restrict__ dout, int64_t ldo, int64_t n_parents,
+                           const int64_t *__restrict__ offs, const int64_t *__restrict__ order,
+                           const int64_t *__restrict__ parent_row, float *__restrict__ d_anchor,
+                           float *__restrict__ d_f, float *__restrict__ d_s, int acc_anchor) {
+    constexpr int WA = 3, DF = 50, DS = 6, W = WA + DF + DS;
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int64_t stride = (int64_t)gridDim.x * 16;
+    for (int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; p0 < n_parents; p0 += stride) {
+        const int64_t p = p0 + grp;
+        const bool live = p < n_parents;
+        const int64_t b = live ? offs[p] : 0, e = live ? offs[p + 1] : 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool col_ok = 4 * sub < W;                     // lanes 0..14
+        for (int64_t k = b; __builtin_amdgcn_ballot_w64(k < e) != 0ull; k += 4) {
+            int64_t child[4];
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) child[u] = (k + u < e) ? order[k + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = col_ok && (k + u < e);
+                // (16-byte load at a 4-byte-aligned address: rows are ldo floats apart)
+                v[u] = ok ? *(const float4 *)(dout + child[u] * ldo + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k + u < e) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+        }
+        if (!live || !col_ok) continue;
+        const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * sub + j;
+            if (c >= W) continue;
+            const float vv = a4[j];
+            if (c < WA) {
+                if (d_anchor && e > b) { float *q = d_anchor + parent_row[p] * WA + c; *q = (acc_anchor & 1) ? *q + vv : vv; }
+            } else if (c < WA + DF) {
+                if (d_f) { float *q = d_f + p * DF + (c - WA); *q = (acc_anchor & 2) ? *q + vv : vv; }
+            } else if (d_s) {
+                float *q = d_s + p * DS + (c - WA - DF);
+                *q = (acc_anchor & 4) ? *q + vv : vv;
+            }
+        }
+    }
+}
+
 extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
                                       const int64_t *order, const int64_t *parent_row, float *d_anchor, float *d_f,
                                       float *d_s, int wa, int DF, int DS, int accumulate_anchor, void *stream);
@@ -975,6 +1029,7 @@ extern "C" int cgs_ctx_gather_bwd(const float *dout, int64_t ldo, int64_t n_pare
                                   float *d_s, int wa, int DF, int DS, void *stream) {
     return cgs_ctx_gather_bwd_acc(dout, ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, 0, stream);
 }
+static const bool g_gather1 = getenv("CGS_CTX_GATHER1") != nullptr;       // A/B knob: the one-parent-per-wave kernel
 // accumulate_anchor: bit 0 = d_anchor rows are ADDED to (the levels of one backward share one anchor-gradient buffer);
 // bit 1 / bit 2 = d_f / d_s rows are added to (they are the first rows of the gradient buffer of the level outputs)
 extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_parents, const int64_t *offs,
@@ -987,6 +1042,12 @@ extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_
     if (n_parents == 0) return CGS_OK;
     if (!dout || !offs || !order || (d_anchor && !parent_row)) { cgs_set_error("ctx_gather_bwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
+    if (wa == 3 && DF == 50 && DS == 6 && ldo >= 60 && !g_gather1) {      // (ldo >= 60: the 15th lane's 16-byte load stays inside its row)
+        hipLaunchKernelGGL(ctx_gather_bwd4_kernel, dim3(stream_grid(n_parents, 16 * 2)), dim3(256), 0, (hipStream_t)stream, dout, ldo,
+                           n_parents, offs, order, parent_row, d_anchor, d_f, d_s, accumulate_anchor & 7);
+        CGS_CHECK_HIP(hipGetLastError());
+        return CGS_OK;
+    }
     hipLaunchKernelGGL(ctx_gather_bwd_kernel, dim3(stream_grid(n_parents, 4 * 8)), dim3(256), 0, (hipStream_t)stream, dout,
                        ldo, n_parents, offs, order, parent_row, d_anchor, d_f, d_s, wa, DF, DS, accumulate_anchor & 7);
     CGS_CHECK_HIP(hipGetLastError());
