@@ -394,7 +394,8 @@ def _upload_small(arrays, dev, key=None):
     return out
 
 
-def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None, deferred=False):
+def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False, lanes=False, overlap=None, deferred=False,
+                           stage_key="bitstream", copy_stream=None, ready_out=None):
     """x/mean/scale flat [n] device tensors, element i uses Q[i // q_div]; stream_off int64 [S+1]
     (device or host).  Every stream is coded by its own wave of ONE launch.  Returns (blob, lens, min, max):
     blob = uint8 ndarray holding the S streams back to back (exactly the bytes of the reference's
@@ -459,18 +460,31 @@ def gaussian_encode_packed(x, mean, scale, Q, stream_off, q_div=1, staging=False
         # stage_ready()) lets the writer threads start on a piece the moment it has landed, so the ~5 ms of PCIe and the
         # ~5 ms of page-cache writes of a 1 M-anchor container overlap instead of adding up.
         mnmx_h = mnmx.cpu().numpy()                   # (before the big copies: this read drains the stream)
-        stage = _pinned_staging(nbytes)
+        stage = _pinned_staging(nbytes, stage_key)
         events = []
-        for lo in range(0, nbytes, _STAGE_PIECE):
-            hi = min(nbytes, lo + _STAGE_PIECE)
-            stage[lo:hi].copy_(packed[lo:hi], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            events.append(ev)
-        _STAGE_READY = StageReady(stage.data_ptr(), nbytes, events, packed)
+        # copy_stream (a side stream): the download runs beside whatever the caller queues on the current stream next — the coder
+        # launch of the next range of groups (gaussian_encode_groups(on_range=))
+        cs = copy_stream if copy_stream is not None else torch.cuda.current_stream(dev)
+        if copy_stream is not None:
+            copy_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cs):
+            for lo in range(0, nbytes, _STAGE_PIECE):
+                hi = min(nbytes, lo + _STAGE_PIECE)
+                stage[lo:hi].copy_(packed[lo:hi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+                events.append(ev)
+        if copy_stream is not None:
+            packed.record_stream(copy_stream)
+        ready = StageReady(stage.data_ptr(), nbytes, events, packed)
+        if ready_out is not None:
+            ready_out.append(ready)
+        else:
+            _STAGE_READY = ready
         if not deferred:
-            _STAGE_READY.wait_all()
-            _STAGE_READY = None
+            ready.wait_all()
+            if ready_out is None:
+                _STAGE_READY = None
         blob = stage.numpy()[:nbytes]
     else:
         blob = packed.cpu().numpy()[:nbytes]
@@ -509,14 +523,60 @@ def _expand_q(Q, q_div):
     return Q if q_div == 1 else Q.repeat_interleave(int(q_div))
 
 
-def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None, deferred=False):
+RANGE_MIN_SYMBOLS = 16 << 20          # below this many symbols the groups go through one coder launch
+
+
+def _group_ranges(groups):
+    """Consecutive runs of groups, each at most ~40 % of the symbols (a group larger than that is a run of its own)."""
+    sizes = [int(g_[0].numel()) for g_ in groups]
+    total = sum(sizes)
+    runs, cur, acc = [], [], 0
+    for i, n in enumerate(sizes):
+        if cur and acc + n > 0.4 * total:
+            runs.append(cur); cur, acc = [], 0
+        cur.append(i); acc += n
+    if cur:
+        runs.append(cur)
+    return runs, total
+
+
+_COPY_STREAMS = {}
+
+
+def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None, deferred=False, on_range=None):
     """groups = [(x, mean, scale, Q, stream_off, q_div), ...] -> [(blob, lens, min, max), ...] (see gaussian_encode_packed).
     staging: download through the module's reused pinned buffer; the blobs then alias it until the next staging call.
     All streams of all groups go through ONE coder launch: a stream is a serial chain on one wave, so the launch
-    lasts as long as its longest stream however many streams it holds."""
+    lasts as long as its longest stream however many streams it holds.
+    on_range (with staging + deferred, one process, a large model): the groups are coded in 2-4 consecutive RANGES, a launch
+    each, and on_range(indices, results, ready) is called as soon as a range's stream lengths are on the host — its download
+    (a side stream, a pinned buffer of its own) and whatever the callback starts (the file writers) then run beside the coder
+    launch of the next range instead of behind the last one.  Same bytes: a range's streams are the same streams."""
     groups = list(groups)
     if not groups:
         return []
+    from . import dist as _D0
+    if on_range is not None and staging and deferred and _D0.world() == 1:
+        runs, total = _group_ranges(groups)
+        if len(runs) > 1 and total >= RANGE_MIN_SYMBOLS:
+            dev = groups[0][0].device
+            cs = _COPY_STREAMS.get(dev)
+            if cs is None:
+                cs = _COPY_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            out = [None] * len(groups)
+            for r, idxs in enumerate(runs):
+                sub = [groups[i] for i in idxs]
+                ready_out = []
+                res = _encode_group_run(sub, lanes, overlap if r == 0 else None, f"bitstream{r}", cs, ready_out)
+                for i, one in zip(idxs, res):
+                    out[i] = one
+                on_range(idxs, res, ready_out[0] if ready_out else None)
+            return out
+    return _encode_group_run(groups, lanes, overlap, "bitstream", None, None, staging=staging, deferred=deferred)
+
+
+def _encode_group_run(groups, lanes, overlap, stage_key, copy_stream, ready_out, staging=True, deferred=True):
+    """One coder launch over `groups` (see gaussian_encode_groups)."""
     xs, ms, ss, qs, edges, counts, base = [], [], [], [], [torch.zeros(1, dtype=torch.int64)], [], 0
     dev = groups[0][0].device
     _lib.require_device(*[t for g_ in groups for t in g_[:4]])
@@ -546,7 +606,8 @@ def gaussian_encode_groups(groups, staging=False, lanes=False, overlap=None, def
             return None
         blob, lens, mn, mx = (np.concatenate([p[i] for p in parts]) for i in range(4))
     else:
-        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes, overlap=overlap, deferred=deferred)
+        blob, lens, mn, mx = gaussian_encode_packed(X, M, Sc, Qe, E, 1, staging=staging, lanes=lanes, overlap=overlap, deferred=deferred,
+                                                    stage_key=stage_key, copy_stream=copy_stream, ready_out=ready_out)
         overlap = None
     if overlap is not None:
         overlap()

@@ -54,6 +54,13 @@ V2_CHUNK = {"masks": 1000}               # anchors per mask chunk stream
 V2_HYPER_BLOCK = 64 * 512                # anchors of one channel per hyper.b block (lane-parallel table coder)
 
 
+# 1 = the groups coded in 2-4 ranges, a range's files handed to the writers while the next range is coded (codec.gaussian_encode_groups(
+# on_range=)).  Built and measured in round 6: no gain — 17.4-17.7 ms against 16.9-18.0 ms at 1 M anchors; the encode ends when the
+# LARGEST file (feat0.b, 60 MB) is in the page cache, buffered writes to one file serialise on its inode lock (~10 GB/s whatever the
+# number of writers), and under the coder's downloads they run slower still (profiles/r06_codec_ranges.txt).  Off.
+RANGED_ENCODE = os.environ.get("CGS_RANGED_ENCODE", "0") != "0"
+
+
 def default_container_version():
     return int(os.environ.get("CGS_CONTAINER_VERSION", CONTAINER_VERSION))
 
@@ -472,7 +479,19 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
         if root:
             with torch.cuda.stream(_side_stream(_mask.device, "mlp")):
                 save_mlp_checkpoints(pc, path("mlp.pt"))
-    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes, overlap=write_mlp, deferred=True)   # blobs alias a pinned buffer
+    # (version 2, one process, a large model: the groups are coded in 2-4 ranges and a range's files are handed to the writers as soon
+    #  as its stream lengths are known — its download and its page-cache writes run beside the next range's coder launch instead of
+    #  behind the last one; tools/codec_trace.sh)
+    early_written = set()
+
+    def on_range(idxs, results, ready_r):
+        for gi, (blob_r, _l, _mn, _mx) in zip(idxs, results):
+            name_r, level_r = tags[gi]
+            writes.extend(codec.write_file(path(f"{name_r}{level_r}.b"), blob_r, ready=ready_r))
+            early_written.add(gi)
+        tr(f"range of {len(idxs)} groups coded, writers started")
+    coded = codec.gaussian_encode_groups(groups, staging=True, lanes=lanes, overlap=write_mlp, deferred=True,
+                                         on_range=on_range if (root and lanes and RANGED_ENCODE) else None)   # blobs alias pinned buffers
     ready = codec.stage_ready()          # the download is still in flight: the file writers below wait piece by piece
     tr("coder launch done, download queued")
     if not root:
@@ -482,8 +501,9 @@ def conduct_encoding(pc, pre_path_name, container_version=None):   # :1007-1295
     bit_d = {"feat": {}, "scaling": {}, "offsets": {}}
     min_d = {"feat": {}, "scaling": {}, "offsets": {}}
     max_d = {"feat": {}, "scaling": {}, "offsets": {}}
-    for (name, level), (blob, lens, mn, mx) in zip(tags, coded):
-        writes += codec.write_file(path(f"{name}{level}.b"), blob, ready=ready)           # :1235-1238
+    for gi, ((name, level), (blob, lens, mn, mx)) in enumerate(zip(tags, coded)):
+        if gi not in early_written:
+            writes += codec.write_file(path(f"{name}{level}.b"), blob, ready=ready)       # :1235-1238
         if version == 2:      # arrays: thousands of blocks as Python ints cost the decoder's unpickling a garbage-collector pass
             bit_d[name][level], min_d[name][level], max_d[name][level] = lens * 8, mn.astype(np.int32), mx.astype(np.int32)
         else:
