@@ -310,6 +310,8 @@ def test_early_launches_fall_back_when_the_plan_turns_out_stale():
     (context_model._early_levels).  Moving anchors between two steps makes the plan stale AFTER they were enqueued: the step must
     rebuild the plan and run the plain way (context_model._EarlyMismatch), with finite results and gradients everywhere."""
     from contextgs_amd import context_model as cm
+    if not cm.EARLY_LEVELS:
+        pytest.skip("CGS_EARLY_LEVELS=0: nothing is enqueued early")
     pc, cams, pipe, bg = _setup(N=12000, W=256, H=144, seed=7)
     _ctx_step(pc, cams[0], pipe, bg)                     # builds the plan
     _ctx_step(pc, cams[1], pipe, bg)                     # a step on the cached plan: the early path
