@@ -46,17 +46,39 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *t
     return wbase + inc - v;
 }
 
+// A thread's SCAN_ITEMS (8) consecutive items as two 16-byte accesses when the run lies inside [0, n) and on a 16-byte boundary
+// (it does for every full tile of a 16-byte-aligned array); element by element otherwise.  (Round 6: the element-wise form made
+// every load instruction of a wave touch all of the wave's 64 32-byte segments for 4 bytes each.)
+__device__ __forceinline__ void scan_load8(const uint32_t *__restrict__ in, int64_t base, int64_t n, uint32_t (&v)[SCAN_ITEMS]) {
+    static_assert(SCAN_ITEMS == 8, "scan_load8");
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 15) == 0) {
+        const uint4 a = *(const uint4 *)(in + base), b = *(const uint4 *)(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? in[base + i] : 0u;
+    }
+}
+__device__ __forceinline__ void scan_store8(uint32_t *__restrict__ out, int64_t base, int64_t n, const uint32_t (&v)[SCAN_ITEMS]) {
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)(out + base)) & 15) == 0) {
+        *(uint4 *)(out + base) = make_uint4(v[0], v[1], v[2], v[3]);
+        *(uint4 *)(out + base + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i)
+            if (base + i < n) out[base + i] = v[i];
+    }
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in,
                                                                    uint32_t *__restrict__ sums,
                                                                    int64_t n) {
     __shared__ uint32_t lds_wave[4];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    uint32_t acc = 0;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], acc = 0;
+    scan_load8(in, base, n, v);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
-        if (idx < n) acc += in[idx];
-    }
+    for (int i = 0; i < SCAN_ITEMS; ++i) acc += v[i];
     uint32_t tot;
     block_exclusive_scan(acc, &tot, lds_wave);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -71,21 +93,16 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t acc = 0;
+    scan_load8(in, base, n, v);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + i;
-        v[i] = idx < n ? in[idx] : 0u;
-        acc += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; ++i) acc += v[i];
     uint32_t tot;
     uint32_t excl = block_exclusive_scan(acc, &tot, lds_wave);
     uint32_t run = excl + (block_offsets ? block_offsets[blockIdx.x] : 0u);
+    uint32_t o[SCAN_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + i;
-        if (idx < n) out[idx] = run;
-        run += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; ++i) { o[i] = run; run += v[i]; }
+    scan_store8(out, base, n, o);
     if (grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1)
         *grand_total = run;
 }
@@ -106,21 +123,16 @@ __global__ void __launch_bounds__(SCAN_THREADS)
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t acc = 0;
+    scan_load8(in, base, n, v);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + i;
-        v[i] = idx < n ? in[idx] : 0u;
-        acc += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; ++i) acc += v[i];
     uint32_t tot;
     uint32_t excl = block_exclusive_scan(acc, &tot, lds_wave);
     uint32_t run = excl + block_base;
+    uint32_t o[SCAN_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        int64_t idx = base + i;
-        if (idx < n) out[idx] = run;
-        run += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; ++i) { o[i] = run; run += v[i]; }
+    scan_store8(out, base, n, o);
     if (grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1)
         *grand_total = run;
 }
