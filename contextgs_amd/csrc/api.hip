@@ -251,7 +251,7 @@ static int raster_count_tail(int64_t P, CgsGeom &g, RasterCountSlot &sl, hipStre
 // P = the count it returned); scaling_out [P,3] receives the Gaussians' scales (the one per-Gaussian tensor the training
 // loss reads), xyz_out [P,3] / rot_out [P,4] (both or neither) the positions and rotations for a later cgs_raster_backward.
 // Everything downstream (cgs_raster_render*, _wait, cgs_raster_backward + cgs_expand_backward) is unchanged.
-extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anchor, int K, const uint32_t *flags,
+extern "C" int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anchor, int K, const uint8_t *flags,
                                                    const uint32_t *pos, const float *anchor, const float *gscaling,
                                                    const float *offsets, const float *neural_opacity, const float *color_in,
                                                    const float *cov_in, const int64_t *src_row, int64_t P, float *scaling_out,

@@ -169,7 +169,8 @@ int cgs_launch_preprocess_bwd(const cgs_raster_cfg *cfg, int64_t P, const float4
 struct CgsExpandSrc {
     int64_t n_anchor;
     int K;
-    const uint32_t *flags, *pos;
+    const uint8_t *flags;      // survivor flags, one byte per slot (cgs_expand_count's mask_out)
+    const uint32_t *pos;
     const float *anchor, *gscaling, *offsets, *neural_opacity, *color_in, *cov_in;
     const int64_t *src_row;
 };

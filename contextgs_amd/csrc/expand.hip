@@ -27,12 +27,12 @@ __global__ void __launch_bounds__(EX_THREADS)
     const float v = op_raw[i] * mask[i];
     neural_opacity[i] = v;
     const bool f = v > 0.f;
-    flags[i] = f ? 1u : 0u;
+    if (flags) flags[i] = f ? 1u : 0u;         // (optional uint32 copy; the kernels of this library read the bytes of mask_out)
     mask_out[i] = f ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(EX_THREADS)
-    expand_write_kernel(int64_t n_slots, int K, const uint32_t *__restrict__ flags,
+    expand_write_kernel(int64_t n_slots, int K, const uint8_t *__restrict__ flags,
                         const uint32_t *__restrict__ pos, const float *__restrict__ anchor,
                         const float *__restrict__ gscaling, const float *__restrict__ offsets,
                         const float *__restrict__ neural_opacity, const float *__restrict__ color_in,
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(EX_THREADS)
 // and no LDS float atomics (ten slots of an anchor hit the same address; ds_add_f32 retires < 1 lane per clock).
 // Workgroup = EX_APB anchors x K slots; dynamic LDS = 9 * blockDim floats.
 __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
-    expand_bwd_kernel(int64_t n_anchor, int K, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
+    expand_bwd_kernel(int64_t n_anchor, int K, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ pos,
                       const float *__restrict__ gscaling, const float *__restrict__ offsets,
                       const float *__restrict__ op_raw, const float *__restrict__ mask,
                       const float *__restrict__ cov_in, const float *__restrict__ g_xyz,
@@ -159,14 +159,14 @@ __global__ void __launch_bounds__(EX_APB * EX_MAX_K)
     }
 }
 
-int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
-                                 size_t scratch_bytes, uint32_t *grand_total, hipStream_t stream);
+int cgs_scan_exclusive_u8_total(const uint8_t *in, uint32_t *out, int64_t n, void *scratch, size_t scratch_bytes,
+                                uint32_t *grand_total, hipStream_t stream);
 
 extern "C" size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K) {
     return cgs_scan_scratch_bytes(n_anchor * (int64_t)K) + 256;
 }
 
-// Pass A + scan.  flags/pos are uint32 [n_anchor*K] kept by the caller for pass B
+// Pass A + scan.  mask_out (survivor flags, one byte per slot) / pos (uint32) [n_anchor*K] are kept by the caller for pass B
 // and the backward; the number of surviving Gaussians goes to the host through a pinned
 // slot + event: cgs_expand_count_launch enqueues everything and returns, cgs_expand_count_wait
 // blocks on THAT copy only (hipEventSynchronize), so work the caller enqueued in between keeps
@@ -193,7 +193,7 @@ extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_
     const int64_t n = n_anchor * K;
     if (n == 0) return CGS_OK;
     if (n >= (1ll << 31)) { cgs_set_error("expand_count: too many slots"); return CGS_ERR_ARG; }
-    if (!op_raw || !mask || !neural_opacity || !mask_out || !flags || !pos || !scratch) {
+    if (!op_raw || !mask || !neural_opacity || !mask_out || !pos || !scratch) {
         cgs_set_error("expand_count: NULL");
         return CGS_ERR_ARG;
     }
@@ -203,7 +203,7 @@ extern "C" int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_
     // grand total lands in the last 4 bytes of the scratch area
     if (scratch_bytes < cgs_expand_scratch_bytes(n_anchor, K)) { cgs_set_error("expand_count: scratch too small"); return CGS_ERR_WORKSPACE; }
     uint32_t *total = (uint32_t *)((char *)scratch + scratch_bytes - 256);
-    int rc = cgs_scan_exclusive_u32_total(flags, pos, n, scratch, scratch_bytes - 256, total, stream);
+    int rc = cgs_scan_exclusive_u8_total(mask_out, pos, n, scratch, scratch_bytes - 256, total, stream);      // (bytes: a quarter of the reads)
     if (rc) return rc;
     CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
@@ -240,7 +240,7 @@ extern "C" int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw, co
     return cgs_expand_count_wait(ticket, count_host);
 }
 
-extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags, const uint32_t *pos,
+extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint8_t *flags, const uint32_t *pos,
                                 const float *anchor, const float *gscaling, const float *offsets,
                                 const float *neural_opacity, const float *color_in, const float *cov_in, float *xyz,
                                 float *color, float *opacity, float *scaling, float *rot, const int64_t *src_row,
@@ -256,7 +256,7 @@ extern "C" int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags, 
     return CGS_OK;
 }
 
-extern "C" int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags, const uint32_t *pos,
+extern "C" int cgs_expand_backward(int64_t n_anchor, int K, const uint8_t *flags, const uint32_t *pos,
                                    const float *gscaling, const float *offsets, const float *op_raw,
                                    const float *mask, const float *cov_in, const float *g_xyz, const float *g_color,
                                    const float *g_opacity, const float *g_scaling, const float *g_rot,

@@ -44,7 +44,7 @@ __device__ __forceinline__ XrSlot xr_slot(const float *__restrict__ anchor3, con
 }
 
 __global__ void __launch_bounds__(XR_THREADS)
-    expand_preprocess_kernel(int64_t n_slots, int K, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos,
+    expand_preprocess_kernel(int64_t n_slots, int K, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ pos,
                              const float *__restrict__ anchor, const float *__restrict__ gscaling,
                              const float *__restrict__ offsets, const float *__restrict__ neural_opacity,
                              const float *__restrict__ color_in, const float *__restrict__ cov_in,

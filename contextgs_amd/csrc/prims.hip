@@ -59,6 +59,17 @@ __device__ __forceinline__ void scan_load8(const uint32_t *__restrict__ in, int6
         for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? in[base + i] : 0u;
     }
 }
+// (uint8 input — survivor flags, one byte per slot: a thread's eight bytes are one 8-byte load)
+__device__ __forceinline__ void scan_load8(const uint8_t *__restrict__ in, int64_t base, int64_t n, uint32_t (&v)[SCAN_ITEMS]) {
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 7) == 0) {
+        const uint2 a = *(const uint2 *)(in + base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (a.x >> (8 * i)) & 0xFFu; v[4 + i] = (a.y >> (8 * i)) & 0xFFu; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? (uint32_t)in[base + i] : 0u;
+    }
+}
 __device__ __forceinline__ void scan_store8(uint32_t *__restrict__ out, int64_t base, int64_t n, const uint32_t (&v)[SCAN_ITEMS]) {
     if (base + SCAN_ITEMS <= n && (((uintptr_t)(out + base)) & 15) == 0) {
         *(uint4 *)(out + base) = make_uint4(v[0], v[1], v[2], v[3]);
@@ -70,7 +81,8 @@ __device__ __forceinline__ void scan_store8(uint32_t *__restrict__ out, int64_t 
     }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in,
+template <typename IN>
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const IN *__restrict__ in,
                                                                    uint32_t *__restrict__ sums,
                                                                    int64_t n) {
     __shared__ uint32_t lds_wave[4];
@@ -85,8 +97,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_
 }
 
 // Scans one tile per block.  block_offsets == nullptr => single-tile call.
+template <typename IN>
 __global__ void __launch_bounds__(SCAN_THREADS)
-    scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    scan_apply_kernel(const IN *__restrict__ in, uint32_t *__restrict__ out,
                       const uint32_t *__restrict__ block_offsets, int64_t n,
                       uint32_t *__restrict__ grand_total) {
     __shared__ uint32_t lds_wave[4];
@@ -111,8 +124,9 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 // up the totals of the blocks before it itself (<= SCAN_SELF_PREFIX_MAX values, L2-resident), which removes the
 // recursive scan of the block sums: two launches per scan instead of three to five.
 #define SCAN_SELF_PREFIX_MAX 16384
+template <typename IN>
 __global__ void __launch_bounds__(SCAN_THREADS)
-    scan_apply_selfprefix_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+    scan_apply_selfprefix_kernel(const IN *__restrict__ in, uint32_t *__restrict__ out,
                                  const uint32_t *__restrict__ block_totals, int64_t n, uint32_t *__restrict__ grand_total) {
     __shared__ uint32_t lds_wave[4];
     __shared__ uint32_t lds_wave2[4];
@@ -149,13 +163,15 @@ extern "C" size_t cgs_scan_scratch_bytes(int64_t n) {
     return bytes + 256;
 }
 
-// Recursive helper: exclusive scan of `in` into `out`, optional grand total.
-static int scan_rec(const uint32_t *in, uint32_t *out, int64_t n, char *scratch, size_t scratch_bytes,
+// Recursive helper: exclusive scan of `in` into `out`, optional grand total.  IN: uint32 or uint8 items (the block sums of the
+// recursion are always uint32).
+template <typename IN>
+static int scan_rec(const IN *in, uint32_t *out, int64_t n, char *scratch, size_t scratch_bytes,
                     uint32_t *grand_total, hipStream_t stream) {
     if (n <= 0) return CGS_OK;
     int64_t nb = scan_blocks(n);
     if (nb == 1) {
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, in, out,
+        hipLaunchKernelGGL(scan_apply_kernel<IN>, dim3(1), dim3(SCAN_THREADS), 0, stream, in, out,
                            (const uint32_t *)nullptr, n, grand_total);
         CGS_CHECK_HIP(hipGetLastError());
         return CGS_OK;
@@ -166,31 +182,37 @@ static int scan_rec(const uint32_t *in, uint32_t *out, int64_t n, char *scratch,
         return CGS_ERR_WORKSPACE;
     }
     uint32_t *sums = (uint32_t *)scratch;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, sums, n);
+    hipLaunchKernelGGL(scan_reduce_kernel<IN>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, sums, n);
     CGS_CHECK_HIP(hipGetLastError());
     if (nb <= SCAN_SELF_PREFIX_MAX) {
-        hipLaunchKernelGGL(scan_apply_selfprefix_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out,
+        hipLaunchKernelGGL(scan_apply_selfprefix_kernel<IN>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out,
                            (const uint32_t *)sums, n, grand_total);
         CGS_CHECK_HIP(hipGetLastError());
         return CGS_OK;
     }
-    int rc = scan_rec(sums, sums, nb, scratch + need, scratch_bytes - need, nullptr, stream);
+    int rc = scan_rec<uint32_t>(sums, sums, nb, scratch + need, scratch_bytes - need, nullptr, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out,
+    hipLaunchKernelGGL(scan_apply_kernel<IN>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, stream, in, out,
                        (const uint32_t *)sums, n, grand_total);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
 }
 
+// exclusive scan of BYTES (0 / 1 flags) into uint32 positions + the grand total (the expansion's survivor flags: expand.hip)
+int cgs_scan_exclusive_u8_total(const uint8_t *in, uint32_t *out, int64_t n, void *scratch, size_t scratch_bytes,
+                                uint32_t *grand_total, hipStream_t stream) {
+    return scan_rec<uint8_t>(in, out, n, (char *)scratch, scratch_bytes, grand_total, stream);
+}
+
 int cgs_scan_exclusive_u32_total(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
                                  size_t scratch_bytes, uint32_t *grand_total, hipStream_t stream) {
-    return scan_rec(in, out, n, (char *)scratch, scratch_bytes, grand_total, stream);
+    return scan_rec<uint32_t>(in, out, n, (char *)scratch, scratch_bytes, grand_total, stream);
 }
 
 extern "C" int cgs_scan_exclusive_u32(const uint32_t *in, uint32_t *out, int64_t n, void *scratch,
                                       size_t scratch_bytes, void *stream) {
     if (n < 0) { cgs_set_error("scan: negative n"); return CGS_ERR_ARG; }
-    return scan_rec(in, out, n, (char *)scratch, scratch_bytes, nullptr, (hipStream_t)stream);
+    return scan_rec<uint32_t>(in, out, n, (char *)scratch, scratch_bytes, nullptr, (hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------

@@ -91,13 +91,13 @@ class ExpandCount:
         self.n, self.K = n, K
         self.neural_opacity = torch.empty(slots, 1, dtype=torch.float32, device=dev)
         self.mask_out = torch.empty(slots, dtype=torch.bool, device=dev)
-        self.flags = torch.empty(slots, dtype=torch.int32, device=dev)
+        self.flags = self.mask_out        # (the survivor flags ARE the bytes of mask_out: the kernels scan and read those)
         self.pos = torch.empty(slots, dtype=torch.int32, device=dev)
         self.scratch = torch.empty(L.cgs_expand_scratch_bytes(n, K), dtype=torch.uint8, device=dev)
         self.P = None
         self.ticket = C.c_uint64(0)
         _lib.check(L.cgs_expand_count_launch(n, K, _lib.ptr(op_raw), _lib.ptr(masks), _lib.ptr(self.neural_opacity),
-                                             _lib.ptr(self.mask_out), _lib.ptr(self.flags), _lib.ptr(self.pos),
+                                             _lib.ptr(self.mask_out), None, _lib.ptr(self.pos),
                                              _lib.ptr(self.scratch), self.scratch.numel(), _lib.current_stream(),
                                              C.byref(self.ticket)), "cgs_expand_count_launch")
         _own_slot("expand_count", self)

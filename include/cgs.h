@@ -193,7 +193,7 @@ int cgs_raster_backward(const cgs_raster_cfg *cfg, int64_t P,
  * cgs_raster_preprocess_wait / cgs_raster_render* / cgs_raster_backward / cgs_expand_backward follow as usual.  Records, radii
  * and scales are bit-identical to cgs_expand_write + cgs_raster_preprocess_launch (same device functions, same values). */
 int cgs_raster_preprocess_expand_launch(const cgs_raster_cfg *cfg, int64_t n_anchor, int K,
-                                        const uint32_t *flags, const uint32_t *pos, const float *anchor,
+                                        const uint8_t *flags, const uint32_t *pos, const float *anchor,
                                         const float *gscaling, const float *offsets,
                                         const float *neural_opacity, const float *color_in,
                                         const float *cov_in, const int64_t *src_row, int64_t P,
@@ -919,6 +919,9 @@ int cgs_anchor_gen_backward(const float *feat_src, const int64_t *feat_row,
  * array (the context model's coding-order output: the visibility gather is fused into
  * the kernel); d_gscaling / d_offsets then have that array's shape, rows src_row[n]
  * are written and the caller pre-zeroes the rest. */
+/* SURVIVOR FLAGS are bytes (round 6): `mask_out` [n_anchor*K] (1 = the slot becomes a Gaussian) is what cgs_expand_write,
+ * cgs_expand_backward and cgs_raster_preprocess_expand_launch take as `flags`, and what the count's scan runs over (a quarter of
+ * the bytes of a uint32 array in three kernels).  The uint32 `flags` output of cgs_expand_count* is OPTIONAL (NULL: not written). */
 size_t cgs_expand_scratch_bytes(int64_t n_anchor, int K);
 int cgs_expand_count(int64_t n_anchor, int K, const float *op_raw,
                      const float *mask, float *neural_opacity,
@@ -932,14 +935,14 @@ int cgs_expand_count_launch(int64_t n_anchor, int K, const float *op_raw,
                             uint8_t *mask_out, uint32_t *flags, uint32_t *pos,
                             void *scratch, size_t scratch_bytes, void *stream, uint64_t *ticket);
 int cgs_expand_count_wait(uint64_t ticket, int64_t *count_host);
-int cgs_expand_write(int64_t n_anchor, int K, const uint32_t *flags,
+int cgs_expand_write(int64_t n_anchor, int K, const uint8_t *flags,
                      const uint32_t *pos, const float *anchor,
                      const float *gscaling, const float *offsets,
                      const float *neural_opacity, const float *color_in,
                      const float *cov_in, float *xyz, float *color,
                      float *opacity, float *scaling, float *rot,
                      const int64_t *src_row, void *stream);
-int cgs_expand_backward(int64_t n_anchor, int K, const uint32_t *flags,
+int cgs_expand_backward(int64_t n_anchor, int K, const uint8_t *flags,
                         const uint32_t *pos, const float *gscaling,
                         const float *offsets, const float *op_raw,
                         const float *mask, const float *cov_in,
