@@ -59,15 +59,15 @@ __device__ __forceinline__ void scan_load8(const uint32_t *__restrict__ in, int6
         for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? in[base + i] : 0u;
     }
 }
-// (uint8 input — survivor flags, one byte per slot: a thread's eight bytes are one 8-byte load)
+// (uint8 input — flags, one byte per item, ANY non-zero byte counts as 1: a thread's eight bytes are one 8-byte load)
 __device__ __forceinline__ void scan_load8(const uint8_t *__restrict__ in, int64_t base, int64_t n, uint32_t (&v)[SCAN_ITEMS]) {
     if (base + SCAN_ITEMS <= n && (((uintptr_t)(in + base)) & 7) == 0) {
         const uint2 a = *(const uint2 *)(in + base);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = (a.x >> (8 * i)) & 0xFFu; v[4 + i] = (a.y >> (8 * i)) & 0xFFu; }
+        for (int i = 0; i < 4; ++i) { v[i] = ((a.x >> (8 * i)) & 0xFFu) ? 1u : 0u; v[4 + i] = ((a.y >> (8 * i)) & 0xFFu) ? 1u : 0u; }
     } else {
 #pragma unroll
-        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? (uint32_t)in[base + i] : 0u;
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = (base + i < n && in[base + i]) ? 1u : 0u;
     }
 }
 __device__ __forceinline__ void scan_store8(uint32_t *__restrict__ out, int64_t base, int64_t n, const uint32_t (&v)[SCAN_ITEMS]) {
@@ -584,13 +584,9 @@ extern "C" int cgs_sort_depth_keys(const uint32_t *keys_in, uint32_t *keys_out, 
 // here the kernels the caller enqueues between the halves (the context model's accessors, the step's bookkeeping) keep
 // the device busy while the host learns the count.  idx_out has room for n entries; the first *count are valid.
 // ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) nz_flags_kernel(const uint8_t *__restrict__ mask, int64_t n, uint32_t *__restrict__ f) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) f[i] = mask[i] ? 1u : 0u;
-}
-
+// (round 6: the scan runs over the mask's bytes themselves — no uint32 flag array, no launch to make one)
 __global__ void __launch_bounds__(256)
-    nz_scatter_kernel(const uint32_t *__restrict__ f, const uint32_t *__restrict__ pos, int64_t n, int64_t *__restrict__ idx) {
+    nz_scatter_kernel(const uint8_t *__restrict__ f, const uint32_t *__restrict__ pos, int64_t n, int64_t *__restrict__ idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n && f[i]) idx[pos[i]] = i;
 }
@@ -622,15 +618,14 @@ extern "C" int cgs_nonzero_launch(const uint8_t *mask, int64_t n, int64_t *idx_o
     if (scratch_bytes < cgs_nonzero_scratch_bytes(n)) { cgs_set_error("nonzero: scratch too small"); return CGS_ERR_WORKSPACE; }
     CgsCarver cv(scratch, scratch_bytes);
     uint32_t *f = cv.take<uint32_t>(n), *pos = cv.take<uint32_t>(n);
+    (void)f;      // (the uint32 flag array of rounds 1-5: still carved so that cgs_nonzero_scratch_bytes keeps its meaning)
     const size_t scan_bytes = cgs_scan_scratch_bytes(n);
     char *scan_scratch = cv.take<char>(scan_bytes + 256);
     uint32_t *total = (uint32_t *)(scan_scratch + scan_bytes);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    hipLaunchKernelGGL(nz_flags_kernel, grid, block, 0, stream, mask, n, f);
-    CGS_CHECK_HIP(hipGetLastError());
-    int rc = cgs_scan_exclusive_u32_total(f, pos, n, scan_scratch, scan_bytes, total, stream);
+    int rc = cgs_scan_exclusive_u8_total(mask, pos, n, scan_scratch, scan_bytes, total, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(nz_scatter_kernel, grid, block, 0, stream, (const uint32_t *)f, (const uint32_t *)pos, n, idx_out);
+    hipLaunchKernelGGL(nz_scatter_kernel, grid, block, 0, stream, mask, (const uint32_t *)pos, n, idx_out);
     CGS_CHECK_HIP(hipGetLastError());
     CGS_CHECK_HIP(hipMemcpyAsync(sl.pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CGS_CHECK_HIP(hipEventRecord(sl.ev, stream));
