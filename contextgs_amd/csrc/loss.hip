@@ -11,9 +11,14 @@
 // HBM traffic: forward 8 + 12 B / pixel / channel (two reads, three map writes), backward 20 + 4 B.
 #include "cgs_internal.h"
 
-#define SS_T 32                    // output tile: 32 x 32 pixels of one channel per workgroup (256 threads, four outputs each)
+#define SS_T 32                    // output tile: SS_T x SS_TY pixels of one channel per workgroup (256 threads, SS_CB outputs each)
+#ifndef SS_TY
+#define SS_TY 32
+#endif
+#define SS_CB (SS_T * SS_TY / 256) // outputs of a thread in the column pass (consecutive rows)
 #define SS_R 5
-#define SS_P (SS_T + 2 * SS_R)     // 42
+#define SS_P (SS_T + 2 * SS_R)     // 42 columns of the input patch
+#define SS_PY (SS_TY + 2 * SS_R)   // its rows
 #define SS_K 11
 #define SS_NG (SS_T / 4)           // groups of four neighbouring outputs per row / column
 
@@ -46,24 +51,42 @@ __device__ __forceinline__ float block_sum_256(float v, float *sh) {
 __global__ void __launch_bounds__(256)
     l1_ssim_fwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, int H, int W, SsimWin win,
                        float *__restrict__ maps /* [3][C][H][W] or null */, float *__restrict__ partials) {
-    __shared__ float sx[SS_P][SS_P + 1], sy[SS_P][SS_P + 1];
-    __shared__ float hq[5][SS_P][SS_T + 1];
+    __shared__ float sx[SS_PY][SS_P + 1], sy[SS_PY][SS_P + 1];
+    __shared__ float hq[5][SS_PY][SS_T + 1];
     __shared__ float red[4];
     const int c = blockIdx.z, C = gridDim.z;
-    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_TY;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)H * W;
     const float *xi = img + c * plane, *yi = gt + c * plane;
-    for (int i = tid; i < SS_P * SS_P; i += 256) {
-        const int py = i / SS_P, px = i - py * SS_P;
-        const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[py][px] = in ? xi[(size_t)gy * W + gx] : 0.f;
-        sy[py][px] = in ? yi[(size_t)gy * W + gx] : 0.f;
+    {
+        // the patch: every load of the thread is requested before the first goes to LDS (as a plain loop the seven rounds were seven
+        // dependent round trips per workgroup, with three workgroups per CU to hide them)
+        constexpr int NL = (SS_PY * SS_P + 255) / 256;
+        float vx[NL], vy[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            const int py = i / SS_P, px = i - py * SS_P;
+            const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
+            const bool in = i < SS_PY * SS_P && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            vx[k] = in ? xi[o] : 0.f;
+            vy[k] = in ? yi[o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            if (i < SS_PY * SS_P) {
+                const int py = i / SS_P, px = i - py * SS_P;
+                sx[py][px] = vx[k];
+                sy[py][px] = vy[k];
+            }
+        }
     }
     __syncthreads();
-    // rows: item = (row r of the 42, group of four columns)
-    for (int i = tid; i < SS_P * SS_NG; i += 256) {
+    // rows: item = (row r of the patch, group of four columns)
+    for (int i = tid; i < SS_PY * SS_NG; i += 256) {
         const int r = i / SS_NG, col = 4 * (i - r * SS_NG);
         float xv[SS_K + 3], yv[SS_K + 3];
 #pragma unroll
@@ -80,17 +103,17 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    // columns: thread = (column lx of the 32, group of four rows)
-    const int lx = tid & (SS_T - 1), ly0 = 4 * (tid / SS_T);
-    float mu1[4], mu2[4], e11[4], e22[4], e12[4];
+    // columns: thread = (column lx of the 32, group of SS_CB rows)
+    const int lx = tid & (SS_T - 1), ly0 = SS_CB * (tid / SS_T);
+    float mu1[SS_CB], mu2[SS_CB], e11[SS_CB], e22[SS_CB], e12[SS_CB];
     {
-        float v[5][SS_K + 3];
+        float v[5][SS_K + SS_CB - 1];
 #pragma unroll
         for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int k = 0; k < SS_K + 3; ++k) v[q][k] = hq[q][ly0 + k][lx];
+            for (int k = 0; k < SS_K + SS_CB - 1; ++k) v[q][k] = hq[q][ly0 + k][lx];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SS_CB; ++j) {
             float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f;
 #pragma unroll
             for (int k = 0; k < SS_K; ++k) {
@@ -102,7 +125,7 @@ __global__ void __launch_bounds__(256)
     }
     float m = 0.f, l1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < SS_CB; ++j) {
         const int ly = ly0 + j, gx = x0 + lx, gy = y0 + ly;
         if (gx < W && gy < H) {
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -142,22 +165,37 @@ __global__ void __launch_bounds__(256)
     // g [2] (may be null): gradients of (L1, SSIM); g_loss [1] (may be null): gradient of (1 - lam) L1 + lam (1 - SSIM)
     const float gl = g_loss ? g_loss[0] : 0.f;
     const float g0 = (g ? g[0] : 0.f) + gl * (1.f - lam), g1 = (g ? g[1] : 0.f) - gl * lam;
-    __shared__ float sm[3][SS_P][SS_P + 1];
-    __shared__ float hq[3][SS_P][SS_T + 1];
+    __shared__ float sm[3][SS_PY][SS_P + 1];
+    __shared__ float hq[3][SS_PY][SS_T + 1];
     const int c = blockIdx.z, C = gridDim.z;
-    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_TY;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)H * W, cs = (size_t)C * plane;
-    for (int i = tid; i < SS_P * SS_P; i += 256) {
-        const int py = i / SS_P, px = i - py * SS_P;
-        const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = (size_t)c * plane + (size_t)gy * W + gx;
+    {
+        constexpr int NL = (SS_PY * SS_P + 255) / 256;      // (all loads before the first LDS store: see the forward)
+        float vm[NL][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sm[q][py][px] = in ? maps[q * cs + o] : 0.f;
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            const int py = i / SS_P, px = i - py * SS_P;
+            const int gy = y0 + py - SS_R, gx = x0 + px - SS_R;
+            const bool in = i < SS_PY * SS_P && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = in ? (size_t)c * plane + (size_t)gy * W + gx : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vm[k][q] = in ? maps[q * cs + o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + 256 * k;
+            if (i < SS_PY * SS_P) {
+                const int py = i / SS_P, px = i - py * SS_P;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sm[q][py][px] = vm[k][q];
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < SS_P * SS_NG; i += 256) {
+    for (int i = tid; i < SS_PY * SS_NG; i += 256) {
         const int r = i / SS_NG, col = 4 * (i - r * SS_NG);
         float v[3][SS_K + 3];
 #pragma unroll
@@ -176,14 +214,14 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    const int lx = tid & (SS_T - 1), ly0 = 4 * (tid / SS_T);
-    float v[3][SS_K + 3];
+    const int lx = tid & (SS_T - 1), ly0 = SS_CB * (tid / SS_T);
+    float v[3][SS_K + SS_CB - 1];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int k = 0; k < SS_K + 3; ++k) v[q][k] = hq[q][ly0 + k][lx];
+        for (int k = 0; k < SS_K + SS_CB - 1; ++k) v[q][k] = hq[q][ly0 + k][lx];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < SS_CB; ++j) {
         float cA = 0.f, cB = 0.f, cC = 0.f;
 #pragma unroll
         for (int k = 0; k < SS_K; ++k) {
@@ -203,7 +241,7 @@ __global__ void __launch_bounds__(256)
 }
 
 extern "C" size_t cgs_l1_ssim_partials(int C, int H, int W) {
-    return (size_t)C * ((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T);
+    return (size_t)C * ((H + SS_TY - 1) / SS_TY) * ((W + SS_T - 1) / SS_T);
 }
 
 extern "C" int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, int W, float *maps, float *partials,
@@ -211,7 +249,7 @@ extern "C" int cgs_l1_ssim_fwd(const float *img, const float *gt, int C, int H, 
     if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_fwd: bad shape"); return CGS_ERR_ARG; }
     if (!img || !gt || !partials) { cgs_set_error("l1_ssim_fwd: NULL"); return CGS_ERR_ARG; }
     static const SsimWin win = ssim_window();
-    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_TY - 1) / SS_TY, C);
     CgsProfScope prof(CGS_PROF_LOSS_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, H, W, win, maps, partials);
     CGS_CHECK_HIP(hipGetLastError());
@@ -223,7 +261,7 @@ extern "C" int cgs_l1_ssim_bwd(const float *img, const float *gt, const float *m
     if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_bwd: bad shape"); return CGS_ERR_ARG; }
     if (!img || !gt || !maps || !g || !dimg) { cgs_set_error("l1_ssim_bwd: NULL"); return CGS_ERR_ARG; }
     static const SsimWin win = ssim_window();
-    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_TY - 1) / SS_TY, C);
     CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g, (const float *)nullptr, 0.f,
                        H, W, win, dimg);
@@ -266,7 +304,7 @@ extern "C" int cgs_l1_ssim_bwd_loss(const float *img, const float *gt, const flo
     if (C < 1 || H < 1 || W < 1) { cgs_set_error("l1_ssim_bwd: bad shape"); return CGS_ERR_ARG; }
     if (!img || !gt || !maps || (!g_loss && !g2) || !dimg) { cgs_set_error("l1_ssim_bwd: NULL"); return CGS_ERR_ARG; }
     static const SsimWin win = ssim_window();
-    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_T - 1) / SS_T, C);
+    const dim3 grid((W + SS_T - 1) / SS_T, (H + SS_TY - 1) / SS_TY, C);
     CgsProfScope prof(CGS_PROF_LOSS_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gt, maps, g2, g_loss, lam, H, W, win, dimg);
     CGS_CHECK_HIP(hipGetLastError());
