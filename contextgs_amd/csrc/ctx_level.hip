@@ -91,10 +91,10 @@ __device__ __forceinline__ void cl_gather_merge(const ClGatherRaw<IN> &w, int g,
 #define CL_W1T(XP) ((XP) * 128)
 template <int IN>
 __device__ __forceinline__ void cl_stage_w1t(float *__restrict__ W1t, const float *__restrict__ W1, int tid, int nthr) {
-    for (int i = tid; i < CL_W1T(ClShape<IN>::XP); i += nthr) {
-        const int k = i >> 7, c = (i >> 3) & 15, t = i & 7, j = 16 * t + c;
-        W1t[i] = (t < CL_NT1 && j < CL_HID && k < IN) ? W1[j * IN + k] : 0.f;
-    }
+    frag_stage_loop(W1, CL_W1T(ClShape<IN>::XP), tid, nthr,
+                    [](int i) { const int k = i >> 7, c = (i >> 3) & 15, t = i & 7, j = 16 * t + c;
+                                return (t < CL_NT1 && j < CL_HID && k < IN) ? j * IN + k : -1; },
+                    [&](int i, float v) { W1t[i] = v; });
 }
 
 // H^T = relu(W1 X^T + b1): lane (g, c) ends with hidden units 16t + 4g + {0..3} of row c.  Forward and backward call THIS
@@ -431,14 +431,11 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
     float *W1s = lds, *W1n4 = W1s + CL_W1T(XP), *W1n1 = W1n4 + N4, *b1s = W1n1 + N1, *W2qs = b1s + CL_HP, *b2qs = W2qs + 3 * CL_HP;
     const int tid = threadIdx.x, nthr = CLB_WAVES * 64;
     cl_stage_w1t<IN>(W1s, a.W1, tid, nthr);
-    for (int i = tid; i < N4; i += nthr) {
-        const int h = i >> 6, c_ = (i >> 2) & 15, v = i & 3, k = 16 * v + c_;
-        W1n4[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;
-    }
-    for (int i = tid; i < N1; i += nthr) {
-        const int h = i >> 4, k = 64 + (i & 15);
-        W1n1[i] = (h < CL_HID && k < IN) ? a.W1[h * IN + k] : 0.f;
-    }
+    frag_stage_loop(a.W1, N4, tid, nthr,
+                    [](int i) { const int h = i >> 6, c_ = (i >> 2) & 15, v = i & 3, k = 16 * v + c_; return (h < CL_HID && k < IN) ? h * IN + k : -1; },
+                    [&](int i, float v) { W1n4[i] = v; });
+    frag_stage_loop(a.W1, N1, tid, nthr, [](int i) { const int h = i >> 4, k = 64 + (i & 15); return (h < CL_HID && k < IN) ? h * IN + k : -1; },
+                    [&](int i, float v) { W1n1[i] = v; });
     for (int i = tid; i < CL_HP; i += nthr) b1s[i] = i < CL_HID ? a.b1[i] : 0.f;
     for (int i = tid; i < 3 * CL_HP; i += nthr) W2qs[i] = (i % CL_HP) < CL_HID ? a.W2q[(i / CL_HP) * CL_HID + (i % CL_HP)] : 0.f;
     if (tid < 4) b2qs[tid] = tid < 3 ? a.b2q[tid] : 0.f;

@@ -155,14 +155,10 @@ __global__ void __launch_bounds__(WAVES * 64)
     __shared__ float W2n[OP * SA];   // [o][h]
     __shared__ float W1n[HP * SB];   // [h][k]
     const int tid = threadIdx.x, nthr = WAVES * 64;
-    for (int i = tid; i < OP * SA; i += nthr) {
-        const int o = i / SA, h = i % SA;
-        W2n[i] = (o < OUT && h < HID) ? W2[o * HID + h] : 0.f;
-    }
-    for (int i = tid; i < HP * SB; i += nthr) {
-        const int h = i / SB, k = i % SB;
-        W1n[i] = (h < HID && k < IN) ? W1[h * IN + k] : 0.f;
-    }
+    frag_stage_loop(W2, OP * SA, tid, nthr, [](int i) { const int o = i / SA, h = i % SA; return (o < OUT && h < HID) ? o * HID + h : -1; },
+                    [&](int i, float v) { W2n[i] = v; });
+    frag_stage_loop(W1, HP * SB, tid, nthr, [](int i) { const int h = i / SB, k = i % SB; return (h < HID && k < IN) ? h * IN + k : -1; },
+                    [&](int i, float v) { W1n[i] = v; });
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;

@@ -323,14 +323,12 @@ template <int OUT>
 __device__ __forceinline__ void m3_stage_bwd(float *lds, const M3Head &h, int tid, int nthr) {
     using L = M3BwdLds<OUT>;
     float *W2n = lds, *W1n = W2n + L::OP * L::SA;
-    for (int i = tid; i < L::OP * L::SA; i += nthr) {
-        const int o = i / L::SA, hh = i % L::SA;
-        W2n[i] = (o < OUT && hh < M3_HID) ? h.W2[o * M3_HID + hh] : 0.f;
-    }
-    for (int i = tid; i < M3_HP * L::SB; i += nthr) {
-        const int hh = i / L::SB, k = i % L::SB;
-        W1n[i] = (hh < M3_HID && k < M3_IN) ? h.W1[hh * M3_IN + k] : 0.f;
-    }
+    frag_stage_loop(h.W2, L::OP * L::SA, tid, nthr,
+                    [](int i) { const int o = i / L::SA, hh = i % L::SA; return (o < OUT && hh < M3_HID) ? o * M3_HID + hh : -1; },
+                    [&](int i, float v) { W2n[i] = v; });
+    frag_stage_loop(h.W1, M3_HP * L::SB, tid, nthr,
+                    [](int i) { const int hh = i / L::SB, k = i % L::SB; return (hh < M3_HID && k < M3_IN) ? hh * M3_IN + k : -1; },
+                    [&](int i, float v) { W1n[i] = v; });
 }
 
 template <int OUT, int ACT, int RT>

@@ -68,6 +68,32 @@ constexpr int frag_pad4mod8(int x) { int s = 4; while (s < x) s += 8; return s; 
 #ifndef FRAG_STAGE_COALESCED
 #define FRAG_STAGE_COALESCED 1
 #endif
+// A staging loop  for (i = tid; i < n; i += nthr) put(i, ok(i) ? src[index(i)] : 0)  with EIGHT of a thread's loads in flight.
+// As a plain loop the compiler emits load -> s_waitcnt vmcnt(0) -> LDS store per round (it does not unroll a loop of unknown trip
+// count, and a predicated load sits behind an exec-mask branch whose join drains the load queue): one exposed round trip per
+// round — 80 rounds = ~50 us at the head of mlp3_bwd_wg_kernel, as much again over the level and rate kernels of a step (round 6;
+// rate_sub.hip found it first).  Here the load is UNCONDITIONAL (index 0 where the value is padding) and selected afterwards.
+//   at(i) -> source index, or -1 for padding (value 0)
+template <typename AT, typename PUT>
+__device__ __forceinline__ void frag_stage_loop(const float *__restrict__ src, int n, int tid, int nthr, AT &&at, PUT &&put) {
+    constexpr int UN = 8;
+    for (int i = tid; i < n; i += UN * nthr) {          // (a short tail rides in the same batch: its slots beyond n load index 0 and put nothing)
+        float v[UN];
+        int ix[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = i + u * nthr;
+            ix[u] = j < n ? at(j) : -1;
+            v[u] = src[ix[u] < 0 ? 0 : ix[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = i + u * nthr;
+            if (j < n) put(j, ix[u] < 0 ? 0.f : v[u]);
+        }
+    }
+}
+
 template <int ROWS, int COLS, int RP, int S>
 __device__ __forceinline__ void frag_stage_transposed(float *__restrict__ dst, const float *__restrict__ src, int tid, int nthr) {
 #if FRAG_STAGE_COALESCED
@@ -75,10 +101,8 @@ __device__ __forceinline__ void frag_stage_transposed(float *__restrict__ dst, c
         const int r = i / S, c = i % S;
         if (r >= ROWS || c >= COLS) dst[i] = 0.f;
     }
-    for (int i = tid; i < COLS * ROWS; i += nthr) {
-        const int c = i / ROWS, r = i % ROWS;
-        dst[r * S + c] = src[i];
-    }
+    frag_stage_loop(src, COLS * ROWS, tid, nthr, [](int i) { return i; },
+                    [&](int i, float v) { const int c = i / ROWS, r = i % ROWS; dst[r * S + c] = v; });
 #else
     for (int i = tid; i < RP * S; i += nthr) {
         const int r = i / S, c = i % S;

@@ -28,10 +28,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     __shared__ float red[OUT * HP + OUT];
     const int tid = threadIdx.x, nthr = WAVES * 64;
     frag_stage_transposed<IN, HID, XP, S1>(W1s, W1, tid, nthr);       // W1s[k][j] = W1[j][k]
-    for (int i = tid; i < HP * SB; i += nthr) {
-        const int h = i / SB, k = i % SB;
-        W1n[i] = (h < HID && k < IN) ? W1[h * IN + k] : 0.f;
-    }
+    frag_stage_loop(W1, HP * SB, tid, nthr, [](int i) { const int h = i / SB, k = i % SB; return (h < HID && k < IN) ? h * IN + k : -1; },
+                    [&](int i, float v) { W1n[i] = v; });
     for (int i = tid; i < HP; i += nthr) b1s[i] = i < HID ? b1[i] : 0.f;
     for (int i = tid; i < OUT * HP; i += nthr) W2s[i] = (i % HP) < HID ? W2[(i / HP) * HID + (i % HP)] : 0.f;
     for (int i = tid; i < OUT * HP + OUT; i += nthr) red[i] = 0.f;
