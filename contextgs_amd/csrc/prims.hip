@@ -271,11 +271,19 @@ __global__ void __launch_bounds__(SORT_THREADS)
     for (int d = threadIdx.x; d < NR; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
     const int64_t base = tile * SORT_TILE;
+    // (all of the thread's keys requested first, from clamped indices: a load inside `if (idx < n)` sits behind an exec-mask
+    //  branch whose join drains the load queue — sixteen exposed round trips per thread)
+    uint32_t kk[SORT_ITEMS];
 #pragma unroll
     for (int i = 0; i < SORT_ITEMS; ++i) {
-        int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+        const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+        kk[i] = keys[idx < n ? idx : n - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < SORT_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
         if (idx < n) {
-            uint32_t k = keys[idx];
+            uint32_t k = kk[i];
             if (XF) k = cgs_depth_key27(k, overflow, epoch);
             atomicAdd(&h[(k >> shift) & digit_mask], 1u);
         }
@@ -359,13 +367,21 @@ __global__ void __launch_bounds__(SORT_THREADS)
     volatile uint16_t *my = wcnt[wave];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     uint32_t dummy_overflow;
+    // (keys and values of all rounds requested before the first is ranked, from clamped indices: see radix_hist_kernel)
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const int64_t idx = wbase + (int64_t)r * 64 + lane;
+        const int64_t ci = idx < n ? idx : n - 1;
+        key[r] = keys_in[ci];
+        val[r] = vals_in ? vals_in[ci] : (uint32_t)idx;
+    }
 #pragma unroll
     for (int r = 0; r < SORT_ITEMS; ++r) {
         const int64_t idx = wbase + (int64_t)r * 64 + lane;
         const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        key[r] = valid ? key[r] : 0xFFFFFFFFu;
         if (XF) key[r] = cgs_depth_key27(key[r], &dummy_overflow, 0u);      // (the histogram kernel of this pass reported overflows)
-        val[r] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;   // vals_in == nullptr: values = positions
+        val[r] = valid ? val[r] : 0u;                                       // vals_in == nullptr: values = positions
         const uint32_t d = (key[r] >> shift) & digit_mask;
         uint64_t peers = __ballot(valid);
 #pragma unroll
