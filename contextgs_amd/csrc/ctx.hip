@@ -989,13 +989,21 @@ __global__ void __launch_bounds__(256)
         for (int64_t k = b; __builtin_amdgcn_ballot_w64(k < e) != 0ull; k += 4) {
             int64_t child[4];
             float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) child[u] = (k + u < e) ? order[k + u] : 0;
+            // UNCONDITIONAL loads from clamped indices (a load behind `k + u < e` is an exec-mask branch whose join drains the load
+            // queue: the four index loads and the four row loads were eight exposed round trips); selected afterwards.
+            // (e > b here for some lane; a lane without children reads entry 0 / row order[0]: valid memory, value dropped)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                const int64_t kk = k + u < e ? k + u : (e > b ? e - 1 : 0);
+                child[u] = order[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // (16-byte load at a 4-byte-aligned address: rows are ldo floats apart; lane 15 of a group reads columns 60..63
+                //  of the row — inside it, ldo >= 64 is checked by the launcher — and drops them)
+                const float4 t = *(const float4 *)(dout + child[u] * ldo + 4 * sub);
                 const bool ok = col_ok && (k + u < e);
-                // (16-byte load at a 4-byte-aligned address: rows are ldo floats apart)
-                v[u] = ok ? *(const float4 *)(dout + child[u] * ldo + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1042,7 +1050,7 @@ extern "C" int cgs_ctx_gather_bwd_acc(const float *dout, int64_t ldo, int64_t n_
     if (n_parents == 0) return CGS_OK;
     if (!dout || !offs || !order || (d_anchor && !parent_row)) { cgs_set_error("ctx_gather_bwd: NULL"); return CGS_ERR_ARG; }
     CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);
-    if (wa == 3 && DF == 50 && DS == 6 && ldo >= 60 && !g_gather1) {      // (ldo >= 60: the 15th lane's 16-byte load stays inside its row)
+    if (wa == 3 && DF == 50 && DS == 6 && ldo >= 64 && !g_gather1) {      // (ldo >= 64: every lane's 16-byte load stays inside its row)
         hipLaunchKernelGGL(ctx_gather_bwd4_kernel, dim3(stream_grid(n_parents, 16 * 2)), dim3(256), 0, (hipStream_t)stream, dout, ldo,
                            n_parents, offs, order, parent_row, d_anchor, d_f, d_s, accumulate_anchor & 7);
         CGS_CHECK_HIP(hipGetLastError());
