@@ -31,6 +31,9 @@
 #ifndef RB_TILE_ORDER
 #define RB_TILE_ORDER 1      // 0: tile = workgroup id (raster order)
 #endif
+#ifndef RB_XCD_RUN
+#define RB_XCD_RUN 0         // > 0: runs of RB_XCD_RUN consecutive entries of the tile order share an XCD (rb_slot)
+#endif
 
 
 namespace {
@@ -96,6 +99,19 @@ __device__ __forceinline__ float rb_dpp(float v) {
 struct RbLane {
     int px, py, blk;
 };
+
+// Workgroup -> entry of the tile order.  Workgroups are dealt to the eight XCDs round robin (workgroup b -> XCD b % 8, each with
+// its own L2) and neighbouring tiles read the same Gaussians' records: with entry = b, eight neighbours fetch them into eight
+// L2s.  Inside every group of 8 R consecutive entries (started together: the longest-first order survives at that granularity)
+// XCD x takes entries R x .. R x + R - 1.
+__device__ __forceinline__ uint32_t rb_slot(uint32_t b, uint32_t n) {
+#if RB_XCD_RUN > 0
+    const uint32_t G = 8u * RB_XCD_RUN, q = b / G, r = b % G;
+    return (q + 1u) * G <= n ? q * G + (r & 7u) * RB_XCD_RUN + (r >> 3) : b;
+#else
+    return b;
+#endif
+}
 
 // lane -> pixel: wave = quadrant, row (lane >> 4) = 4x4 block of the quadrant, lane & 15 = pixel of the block
 __device__ __forceinline__ RbLane rb_lane(int tx, int ty, int wave, int lane) {
@@ -165,7 +181,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     __shared__ RbLists S;
     __shared__ uint32_t wave_last[4];
 
-    const int tile = RB_TILE_ORDER ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;        // longest lists first (tile_order_kernel)
+    const int tile = RB_TILE_ORDER ? (int)tile_order[rb_slot(blockIdx.x, gridDim.x)] : (int)rb_slot(blockIdx.x, gridDim.x);        // longest lists first (tile_order_kernel)
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RbLane L = rb_lane(tx, ty, wave, lane);
@@ -274,7 +290,7 @@ __global__ void __launch_bounds__(RB_THREADS)
     __shared__ float sacc[RB_THREADS][RB_NGRAD];
     __shared__ RbLists S;
 
-    const int tile = RB_TILE_ORDER ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;        // longest lists first (tile_order_kernel)
+    const int tile = RB_TILE_ORDER ? (int)tile_order[rb_slot(blockIdx.x, gridDim.x)] : (int)rb_slot(blockIdx.x, gridDim.x);        // longest lists first (tile_order_kernel)
     const uint32_t tlast = tile_last[tile];
     if (tlast == 0) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
