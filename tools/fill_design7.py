@@ -26,6 +26,7 @@ vals = dict(value="%.1f" % j["value"], ms="%.2f" % j["ms_per_step"], smin="%.3f"
             e1="%.1f" % c["encode_Manchors_per_s"], d1="%.1f" % c["decode_Manchors_per_s"],
             e2="%.1f" % v2["encode_Manchors_per_s"], d2="%.1f" % v2["decode_Manchors_per_s"],
             e2ms="%.1f" % (v2["encode_s"] * 1e3), d2ms="%.1f" % (v2["decode_s"] * 1e3),
+            e2runs=" / ".join("%.1f" % (x * 1e3) for x in v2["encode_s_runs"]),
             c3e1="%.1f" % c3["container_v1"]["encode_Manchors_per_s"], c3d1="%.1f" % c3["container_v1"]["decode_Manchors_per_s"],
             c3e2="%.1f" % c3["container_v2"]["encode_Manchors_per_s"], c3d2="%.1f" % c3["container_v2"]["decode_Manchors_per_s"],
             fps_d="%.0f" % c["test_fps"]["decoded_views_per_s"], fps_n="%.0f" % c["test_fps"]["not_decoded_views_per_s"],
