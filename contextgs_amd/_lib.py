@@ -152,6 +152,8 @@ SIGNATURES = {
     "cgs_ctx_level_bwd_scratch_bytes": (c_size_t, []),
     "cgs_ctx_level_bwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int64, C.c_uint64, c_float, c_float, c_float, c_void_p, c_int64] +
                           [c_void_p] * 4 + [c_int64] + [c_void_p] * 11 + [c_size_t, c_void_p]),
+    "cgs_ctx_level_bwd2": (c_int, [c_int] + [c_void_p] * 9 + [c_int64, C.c_uint64, c_float, c_float, c_float, c_void_p, c_int64] +
+                           [c_void_p] * 4 + [c_int64] + [c_void_p] * 12 + [c_size_t, c_void_p]),
     "cgs_level_rate_fwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "cgs_level_rate_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int64, c_int, c_int, c_int64] + [c_void_p] * 7 +
                            [c_int, c_void_p]),

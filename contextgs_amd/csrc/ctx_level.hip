@@ -346,6 +346,7 @@ struct ClBwdArgs {
     const float *side_f, *side_s, *side_o, *side_Q;     //   these [m,50] [m,6] [m,30] [m,3] arrays
     const float *dx_sub;                     //   and its extra input gradient (the mean / scale branch of the MLP) is row side_map[r] of this [m, IN]; may be NULL
     float *dX;                               // [n, IN] input-row gradient
+    float *dhyp;                             // may be NULL; [n_anchor, 12]: row rows[r] receives the hyper columns of dX[r] (the last 12)
     float *partial;                          // [gridDim.x][E] weight-gradient images, E = 100 IN + 100 + 300 + 3
     int64_t n, n_anchor, m;
     uint64_t seed;
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
     const ClRowBufs DXB = {cl_buf(a.dxf, NA * CL_D * 4), cl_buf(a.dxs, NA * CL_S * 4), cl_buf(a.dxo, NA * CL_O * 4)};
     const ClRowBufs SDB = {cl_buf(a.side_f, M * CL_D * 4), cl_buf(a.side_s, M * CL_S * 4), cl_buf(a.side_o, M * CL_O * 4)};
     const ClBuf bSQ = cl_buf(a.side_Q, M * 12), bQe = cl_buf(a.dQ_ext, nb * 12), bRows = cl_buf(a.rows, nb * 8),
-                bMap = cl_buf(a.side_map, nb * 4);
+                bMap = cl_buf(a.side_map, nb * 4), bDH = cl_buf(a.dhyp, NA * 48);
     const uint32_t kf = ctx_noise_key(a.seed, 0), ks = ctx_noise_key(a.seed, 1), ko = ctx_noise_key(a.seed, 2);
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     // accumulators held for the whole launch (matrix-core outputs: AGPRs)
@@ -519,6 +520,7 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
         CLB_FENCE();
         f32x4 dxs[NTI];
         cl_xrow_load<IN>(bSub, sm * (IN * 4), g, chosen, dxs);
+        const uint32_t hrow = (uint32_t)op.srow * 48u;             // this tile's row of dhyp (op.srow is the next tile's from here on)
         op_issue_x(op, row + tstride * 16);
         CLB_FENCE();
         // rows 4g + r of this tile that exist (the ones columns of [X | 1] and [H | 1]); d qadj in layout N
@@ -583,6 +585,20 @@ __global__ void __launch_bounds__(CLB_WAVES * 64) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int v = 0; v < NTI; ++v) adx[v] += dxs[v];          // (a dx_sub piece that runs past its row end is cut by the store)
         cl_xrow_store<IN>(bdX, (uint32_t)row * (IN * 4), g, valid, adx);
+        // the hyper latents' columns (the last 12 of the row) also go straight to the latents' gradient row, in parameter order: their
+        // consumer (the hyper prior's backward) then needs no pass through the inverse coding permutation.  A NULL dhyp drops the stores.
+        {
+            constexpr int H0 = IN - 12;
+#pragma unroll
+            for (int v = 0; v < NTI; ++v) {
+                if (16 * v + 15 < H0) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int h = 16 * v + 4 * g + j - H0;
+                    cl_s32(bDH, cl_sel(valid && h >= 0 && h < 12, hrow + (uint32_t)h * 4u), adx[v][j]);
+                }
+            }
+        }
         // dW1 += dZ1^T [X | 1]
         f32x4 xn[NTI];
 #pragma unroll
@@ -695,12 +711,33 @@ extern "C" size_t cgs_ctx_level_bwd_scratch_bytes(void) { return (size_t)cl_cus(
 // overwritten with dy[r] (+ the rate subset's compact gradient row side_map[r] when >= 0; the side arrays have m_side rows).
 // dX [n, in_dim] receives the input-row gradient (+ row side_map[r] of dx_sub).  dW1 / db1 / dW2q / db2q are ACCUMULATED into
 // (zero or pre-load them): atomics-free, the same bits every run.  scratch >= cgs_ctx_level_bwd_scratch_bytes().
+// d_hyp_rows (cgs_ctx_level_bwd2; may be NULL): [n_anchor, 12] — row rows[r] also receives the last 12 columns of dX[r] (the gradient
+// of the level's hyper latents, in the latents' own row order).
+extern "C" int cgs_ctx_level_bwd2(int in_dim, const float *X, const float *W1, const float *b1, const float *W2q,
+                                  const float *b2q, const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
+                                  int64_t n, uint64_t seed, float q0f, float q0s, float q0o, const int64_t *rows, int64_t n_anchor,
+                                  float *dxf, float *dxs, float *dxo, const int32_t *side_map, int64_t m_side, const float *side_f,
+                                  const float *side_s, const float *side_o, const float *side_Q, const float *dx_sub, float *dX,
+                                  float *d_hyp_rows, float *dW1, float *db1, float *dW2q, float *db2q, void *scratch,
+                                  size_t scratch_bytes, void *stream);
 extern "C" int cgs_ctx_level_bwd(int in_dim, const float *X, const float *W1, const float *b1, const float *W2q,
                                  const float *b2q, const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
                                  int64_t n, uint64_t seed, float q0f, float q0s, float q0o, const int64_t *rows, int64_t n_anchor,
                                  float *dxf, float *dxs, float *dxo, const int32_t *side_map, int64_t m_side, const float *side_f,
                                  const float *side_s, const float *side_o, const float *side_Q, const float *dx_sub, float *dX,
                                  float *dW1, float *db1, float *dW2q, float *db2q, void *scratch, size_t scratch_bytes, void *stream) {
+    return cgs_ctx_level_bwd2(in_dim, X, W1, b1, W2q, b2q, dyf, dys, dyo, dQ_ext, n, seed, q0f, q0s, q0o, rows, n_anchor, dxf, dxs, dxo,
+                              side_map, m_side, side_f, side_s, side_o, side_Q, dx_sub, dX, nullptr, dW1, db1, dW2q, db2q, scratch,
+                              scratch_bytes, stream);
+}
+
+extern "C" int cgs_ctx_level_bwd2(int in_dim, const float *X, const float *W1, const float *b1, const float *W2q,
+                                  const float *b2q, const float *dyf, const float *dys, const float *dyo, const float *dQ_ext,
+                                  int64_t n, uint64_t seed, float q0f, float q0s, float q0o, const int64_t *rows, int64_t n_anchor,
+                                  float *dxf, float *dxs, float *dxo, const int32_t *side_map, int64_t m_side, const float *side_f,
+                                  const float *side_s, const float *side_o, const float *side_Q, const float *dx_sub, float *dX,
+                                  float *d_hyp_rows, float *dW1, float *db1, float *dW2q, float *db2q, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
     if (n < 0 || n_anchor < 0 || m_side < 0 || (in_dim != 71 && in_dim != 15)) { cgs_set_error("ctx_level_bwd: bad args (in_dim 71 or 15)"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!X || !W1 || !b1 || !W2q || !b2q || !rows || !dxf || !dxs || !dxo || !dX || !dW1 || !db1 || !dW2q || !db2q || !scratch) {
@@ -721,7 +758,7 @@ extern "C" int cgs_ctx_level_bwd(int in_dim, const float *X, const float *W1, co
     a.X = X; a.W1 = W1; a.b1 = b1; a.W2q = W2q; a.b2q = b2q; a.dyf = dyf; a.dys = dys; a.dyo = dyo; a.dQ_ext = dQ_ext;
     a.rows = rows; a.dxf = dxf; a.dxs = dxs; a.dxo = dxo; a.side_map = side ? side_map : nullptr; a.side_f = side ? side_f : nullptr;
     a.side_s = side ? side_s : nullptr; a.side_o = side ? side_o : nullptr; a.side_Q = side ? side_Q : nullptr;
-    a.dx_sub = side ? dx_sub : nullptr; a.dX = dX; a.partial = (float *)scratch;
+    a.dx_sub = side ? dx_sub : nullptr; a.dX = dX; a.dhyp = d_hyp_rows; a.partial = (float *)scratch;
     a.n = n; a.n_anchor = n_anchor; a.m = side ? m_side : 0; a.seed = seed; a.q0f = q0f; a.q0s = q0s; a.q0o = q0o;
     {
         CgsProfScope prof(CGS_PROF_CTX_BWD, (hipStream_t)stream);

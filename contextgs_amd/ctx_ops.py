@@ -158,6 +158,29 @@ def next_seed() -> int:
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & (2 ** 63 - 1)
 
 
+class HyperDirect:
+    """Where the fused levels' backward kernels leave the gradient of the noisy hyper latents: ONE [N, C] buffer in the latents' own
+    row order, row rows[r] written by the level that owns anchor rows[r] (cgs_ctx_level_bwd2) — instead of one strided column slice
+    of dX per level that the hyper prior's backward gathers through the inverse coding permutation (a 49 us pass at 1 M anchors).
+    Created by EntropyBottleneck.training_step_forms(sizes=...), reachable from every level block as `block._cgs_hyp_direct =
+    (holder, block index)`; the hyper prior's backward takes the buffer when every non-empty block was written this way and
+    repairs the others' rows otherwise."""
+
+    def __init__(self, n_rows: int, channels: int, sizes):
+        self.n, self.c, self.sizes = int(n_rows), int(channels), tuple(int(t) for t in sizes)
+        self.buf, self.done = None, set()
+
+    def buffer(self, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.n, self.c, dtype=_f32, device=device)
+        return self.buf
+
+    def take(self):
+        buf, done = self.buf, self.done
+        self.buf, self.done = None, set()
+        return buf, done
+
+
 class RowSource:
     """The three per-anchor parameter tensors (features [N,D], scaling [N,S], offsets [N,K,3]) read THROUGH a row
     index by the level kernels, instead of being gathered into coding order first.
@@ -784,6 +807,7 @@ def choose_rows(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref
 
 # ---- one launch per level and direction for the every-row half of the level loop (csrc/ctx_level.hip) ---------------
 ANCHOR_SHARED = os.environ.get("CGS_ANCHOR_SHARED", "1") != "0"      # A/B knob: 0 = one zero-filled [N,3] anchor gradient per level (rounds 5)
+HYPER_DIRECT = os.environ.get("CGS_HYPER_DIRECT", "1") != "0"        # A/B knob: 0 = the hyper latents' gradient leaves the levels as column slices of dX (gather_rows_segmented)
 PREFIX_INPLACE = os.environ.get("CGS_PREFIX_INPLACE", "1") != "0"    # A/B knob: 0 = the coded prefix's gradient as its own tensors, summed by autograd
 
 
@@ -964,13 +988,20 @@ class _LevelFused(torch.autograd.Function):
         dxf, dxs, dxo = src.grad_buffers()
         dX = torch.empty(n, in_f, dtype=_f32, device=dev)
         ws2 = torch.empty(int(L.cgs_ctx_level_bwd_scratch_bytes()), dtype=torch.uint8, device=dev)
-        _lib.check(L.cgs_ctx_level_bwd(
+        # the hyper latents' gradient rows straight into the hyper prior's buffer (HyperDirect), when this level's block of latents
+        # came from training_step_forms(sizes=) and the latents are indexed like the per-anchor tensors (rows = coding permutation)
+        hd, d_hyp_rows = cfg.get("hyp_direct"), None
+        if hd is not None and ctx.needs_input_grad[3] and hd[0].n == int(dxf.shape[0]) and hd[0].c == 12 and hd[0].sizes[hd[1]] == n:
+            d_hyp_rows = hd[0].buffer(dev)
+        _lib.check(L.cgs_ctx_level_bwd2(
             in_f, _lib.ptr(X), _lib.ptr(W1), _lib.ptr(b1), W2.data_ptr() + 4 * n_stat * hid, b2.data_ptr() + 4 * n_stat,
             _lib.ptr(gf), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(gQ), n, int(cfg["seed"]), cfg["q0"][0], cfg["q0"][1], cfg["q0"][2],
             _lib.ptr(rows), int(dxf.shape[0]), _lib.ptr(dxf), _lib.ptr(dxs), _lib.ptr(dxo), _lib.ptr(smap),
             int(sd[0].shape[0]) if sd[0] is not None else 0, *[_lib.ptr(t) for t in sd],
-            _lib.ptr(dx_sub), _lib.ptr(dX), _lib.ptr(dW1), _lib.ptr(db1), dW2.data_ptr() + 4 * n_stat * hid,
+            _lib.ptr(dx_sub), _lib.ptr(dX), _lib.ptr(d_hyp_rows), _lib.ptr(dW1), _lib.ptr(db1), dW2.data_ptr() + 4 * n_stat * hid,
             db2.data_ptr() + 4 * n_stat, _lib.ptr(ws2), ws2.numel(), stream), "cgs_ctx_level_bwd")
+        if d_hyp_rows is not None:
+            hd[0].done.add(hd[1])
         if side is not None:
             side.map = side.f = side.s = side.o = side.q = None
         src.rows_written += n
@@ -1000,9 +1031,9 @@ class _LevelFused(torch.autograd.Function):
                 d_f = None                  # (already summed into the earlier levels' slices)
             if in_s_ is not None:
                 d_s = None
-            d_hyp = dX[:, 59:] if need[3] else None          # a column slice: its consumer takes strided rows
+            d_hyp = dX[:, 59:] if (need[3] and d_hyp_rows is None) else None          # a column slice: its consumer takes strided rows
         else:                                    # first level: X = [anchor[a_rows] * mask | hyper]
-            d_hyp = dX[:, 3:] if need[3] else None
+            d_hyp = dX[:, 3:] if (need[3] and d_hyp_rows is None) else None
             if d_anchor is not None:
                 a_mask = cfg["a_mask"]
                 if a_mask is not None:
@@ -1043,5 +1074,5 @@ def level_fused(anchor, base_f, base_s, hyp, seq, n_stat, loc, a_rows, a_mask, p
     l1, l2 = seq[0], seq[2]
     cfg = dict(a_rows=a_rows, a_mask=a_mask, pos=pos, csr=csr, loc=loc, n_stat=int(n_stat), src=src, rows=rows,
                seed=next_seed() if seed is None else int(seed), q0=tuple(float(v) for v in q0), outs=outs, side=side,
-               rate_lazy=bool(rate_lazy), pre=pre)
+               rate_lazy=bool(rate_lazy), pre=pre, hyp_direct=getattr(hyp, "_cgs_hyp_direct", None) if HYPER_DIRECT else None)
     return _LevelFused.apply(anchor, base_f, base_s, hyp, l1.weight, l1.bias, l2.weight, l2.bias, src.token, cfg)

@@ -96,7 +96,7 @@ class _HyperStep(torch.autograd.Function):
     buffer that autograd then adds in full."""
 
     @staticmethod
-    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed, noisy=None, sizes=None, rows_orig=None):
+    def forward(ctx, x, perm, inv_perm, rows_pos, packed, seed, noisy=None, sizes=None, rows_orig=None, holder=None):
         from . import _lib
         L = _lib.lib()
         x, packed = x.contiguous(), packed.contiguous()
@@ -125,6 +125,7 @@ class _HyperStep(torch.autograd.Function):
             # autograd's cat of the split + a copy + a gather.  rows_orig = perm[rows_pos] (the subset's anchor rows).
             ctx.sizes = tuple(int(t) for t in sizes)
             assert sum(ctx.sizes) == N
+            ctx.holder, ctx.perm = holder, perm         # ctx_ops.HyperDirect: the fused levels' backward may write g_x's rows themselves
             ctx.set_materialize_grads(False)
             ctx.save_for_backward(v, rows_pos, packed, inv_perm, rows_orig if rows_orig is not None else rows_pos)
             return (*torch.split(v, ctx.sizes), bits)
@@ -147,8 +148,19 @@ class _HyperStep(torch.autograd.Function):
             g_p = torch.zeros_like(packed)
             _lib.check(L.cgs_eb_bits_bwd(_lib.ptr(v), _lib.ptr(rows), _lib.ptr(packed), _lib.ptr(g_bits.contiguous()), n, C,
                                          _lib.ptr(g_sub), _lib.ptr(g_p), stream), "cgs_eb_bits_bwd")
-        if all(g is None for g in g_blocks) and g_sub is None:
-            return (None,) * 9
+        hd = getattr(ctx, "holder", None)
+        direct, done = hd.take() if hd is not None else (None, set())
+        if direct is not None and not done:
+            direct = None
+        if all(g is None for g in g_blocks) and g_sub is None and direct is None:
+            return (None,) * 10
+        if direct is not None and all((sz == 0) or (j in done and g is None) for j, (g, sz) in enumerate(zip(g_blocks, ctx.sizes))):
+            # every level wrote its rows of the latents' gradient itself, in parameter order (cgs_ctx_level_bwd2): nothing to gather
+            g_x = direct
+            if g_sub is not None:
+                from .ctx_ops import add_rows_
+                add_rows_(g_x, rows_orig, g_sub)
+            return g_x, None, None, None, g_p, None, None, None, None, None
         srcs, lds, begin = [], [], [0]
         for g, sz in zip(g_blocks, ctx.sizes):
             if g is not None and (g.dtype != torch.float32 or g.stride(1) != 1 or (sz > 1 and g.stride(0) < C)):
@@ -162,10 +174,15 @@ class _HyperStep(torch.autograd.Function):
             k, (C_.c_void_p * k)(*[None if (t is None or t.numel() == 0) else t.data_ptr() for t in srcs]),
             (C_.c_int64 * k)(*lds), (C_.c_int64 * (k + 1))(*begin), _lib.ptr(inv_perm), N, C, _lib.ptr(g_x), stream),
             "cgs_gather_rows_segmented")
+        if direct is not None:          # some levels wrote their rows directly, others came back as blocks: add the direct rows
+            for j in sorted(done):
+                pos = torch.arange(begin[j], begin[j + 1], device=dev)
+                rows_j = pos if ctx.perm is None else ctx.perm[begin[j]:begin[j + 1]]
+                g_x.index_add_(0, rows_j, direct[rows_j])
         if g_sub is not None:
             from .ctx_ops import add_rows_
             add_rows_(g_x, rows_orig, g_sub)             # the rate subset's rows (distinct), in parameter order
-        return g_x, None, None, None, g_p, None, None, None, None
+        return g_x, None, None, None, g_p, None, None, None, None, None
 
     @staticmethod
     def backward(ctx, *gs):
@@ -190,11 +207,11 @@ class _HyperStep(torch.autograd.Function):
                 g_v = torch.zeros_like(v) if g_v is None else g_v.clone(memory_format=torch.contiguous_format)
                 g_v.index_add_(0, rows, g_sub)
         if g_v is None:
-            return None, None, None, None, g_p, None, None, None, None
+            return None, None, None, None, g_p, None, None, None, None, None
         # rows of 48 bytes: torch's index_select takes its slow "vectorized gather" path for 16-byte-multiple rows
         # (210 us for [1 M, 12] on gfx950); the one-source rowcat kernel does the same gather in ~35 us
         g_x = g_v if inv_perm is None else ctx_ops.gather_rows_nograd(g_v, inv_perm)
-        return g_x, None, None, None, g_p, None, None, None, None
+        return g_x, None, None, None, g_p, None, None, None, None, None
 
 
 class HyperBitSum:
@@ -403,9 +420,16 @@ class EntropyBottleneck(nn.Module):
         # packed: self._packed_params() evaluated earlier by the caller (the renderer does it before a host read-back, so
         # that the GPU has the launch queued while the host waits)
         # sizes (optional): return the noisy latents as one row block per level (a tuple) — see _HyperStep.forward
+        holder = None
+        if sizes is not None:
+            from .ctx_ops import HyperDirect
+            holder = HyperDirect(x.shape[0], x.shape[1], sizes)
         out = _HyperStep.apply(x, perm, inv_perm, rows_pos, self._packed_params() if packed is None else packed, seed, noisy,
-                               sizes, rows_orig)
+                               sizes, rows_orig, holder)
         v_p, bits = (out[0], out[1]) if len(out) == 2 else (tuple(out[:-1]), out[-1])
+        if isinstance(v_p, tuple) and holder is not None and len(v_p) == len(holder.sizes):
+            for j_, blk in enumerate(v_p):               # ctx_ops.level_fused finds the holder on its block of latents
+                blk._cgs_hyp_direct = (holder, j_)
         n_rows = int(rows_pos.shape[0]) if rows_pos is not None else int(x.shape[0])
         return v_p, HyperBitSum(bits, n_rows * self.channels)
 

@@ -593,6 +593,17 @@ int cgs_ctx_level_bwd(int in_dim, const float *X, const float *W1, const float *
                       const int32_t *side_map, int64_t m_side, const float *side_f, const float *side_s, const float *side_o, const float *side_Q,
                       const float *dx_sub, float *dX, float *dW1, float *db1, float *dW2q, float *db2q,
                       void *scratch, size_t scratch_bytes, void *stream);
+/* cgs_ctx_level_bwd with one more output: d_hyp_rows [n_anchor, 12] (may be NULL = cgs_ctx_level_bwd) — row rows[r] also receives the
+ * last 12 columns of dX[r], the gradient of the level's hyper latents, in the latents' own row order (every anchor belongs to one
+ * level: after all levels of a step every row is written, and the hyper prior's backward needs no pass through the inverse coding
+ * permutation; scene/gaussian_model.py:1588-1600 concatenates the latents into the level MLP's input). */
+int cgs_ctx_level_bwd2(int in_dim, const float *X, const float *W1, const float *b1, const float *W2q,
+                       const float *b2q, const float *dyf, const float *dys, const float *dyo,
+                       const float *dQ_ext, int64_t n, uint64_t seed, float q0f, float q0s, float q0o,
+                       const int64_t *rows, int64_t n_anchor, float *dxf, float *dxs, float *dxo,
+                       const int32_t *side_map, int64_t m_side, const float *side_f, const float *side_s, const float *side_o, const float *side_Q,
+                       const float *dx_sub, float *dX, float *d_hyp_rows, float *dW1, float *db1, float *dW2q, float *db2q,
+                       void *scratch, size_t scratch_bytes, void *stream);
 
 /* Row strides (floats) of the buffers the anchor-MLP forward and backward hand to each other, so that callers size them:
  * out4 = {row stride of Hcat (150: head h in columns 50 h .. 50 h + 49), row stride of X_out of the _rows variant (54),

@@ -151,13 +151,13 @@ def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
     # 10 000 on they pass through the level kernels (quantisation noise, scene/gaussian_model.py:1610-1616) and their gradients
     # leave the LAST of those kernels.)
     Lc = _lib.lib()
-    real_bwd = Lc.cgs_ctx_level_bwd
+    real_bwd = Lc.cgs_ctx_level_bwd2          # (the entry the training path calls: cgs_ctx_level_bwd + the hyper latents' gradient rows)
 
     class _LogBwd:
         def __call__(self, *a):
             log.append(("ctxl_bwd", 0, "", ""))
             return real_bwd(*a)
-    Lc.cgs_ctx_level_bwd = _LogBwd()
+    Lc.cgs_ctx_level_bwd2 = _LogBwd()
     n_mask = int(pc._mask.numel())
     try:
         assert mlp._Deferred.on, "GradientSync did not switch the deferred weight gradients on"
@@ -200,7 +200,7 @@ def collective_sequences(pc, opt, sync, params, cams, pipe, bg, rank):
     finally:
         for k_, fn in real.items():
             setattr(mgpu.dist, k_, fn)
-        Lc.cgs_ctx_level_bwd = real_bwd
+        Lc.cgs_ctx_level_bwd2 = real_bwd
     sync.close()
     dist.barrier()
     print(f"rank {rank}: identical collective sequences in 9 steps (3 phases x 3, one empty view per phase)", flush=True)

@@ -174,6 +174,21 @@ def test_level_kernels_against_a_torch_statement(n, in_dim):
     _lib.check(L.cgs_ctx_level_bwd(in_dim, p(X), p(W1), p(b1), p(W2q), p(b2q), p(dyf), p(dys), p(dyo), p(dQe), n, seed, *q0, p(rows),
                                    N, p(dxf), p(dxs), p(dxo), p(smap), m, p(sf), p(ss), p(so), p(sQ), p(dxsub), p(dX), p(dW1), p(db1),
                                    p(dW2q), p(db2q), p(ws), ws.numel(), _lib.current_stream()), "bwd")
+    # cgs_ctx_level_bwd2: the same launch + the hyper columns of dX (the last 12) scattered to rows rows[r] of a [N, 12] buffer; every
+    # other output bit-equal to cgs_ctx_level_bwd's, rows no level row names untouched
+    dxf2, dxs2, dxo2 = (torch.full((N, w), 7.0, device=dev) for w in (50, 6, 30))
+    dX2, dh = torch.empty(n, in_dim, device=dev), torch.full((N, 12), 9.0, device=dev)
+    dW1b, db1b, dW2qb, db2qb = torch.ones(100, in_dim, device=dev), torch.ones(100, device=dev), torch.ones(3, 100, device=dev), \
+        torch.ones(3, device=dev)
+    _lib.check(L.cgs_ctx_level_bwd2(in_dim, p(X), p(W1), p(b1), p(W2q), p(b2q), p(dyf), p(dys), p(dyo), p(dQe), n, seed, *q0, p(rows),
+                                    N, p(dxf2), p(dxs2), p(dxo2), p(smap), m, p(sf), p(ss), p(so), p(sQ), p(dxsub), p(dX2), p(dh), p(dW1b),
+                                    p(db1b), p(dW2qb), p(db2qb), p(ws), ws.numel(), _lib.current_stream()), "bwd2")
+    assert torch.equal(dX2, dX) and torch.equal(dxf2, dxf) and torch.equal(dxs2, dxs) and torch.equal(dxo2, dxo)
+    assert torch.equal(dW1b, dW1) and torch.equal(db1b, db1) and torch.equal(dW2qb, dW2q) and torch.equal(db2qb, db2q)
+    assert torch.equal(dh[rows], dX[:, in_dim - 12:])
+    not_named = torch.ones(N, dtype=torch.bool, device=dev)
+    not_named[rows] = False
+    assert bool((dh[not_named] == 9.0).all())
     gf, gs, go = dyf.clone(), dys.clone(), dyo.clone()
     gf[sub] += sf; gs[sub] += ss; go[sub] += so
     for d, gg, w in ((dxf, gf, 50), (dxs, gs, 6), (dxo, go, 30)):

@@ -364,3 +364,43 @@ def test_early_launches_change_nothing_but_the_order():
     assert close(a[2], b[2]) and close(a[3], b[3])
     for x, y in zip(a[4], b[4]):
         assert close(x, y)
+
+
+def test_hyper_latent_gradient_rows_written_by_the_levels_equal_the_gathered_blocks():
+    """The fused levels' backward writes the hyper latents' gradient rows straight into one buffer in parameter order
+    (ctx_ops.HyperDirect, cgs_ctx_level_bwd2) instead of handing one strided block per level to the hyper prior's backward, which
+    gathered them through the inverse coding permutation: the same values by another route (compared up to the run-to-run noise of
+    the blend backward's float atomics, which reaches the level kernels through dy), and the direct route must actually be taken;
+    the kernel-level statement is bit-exact: tests/test_ctx_level_gpu.py."""
+    import itertools
+    from contextgs_amd import ctx_ops
+    outs, taken = [], []
+    for direct in (True, False):
+        pc, cams, pipe, bg = _setup(N=12000, W=256, H=144, seed=11)
+        old = ctx_ops.HYPER_DIRECT
+        ctx_ops.HYPER_DIRECT = direct
+        real = ctx_ops.HyperDirect.take
+        seen = []
+
+        def take(self, _real=real, _seen=seen):
+            buf, done = _real(self)
+            _seen.append((buf is not None, len(done)))
+            return buf, done
+        ctx_ops.HyperDirect.take = take
+        try:
+            _ctx_step(pc, cams[0], pipe, bg)
+            ctx_ops._seed_counter = itertools.count(2000)
+            pkg, loss = _ctx_step(pc, cams[1], pipe, bg)
+        finally:
+            ctx_ops.HYPER_DIRECT = old
+            ctx_ops.HyperDirect.take = real
+        taken.append(list(seen))
+        outs.append((pc._hyper_latent.grad.clone(), [p.grad.clone() for p in pc.latent_codec.parameters() if p.grad is not None]))
+    assert taken[0] and all(t[0] and t[1] >= 1 for t in taken[0]), f"the direct route was not taken: {taken[0]}"
+    assert all(not t[0] for t in taken[1])
+    assert float(outs[0][0].abs().sum()) > 0
+    close = lambda x, y: float((x - y).abs().max()) <= 2e-5 * float(x.abs().max()) + 1e-12
+    assert close(outs[0][0], outs[1][0])
+    assert bool(((outs[0][0] != 0) == (outs[1][0] != 0)).all())              # the same rows carry a gradient
+    for x, y in zip(outs[0][1], outs[1][1]):
+        assert close(x, y)
