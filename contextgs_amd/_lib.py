@@ -140,6 +140,9 @@ SIGNATURES = {
     "cgs_ctx_choose_blocks": (c_size_t, [c_int64]),
     "cgs_ctx_choose_flags": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, C.c_uint64, c_float, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cgs_ctx_choose_slot_ints": (c_int, []),
+    "cgs_ctx_choose_flags_slots": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, C.c_uint64, c_float, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "cgs_ctx_choose_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "cgs_means_accum_doubles": (c_size_t, []),

@@ -20,6 +20,7 @@
 #define CP_PER_THREAD 4           // (16 was tried in round 6 for fewer closing atomics: flags 36 -> 41 us, compact 11 -> 25 us: worse)
 #define CP_CHUNK (CP_THREADS * CP_PER_THREAD)
 #define CP_MAX_LEVELS 8
+#define CP_SLOT_INTS 32           // ints between two slots of the spread `meta` (cgs_ctx_choose_flags_slots): a 128-byte line each
 
 namespace {
 
@@ -47,7 +48,10 @@ __global__ void __launch_bounds__(CP_THREADS)
                             const uint8_t *__restrict__ given, uint64_t seed, float thresh,
                             const float *__restrict__ anchor, const float *__restrict__ anchor_ref,
                             const uint8_t *__restrict__ mask_ref, CpBounds B, uint8_t *__restrict__ flags,
-                            uint32_t *__restrict__ block_counts, int32_t *__restrict__ meta) {
+                            uint32_t *__restrict__ block_counts, int32_t *__restrict__ meta_all, int nslots) {
+    // (a block's closing atomics go to slot blockIdx.x % nslots, CP_SLOT_INTS ints = one 128-byte line per slot: ~1000 blocks adding
+    //  to ONE live counter serialise on that address — most of the kernel's 34 us with a single slot)
+    int32_t *__restrict__ meta = meta_all + (size_t)(blockIdx.x % (unsigned)nslots) * CP_SLOT_INTS;
     // per-thread tallies, reduced once per block: [0] chosen, [1] live, [2] stale, [3 + l] chosen of level l
     __shared__ uint32_t tally[3 + CP_MAX_LEVELS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,16 +196,19 @@ extern "C" size_t cgs_ctx_choose_blocks(int64_t n) { return (size_t)((n + CP_CHU
 // meta: int32 [2 + nlevels], ZEROED by this call before the kernel: [0] != 0 <=> anchor / mask differ from the
 // reference copies, [1] = number of live (mask != 0) anchors, [2 + l] = chosen rows of level l (coding order).
 // bounds_host: int64 [nlevels + 1], coding-order level boundaries (bounds[0] = 0, bounds[nlevels] = n).
-extern "C" int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask, const uint8_t *given,
-                                    uint64_t seed, float thresh, const float *anchor, const float *anchor_ref,
-                                    const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels, uint8_t *flags,
-                                    uint32_t *block_counts, int32_t *meta, void *stream) {
-    if (n < 0 || nlevels < 1 || nlevels > CP_MAX_LEVELS || !bounds_host || !flags || !block_counts || !meta) {
+// meta_slots: int32 [nslots][32] (cgs_ctx_choose_flags_slots; ZEROED by this call): slot s, entries 0 .. 1 + nlevels = the partial
+// `meta` of the blocks s, s + nslots, ...: the caller adds the slots up ([0]: ORs them).  nslots == 1 with a [2 + nlevels] array
+// is cgs_ctx_choose_flags.
+static int cp_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask, const uint8_t *given, uint64_t seed, float thresh,
+                           const float *anchor, const float *anchor_ref, const uint8_t *mask_ref, const int64_t *bounds_host,
+                           int nlevels, uint8_t *flags, uint32_t *block_counts, int32_t *meta, int nslots, void *stream) {
+    if (n < 0 || nlevels < 1 || nlevels > CP_MAX_LEVELS || !bounds_host || !flags || !block_counts || !meta || nslots < 1 || nslots > 256) {
         cgs_set_error("ctx_choose_flags: bad args");
         return CGS_ERR_ARG;
     }
     if ((anchor_ref && !anchor) || (mask_ref && !mask)) { cgs_set_error("ctx_choose_flags: reference without live tensor"); return CGS_ERR_ARG; }
-    CGS_CHECK_HIP(hipMemsetAsync(meta, 0, (size_t)(2 + nlevels) * sizeof(int32_t), (hipStream_t)stream));
+    const size_t meta_bytes = nslots == 1 ? (size_t)(2 + nlevels) * sizeof(int32_t) : (size_t)nslots * CP_SLOT_INTS * sizeof(int32_t);
+    CGS_CHECK_HIP(hipMemsetAsync(meta, 0, meta_bytes, (hipStream_t)stream));
     if (n == 0) return CGS_OK;
     CpBounds B;
     B.n = nlevels;
@@ -209,9 +216,28 @@ extern "C" int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_
     CgsProfScope prof(CGS_PROF_CTX_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(ctx_choose_flags_kernel, dim3((unsigned)cgs_ctx_choose_blocks(n)), dim3(CP_THREADS), 0,
                        (hipStream_t)stream, perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, B, flags,
-                       block_counts, meta);
+                       block_counts, meta, nslots);
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
+}
+
+extern "C" int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask, const uint8_t *given,
+                                    uint64_t seed, float thresh, const float *anchor, const float *anchor_ref,
+                                    const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels, uint8_t *flags,
+                                    uint32_t *block_counts, int32_t *meta, void *stream) {
+    return cp_choose_flags(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds_host, nlevels, flags, block_counts,
+                           meta, 1, stream);
+}
+
+extern "C" int cgs_ctx_choose_slot_ints(void) { return CP_SLOT_INTS; }
+
+extern "C" int cgs_ctx_choose_flags_slots(const int64_t *perm, int64_t n, const uint8_t *mask, const uint8_t *given,
+                                          uint64_t seed, float thresh, const float *anchor, const float *anchor_ref,
+                                          const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels, uint8_t *flags,
+                                          uint32_t *block_counts, int32_t *meta_slots, int nslots, void *stream) {
+    if (nslots < 2) { cgs_set_error("ctx_choose_flags_slots: nslots >= 2 (one slot: cgs_ctx_choose_flags)"); return CGS_ERR_ARG; }
+    return cp_choose_flags(perm, n, mask, given, seed, thresh, anchor, anchor_ref, mask_ref, bounds_host, nlevels, flags, block_counts,
+                           meta_slots, nslots, stream);
 }
 
 // nz / rows / loc: int64 [>= number of chosen rows]; entries appear in coding order.  sub_map (may be NULL): int32 [n],

@@ -356,21 +356,19 @@ __global__ void __launch_bounds__(256)
     if (lane == 0) sh[wave] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        cgs_publish(&partial[blockIdx.x], (sh[0] + sh[1]) + (sh[2] + sh[3]));
+        last = cgs_ticket_last(counter);
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     double t = 0.0;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) t += ((volatile double *)partial)[j];
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) t += cgs_published(&partial[j]);
 #pragma unroll
     for (int k = 32; k >= 1; k >>= 1) t += __shfl_xor(t, k, 64);
     __syncthreads();
     if (lane == 0) sh[wave] = t;
     __syncthreads();
-    if (threadIdx.x == 0) { *out = (float)((sh[0] + sh[1]) + (sh[2] + sh[3])); *counter = 0u; }
+    if (threadIdx.x == 0) *out = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
 // backward of the above for an upstream gradient *g_sum (device scalar): g_v_sub [n, C] (row r <-> rows[r]) and g_raw += .
@@ -430,18 +428,18 @@ __global__ void __launch_bounds__(256)
 }
 
 #define EB_BITS_MAX_BLOCKS 2048
-extern "C" size_t cgs_eb_bits_scratch_bytes(void) { return (size_t)EB_BITS_MAX_BLOCKS * sizeof(double) + 256; }
+extern "C" size_t cgs_eb_bits_scratch_bytes(void) { return (size_t)EB_BITS_MAX_BLOCKS * sizeof(double) + CGS_TICKET_BYTES; }
 
-// scratch: cgs_eb_bits_scratch_bytes() bytes whose last 256 bytes (the arrival counter) are ZERO before the first use (the
-// kernel leaves them zero); out: float [1]
+// scratch: cgs_eb_bits_scratch_bytes() bytes whose last CGS_TICKET_BYTES (the arrival ticket, cgs_ticket_last) are ZERO before the
+// first use (the kernel leaves them zero); out: float [1]
 extern "C" int cgs_eb_bits_fwd(const float *v, const int64_t *rows, const float *raw, int64_t n, int C, void *scratch,
                                size_t scratch_bytes, float *out, void *stream) {
     if (n < 0 || C < 1 || !out || !scratch || scratch_bytes < cgs_eb_bits_scratch_bytes()) { cgs_set_error("eb_bits_fwd: bad args"); return CGS_ERR_ARG; }
     if (n == 0) { CGS_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream)); return CGS_OK; }
     if (!v || !raw) { cgs_set_error("eb_bits_fwd: NULL"); return CGS_ERR_ARG; }
 #ifndef EB_BITS_FWD_BPC
-#define EB_BITS_FWD_BPC 2        // workgroups per CU (3 waves per SIMD would fit); every workgroup ends with an atomic on ONE
-#endif                           // counter (~25 ns each, serial in L2): 8 per CU = 2 040 of them cost 90 us, 3: 50 us, 2: 41 us (same box)
+#define EB_BITS_FWD_BPC 3        // workgroups per CU.  With the textbook arrival ticket (store, __threadfence, atomic: ~25 ns per workgroup,
+#endif                           // serial) 8 per CU = 2 040 workgroups cost 90 us, 3: 50 us, 2: 41 us; fence-free (cgs_publish): 2: 31.0, 3: 30.3, 4 / 8: 34.9 us
     int grid = eb_grid(n, C, EB_BITS_FWD_BPC);
     if (grid > EB_BITS_MAX_BLOCKS) grid = EB_BITS_MAX_BLOCKS / C * C;
     hipLaunchKernelGGL(eb_bits_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, v, rows, raw, n, C, (double *)scratch,

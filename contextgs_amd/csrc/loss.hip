@@ -443,8 +443,10 @@ extern "C" int cgs_sigmoid_mean_bwd(const float *x, const float *g, int64_t n, f
 // The fixed linear objective a throughput measurement puts behind render() (bench.py: sum(image * w) + lambda * bit_per_param,
 // train.py:206-209 with the image term made linear) as ONE launch each way instead of dot (2 launches) + add and two muls.
 // Deterministic: per-workgroup partial sums in double, the last workgroup to finish adds them in workgroup order and clears the
-// counter for the next call (scratch = WS_BLOCKS doubles + one zero-initialised uint32, owned by the caller).
-#define WS_BLOCKS 256       // (one same-address atomic per workgroup closes the launch: ~25 ns each, 1024 of them were most of the kernel)
+// ticket for the next call (scratch = WS_BLOCKS doubles + a zero-initialised arrival ticket, cgs_ticket_last; owned by the caller).
+#ifndef WS_BLOCKS
+#define WS_BLOCKS 512       // (textbook arrival ticket: ~25 ns per workgroup for its __threadfence — 256: 18.8, 512: 26.8, 1024: 47 us; fence-free: 13.4 / 12.5 / 13.1 us)
+#endif
 __global__ void __launch_bounds__(256)
     wsum_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, const float *__restrict__ rate, float lam,
                     double *__restrict__ partial, unsigned int *__restrict__ counter, float *__restrict__ out) {
@@ -473,15 +475,13 @@ __global__ void __launch_bounds__(256)
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        cgs_publish(&partial[blockIdx.x], sh[0] + sh[1] + sh[2] + sh[3]);
+        last = cgs_ticket_last(counter);
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     double v = 0.0;
-    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) v += ((volatile double *)partial)[j];
+    for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) v += cgs_published(&partial[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
@@ -489,7 +489,6 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]) + (rate ? lam * rate[0] : 0.f);
-        *counter = 0u;
     }
 }
 
@@ -507,7 +506,7 @@ __global__ void __launch_bounds__(256)
     if (drate && t0 == 0) drate[0] = gv * lam;
 }
 
-extern "C" size_t cgs_weighted_sum_scratch_bytes(void) { return (size_t)WS_BLOCKS * sizeof(double) + 256; }
+extern "C" size_t cgs_weighted_sum_scratch_bytes(void) { return (size_t)WS_BLOCKS * sizeof(double) + CGS_TICKET_BYTES; }
 
 extern "C" int cgs_weighted_sum_fwd(const float *img, const float *w, int64_t n, const float *rate, float lam, void *scratch,
                                     size_t scratch_bytes, float *out, void *stream) {

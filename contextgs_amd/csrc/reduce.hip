@@ -31,26 +31,24 @@ means3_kernel(const float *__restrict__ a, int64_t na, const float *__restrict__
     sb = m3_block_sum(sb, sh);
     sc = m3_block_sum(sc, sh);
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = sa;
-        partial[gridDim.x + blockIdx.x] = sb;
-        partial[2 * gridDim.x + blockIdx.x] = sc;
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        // (published by device-scope exchanges, no fence: cgs_ticket_last in cgs_internal.h)
+        cgs_publish(&partial[blockIdx.x], sa);
+        cgs_publish(&partial[gridDim.x + blockIdx.x], sb);
+        cgs_publish(&partial[2 * gridDim.x + blockIdx.x], sc);
+        last = cgs_ticket_last(counter);
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();
     const int64_t n[3] = {na, nb, nc};
     for (int k = 0; k < 3; ++k) {
         double v = 0.0;
-        for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) v += ((volatile double *)partial)[k * gridDim.x + j];
+        for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) v += cgs_published(&partial[k * gridDim.x + j]);
         v = m3_block_sum(v, sh);
         if (threadIdx.x == 0) out[k] = n[k] > 0 ? (float)(v / (double)n[k]) : 0.f;
     }
-    if (threadIdx.x == 0) *counter = 0u;
 }
 
-extern "C" size_t cgs_means3_scratch_bytes(void) { return (size_t)3 * M3_BLOCKS * sizeof(double) + 256; }
+extern "C" size_t cgs_means3_scratch_bytes(void) { return (size_t)3 * M3_BLOCKS * sizeof(double) + CGS_TICKET_BYTES; }
 
 extern "C" int cgs_means3(const float *a, int64_t na, const float *b, int64_t nb, int exp_b, const float *c, int64_t nc,
                           void *scratch, size_t scratch_bytes, float *out3, void *stream) {
@@ -61,7 +59,7 @@ extern "C" int cgs_means3(const float *a, int64_t na, const float *b, int64_t nb
     if ((na && !a) || (nb && !b) || (nc && !c)) { cgs_set_error("means3: NULL input"); return CGS_ERR_ARG; }
     double *partial = (double *)scratch;
     unsigned int *counter = (unsigned int *)((char *)scratch + (size_t)3 * M3_BLOCKS * sizeof(double));
-    CGS_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), (hipStream_t)stream));
+    CGS_CHECK_HIP(hipMemsetAsync(counter, 0, CGS_TICKET_BYTES, (hipStream_t)stream));
     hipLaunchKernelGGL(means3_kernel, dim3(M3_BLOCKS), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, exp_b, c, nc, partial,
                        counter, out3);
     CGS_CHECK_HIP(hipGetLastError());

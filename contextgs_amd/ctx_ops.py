@@ -731,6 +731,7 @@ def means3(a, b, c, exp_b=False):
 
 
 _PINNED_FREE = []
+CHOOSE_SLOTS = int(os.environ.get("CGS_CHOOSE_SLOTS", "32"))          # A/B knob: 1 = one `meta` array for all blocks (rounds 4-6)
 
 
 def _pinned_i32(k):
@@ -753,28 +754,39 @@ def choose_rows_begin(perm, n, mask, given, seed, thresh, anchor, anchor_ref, ma
     nblk = int(L.cgs_ctx_choose_blocks(n))
     flags = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
     counts = torch.empty(max(nblk, 1), dtype=torch.int32, device=dev)
-    meta = torch.empty(2 + nlev, dtype=torch.int32, device=dev)
+    # the blocks' closing atomics spread over CHOOSE_SLOTS lines (one counter for ~1000 blocks serialises on its address); the host
+    # adds the slots up after the read it makes anyway
+    slots, sw = (CHOOSE_SLOTS, int(L.cgs_ctx_choose_slot_ints())) if CHOOSE_SLOTS >= 2 else (1, 2 + nlev)
+    meta = torch.empty(slots * sw, dtype=torch.int32, device=dev)
     b_host = (C.c_int64 * (nlev + 1))(*[int(b) for b in bounds])
-    _lib.check(L.cgs_ctx_choose_flags(_lib.ptr(perm), n, _lib.ptr(mask_u8), _lib.ptr(given_u8), int(seed), float(thresh),
-                                      _lib.ptr(None if anchor is None else _c(anchor)),
-                                      _lib.ptr(None if anchor_ref is None else _c(anchor_ref)), _lib.ptr(mref_u8), b_host,
-                                      nlev, _lib.ptr(flags), _lib.ptr(counts), _lib.ptr(meta), _lib.current_stream()),
-               "cgs_ctx_choose_flags")
+    args = (_lib.ptr(perm), n, _lib.ptr(mask_u8), _lib.ptr(given_u8), int(seed), float(thresh),
+            _lib.ptr(None if anchor is None else _c(anchor)), _lib.ptr(None if anchor_ref is None else _c(anchor_ref)), _lib.ptr(mref_u8),
+            b_host, nlev, _lib.ptr(flags), _lib.ptr(counts), _lib.ptr(meta))
+    if slots >= 2:
+        _lib.check(L.cgs_ctx_choose_flags_slots(*args, slots, _lib.current_stream()), "cgs_ctx_choose_flags_slots")
+    else:
+        _lib.check(L.cgs_ctx_choose_flags(*args, _lib.current_stream()), "cgs_ctx_choose_flags")
     # the counts travel to a pinned host buffer behind the kernel, with an event of their own: choose_rows_end waits for
     # THAT copy (long finished by then) instead of draining whatever the caller has queued since
-    pinned = _pinned_i32(2 + nlev)
-    pinned[:2 + nlev].copy_(meta, non_blocking=True)
+    pinned = _pinned_i32(slots * sw)
+    pinned[:slots * sw].copy_(meta, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     return dict(perm=perm, n=n, nlev=nlev, flags=flags, counts=counts, meta=meta, b_host=b_host, dev=dev,
-                keep=(mask_u8, given_u8, mref_u8), pinned=pinned, event=ev)
+                keep=(mask_u8, given_u8, mref_u8), pinned=pinned, event=ev, slots=(slots, sw))
 
 
 def choose_rows_end(h):
     """Second half: read the counts (the step's synchronisation of the context model), compact the chosen rows."""
     L = _lib.lib()
     h["event"].synchronize()
-    host = h["pinned"][:2 + h["nlev"]].tolist()
+    slots, sw = h["slots"]
+    k_ = 2 + h["nlev"]
+    if slots >= 2:
+        part = h["pinned"][:slots * sw].view(slots, sw)[:, :k_]
+        host = [int(bool(part[:, 0].any()))] + [int(v) for v in part[:, 1:].sum(dim=0).tolist()]
+    else:
+        host = h["pinned"][:k_].tolist()
     _PINNED_FREE.append(h.pop("pinned"))
     stale, live, per_level = bool(host[0]), int(host[1]), [int(v) for v in host[2:]]
     total = sum(per_level)

@@ -458,7 +458,7 @@ int cgs_noise_quant_fwd(const float *xf, const float *xs, const float *xo,
  * counter-based u(seed, tensor 3, a*C + c) — EntropyBottleneck's training quantisation, delivered in coding
  * order.  eb_bits: out[0] = sum over rows[0..n) (NULL: 0..n) and channels of -log2(max(likelihood, 1e-9))
  * of v [.,C] under the packed prior raw [C,58]; deterministic (block partials added in block order).
- * scratch: cgs_eb_bits_scratch_bytes(), its last 256 bytes zero before the first use.  eb_bits_bwd: for the
+ * scratch: cgs_eb_bits_scratch_bytes() bytes, ZERO before the first use (the kernel leaves its arrival ticket zero).  eb_bits_bwd: for the
  * upstream gradient *g_sum (device scalar) g_v_sub [n,C] (row r <-> rows[r]) and g_raw [C,58] += . */
 int cgs_hyper_noise_gather(const float *hyper, const int64_t *perm, int64_t n, int C,
                            uint64_t seed, float *out, void *stream);
@@ -496,6 +496,15 @@ int cgs_ctx_choose_flags(const int64_t *perm, int64_t n, const uint8_t *mask,
                          const float *anchor, const float *anchor_ref,
                          const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels,
                          uint8_t *flags, uint32_t *block_counts, int32_t *meta, void *stream);
+/* The same with `meta` spread over nslots (2 .. 256) slots of cgs_ctx_choose_slot_ints() ints each (one 128-byte line; zeroed by the
+ * call): slot s holds the partial meta of the blocks s, s + nslots, ...; the caller adds entries [1 ..] over the slots and ORs [0].
+ * (~1000 workgroups adding to one counter serialise on its address: 34 -> ~15 us at 1 M anchors.) */
+int cgs_ctx_choose_slot_ints(void);
+int cgs_ctx_choose_flags_slots(const int64_t *perm, int64_t n, const uint8_t *mask,
+                               const uint8_t *given, uint64_t seed, float thresh,
+                               const float *anchor, const float *anchor_ref,
+                               const uint8_t *mask_ref, const int64_t *bounds_host, int nlevels,
+                               uint8_t *flags, uint32_t *block_counts, int32_t *meta_slots, int nslots, void *stream);
 int cgs_ctx_choose_compact(const uint8_t *flags, const uint32_t *block_counts,
                            const int64_t *perm, int64_t n, const int64_t *bounds_host,
                            int nlevels, int64_t *nz, int64_t *rows, int64_t *loc,
