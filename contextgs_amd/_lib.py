@@ -106,6 +106,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "cgs_anchor_mlp3_forward_rows": (c_int, [c_void_p] * 13 + [c_int64, c_void_p]),
     "cgs_anchor_mlp3_backward_rows": (c_int, [c_void_p] * 22 + [c_int64, c_void_p, c_size_t, c_void_p]),
+    "cgs_anchor_mlp3_forward_rows_t": (c_int, [c_void_p] * 13 + [c_int64, c_int, c_void_p]),
+    "cgs_anchor_mlp3_backward_rows_t": (c_int, [c_void_p] * 22 + [c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "cgs_rowcat_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_rowcat_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "cgs_anchor_mlp3_layout": (c_int, [c_void_p]),

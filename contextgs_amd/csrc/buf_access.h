@@ -91,3 +91,60 @@ __device__ __forceinline__ void frag_bstore4(ClBuf b, uint32_t rowoff, int q, in
     if (DIM % 4 == 2) cl_s64(b, cl_sel(on && col0 + 2 == DIM, o), v);
     if (DIM % 4 == 1) cl_s32(b, cl_sel(on && col0 + 1 == DIM, o), v[0]);
 }
+
+// The same pieces of a hand-over buffer in FRAGMENT-MAJOR ("tiled") form: per 16-row tile (DIM * 64 bytes at `tilebase`) the full
+// 16-column pieces come first, 1 KB each in LANE order (lane 16 g + c -> its 16 bytes: one store / load instruction of a wave is one
+// contiguous, aligned KB instead of sixteen 64-byte chunks DIM * 4 bytes apart that straddle sectors), then the DIM % 16 tail
+// columns row by row.  c = the lane's row of the tile.  Same bytes as the row-major form (rows padded to a multiple of 16).
+template <int DIM>
+__device__ __forceinline__ uint32_t frag_toff(int q, int g, int c) {
+    constexpr int FULL = DIM / 16, TAIL = DIM % 16;
+    return q < FULL ? (uint32_t)(q * 1024 + (16 * g + c) * 16) : (uint32_t)(FULL * 1024 + c * (TAIL * 4) + 16 * g);
+}
+template <int DIM>
+__device__ __forceinline__ f32x4 frag_tload4(ClBuf b, uint32_t tilebase, int q, int g, int c, bool on) {
+    const int col0 = 16 * q + 4 * g;
+    return cl_l128(b, cl_sel(on && col0 < DIM, tilebase + frag_toff<DIM>(q, g, c)));
+}
+template <int DIM>
+__device__ __forceinline__ void frag_tstore4(ClBuf b, uint32_t tilebase, int q, int g, int c, bool on, f32x4 v) {
+    const int col0 = 16 * q + 4 * g;
+    const uint32_t o = tilebase + frag_toff<DIM>(q, g, c);
+    if (16 * q + 15 < DIM) { cl_s128(b, cl_sel(on, o), v); return; }
+    cl_s128(b, cl_sel(on && col0 + 3 < DIM, o), v);
+    if (DIM % 4 == 3) cl_s96(b, cl_sel(on && col0 + 3 == DIM, o), v);
+    if (DIM % 4 == 2) cl_s64(b, cl_sel(on && col0 + 2 == DIM, o), v);
+    if (DIM % 4 == 1) cl_s32(b, cl_sel(on && col0 + 1 == DIM, o), v[0]);
+}
+
+// A 16-row tile of a ROW-MAJOR [*, DIM] array stored from its fragments through a per-wave LDS patch of 16 * DIM floats: the
+// fragments are written to the patch in row-major order, and the patch — byte for byte the tile's memory image, 64 * DIM contiguous
+// bytes at `tile_off` of b — leaves as contiguous 1 KB store instructions instead of sixteen 64-byte chunks a row apart per
+// fragment.  Rows behind the end of b are dropped by its bounds check (the tile's valid rows are a prefix of its image).
+// LDS operations of one wave execute in order: no barrier between the two phases, nor before the patch's next use.
+typedef float f32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+template <int DIM, int NT>
+__device__ __forceinline__ void frag_tile_store(float *patch, ClBuf b, uint32_t tile_off, const f32x4 (&v)[NT], int g, int c, int lane) {
+    static_assert(DIM % 2 == 0, "8-byte aligned pieces");
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col0 = 16 * u + 4 * g;
+        float *p = patch + c * DIM + col0;
+        const f32x2_a8 lo = (f32x2_a8){v[u][0], v[u][1]}, hi = (f32x2_a8){v[u][2], v[u][3]};
+        if (16 * u + 15 < DIM) {
+            *(f32x2_a8 *)p = lo;
+            *(f32x2_a8 *)(p + 2) = hi;
+        } else {
+            if (col0 + 1 < DIM) *(f32x2_a8 *)p = lo;
+            if (col0 + 3 < DIM) *(f32x2_a8 *)(p + 2) = hi;
+        }
+    }
+    constexpr int TB = 64 * DIM;
+#pragma unroll
+    for (int k = 0; k < (TB + 1023) / 1024; ++k) {
+        const int off = k * 1024 + lane * 16;
+        const bool in = (k + 1) * 1024 <= TB || off < TB;
+        const f32x4 t = *(const f32x4 *)((const char *)patch + (in ? off : 0));
+        cl_s128(b, cl_sel(in, tile_off + (uint32_t)off), t);
+    }
+}

@@ -33,6 +33,10 @@
 #ifndef M3_FWD_RT
 #define M3_FWD_RT 1
 #define M3_FWD_WAVES 16
+#ifndef M3_FWD_LDS_STORE
+#define M3_FWD_LDS_STORE 1     // the forward's row-major outputs (Y_*, X_out) leave through a per-wave LDS patch as contiguous 1 KB stores
+#endif
+#define M3_FWD_PATCH (16 * 70)  // floats per wave: the widest tile image (Y_cov)
 #endif
 #ifndef M3_BWD_RT
 #define M3_BWD_RT 2
@@ -87,10 +91,10 @@ __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int ti
 #define M3_MAX_ROWS (4ll << 20)          // x 600-byte Hcat rows = 2.5 GB: every operand of a launch stays below CL_MAX_BYTES
 struct M3FwdBufs { ClBuf H, Y[3], Xo, X, src, feat, anc; };
 
-template <int OUT, int ACT, int RT>
+template <int OUT, int ACT, int RT, bool TILED>
 __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const f32x4 (&xb)[RT][M3_NTI],
                                             const bool (&valid)[RT], int64_t row0, int g, int c,
-                                            float *__restrict__ Hcat, const M3FwdBufs &B) {
+                                            float *__restrict__ Hcat, const M3FwdBufs &B, float *patch) {
     using L = M3FwdLds<OUT>;
     const float *W1s = lds, *W2s = W1s + M3_XP * L::S1, *b1s = W2s + M3_HP * L::S2, *b2s = b1s + M3_HP;
     f32x4 acc1[M3_NT1][RT];
@@ -148,7 +152,11 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             const int64_t row = row0 + rt * 16 + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc1[t][rt][r] = fmaxf(acc1[t][rt][r] + b1s[16 * t + 4 * g + r], 0.f);
-            frag_bstore4<M3_HID>(B.H, (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4, t, g, valid[rt], acc1[t][rt]);
+            if (TILED)
+                frag_tstore4<M3_HID>(B.H, (uint32_t)((row0 + rt * 16) >> 4) * (16 * M3_HLD * 4) + (uint32_t)head * (16 * M3_HID * 4), t, g, c,
+                                     valid[rt], acc1[t][rt]);
+            else
+                frag_bstore4<M3_HID>(B.H, (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4, t, g, valid[rt], acc1[t][rt]);
         }
     f32x4 acc2[L::NT2][RT];
 #pragma unroll
@@ -196,6 +204,17 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             }
         }
 #endif
+#if M3_FWD_LDS_STORE
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        f32x4 yv[L::NT2];
+#pragma unroll
+        for (int u = 0; u < L::NT2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[u][r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
+        frag_tile_store<OUT, L::NT2>(patch, B.Y[head], (uint32_t)(row0 + rt * 16) * (OUT * 4), yv, g, c, 16 * g + c);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < L::NT2; ++u)
 #pragma unroll
@@ -206,6 +225,7 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             for (int r = 0; r < 4; ++r) y[r] = frag_act<ACT>(acc2[u][rt][r] + b2s[16 * u + 4 * g + r]);
             frag_bstore4<OUT>(B.Y[head], (uint32_t)row * (OUT * 4), u, g, valid[rt], y);
         }
+#endif
 }
 
 // Input row assembled on the fly (ROWS variant): [ feat_src[src_row[r], 0:50] | (a - cam)/|a - cam| | |a - cam| ] with a =
@@ -235,13 +255,21 @@ __device__ __forceinline__ f32x4 m3_load_x_rows_b(const M3FwdBufs &B, float cam0
     return !valid ? z : (g == 0 ? v0 : (g == 1 ? v1 : z));
 }
 
-template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES, bool ROWS>
+// TILED (ROWS only): Hcat — a buffer only the fused backward reads, 600 of the 1256 bytes per anchor this kernel stores — leaves
+// in fragment-major form (buf_access.h frag_tstore4): every store instruction one contiguous KB instead of sixteen 64-byte chunks
+// 600 bytes apart (the kernel is bound by its stores, and the L2 has to merge those chunks into lines: with non-temporal stores,
+// i.e. without the merging, it takes 1.41 ms instead of 0.51).  456 -> 421 us at 1 M anchors; X_out the same way gave the forward
+// another 12 us and cost the one-wave backward 25 (profiles/r06_mlp3_tiled.txt): X_out stays row-major.
+template <int O0, int A0, int O1, int A1, int O2, int A2, int RT, int WAVES, bool ROWS, bool TILED = false>
 __global__ void __launch_bounds__(WAVES * 64)
     mlp3_fwd_kernel(const float *__restrict__ X, int64_t ldx, M3Head h0, M3Head h1, M3Head h2,
                     float *__restrict__ Hcat, int64_t n, M3Rows R) {
-    __shared__ float lds[M3FwdLds<O0>::FLOATS + M3FwdLds<O1>::FLOATS + M3FwdLds<O2>::FLOATS];
+    constexpr int WFL = M3FwdLds<O0>::FLOATS + M3FwdLds<O1>::FLOATS + M3FwdLds<O2>::FLOATS;
+    static_assert(WFL % 4 == 0 && O0 <= 70 && O1 <= 70 && O2 <= 70 && M3_IN <= 70, "patch: 16-byte aligned, the widest image fits");
+    __shared__ __attribute__((aligned(16))) float lds[WFL + (M3_FWD_LDS_STORE ? WAVES * M3_FWD_PATCH : 0)];
     float *l0 = lds, *l1 = l0 + M3FwdLds<O0>::FLOATS, *l2 = l1 + M3FwdLds<O1>::FLOATS;
     const int tid = threadIdx.x, nthr = WAVES * 64;
+    float *patch = lds + WFL + (M3_FWD_LDS_STORE ? (tid >> 6) * M3_FWD_PATCH : 0);
     m3_stage_fwd<O0>(l0, h0, tid, nthr);
     m3_stage_fwd<O1>(l1, h1, tid, nthr);
     m3_stage_fwd<O2>(l2, h2, tid, nthr);
@@ -255,7 +283,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     M3FwdBufs B;
     {
         const uint64_t nb = (uint64_t)n;
-        B.H = cl_buf(Hcat, nb * (M3_HLD * 4));
+        const uint64_t nbt = (nb + 15) / 16 * 16;
+        B.H = cl_buf(Hcat, (TILED ? nbt : nb) * (M3_HLD * 4));
         B.Y[0] = cl_buf(h0.Y, nb * (O0 * 4)); B.Y[1] = cl_buf(h1.Y, nb * (O1 * 4)); B.Y[2] = cl_buf(h2.Y, nb * (O2 * 4));
         B.Xo = cl_buf(ROWS ? R.X_out : nullptr, nb * (M3_XLD * 4));
         B.X = cl_buf(ROWS ? nullptr : X, nb > 0 ? ((nb - 1) * (uint64_t)ldx + M3_IN) * 4 : 0);
@@ -294,13 +323,17 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (ROWS) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
+#if M3_FWD_LDS_STORE
+                if (R.X_out) frag_tile_store<M3_IN, M3_NTI>(patch, B.Xo, (uint32_t)(row0 + rt * 16) * (M3_XLD * 4), xb[rt], g, c, lane);
+#else
 #pragma unroll
                 for (int q = 0; q < M3_NTI; ++q)
                     frag_bstore4<M3_IN>(B.Xo, (uint32_t)(row0 + rt * 16 + c) * (M3_XLD * 4), q, g, valid[rt], xb[rt][q]);
+#endif
         }
-        m3_head_fwd<O0, A0, RT>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B);
-        m3_head_fwd<O1, A1, RT>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B);
-        m3_head_fwd<O2, A2, RT>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B);
+        m3_head_fwd<O0, A0, RT, TILED>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B, patch);
+        m3_head_fwd<O1, A1, RT, TILED>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B, patch);
+        m3_head_fwd<O2, A2, RT, TILED>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B, patch);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             valid[rt] = validn[rt];
@@ -514,15 +547,18 @@ template <int OUT, int ACT>
 struct M3wOps {
     static constexpr int NT2 = (OUT + 15) / 16;
     f32x4 dy[NT2], y[ACT != FRAG_ACT_NONE ? NT2 : 1], h[M3_NT1];
+    template <bool TILED = false>
     __device__ __forceinline__ void load(const M3wBufs &B, int head, int64_t row, int g, bool valid) {
         const uint32_t ro = (uint32_t)row * (OUT * 4), rh = (uint32_t)row * (M3_HLD * 4) + (uint32_t)(M3_HPITCH * head) * 4;
+        const uint32_t th = (uint32_t)(row >> 4) * (16 * M3_HLD * 4) + (uint32_t)head * (16 * M3_HID * 4);
 #pragma unroll
         for (int u = 0; u < NT2; ++u) {
             dy[u] = frag_bload4<OUT>(B.dY[head], ro, u, g, valid);
             if (ACT != FRAG_ACT_NONE) y[u] = frag_bload4<OUT>(B.Y[head], ro, u, g, valid);
         }
 #pragma unroll
-        for (int t = 0; t < M3_NT1; ++t) h[t] = frag_bload4<M3_HID>(B.H, rh, t, g, valid);
+        for (int t = 0; t < M3_NT1; ++t)
+            h[t] = TILED ? frag_tload4<M3_HID>(B.H, th, t, g, (int)(row & 15), valid) : frag_bload4<M3_HID>(B.H, rh, t, g, valid);
     }
     __device__ __forceinline__ void mask(int g) {
 #pragma unroll
@@ -674,7 +710,7 @@ __device__ __forceinline__ void m3w_head(const float *lds, float *patches, M3wOp
     }
 }
 
-template <bool ROWS>
+template <bool ROWS, bool TL = false>         // TL: Hcat is the TILED forward's (fragment-major: one contiguous KB per load)
 __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     mlp3_bwd_wg_kernel(M3Head h0, M3Head h1, M3Head h2, const float *__restrict__ X, int64_t ldx,
                        const float *__restrict__ Hcat, float *__restrict__ dX, int64_t lddx, int64_t n, M3Rows R,
@@ -710,7 +746,8 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
     M3wBufs B;
     B.dY[0] = cl_buf(h0.dY, nb * 40); B.dY[1] = cl_buf(h1.dY, nb * 120); B.dY[2] = cl_buf(h2.dY, nb * 280);
     B.Y[0] = cl_buf(h0.Y, nb * 40); B.Y[1] = cl_buf(h1.Y, nb * 120); B.Y[2] = cl_buf(h2.Y, nb * 280);
-    B.H = cl_buf(Hcat, nb * (M3_HLD * 4));
+    static_assert(ROWS || !TL, "the tiled hand-over belongs to the ROWS pair");
+    B.H = cl_buf(Hcat, (TL ? (nb + 15) / 16 * 16 : nb) * (M3_HLD * 4));
     B.X = cl_buf(X, nb > 0 ? ((nb - 1) * (uint64_t)ldx + M3_IN) * 4 : 0);
     const ClBuf bSrc = cl_buf(ROWS ? R.src_row : nullptr, nb * 8), bAnc = cl_buf(ROWS ? R.anchor : nullptr, nb * 12);
     const float cam0 = ROWS ? R.cam[0] : 0.f, cam1 = ROWS ? R.cam[1] : 0.f, cam2 = ROWS ? R.cam[2] : 0.f;
@@ -736,7 +773,7 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
     {
         const int64_t row = tile * 16 + c;
         const bool v0 = tile < ntiles && row < n;
-        op0.load(B, 0, row, g, v0);
+        op0.template load<TL>(B, 0, row, g, v0);
         const int64_t s0 = regather ? cl_li64(bSrc, cl_sel(v0, (uint32_t)row * 8)) : 0;
         load_x(xf, row, s0, v0);
     }
@@ -765,10 +802,10 @@ __global__ void __launch_bounds__(M3W_WAVES * 64) __attribute__((amdgpu_waves_pe
         f32x4 adx[M3_NTI];
 #pragma unroll
         for (int v = 0; v < M3_NTI; ++v) adx[v] = zero;
-        m3w_head<10, 1>(l0, patches, op0, ones, g, c, xn, adx, a2_0, a1_0, [&]() { op1.load(B, 1, row0 + c, g, valid); });
-        m3w_head<30, 2>(l1, patches, op1, ones, g, c, xn, adx, a2_1, a1_1, [&]() { op2.load(B, 2, row0 + c, g, valid); });
+        m3w_head<10, 1>(l0, patches, op0, ones, g, c, xn, adx, a2_0, a1_0, [&]() { op1.template load<TL>(B, 1, row0 + c, g, valid); });
+        m3w_head<30, 2>(l1, patches, op1, ones, g, c, xn, adx, a2_1, a1_1, [&]() { op2.template load<TL>(B, 2, row0 + c, g, valid); });
         m3w_head<70, 0>(l2, patches, op2, ones, g, c, xn, adx, a2_2, a1_2, [&]() {
-            op0.load(B, 0, rown, g, validn);
+            op0.template load<TL>(B, 0, rown, g, validn);
 #if M3W_XPREFETCH
             load_x(xf, rown, srow_next, validn);
 #endif
@@ -899,10 +936,26 @@ extern "C" int cgs_anchor_mlp3_forward(const float *X, int64_t ldx, const float 
 // The same with the input row assembled on the fly: X[r] = [feat_src[src_row[r], 0:50] | view direction (3) | distance (1)]
 // of anchor_vis[r] as seen from cam3 (device float[3]); X_out [n,54] receives the assembled rows (the weight-gradient
 // pass of the backward reads them).
+extern "C" int cgs_anchor_mlp3_forward_rows_t(const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                              const float *cam3, float *X_out, const float *const *W1,
+                                              const float *const *b1, const float *const *W2, const float *const *b2,
+                                              float *Y_op, float *Y_color, float *Y_cov, float *Hcat, int64_t n, int tiled,
+                                              void *stream);
 extern "C" int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t *src_row, const float *anchor_vis,
                                             const float *cam3, float *X_out, const float *const *W1,
                                             const float *const *b1, const float *const *W2, const float *const *b2,
                                             float *Y_op, float *Y_color, float *Y_cov, float *Hcat, int64_t n, void *stream) {
+    return cgs_anchor_mlp3_forward_rows_t(feat_src, src_row, anchor_vis, cam3, X_out, W1, b1, W2, b2, Y_op, Y_color, Y_cov, Hcat, n, 0,
+                                          stream);
+}
+// tiled != 0: Hcat (ceil(n / 16) * 16 rows) leaves in fragment-major form (mlp3_fwd_kernel, TILED) — only
+// cgs_anchor_mlp3_backward_rows_t(tiled = 1) reads that form.  One launch (n <= M3_MAX_ROWS) in that case.
+extern "C" int cgs_anchor_mlp3_forward_rows_t(const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                              const float *cam3, float *X_out, const float *const *W1,
+                                              const float *const *b1, const float *const *W2, const float *const *b2,
+                                              float *Y_op, float *Y_color, float *Y_cov, float *Hcat, int64_t n, int tiled,
+                                              void *stream) {
+    if (tiled && n > M3_MAX_ROWS) { cgs_set_error("anchor_mlp3_forward_rows: tiled hand-over needs <= %lld rows", (long long)M3_MAX_ROWS); return CGS_ERR_ARG; }
     if (n < 0) { cgs_set_error("anchor_mlp3_forward_rows: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
     if (!feat_src || !src_row || !anchor_vis || !cam3 || !W1 || !b1 || !W2 || !b2 || !Y_op || !Y_color || !Y_cov) {
@@ -925,8 +978,12 @@ extern "C" int cgs_anchor_mlp3_forward_rows(const float *feat_src, const int64_t
         const int64_t want = (tiles + WAVES - 1) / WAVES;
         const int grid = (int)(want < m3_cus() ? want : m3_cus());
         M3Rows R{feat_src, src_row + r0, anchor_vis + 3 * r0, cam3, X_out ? X_out + r0 * M3_XLD : nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
-                           nullptr, 0, h[0], h[1], h[2], Hcat ? Hcat + r0 * M3_HLD : nullptr, m, R);
+        if (tiled)
+            hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                               nullptr, 0, h[0], h[1], h[2], Hcat, m, R);
+        else
+            hipLaunchKernelGGL((mlp3_fwd_kernel<10, 1, 30, 2, 70, 0, RT, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, (hipStream_t)stream,
+                               nullptr, 0, h[0], h[1], h[2], Hcat ? Hcat + r0 * M3_HLD : nullptr, m, R);
     }
     CGS_CHECK_HIP(hipGetLastError());
     return CGS_OK;
@@ -939,7 +996,7 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
                        const float *Y_color, const float *dY_op, const float *dY_color, const float *dY_cov,
                        const float *Hcat, float *dX, int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color,
                        float *dW1cat, float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
-                       size_t scratch_bytes, const M3Rows *rows, void *stream_);
+                       size_t scratch_bytes, const M3Rows *rows, void *stream_, int tiled = 0);
 extern "C" int cgs_anchor_mlp3_wgrad(const float *X, int64_t ldx, const float *Hcat, const float *dZ1cat,
                                      const float *dZ2_op, const float *dZ2_color, const float *dY_cov, float *dW1cat,
                                      float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
@@ -958,6 +1015,14 @@ extern "C" int cgs_anchor_mlp3_backward(const float *X, int64_t ldx, const float
 // Backward of cgs_anchor_mlp3_forward_rows: X is the [n,54] side output of the forward; instead of a dense dX the
 // feature columns are stored into rows src_row[r] of d_feat_src [*,50] (distinct rows; rows no visible anchor reads
 // are the caller's to zero) and the view columns are pulled back to d_anchor_vis [n,3].
+extern "C" int cgs_anchor_mlp3_backward_rows_t(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                               const float *cam3, const float *const *W1, const float *const *W2,
+                                               const float *Y_op, const float *Y_color, const float *dY_op,
+                                               const float *dY_color, const float *dY_cov, const float *Hcat,
+                                               float *d_feat_src, float *d_anchor_vis, float *dZ1cat, float *dZ2_op,
+                                               float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
+                                               float *const *db2, int64_t n, int tiled, void *scratch, size_t scratch_bytes,
+                                               void *stream_);
 extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
                                              const float *cam3, const float *const *W1, const float *const *W2,
                                              const float *Y_op, const float *Y_color, const float *dY_op,
@@ -966,6 +1031,20 @@ extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_s
                                              float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
                                              float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
                                              void *stream_) {
+    return cgs_anchor_mlp3_backward_rows_t(X, feat_src, src_row, anchor_vis, cam3, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat,
+                                           d_feat_src, d_anchor_vis, dZ1cat, dZ2_op, dZ2_color, dW1cat, db1cat, dW2, db2, n, 0, scratch,
+                                           scratch_bytes, stream_);
+}
+// tiled != 0: Hcat is the fragment-major buffer of cgs_anchor_mlp3_forward_rows_t(tiled = 1) (X stays row-major); the weight
+// gradients must be asked for in the same call (the fused form is the only reader of that layout).
+extern "C" int cgs_anchor_mlp3_backward_rows_t(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                               const float *cam3, const float *const *W1, const float *const *W2,
+                                               const float *Y_op, const float *Y_color, const float *dY_op,
+                                               const float *dY_color, const float *dY_cov, const float *Hcat,
+                                               float *d_feat_src, float *d_anchor_vis, float *dZ1cat, float *dZ2_op,
+                                               float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
+                                               float *const *db2, int64_t n, int tiled, void *scratch, size_t scratch_bytes,
+                                               void *stream_) {
     if (n == 0) return CGS_OK;           // no visible anchor: nothing to do (empty tensors arrive as NULL pointers)
     if (!src_row || !anchor_vis || !cam3 || !d_feat_src || !d_anchor_vis) { cgs_set_error("anchor_mlp3_backward_rows: NULL"); return CGS_ERR_ARG; }
     if (!X && (!feat_src || !dW1cat || n > M3_MAX_ROWS)) {
@@ -974,14 +1053,14 @@ extern "C" int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_s
     }
     M3Rows R{X ? nullptr : feat_src, src_row, anchor_vis, cam3, nullptr, d_feat_src, d_anchor_vis};
     return m3_backward(X, M3_XLD, W1, W2, Y_op, Y_color, dY_op, dY_color, dY_cov, Hcat, nullptr, 0, dZ1cat, dZ2_op, dZ2_color,
-                       dW1cat, db1cat, dW2, db2, n, scratch, scratch_bytes, &R, stream_);
+                       dW1cat, db1cat, dW2, db2, n, scratch, scratch_bytes, &R, stream_, tiled);
 }
 
 static int m3_backward(const float *X, int64_t ldx, const float *const *W1, const float *const *W2, const float *Y_op,
                        const float *Y_color, const float *dY_op, const float *dY_color, const float *dY_cov,
                        const float *Hcat, float *dX, int64_t lddx, float *dZ1cat, float *dZ2_op, float *dZ2_color,
                        float *dW1cat, float *db1cat, float *const *dW2, float *const *db2, int64_t n, void *scratch,
-                       size_t scratch_bytes, const M3Rows *rows, void *stream_) {
+                       size_t scratch_bytes, const M3Rows *rows, void *stream_, int tiled) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0) { cgs_set_error("anchor_mlp3_backward: n < 0"); return CGS_ERR_ARG; }
     if (n == 0) return CGS_OK;
@@ -1008,7 +1087,10 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
         if (scratch && scratch_bytes >= (size_t)gridw * M3W_E * sizeof(float)) {
             {
                 CgsProfScope prof(CGS_PROF_MLP_BWD, stream);
-                if (rows)
+                if (rows && tiled)
+                    hipLaunchKernelGGL((mlp3_bwd_wg_kernel<true, true>), dim3(gridw), dim3(M3W_WAVES * 64), 0, stream, h[0], h[1], h[2], X,
+                                       ldx, Hcat, nullptr, 0, n, *rows, (float *)scratch);
+                else if (rows)
                     hipLaunchKernelGGL((mlp3_bwd_wg_kernel<true>), dim3(gridw), dim3(M3W_WAVES * 64), 0, stream, h[0], h[1], h[2], X,
                                        ldx, Hcat, nullptr, 0, n, *rows, (float *)scratch);
                 else
@@ -1026,6 +1108,11 @@ static int m3_backward(const float *X, int64_t ldx, const float *const *W1, cons
     }
 #endif
     if (no_x) { cgs_set_error("anchor_mlp3_backward: X == NULL but the fused weight-gradient form could not run (scratch)"); return CGS_ERR_WORKSPACE; }
+    if (tiled) {
+        cgs_set_error("anchor_mlp3_backward: the tiled hand-over is read by the fused weight-gradient form only (needs the weight-gradient pointers, "
+                      "<= %lld rows and its scratch)", (long long)M3_MAX_ROWS);
+        return CGS_ERR_ARG;
+    }
     const int64_t tiles = (n + 16 * RT - 1) / (16 * RT);
     const int64_t want = (tiles + WAVES - 1) / WAVES;
     const int grid = (int)(want < m3_cus() ? want : m3_cus());

@@ -422,6 +422,10 @@ class _AnchorMLP3(torch.autograd.Function):
 # it is bound by the bytes it stores) and the fused backward assembles them again (903 -> 957 us: one wave per SIMD, every
 # instruction of the re-gather is added time) — a net loss of ~12 us per step, same box, two pairs: profiles/r06_mlp3_xout_ab.txt
 KEEP_X_OFF = os.environ.get("CGS_M3_KEEP_X", "1") == "0"
+# (round 6) the forward's private hand-over buffer Hcat in fragment-major form: every store of the forward and load of the fused
+# backward one contiguous KB (include/cgs.h, cgs_anchor_mlp3_forward_rows_t): forward 456 -> 421 us at 1 M anchors.  Off when the
+# weight gradients are deferred (the separate weight-gradient launch reads row-major buffers).  CGS_M3_TILED=0: row-major (A/B knob).
+M3_TILED = os.environ.get("CGS_M3_TILED", "1") != "0"
 _M3_REGATHER_MAX_ROWS = 4_000_000                                # the fused backward's row limit (32-bit buffer offsets)
 
 
@@ -449,17 +453,19 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         y_color = torch.empty(n, 30, dtype=torch.float32, device=dev)
         y_cov = torch.empty(n, 70, dtype=torch.float32, device=dev)
         hld, xld, _gld, _gp = _m3_layout()
-        hcat = torch.empty(n, hld, dtype=torch.float32, device=dev) if need_grad else None
+        tiled = bool(M3_TILED and need_grad and not _Deferred.on and 0 < n <= _M3_REGATHER_MAX_ROWS)
+        n_buf = (n + 15) // 16 * 16 if tiled else n           # (whole 16-row tiles)
+        hcat = torch.empty(n_buf, hld, dtype=torch.float32, device=dev) if need_grad else None
         # (round 6) the assembled input rows are kept only for the deferred weight-gradient launch of the multi-GPU step; the
         # fused backward of the single-GPU step assembles them again (216 of the 1256 bytes per anchor the forward is bound by)
         keep_x = need_grad and (_Deferred.on or n > _M3_REGATHER_MAX_ROWS or not KEEP_X_OFF)
         x = torch.empty(n, xld, dtype=torch.float32, device=dev) if keep_x else None
-        _lib.check(L.cgs_anchor_mlp3_forward_rows(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
-                                                  _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
-                                                  _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n,
-                                                  _lib.current_stream()), "cgs_anchor_mlp3_forward_rows")
+        _lib.check(L.cgs_anchor_mlp3_forward_rows_t(_lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam),
+                                                    _lib.ptr(x), _ptr_array(W1), _ptr_array(b1), _ptr_array(W2), _ptr_array(b2),
+                                                    _lib.ptr(y_op), _lib.ptr(y_color), _lib.ptr(y_cov), _lib.ptr(hcat), n, int(tiled),
+                                                    _lib.current_stream()), "cgs_anchor_mlp3_forward_rows")
         return dict(feat_src=feat_src, src_row=src_row, anchor_vis=anchor_vis, cam=cam, W1=W1, W2=W2, y=(y_op, y_color, y_cov), hcat=hcat,
-                    x=x, keep_x=keep_x, need_grad=need_grad, deferred=_Deferred.on,
+                    x=x, keep_x=keep_x, need_grad=need_grad, deferred=_Deferred.on, tiled=tiled,
                     key=(feat_src.data_ptr(), tuple(feat_src.shape), anchor_vis.data_ptr(), n))
 
     @staticmethod
@@ -483,6 +489,7 @@ class _AnchorMLP3Rows(torch.autograd.Function):
             ctx.save_for_backward(x if keep_x else feat_src, src_row, anchor_vis, cam, y_op, y_color, hcat, *W1, *W2)
             ctx.n_src = int(feat_src.shape[0])
             ctx.keep_x = keep_x
+            ctx.tiled = bool(pre.get("tiled", False))
         ctx.params = params
         return y_op, y_color, y_cov
 
@@ -514,13 +521,14 @@ class _AnchorMLP3Rows(torch.autograd.Function):
         views = _zeros_views(dev, (gld, 54), (gld,), *[tuple(w.shape) for w in W2], *[(w.shape[0],) for w in W2])
         dW1cat, db1cat, dW2, db2 = views[0], views[1], list(views[2:5]), list(views[5:8])
         ws = _wgrad_workspace(dev)
-        defer = _can_defer(ctx.params) and n > 0 and x is not None
-        _lib.check(L.cgs_anchor_mlp3_backward_rows(
+        # (the tiled hand-over is read by the fused data + weight-gradient kernel only: never deferred)
+        defer = _can_defer(ctx.params) and n > 0 and x is not None and not ctx.tiled
+        _lib.check(L.cgs_anchor_mlp3_backward_rows_t(
             _lib.ptr(x), _lib.ptr(feat_src), _lib.ptr(src_row), _lib.ptr(anchor_vis), _lib.ptr(cam), _ptr_array(W1), _ptr_array(W2), _lib.ptr(y_op),
             _lib.ptr(y_color), _lib.ptr(g_op), _lib.ptr(g_color), _lib.ptr(g_cov), _lib.ptr(hcat), _lib.ptr(d_src),
             _lib.ptr(d_anchor), _lib.ptr(dz1), _lib.ptr(dz2_op), _lib.ptr(dz2_color), None if defer else _lib.ptr(dW1cat),
             None if defer else _lib.ptr(db1cat), None if defer else _ptr_array(dW2), None if defer else _ptr_array(db2), n,
-            _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward_rows")
+            int(ctx.tiled), _lib.ptr(ws), ws.numel(), _lib.current_stream()), "cgs_anchor_mlp3_backward_rows")
         grads = [d_src if ctx.needs_input_grad[0] else None, None, d_anchor if ctx.needs_input_grad[2] else None, None, None]
         wgrads = []
         for i in range(3):

@@ -664,6 +664,25 @@ int cgs_anchor_mlp3_backward_rows(const float *X, const float *feat_src, const i
                                   float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
                                   float *const *db2, int64_t n, void *scratch, size_t scratch_bytes,
                                   void *stream);
+/* (round 6) The _rows pair with Hcat — a buffer nothing but the fused backward reads — in FRAGMENT-MAJOR form (tiled != 0): per
+ * 16-row tile the 1 KB register fragments of the kernels in lane order, the columns past the last full 16 behind them; every
+ * store / load instruction of a wave is then one contiguous KB instead of sixteen 64-byte chunks a row apart.  Hcat holds
+ * ceil(n / 16) * 16 rows; n <= 4 M rows; the backward must ask for the weight gradients in the same call (dW1cat != NULL).
+ * X_out / X stay row-major.  tiled == 0: exactly the two functions above.  Same arithmetic either way
+ * (gaussian_renderer/__init__.py:106-127 is the contract; the layout of Hcat is internal to the pair). */
+int cgs_anchor_mlp3_forward_rows_t(const float *feat_src, const int64_t *src_row,
+                                   const float *anchor_vis, const float *cam3, float *X_out,
+                                   const float *const *W1, const float *const *b1,
+                                   const float *const *W2, const float *const *b2, float *Y_op,
+                                   float *Y_color, float *Y_cov, float *Hcat, int64_t n, int tiled, void *stream);
+int cgs_anchor_mlp3_backward_rows_t(const float *X, const float *feat_src, const int64_t *src_row, const float *anchor_vis,
+                                    const float *cam3, const float *const *W1, const float *const *W2,
+                                    const float *Y_op, const float *Y_color, const float *dY_op,
+                                    const float *dY_color, const float *dY_cov, const float *Hcat,
+                                    float *d_feat_src, float *d_anchor_vis, float *dZ1cat, float *dZ2_op,
+                                    float *dZ2_color, float *dW1cat, float *db1cat, float *const *dW2,
+                                    float *const *db2, int64_t n, int tiled, void *scratch, size_t scratch_bytes,
+                                    void *stream);
 /* cgs_anchor_mlp3_backward / _backward_rows with dW1cat == db1cat == dW2 == db2 == NULL write the data gradients
  * only; this is the weight-gradient launch they leave out, on the buffers they wrote (X: the backward's X, ldx = 54 —
  * or the forward's X_out with ldx = cgs_anchor_mlp3_layout()[1] for the _rows pair; dY_cov: the covariance head's

@@ -155,6 +155,84 @@ def test_anchor_mlp3_rows_equals_the_materialised_input(keep_x, monkeypatch):
     assert float(got[0][unread].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 3777, 100003])
+@pytest.mark.parametrize("keep_x", [True, False])
+def test_anchor_mlp3_rows_tiled_handover_changes_no_bit(n, keep_x, monkeypatch):
+    """(round 6) Hcat in fragment-major form between the forward and the fused backward
+    (cgs_anchor_mlp3_{forward,backward}_rows_t, tiled = 1) against the row-major buffers (tiled = 0): only the layout of a
+    private buffer differs, so the three outputs and every gradient are the same bits — including row counts that end inside a
+    16-row tile and the X-less backward."""
+    import torch.nn as nn
+    from contextgs_amd import mlp
+    monkeypatch.setattr(mlp, "KEEP_X_OFF", not keep_x)
+    torch.manual_seed(5)
+    dev = "cuda"
+    mk = lambda out, act: nn.Sequential(nn.Linear(54, 50), nn.ReLU(True), nn.Linear(50, out), *([act()] if act else [])).to(dev)
+    mo, mc, mv = mk(10, nn.Tanh), mk(30, nn.Sigmoid), mk(70, None)
+    n_src = n + 1234
+    feat_src = torch.randn(n_src, 50, device=dev, requires_grad=True)
+    src_row = torch.randperm(n_src, device=dev)[:n].contiguous()
+    anchor = (torch.randn(n, 3, device=dev) * 2).requires_grad_(True)
+    cam = torch.tensor([0.3, -3.0, 0.5], device=dev)
+    ws = [torch.randn(n, k, device=dev) for k in (10, 30, 70)]
+    params = [p for m in (mo, mc, mv) for p in m.parameters()]
+
+    def run(tiled):
+        monkeypatch.setattr(mlp, "M3_TILED", tiled)
+        for t in [feat_src, anchor] + params:
+            t.grad = None
+        outs = mlp.anchor_mlp3_rows(feat_src, src_row, anchor, cam, mo, mc, mv)
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        return [o.detach().clone() for o in outs] + [feat_src.grad.clone(), anchor.grad.clone()] + [p.grad.clone() for p in params]
+
+    a, b = run(True), run(False)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), (i, float((x - y).abs().max()))
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 33, 1001])
+def test_anchor_mlp3_forward_writes_nothing_behind_its_rows(n):
+    """The forward stores 16-row tile images as 16-byte pieces and leaves the rows behind n to the buffer bounds check (per
+    dword): outputs placed inside larger sentinel-filled buffers — nothing behind row n - 1 changes, for row counts whose last
+    row ends inside a 16-byte piece (40-, 120-, 280-, 216-byte rows), on both forward entry points."""
+    import torch.nn as nn
+    from contextgs_amd import _lib, mlp
+    torch.manual_seed(11)
+    dev = "cuda"
+    L = _lib.lib()
+    mk = lambda out: nn.Sequential(nn.Linear(54, 50), nn.ReLU(True), nn.Linear(50, out)).to(dev)
+    ms = [mk(10), mk(30), mk(70)]
+    W1, b1 = [m[0].weight.detach().contiguous() for m in ms], [m[0].bias.detach().contiguous() for m in ms]
+    W2, b2 = [m[2].weight.detach().contiguous() for m in ms], [m[2].bias.detach().contiguous() for m in ms]
+    x = torch.randn(n, 54, device=dev)
+    pad = 64
+    mkbuf = lambda w: torch.full((n * w + pad,), -7.25, device=dev)
+    ref = None
+    for rows in (False, True):
+        ys, h, xo = [mkbuf(10), mkbuf(30), mkbuf(70)], mkbuf(150), mkbuf(54)
+        if rows:
+            feat = x[:, :50].contiguous()
+            src = torch.arange(n, device=dev)
+            cam = torch.tensor([0.3, -3.0, 0.5], device=dev)
+            anchor = torch.randn(n, 3, device=dev) * 2
+            _lib.check(L.cgs_anchor_mlp3_forward_rows_t(_lib.ptr(feat), _lib.ptr(src), _lib.ptr(anchor), _lib.ptr(cam), _lib.ptr(xo),
+                                                        mlp._ptr_array(W1), mlp._ptr_array(b1), mlp._ptr_array(W2), mlp._ptr_array(b2),
+                                                        _lib.ptr(ys[0]), _lib.ptr(ys[1]), _lib.ptr(ys[2]), _lib.ptr(h), n, 0,
+                                                        _lib.current_stream()), "fwd rows")
+            assert bool((xo[n * 54:] == -7.25).all()) and bool((xo[:n * 54] != -7.25).all())
+        else:
+            _lib.check(L.cgs_anchor_mlp3_forward(_lib.ptr(x), 54, mlp._ptr_array(W1), mlp._ptr_array(b1), mlp._ptr_array(W2),
+                                                 mlp._ptr_array(b2), _lib.ptr(ys[0]), _lib.ptr(ys[1]), _lib.ptr(ys[2]), _lib.ptr(h), n,
+                                                 _lib.current_stream()), "fwd")
+            ref = [torch.tanh(ms[0](x)).detach(), torch.sigmoid(ms[1](x)).detach(), ms[2](x).detach()]     # the heads' fixed activations
+            for y, r, w in zip(ys, ref, (10, 30, 70)):
+                assert torch.allclose(y[:n * w].view(n, w), r, rtol=1e-5, atol=1e-5)
+        torch.cuda.synchronize()
+        for y, w in zip(ys + [h], (10, 30, 70, 150)):
+            assert bool((y[n * w:] == -7.25).all()), (rows, w)
+            assert bool((y[:n * w] != -7.25).all()), (rows, w)
+
+
 def _mlp_zoo_grads(defer, twice=False):
     """Every MLP node of the path in one graph (plain, recomputing, level node, fused anchor MLPs both ways); returns the
     gradients of all parameters and inputs with the weight gradients launched inline or at the end of the backward."""
