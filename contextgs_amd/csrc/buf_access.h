@@ -148,3 +148,23 @@ __device__ __forceinline__ void frag_tile_store(float *patch, ClBuf b, uint32_t 
         cl_s128(b, cl_sel(in, tile_off + (uint32_t)off), t);
     }
 }
+
+// The two halves of frag_tile_store for tiles assembled from pieces of other shapes (ctx_level.hip): cl_patch_put4 writes the first
+// `cnt` values of a piece at a 4-byte aligned LDS address, cl_patch_flush stores TB bytes of the patch (16-byte aligned, TB a
+// multiple of 16) to byte offset `off` of b as contiguous 16-byte-per-lane stores.
+__device__ __forceinline__ void cl_patch_put4(float *p, f32x4 v, int cnt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < cnt) p[j] = v[j];
+}
+template <int TB>
+__device__ __forceinline__ void cl_patch_flush(const float *patch, ClBuf b, uint32_t off, int lane) {
+    static_assert(TB % 16 == 0, "whole 16-byte pieces");
+#pragma unroll
+    for (int k = 0; k < (TB + 1023) / 1024; ++k) {
+        const int o = k * 1024 + lane * 16;
+        const bool in = (k + 1) * 1024 <= TB || o < TB;
+        const f32x4 t = *(const f32x4 *)((const char *)patch + (in ? o : 0));
+        cl_s128(b, cl_sel(in, off + (uint32_t)o), t);
+    }
+}

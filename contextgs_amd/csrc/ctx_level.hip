@@ -201,6 +201,9 @@ __device__ __forceinline__ void cl_row_noise(ClRow &u, uint32_t kf, uint32_t ks,
 #ifndef CLF_OCC
 #define CLF_OCC 0                 // > 0: force this many waves per SIMD (register budget) — tuning knob of tools/variant_lib.sh
 #endif
+#ifndef CLF_LDS_STORE
+#define CLF_LDS_STORE 1           // the forward's outputs (X, yf / ys / yo, Q: tile images contiguous in memory) leave through a per-wave LDS patch
+#endif
 #ifndef CLF_GRID
 #define CLF_GRID 2                // workgroups per CU in the forward's persistent grid
 #endif
@@ -238,7 +241,11 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
     __shared__ float W2qs[3 * CL_HP];
     __shared__ float b2qs[4];
     __shared__ double part[CLF_WAVES][3];
+    constexpr int PATCH = CLF_LDS_STORE ? (16 * IN > CL_ROW_PATCH ? 16 * IN : CL_ROW_PATCH) : 4;       // floats per wave
+    static_assert(PATCH % 4 == 0, "16-byte aligned patches");
+    __shared__ __attribute__((aligned(16))) float patches[CLF_WAVES * PATCH];
     const int tid = threadIdx.x, nthr = CLF_WAVES * 64;
+    float *patch = patches + (tid >> 6) * PATCH;
     cl_stage_w1t<IN>(W1s, a.W1, tid, nthr);
     for (int i = tid; i < CL_HP; i += nthr) b1s[i] = i < CL_HID ? a.b1[i] : 0.f;
     for (int i = tid; i < 3 * CL_HP; i += nthr) W2qs[i] = (i % CL_HP) < CL_HID ? a.W2q[(i / CL_HP) * CL_HID + (i % CL_HP)] : 0.f;
@@ -293,13 +300,19 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
         cl_row_issue(x, XB, (uint32_t)ix.srow, g, rn < n);
         ix = idx_issue(rn + tstride * 16);
         CLB_FENCE();
+#if CLF_LDS_STORE
+        cl_xrow_store_tile<IN>(bX, patch, (uint32_t)(tile * 16), g, c, lane, xb);
+#else
         cl_xrow_store<IN>(bX, (uint32_t)row * (IN * 4), g, valid, xb);
+#endif
         f32x4 acc1[CL_NT1];
         cl_layer1<IN>(W1s, b1s, xb, g, c, acc1);
         float qa[3];
         cl_qadj(W2qs, b2qs, acc1, g, qa);
         const float qf = ctx_step(a.q0f, qa[0]), qs = ctx_step(a.q0s, qa[1]), qo = ctx_step(a.q0o, qa[2]);
+#if !CLF_LDS_STORE
         cl_s32(bQ, cl_sel(valid && g < 3, (uint32_t)row * 12 + (uint32_t)g * 4), g == 0 ? qf : (g == 1 ? qs : qo));
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) pf += cl_sum4(xc.F[i]);
         ps += cl_sum4(xc.S);
@@ -316,7 +329,11 @@ __global__ void __launch_bounds__(CLF_WAVES * 64) CLF_ATTR ctxl_fwd_kernel(ClFwd
             xc.O[0][j] = xc.O[0][j] + u.O[0][j] * qo;
             xc.O[1][j] = xc.O[1][j] + u.O[1][j] * qo;
         }
+#if CLF_LDS_STORE
+        cl_row_store_tile(xc, (f32x4){qf, qs, qo, 0.f}, YB, bQ, patch, (uint32_t)(tile * 16), g, c, lane);
+#else
         cl_row_store(xc, YB, (uint32_t)row, g, valid);
+#endif
     }
     if (a.sums) {        // one atomic per block and quantity, spread over CTX_SUM_SLOTS cache lines
         const double sa = ctx_wave_sum((double)pf), sb = ctx_wave_sum((double)ps), sc = ctx_wave_sum((double)po);

@@ -93,4 +93,39 @@ __device__ __forceinline__ void cl_row_store(const ClRow &v, const ClRowBufs &B,
     cl_s64(B.o, cl_sel(on && g == 3, oo + 28 * 4), v.O[1]);
 }
 
+// The same rows (and Q) of a whole 16-row tile through a per-wave LDS patch: the three tile images — 16 x 50, 16 x 6, 16 x 30
+// floats, each contiguous in its array — are assembled in the patch and leave as contiguous 16-byte-per-lane stores
+// (buf_access.h frag_tile_store; rows behind the end of an array are dropped by its bounds check).  c = the lane's row of the tile.
+#define CL_ROW_PATCH (16 * CL_D)          // floats: the feature image; scaling + offsets + Q (16 x (6 + 30 + 4)) reuse it afterwards
+__device__ __forceinline__ void cl_row_store_tile(const ClRow &v, f32x4 q3, const ClRowBufs &B, ClBuf bQ, float *patch, uint32_t row0,
+                                                  int g, int c, int lane) {
+    float *pf = patch;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cl_patch_put4(pf + c * CL_D + 16 * i + 4 * g, v.F[i], 4);
+    if (g == 0) cl_patch_put4(pf + c * CL_D + 48, v.F[3], 2);
+    cl_patch_flush<64 * CL_D>(pf, B.f, row0 * (CL_D * 4), lane);
+    float *ps = patch, *po = ps + 16 * CL_S, *pq = po + 16 * CL_O;          // (LDS operations of a wave execute in order)
+    if (g == 1) cl_patch_put4(ps + c * CL_S, v.S, 4);
+    if (g == 2) cl_patch_put4(ps + c * CL_S + 4, v.S, 2);
+    cl_patch_put4(po + c * CL_O + 4 * g, v.O[0], 4);
+    cl_patch_put4(po + c * CL_O + 16 + 4 * g, v.O[1], g == 3 ? 2 : 4);
+    if (g == 0) cl_patch_put4(pq + c * 3, q3, 3);
+    cl_patch_flush<64 * CL_S>(ps, B.s, row0 * (CL_S * 4), lane);
+    cl_patch_flush<64 * CL_O>(po, B.o, row0 * (CL_O * 4), lane);
+    cl_patch_flush<64 * 3>(pq, bQ, row0 * 12, lane);
+}
+// a 16-row tile of [n, IN] (X) the same way: 64 * IN contiguous bytes
+template <int IN>
+__device__ __forceinline__ void cl_xrow_store_tile(ClBuf b, float *patch, uint32_t row0, int g, int c, int lane,
+                                                   const f32x4 (&x)[ClShape<IN>::NTI]) {
+    constexpr int NTI = ClShape<IN>::NTI;
+#pragma unroll
+    for (int q = 0; q < NTI; ++q) {
+        const int col0 = 16 * q + 4 * g;
+        if (q < NTI - 1) cl_patch_put4(patch + c * IN + col0, x[q], 4);
+        else if (col0 < IN) cl_patch_put4(patch + c * IN + col0, x[q], IN - col0 < 4 ? IN - col0 : 4);
+    }
+    cl_patch_flush<64 * IN>(patch, b, row0 * (IN * 4), lane);
+}
+
 __device__ __forceinline__ float cl_sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
