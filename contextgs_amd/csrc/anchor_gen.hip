@@ -51,12 +51,22 @@ __host__ __device__ __forceinline__ int ag_vo_to_out(int vo) {
     return slot < AG_K ? slot * C + v % C : -1;
 }
 
+// TM: the last piece in the TAIL ORDER of mlp3.hip's forward (lane g, slot j holds input 48 + g + 4 j: the six inputs 48..53 in two
+// MFMA k-steps instead of four) — the forward kernels of this file keep the k order of mlp3_fwd_kernel, bit for bit
+template <bool TM = false>
 __device__ __forceinline__ f32x4 ag_load_x(const AgRows &R, int64_t row, int q, int g, bool valid) {
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!valid) return v;
     const float *fr = R.feat_src + (R.feat_row ? R.feat_row[row] : row) * AG_HID;
     const int col0 = 16 * q + 4 * g;
     if (col0 + 3 < AG_HID) return *(const f32x4_a4 *)(fr + col0);
+    if (TM) {
+        const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1], uz = R.anchor[3 * row + 2] - R.cam[2];
+        const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
+        v[0] = g == 0 ? fr[48] : (g == 1 ? fr[49] : (g == 2 ? ux / dist : uy / dist));
+        v[1] = g == 0 ? uz / dist : (g == 1 ? dist : 0.f);
+        return v;
+    }
     if (col0 >= AG_IN) return v;
     const float ux = R.anchor[3 * row] - R.cam[0], uy = R.anchor[3 * row + 1] - R.cam[1], uz = R.anchor[3 * row + 2] - R.cam[2];
     const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
@@ -106,7 +116,7 @@ __device__ __forceinline__ void ag_stage_fwd(float *lds, const float *W1, const 
 }
 
 // y[u][rt][j] = act(head(x))[virtual output 16u + 4g + j] of row c
-template <int C, int ACT, int RT>
+template <int C, int ACT, int RT, bool TM = false>
 __device__ __forceinline__ void ag_head_fwd(const float *lds, const f32x4 (&xb)[RT][AG_NTI], int g, int c,
                                             f32x4 (&y)[AgFwdLds<C>::NT2][RT]) {
     using L = AgFwdLds<C>;
@@ -121,9 +131,10 @@ __device__ __forceinline__ void ag_head_fwd(const float *lds, const f32x4 (&xb)[
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (16 * q + j >= AG_IN) continue;
+            if (TM && q == AG_NTI - 1 && 16 * q + 4 * j >= AG_IN) continue;          // tail order: inputs 48 + g + 4 j
 #pragma unroll
             for (int t = 0; t < AG_NT1; ++t) {
-                const float a = W1s[(16 * q + 4 * g + j) * L::S1 + 16 * t + c];
+                const float a = W1s[((TM && q == AG_NTI - 1) ? 16 * q + g + 4 * j : 16 * q + 4 * g + j) * L::S1 + 16 * t + c];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = frag_mfma(a, xb[rt][q][j], acc1[t][rt]);
             }
@@ -183,10 +194,10 @@ __global__ void __launch_bounds__(WAVES * 64)
             const int64_t row = row0 + rt * 16 + c;
             valid[rt] = row < n;
 #pragma unroll
-            for (int q = 0; q < AG_NTI; ++q) xb[rt][q] = ag_load_x(R, row, q, g, valid[rt]);
+            for (int q = 0; q < AG_NTI; ++q) xb[rt][q] = ag_load_x<true>(R, row, q, g, valid[rt]);
         }
         f32x4 y[1][RT];
-        ag_head_fwd<1, FRAG_ACT_TANH, RT>(lds, xb, g, c, y);
+        ag_head_fwd<1, FRAG_ACT_TANH, RT, true>(lds, xb, g, c, y);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;
@@ -285,7 +296,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         const int64_t row = tile0 * 16 * RT + rt * 16 + c;
         valid[rt] = tile0 < ntiles && row < n;
 #pragma unroll
-        for (int q = 0; q < AG_NTI; ++q) xb[rt][q] = ag_load_x(R, row, q, g, valid[rt]);
+        for (int q = 0; q < AG_NTI; ++q) xb[rt][q] = ag_load_x<true>(R, row, q, g, valid[rt]);
     }
     for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
         const int64_t row0 = tile * 16 * RT;
@@ -295,11 +306,11 @@ __global__ void __launch_bounds__(WAVES * 64)
             const int64_t row = (tile + tstride) * 16 * RT + rt * 16 + c;
             validn[rt] = row < n;
 #pragma unroll
-            for (int q = 0; q < AG_NTI; ++q) xn[rt][q] = ag_load_x(R, row, q, g, validn[rt]);
+            for (int q = 0; q < AG_NTI; ++q) xn[rt][q] = ag_load_x<true>(R, row, q, g, validn[rt]);
         }
         f32x4 yc[AgFwdLds<3>::NT2][RT], yv[AgFwdLds<7>::NT2][RT];
-        ag_head_fwd<3, FRAG_ACT_SIGMOID, RT>(lc, xb, g, c, yc);
-        ag_head_fwd<7, FRAG_ACT_NONE, RT>(lv, xb, g, c, yv);
+        ag_head_fwd<3, FRAG_ACT_SIGMOID, RT, true>(lc, xb, g, c, yc);
+        ag_head_fwd<7, FRAG_ACT_NONE, RT, true>(lv, xb, g, c, yv);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int64_t row = row0 + rt * 16 + c;

@@ -36,6 +36,9 @@
 #ifndef M3_FWD_LDS_STORE
 #define M3_FWD_LDS_STORE 1     // the forward's row-major outputs (Y_*, X_out) leave through a per-wave LDS patch as contiguous 1 KB stores
 #endif
+#ifndef M3_TAILMAP
+#define M3_TAILMAP 1           // ROWS forward: inputs 48..53 in tail order (two MFMA k-steps instead of four per hidden tile)
+#endif
 #define M3_FWD_PATCH (16 * 70)  // floats per wave: the widest tile image (Y_cov)
 #endif
 #ifndef M3_BWD_RT
@@ -91,7 +94,7 @@ __device__ __forceinline__ void m3_stage_fwd(float *lds, const M3Head &h, int ti
 #define M3_MAX_ROWS (4ll << 20)          // x 600-byte Hcat rows = 2.5 GB: every operand of a launch stays below CL_MAX_BYTES
 struct M3FwdBufs { ClBuf H, Y[3], Xo, X, src, feat, anc; };
 
-template <int OUT, int ACT, int RT, bool TILED>
+template <int OUT, int ACT, int RT, bool TILED, bool TM>
 __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, int head, const f32x4 (&xb)[RT][M3_NTI],
                                             const bool (&valid)[RT], int64_t row0, int g, int c,
                                             float *__restrict__ Hcat, const M3FwdBufs &B, float *patch) {
@@ -111,6 +114,8 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int t = 0; t < M3_NT1; ++t) a1[0][j][t] = W1s[(4 * g + j) * L::S1 + 16 * t + c];
+    // input row of W1 for (q, j): 16 q + 4 g + j — in the last piece of a TM operand 48 + g + 4 j (m3_load_x_rows_b)
+    auto krow = [&](int q, int j) { return (TM && q == M3_NTI - 1) ? 16 * q + g + 4 * j : 16 * q + 4 * g + j; };
 #pragma unroll
     for (int q = 0; q < M3_NTI; ++q) {
         if (q + 1 < M3_NTI) {
@@ -118,12 +123,13 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < M3_NT1; ++t)
-                    a1[(q + 1) & 1][j][t] = W1s[(16 * (q + 1) + 4 * g + j) * L::S1 + 16 * t + c];
+                    a1[(q + 1) & 1][j][t] = W1s[krow(q + 1, j) * L::S1 + 16 * t + c];
         }
         M3_FENCE();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (16 * q + j >= M3_IN) continue;
+            if (TM && q == M3_NTI - 1 && 16 * q + 4 * j >= M3_IN) continue;          // tail order: inputs 48 + g + 4 j
 #pragma unroll
             for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
@@ -137,9 +143,10 @@ __device__ __forceinline__ void m3_head_fwd(const float *lds, const M3Head &h, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (16 * q + j >= M3_IN) continue;
+            if (TM && q == M3_NTI - 1 && 16 * q + 4 * j >= M3_IN) continue;
 #pragma unroll
             for (int t = 0; t < M3_NT1; ++t) {
-                const float a = W1s[(16 * q + 4 * g + j) * L::S1 + 16 * t + c];
+                const float a = W1s[((TM && q == M3_NTI - 1) ? 16 * q + g + 4 * j : 16 * q + 4 * g + j) * L::S1 + 16 * t + c];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc1[t][rt] = frag_mfma(a, xb[rt][q][j], acc1[t][rt]);
             }
@@ -242,10 +249,23 @@ struct M3Rows {
 };
 
 // through buffer loads: `srow` = src_row[row] (fetched a tile earlier by the caller), no branch anywhere
+// TM (the forward's own operand): the last piece in TAIL ORDER — lane g, slot j holds input 48 + g + 4 j instead of 48 + 4 g + j, so
+// that the six inputs 48..53 fill the k-slots of TWO MFMA steps (j = 0: 48..51, j = 1: 52, 53) instead of being spread over four;
+// the matching rows of W1 are read in m3_head_fwd.  Free here: the tail is assembled in registers.
+template <bool TM = false>
 __device__ __forceinline__ f32x4 m3_load_x_rows_b(const M3FwdBufs &B, float cam0, float cam1, float cam2, int64_t row, int64_t srow,
                                                   int q, int g, bool valid) {
     const uint32_t fo = (uint32_t)srow * (M3_HID * 4);
     if (q < 3) return cl_l128(B.feat, cl_sel(valid, fo + (uint32_t)(16 * q + 4 * g) * 4));
+    if (TM) {
+        const f32x4 f2 = cl_l64(B.feat, cl_sel(valid && g < 2, fo + 48 * 4));                 // features 48, 49
+        const f32x4 a = cl_l96(B.anc, cl_sel(valid, (uint32_t)row * 12));
+        const float ux = a[0] - cam0, uy = a[1] - cam1, uz = a[2] - cam2;
+        const float dist = sqrtf(ux * ux + uy * uy + uz * uz);
+        const float s0 = g == 0 ? f2[0] : (g == 1 ? f2[1] : (g == 2 ? ux / dist : uy / dist));
+        const float s1 = g == 0 ? uz / dist : (g == 1 ? dist : 0.f);
+        return valid ? (f32x4){s0, s1, 0.f, 0.f} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const f32x4 f2 = cl_l64(B.feat, cl_sel(valid && g == 0, fo + 48 * 4));                    // features 48, 49
     const f32x4 a = cl_l96(B.anc, cl_sel(valid && g < 2, (uint32_t)row * 12));
     const float ux = a[0] - cam0, uy = a[1] - cam1, uz = a[2] - cam2;
@@ -304,7 +324,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         srow_n[rt] = ROWS ? cl_li64(B.src, cl_sel(rown < n, (uint32_t)rown * 8)) : 0;
 #pragma unroll
         for (int q = 0; q < M3_NTI; ++q)
-            xb[rt][q] = ROWS ? m3_load_x_rows_b(B, cam0, cam1, cam2, row, srow, q, g, valid[rt])
+            xb[rt][q] = ROWS ? m3_load_x_rows_b<M3_TAILMAP>(B, cam0, cam1, cam2, row, srow, q, g, valid[rt])
                              : frag_bmask4<M3_IN>(frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, valid[rt]), q, g);
     }
     for (int64_t tile = tile0; tile < ntiles; tile += tstride) {
@@ -317,23 +337,33 @@ __global__ void __launch_bounds__(WAVES * 64)
             srow_nn[rt] = ROWS ? cl_li64(B.src, cl_sel(rownn < n, (uint32_t)rownn * 8)) : 0;
 #pragma unroll
             for (int q = 0; q < M3_NTI; ++q)
-                xn[rt][q] = ROWS ? m3_load_x_rows_b(B, cam0, cam1, cam2, row, srow_n[rt], q, g, validn[rt])
+                xn[rt][q] = ROWS ? m3_load_x_rows_b<M3_TAILMAP>(B, cam0, cam1, cam2, row, srow_n[rt], q, g, validn[rt])
                                  : frag_bmask4<M3_IN>(frag_bload4<M3_IN>(B.X, (uint32_t)row * ldx4, q, g, validn[rt]), q, g);
         }
         if (ROWS) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #if M3_FWD_LDS_STORE
-                if (R.X_out) frag_tile_store<M3_IN, M3_NTI>(patch, B.Xo, (uint32_t)(row0 + rt * 16) * (M3_XLD * 4), xb[rt], g, c, lane);
+                if (R.X_out) {
+                    if (M3_TAILMAP) {       // (the last piece is in tail order: values 48 + g and 52 + g of the row)
+#pragma unroll
+                        for (int q = 0; q < M3_NTI - 1; ++q) cl_patch_put4(patch + c * M3_IN + 16 * q + 4 * g, xb[rt][q], 4);
+                        patch[c * M3_IN + 48 + g] = xb[rt][M3_NTI - 1][0];
+                        if (g < 2) patch[c * M3_IN + 52 + g] = xb[rt][M3_NTI - 1][1];
+                        cl_patch_flush<64 * M3_IN>(patch, B.Xo, (uint32_t)(row0 + rt * 16) * (M3_XLD * 4), lane);
+                    } else {
+                        frag_tile_store<M3_IN, M3_NTI>(patch, B.Xo, (uint32_t)(row0 + rt * 16) * (M3_XLD * 4), xb[rt], g, c, lane);
+                    }
+                }
 #else
 #pragma unroll
                 for (int q = 0; q < M3_NTI; ++q)
                     frag_bstore4<M3_IN>(B.Xo, (uint32_t)(row0 + rt * 16 + c) * (M3_XLD * 4), q, g, valid[rt], xb[rt][q]);
 #endif
         }
-        m3_head_fwd<O0, A0, RT, TILED>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B, patch);
-        m3_head_fwd<O1, A1, RT, TILED>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B, patch);
-        m3_head_fwd<O2, A2, RT, TILED>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B, patch);
+        m3_head_fwd<O0, A0, RT, TILED, ROWS && M3_TAILMAP>(l0, h0, 0, xb, valid, row0, g, c, Hcat, B, patch);
+        m3_head_fwd<O1, A1, RT, TILED, ROWS && M3_TAILMAP>(l1, h1, 1, xb, valid, row0, g, c, Hcat, B, patch);
+        m3_head_fwd<O2, A2, RT, TILED, ROWS && M3_TAILMAP>(l2, h2, 2, xb, valid, row0, g, c, Hcat, B, patch);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             valid[rt] = validn[rt];
