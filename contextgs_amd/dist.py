@@ -639,8 +639,9 @@ def diagnostics(payload_bytes: int, small_bytes: int = 350_000, reps: int = 5, d
         t = torch.tensor([sorted(times)[len(times) // 2]], dtype=torch.float64, device=dev if on_dev else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sec = float(t.item())
-        out["all_reduce"][tag] = {"bytes": n * 4, "median_ms": round(sec * 1e3, 4),
-                                  "algbw_GBps": round(n * 4 / sec / 1e9, 5),
-                                  "busbw_GBps": round(2.0 * (w - 1) / w * n * 4 / sec / 1e9, 5)}
+        sig = lambda x: float("%.4g" % x)          # (four significant digits: a 64-byte probe on a slow host is ~1e-6 GB/s, not 0)
+        out["all_reduce"][tag] = {"bytes": n * 4, "median_ms": sig(sec * 1e3),
+                                  "algbw_GBps": sig(n * 4 / sec / 1e9),
+                                  "busbw_GBps": sig(2.0 * (w - 1) / w * n * 4 / sec / 1e9)}
         del buf
     return out
