@@ -816,4 +816,6 @@ def conduct_decoding(pc, pre_path_name):                       # :1299-1539
     pc._mask = nn.Parameter(_mask)
     if hasattr(pc, "_level_cache"):
         pc._level_cache = None
+        pc._anchor_q_cache = None
+    pc._anchor_q_cache = None
     return f"\nDecTime {round(t2 - t1, 4)}"

@@ -279,6 +279,7 @@ def _assign(pc, params):
         if name in params:
             setattr(pc, attr, params[name])
     pc._level_cache = None
+    pc._anchor_q_cache = None
 
 
 @torch.no_grad()

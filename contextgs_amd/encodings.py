@@ -85,6 +85,19 @@ class Quantize_anchor(torch.autograd.Function):             # :219-231
         return grad_output, None, None
 
 
+class Quantize_anchor_attach(torch.autograd.Function):
+    """Quantize_anchor's node around values that an earlier call of the same step computed from the same parameter (model.get_anchor:
+    the anchor cull of a step quantises the anchors without a graph, render() quantises them again with one): no launch, the same
+    straight-through backward."""
+    @staticmethod
+    def forward(ctx, anchors, values):
+        return values.view_as(values)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None
+
+
 def get_binary_vxl_size(binary_vxl):                         # :15-32
     ttl_num = binary_vxl.numel()
     pos_num = torch.sum(binary_vxl)

@@ -14,12 +14,16 @@ Cited lines are scene/gaussian_model.py unless stated otherwise.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
-from .encodings import Quantize_anchor
+from .encodings import Quantize_anchor, Quantize_anchor_attach
 from .entropy_bottleneck import EntropyBottleneck
 from .entropy_models import Entropy_gaussian
+
+ANCHOR_Q_CACHE = os.environ.get("CGS_ANCHOR_Q_CACHE", "1") != "0"      # get_anchor: one quantisation per version of the anchors (A/B knob)
 
 
 def expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000, step_sub=0):
@@ -74,6 +78,7 @@ class GaussianModel(nn.Module):
         self.rotation_activation = torch.nn.functional.normalize      # :58
         # caches (SURVEY §8a "caching opportunity"): see context_model.divide_levels_cached
         self._level_cache = None
+        self._anchor_q_cache = None
 
     # ---- train / eval switches (:200-220) ------------------------------------
     def eval(self):
@@ -132,7 +137,20 @@ class GaussianModel(nn.Module):
     def get_anchor(self):
         if self.decoded_version:
             return self._anchor
-        anchor, _q = Quantize_anchor.apply(self._anchor, self.x_bound_min, self.x_bound_max)
+        # (round 6) one quantisation per VERSION of the parameter and the bounds: a training step asks twice (prefilter_voxel without
+        # a graph, render() with one — the reference's property re-derives it on every access, scene/gaussian_model.py:296-300); the
+        # second call wraps the first call's values in the straight-through node.  Keyed like the level plan and _rot0_cache: object
+        # identity + version counter (+ the storage, for a replaced .data); whoever rewrites the anchors clears _level_cache and this.
+        a, lo, hi = self._anchor, self.x_bound_min, self.x_bound_max
+        key = (a, a._version, a.data_ptr(), lo, lo._version, lo.data_ptr(), hi, hi._version, hi.data_ptr())
+        hit = getattr(self, "_anchor_q_cache", None)
+        if ANCHOR_Q_CACHE and hit is not None and len(hit[0]) == len(key) and all(
+                (x is y) if isinstance(x, torch.Tensor) else (x == y) for x, y in zip(hit[0], key)):
+            if torch.is_grad_enabled() and a.requires_grad:
+                return Quantize_anchor_attach.apply(a, hit[1])
+            return hit[1]
+        anchor, _q = Quantize_anchor.apply(a, lo, hi)
+        self._anchor_q_cache = (key, anchor.detach()) if (ANCHOR_Q_CACHE and a.is_cuda) else None
         return anchor
 
     @torch.no_grad()
@@ -142,6 +160,7 @@ class GaussianModel(nn.Module):
         self.x_bound_min = torch.where(lo < 0, lo * 1.2, lo * 0.8)
         self.x_bound_max = torch.where(hi > 0, hi * 1.2, hi * 0.8)
         self._level_cache = None
+        self._anchor_q_cache = None
 
     def get_mlp_size(self, digit: int = 32):                        # :193-198
         n = sum(p.numel() for name, p in self.named_parameters() if "mlp" in name and "deform" not in name)
@@ -166,6 +185,7 @@ class GaussianModel(nn.Module):
         self._rotation = P(rotation, False)
         self._opacity = P(torch.zeros(N, 1), False)
         self._level_cache = None
+        self._anchor_q_cache = None
         return self
 
     # ---- initialisation and ply I/O --------------------------
@@ -314,6 +334,7 @@ class GaussianModel(nn.Module):
         self.latent_codec.update(force=True)
         self.mlp_grid.load_state_dict(sd_grid)
         self._level_cache = None
+        self._anchor_q_cache = None
         return self
 
     # the codec / rate-report methods live in codec_driver.py and are bound here so the
