@@ -36,6 +36,9 @@
 #ifndef M3_FWD_LDS_STORE
 #define M3_FWD_LDS_STORE 1     // the forward's row-major outputs (Y_*, X_out) leave through a per-wave LDS patch as contiguous 1 KB stores
 #endif
+#ifndef M3W_ROUTER
+#define M3W_ROUTER 1          // fused backward: weight-gradient MFMAs of a group interleaved over its accumulators
+#endif
 #ifndef M3_TAILMAP
 #define M3_TAILMAP 1           // ROWS forward: inputs 48..53 in tail order (two MFMA k-steps instead of four per hidden tile)
 #endif
@@ -700,10 +703,17 @@ __device__ __forceinline__ void m3w_head(const float *lds, float *patches, M3wOp
         f32x4 zn = zc;
         if (u + 1 < L::NT2) zn = m3w_get(patches + (4 + u + 1) * M3W_PATCH, g, c);
         M3_FENCE();
+#if M3W_ROUTER      // r outermost: consecutive MFMAs go to DIFFERENT accumulators (same additions per accumulator, same order)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < M3_NT1; ++t) aw2[u][t] = frag_mfma(zc[r], hn[t][r], aw2[u][t]);
+#else
 #pragma unroll
         for (int t = 0; t < M3_NT1; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) aw2[u][t] = frag_mfma(zc[r], hn[t][r], aw2[u][t]);
+#endif
         M3_FENCE();
         zc = zn;
     }
@@ -731,10 +741,17 @@ __device__ __forceinline__ void m3w_head(const float *lds, float *patches, M3wOp
         f32x4 dn = dc;
         if (t + 1 < M3_NT1) dn = m3w_get(patches + (9 + t + 1) * M3W_PATCH, g, c);
         M3_FENCE();
+#if M3W_ROUTER
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < M3_NTI; ++v) aw1[t][v] = frag_mfma(dc[r], xn[v][r], aw1[t][v]);
+#else
 #pragma unroll
         for (int v = 0; v < M3_NTI; ++v)
 #pragma unroll
             for (int r = 0; r < 4; ++r) aw1[t][v] = frag_mfma(dc[r], xn[v][r], aw1[t][v]);
+#endif
         M3_FENCE();
         dc = dn;
     }
